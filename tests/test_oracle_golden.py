@@ -1,0 +1,161 @@
+"""Pins the oracle (oracle/mmbidaf_oracle.py) against fixtures produced by running the real
+reference (tools/gen_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_flat, maxdiff
+from oracle import mmbidaf_oracle as O
+
+TOL = 2e-6
+
+
+def test_g1_masked_softmax():
+    g = load_flat("g1_masked_softmax.npz")
+    assert maxdiff(O.masked_softmax(g["x"], g["mask_dim2"], dim=2), g["y_dim2"]) < TOL
+    assert maxdiff(O.masked_softmax(g["x"], g["mask_dim1"], dim=1), g["y_dim1"]) < TOL
+    y = O.masked_softmax(g["x"], g["mask_dim2"], dim=2, log_softmax=True)
+    fin = g["y_dim2_log"] > -1e29
+    assert maxdiff(y[fin], g["y_dim2_log"][fin]) < 1e-5
+    assert maxdiff(O.masked_softmax(g["x2"], g["mask_last"]), g["y_last"]) < TOL
+    # Q1: fully masked row -> uniform
+    assert torch.allclose(g["y_last"][3], torch.full((9,), 1.0 / 9))
+    assert torch.allclose(O.masked_softmax(g["x2"], g["mask_last"])[3], torch.full((9,), 1.0 / 9))
+
+
+ATT_CASES = ["small_full", "ragged", "nonprefix", "m1", "t1", "cfg1_audio", "cfg1_image"]
+
+
+@pytest.mark.parametrize("case", ATT_CASES)
+def test_g3_attention_forward_and_autograd(golden_attention, case):
+    c = golden_attention[case]
+    text = c["text"].clone().requires_grad_(True)
+    mod = c["mod"].clone().requires_grad_(True)
+    ps = [c[k].clone().requires_grad_(True) for k in ("w_t", "w_m", "w_tm", "bias")]
+    sim = O.similarity_matrix(text, mod, *ps)
+    assert maxdiff(sim, c["sim"]) < 1e-5
+    out = O.bidaf_attention(text, mod, c["text_mask"], c["mod_mask"], *ps)
+    assert maxdiff(out, c["out"]) < 1e-5
+    (out * c["cot"]).sum().backward()
+    for name, t in zip(("d_text", "d_mod", "d_w_t", "d_w_m", "d_w_tm", "d_bias"), [text, mod] + ps):
+        ref = c[name]
+        assert maxdiff(t.grad, ref) < 2e-5 * max(1.0, ref.abs().max().item()), name
+
+
+@pytest.mark.parametrize("case", ATT_CASES)
+def test_g3_attention_manual_backward(golden_attention, case):
+    """The re-associated forward and the analytic backward the HIP kernels implement."""
+    c = golden_attention[case]
+    out, g = O.bidaf_attention_manual(c["text"], c["mod"], c["text_mask"], c["mod_mask"],
+                                      c["w_t"], c["w_m"], c["w_tm"], c["bias"], c["cot"])
+    assert maxdiff(out, c["out"]) < 1e-5
+    for name in ("d_text", "d_mod", "d_w_t", "d_w_m", "d_w_tm"):
+        ref = c[name]
+        assert maxdiff(g[name], ref) < 5e-5 * max(1.0, ref.abs().max().item()), name
+    # Q5: d_bias is analytically 0; the reference's autograd value is round-off
+    assert abs(c["d_bias"].item()) < 1e-3 and abs(g["d_bias"].item()) < 1e-3
+
+
+def test_attention_manual_with_dropout_copies():
+    torch.manual_seed(0)
+    B, T, M, D = 2, 6, 5, 8
+    text = torch.randn(B, T, D, requires_grad=True)
+    mod = torch.randn(B, M, D, requires_grad=True)
+    kt = (torch.rand(B, T, D) > 0.3).float() / 0.7
+    km = (torch.rand(B, M, D) > 0.3).float() / 0.7
+    ps = [torch.randn(D, 1, requires_grad=True), torch.randn(D, 1, requires_grad=True),
+          torch.randn(1, 1, D, requires_grad=True), torch.randn(1, requires_grad=True)]
+    tm, mm = O.get_mask(T, [6, 3]), O.get_mask(M, [2, 5])
+    cot = torch.randn(B, T, 4 * D)
+    out = O.bidaf_attention(text, mod, tm, mm, *ps, text_d=text * kt, mod_d=mod * km)
+    (out * cot).sum().backward()
+    o2, g = O.bidaf_attention_manual(text.detach(), mod.detach(), tm, mm, *[p.detach() for p in ps], cot,
+                                     text_d=(text * kt).detach(), mod_d=(mod * km).detach())
+    assert maxdiff(out, o2) < 1e-5
+    assert maxdiff(text.grad, g["d_text"] + g["d_text_d"] * kt) < 1e-4
+    assert maxdiff(mod.grad, g["d_mod"] + g["d_mod_d"] * km) < 1e-4
+    assert maxdiff(ps[0].grad, g["d_w_t"]) < 1e-4
+    assert maxdiff(ps[2].grad, g["d_w_tm"]) < 1e-4
+
+
+RNN_CASES = {"l1_ragged": 1, "l1_ties": 1, "l2_i8h": 2, "l1_full": 1, "l1_h100": 1, "l2_h25": 2}
+
+
+def _params(c, grad=False):
+    pre = "grad__rnn." if grad else "param__rnn."
+    return {k[len(pre):]: v for k, v in c.items() if k.startswith(pre)}
+
+
+@pytest.mark.parametrize("case", list(RNN_CASES))
+def test_g4_rnn_encoder(golden_rnn, case):
+    c = golden_rnn[case]
+    L = RNN_CASES[case]
+    x = c["x"].clone().requires_grad_(True)
+    P = {k: v.clone().requires_grad_(True) for k, v in _params(c).items()}
+    lengths = c["lengths"].tolist()
+    y, hn = O.rnn_encoder(x, lengths, P, L)
+    assert maxdiff(y, c["y"]) < 1e-5
+    assert maxdiff(hn, c["h_n"]) < 1e-5          # Q3: sorted order
+    ((y * c["cot_y"]).sum() + (hn * c["cot_h"]).sum()).backward()
+    assert maxdiff(x.grad, c["d_x"]) < 2e-5
+    G = _params(c, grad=True)
+    for k in P:
+        assert maxdiff(P[k].grad, G[k]) < 2e-5 * max(1.0, G[k].abs().max().item()), k
+
+
+@pytest.mark.parametrize("case", list(RNN_CASES))
+def test_g4_rnn_encoder_aten(golden_rnn, case):
+    c = golden_rnn[case]
+    L = RNN_CASES[case]
+    P = _params(c)
+    H = P["weight_hh_l0"].shape[1]
+    rnn = torch.nn.LSTM(c["x"].shape[2], H, L, batch_first=True, bidirectional=True)
+    rnn.load_state_dict(P)
+    y, hn = O.rnn_encoder_aten(c["x"], c["lengths"].tolist(), rnn)
+    assert maxdiff(y, c["y"]) < 1e-6
+    assert maxdiff(hn, c["h_n"]) < 1e-6
+
+
+def test_q3_tie_order(golden_rnn):
+    """encoding.py:91: torch.sort(descending) on float lengths; [5,7,5,7,5] -> idx [1,3,0,2,4]."""
+    _, idx = O.sort_lengths([5, 7, 5, 7, 5])
+    assert idx.tolist() == [1, 3, 0, 2, 4]
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+def test_lstm_manual_bptt(reverse):
+    torch.manual_seed(3)
+    B, T, I, H = 4, 7, 5, 6
+    x = torch.randn(B, T, I, requires_grad=True)
+    ps = [torch.randn(4 * H, I) * 0.4, torch.randn(4 * H, H) * 0.4, torch.randn(4 * H) * 0.1, torch.randn(4 * H) * 0.1]
+    ps = [p.requires_grad_(True) for p in ps]
+    lengths = [7, 3, 1, 5]
+    d_y, d_h = torch.randn(B, T, H), torch.randn(B, H)
+    y, h, _ = O.lstm_layer_dir(x, lengths, *ps, reverse)
+    ((y * d_y).sum() + (h * d_h).sum()).backward()
+    y2, h2, g = O.lstm_layer_dir_manual(x.detach(), lengths, *[p.detach() for p in ps], reverse, d_y, d_h)
+    assert maxdiff(y, y2) < 1e-6 and maxdiff(h, h2) < 1e-6
+    assert maxdiff(x.grad, g["d_x"]) < 1e-5
+    assert maxdiff(ps[0].grad, g["d_w_ih"]) < 1e-5
+    assert maxdiff(ps[1].grad, g["d_w_hh"]) < 1e-5
+    assert maxdiff(ps[2].grad, g["d_b"]) < 1e-5 and maxdiff(ps[3].grad, g["d_b"]) < 1e-5
+
+
+def test_g5_hot_region(golden_hot):
+    g = golden_hot
+    P = {}
+    for k, v in g.items():
+        if k.startswith("param__"):
+            mod, rest = k[len("param__"):].split(".", 1)
+            P.setdefault(mod, {})[rest[4:] if rest.startswith("rnn.") else rest] = v
+    r = O.hot_region(g["cap__text_enc__x"], g["cap__audio_enc__x"], g["cap__image_enc__x"],
+                     g["text_len"].tolist(), g["audio_len"].tolist(), g["image_len"].tolist(), P)
+    assert maxdiff(r["text_enc"], g["cap__text_enc__y"]) < 1e-5
+    assert maxdiff(r["audio_enc"], g["cap__audio_enc__y"]) < 1e-5
+    assert maxdiff(r["image_enc"], g["cap__image_enc__y"]) < 1e-5
+    assert maxdiff(r["att_audio"], g["cap__bidaf_att_audio"]) < 1e-5
+    assert maxdiff(r["att_image"], g["cap__bidaf_att_image"]) < 1e-5
+    assert maxdiff(r["mod_t_a"], g["cap__mod_t_a__y"]) < 1e-5
+    assert maxdiff(r["mod_t_a_h"], g["cap__mod_t_a__h"]) < 1e-5
+    assert maxdiff(r["mod_t_i"], g["cap__mod_t_i__y"]) < 1e-5
+    assert maxdiff(r["mod_t_i_h"], g["cap__mod_t_i__h"]) < 1e-5

@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Generate the golden parity fixtures under tests/golden/ by RUNNING the reference.
+
+Runs only in the build container (where /root/reference exists). The reference is imported
+from where it lies (sys.path), with PYTHONDONTWRITEBYTECODE semantics, and nothing of it is
+copied: only numeric inputs/outputs are stored (fixtures G1-G6).
+
+The reference imports `torchvision` at module top (layers/attention.py:3, layers/encoding.py:3)
+but uses it only in ImageEmbedding.__init__ (layers/encoding.py:124); torchvision is absent
+from this image, so an in-memory stand-in module is registered before the import.  For the
+whole-model fixture G5 the stand-in's `models.resnet101` returns a tiny frozen linear
+"image embedder" (N,3,h,w)->(N,20) whose weight is stored in the fixture.
+
+    python tools/gen_goldens.py            # writes tests/golden/*.npz + state_dict_keys.json
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = os.environ.get("MMB_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+class _StubResNet(nn.Module):
+    """Stand-in for torchvision.models.resnet101: mean-pool + linear to 20 features."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(77)
+        self.fc = nn.Linear(3, 20)
+        with torch.no_grad():
+            self.fc.weight.copy_(torch.randn(20, 3, generator=g) * 0.5)
+            self.fc.bias.copy_(torch.randn(20, generator=g) * 0.1)
+
+    def forward(self, images):
+        return self.fc(images.mean(dim=(2, 3)))
+
+
+def _install_torchvision_stub():
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvm.resnet101 = lambda pretrained=True: _StubResNet()
+    tv.models = tvm
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tvm
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def _save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def gen_masked_softmax(ref_att):
+    """G1: masked_softmax, reference layers/attention.py:78-98."""
+    g = torch.Generator().manual_seed(1)
+    out = {}
+    x = torch.randn(2, 6, 5, generator=g)
+    # prefix mask on dim 2
+    m2 = (torch.arange(5)[None, None, :] < torch.tensor([3, 5])[:, None, None])
+    # non-prefix mask on dim 1, with one fully masked batch entry
+    m1 = torch.tensor([[1, 0, 1, 1, 0, 1], [0, 0, 0, 0, 0, 0]], dtype=torch.bool)[:, :, None]
+    out["x"] = _np(x)
+    out["mask_dim2"] = _np(m2)
+    out["mask_dim1"] = _np(m1)
+    out["y_dim2"] = _np(ref_att.masked_softmax(x, m2, dim=2))
+    out["y_dim1"] = _np(ref_att.masked_softmax(x, m1, dim=1))
+    out["y_dim2_log"] = _np(ref_att.masked_softmax(x, m2, dim=2, log_softmax=True))
+    x2 = torch.randn(4, 9, generator=g)
+    mm = torch.tensor([[1] * 9, [1, 1, 1, 0, 0, 0, 0, 0, 0], [0, 1, 0, 1, 0, 1, 0, 1, 0], [0] * 9])
+    out["x2"] = _np(x2)
+    out["mask_last"] = _np(mm)
+    out["y_last"] = _np(ref_att.masked_softmax(x2, mm))
+    out["y_last_log"] = _np(ref_att.masked_softmax(x2, mm, log_softmax=True))
+    _save("g1_masked_softmax", **out)
+
+
+def _attn_case(ref_att, seed, B, T, M, D, text_mask, mod_mask):
+    torch.manual_seed(seed)
+    att = ref_att.BiDAFAttention(D, drop_prob=0.0)
+    with torch.no_grad():
+        att.bias.fill_(0.3)  # non-zero so the bias path is exercised
+    att.eval()
+    g = torch.Generator().manual_seed(seed + 1000)
+    text = torch.randn(B, T, D, generator=g, requires_grad=True)
+    mod = torch.randn(B, M, D, generator=g, requires_grad=True)
+    cot = torch.randn(B, T, 4 * D, generator=g)
+    s = att.get_similarity_matrix(text, mod)
+    out = att(text, mod, text_mask, mod_mask)
+    (out * cot).sum().backward()
+    return dict(
+        text=_np(text), mod=_np(mod), text_mask=_np(text_mask), mod_mask=_np(mod_mask), cot=_np(cot),
+        w_t=_np(att.text_weight), w_m=_np(att.modality_weight), w_tm=_np(att.text_modality_weight),
+        bias=_np(att.bias), sim=_np(s), out=_np(out), d_text=_np(text.grad), d_mod=_np(mod.grad),
+        d_w_t=_np(att.text_weight.grad), d_w_m=_np(att.modality_weight.grad),
+        d_w_tm=_np(att.text_modality_weight.grad), d_bias=_np(att.bias.grad))
+
+
+def _prefix(lens, n):
+    return torch.arange(n)[None, :] < torch.tensor(lens)[:, None]
+
+
+def gen_attention(ref_att):
+    """G2+G3: BiDAFAttention.get_similarity_matrix / forward / autograd (attention.py:37-75)."""
+    cases = {}
+    # G2-sized + full masks
+    cases["small_full"] = _attn_case(ref_att, 2, 2, 7, 5, 8, _prefix([7, 7], 7), _prefix([5, 5], 5))
+    cases["ragged"] = _attn_case(ref_att, 3, 3, 9, 6, 8, _prefix([9, 4, 1], 9), _prefix([6, 2, 3], 6))
+    tm = torch.tensor([[1, 0, 1, 1, 0, 1, 1, 0], [0, 0, 0, 0, 0, 0, 0, 0]], dtype=torch.bool)
+    mm = torch.tensor([[0, 1, 1, 0, 1], [0, 0, 0, 0, 0]], dtype=torch.bool)
+    cases["nonprefix"] = _attn_case(ref_att, 4, 2, 8, 5, 12, tm, mm)
+    cases["m1"] = _attn_case(ref_att, 5, 2, 6, 1, 8, _prefix([6, 3], 6), _prefix([1, 1], 1))
+    cases["t1"] = _attn_case(ref_att, 6, 2, 1, 4, 8, _prefix([1, 1], 1), _prefix([4, 2], 4))
+    # cfg-1 shapes, D = 2H = 200
+    cases["cfg1_audio"] = _attn_case(ref_att, 7, 2, 50, 32, 200, _prefix([50, 17], 50), _prefix([32, 9], 32))
+    cases["cfg1_image"] = _attn_case(ref_att, 8, 2, 50, 8, 200, _prefix([31, 50], 50), _prefix([8, 2], 8))
+    flat = {}
+    for cname, c in cases.items():
+        for k, v in c.items():
+            flat[cname + "__" + k] = v
+    _save("g3_bidaf_attention", **flat)
+
+
+def _rnn_case(ref_enc, seed, B, T, I, H, L, lengths):
+    torch.manual_seed(seed)
+    enc = ref_enc.RNNEncoder(I, H, L, drop_prob=0.0)
+    enc.eval()
+    g = torch.Generator().manual_seed(seed + 2000)
+    x = torch.randn(B, T, I, generator=g, requires_grad=True)
+    cot_y = torch.randn(B, T, 2 * H, generator=g)
+    cot_h = torch.randn(B, 2 * L, H, generator=g)
+    y, hn = enc(x, lengths)
+    ((y * cot_y).sum() + (hn * cot_h).sum()).backward()
+    out = dict(x=_np(x), lengths=np.asarray(lengths, dtype=np.int64), cot_y=_np(cot_y), cot_h=_np(cot_h),
+               y=_np(y), h_n=_np(hn), d_x=_np(x.grad))
+    for n, p in enc.named_parameters():
+        out["param__" + n] = _np(p)
+        out["grad__" + n] = _np(p.grad)
+    return out
+
+
+def gen_rnn(ref_enc):
+    """G4: RNNEncoder forward / autograd (layers/encoding.py:62-108), incl. Q3 tie order."""
+    cases = {}
+    cases["l1_ragged"] = _rnn_case(ref_enc, 11, 5, 9, 6, 6, 1, [9, 1, 5, 7, 3])
+    cases["l1_ties"] = _rnn_case(ref_enc, 12, 5, 8, 6, 6, 1, [5, 7, 5, 7, 5])
+    cases["l2_i8h"] = _rnn_case(ref_enc, 13, 4, 7, 40, 5, 2, [7, 2, 7, 4])
+    cases["l1_full"] = _rnn_case(ref_enc, 14, 3, 6, 4, 4, 1, [6, 6, 6])
+    cases["l1_h100"] = _rnn_case(ref_enc, 15, 3, 12, 20, 100, 1, [12, 5, 9])
+    cases["l2_h25"] = _rnn_case(ref_enc, 16, 3, 10, 200, 25, 2, [7, 10, 10])
+    flat = {}
+    for cname, c in cases.items():
+        for k, v in c.items():
+            flat[cname + "__" + k] = v
+    _save("g4_rnn_encoder", **flat)
+
+
+def gen_hot_region(ref_models):
+    """G5: hook captures inside a real MMBiDAF (models.py:94-206) at cfg-1 lengths, drop_prob = 0.
+
+    Hidden/embedding sizes are reduced (H=16) so the fixture stays small: the oracle is
+    size-generic and the H=100 sizes are compared oracle<->HIP on the GPU."""
+    B, T, Ma, Mi, H = 3, 50, 32, 8, 16
+    Et, Ea, Ei = 24, 12, 20
+    torch.manual_seed(224)
+    model = ref_models.MMBiDAF(H, Et, Ea, Ei, torch.device("cpu"), drop_prob=0.0, max_transcript_length=60)
+    g = torch.Generator().manual_seed(99)
+    text = torch.randn(B, T, Et, generator=g)
+    audio = torch.randn(B, Ma, Ea, generator=g)
+    images = torch.randn(B, Mi, 3, 4, 4, generator=g)
+    tl, al, il = [50, 31, 17], [32, 20, 9], [8, 5, 2]
+    steps = 4
+    targets = torch.randint(0, 17, (B, steps, 1), generator=g).float()
+    caps = {}
+
+    def hook(name):
+        def fn(mod, inp, out):
+            if isinstance(out, tuple):
+                caps[name + "__y"] = _np(out[0])
+                caps[name + "__h"] = _np(out[1])
+            else:
+                caps[name] = _np(out)
+            if name in ("text_enc", "audio_enc", "image_enc"):
+                caps[name + "__x"] = _np(inp[0])
+        return fn
+
+    hs = [getattr(model, n).register_forward_hook(hook(n)) for n in
+          ("text_enc", "audio_enc", "image_enc", "bidaf_att_audio", "bidaf_att_image", "mod_t_a", "mod_t_i")]
+    out = dict(text=_np(text), audio=_np(audio), images=_np(images), text_len=np.asarray(tl), audio_len=np.asarray(al),
+               image_len=np.asarray(il), targets=_np(targets), resnet_w=_np(model.image_keyframes_emb.resnet.fc.weight),
+               resnet_b=_np(model.image_keyframes_emb.resnet.fc.bias))
+    model.train()
+    dist, loss = model(text, tl, audio, al, images, il, targets, [steps] * B, steps)
+    out["train_dist"] = _np(dist)
+    out["train_loss"] = _np(loss)
+    for k, v in caps.items():
+        out["cap__" + k] = v
+    model.zero_grad()
+    loss.backward()
+    for n, p in model.named_parameters():
+        if p.grad is not None and not n.startswith("image_keyframes_emb"):
+            out["grad__" + n] = _np(p.grad)
+    model.eval()
+    with torch.no_grad():
+        dist_e, loss_e = model(text, tl, audio, al, images, il, targets, [steps] * B, steps)
+    out["eval_dist"] = _np(dist_e)
+    out["eval_loss"] = _np(loss_e)
+    for h in hs:
+        h.remove()
+    for n, p in model.state_dict().items():
+        if not n.startswith("image_keyframes_emb"):
+            out["param__" + n] = _np(p)
+    _save("g5_hot_region", **out)
+
+    keys = [[n, list(p.shape)] for n, p in model.state_dict().items() if not n.startswith("image_keyframes_emb")]
+    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0)
+    print("wrote state_dict_keys.json", len(keys), "tensors")
+
+
+def main():
+    _install_torchvision_stub()
+    sys.path.insert(0, REF)
+    import layers.attention as ref_att
+    import layers.encoding as ref_enc
+    import models as ref_models
+    torch.set_num_threads(1)  # fixed summation order on the generating side
+    gen_masked_softmax(ref_att)
+    gen_attention(ref_att)
+    gen_rnn(ref_enc)
+    gen_hot_region(ref_models)
+
+
+if __name__ == "__main__":
+    main()
