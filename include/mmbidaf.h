@@ -1,0 +1,150 @@
+/*
+ * mmbidaf.h -- C ABI of libmmbidaf_hip.so: the MI355X (gfx950) kernels of the MMBiDAF hot path.
+ *
+ * The reference (amankhullar/MMBiDAF) has no FFI of its own: its hot path is Python calling
+ * third-party torch ops.  Each entry point below replaces the arithmetic of one reference
+ * call site; the Python host (mmbidaf_amd/) binds them with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 (or int32 / uint8 where stated), row-major,
+ *     contiguous, 16-byte aligned base; the caller owns all memory (inputs, outputs, saved
+ *     tensors and workspaces); the library never allocates, frees or retains pointers.
+ *   - `stream` is a hipStream_t; every call only enqueues work on it (no sync, capturable).
+ *   - `device` is the HIP device ordinal the pointers live on (backward is called from the
+ *     autograd worker thread, so no thread-local current device is assumed).
+ *   - return 0 on success, negative on error; mmb_last_error() gives the thread-local text.
+ */
+#ifndef MMBIDAF_H
+#define MMBIDAF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMB_VERSION 100            /* 0.1.0 */
+#define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
+#define MMB_ATT_MAX_D 208          /* attention feature width D = 2H supported by this build */
+#define MMB_LSTM_MAX_H 128         /* hidden size supported by the register-resident recurrence */
+
+enum {
+    MMB_OK = 0,
+    MMB_ERR_ARG = -1,              /* bad shape / null pointer / unsupported size */
+    MMB_ERR_HIP = -2,              /* a HIP runtime call failed */
+};
+
+int mmb_version(void);
+const char* mmb_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * BiDAF attention.  Replaces BiDAFAttention.forward / get_similarity_matrix / masked_softmax
+ * (reference layers/attention.py:37-98) and their autograd.
+ *
+ *   text (B,T,D)  mod (B,M,D)  text_mask (B,T) u8  mod_mask (B,M) u8
+ *   text_d / mod_d : the dropped copies that only the similarity sees (attention.py:66-67);
+ *                    NULL = eval mode (use text / mod).
+ *   w_t (D) w_m (D) w_tm (D) bias (1)
+ * outputs
+ *   out (B,T,4D) = [text, a, text*a, text*b]                       (attention.py:52)
+ * saved for backward (caller-allocated)
+ *   q (B,M,D)   = s2^T . text         bsave (B,T,D) = b
+ *   rterm (B,T) = text_d.w_t + bias   cterm (B,M)   = mod_d.w_m
+ *   row_stat (B,T,2) = {max, sum} of the row softmax     col_stat (B,M,2) likewise
+ * D must be a multiple of 4 and <= MMB_ATT_MAX_D.
+ */
+int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t* text_mask, const uint8_t* mod_mask,
+                  const float* text_d, const float* mod_d,
+                  const float* w_t, const float* w_m, const float* w_tm, const float* bias,
+                  float* out, float* q, float* bsave, float* rterm, float* cterm,
+                  float* row_stat, float* col_stat,
+                  int B, int T, int M, int D, int device, void* stream);
+
+/* bytes of scratch mmb_bidaf_bwd needs (fp32 workspace, contents undefined on entry) */
+size_t mmb_bidaf_bwd_workspace_bytes(int B, int T, int M, int D);
+
+/*
+ * Backward of the above.  d_out (B,T,4D) -> d_text (B,T,D), d_mod (B,M,D), parameter grads
+ * d_w_t (D), d_w_m (D), d_w_tm (D), d_bias (1) (all OVERWRITTEN).  When text_d / mod_d were
+ * given, d_text_d / d_mod_d receive the gradient w.r.t. the dropped copies and d_text / d_mod
+ * only the clean-path part; when they are NULL everything is folded into d_text / d_mod and
+ * d_text_d / d_mod_d must be NULL.
+ */
+int mmb_bidaf_bwd(const float* d_out, const float* out,
+                  const float* text, const float* mod, const uint8_t* text_mask, const uint8_t* mod_mask,
+                  const float* text_d, const float* mod_d,
+                  const float* w_t, const float* w_m, const float* w_tm,
+                  const float* q, const float* bsave, const float* rterm, const float* cterm,
+                  const float* row_stat, const float* col_stat,
+                  float* d_text, float* d_mod, float* d_text_d, float* d_mod_d,
+                  float* d_w_t, float* d_w_m, float* d_w_tm, float* d_bias,
+                  float* workspace, size_t workspace_bytes,
+                  int B, int T, int M, int D, int device, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Bidirectional LSTM layer on a "packed" (per-sample length) batch.  Replaces torch.nn.LSTM as
+ * called by RNNEncoder.forward (reference layers/encoding.py:79-81,96) -- one call = one layer,
+ * both directions, for up to MMB_MAX_GROUP independent encoders co-scheduled in one launch.
+ * Samples stay in their ORIGINAL batch order (the recurrence is per sample, so the reference's
+ * sort/unsort, encoding.py:91-101, is only needed for the order of h_n and is done by the host).
+ */
+typedef struct {
+    /* inputs */
+    const float* x;            /* (B,T,I) layer input                                           */
+    const int32_t* lengths;    /* (B)  1 <= len <= T                                            */
+    const float* w_ih[2];      /* (4H,I) forward / reverse, torch gate order i,f,g,o            */
+    const float* w_hh[2];      /* (4H,H)                                                         */
+    const float* b_ih[2];      /* (4H)                                                           */
+    const float* b_hh[2];      /* (4H)                                                           */
+    /* outputs */
+    float* y;                  /* (B,T,2H) [fwd | rev], zeros at t >= len                        */
+    float* h_n;                /* (2,B,H) final hidden state per direction, batch order          */
+    float* c_n;                /* (2,B,H)                                                         */
+    /* saved for backward / scratch, caller-allocated */
+    float* gx;                 /* (B,T,2,H,4) input projection, gate-interleaved                 */
+    float* gates;              /* (B,T,2,H,4) post-activation i,f,g,o                            */
+    float* cs;                 /* (B,T,2,H)   cell state after each step                         */
+    int32_t B, T, I, H;
+} mmb_lstm_fwd_desc;
+
+int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* descs, int n, int device, void* stream);
+
+typedef struct {
+    /* inputs */
+    const float* d_y;          /* (B,T,2H) cotangent of y                                        */
+    const float* d_hn;         /* (2,B,H)  cotangent of h_n (batch order) or NULL                */
+    const float* x;            /* (B,T,I)                                                        */
+    const float* y;            /* (B,T,2H) forward output                                        */
+    const int32_t* lengths;    /* (B)                                                            */
+    const float* w_ih[2];      /* (4H,I)                                                         */
+    const float* w_hh[2];      /* (4H,H)                                                         */
+    const float* gates;        /* saved by forward                                               */
+    const float* cs;
+    /* outputs (all overwritten) */
+    float* d_x;                /* (B,T,I) or NULL when the input needs no gradient               */
+    float* d_w_ih;             /* (2,4H,I)  both directions, packed                              */
+    float* d_w_hh;             /* (2,4H,H)                                                       */
+    float* d_b;                /* (2,4H)    = d_b_ih = d_b_hh                                    */
+    /* scratch */
+    float* d_a;                /* (B,T,2,4H) pre-activation gate gradients                       */
+    int32_t B, T, I, H;
+} mmb_lstm_bwd_desc;
+
+int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* descs, int n, int device, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * fp32 MFMA GEMM used by the LSTM input projection / weight gradients (exported for tests and
+ * for the host-side highway fusion):  C (M,N) = op(A) . op(B) [+ bias(N)]
+ *   ta = 0: A is (M,K) row-major (lda)    ta = 1: A is (K,M) row-major (lda)
+ *   tb = 0: B is (K,N) row-major (ldb)    tb = 1: B is (N,K) row-major (ldb)
+ *   accumulate != 0: C += result (C must hold valid data)
+ */
+int mmb_gemm_f32(const float* A, const float* Bm, float* C, const float* bias,
+                 int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb, int accumulate,
+                 int device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMBIDAF_H */

@@ -1,0 +1,79 @@
+"""ctypes binding of libmmbidaf_hip.so (C ABI declared in include/mmbidaf.h).
+
+The library is built in-tree by `mmbidaf_amd.build.build_library()` (called from
+`__graft_entry__.build()`); there is NO fallback: if it is missing or a symbol is absent the
+import of the compute path fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmbidaf_hip.so")
+
+MAX_GROUP = 8
+ATT_MAX_D = 208
+LSTM_MAX_H = 128
+
+c_f = ctypes.c_void_p  # device pointers travel as raw addresses
+c_i = ctypes.c_int
+
+
+class LstmFwdDesc(ctypes.Structure):
+    """mmb_lstm_fwd_desc"""
+    _fields_ = [
+        ("x", c_f), ("lengths", c_f),
+        ("w_ih", c_f * 2), ("w_hh", c_f * 2), ("b_ih", c_f * 2), ("b_hh", c_f * 2),
+        ("y", c_f), ("h_n", c_f), ("c_n", c_f),
+        ("gx", c_f), ("gates", c_f), ("cs", c_f),
+        ("B", ctypes.c_int32), ("T", ctypes.c_int32), ("I", ctypes.c_int32), ("H", ctypes.c_int32),
+    ]
+
+
+class LstmBwdDesc(ctypes.Structure):
+    """mmb_lstm_bwd_desc"""
+    _fields_ = [
+        ("d_y", c_f), ("d_hn", c_f), ("x", c_f), ("y", c_f), ("lengths", c_f),
+        ("w_ih", c_f * 2), ("w_hh", c_f * 2), ("gates", c_f), ("cs", c_f),
+        ("d_x", c_f), ("d_w_ih", c_f), ("d_w_hh", c_f), ("d_b", c_f), ("d_a", c_f),
+        ("B", ctypes.c_int32), ("T", ctypes.c_int32), ("I", ctypes.c_int32), ("H", ctypes.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/mmbidaf.h one to one
+SIGNATURES = {
+    "mmb_version": (c_i, []),
+    "mmb_last_error": (ctypes.c_char_p, []),
+    "mmb_bidaf_fwd": (c_i, [c_f] * 17 + [c_i] * 5 + [c_f]),
+    "mmb_bidaf_bwd_workspace_bytes": (ctypes.c_size_t, [c_i] * 4),
+    "mmb_bidaf_bwd": (c_i, [c_f] * 26 + [ctypes.c_size_t] + [c_i] * 5 + [c_f]),
+    "mmb_bilstm_layer_fwd": (c_i, [ctypes.POINTER(LstmFwdDesc), c_i, c_i, c_f]),
+    "mmb_bilstm_layer_bwd": (c_i, [ctypes.POINTER(LstmBwdDesc), c_i, c_i, c_f]),
+    "mmb_gemm_f32": (c_i, [c_f] * 4 + [c_i] * 10 + [c_f]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the MI355X HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU or PyTorch fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mmb_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,69 @@
+// Shared host/device helpers for libmmbidaf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mmbidaf.h"
+
+namespace mmb {
+
+using f4 = float __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing (thread-local message, C-ABI return codes)
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+#define MMB_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return mmb::fail(MMB_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                          \
+    } while (0)
+
+#define MMB_REQUIRE(cond, ...)                                  \
+    do {                                                        \
+        if (!(cond)) return mmb::fail(MMB_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+// ---- device helpers
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
+    // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C/D[row=4*(l>>4)+reg][col=l&15]
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// quad (4-lane) DPP permutes: ctrl = quad_perm[a,b,c,d] = a | b<<2 | c<<4 | d<<6
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor1(float v) { return quad_perm<0xB1>(v); }  // [1,0,3,2]
+__device__ __forceinline__ float quad_xor2(float v) { return quad_perm<0x4E>(v); }  // [2,3,0,1]
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) { return quad_perm<K * 0x55>(v); }
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.0f * fast_rcp(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+// ---- GEMM (gemm.hip), usable from the other translation units
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;   // (N) or null
+    const float* bias2;  // (N) or null, added as well (b_ih + b_hh)
+    int M, N, K, lda, ldb, ldc;
+    int ta, tb;          // see mmb_gemm_f32
+    int accumulate;      // C += (atomic when split-K)
+    int gate_H;          // > 0: column n=(g*H+u) of each 4H block is stored at (u*4+g)
+    int shiftB, periodB; // tb == 0 only: B row k is read from row k+shiftB, zero when (k % period)+shift leaves [0,period)
+};
+// enqueue; C must be pre-zeroed by the caller when the launcher picks split-K (it tells via *needs_zero)
+int gemm_launch(const GemmArgs& g, hipStream_t stream);
+// true when gemm_launch(g) will accumulate with atomics over K splits (caller zeroes C unless accumulate)
+int gemm_splitk_for(const GemmArgs& g);
+
+}  // namespace mmb

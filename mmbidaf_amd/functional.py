@@ -1,0 +1,222 @@
+"""torch.autograd.Function wrappers over the C-ABI HIP kernels.
+
+Every tensor handed to the library is a contiguous fp32 CUDA(=HIP) tensor allocated here, so
+the library never owns memory; kernels are enqueued on torch's current stream.  Backward runs
+on the autograd worker thread: the device ordinal is passed explicitly on every call.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "mmbidaf_amd: the hot path runs only on an MI355X (HIP) device; got a CPU tensor. "
+                "There is no CPU fallback -- move the module and its inputs to cuda.")
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"mmbidaf_amd: fp32 tensors expected, got {t.dtype}")
+    return t.contiguous()
+
+
+def _mask_u8(mask, B, n):
+    m = mask.reshape(B, n)
+    if m.dtype == torch.bool:
+        return m.contiguous()
+    return (m != 0).contiguous()
+
+
+class _BiDAFAttentionFn(torch.autograd.Function):
+    """out = BiDAFAttention(text, mod)  -- reference layers/attention.py:37-75 (A1-A5, A-bwd)."""
+
+    @staticmethod
+    def forward(ctx, text, mod, text_d, mod_d, w_t, w_m, w_tm, bias, text_mask, mod_mask):
+        lib = _lib.load()
+        _require_gpu(text, mod, w_t, w_m, w_tm, bias, text_mask, mod_mask)
+        B, T, D = text.shape
+        M = mod.shape[1]
+        if D % 4 != 0 or D > _lib.ATT_MAX_D:
+            raise RuntimeError(f"mmbidaf_amd: attention width D=2H={D} must be a multiple of 4 and <= {_lib.ATT_MAX_D}")
+        text, mod = _f32c(text), _f32c(mod)
+        has_drop = text_d is not None
+        if has_drop:
+            text_d, mod_d = _f32c(text_d), _f32c(mod_d)
+        w_t_, w_m_, w_tm_, bias_ = (_f32c(w_t.reshape(-1)), _f32c(w_m.reshape(-1)),
+                                    _f32c(w_tm.reshape(-1)), _f32c(bias.reshape(-1)))
+        tmask, mmask = _mask_u8(text_mask, B, T), _mask_u8(mod_mask, B, M)
+        dev = text.device
+        out = torch.empty(B, T, 4 * D, device=dev, dtype=torch.float32)
+        q = torch.empty(B, M, D, device=dev, dtype=torch.float32)
+        bsave = torch.empty(B, T, D, device=dev, dtype=torch.float32)
+        rterm = torch.empty(B, T, device=dev, dtype=torch.float32)
+        cterm = torch.empty(B, M, device=dev, dtype=torch.float32)
+        row_stat = torch.empty(B, T, 2, device=dev, dtype=torch.float32)
+        col_stat = torch.empty(B, M, 2, device=dev, dtype=torch.float32)
+        rc = lib.mmb_bidaf_fwd(_ptr(text), _ptr(mod), _ptr(tmask), _ptr(mmask),
+                               _ptr(text_d) if has_drop else None, _ptr(mod_d) if has_drop else None,
+                               _ptr(w_t_), _ptr(w_m_), _ptr(w_tm_), _ptr(bias_),
+                               _ptr(out), _ptr(q), _ptr(bsave), _ptr(rterm), _ptr(cterm), _ptr(row_stat), _ptr(col_stat),
+                               B, T, M, D, dev.index, _stream())
+        _lib.check(rc, "mmb_bidaf_fwd")
+        ctx.has_drop = has_drop
+        ctx.shapes = (w_t.shape, w_m.shape, w_tm.shape, bias.shape)
+        ctx.save_for_backward(text, mod, text_d if has_drop else None, mod_d if has_drop else None,
+                              w_t_, w_m_, w_tm_, tmask, mmask, out, q, bsave, rterm, cterm, row_stat, col_stat)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        (text, mod, text_d, mod_d, w_t, w_m, w_tm, tmask, mmask, out, q, bsave, rterm, cterm,
+         row_stat, col_stat) = ctx.saved_tensors
+        B, T, D = text.shape
+        M = mod.shape[1]
+        dev = text.device
+        d_out = _f32c(d_out)
+        d_text = torch.empty_like(text)
+        d_mod = torch.empty_like(mod)
+        d_text_d = torch.empty_like(text) if ctx.has_drop else None
+        d_mod_d = torch.empty_like(mod) if ctx.has_drop else None
+        d_w = torch.empty(3 * D + 4, device=dev, dtype=torch.float32)
+        d_w_t, d_w_m, d_w_tm, d_bias = d_w[0:D], d_w[D:2 * D], d_w[2 * D:3 * D], d_w[3 * D:3 * D + 1]
+        ws_bytes = lib.mmb_bidaf_bwd_workspace_bytes(B, T, M, D)
+        ws = torch.empty(ws_bytes // 4, device=dev, dtype=torch.float32)
+        rc = lib.mmb_bidaf_bwd(_ptr(d_out), _ptr(out), _ptr(text), _ptr(mod), _ptr(tmask), _ptr(mmask),
+                               _ptr(text_d), _ptr(mod_d), _ptr(w_t), _ptr(w_m), _ptr(w_tm),
+                               _ptr(q), _ptr(bsave), _ptr(rterm), _ptr(cterm), _ptr(row_stat), _ptr(col_stat),
+                               _ptr(d_text), _ptr(d_mod), _ptr(d_text_d), _ptr(d_mod_d),
+                               _ptr(d_w_t), _ptr(d_w_m), _ptr(d_w_tm), _ptr(d_bias),
+                               _ptr(ws), ws_bytes, B, T, M, D, dev.index, _stream())
+        _lib.check(rc, "mmb_bidaf_bwd")
+        s_t, s_m, s_tm, s_b = ctx.shapes
+        return (d_text, d_mod, d_text_d, d_mod_d, d_w_t.reshape(s_t), d_w_m.reshape(s_m), d_w_tm.reshape(s_tm),
+                d_bias.reshape(s_b), None, None)
+
+
+def bidaf_attention(text, mod, text_mask, mod_mask, w_t, w_m, w_tm, bias, text_d=None, mod_d=None):
+    """Fused BiDAF attention.  text_d / mod_d: dropped copies seen only by the similarity (Q6)."""
+    if (text_d is None) != (mod_d is None):
+        raise ValueError("text_d and mod_d must be given together")
+    return _BiDAFAttentionFn.apply(text, mod, text_d, mod_d, w_t, w_m, w_tm, bias, text_mask, mod_mask)
+
+
+# --------------------------------------------------------------------------------------- LSTM
+_PER_PROBLEM = 9  # x + (w_ih, w_hh, b_ih, b_hh) x 2 directions
+
+
+class _BiLSTMLayerFn(torch.autograd.Function):
+    """One bidirectional LSTM layer for n co-scheduled encoders (reference: nn.LSTM on a packed
+    batch, layers/encoding.py:79-81,96; rows L2-L4, L-bwd).  Flat tensor args per problem:
+    x, w_ih, w_hh, b_ih, b_hh (forward), w_ih, w_hh, b_ih, b_hh (reverse).
+    Returns (y_0, h_n_0, y_1, h_n_1, ...) with y (B,T,2H) and h_n (2,B,H) in batch order."""
+
+    @staticmethod
+    def forward(ctx, lengths_dev, *flat):
+        lib = _lib.load()
+        n = len(lengths_dev)
+        assert len(flat) == n * _PER_PROBLEM and 1 <= n <= _lib.MAX_GROUP
+        descs = (_lib.LstmFwdDesc * n)()
+        keep, outs, saved = [], [], []
+        dev = flat[0].device
+        for i in range(n):
+            x, *ws = flat[i * _PER_PROBLEM:(i + 1) * _PER_PROBLEM]
+            _require_gpu(x, *ws)
+            x = _f32c(x)
+            ws = [_f32c(w) for w in ws]
+            B, T, I = x.shape
+            H = ws[1].shape[1]
+            if H > _lib.LSTM_MAX_H:
+                raise RuntimeError(f"mmbidaf_amd: hidden size {H} > {_lib.LSTM_MAX_H} not supported by this build")
+            y = torch.empty(B, T, 2 * H, device=dev, dtype=torch.float32)
+            h_n = torch.empty(2, B, H, device=dev, dtype=torch.float32)
+            c_n = torch.empty(2, B, H, device=dev, dtype=torch.float32)
+            gx = torch.empty(B, T, 8 * H, device=dev, dtype=torch.float32)
+            gates = torch.empty(B, T, 8 * H, device=dev, dtype=torch.float32)
+            cs = torch.empty(B, T, 2 * H, device=dev, dtype=torch.float32)
+            d = descs[i]
+            d.x, d.lengths = _ptr(x), _ptr(lengths_dev[i])
+            for k in range(2):
+                d.w_ih[k], d.w_hh[k], d.b_ih[k], d.b_hh[k] = (_ptr(ws[4 * k]), _ptr(ws[4 * k + 1]),
+                                                              _ptr(ws[4 * k + 2]), _ptr(ws[4 * k + 3]))
+            d.y, d.h_n, d.c_n, d.gx, d.gates, d.cs = _ptr(y), _ptr(h_n), _ptr(c_n), _ptr(gx), _ptr(gates), _ptr(cs)
+            d.B, d.T, d.I, d.H = B, T, I, H
+            keep += [x, gx, c_n] + ws
+            outs += [y, h_n]
+            saved += [x, y, gates, cs, ws[0], ws[1], ws[4], ws[5], lengths_dev[i]]
+        rc = lib.mmb_bilstm_layer_fwd(descs, n, dev.index, _stream())
+        _lib.check(rc, "mmb_bilstm_layer_fwd")
+        ctx.n = n
+        ctx.need_dx = [bool(ctx.needs_input_grad[1 + i * _PER_PROBLEM]) for i in range(n)]
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        n = ctx.n
+        sv = ctx.saved_tensors
+        descs = (_lib.LstmBwdDesc * n)()
+        keep, results = [], []
+        dev = sv[0].device
+        for i in range(n):
+            x, y, gates, cs, w_ih_f, w_hh_f, w_ih_r, w_hh_r, lens = sv[i * 9:(i + 1) * 9]
+            B, T, I = x.shape
+            H = w_hh_f.shape[1]
+            d_y, d_hn = grads[2 * i], grads[2 * i + 1]
+            d_y = torch.zeros_like(y) if d_y is None else _f32c(d_y)
+            d_hn = None if d_hn is None else _f32c(d_hn)
+            d_x = torch.empty_like(x) if ctx.need_dx[i] else None
+            d_w_ih = torch.empty(2, 4 * H, I, device=dev, dtype=torch.float32)
+            d_w_hh = torch.empty(2, 4 * H, H, device=dev, dtype=torch.float32)
+            d_b = torch.empty(2, 4 * H, device=dev, dtype=torch.float32)
+            d_a = torch.empty(B, T, 8 * H, device=dev, dtype=torch.float32)
+            d = descs[i]
+            d.d_y, d.d_hn, d.x, d.y, d.lengths = _ptr(d_y), _ptr(d_hn), _ptr(x), _ptr(y), _ptr(lens)
+            d.w_ih[0], d.w_ih[1], d.w_hh[0], d.w_hh[1] = _ptr(w_ih_f), _ptr(w_ih_r), _ptr(w_hh_f), _ptr(w_hh_r)
+            d.gates, d.cs = _ptr(gates), _ptr(cs)
+            d.d_x, d.d_w_ih, d.d_w_hh, d.d_b, d.d_a = _ptr(d_x), _ptr(d_w_ih), _ptr(d_w_hh), _ptr(d_b), _ptr(d_a)
+            d.B, d.T, d.I, d.H = B, T, I, H
+            keep += [d_y, d_hn, d_a]
+            results += [d_x, d_w_ih[0], d_w_hh[0], d_b[0], d_b[0], d_w_ih[1], d_w_hh[1], d_b[1], d_b[1]]
+        rc = lib.mmb_bilstm_layer_bwd(descs, n, dev.index, _stream())
+        _lib.check(rc, "mmb_bilstm_layer_bwd")
+        return (None, *results)
+
+
+def bilstm_layer(problems):
+    """problems: list of (x, lengths_i32_device, [w_ih, w_hh, b_ih, b_hh] fwd, [..] reverse).
+    Returns list of (y, h_n) -- h_n (2,B,H) in batch order."""
+    lengths = [p[1] for p in problems]
+    flat = []
+    for x, _, wf, wr in problems:
+        flat += [x] + list(wf) + list(wr)
+    outs = _BiLSTMLayerFn.apply(lengths, *flat)
+    return [(outs[2 * i], outs[2 * i + 1]) for i in range(len(problems))]
+
+
+def gemm(a, b, bias=None, ta=False, tb=False):
+    """C = op(a) . op(b) (+bias) through the library's fp32 MFMA GEMM (used by tests / tools)."""
+    lib = _lib.load()
+    _require_gpu(a, b)
+    a, b = _f32c(a), _f32c(b)
+    M, K = (a.shape[1], a.shape[0]) if ta else a.shape
+    N = b.shape[0] if tb else b.shape[1]
+    c = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    rc = lib.mmb_gemm_f32(_ptr(a), _ptr(b), _ptr(c), _ptr(bias), M, N, K, a.stride(0), b.stride(0), N,
+                          int(ta), int(tb), 0, a.device.index, _stream())
+    _lib.check(rc, "mmb_gemm_f32")
+    return c

@@ -1,0 +1,99 @@
+"""Drop-in for the reference's `models.MMBiDAF` (same constructor / forward signature and
+state-dict keys, reference models.py:8-206).
+
+The hot segment (3 encoders -> 2 BiDAF attentions -> 2 two-layer modelling encoders,
+models.py:97,102,113,131-135) runs on the HIP kernels, with the independent encoders
+co-scheduled in grouped launches.  Everything else is the surrounding graph in stock
+PyTorch-ROCm; the decoder loss is gathered on the device instead of the reference's
+per-sample `int(tensor)` host syncs (same values).
+"""
+import torch
+import torch.nn as nn
+
+from .attention import BiDAFAttention, MultimodalAttentionDecoder
+from .encoding import Embedding, ImageEmbedding, RNNEncoder, encode_group
+
+
+class MMBiDAF(nn.Module):
+    def __init__(self, hidden_size, text_embedding_size, audio_embedding_size, image_embedding_size, device,
+                 drop_prob=0., max_transcript_length=405, image_backbone=None):
+        super().__init__()
+        self.device = device
+        self.max_transcript_length = max_transcript_length
+        self.emb = Embedding(text_embedding_size, hidden_size, drop_prob)
+        self.a_emb = Embedding(audio_embedding_size, hidden_size, drop_prob)
+        self.i_emb = Embedding(image_embedding_size, hidden_size, drop_prob)
+        self.text_enc = RNNEncoder(hidden_size, hidden_size, 1, drop_prob)
+        self.audio_enc = RNNEncoder(hidden_size, hidden_size, 1, drop_prob)
+        self.image_enc = RNNEncoder(hidden_size, hidden_size, 1, drop_prob)
+        self.image_keyframes_emb = ImageEmbedding(image_backbone)
+        self.bidaf_att_audio = BiDAFAttention(2 * hidden_size, drop_prob=drop_prob)
+        self.bidaf_att_image = BiDAFAttention(2 * hidden_size, drop_prob=drop_prob)
+        self.mod_t_a = RNNEncoder(8 * hidden_size, hidden_size, 2, drop_prob)
+        self.mod_t_i = RNNEncoder(8 * hidden_size, hidden_size, 2, drop_prob)
+        self.multimodal_att_decoder = MultimodalAttentionDecoder(text_embedding_size, hidden_size,
+                                                                 max_transcript_length, num_layers=1)
+
+    def get_mask(self, X, X_len):
+        """bool prefix mask (B, X.size(1)) built on the host like the reference (models.py:86-92)."""
+        lens = torch.as_tensor(X_len, dtype=torch.long)
+        return torch.arange(X.size(1)).unsqueeze(0) < lens.unsqueeze(1)
+
+    def hot_path(self, text_emb, audio_emb, image_emb, text_lengths, audio_lengths, image_lengths):
+        """models.py:97,102,113,116-118,131-135: returns the two modality-aware encodings and
+        their (length-sorted) final hidden states."""
+        (text_enc, _), (audio_enc, _), (image_enc, _) = encode_group(
+            [self.text_enc, self.audio_enc, self.image_enc], [text_emb, audio_emb, image_emb],
+            [text_lengths, audio_lengths, image_lengths])
+        dev = text_emb.device
+        text_mask = self.get_mask(text_emb, text_lengths).to(dev)
+        audio_mask = self.get_mask(audio_emb, audio_lengths).to(dev)
+        image_mask = self.get_mask(image_emb, image_lengths).to(dev)
+        att_audio = self.bidaf_att_audio(text_enc, audio_enc, text_mask, audio_mask)
+        att_image = self.bidaf_att_image(text_enc, image_enc, text_mask, image_mask)
+        (mod_a, hid_a), (mod_i, hid_i) = encode_group([self.mod_t_a, self.mod_t_i], [att_audio, att_image],
+                                                      [text_lengths, text_lengths])
+        return mod_a, hid_a, mod_i, hid_i, text_mask
+
+    def forward(self, embedded_text, original_text_lengths, embedded_audio, original_audio_lengths,
+                transformed_images, original_image_lengths, batch_target_indices, original_target_len, max_dec_len):
+        B = embedded_text.size(0)
+        dev = embedded_text.device
+        text_emb = self.emb(embedded_text)
+        audio_emb = self.a_emb(embedded_audio)
+        frames = transformed_images.reshape(-1, *transformed_images.shape[2:])
+        image_feat = self.image_keyframes_emb(frames).reshape(B, transformed_images.size(1), -1)
+        image_emb = self.i_emb(image_feat)
+
+        mod_a, hid_a, mod_i, hid_i, text_mask = self.hot_path(
+            text_emb, audio_emb, image_emb, original_text_lengths, original_audio_lengths, original_image_lengths)
+
+        pad = torch.zeros(B, self.max_transcript_length - text_mask.size(1), dtype=text_mask.dtype, device=dev)
+        decoder_mask = torch.cat((text_mask, pad), dim=1)
+        # the reference sums the (length-sorted) hidden states over layers and directions, models.py:143
+        decoder_hidden = (hid_a.sum(1) + hid_i.sum(1)).unsqueeze(1)
+        decoder_cell = torch.zeros(1, B, decoder_hidden.size(-1), device=dev)
+        decoder_input = torch.zeros(B, 1, embedded_text.size(-1), device=dev)
+        coverage = torch.zeros(B, text_emb.size(1), 1, device=dev)
+
+        eps = 1e-12
+        loss = torch.zeros((), device=dev)
+        dists = []
+        rows = torch.arange(B, device=dev)
+        targets = batch_target_indices.to(dev).reshape(B, -1).long()
+        steps = targets.size(1) if self.training else max_dec_len
+        att_cov = None
+        for step in range(steps):
+            dist, decoder_hidden, decoder_cell, att_cov, coverage = self.multimodal_att_decoder(
+                decoder_input, decoder_hidden, decoder_cell, mod_a, mod_i, coverage, decoder_mask)
+            tgt = targets[:, step]
+            loss = loss - torch.log(dist[rows, tgt] + eps).sum()
+            nxt = tgt if self.training else dist.argmax(dim=1)     # teacher forcing vs greedy
+            decoder_input = embedded_text[rows, nxt].unsqueeze(1)
+            dists.append(dist)
+            if self.training:
+                loss = loss + torch.sum(torch.min(att_cov, coverage))
+        if not self.training:
+            loss = loss + torch.sum(torch.min(att_cov, coverage))
+        loss = loss / steps
+        return torch.stack(dists).transpose(0, 1), loss
