@@ -39,6 +39,21 @@ int mmb_version(void);
 const char* mmb_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Opt-in kernel timing (the reference has no tracing at all).  When bit k of
+ * `kernel_mask` is set, every launch of kernel k is bracketed by a pair of hipEvents recorded on
+ * the launch stream.  mmb_profile_read sums and clears the finished pairs of one kernel; call it
+ * after synchronising the stream.  Disabled (mask 0) by default: no events, no overhead.
+ */
+enum {
+    MMB_K_ATT_RANK1 = 0, MMB_K_ATT_COL, MMB_K_ATT_COMBINE, MMB_K_ATT_ROW,
+    MMB_K_ATT_BWD_PRE, MMB_K_ATT_BWD_J1, MMB_K_ATT_BWD_J2, MMB_K_ATT_BWD_JFIN, MMB_K_ATT_BWD_I,
+    MMB_K_GEMM, MMB_K_LSTM_REC_FWD, MMB_K_LSTM_REC_BWD, MMB_K_COUNT
+};
+int mmb_profile_enable(uint32_t kernel_mask);
+int mmb_profile_read(int kernel_id, double* total_ms, int* launches);
+const char* mmb_kernel_name(int kernel_id);   /* device-side symbol stem, as rocprofv3 prints it */
+
+/* ------------------------------------------------------------------------------------------
  * BiDAF attention.  Replaces BiDAFAttention.forward / get_similarity_matrix / masked_softmax
  * (reference layers/attention.py:37-98) and their autograd.
  *

@@ -43,6 +43,9 @@ class LstmBwdDesc(ctypes.Structure):
 SIGNATURES = {
     "mmb_version": (c_i, []),
     "mmb_last_error": (ctypes.c_char_p, []),
+    "mmb_profile_enable": (c_i, [ctypes.c_uint32]),
+    "mmb_profile_read": (c_i, [c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i)]),
+    "mmb_kernel_name": (ctypes.c_char_p, [c_i]),
     "mmb_bidaf_fwd": (c_i, [c_f] * 17 + [c_i] * 5 + [c_f]),
     "mmb_bidaf_bwd_workspace_bytes": (ctypes.c_size_t, [c_i] * 4),
     "mmb_bidaf_bwd": (c_i, [c_f] * 26 + [ctypes.c_size_t] + [c_i] * 5 + [c_f]),
@@ -50,6 +53,11 @@ SIGNATURES = {
     "mmb_bilstm_layer_bwd": (c_i, [ctypes.POINTER(LstmBwdDesc), c_i, c_i, c_f]),
     "mmb_gemm_f32": (c_i, [c_f] * 4 + [c_i] * 10 + [c_f]),
 }
+
+# kernel ids of the opt-in timing hook (enum in include/mmbidaf.h)
+KERNEL_IDS = {n: i for i, n in enumerate(
+    ["att_rank1", "att_col", "att_combine", "att_row", "att_bwd_pre", "att_bwd_j1", "att_bwd_j2", "att_bwd_jfin",
+     "att_bwd_i", "gemm", "lstm_rec_fwd", "lstm_rec_bwd"])}
 
 _lib = None
 
@@ -77,3 +85,19 @@ def check(rc, what):
     if rc != 0:
         msg = load().mmb_last_error()
         raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def profile_enable(names):
+    """Bracket every launch of the named kernels (keys of KERNEL_IDS) with hipEvents; [] disables."""
+    mask = 0
+    for n in names:
+        mask |= 1 << KERNEL_IDS[n]
+    check(load().mmb_profile_enable(mask), "mmb_profile_enable")
+
+
+def profile_read(name):
+    """(total_ms, launches, device symbol stem) of the finished launches of one kernel since the last read."""
+    ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+    kid = KERNEL_IDS[name]
+    check(load().mmb_profile_read(kid, ctypes.byref(ms), ctypes.byref(n)), "mmb_profile_read")
+    return ms.value, n.value, load().mmb_kernel_name(kid).decode()

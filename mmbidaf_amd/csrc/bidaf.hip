@@ -800,8 +800,8 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
     if (!text_d) text_d = text;
     if (!mod_d) mod_d = mod;
 
-    hipLaunchKernelGGL(att_rank1_kernel, dim3((B * T + B * M + 3) / 4), dim3(256), 0, stream, text_d, mod_d, w_t, w_m, bias,
-                       rterm, cterm, B * T, B * M, D);
+    { ProfScope ps_(MMB_K_ATT_RANK1, stream); hipLaunchKernelGGL(att_rank1_kernel, dim3((B * T + B * M + 3) / 4), dim3(256), 0, stream, text_d, mod_d, w_t, w_m, bias,
+                       rterm, cterm, B * T, B * M, D); }
     MMB_HIP(hipGetLastError());
 
     // ---- column pass: lane side = modality rows, streams text.  (`out` is used as scratch for the split
@@ -820,12 +820,12 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
         const size_t lds = ((size_t)(1 + 1) * PR * LDP + 2 * PR) * sizeof(float);
         if (int rc = allow_lds(att_fwd_kernel<1>, lds)) return rc;
         dim3 grid((M + 16 * NW - 1) / (16 * NW), splits, B);
-        hipLaunchKernelGGL(att_fwd_kernel<1>, grid, dim3(NTHR), lds, stream, a);
+        { ProfScope ps_(MMB_K_ATT_COL, stream); hipLaunchKernelGGL(att_fwd_kernel<1>, grid, dim3(NTHR), lds, stream, a); }
         MMB_HIP(hipGetLastError());
         if (splits > 1) {
             const size_t nthr = (size_t)B * M * (D / 4);
-            hipLaunchKernelGGL(att_combine_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, a.part_o, a.part_stat, q,
-                               col_stat, B, M, D, splits);
+            { ProfScope ps_(MMB_K_ATT_COMBINE, stream); hipLaunchKernelGGL(att_combine_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, a.part_o, a.part_stat, q,
+                               col_stat, B, M, D, splits); }
             MMB_HIP(hipGetLastError());
         }
     }
@@ -839,7 +839,7 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
         const size_t lds = ((size_t)(2 + 1) * PR * LDP + 2 * PR) * sizeof(float);
         if (int rc = allow_lds(att_fwd_kernel<2>, lds)) return rc;
         dim3 grid((T + 16 * NW - 1) / (16 * NW), 1, B);
-        hipLaunchKernelGGL(att_fwd_kernel<2>, grid, dim3(NTHR), lds, stream, a);
+        { ProfScope ps_(MMB_K_ATT_ROW, stream); hipLaunchKernelGGL(att_fwd_kernel<2>, grid, dim3(NTHR), lds, stream, a); }
         MMB_HIP(hipGetLastError());
     }
     return MMB_OK;
@@ -885,33 +885,33 @@ extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* 
     a.splits = L.splits;
     a.rows_per_split = rows_per_split(T, a.splits);
 
-    hipLaunchKernelGGL(att_bwd_pre_kernel, dim3((B * T + 3) / 4), dim3(256), 0, stream, d_out, out, text, bsave,
-                       workspace + L.da, workspace + L.db, workspace + L.delta1, d_text, d_w_t, d_w_m, d_w_tm, d_bias, B * T, D);
+    { ProfScope ps_(MMB_K_ATT_BWD_PRE, stream); hipLaunchKernelGGL(att_bwd_pre_kernel, dim3((B * T + 3) / 4), dim3(256), 0, stream, d_out, out, text, bsave,
+                       workspace + L.da, workspace + L.db, workspace + L.delta1, d_text, d_w_t, d_w_m, d_w_tm, d_bias, B * T, D); }
     MMB_HIP(hipGetLastError());
     {
         const size_t lds = ((size_t)3 * PR * LDP + 4 * PR) * sizeof(float);
         if (int rc = allow_lds(att_bwd_j1_kernel, lds)) return rc;
         dim3 grid((M + 16 * NW - 1) / (16 * NW), a.splits, B);
-        hipLaunchKernelGGL(att_bwd_j1_kernel, grid, dim3(NTHR), lds, stream, a);
+        { ProfScope ps_(MMB_K_ATT_BWD_J1, stream); hipLaunchKernelGGL(att_bwd_j1_kernel, grid, dim3(NTHR), lds, stream, a); }
         MMB_HIP(hipGetLastError());
     }
     {
         const size_t lds = ((size_t)2 * PR * LDP + 2 * PR) * sizeof(float);
         if (int rc = allow_lds(att_bwd_j2_kernel, lds)) return rc;
         dim3 grid((M + 16 * NW - 1) / (16 * NW), a.splits, B);
-        hipLaunchKernelGGL(att_bwd_j2_kernel, grid, dim3(NTHR), lds, stream, a);
+        { ProfScope ps_(MMB_K_ATT_BWD_J2, stream); hipLaunchKernelGGL(att_bwd_j2_kernel, grid, dim3(NTHR), lds, stream, a); }
         MMB_HIP(hipGetLastError());
     }
     {
         const int chunks = (B * M + JF_ROWS - 1) / JF_ROWS;
-        hipLaunchKernelGGL(att_bwd_jfin_kernel, dim3((chunks + 3) / 4), dim3(256), 0, stream, a, B);
+        { ProfScope ps_(MMB_K_ATT_BWD_JFIN, stream); hipLaunchKernelGGL(att_bwd_jfin_kernel, dim3((chunks + 3) / 4), dim3(256), 0, stream, a, B); }
         MMB_HIP(hipGetLastError());
     }
     {
         const size_t lds = ((size_t)4 * PR * LDP + 5 * PR) * sizeof(float);
         if (int rc = allow_lds(att_bwd_i_kernel, lds)) return rc;
         dim3 grid((T + 16 * NW - 1) / (16 * NW), 1, B);
-        hipLaunchKernelGGL(att_bwd_i_kernel, grid, dim3(NTHR), lds, stream, a);
+        { ProfScope ps_(MMB_K_ATT_BWD_I, stream); hipLaunchKernelGGL(att_bwd_i_kernel, grid, dim3(NTHR), lds, stream, a); }
         MMB_HIP(hipGetLastError());
     }
     return MMB_OK;

@@ -28,6 +28,15 @@ int fail(int code, const char* fmt, ...);
         if (!(cond)) return mmb::fail(MMB_ERR_ARG, __VA_ARGS__); \
     } while (0)
 
+// ---- opt-in per-kernel timing (api.hip)
+struct ProfScope {
+    int id;
+    hipStream_t stream;
+    void* slot;
+    ProfScope(int id, hipStream_t s);
+    ~ProfScope();
+};
+
 // ---- device helpers
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
     // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C/D[row=4*(l>>4)+reg][col=l&15]

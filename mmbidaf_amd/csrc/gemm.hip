@@ -198,6 +198,7 @@ static int launch_cfg(const GemmArgs& g, int splitk, hipStream_t stream) {
     int kchunk = (g.K + splitk - 1) / splitk;
     kchunk = (kchunk + BK - 1) / BK * BK;
     dim3 block(WAVES * 64);
+    ProfScope ps_(MMB_K_GEMM, stream);
     if (!g.ta && g.tb)
         hipLaunchKernelGGL((gemm_kernel<WAVES, MT, NT, false, true>), grid, block, 0, stream, g, kchunk);
     else if (!g.ta && !g.tb)

@@ -290,8 +290,9 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(const RecBwdArgs args
 }
 
 template <typename ArgsT, typename K>
-static int launch_rec(K kernel, const ArgsT& a, int total_wgs, int H, hipStream_t stream) {
+static int launch_rec(K kernel, const ArgsT& a, int total_wgs, int H, hipStream_t stream, int kid) {
     const int threads = ((4 * H + 63) / 64) * 64;
+    ProfScope ps_(kid, stream);
     hipLaunchKernelGGL(kernel, dim3(total_wgs), dim3(threads), 0, stream, a);
     MMB_HIP(hipGetLastError());
     return MMB_OK;
@@ -341,10 +342,10 @@ extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int devic
         wg += 2 * p.B;
     }
     switch (kq_for(H)) {
-        case 8: return launch_rec(lstm_rec_fwd_kernel<8>, ra, wg, H, stream);
-        case 16: return launch_rec(lstm_rec_fwd_kernel<16>, ra, wg, H, stream);
-        case 25: return launch_rec(lstm_rec_fwd_kernel<25>, ra, wg, H, stream);
-        default: return launch_rec(lstm_rec_fwd_kernel<32>, ra, wg, H, stream);
+        case 8: return launch_rec(lstm_rec_fwd_kernel<8>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+        case 16: return launch_rec(lstm_rec_fwd_kernel<16>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+        case 25: return launch_rec(lstm_rec_fwd_kernel<25>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+        default: return launch_rec(lstm_rec_fwd_kernel<32>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
     }
 }
 
@@ -371,10 +372,10 @@ extern "C" int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* d, int n, int devic
     }
     int rc;
     switch (kq_for(H)) {
-        case 8: rc = launch_rec(lstm_rec_bwd_kernel<8>, ra, wg, H, stream); break;
-        case 16: rc = launch_rec(lstm_rec_bwd_kernel<16>, ra, wg, H, stream); break;
-        case 25: rc = launch_rec(lstm_rec_bwd_kernel<25>, ra, wg, H, stream); break;
-        default: rc = launch_rec(lstm_rec_bwd_kernel<32>, ra, wg, H, stream); break;
+        case 8: rc = launch_rec(lstm_rec_bwd_kernel<8>, ra, wg, H, stream, MMB_K_LSTM_REC_BWD); break;
+        case 16: rc = launch_rec(lstm_rec_bwd_kernel<16>, ra, wg, H, stream, MMB_K_LSTM_REC_BWD); break;
+        case 25: rc = launch_rec(lstm_rec_bwd_kernel<25>, ra, wg, H, stream, MMB_K_LSTM_REC_BWD); break;
+        default: rc = launch_rec(lstm_rec_bwd_kernel<32>, ra, wg, H, stream, MMB_K_LSTM_REC_BWD); break;
     }
     if (rc) return rc;
     for (int i = 0; i < n; ++i) {

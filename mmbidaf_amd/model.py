@@ -68,13 +68,22 @@ class MMBiDAF(nn.Module):
         mod_a, hid_a, mod_i, hid_i, text_mask = self.hot_path(
             text_emb, audio_emb, image_emb, original_text_lengths, original_audio_lengths, original_image_lengths)
 
+        return self.decode(embedded_text, text_emb.size(1), mod_a, hid_a, mod_i, hid_i, text_mask,
+                           batch_target_indices, max_dec_len)
+
+    def decode(self, embedded_text, T, mod_a, hid_a, mod_i, hid_i, text_mask, batch_target_indices, max_dec_len):
+        """Pointer decoder loop with coverage (reference models.py:120-206): teacher forcing when
+        training, greedy otherwise.  Surrounding graph, stock PyTorch; the per-sample loss terms
+        are gathered on the device (same values as the reference's per-sample Python loop)."""
+        B = embedded_text.size(0)
+        dev = embedded_text.device
         pad = torch.zeros(B, self.max_transcript_length - text_mask.size(1), dtype=text_mask.dtype, device=dev)
         decoder_mask = torch.cat((text_mask, pad), dim=1)
         # the reference sums the (length-sorted) hidden states over layers and directions, models.py:143
         decoder_hidden = (hid_a.sum(1) + hid_i.sum(1)).unsqueeze(1)
         decoder_cell = torch.zeros(1, B, decoder_hidden.size(-1), device=dev)
         decoder_input = torch.zeros(B, 1, embedded_text.size(-1), device=dev)
-        coverage = torch.zeros(B, text_emb.size(1), 1, device=dev)
+        coverage = torch.zeros(B, T, 1, device=dev)
 
         eps = 1e-12
         loss = torch.zeros((), device=dev)

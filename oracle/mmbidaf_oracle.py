@@ -296,3 +296,48 @@ def hot_region(x_text, x_aud, x_img, text_len, aud_len, img_len, P):
                mod_t_a=ya, mod_t_a_h=ha, mod_t_i=yi, mod_t_i_h=hi,
                decoder_hidden=(ha.sum(1) + hi.sum(1)).unsqueeze(1))
     return out
+
+
+class HotRegionCPU(torch.nn.Module):
+    """The same region through torch's own CPU kernels, exactly as the reference's modules call them
+    (nn.LSTM on packed sequences, bmm/softmax attention): the CPU baseline that bench.py times on the
+    host cores.  Built from a hot-region state dict (keys `text_enc.rnn.weight_ih_l0`, ...)."""
+
+    def __init__(self, state_dict, hidden_size):
+        super().__init__()
+        H = hidden_size
+        mk = lambda i, l: torch.nn.LSTM(i, H, l, batch_first=True, bidirectional=True)
+        self.rnns = torch.nn.ModuleDict(dict(text_enc=mk(H, 1), audio_enc=mk(H, 1), image_enc=mk(H, 1),
+                                             mod_t_a=mk(8 * H, 2), mod_t_i=mk(8 * H, 2)))
+        for name, rnn in self.rnns.items():
+            rnn.load_state_dict({k[len(name) + 5:]: v.detach().cpu() for k, v in state_dict.items()
+                                 if k.startswith(name + ".rnn.")})
+        self.att = torch.nn.ParameterDict()
+        for a in ("bidaf_att_audio", "bidaf_att_image"):
+            for p in ("text_weight", "modality_weight", "text_modality_weight", "bias"):
+                self.att[a + "__" + p] = torch.nn.Parameter(state_dict[a + "." + p].detach().cpu().clone())
+
+    def _att(self, name, text, mod, tm, mm):
+        g = lambda p: self.att[name + "__" + p]
+        return bidaf_attention(text, mod, tm, mm, g("text_weight"), g("modality_weight"), g("text_modality_weight"), g("bias"))
+
+    def forward(self, x_text, x_aud, x_img, text_len, aud_len, img_len):
+        te, _ = rnn_encoder_aten(x_text, text_len, self.rnns["text_enc"])
+        ae, _ = rnn_encoder_aten(x_aud, aud_len, self.rnns["audio_enc"])
+        ie, _ = rnn_encoder_aten(x_img, img_len, self.rnns["image_enc"])
+        tm, am, im = get_mask(x_text.size(1), text_len), get_mask(x_aud.size(1), aud_len), get_mask(x_img.size(1), img_len)
+        ta = self._att("bidaf_att_audio", te, ae, tm, am)
+        ti = self._att("bidaf_att_image", te, ie, tm, im)
+        ya, ha = rnn_encoder_aten(ta, text_len, self.rnns["mod_t_a"])
+        yi, hi = rnn_encoder_aten(ti, text_len, self.rnns["mod_t_i"])
+        return ya, ha, yi, hi, (ha.sum(1) + hi.sum(1)).unsqueeze(1)
+
+    def named_grads(self):
+        """{hot-region parameter name: grad} for comparison with the HIP modules."""
+        out = {}
+        for name, rnn in self.rnns.items():
+            for k, p in rnn.named_parameters():
+                out[f"{name}.rnn.{k}"] = p.grad
+        for k, p in self.att.items():
+            out[k.replace("__", ".")] = p.grad
+        return out

@@ -1,0 +1,327 @@
+"""Parity of the HIP hot path (through the C ABI) against the golden fixtures and the oracle.
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+
+Tolerance (north_star): max-abs <= 1e-4 in fp32, scaled by max|ref| when that exceeds 1 (sums over
+B*T terms such as weight gradients grow with the problem size)."""
+import os
+
+import pytest
+import torch
+
+from conftest import load_cases, load_flat, maxdiff, scaled_tol
+from oracle import mmbidaf_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def close(got, ref, name="", tol=TOL):
+    got = got.detach().float().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{name}: non-finite values"
+    err = maxdiff(got, ref.detach())
+    assert err <= scaled_tol(ref.detach(), tol), f"{name}: max err {err:.3e} > {scaled_tol(ref.detach(), tol):.3e}"
+
+
+def test_native_library_is_the_one_loaded():
+    from mmbidaf_amd import _lib
+    _lib.load()
+    maps = open("/proc/self/maps").read()
+    assert "libmmbidaf_hip.so" in maps
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(37, 29, 19), (300, 400, 100), (1000, 100, 800), (800, 200, 1300), (64, 5, 7)])
+@pytest.mark.parametrize("ta", [False, True])
+@pytest.mark.parametrize("tb", [False, True])
+def test_gemm(M, N, K, ta, tb):
+    from mmbidaf_amd import functional as MF
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (a.t() if ta else a).double() @ (b.t() if tb else b).double() + bias.double()
+    got = MF.gemm(a.to(dev()), b.to(dev()), bias.to(dev()), ta=ta, tb=tb)
+    close(got, ref.float(), "gemm", tol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _run_att(c, drop=None):
+    from mmbidaf_amd import functional as MF
+    d = dev()
+    text = c["text"].to(d).requires_grad_(True)
+    mod = c["mod"].to(d).requires_grad_(True)
+    ps = [c[k].to(d).requires_grad_(True) for k in ("w_t", "w_m", "w_tm", "bias")]
+    kw = dict(text_d=text * drop[0].to(d), mod_d=mod * drop[1].to(d)) if drop is not None else {}
+    out = MF.bidaf_attention(text, mod, c["text_mask"].to(d), c["mod_mask"].to(d), *ps, **kw)
+    (out * c["cot"].to(d)).sum().backward()
+    return out, text.grad, mod.grad, [p.grad for p in ps]
+
+
+ATT_CASES = ["small_full", "ragged", "nonprefix", "m1", "t1", "cfg1_audio", "cfg1_image"]
+
+
+@pytest.mark.parametrize("case", ATT_CASES)
+def test_attention_golden(case):
+    c = load_cases("g3_bidaf_attention.npz")[case]
+    out, dt, dm, dps = _run_att(c)
+    close(out, c["out"], "out")
+    close(dt, c["d_text"], "d_text")
+    close(dm, c["d_mod"], "d_mod")
+    for k, g in zip(("d_w_t", "d_w_m", "d_w_tm"), dps):
+        close(g, c[k], k)
+    assert abs(dps[3].item()) < 1e-3          # Q5: d_bias is analytically zero
+    assert dps[3].shape == c["d_bias"].shape
+
+
+def _random_att_case(seed, B, T, M, D, use_drop, full=False):
+    g = torch.Generator().manual_seed(seed)
+    text, mod = torch.randn(B, T, D, generator=g), torch.randn(B, M, D, generator=g)
+    tl = [T] * B if full else torch.randint(1, T + 1, (B,), generator=g).tolist()
+    ml = [M] * B if full else torch.randint(1, M + 1, (B,), generator=g).tolist()
+    tl[0], ml[0] = T, M
+    c = dict(text=text, mod=mod, text_mask=O.get_mask(T, tl), mod_mask=O.get_mask(M, ml),
+             cot=torch.randn(B, T, 4 * D, generator=g),
+             w_t=torch.randn(D, 1, generator=g) * 0.1, w_m=torch.randn(D, 1, generator=g) * 0.1,
+             w_tm=torch.randn(1, 1, D, generator=g) * 0.1, bias=torch.randn(1, generator=g))
+    drop = None
+    if use_drop:
+        drop = ((torch.rand(B, T, D, generator=g) > 0.2).float() / 0.8, (torch.rand(B, M, D, generator=g) > 0.2).float() / 0.8)
+    return c, drop
+
+
+@pytest.mark.parametrize("B,T,M,D,use_drop", [(2, 50, 32, 200, True), (3, 70, 9, 200, False), (4, 400, 256, 200, False),
+                                              (4, 400, 64, 200, True), (2, 33, 65, 64, False), (1, 1, 1, 4, False),
+                                              (2, 130, 257, 208, True)])
+def test_attention_vs_oracle(B, T, M, D, use_drop):
+    c, drop = _random_att_case(B * 1000 + T + M, B, T, M, D, use_drop)
+    t_ = c["text"].clone().requires_grad_(True)
+    m_ = c["mod"].clone().requires_grad_(True)
+    ps = [c[k].clone().requires_grad_(True) for k in ("w_t", "w_m", "w_tm", "bias")]
+    kw = dict(text_d=t_ * drop[0], mod_d=m_ * drop[1]) if use_drop else {}
+    ref = O.bidaf_attention(t_, m_, c["text_mask"], c["mod_mask"], *ps, **kw)
+    (ref * c["cot"]).sum().backward()
+    out, dt, dm, dps = _run_att(c, drop)
+    close(out, ref, "out")
+    close(dt, t_.grad, "d_text")
+    close(dm, m_.grad, "d_mod")
+    for k, g, p in zip(("d_w_t", "d_w_m", "d_w_tm"), dps, ps):
+        close(g, p.grad, k)
+
+
+def test_attention_full_size_properties():
+    """cfg2 size (B=32, T=400, M=256, D=200): size-independent properties instead of the oracle."""
+    B, T, M, D = 32, 400, 256, 200
+    c, _ = _random_att_case(11, B, T, M, D, False)
+    out, dt, dm, dps = _run_att(c)
+    out = out.cpu()
+    text = c["text"]
+    assert torch.equal(out[:, :, :D], text)                                  # first quarter is a verbatim copy
+    a = out[:, :, D:2 * D]
+    close(out[:, :, 2 * D:3 * D], text * a, "text*a", tol=1e-6)
+    # a is a convex combination of the unmasked modality rows: inside their per-feature range
+    for b in (0, 5, 31):
+        n = int(c["mod_mask"][b].sum())
+        lo, hi = c["mod"][b, :n].min(0).values, c["mod"][b, :n].max(0).values
+        assert (a[b] >= lo - 1e-4).all() and (a[b] <= hi + 1e-4).all()
+    # linearity of the backward pass in the cotangent: grad(2*cot) == 2*grad(cot)
+    c2 = dict(c, cot=2 * c["cot"])
+    _, dt2, dm2, _ = _run_att(c2)
+    close(dt2, 2 * dt.cpu(), "linearity d_text", tol=2e-5)
+    close(dm2, 2 * dm.cpu(), "linearity d_mod", tol=2e-5)
+    # and the oracle on a slice of the batch (independent per sample)
+    sl = slice(28, 32)
+    cs = {k: (v[sl] if v.dim() >= 2 and v.shape[0] == B else v) for k, v in c.items()}
+    ref = O.bidaf_attention(cs["text"], cs["mod"], cs["text_mask"], cs["mod_mask"], c["w_t"], c["w_m"], c["w_tm"], c["bias"])
+    close(out[sl], ref, "out slice")
+
+
+def test_attention_rejects_bad_width():
+    from mmbidaf_amd import functional as MF
+    d = dev()
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        MF.bidaf_attention(torch.randn(1, 2, 6, device=d), torch.randn(1, 2, 6, device=d), torch.ones(1, 2, device=d),
+                           torch.ones(1, 2, device=d), torch.randn(6, 1, device=d), torch.randn(6, 1, device=d),
+                           torch.randn(1, 1, 6, device=d), torch.zeros(1, device=d))
+
+
+# ------------------------------------------------------------------------------------------- LSTM
+RNN_CASES = {"l1_ragged": 1, "l1_ties": 1, "l2_i8h": 2, "l1_full": 1, "l1_h100": 1, "l2_h25": 2}
+
+
+@pytest.mark.parametrize("case", list(RNN_CASES))
+def test_rnn_encoder_golden(case):
+    from layers.encoding import RNNEncoder
+    c = load_cases("g4_rnn_encoder.npz")[case]
+    L = RNN_CASES[case]
+    I, H = c["x"].shape[2], c["param__rnn.weight_hh_l0"].shape[1]
+    enc = RNNEncoder(I, H, L).to(dev())
+    enc.load_state_dict({k[len("param__"):]: v for k, v in c.items() if k.startswith("param__")})
+    x = c["x"].to(dev()).requires_grad_(True)
+    y, hn = enc(x, c["lengths"].tolist())
+    ((y * c["cot_y"].to(dev())).sum() + (hn * c["cot_h"].to(dev())).sum()).backward()
+    close(y, c["y"], "y")
+    close(hn, c["h_n"], "h_n (length-sorted, Q3)")
+    close(x.grad, c["d_x"], "d_x")
+    for n, p in enc.named_parameters():
+        close(p.grad, c["grad__" + n], "grad " + n)
+
+
+def _oracle_encoder(e, x, lengths, cy, ch):
+    P = {k[4:]: v.detach().cpu().clone().requires_grad_(True) for k, v in e.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    yr, hr = O.rnn_encoder(xr, lengths, P, e.rnn.num_layers)
+    ((yr * cy).sum() + (hr * ch).sum()).backward()
+    return yr, hr, xr.grad, P
+
+
+def test_rnn_encoders_grouped_vs_oracle():
+    """text/audio/image encoder shapes of cfg2 (H=100), ragged, co-scheduled in one grouped launch."""
+    from mmbidaf_amd.encoding import RNNEncoder, encode_group
+    g = torch.Generator().manual_seed(9)
+    encs, xs, lens = [], [], []
+    for T in (400, 256, 64):
+        torch.manual_seed(100 + T)
+        encs.append(RNNEncoder(100, 100, 1).to(dev()))
+        xs.append(torch.randn(4, T, 100, generator=g))
+        l = torch.randint(T // 2, T + 1, (4,), generator=g).tolist()
+        l[1], l[2] = T, 1
+        lens.append(l)
+    xg = [x.to(dev()).requires_grad_(True) for x in xs]
+    outs = encode_group(encs, xg, lens)
+    cots = [(torch.randn(*o[0].shape, generator=g), torch.randn(*o[1].shape, generator=g)) for o in outs]
+    sum((y * cy.to(dev())).sum() + (h * ch.to(dev())).sum() for (y, h), (cy, ch) in zip(outs, cots)).backward()
+    for e, x, l, (y, h), (cy, ch), xgi in zip(encs, xs, lens, outs, cots, xg):
+        yr, hr, dxr, P = _oracle_encoder(e, x, l, cy, ch)
+        close(y, yr, "y")
+        close(h, hr, "h_n")
+        close(xgi.grad, dxr, "d_x")
+        for n, p in e.named_parameters():
+            close(p.grad, P[n[4:]].grad, "grad " + n)
+        # padded outputs are exactly zero (pad_packed_sequence)
+        for b, lb in enumerate(l):
+            assert (y[b, lb:] == 0).all()
+
+
+def test_modelling_encoder_vs_oracle():
+    from layers.encoding import RNNEncoder
+    g = torch.Generator().manual_seed(21)
+    torch.manual_seed(7)
+    e = RNNEncoder(800, 100, 2).to(dev())
+    x = torch.randn(3, 120, 800, generator=g) * 0.3
+    l = [120, 77, 100]
+    xd = x.to(dev()).requires_grad_(True)
+    y, h = e(xd, l)
+    cy, ch = torch.randn(*y.shape, generator=g), torch.randn(*h.shape, generator=g)
+    ((y * cy.to(dev())).sum() + (h * ch.to(dev())).sum()).backward()
+    yr, hr, dxr, P = _oracle_encoder(e, x, l, cy, ch)
+    close(y, yr, "y")
+    close(h, hr, "h_n")
+    close(xd.grad, dxr, "d_x")
+    for n, p in e.named_parameters():
+        close(p.grad, P[n[4:]].grad, "grad " + n)
+
+
+def test_lstm_time_reversal_property_full_size():
+    """Full cfg2 size (B=32, T=400): with full lengths, the reverse direction of an encoder equals the
+    forward direction of the same weights on the time-reversed input (size-independent check)."""
+    from layers.encoding import RNNEncoder
+    torch.manual_seed(3)
+    e = RNNEncoder(100, 100, 1).to(dev())
+    with torch.no_grad():
+        for n in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+            getattr(e.rnn, n + "_reverse").copy_(getattr(e.rnn, n))
+    x = torch.randn(32, 400, 100, device=dev())
+    y, _ = e(x, [400] * 32)
+    y2, _ = e(x.flip(1), [400] * 32)
+    assert maxdiff(y[:, :, 100:].cpu(), y2[:, :, :100].flip(1).cpu()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- model
+class _Stub(torch.nn.Module):
+    def __init__(self, w, b):
+        super().__init__()
+        self.fc = torch.nn.Linear(3, w.shape[0])
+        with torch.no_grad():
+            self.fc.weight.copy_(w)
+            self.fc.bias.copy_(b)
+
+    def forward(self, images):
+        return self.fc(images.mean(dim=(2, 3)))
+
+
+def test_whole_model_golden():
+    """models.MMBiDAF end to end against the reference run (G5): captured hot-path outputs, the output
+    distributions, the loss and every parameter gradient, train and eval mode."""
+    from models import MMBiDAF
+    g = load_flat("g5_hot_region.npz")
+    d = dev()
+    model = MMBiDAF(16, 24, 12, 20, d, drop_prob=0.0, max_transcript_length=60, image_backbone=_Stub(g["resnet_w"], g["resnet_b"]))
+    model.load_state_dict({k[len("param__"):]: v for k, v in g.items() if k.startswith("param__")}, strict=False)
+    model.to(d)
+    caps = {}
+    for n in ("text_enc", "audio_enc", "image_enc", "bidaf_att_audio", "bidaf_att_image", "mod_t_a", "mod_t_i"):
+        getattr(model, n).register_forward_hook(lambda m, i, o, n=n: caps.__setitem__(n, o))
+    tl, al, il = g["text_len"].tolist(), g["audio_len"].tolist(), g["image_len"].tolist()
+    args = (g["text"].to(d), tl, g["audio"].to(d), al, g["images"].to(d), il, g["targets"].to(d), [4] * 3, 4)
+    model.train()
+    dist, loss = model(*args)
+    close(dist, g["train_dist"], "train_dist")
+    close(loss, g["train_loss"].reshape(()), "train_loss")
+    for n in ("bidaf_att_audio", "bidaf_att_image"):
+        close(caps[n], g["cap__" + n], n)
+    for n in ("mod_t_a", "mod_t_i"):
+        close(caps[n][0], g[f"cap__{n}__y"], n + " y")
+        close(caps[n][1], g[f"cap__{n}__h"], n + " h")
+    model.zero_grad()
+    loss.backward()
+    for n, p in model.named_parameters():
+        if ("grad__" + n) in g:
+            close(p.grad if p.grad is not None else torch.zeros_like(p), g["grad__" + n], "grad " + n)
+    model.eval()
+    with torch.no_grad():
+        dist_e, loss_e = model(*args)
+    close(dist_e, g["eval_dist"], "eval_dist")
+    close(loss_e, g["eval_loss"].reshape(()), "eval_loss")
+
+
+def test_hot_region_cfg1_vs_oracle_with_dropout_training_mode():
+    """cfg1 (B=3, T=50/32/8, H=100): region in training mode with drop_prob > 0 runs and is finite; with
+    drop_prob = 0 it matches the CPU baseline module (the reference's op sequence) incl. all gradients."""
+    from mmbidaf_amd import synth
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    torch.manual_seed(224)
+    region = HotRegion(100).to(d)
+    batch = synth.make_batch("cfg1", ragged=True)
+    gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    xs = [gpu[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+    outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+    synth.region_loss(outs, gpu).backward()
+    ref = O.HotRegionCPU(region.state_dict(), 100)
+    xr = [batch[k].clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+    routs = ref(*xr, batch["text_len"], batch["aud_len"], batch["img_len"])
+    synth.region_loss(routs, batch).backward()
+    for n, a, b in zip(("mod_a", "hid_a", "mod_i", "hid_i", "dec_hidden"), outs, routs):
+        close(a, b, n)
+    for n, a, b in zip(("d_x_text", "d_x_aud", "d_x_img"), xs, xr):
+        close(a.grad, b.grad, n)
+    rg = ref.named_grads()
+    for n, p in region.named_parameters():
+        if not n.endswith("bidaf_att_audio.bias") and not n.endswith("bidaf_att_image.bias"):
+            close(p.grad, rg[n], "grad " + n)
+    torch.manual_seed(1)
+    drop = HotRegion(100, drop_prob=0.2).to(d).train()
+    o2 = drop(*[x.detach() for x in xs], batch["text_len"], batch["aud_len"], batch["img_len"])
+    synth.region_loss(o2, gpu).backward()
+    assert all(torch.isfinite(t).all() for t in o2)
+    assert all(torch.isfinite(p.grad).all() for p in drop.parameters())

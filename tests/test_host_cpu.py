@@ -1,0 +1,185 @@
+"""CPU-side tests of the product: C-ABI surface, host logic (sorting, masks, state-dict layout,
+surrounding graph), loud failure without a GPU, and the N>1 gradient exchange over gloo."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, load_flat, maxdiff
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    from mmbidaf_amd import _lib
+    import ctypes
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    header = open(os.path.join(ROOT, "include", "mmbidaf.h")).read()
+    declared = set(re.findall(r"\b(mmb_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 11
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/mmbidaf.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes binding table out of sync with the header"
+    assert _lib.load().mmb_version() == 100
+    # struct layouts mirror the header (pointer/int counts)
+    assert ctypes.sizeof(_lib.LstmFwdDesc) == 8 * 16 + 4 * 4
+    assert ctypes.sizeof(_lib.LstmBwdDesc) == 8 * 16 + 4 * 4
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base in ("mmbidaf_amd", "layers"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith(".py") and "oracle" in open(os.path.join(dp, f)).read():
+                    bad.append(os.path.join(dp, f))
+    if "oracle" in open(os.path.join(ROOT, "models.py")).read():
+        bad.append("models.py")
+    assert not bad, f"product files mention the oracle: {bad}"
+
+
+def test_hot_path_fails_loudly_on_cpu():
+    from layers.encoding import RNNEncoder
+    from layers.attention import BiDAFAttention
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        RNNEncoder(4, 4, 1)(torch.randn(2, 3, 4), [3, 2])
+    att = BiDAFAttention(8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        att(torch.randn(1, 3, 8), torch.randn(1, 2, 8), torch.ones(1, 3, dtype=torch.bool), torch.ones(1, 2, dtype=torch.bool))
+
+
+def test_sorted_order_matches_reference_tie_order():
+    from mmbidaf_amd.encoding import sorted_order
+    assert sorted_order([5, 7, 5, 7, 5]).tolist() == [1, 3, 0, 2, 4]
+    assert sorted_order([9, 1, 5, 7, 3]).tolist() == [0, 3, 2, 4, 1]
+
+
+def test_masked_softmax_golden():
+    from layers.attention import masked_softmax
+    g = load_flat("g1_masked_softmax.npz")
+    assert maxdiff(masked_softmax(g["x"], g["mask_dim2"], dim=2), g["y_dim2"]) < 2e-6
+    assert maxdiff(masked_softmax(g["x"], g["mask_dim1"], dim=1), g["y_dim1"]) < 2e-6
+    assert maxdiff(masked_softmax(g["x2"], g["mask_last"]), g["y_last"]) < 2e-6
+
+
+def _golden_model(g):
+    from models import MMBiDAF
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = torch.nn.Linear(3, 20)
+
+        def forward(self, images):
+            return self.fc(images.mean(dim=(2, 3)))
+
+    bb = Stub()
+    with torch.no_grad():
+        bb.fc.weight.copy_(g["resnet_w"])
+        bb.fc.bias.copy_(g["resnet_b"])
+    m = MMBiDAF(16, 24, 12, 20, torch.device("cpu"), drop_prob=0.0, max_transcript_length=60, image_backbone=bb)
+    sd = {k[len("param__"):]: v for k, v in g.items() if k.startswith("param__")}
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    assert all(k.startswith("image_keyframes_emb") for k in res.missing_keys)
+    return m
+
+
+def test_state_dict_keys_match_reference(golden_hot):
+    ref = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    m = _golden_model(golden_hot)
+    mine = [[k, list(v.shape)] for k, v in m.state_dict().items() if not k.startswith("image_keyframes_emb")]
+    assert mine == ref
+
+
+def test_surrounding_graph_matches_reference(golden_hot):
+    """Embedding/highway before and the decoder loop after the hot path (stock torch, CPU-runnable),
+    fed with the reference's captured hot-path outputs."""
+    g = golden_hot
+    m = _golden_model(g)
+    m.eval()
+    assert maxdiff(m.emb(g["text"]), g["cap__text_enc__x"]) < 1e-5
+    assert maxdiff(m.a_emb(g["audio"]), g["cap__audio_enc__x"]) < 1e-5
+    frames = g["images"].reshape(-1, *g["images"].shape[2:])
+    img = m.i_emb(m.image_keyframes_emb(frames).reshape(3, 8, -1))
+    assert maxdiff(img, g["cap__image_enc__x"]) < 1e-5
+    tmask = m.get_mask(g["text"], g["text_len"].tolist())
+    caps = (g["cap__mod_t_a__y"], g["cap__mod_t_a__h"], g["cap__mod_t_i__y"], g["cap__mod_t_i__h"])
+    m.train()
+    dist, loss = m.decode(g["text"], 50, *caps, tmask, g["targets"], 4)
+    assert maxdiff(dist, g["train_dist"]) < 1e-5
+    assert abs(loss.item() - g["train_loss"].item()) < 1e-4
+    m.eval()
+    with torch.no_grad():
+        dist, loss = m.decode(g["text"], 50, *caps, tmask, g["targets"], 4)
+    assert maxdiff(dist, g["eval_dist"]) < 1e-5
+    assert abs(loss.item() - g["eval_loss"].item()) < 1e-4
+
+
+def test_similarity_matrix_api(golden_attention):
+    from layers.attention import BiDAFAttention
+    c = golden_attention["ragged"]
+    att = BiDAFAttention(8, drop_prob=0.0).eval()
+    with torch.no_grad():
+        att.text_weight.copy_(c["w_t"]); att.modality_weight.copy_(c["w_m"])
+        att.text_modality_weight.copy_(c["w_tm"]); att.bias.copy_(c["bias"])
+    assert maxdiff(att.get_similarity_matrix(c["text"], c["mod"]), c["sim"]) < 1e-5
+
+
+def test_synthetic_workload_is_deterministic_and_sharded():
+    from mmbidaf_amd import ddp, synth
+    a = synth.make_batch("cfg1", rank=1, ragged=True)
+    b = synth.make_batch("cfg1", rank=1, ragged=True)
+    assert torch.equal(a["x_text"], b["x_text"]) and a["text_len"] == b["text_len"]
+    assert a["text_len"][0] == 50 and min(a["text_len"]) >= 25
+    c = synth.make_batch("cfg1", rank=2)
+    assert not torch.equal(a["x_text"], c["x_text"]) and c["aud_len"] == [32] * 3
+    assert [ddp.shard_range(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]
+    with pytest.raises(ValueError):
+        ddp.shard_range(10, 0, 4)
+    assert synth.attention_algorithmic_bytes(32, 400, 256, 200) == 57_753_600           # 57.75 MB
+    assert synth.attention_algorithmic_bytes(32, 400, 256, 200, backward=True) == 74_547_200
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from mmbidaf_amd import ddp
+rank, world, _ = ddp.init_from_env("gloo")
+torch.manual_seed(100 + rank)                      # different replicas on purpose
+model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
+sync = ddp.FlatGradAllReduce(model.parameters())
+sync.broadcast_parameters(0)
+p0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+gathered = [torch.zeros_like(p0) for _ in range(world)]
+dist.all_gather(gathered, p0)
+assert all(torch.equal(g, gathered[0]) for g in gathered), "broadcast_parameters did not equalise replicas"
+lo, hi = ddp.shard_range(8, rank, world)
+torch.manual_seed(7)
+x, y = torch.randn(8, 5), torch.randn(8, 3)
+((model(x[lo:hi]) - y[lo:hi]) ** 2).sum().backward()
+sync()
+mine = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+# single-process reference: whole batch, then divide by world (sum of shard losses / world)
+ref = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
+ref.load_state_dict(model.state_dict())
+((ref(x) - y) ** 2).sum().backward()
+want = torch.cat([p.grad.reshape(-1) for p in ref.parameters()]) / world
+assert torch.allclose(mine, want, atol=1e-5), (mine - want).abs().max()
+dist.barrier()
+print("rank", rank, "ok")
+'''
+
+
+def test_flat_grad_allreduce_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o
