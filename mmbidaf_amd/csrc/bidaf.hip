@@ -545,51 +545,57 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
     if (kg == 0) a.p_dc2[prow] = dc;
 }
 
-// j-side epilogue: one wave per JF_ROWS modality rows.  Sums the split partials, writes
+// j-side epilogue: one wave per JF_ROWS modality rows, lane = 4 features.  Sums the split partials, writes
 //   d_mod_d_j = dc_j w_m + w_tm * dmodd_j ;  d_mod_j = dmodc_j (+ d_mod_d_j when folded)
-// and accumulates d_w_m += sum_j dc_j mod_d[j,:] (registers over the wave's rows, then one atomic per lane).
-constexpr int JF_ROWS = 16;
+// and accumulates d_w_m += sum_j dc_j mod_d[j,:] (registers, then LDS across the 4 waves, then one atomic per feature).
+constexpr int JF_ROWS = 2;
 __global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a, int B) {
-    const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    __shared__ f4 wred[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x * 4 + wave;
     const int M = a.M, D = a.D, S = a.splits;
     const int rows = B * M;
-    if (chunk * JF_ROWS >= rows) return;
     const int d = lane * 4;
     f4 wacc = f4{0.f, 0.f, 0.f, 0.f};
     const bool din = d < D;
     const f4 wm = din ? *reinterpret_cast<const f4*>(a.w_m + d) : f4{0.f, 0.f, 0.f, 0.f};
     const f4 wtm = din ? *reinterpret_cast<const f4*>(a.w_tm + d) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
     for (int rr = 0; rr < JF_ROWS; ++rr) {
         const int row = chunk * JF_ROWS + rr;
-        if (row >= rows) break;
-        const int b = row / M, n = row % M;
-        float dc = 0.f;
-        f4 c = f4{0.f, 0.f, 0.f, 0.f}, dd = c;
-        for (int p = 0; p < S; ++p) {
-            const size_t prow = ((size_t)b * S + p) * M + n;
-            dc += a.p_dc1[prow] + a.p_dc2[prow];
+        if (row < rows) {
+            const int b = row / M, n = row % M;
+            float dc = 0.f;
+            f4 c = f4{0.f, 0.f, 0.f, 0.f}, dd = c;
+            for (int p = 0; p < S; ++p) {
+                const size_t prow = ((size_t)b * S + p) * M + n;
+                dc += a.p_dc1[prow] + a.p_dc2[prow];
+                if (din) {
+                    c += *reinterpret_cast<const f4*>(a.p_dmc + prow * D + d);
+                    dd += *reinterpret_cast<const f4*>(a.p_dmd1 + prow * D + d);
+                    dd += *reinterpret_cast<const f4*>(a.p_dmd2 + prow * D + d);
+                }
+            }
             if (din) {
-                c += *reinterpret_cast<const f4*>(a.p_dmc + prow * D + d);
-                dd += *reinterpret_cast<const f4*>(a.p_dmd1 + prow * D + d);
-                dd += *reinterpret_cast<const f4*>(a.p_dmd2 + prow * D + d);
+                const f4 gd = wm * dc + wtm * dd;
+                if (a.fold) {
+                    *reinterpret_cast<f4*>(a.d_mod + (size_t)row * D + d) = c + gd;
+                } else {
+                    *reinterpret_cast<f4*>(a.d_mod + (size_t)row * D + d) = c;
+                    *reinterpret_cast<f4*>(a.d_mod_d + (size_t)row * D + d) = gd;
+                }
+                wacc += *reinterpret_cast<const f4*>(a.mod_d + (size_t)row * D + d) * dc;
             }
-        }
-        if (din) {
-            const f4 gd = wm * dc + wtm * dd;
-            if (a.fold) {
-                *reinterpret_cast<f4*>(a.d_mod + (size_t)row * D + d) = c + gd;
-            } else {
-                *reinterpret_cast<f4*>(a.d_mod + (size_t)row * D + d) = c;
-                *reinterpret_cast<f4*>(a.d_mod_d + (size_t)row * D + d) = gd;
-            }
-            wacc += *reinterpret_cast<const f4*>(a.mod_d + (size_t)row * D + d) * dc;
         }
     }
-    if (din) {
-        atomicAdd(a.d_w_m + d + 0, wacc.x);
-        atomicAdd(a.d_w_m + d + 1, wacc.y);
-        atomicAdd(a.d_w_m + d + 2, wacc.z);
-        atomicAdd(a.d_w_m + d + 3, wacc.w);
+    wred[wave][lane] = wacc;
+    __syncthreads();
+    if (wave == 0 && din) {
+        const f4 t = wred[0][lane] + wred[1][lane] + wred[2][lane] + wred[3][lane];
+        atomicAdd(a.d_w_m + d + 0, t.x);
+        atomicAdd(a.d_w_m + d + 1, t.y);
+        atomicAdd(a.d_w_m + d + 2, t.z);
+        atomicAdd(a.d_w_m + d + 3, t.w);
     }
 }
 

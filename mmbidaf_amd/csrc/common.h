@@ -67,7 +67,7 @@ struct GemmArgs {
     int M, N, K, lda, ldb, ldc;
     int ta, tb;          // see mmb_gemm_f32
     int accumulate;      // C += (atomic when split-K)
-    int gate_H;          // > 0: column n=(g*H+u) of each 4H block is stored at (u*4+g)
+    int gate_H;          // > 0 (tb == 1 only): output column u*4+g of each 4H block comes from B row / bias entry g*H+u
     int shiftB, periodB; // tb == 0 only: B row k is read from row k+shiftB, zero when (k % period)+shift leaves [0,period)
 };
 // enqueue; C must be pre-zeroed by the caller when the launcher picks split-K (it tells via *needs_zero)

@@ -10,14 +10,25 @@
 // in): a K-contiguous tile is stored [rows][BK+1] (conflict-free ds_read_b32 down a column), an
 // M/N-contiguous tile is stored [BK][cols] with cols % 32 == 16 so that the two 16-lane halves of a
 // 32-lane bank group land on disjoint banks.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mmb {
 
-constexpr int BK = 16;
+constexpr int BK = 20;  // every K of this model (100, 200, 400, 800, B*T) is a multiple of 20: no K-tail waste
 
 __host__ __device__ constexpr int pad16mod32(int c) { return (c % 32 == 16) ? c : c + ((16 - c % 32) + 32) % 32; }
 
+// source row of B for output column n when the columns are gate-interleaved (n = u*4+g inside each
+// 4H block is produced from weight row g*H+u): the permutation costs nothing on the way in (whole rows).
+__device__ __forceinline__ int gate_src_row(int n, int H) {
+    const int blk = n / (4 * H), rem = n % (4 * H);
+    return blk * 4 * H + (rem & 3) * H + (rem >> 2);
+}
+
+// Software-pipelined main loop: the global loads of K-tile t+1 are issued into registers before the MFMAs
+// of tile t and written to the other LDS buffer after them; one barrier per tile.
 template <int WAVES, int MT, int NT, bool TA, bool TB>
 __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(const GemmArgs g, const int kchunk) {
     constexpr int BM = WAVES * MT * 16;
@@ -25,10 +36,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(const GemmArgs g, cons
     constexpr int NTHR = WAVES * 64;
     constexpr int BMP = pad16mod32(BM);
     constexpr int BNP = pad16mod32(BN);
-    constexpr int A_ELEMS = TA ? BK * BMP : BM * (BK + 1);
-    constexpr int B_ELEMS = TB ? BN * (BK + 1) : BK * BNP;
-    __shared__ __attribute__((aligned(16))) float As[A_ELEMS];
-    __shared__ __attribute__((aligned(16))) float Bs[B_ELEMS];
+    constexpr int KP = BK + 1;
+    constexpr int A_ELEMS = TA ? BK * BMP : BM * KP;
+    constexpr int B_ELEMS = TB ? BN * KP : BK * BNP;
+    constexpr int A_CH = BM * BK / 4, B_CH = BN * BK / 4;  // float4 chunks per tile
+    constexpr int A_V = (A_CH + NTHR - 1) / NTHR, B_V = (B_CH + NTHR - 1) / NTHR;
+    __shared__ __attribute__((aligned(16))) float As[2][A_ELEMS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][B_ELEMS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -40,100 +54,116 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(const GemmArgs g, cons
     const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
     const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
 
+    f4 ra[A_V], rb[B_V];
+
+    auto load4 = [](const float* src, bool vec, int valid) -> f4 {  // valid = number of in-range elements (<= 4)
+        f4 t = f4{0.f, 0.f, 0.f, 0.f};
+        if (valid >= 4 && vec) {
+            t = *reinterpret_cast<const f4*>(src);
+        } else {
+            if (valid > 0) t.x = src[0];
+            if (valid > 1) t.y = src[1];
+            if (valid > 2) t.z = src[2];
+            if (valid > 3) t.w = src[3];
+        }
+        return t;
+    };
+
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_V; ++i) {
+            const int c = tid + i * NTHR;
+            f4 t = f4{0.f, 0.f, 0.f, 0.f};
+            if (c < A_CH) {
+                if (!TA) {  // (M,K): row m, 4 consecutive k
+                    const int m = c / (BK / 4), k4 = (c % (BK / 4)) * 4;
+                    const int gm = m0 + m, gk = k0 + k4;
+                    if (gm < g.M && gk < ke) t = load4(g.A + (size_t)gm * g.lda + gk, a_vec, min(4, ke - gk));
+                } else {  // (K,M): row k, 4 consecutive m
+                    const int k = c / (BM / 4), m4 = (c % (BM / 4)) * 4;
+                    const int gk = k0 + k, gm = m0 + m4;
+                    if (gk < ke && gm < g.M) t = load4(g.A + (size_t)gk * g.lda + gm, a_vec, min(4, g.M - gm));
+                }
+            }
+            ra[i] = t;
+        }
+#pragma unroll
+        for (int i = 0; i < B_V; ++i) {
+            const int c = tid + i * NTHR;
+            f4 t = f4{0.f, 0.f, 0.f, 0.f};
+            if (c < B_CH) {
+                if (TB) {  // (N,K)
+                    const int n = c / (BK / 4), k4 = (c % (BK / 4)) * 4;
+                    const int gn = n0 + n, gk = k0 + k4;
+                    if (gn < g.N && gk < ke) {
+                        const int srow = g.gate_H > 0 ? gate_src_row(gn, g.gate_H) : gn;
+                        t = load4(g.B + (size_t)srow * g.ldb + gk, b_vec, min(4, ke - gk));
+                    }
+                } else {  // (K,N), optional row shift inside periods of periodB rows
+                    const int k = c / (BN / 4), n4 = (c % (BN / 4)) * 4;
+                    int gk = k0 + k;
+                    const int gn = n0 + n4;
+                    bool ok = gk < ke && gn < g.N;
+                    if (g.shiftB != 0) {
+                        const int tt = gk % g.periodB + g.shiftB;
+                        ok = ok && tt >= 0 && tt < g.periodB;
+                        gk += g.shiftB;
+                    }
+                    if (ok) t = load4(g.B + (size_t)gk * g.ldb + gn, b_vec, min(4, g.N - gn));
+                }
+            }
+            rb[i] = t;
+        }
+    };
+
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_V; ++i) {
+            const int c = tid + i * NTHR;
+            if (c < A_CH) {
+                if (!TA) {
+                    const int m = c / (BK / 4), k4 = (c % (BK / 4)) * 4;
+                    float* d = &As[buf][m * KP + k4];
+                    d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+                } else {
+                    const int k = c / (BM / 4), m4 = (c % (BM / 4)) * 4;
+                    *reinterpret_cast<f4*>(&As[buf][k * BMP + m4]) = ra[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_V; ++i) {
+            const int c = tid + i * NTHR;
+            if (c < B_CH) {
+                if (TB) {
+                    const int n = c / (BK / 4), k4 = (c % (BK / 4)) * 4;
+                    float* d = &Bs[buf][n * KP + k4];
+                    d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w;
+                } else {
+                    const int k = c / (BN / 4), n4 = (c % (BN / 4)) * 4;
+                    *reinterpret_cast<f4*>(&Bs[buf][k * BNP + n4]) = rb[i];
+                }
+            }
+        }
+    };
+
     f4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
+    int buf = 0;
+    if (kb < ke) {
+        gload(kb);
+        lstore(0);
+    }
+    __syncthreads();
     for (int k0 = kb; k0 < ke; k0 += BK) {
-        // ---- stage A
-        if (!TA) {  // (M,K) row-major: tile rows = m, 16 k's contiguous
-            for (int c = tid; c < BM * 4; c += NTHR) {
-                const int m = c >> 2, k4 = (c & 3) * 4;
-                const int gm = m0 + m, gk = k0 + k4;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (gm < g.M) {
-                    const float* src = g.A + (size_t)gm * g.lda + gk;
-                    if (a_vec && gk + 3 < ke) {
-                        const f4 t = *reinterpret_cast<const f4*>(src);
-                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (gk + e < ke) v[e] = src[e];
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) As[m * (BK + 1) + k4 + e] = v[e];
-            }
-        } else {  // (K,M) row-major: tile rows = k, m contiguous
-            for (int c = tid; c < BK * (BM / 4); c += NTHR) {
-                const int k = c / (BM / 4), m4 = (c % (BM / 4)) * 4;
-                const int gk = k0 + k, gm = m0 + m4;
-                f4 t = f4{0.f, 0.f, 0.f, 0.f};
-                if (gk < ke) {
-                    const float* src = g.A + (size_t)gk * g.lda + gm;
-                    if (a_vec && gm + 3 < g.M) {
-                        t = *reinterpret_cast<const f4*>(src);
-                    } else {
-                        if (gm + 0 < g.M) t.x = src[0];
-                        if (gm + 1 < g.M) t.y = src[1];
-                        if (gm + 2 < g.M) t.z = src[2];
-                        if (gm + 3 < g.M) t.w = src[3];
-                    }
-                }
-                *reinterpret_cast<f4*>(&As[k * BMP + m4]) = t;
-            }
-        }
-        // ---- stage B
-        if (TB) {  // (N,K) row-major
-            for (int c = tid; c < BN * 4; c += NTHR) {
-                const int n = c >> 2, k4 = (c & 3) * 4;
-                const int gn = n0 + n, gk = k0 + k4;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (gn < g.N) {
-                    const float* src = g.B + (size_t)gn * g.ldb + gk;
-                    if (b_vec && gk + 3 < ke) {
-                        const f4 t = *reinterpret_cast<const f4*>(src);
-                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (gk + e < ke) v[e] = src[e];
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[n * (BK + 1) + k4 + e] = v[e];
-            }
-        } else {  // (K,N) row-major, optional row shift inside periods of periodB rows
-            for (int c = tid; c < BK * (BN / 4); c += NTHR) {
-                const int k = c / (BN / 4), n4 = (c % (BN / 4)) * 4;
-                int gk = k0 + k;
-                const int gn = n0 + n4;
-                bool ok = gk < ke;
-                if (g.shiftB != 0) {
-                    const int t = gk % g.periodB + g.shiftB;
-                    ok = ok && t >= 0 && t < g.periodB;
-                    gk += g.shiftB;
-                }
-                f4 t = f4{0.f, 0.f, 0.f, 0.f};
-                if (ok) {
-                    const float* src = g.B + (size_t)gk * g.ldb + gn;
-                    if (b_vec && gn + 3 < g.N) {
-                        t = *reinterpret_cast<const f4*>(src);
-                    } else {
-                        if (gn + 0 < g.N) t.x = src[0];
-                        if (gn + 1 < g.N) t.y = src[1];
-                        if (gn + 2 < g.N) t.z = src[2];
-                        if (gn + 3 < g.N) t.w = src[3];
-                    }
-                }
-                *reinterpret_cast<f4*>(&Bs[k * BNP + n4]) = t;
-            }
-        }
-        __syncthreads();
-        // ---- MFMA over the 16-deep tile: 4 k-steps of 4
+        const bool more = k0 + BK < ke;
+        if (more) gload(k0 + BK);
+        const float* as = As[buf];
+        const float* bs = Bs[buf];
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
             const int kk = ks * 4 + kg;
@@ -141,36 +171,34 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(const GemmArgs g, cons
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int m = (wave * MT + i) * 16 + r;
-                a[i] = TA ? As[kk * BMP + m] : As[m * (BK + 1) + kk];
+                a[i] = TA ? as[kk * BMP + m] : as[m * KP + kk];
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = j * 16 + r;
-                b[j] = TB ? Bs[n * (BK + 1) + kk] : Bs[kk * BNP + n];
+                b[j] = TB ? bs[n * KP + kk] : bs[kk * BNP + n];
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
         }
+        if (more) lstore(buf ^ 1);
         __syncthreads();
+        buf ^= 1;
     }
 
-    // ---- epilogue
+    // ---- epilogue: lane (r,kg) holds C[m = 4kg+e][n = r] of each 16x16 tile
     const bool atomic = gridDim.z > 1;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + j * 16 + r;
         if (n >= g.N) continue;
         float bv = 0.f;
-        if (blockIdx.z == 0) {
-            if (g.bias) bv += g.bias[n];
-            if (g.bias2) bv += g.bias2[n];
-        }
-        int nc = n;
-        if (g.gate_H > 0) {
-            const int H = g.gate_H, blk = n / (4 * H), rem = n % (4 * H);
-            nc = blk * 4 * H + (rem % H) * 4 + rem / H;
+        if (blockIdx.z == 0 && (g.bias || g.bias2)) {
+            const int srow = g.gate_H > 0 ? gate_src_row(n, g.gate_H) : n;
+            if (g.bias) bv += g.bias[srow];
+            if (g.bias2) bv += g.bias2[srow];
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -178,7 +206,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(const GemmArgs g, cons
             for (int e = 0; e < 4; ++e) {
                 const int m = m0 + (wave * MT + i) * 16 + 4 * kg + e;
                 if (m >= g.M) continue;
-                float* dst = g.C + (size_t)m * g.ldc + nc;
+                float* dst = g.C + (size_t)m * g.ldc + n;
                 const float v = acc[i][j][e] + bv;
                 if (atomic)
                     atomicAdd(dst, v);
@@ -191,6 +219,194 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(const GemmArgs g, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path (host-checked): lda, ldb multiples of 4, 16-B aligned bases, K a multiple of BK, and the
+// contiguous dimension of an M/N-contiguous operand a multiple of 4.  Every tile load is one
+// unconditional global_load_dwordx4 through a per-thread pointer that is bumped once per K-tile; rows
+// beyond M / N are clamped onto valid rows (their results are never stored), the only data-dependent
+// zeroing is the optional row shift of B.  K-contiguous tiles sit in LDS with row stride BK (16-B aligned
+// b128 writes; the 2-way conflict of the b32 fragment reads is irrelevant next to 32-cycle MFMAs).
+template <int WAVES, int MT, int NT, bool TA, bool TB>
+__global__ __launch_bounds__(WAVES * 64) void gemm_fast_kernel(const GemmArgs g, const int kchunk) {
+    constexpr int BM = WAVES * MT * 16;
+    constexpr int BN = NT * 16;
+    constexpr int NTHR = WAVES * 64;
+    constexpr int BMP = pad16mod32(BM);
+    constexpr int BNP = pad16mod32(BN);
+    constexpr int A_ELEMS = TA ? BK * BMP : BM * BK;
+    constexpr int B_ELEMS = TB ? BN * BK : BK * BNP;
+    constexpr int A_CH = BM * BK / 4, B_CH = BN * BK / 4;
+    constexpr int A_V = (A_CH + NTHR - 1) / NTHR, B_V = (B_CH + NTHR - 1) / NTHR;
+    __shared__ __attribute__((aligned(16))) float As[2][A_ELEMS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][B_ELEMS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kb = blockIdx.z * kchunk;
+    const int ke = min(g.K, kb + kchunk);
+
+    // loop-invariant per-thread source pointers / LDS offsets of this thread's float4 chunks
+    const float* pa[A_V];
+    const float* pb[B_V];
+    int la[A_V], lb[B_V];
+    int kb_row[B_V];  // !TB with shift: the k row (before shift) this chunk reads, for the period test
+#pragma unroll
+    for (int i = 0; i < A_V; ++i) {
+        const int c = min(tid + i * NTHR, A_CH - 1);
+        if (!TA) {
+            const int m = c / (BK / 4), k4 = (c % (BK / 4)) * 4;
+            pa[i] = g.A + (size_t)min(m0 + m, g.M - 1) * g.lda + kb + k4;
+            la[i] = m * BK + k4;
+        } else {
+            const int k = c / (BM / 4), m4 = (c % (BM / 4)) * 4;
+            pa[i] = g.A + (size_t)(kb + k) * g.lda + min(m0 + m4, g.M - 4);
+            la[i] = k * BMP + m4;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_V; ++i) {
+        const int c = min(tid + i * NTHR, B_CH - 1);
+        kb_row[i] = 0;
+        if (TB) {
+            const int n = c / (BK / 4), k4 = (c % (BK / 4)) * 4;
+            const int gn = min(n0 + n, g.N - 1);
+            const int srow = g.gate_H > 0 ? gate_src_row(gn, g.gate_H) : gn;
+            pb[i] = g.B + (size_t)srow * g.ldb + kb + k4;
+            lb[i] = n * BK + k4;
+        } else {
+            const int k = c / (BN / 4), n4 = (c % (BN / 4)) * 4;
+            kb_row[i] = kb + k;
+            pb[i] = g.B + (size_t)(kb + k) * g.ldb + min(n0 + n4, g.N - 4);
+            lb[i] = k * BNP + n4;
+        }
+    }
+    const size_t a_step = TA ? (size_t)BK * g.lda : BK;
+    const size_t b_step = TB ? BK : (size_t)BK * g.ldb;
+    const bool shifted = !TB && g.shiftB != 0;
+    const float* b_lo = g.B;                                  // clamp window for shifted rows
+    const float* b_hi = g.B + (size_t)(g.K - 1) * g.ldb;
+
+    f4 ra[A_V], rb[B_V];
+    auto gload = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_V; ++i) {
+            ra[i] = *reinterpret_cast<const f4*>(pa[i]);
+            pa[i] += a_step;
+        }
+#pragma unroll
+        for (int i = 0; i < B_V; ++i) {
+            if (shifted) {
+                const int tt = kb_row[i] % g.periodB + g.shiftB;
+                const bool ok = tt >= 0 && tt < g.periodB;
+                const float* src = pb[i] + (ptrdiff_t)g.shiftB * g.ldb;
+                src = src < b_lo ? pb[i] : (src > b_hi + g.ldb ? pb[i] : src);
+                const f4 t = *reinterpret_cast<const f4*>(ok ? src : pb[i]);
+                rb[i] = ok ? t : f4{0.f, 0.f, 0.f, 0.f};
+                kb_row[i] += BK;
+            } else {
+                rb[i] = *reinterpret_cast<const f4*>(pb[i]);
+            }
+            pb[i] += b_step;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_V; ++i)
+            if (A_CH % NTHR == 0 || tid + i * NTHR < A_CH) *reinterpret_cast<f4*>(&As[buf][la[i]]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_V; ++i)
+            if (B_CH % NTHR == 0 || tid + i * NTHR < B_CH) *reinterpret_cast<f4*>(&Bs[buf][lb[i]]) = rb[i];
+    };
+
+    f4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (loop-invariant)
+    int oa[MT], ob[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = (wave * MT + i) * 16 + r;
+        oa[i] = TA ? kg * BMP + m : m * BK + kg;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = j * 16 + r;
+        ob[j] = TB ? n * BK + kg : kg * BNP + n;
+    }
+    constexpr int A_KS = TA ? 4 * BMP : 4;  // offset step per k-step of 4
+    constexpr int B_KS = TB ? 4 : 4 * BNP;
+
+    int buf = 0;
+    if (kb < ke) {
+        gload();
+        lstore(0);
+    }
+    __syncthreads();
+    for (int k0 = kb; k0 < ke; k0 += BK) {
+        const bool more = k0 + BK < ke;
+        if (more) gload();
+        const float* as = As[buf];
+        const float* bs = Bs[buf];
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            float a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = as[oa[i] + ks * A_KS];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = bs[ob[j] + ks * B_KS];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    const bool atomic = gridDim.z > 1;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 16 + r;
+        if (n >= g.N) continue;
+        float bv = 0.f;
+        if (blockIdx.z == 0 && (g.bias || g.bias2)) {
+            const int srow = g.gate_H > 0 ? gate_src_row(n, g.gate_H) : n;
+            if (g.bias) bv += g.bias[srow];
+            if (g.bias2) bv += g.bias2[srow];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + (wave * MT + i) * 16 + 4 * kg + e;
+                if (m >= g.M) continue;
+                float* dst = g.C + (size_t)m * g.ldc + n;
+                const float v = acc[i][j][e] + bv;
+                if (atomic)
+                    atomicAdd(dst, v);
+                else if (g.accumulate)
+                    *dst += v;
+                else
+                    *dst = v;
+            }
+        }
+    }
+}
+
+static bool fast_ok(const GemmArgs& g) {
+    const bool al = (reinterpret_cast<uintptr_t>(g.A) % 16 == 0) && (reinterpret_cast<uintptr_t>(g.B) % 16 == 0);
+    if (!al || g.lda % 4 || g.ldb % 4 || g.K % BK) return false;
+    if (g.ta && (g.M % 4 || g.M < 4)) return false;
+    if (!g.tb && (g.N % 4 || g.N < 4)) return false;
+    return true;
+}
+
 template <int WAVES, int MT, int NT>
 static int launch_cfg(const GemmArgs& g, int splitk, hipStream_t stream) {
     constexpr int BM = WAVES * MT * 16, BN = NT * 16;
@@ -199,14 +415,23 @@ static int launch_cfg(const GemmArgs& g, int splitk, hipStream_t stream) {
     kchunk = (kchunk + BK - 1) / BK * BK;
     dim3 block(WAVES * 64);
     ProfScope ps_(MMB_K_GEMM, stream);
+    const bool fast = fast_ok(g);
+#define MMB_GEMM_LAUNCH(TA_, TB_)                                                                                    \
+    do {                                                                                                             \
+        if (fast)                                                                                                    \
+            hipLaunchKernelGGL((gemm_fast_kernel<WAVES, MT, NT, TA_, TB_>), grid, block, 0, stream, g, kchunk);      \
+        else                                                                                                         \
+            hipLaunchKernelGGL((gemm_kernel<WAVES, MT, NT, TA_, TB_>), grid, block, 0, stream, g, kchunk);           \
+    } while (0)
     if (!g.ta && g.tb)
-        hipLaunchKernelGGL((gemm_kernel<WAVES, MT, NT, false, true>), grid, block, 0, stream, g, kchunk);
+        MMB_GEMM_LAUNCH(false, true);
     else if (!g.ta && !g.tb)
-        hipLaunchKernelGGL((gemm_kernel<WAVES, MT, NT, false, false>), grid, block, 0, stream, g, kchunk);
+        MMB_GEMM_LAUNCH(false, false);
     else if (g.ta && !g.tb)
-        hipLaunchKernelGGL((gemm_kernel<WAVES, MT, NT, true, false>), grid, block, 0, stream, g, kchunk);
+        MMB_GEMM_LAUNCH(true, false);
     else
-        hipLaunchKernelGGL((gemm_kernel<WAVES, MT, NT, true, true>), grid, block, 0, stream, g, kchunk);
+        MMB_GEMM_LAUNCH(true, true);
+#undef MMB_GEMM_LAUNCH
     MMB_HIP(hipGetLastError());
     return MMB_OK;
 }
@@ -221,14 +446,29 @@ static int pick_splitk(const GemmArgs& g, int bm, int bn) {
     return s < 1 ? 1 : (int)s;
 }
 
+// configurations: {WAVES, MT, NT}.  Measured on MI355X (tools/gemm_bench.py): 8 waves x 16 rows is the best
+// shape for the LSTM GEMMs; workgroups whose wave count is not a multiple of 4 load the SIMDs unevenly.
+static const int kCfgs[][3] = {{8, 1, 13}, {8, 1, 7}, {4, 1, 13}, {4, 1, 7}, {4, 2, 13}, {4, 2, 7}};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
 static void pick_tile(const GemmArgs& g, int* bm, int* bn, int* cfg) {
-    // N tile: 208 (13 tiles) unless N is small enough for 112 (7 tiles)
-    const bool narrow = g.N <= 112;
-    // M tile: 128 (4 waves x 2) for tall problems, 160 (5 x 2) when M is a multiple of 160-ish LSTM gate blocks
-    const bool m160 = (g.M % 160 == 0) || (g.M <= 800 && g.M > 128);
-    *bn = narrow ? 112 : 208;
-    *bm = m160 ? 160 : 128;
-    *cfg = (m160 ? 2 : 0) + (narrow ? 1 : 0);
+    static int forced = -2;
+    if (forced == -2) {
+        const char* e = getenv("MMB_GEMM_CFG");
+        forced = e ? atoi(e) : -1;
+    }
+    int c;
+    if (forced >= 0 && forced < kNumCfgs) {
+        c = forced;
+    } else {
+        const bool narrow = g.N <= 112;  // N tile 112 instead of 208
+        const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + (narrow ? 111 : 207)) / (narrow ? 112 : 208));
+        const bool small = tiles128 < 160 && g.K < 4096;  // too few 128-row tiles and no split-K to fill the chip
+        c = (small ? 2 : 0) + (narrow ? 1 : 0);
+    }
+    *cfg = c;
+    *bm = kCfgs[c][0] * kCfgs[c][1] * 16;
+    *bn = kCfgs[c][2] * 16;
 }
 
 int gemm_splitk_for(const GemmArgs& g) {
@@ -245,10 +485,12 @@ int gemm_launch(const GemmArgs& g, hipStream_t stream) {
     if (splitk > 1 && !g.accumulate)
         MMB_HIP(hipMemset2DAsync(g.C, (size_t)g.ldc * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream));
     switch (cfg) {
-        case 0: return launch_cfg<4, 2, 13>(g, splitk, stream);
-        case 1: return launch_cfg<4, 2, 7>(g, splitk, stream);
-        case 2: return launch_cfg<5, 2, 13>(g, splitk, stream);
-        default: return launch_cfg<5, 2, 7>(g, splitk, stream);
+        case 0: return launch_cfg<8, 1, 13>(g, splitk, stream);
+        case 1: return launch_cfg<8, 1, 7>(g, splitk, stream);
+        case 2: return launch_cfg<4, 1, 13>(g, splitk, stream);
+        case 3: return launch_cfg<4, 1, 7>(g, splitk, stream);
+        case 4: return launch_cfg<4, 2, 13>(g, splitk, stream);
+        default: return launch_cfg<4, 2, 7>(g, splitk, stream);
     }
 }
 
