@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel trace stats / PMC counters) into the small summaries kept
+under profiles/.  Usage on the GPU box (after rocprofv3 ... --output-format csv -d DIR):
+
+    python tools/profile_summary.py stats DIR  > profiles/rNN_kernel_stats.md
+    python tools/profile_summary.py pmc DIR    > profiles/rNN_pmc.md   (also rewrites profiles/pmc_traffic.json)
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    return name.replace("mmb::", "")
+
+
+def stats(d):
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        rows += list(csv.DictReader(open(f)))
+    agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+    for r in rows:
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        a = agg[short(r["Kernel_Name"])]
+        a[0] += 1
+        a[1] += dur
+        a[2] = min(a[2], dur)
+        a[3] = max(a[3], dur)
+    tot = sum(a[1] for a in agg.values())
+    print("| kernel | calls | total us | avg us | min us | max us | % |")
+    print("|---|---:|---:|---:|---:|---:|---:|")
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"| `{k[:90]}` | {a[0]} | {a[1]:.1f} | {a[1] / a[0]:.2f} | {a[2]:.2f} | {a[3]:.2f} | {100 * a[1] / tot:.1f} |")
+    print(f"\ntotal kernel time {tot / 1e3:.3f} ms over {sum(a[0] for a in agg.values())} dispatches")
+
+
+def pmc(d, cfg="cfg2"):
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(int))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[k][r["Counter_Name"]] += 1
+    counters = sorted({c for k in acc for c in acc[k]})
+    print("| kernel | " + " | ".join(f"{c} /launch" for c in counters) + " |")
+    print("|---|" + "---:|" * len(counters))
+    traffic = {}
+    for k in sorted(acc):
+        vals = []
+        for c in counters:
+            vals.append(acc[k][c] / max(cnt[k][c], 1) if c in acc[k] else float("nan"))
+        print(f"| `{k[:80]}` | " + " | ".join(f"{v:.4g}" for v in vals) + " |")
+        if ("FETCH_SIZE" in acc[k] or "WRITE_SIZE" in acc[k]) and re.match(r"(att_|lstm_|gemm_)", k):
+            # MI355X_MICROARCH.md (HBM): FETCH_SIZE (KiB) reads exactly half of a wide coalesced stream on gfx950 -> x2;
+            # WRITE_SIZE (KiB) is exact for 16-B-per-lane stores.
+            t = {}
+            if "FETCH_SIZE" in acc[k]:
+                t["fetch_bytes_corrected"] = 2.0 * 1024 * acc[k]["FETCH_SIZE"] / cnt[k]["FETCH_SIZE"]
+            if "WRITE_SIZE" in acc[k]:
+                t["write_bytes"] = 1024 * acc[k]["WRITE_SIZE"] / cnt[k]["WRITE_SIZE"]
+            traffic[k] = t
+    if traffic:
+        print("\nHBM-side traffic per launch (bytes; FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE as is):")
+        for k, v in traffic.items():
+            print(f"- `{k[:80]}`: " + ", ".join(f"{n} {x:.4g}" for n, x in v.items()))
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+        old = json.load(open(path)) if os.path.exists(path) else {}
+        parts = old.setdefault(cfg, {}).setdefault("_parts", {})
+        for k, v in traffic.items():
+            parts.setdefault(k, {}).update(v)
+            if "fetch_bytes_corrected" in parts[k] and "write_bytes" in parts[k]:
+                old[cfg][k] = parts[k]["fetch_bytes_corrected"] + parts[k]["write_bytes"]
+        json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
