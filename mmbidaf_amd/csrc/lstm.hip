@@ -18,11 +18,14 @@
 // Packed-sequence semantics (pack_padded_sequence / pad_packed_sequence, encoding.py:93,99): sample
 // b runs exactly len[b] steps, the reverse direction starts at t = len-1, y is 0 for t >= len, and
 // h_n is the state after the sample's own last step.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mmb {
 
-constexpr int PF = 4;  // software prefetch distance (time steps) for the streamed per-step operands
+constexpr int PF = 4;  // software prefetch distance (time steps) for the streamed per-step operands; vmcnt retires in
+                       // issue order, so a prefetched load also waits for the older per-step stores: keep it deep
 
 struct RecFwdProb {
     const float* gx;       // (B,T,2,H,4)
@@ -40,8 +43,9 @@ struct RecFwdArgs {
     int n;
 };
 
-template <int KQ>
-__global__ __launch_bounds__(512) void lstm_rec_fwd_kernel(const RecFwdArgs args) {
+// DBG (timing-only ablations, never used by the product path): 1 = skip the per-step global stores, 2 = skip the gx loads
+template <int KQ, int PFD = PF, int DBG = 0>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_rec_fwd_kernel(const RecFwdArgs args) {
     constexpr int KQP = (KQ + 3) & ~3;
     __shared__ __attribute__((aligned(16))) float hbuf[2][4][KQP];
 
@@ -53,9 +57,10 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd_kernel(const RecFwdArgs args
     const int dir = local / P.B, b = local % P.B;
     const int H = P.H, T = P.T;
     const int len = min(max(P.len[b], 0), T);
-    const int tid = threadIdx.x, u = tid >> 2, kq = tid & 3;
-    const bool live = u < H;
-    const int uu = live ? u : 0;
+    const int tid = threadIdx.x, kq = tid & 3;
+    // threads beyond 4H (the block is rounded up to whole waves) shadow unit H-1: they compute and store exactly
+    // the same values to the same addresses, so the step loop needs no "live" predicate at all
+    const int u = min(tid >> 2, H - 1);
 
     // ---- W_hh slice into registers
     float w[4][KQ];
@@ -66,91 +71,109 @@ __global__ __launch_bounds__(512) void lstm_rec_fwd_kernel(const RecFwdArgs args
 #pragma unroll
             for (int kk = 0; kk < KQ; ++kk) {
                 const int k = kq * KQ + kk;
-                w[g][kk] = (live && k < H) ? W[(size_t)(g * H + uu) * H + k] : 0.f;
+                w[g][kk] = k < H ? W[(size_t)(g * H + u) * H + k] : 0.f;
             }
     }
     for (int i = tid; i < 2 * 4 * KQP; i += blockDim.x) (&hbuf[0][0][0])[i] = 0.f;
 
-    const size_t row0 = (size_t)b * T;  // row (b,t) = row0 + t
-    const float* gxp = P.gx + (size_t)dir * 4 * H + (size_t)uu * 4 + kq;
-    float* gatesp = P.gates + (size_t)dir * 4 * H + (size_t)uu * 4 + kq;
-    float* csp = P.cs + (size_t)dir * H + uu;
-    float* yp = P.y + (size_t)dir * H + uu;
+    // running element offsets of this thread into the per-sample slabs; one step moves them by +-row strides
     const int rev = dir;
-    auto tof = [&](int s) { return rev ? (len - 1 - s) : s; };
-
-    float gxr[PF];
-#pragma unroll
-    for (int j = 0; j < PF; ++j) gxr[j] = (live && j < len) ? gxp[(row0 + tof(j)) * 8 * H] : 0.f;
+    const int t0 = rev ? len - 1 : 0;
+    const int sgn = rev ? -1 : 1;
+    const float* gx_b = P.gx + (size_t)b * T * 8 * H;       // (T, 2, H, 4)
+    float* gates_b = P.gates + (size_t)b * T * 8 * H;
+    float* cs_b = P.cs + (size_t)b * T * 2 * H;
+    float* y_b = P.y + (size_t)b * T * 2 * H;
+    const int g_step = sgn * 8 * H, s_step = sgn * 2 * H;
+    int g_off = t0 * 8 * H + dir * 4 * H + u * 4 + kq;      // gx / gates element of (t, dir, u, kq)
+    // lanes with even kq store h into y, odd kq store c into cs (duplicates across the quad are harmless)
+    float* st_base = (kq & 1) ? cs_b : y_b;
+    int st_off = t0 * 2 * H + dir * H + u;
+    float* hw0 = &hbuf[0][u / KQ][u % KQ];                  // h_t slot of this unit (buffer 0)
+    const int hstride = 4 * KQP;
 
     float c = 0.f, h = 0.f;
     const bool is_tanh = kq == 2;
-    __syncthreads();
-
+    const bool b0 = kq & 1, b1 = kq & 2;
+    const float act_in = is_tanh ? -2.0f : -1.0f, act_mul = is_tanh ? 2.0f : 1.0f, act_sub = is_tanh ? 1.0f : 0.0f;
     int cur = 0;
-    for (int s0 = 0; s0 < len; s0 += PF) {
+
+    // one time step, given the input-projection value gx of (t, dir, u, kq)
+    auto step = [&](const float gx) {
+        // matvec: my quarter of h against my 4 gate rows.  All LDS reads are issued first, into distinct
+        // registers (otherwise hipcc recycles 4 VGPRs and exposes the LDS latency several times per step)
+        const float* hq = &hbuf[cur][kq][0];
+        f4 hv[KQP / 4];
 #pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            const int s = s0 + j;
-            if (s < len) {  // block-uniform
-                const int t = tof(s);
+        for (int q = 0; q < KQP / 4; ++q) hv[q] = *reinterpret_cast<const f4*>(hq + 4 * q);
+        __builtin_amdgcn_sched_group_barrier(0x100, KQP / 4, 0);  // the whole DS-read burst first
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int k4 = 0; k4 < KQP; k4 += 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (k4 + e < KQ) {
+                    a0 = fmaf(w[0][k4 + e], hv[k4 / 4][e], a0);
+                    a1 = fmaf(w[1][k4 + e], hv[k4 / 4][e], a1);
+                    a2 = fmaf(w[2][k4 + e], hv[k4 / 4][e], a2);
+                    a3 = fmaf(w[3][k4 + e], hv[k4 / 4][e], a3);
+                }
+            }
+        }
+        // transposing quad reduction: lane kq ends with the full sum of gate kq
+        const float keepA = b0 ? a1 : a0, sendA = b0 ? a0 : a1;
+        const float keepB = b0 ? a3 : a2, sendB = b0 ? a2 : a3;
+        const float rA = keepA + quad_xor1(sendA);
+        const float rB = keepB + quad_xor1(sendB);
+        const float keep = b1 ? rB : rA, send = b1 ? rA : rB;
+        const float pre = keep + quad_xor2(send) + gx;
+        // activation of my gate: sigmoid for i,f,o; tanh(x) = 2 sigmoid(2x) - 1 for g
+        const float sg = fast_rcp(1.0f + __expf(act_in * pre));
+        const float act = fmaf(act_mul, sg, -act_sub);
+        const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act);
+        const float gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
+        c = fmaf(gf, c, gi * gg);
+        h = go * tanhf_(c);
+        if (!(DBG & 1)) {
+            gates_b[g_off] = act;
+            st_base[st_off] = (kq & 1) ? c : h;
+        }
+        hw0[(cur ^ 1) * hstride] = h;
+        g_off += g_step;
+        st_off += s_step;
+        cur ^= 1;
+        __syncthreads();
+    };
+
+    // prefetch ring: gxr[j] holds gx of step (s + j); refills are unconditional loads from a clamped step index,
+    // so the main loop body is straight-line code and the compiler keeps counted vmcnt waits
+    const int gx_base = dir * 4 * H + u * 4 + kq;
+    auto gx_at = [&](int sidx) { return (DBG & 2) ? 0.01f * sidx : gx_b[(t0 + sgn * min(sidx, len - 1)) * 8 * H + gx_base]; };
+    float gxr[PFD];
+    __syncthreads();
+    int s = 0;
+    if (len >= PFD) {
+#pragma unroll
+        for (int j = 0; j < PFD; ++j) gxr[j] = gx_at(j);
+        for (; s + PFD <= len; s += PFD) {
+#pragma unroll
+            for (int j = 0; j < PFD; ++j) {
                 const float gx = gxr[j];
-                if (live && s + PF < len) gxr[j] = gxp[(row0 + tof(s + PF)) * 8 * H];
-                // matvec: my quarter of h against my 4 gate rows
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                const float* hq = &hbuf[cur][kq][0];
-#pragma unroll
-                for (int k4 = 0; k4 < KQP; k4 += 4) {
-                    const f4 hv = *reinterpret_cast<const f4*>(hq + k4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (k4 + e < KQ) {
-                            a0 = fmaf(w[0][k4 + e], hv[e], a0);
-                            a1 = fmaf(w[1][k4 + e], hv[e], a1);
-                            a2 = fmaf(w[2][k4 + e], hv[e], a2);
-                            a3 = fmaf(w[3][k4 + e], hv[e], a3);
-                        }
-                    }
-                }
-                // transposing quad reduction: lane kq ends with the full sum of gate kq
-                const bool b0 = kq & 1, b1 = kq & 2;
-                const float keepA = b0 ? a1 : a0, sendA = b0 ? a0 : a1;
-                const float keepB = b0 ? a3 : a2, sendB = b0 ? a2 : a3;
-                const float rA = keepA + quad_xor1(sendA);  // gate b0      over lanes {l, l^1}
-                const float rB = keepB + quad_xor1(sendB);  // gate 2 + b0
-                const float keep = b1 ? rB : rA, send = b1 ? rA : rB;
-                const float pre = keep + quad_xor2(send) + gx;
-                // activation of my gate: sigmoid for i,f,o; tanh for g
-                const float sg = fast_rcp(1.0f + __expf(is_tanh ? -2.0f * pre : -pre));
-                const float act = is_tanh ? 2.0f * sg - 1.0f : sg;
-                const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act);
-                const float gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
-                c = fmaf(gf, c, gi * gg);
-                h = go * tanhf_(c);
-                if (live) {
-                    const size_t row = row0 + t;
-                    gatesp[row * 8 * H] = act;
-                    if (kq == 0) {
-                        hbuf[cur ^ 1][u / KQ][u % KQ] = h;
-                    } else if (kq == 1) {
-                        yp[row * 2 * H] = h;
-                    } else if (kq == 2) {
-                        csp[row * 2 * H] = c;
-                    }
-                }
-                cur ^= 1;
-                __syncthreads();
+                gxr[j] = gx_at(s + j + PFD);
+                step(gx);
             }
         }
     }
-    if (live) {
+    for (; s < len; ++s) step(gx_at(s));  // tail (< PF steps): synchronous loads
+
+    if (tid < 4 * H) {
         if (kq == 0) P.h_n[((size_t)dir * P.B + b) * H + u] = h;
         if (kq == 1) P.c_n[((size_t)dir * P.B + b) * H + u] = c;
     }
     // zero the padded tail of y (pad_packed_sequence, encoding.py:99)
     for (int i = tid; i < (T - len) * H; i += blockDim.x) {
         const int t = len + i / H, k = i % H;
-        P.y[(row0 + t) * 2 * H + dir * H + k] = 0.f;
+        y_b[(size_t)t * 2 * H + dir * H + k] = 0.f;
     }
 }
 
@@ -171,11 +194,27 @@ struct RecBwdArgs {
     int n;
 };
 
-// thread (u, kq) holds column u of gate block kq of W_hh: wT[kk] = W_hh[kq*H + kk][u]
+// BPTT recurrence: dh_{t}[u] = sum_{g,u'} d_a_{t+1}[g][u'] W_hh[g*H+u'][u]  (K = 4H, H outputs).
+// A row of 16 lanes owns 4 consecutive units: lane ks of the row holds, for those 4 output units, the weights of
+// K-slice ks = 4*g + q (gate g, unit quarter q: 4*KQ floats), reads its 25-float slice of the previous step's d_a
+// from LDS (7 b128 reads, as few as the forward), does 4*KQ FMAs and a 16-lane DPP all-reduce gives every lane the
+// 4 sums.  For the element-wise part lane ks acts for (unit 4*ug + (ks>>2), gate ks&3).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_allsum(float v) {
+    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);  // row_half_mirror
+    v = dpp_add<0x140>(v);  // row_mirror
+    return v;
+}
+
 template <int KQ>
-__global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(const RecBwdArgs args) {
-    constexpr int HP = 4 * KQ;  // >= H, multiple of 4
-    __shared__ __attribute__((aligned(16))) float dabuf[2][4][HP];
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_rec_bwd_kernel(const RecBwdArgs args) {
+    constexpr int KQP = (KQ + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) float dabuf[2][16][KQP];
 
     int pi = 0;
     for (int i = 1; i < args.n; ++i)
@@ -185,113 +224,150 @@ __global__ __launch_bounds__(512) void lstm_rec_bwd_kernel(const RecBwdArgs args
     const int dir = local / P.B, b = local % P.B;
     const int H = P.H, T = P.T;
     const int len = min(max(P.len[b], 0), T);
-    const int tid = threadIdx.x, u = tid >> 2, kq = tid & 3;
-    const bool live = u < H;
-    const int uu = live ? u : 0;
+    const int tid = threadIdx.x, ks = tid & 15;
+    const int ngroups = (H + 3) / 4;
+    const bool real = (tid >> 4) < ngroups;
+    const int ug = min(tid >> 4, ngroups - 1);   // surplus rows shadow the last group (same values, same addresses)
+    const int kq = ks & 3;                        // gate this lane acts for in the element-wise part
+    const int u_raw = 4 * ug + (ks >> 2);
+    const bool valid = u_raw < H;                 // H % 4 != 0: the last group has units beyond H
+    const int u = min(u_raw, H - 1);
 
-    float wT[HP];
+    // ---- W_hh slice: wT[o][kk] = W_hh[(g*H + q*KQ + kk)][4*ug + o],  g = ks>>2, q = ks&3
+    float wT[4][KQ];
     {
         const float* W = P.w_hh[dir];
+        const int g = ks >> 2, q = ks & 3;
 #pragma unroll
-        for (int kk = 0; kk < HP; ++kk) wT[kk] = (live && kk < H) ? W[(size_t)(kq * H + kk) * H + uu] : 0.f;
-    }
-    for (int i = tid; i < 2 * 4 * HP; i += blockDim.x) (&dabuf[0][0][0])[i] = 0.f;
-
-    const size_t row0 = (size_t)b * T;
-    const int rev = dir;
-    // BPTT visits the forward processing order backwards: fwd dir t = len-1..0, reverse dir t = 0..len-1
-    auto tof = [&](int s) { return rev ? s : (len - 1 - s); };
-    const float* gatesp = P.gates + (size_t)dir * 4 * H + (size_t)uu * 4;
-    const float* csp = P.cs + (size_t)dir * H + uu;
-    const float* dyp = P.d_y + (size_t)dir * H + uu;
-    float* dap = P.d_a + (size_t)dir * 4 * H + (size_t)kq * H + uu;
-
-    f4 gr[PF];
-    float cpr[PF], dyr[PF];  // c_{prev(t)} and d_y[t]
-    auto load_step = [&](int s, f4& g4, float& cp, float& dyv) {
-        const int t = tof(s);
-        g4 = *reinterpret_cast<const f4*>(gatesp + (row0 + t) * 8 * H);
-        const int tp = rev ? t + 1 : t - 1;  // step processed before t by the forward recurrence
-        cp = (tp >= 0 && tp < len) ? csp[(row0 + tp) * 2 * H] : 0.f;
-        dyv = dyp[(row0 + t) * 2 * H];
-    };
+        for (int kk = 0; kk < KQ; ++kk) {
+            const int k = q * KQ + kk;
 #pragma unroll
-    for (int j = 0; j < PF; ++j) {
-        gr[j] = f4{0.f, 0.f, 0.f, 0.f};
-        cpr[j] = 0.f;
-        dyr[j] = 0.f;
-        if (live && j < len) load_step(j, gr[j], cpr[j], dyr[j]);
-    }
-    float c_t = (live && len > 0) ? csp[(row0 + tof(0)) * 2 * H] : 0.f;
-    float dh = (live && P.d_hn) ? P.d_hn[((size_t)dir * P.B + b) * H + u] : 0.f;
-    float dc = 0.f;
-    float db_acc = 0.f;
-    __syncthreads();
-
-    int cur = 0;
-    for (int s0 = 0; s0 < len; s0 += PF) {
-#pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            const int s = s0 + j;
-            if (s < len) {
-                const int t = tof(s);
-                const f4 g4 = gr[j];
-                const float c_prev = cpr[j], dyv = dyr[j];
-                if (live && s + PF < len) load_step(s + PF, gr[j], cpr[j], dyr[j]);
-                // recurrent part: dh += d_a(prev BPTT step) . W_hh  (my gate block, then quad all-reduce)
-                if (s > 0) {
-                    float a0 = 0.f, a1 = 0.f;
-                    const float* dq = &dabuf[cur][kq][0];
-#pragma unroll
-                    for (int k4 = 0; k4 < HP; k4 += 4) {
-                        const f4 dv = *reinterpret_cast<const f4*>(dq + k4);
-                        a0 = fmaf(wT[k4 + 0], dv.x, a0);
-                        a1 = fmaf(wT[k4 + 1], dv.y, a1);
-                        a0 = fmaf(wT[k4 + 2], dv.z, a0);
-                        a1 = fmaf(wT[k4 + 3], dv.w, a1);
-                    }
-                    float a = a0 + a1;
-                    a += quad_xor1(a);
-                    a += quad_xor2(a);
-                    dh = a;
-                }
-                const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
-                const float tc = tanhf_(c_t);
-                const float dh_t = dh + dyv;
-                const float d_o = dh_t * tc;
-                const float dc_t = fmaf(dh_t * go, 1.0f - tc * tc, dc);
-                float da;
-                if (kq == 0)
-                    da = dc_t * gg * gi * (1.0f - gi);
-                else if (kq == 1)
-                    da = dc_t * c_prev * gf * (1.0f - gf);
-                else if (kq == 2)
-                    da = dc_t * gi * (1.0f - gg * gg);
-                else
-                    da = d_o * go * (1.0f - go);
-                dc = dc_t * gf;
-                c_t = c_prev;
-                if (live) {
-                    dabuf[cur ^ 1][kq][u] = da;
-                    dap[(row0 + t) * 8 * H] = da;
-                    db_acc += da;
-                }
-                cur ^= 1;
-                __syncthreads();
+            for (int o = 0; o < 4; ++o) {
+                const int uo = 4 * ug + o;
+                wT[o][kk] = (k < H && uo < H) ? W[(size_t)(g * H + k) * H + uo] : 0.f;
             }
         }
     }
-    if (live) atomicAdd(&P.d_b[(size_t)dir * 4 * H + kq * H + u], db_acc);
+    for (int i = tid; i < 2 * 16 * KQP; i += blockDim.x) (&dabuf[0][0][0])[i] = 0.f;
+
+    const int rev = dir;
+    // BPTT visits the forward processing order backwards: fwd dir t = len-1..0, reverse dir t = 0..len-1
+    const int t0 = rev ? 0 : len - 1;
+    const int sgn = rev ? 1 : -1;
+    const float* gates_b = P.gates + (size_t)b * T * 8 * H + (size_t)dir * 4 * H + u * 4;
+    const float* cs_b = P.cs + (size_t)b * T * 2 * H + dir * H + u;
+    const float* dy_b = P.d_y + (size_t)b * T * 2 * H + dir * H + u;
+    float* da_b = P.d_a + (size_t)b * T * 8 * H + (size_t)dir * 4 * H + kq * H + u;
+    const int g_step = sgn * 8 * H;
+    int da_off = t0 * 8 * H;
+    float* daw0 = &dabuf[0][kq * 4 + u / KQ][u % KQ];
+    constexpr int dstride = 16 * KQP;
+
+    float c_t = len > 0 ? cs_b[t0 * 2 * H] : 0.f;
+    float dh = P.d_hn ? P.d_hn[((size_t)dir * P.B + b) * H + u] : 0.f;
+    float dc = 0.f;
+    float db_acc = 0.f;
+    int cur = 0;
+    bool first = true;
+    const bool o1 = (ks >> 2) & 1, o2 = (ks >> 2) & 2;   // which of the 4 sums is my unit's
+    const bool k1 = kq & 1, k2 = kq & 2;                 // my gate, as select flags (no divergent branches in the loop)
+    const bool is_g = kq == 2, is_o = kq == 3;
+
+    // one BPTT step given the saved gates (i,f,g,o) of step t, c of the step the forward recurrence ran before it, d_y[t]
+    auto step = [&](const f4 g4, const float c_prev, const float dyv) {
+        if (!first) {  // block-uniform
+            const float* dq = &dabuf[cur][ks][0];
+            f4 dv[KQP / 4];
+#pragma unroll
+            for (int q = 0; q < KQP / 4; ++q) dv[q] = *reinterpret_cast<const f4*>(dq + 4 * q);
+            __builtin_amdgcn_sched_group_barrier(0x100, KQP / 4, 0);  // the whole DS-read burst first
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < KQP; k4 += 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (k4 + e < KQ) {
+                        a0 = fmaf(wT[0][k4 + e], dv[k4 / 4][e], a0);
+                        a1 = fmaf(wT[1][k4 + e], dv[k4 / 4][e], a1);
+                        a2 = fmaf(wT[2][k4 + e], dv[k4 / 4][e], a2);
+                        a3 = fmaf(wT[3][k4 + e], dv[k4 / 4][e], a3);
+                    }
+                }
+            }
+            a0 = row16_allsum(a0);
+            a1 = row16_allsum(a1);
+            a2 = row16_allsum(a2);
+            a3 = row16_allsum(a3);
+            dh = o2 ? (o1 ? a3 : a2) : (o1 ? a1 : a0);
+        }
+        first = false;
+        const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
+        const float tc = tanhf_(c_t);
+        const float dh_t = dh + dyv;
+        const float dc_t = fmaf(dh_t * go, 1.0f - tc * tc, dc);
+        // my gate's pre-activation gradient (kq = i,f,g,o):
+        //   i: dc_t*g*i(1-i)   f: dc_t*c_prev*f(1-f)   g: dc_t*i*(1-g^2)   o: dh_t*tanh(c)*o(1-o)
+        const float m0 = is_o ? dh_t * tc : dc_t;
+        const float m1 = k2 ? (k1 ? 1.0f : gi) : (k1 ? c_prev : gg);
+        const float gv = k2 ? (k1 ? go : gg) : (k1 ? gf : gi);
+        const float dact = is_g ? 1.0f - gg * gg : gv * (1.0f - gv);
+        const float da = m0 * m1 * dact;
+        dc = dc_t * gf;
+        c_t = c_prev;
+        if (valid) {  // loop-invariant predicate (only false for padded units when H % 4 != 0)
+            daw0[(cur ^ 1) * dstride] = da;
+            da_b[da_off] = da;
+        }
+        da_off += g_step;
+        db_acc += da;
+        cur ^= 1;
+        __syncthreads();
+    };
+
+    // streamed operands of BPTT step index sidx (clamped: refills are unconditional, straight-line main loop)
+    auto row_of = [&](int sidx) { return t0 + sgn * min(sidx, len - 1); };
+    auto ld_g = [&](int sidx) { return *reinterpret_cast<const f4*>(gates_b + row_of(sidx) * 8 * H); };
+    auto ld_dy = [&](int sidx) { return dy_b[row_of(sidx) * 2 * H]; };
+    // c of the step the forward recurrence processed before step sidx = the NEXT BPTT step; zero at the sequence start
+    auto ld_cp = [&](int sidx) { const float v = cs_b[row_of(sidx + 1) * 2 * H]; return sidx + 1 < len ? v : 0.f; };
+
+    f4 gr[PF];
+    float cpr[PF], dyr[PF];
+    __syncthreads();
+    int s = 0;
+    if (len >= PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            gr[j] = ld_g(j);
+            cpr[j] = ld_cp(j);
+            dyr[j] = ld_dy(j);
+        }
+        for (; s + PF <= len; s += PF) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const f4 g4 = gr[j];
+                const float cp = cpr[j], dyv = dyr[j];
+                gr[j] = ld_g(s + j + PF);
+                cpr[j] = ld_cp(s + j + PF);
+                dyr[j] = ld_dy(s + j + PF);
+                step(g4, cp, dyv);
+            }
+        }
+    }
+    for (; s < len; ++s) step(ld_g(s), ld_cp(s), ld_dy(s));  // tail (< PF steps): synchronous loads
+
+    if (real && valid) atomicAdd(&P.d_b[(size_t)dir * 4 * H + kq * H + u], db_acc);
     // dead steps contribute nothing: zero their d_a rows for the weight-gradient GEMMs
+    float* da_z = P.d_a + (size_t)b * T * 8 * H + (size_t)dir * 4 * H;
     for (int i = tid; i < (T - len) * 4 * H; i += blockDim.x) {
         const int t = len + i / (4 * H), k = i % (4 * H);
-        P.d_a[(row0 + t) * 8 * H + (size_t)dir * 4 * H + k] = 0.f;
+        da_z[(size_t)t * 8 * H + k] = 0.f;
     }
 }
 
 template <typename ArgsT, typename K>
 static int launch_rec(K kernel, const ArgsT& a, int total_wgs, int H, hipStream_t stream, int kid) {
-    const int threads = ((4 * H + 63) / 64) * 64;
+    const int threads = ((16 * ((H + 3) / 4) + 63) / 64) * 64;  // >= 4H, whole waves (both kernels' layouts)
     ProfScope ps_(kid, stream);
     hipLaunchKernelGGL(kernel, dim3(total_wgs), dim3(threads), 0, stream, a);
     MMB_HIP(hipGetLastError());
@@ -344,7 +420,17 @@ extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int devic
     switch (kq_for(H)) {
         case 8: return launch_rec(lstm_rec_fwd_kernel<8>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
         case 16: return launch_rec(lstm_rec_fwd_kernel<16>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
-        case 25: return launch_rec(lstm_rec_fwd_kernel<25>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+        case 25: {
+            static int var = -1;
+            if (var < 0) { const char* e = getenv("MMB_LSTM_FWD_VARIANT"); var = e ? atoi(e) : 0; }
+            switch (var) {  // 1..4 are timing-only diagnostics (tools/lstm_bench.py)
+                case 1: return launch_rec(lstm_rec_fwd_kernel<25, 4, 0>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+                case 2: return launch_rec(lstm_rec_fwd_kernel<25, 8, 1>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+                case 3: return launch_rec(lstm_rec_fwd_kernel<25, 8, 2>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+                case 4: return launch_rec(lstm_rec_fwd_kernel<25, 8, 3>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+                default: return launch_rec(lstm_rec_fwd_kernel<25>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+            }
+        }
         default: return launch_rec(lstm_rec_fwd_kernel<32>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
     }
 }

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Time the recurrence kernels alone (cfg2 encoder stage: 3 encoders x 2 dirs x 32 samples, H=100) through the
+library's event hook.  MMB_LSTM_FWD_VARIANT selects timing-only diagnostic variants of the forward kernel."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from mmbidaf_amd import _lib
+from mmbidaf_amd.encoding import RNNEncoder, encode_group
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+encs = [RNNEncoder(100, 100, 1).to(dev) for _ in range(3)]
+xs = [torch.randn(32, T, 100, device=dev, requires_grad=True) for T in (400, 256, 64)]
+lens = [[400] * 32, [256] * 32, [64] * 32]
+def run():
+    outs = encode_group(encs, xs, lens)
+    sum(o[0].sum() for o in outs).backward()
+for _ in range(3): run()
+torch.cuda.synchronize()
+_lib.profile_enable(["lstm_rec_fwd", "lstm_rec_bwd"])
+N = 10
+for _ in range(N): run()
+torch.cuda.synchronize()
+for k in ("lstm_rec_fwd", "lstm_rec_bwd"):
+    ms, n, _ = _lib.profile_read(k)
+    print(f"variant {os.environ.get('MMB_LSTM_FWD_VARIANT','0')}: {k}: {ms/n*1e3:.1f} us/launch  = {ms/n*1e3/400:.3f} us/step (T=400)")
