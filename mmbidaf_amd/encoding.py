@@ -40,6 +40,40 @@ class Embedding(nn.Module):
         return self.hwy(self.proj(F.dropout(x, self.drop_prob, self.training)))
 
 
+class _DeviceCache:
+    """Small LRU of host-derived index tensors already resident on the device (lengths, masks, sort order), keyed
+    by the Python lengths they were built from.  A pageable H2D copy is stream-synchronous and stalls the host
+    behind all queued kernels; on a miss the copy goes through pinned memory and is non-blocking."""
+
+    def __init__(self, capacity=256):
+        self.capacity = capacity
+        self.items = {}
+
+    def get(self, key, build):
+        t = self.items.pop(key, None)
+        if t is None:
+            t = build()
+            if len(self.items) >= self.capacity:
+                self.items.pop(next(iter(self.items)))
+        self.items[key] = t
+        return t
+
+
+_cache = _DeviceCache()
+
+
+def to_device_cached(kind, lengths, device, build_host):
+    """build_host() -> CPU tensor derived from `lengths`; returns it on `device` (cached per lengths tuple)."""
+    key = (kind, str(device), tuple(lengths))
+
+    def build():
+        host = build_host()
+        if device.type == "cuda":
+            return host.pin_memory().to(device, non_blocking=True)
+        return host.to(device)
+    return _cache.get(key, build)
+
+
 def sorted_order(lengths):
     """Descending-length order exactly as the reference computes it: float-cast lengths and
     torch.sort(descending=True) on the host (layers/encoding.py:85,91) -- tie order included (Q3)."""
@@ -62,7 +96,7 @@ def encode_group(encoders, xs, lengths_list):
     L = encoders[0].rnn.num_layers
     assert all(e.rnn.num_layers == L and e.rnn.hidden_size == encoders[0].rnn.hidden_size for e in encoders)
     dev = xs[0].device
-    lens_dev = [torch.tensor(list(l), dtype=torch.int32).to(dev, non_blocking=True) for l in lengths_list]
+    lens_dev = [to_device_cached("len_i32", l, dev, lambda l=l: torch.tensor(list(l), dtype=torch.int32)) for l in lengths_list]
     for x, l in zip(xs, lengths_list):
         if len(l) != x.size(0) or min(l) < 1 or max(l) > x.size(1):
             raise ValueError("lengths must have one entry per sample with 1 <= len <= seq_len")
@@ -84,7 +118,7 @@ def encode_group(encoders, xs, lengths_list):
     for e, y, hs, lengths in zip(encoders, inputs, h_all, lengths_list):
         y = F.dropout(y, e.drop_prob, e.training)                  # encoding.py:104, also for 1-layer encoders
         h_n = torch.cat(hs, dim=0)                                 # (2L,B,H): [l0_fwd, l0_bwd, l1_fwd, l1_bwd] (Q4)
-        idx = sorted_order(lengths).to(dev)
+        idx = to_device_cached("sort_idx", lengths, dev, lambda lengths=lengths: sorted_order(lengths))
         results.append((y, h_n[:, idx].transpose(0, 1)))           # h_n stays in length-sorted order (Q3)
     return results
 

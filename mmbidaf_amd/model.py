@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .attention import BiDAFAttention, MultimodalAttentionDecoder
-from .encoding import Embedding, ImageEmbedding, RNNEncoder, encode_group
+from .encoding import Embedding, ImageEmbedding, RNNEncoder, encode_group, to_device_cached
 
 
 class MMBiDAF(nn.Module):
@@ -46,9 +46,10 @@ class MMBiDAF(nn.Module):
             [self.text_enc, self.audio_enc, self.image_enc], [text_emb, audio_emb, image_emb],
             [text_lengths, audio_lengths, image_lengths])
         dev = text_emb.device
-        text_mask = self.get_mask(text_emb, text_lengths).to(dev)
-        audio_mask = self.get_mask(audio_emb, audio_lengths).to(dev)
-        image_mask = self.get_mask(image_emb, image_lengths).to(dev)
+        # masks are built on the host like the reference (models.py:116-118,126-128) and cached on the device
+        def mask(x, lengths):
+            return to_device_cached(("mask", x.size(1)), lengths, dev, lambda: self.get_mask(x, lengths))
+        text_mask, audio_mask, image_mask = mask(text_emb, text_lengths), mask(audio_emb, audio_lengths), mask(image_emb, image_lengths)
         att_audio = self.bidaf_att_audio(text_enc, audio_enc, text_mask, audio_mask)
         att_image = self.bidaf_att_image(text_enc, image_enc, text_mask, image_mask)
         (mod_a, hid_a), (mod_i, hid_i) = encode_group([self.mod_t_a, self.mod_t_i], [att_audio, att_image],
