@@ -143,6 +143,8 @@ typedef struct {
     float* d_b;                /* (2,4H)    = d_b_ih = d_b_hh                                    */
     /* scratch */
     float* d_a;                /* (B,T,2,4H) pre-activation gate gradients                       */
+    float* d_w_cat;            /* (8H, I+2H) or NULL: lets the library compute d_w_ih and both   */
+                               /* d_w_hh with ONE GEMM against [x | y_fwd(t-1) | y_rev(t+1)]     */
     int32_t B, T, I, H;
 } mmb_lstm_bwd_desc;
 
@@ -155,6 +157,16 @@ int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* descs, int n, int device, void
  *   tb = 0: B is (K,N) row-major (ldb)    tb = 1: B is (N,K) row-major (ldb)
  *   accumulate != 0: C += result (C must hold valid data)
  */
+/*
+ * Arithmetic of the dense GEMMs (process-wide; also env MMB_GEMM_MODE = auto | f32 | bf16x2 | bf16x3 at first use):
+ *   1 (default) per shape, whichever of 0 and 3 is faster (both are fp32-accurate);
+ *   3           fp32 operands split exactly into three bf16 terms, six bf16 MFMA cross products, fp32 accumulate:
+ *               fp32-level error (~1e-7 relative) at 2.7x the exact-f32 MFMA peak;
+ *   2           two terms, three products (error ~2^-16 relative);
+ *   0           exact-f32 MFMA (v_mfma_f32_16x16x4_f32).
+ */
+int mmb_set_gemm_mode(int mode);
+
 int mmb_gemm_f32(const float* A, const float* Bm, float* C, const float* bias,
                  int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb, int accumulate,
                  int device, void* stream);

@@ -69,10 +69,22 @@ struct GemmArgs {
     int accumulate;      // C += (atomic when split-K)
     int gate_H;          // > 0 (tb == 1 only): output column u*4+g of each 4H block comes from B row / bias entry g*H+u
     int shiftB, periodB; // tb == 0 only: B row k is read from row k+shiftB, zero when (k % period)+shift leaves [0,period)
+    // tb == 0 only, fast kernels only: B is the virtual column-concatenation of up to 3 (K, cols) matrices, each with
+    // its own leading dimension and row shift (periodB applies to all): [x | y_fwd shifted -1 | y_rev shifted +1]
+    int nseg;
+    const float* seg_ptr[3];
+    int seg_ld[3], seg_cols[3], seg_shift[3];
 };
 // enqueue; C must be pre-zeroed by the caller when the launcher picks split-K (it tells via *needs_zero)
 int gemm_launch(const GemmArgs& g, hipStream_t stream);
 // true when gemm_launch(g) will accumulate with atomics over K splits (caller zeroes C unless accumulate)
 int gemm_splitk_for(const GemmArgs& g);
+// split-bf16 path (gemm_bf16.hip): ns = 3 (fp32-accurate, default) or 2
+bool gemm_bf16_eligible(const GemmArgs& g);
+bool gemm_segments_ok(const GemmArgs& g);   // segmented (virtually concatenated) B usable by the fast kernels
+int gemm_bf16_launch(const GemmArgs& g, int ns, hipStream_t stream);
+// 0 = exact-f32 MFMA kernels, 1 = per-shape choice between 0 and 3 (default), 2 / 3 = split-bf16 with that many terms
+int gemm_mode();
+void set_gemm_mode(int mode);
 
 }  // namespace mmb

@@ -251,7 +251,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_fast_kernel(const GemmArgs g,
     const float* pa[A_V];
     const float* pb[B_V];
     int la[A_V], lb[B_V];
-    int kb_row[B_V];  // !TB with shift: the k row (before shift) this chunk reads, for the period test
+    int kb_row[B_V];   // !TB: the k row (before shift) this chunk reads, for the period test
+    int b_sh[B_V];     // !TB: row shift of this chunk's B segment
+    size_t b_stp[B_V]; // pointer step per K tile
 #pragma unroll
     for (int i = 0; i < A_V; ++i) {
         const int c = min(tid + i * NTHR, A_CH - 1);
@@ -269,24 +271,38 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_fast_kernel(const GemmArgs g,
     for (int i = 0; i < B_V; ++i) {
         const int c = min(tid + i * NTHR, B_CH - 1);
         kb_row[i] = 0;
+        b_sh[i] = 0;
         if (TB) {
             const int n = c / (BK / 4), k4 = (c % (BK / 4)) * 4;
             const int gn = min(n0 + n, g.N - 1);
             const int srow = g.gate_H > 0 ? gate_src_row(gn, g.gate_H) : gn;
             pb[i] = g.B + (size_t)srow * g.ldb + kb + k4;
             lb[i] = n * BK + k4;
+            b_stp[i] = BK;
         } else {
             const int k = c / (BN / 4), n4 = (c % (BN / 4)) * 4;
             kb_row[i] = kb + k;
-            pb[i] = g.B + (size_t)(kb + k) * g.ldb + min(n0 + n4, g.N - 4);
+            int col = min(n0 + n4, g.N - 4), ld = g.ldb;
+            const float* base = g.B;
+            b_sh[i] = g.shiftB;
+            if (g.nseg > 0) {  // virtual concatenation: pick the segment this chunk's columns live in
+                int sg = 0;
+                while (sg < g.nseg - 1 && col >= g.seg_cols[sg]) col -= g.seg_cols[sg++];
+                base = g.seg_ptr[sg];
+                ld = g.seg_ld[sg];
+                b_sh[i] = g.seg_shift[sg];
+            }
+            pb[i] = base + (size_t)(kb + k) * ld + col;
             lb[i] = k * BNP + n4;
+            b_stp[i] = (size_t)BK * ld;
+            b_sh[i] *= 1;
+            kb_row[i] = kb + k;
+            // fold the row shift into the pointer; validity is tested per tile from kb_row
+            pb[i] += (ptrdiff_t)b_sh[i] * ld;
         }
     }
     const size_t a_step = TA ? (size_t)BK * g.lda : BK;
-    const size_t b_step = TB ? BK : (size_t)BK * g.ldb;
-    const bool shifted = !TB && g.shiftB != 0;
-    const float* b_lo = g.B;                                  // clamp window for shifted rows
-    const float* b_hi = g.B + (size_t)(g.K - 1) * g.ldb;
+    const bool shifted = !TB && (g.shiftB != 0 || g.nseg > 0);
 
     f4 ra[A_V], rb[B_V];
     auto gload = [&]() {
@@ -298,17 +314,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_fast_kernel(const GemmArgs g,
 #pragma unroll
         for (int i = 0; i < B_V; ++i) {
             if (shifted) {
-                const int tt = kb_row[i] % g.periodB + g.shiftB;
-                const bool ok = tt >= 0 && tt < g.periodB;
-                const float* src = pb[i] + (ptrdiff_t)g.shiftB * g.ldb;
-                src = src < b_lo ? pb[i] : (src > b_hi + g.ldb ? pb[i] : src);
-                const f4 t = *reinterpret_cast<const f4*>(ok ? src : pb[i]);
+                const int tt = kb_row[i] % g.periodB + b_sh[i];
+                const bool ok = tt >= 0 && tt < g.periodB;   // shifted row stays inside its sample
+                const f4 t = *reinterpret_cast<const f4*>(ok ? pb[i] : pb[i] - (ptrdiff_t)b_sh[i] * (ptrdiff_t)(b_stp[i] / BK));
                 rb[i] = ok ? t : f4{0.f, 0.f, 0.f, 0.f};
                 kb_row[i] += BK;
             } else {
                 rb[i] = *reinterpret_cast<const f4*>(pb[i]);
             }
-            pb[i] += b_step;
+            pb[i] += b_stp[i];
         }
     };
     auto lstore = [&](int buf) {
@@ -399,9 +413,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_fast_kernel(const GemmArgs g,
     }
 }
 
+bool gemm_segments_ok(const GemmArgs& g) {
+    for (int i = 0; i < g.nseg; ++i)
+        if (reinterpret_cast<uintptr_t>(g.seg_ptr[i]) % 16 || g.seg_ld[i] % 4 || g.seg_cols[i] % 4) return false;
+    return g.nseg == 0 || (!g.tb && g.nseg <= 3);
+}
+
 static bool fast_ok(const GemmArgs& g) {
-    const bool al = (reinterpret_cast<uintptr_t>(g.A) % 16 == 0) && (reinterpret_cast<uintptr_t>(g.B) % 16 == 0);
-    if (!al || g.lda % 4 || g.ldb % 4 || g.K % BK) return false;
+    const bool al = (reinterpret_cast<uintptr_t>(g.A) % 16 == 0) && (g.nseg > 0 || reinterpret_cast<uintptr_t>(g.B) % 16 == 0);
+    if (!gemm_segments_ok(g)) return false;
+    if (!al || g.lda % 4 || (g.nseg == 0 && g.ldb % 4) || g.K % BK) return false;
     if (g.ta && (g.M % 4 || g.M < 4)) return false;
     if (!g.tb && (g.N % 4 || g.N < 4)) return false;
     return true;
@@ -477,8 +498,23 @@ int gemm_splitk_for(const GemmArgs& g) {
     return pick_splitk(g, bm, bn);
 }
 
+static int g_gemm_mode = -1;
+int gemm_mode() {
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("MMB_GEMM_MODE");  // "auto" | "f32" | "bf16x2" | "bf16x3"
+        g_gemm_mode = !e ? 1 : (e[0] == 'a' ? 1 : (e[0] == 'f' ? 0 : (e[strlen(e) - 1] == '2' ? 2 : 3)));
+    }
+    return g_gemm_mode;
+}
+void set_gemm_mode(int mode) { g_gemm_mode = (mode == 0 || mode == 2 || mode == 3) ? mode : 1; }
+
 int gemm_launch(const GemmArgs& g, hipStream_t stream) {
     if (g.M <= 0 || g.N <= 0) return MMB_OK;
+    int mode = gemm_mode();
+    if (mode == 1)  // auto: the split-bf16 kernel wins on wide, deep products (tools/gemm_bench.py), both are fp32-accurate
+        mode = (!g.ta && g.N >= 400 && g.K >= 200) ? 3 : 0;   // transposed-A (weight-gradient) shapes: the f32 kernel is faster
+    if (mode != 0 && gemm_bf16_eligible(g)) return gemm_bf16_launch(g, mode, stream);
+    if (g.nseg > 0 && !fast_ok(g)) return fail(MMB_ERR_ARG, "gemm: segmented B needs the aligned fast path");
     int bm, bn, cfg;
     pick_tile(g, &bm, &bn, &cfg);
     const int splitk = pick_splitk(g, bm, bn);
@@ -496,6 +532,12 @@ int gemm_launch(const GemmArgs& g, hipStream_t stream) {
 
 }  // namespace mmb
 
+extern "C" int mmb_set_gemm_mode(int mode) {
+    MMB_REQUIRE(mode >= 0 && mode <= 3, "mmb_set_gemm_mode: mode must be 0 (exact f32 MFMA), 1 (auto), 2 or 3 (bf16 terms)");
+    mmb::set_gemm_mode(mode);
+    return MMB_OK;
+}
+
 extern "C" int mmb_gemm_f32(const float* A, const float* Bm, float* C, const float* bias, int M, int N, int K,
                             int lda, int ldb, int ldc, int ta, int tb, int accumulate, int device, void* stream) {
     MMB_REQUIRE(A && Bm && C, "mmb_gemm_f32: null pointer");
@@ -504,6 +546,6 @@ extern "C" int mmb_gemm_f32(const float* A, const float* Bm, float* C, const flo
     mmb::GemmArgs g{};
     g.A = A; g.B = Bm; g.C = C; g.bias = bias; g.bias2 = nullptr;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.ta = ta; g.tb = tb; g.accumulate = accumulate; g.gate_H = 0; g.shiftB = 0; g.periodB = 1;
+    g.ta = ta; g.tb = tb; g.accumulate = accumulate; g.gate_H = 0; g.shiftB = 0; g.periodB = 1; g.nseg = 0;
     return mmb::gemm_launch(g, static_cast<hipStream_t>(stream));
 }

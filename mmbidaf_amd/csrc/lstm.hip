@@ -365,6 +365,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// d_w_cat (8H, I+2H) -> d_w_ih (2,4H,I), d_w_hh (2,4H,H): rows [dir*4H..), columns [0,I) | [I + dir*H, +H)
+__global__ __launch_bounds__(256) void lstm_unpack_dw_kernel(const float* __restrict__ cat, float* __restrict__ d_w_ih,
+                                                             float* __restrict__ d_w_hh, int H, int I) {
+    const int ldc = I + 2 * H;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 8 * H * ldc) return;
+    const int row = idx / ldc, col = idx % ldc, dir = row / (4 * H);
+    const float v = cat[idx];
+    if (col < I) d_w_ih[(size_t)row * I + col] = v;
+    else if (col - I >= dir * H && col - I < (dir + 1) * H) d_w_hh[(size_t)row * H + (col - I - dir * H)] = v;
+}
+
 template <typename ArgsT, typename K>
 static int launch_rec(K kernel, const ArgsT& a, int total_wgs, int H, hipStream_t stream, int kid) {
     const int threads = ((16 * ((H + 3) / 4) + 63) / 64) * 64;  // >= 4H, whole waves (both kernels' layouts)
@@ -467,23 +479,48 @@ extern "C" int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* d, int n, int devic
     for (int i = 0; i < n; ++i) {
         const mmb_lstm_bwd_desc& p = d[i];
         const int BT = p.B * p.T;
-        // d_w_ih (2,4H,I) = d_a^T (8H x BT) . x (BT x I)
-        {
+        bool fused = false;
+        if (p.d_w_cat) {
+            // ONE GEMM for all weight gradients of the layer: d_a^T (8H x BT) . [x | y_fwd(t-1) | y_rev(t+1)] (BT x (I+2H)).
+            // h_prev of the forward (reverse) direction is y read one row earlier (later), zero across sample boundaries.
             GemmArgs g{};
-            g.A = p.d_a; g.B = p.x; g.C = p.d_w_ih;
-            g.M = 8 * H; g.N = p.I; g.K = BT; g.lda = 8 * H; g.ldb = p.I; g.ldc = p.I;
-            g.ta = 1; g.tb = 0; g.periodB = 1;
-            rc = gemm_launch(g, stream);
-            if (rc) return rc;
+            g.A = p.d_a; g.B = p.x; g.C = p.d_w_cat;
+            g.M = 8 * H; g.N = p.I + 2 * H; g.K = BT; g.lda = 8 * H; g.ldb = p.I; g.ldc = p.I + 2 * H;
+            g.ta = 1; g.tb = 0; g.periodB = p.T;
+            g.nseg = 3;
+            g.seg_ptr[0] = p.x;      g.seg_ld[0] = p.I;   g.seg_cols[0] = p.I; g.seg_shift[0] = 0;
+            g.seg_ptr[1] = p.y;      g.seg_ld[1] = 2 * H; g.seg_cols[1] = H;   g.seg_shift[1] = -1;
+            g.seg_ptr[2] = p.y + H;  g.seg_ld[2] = 2 * H; g.seg_cols[2] = H;   g.seg_shift[2] = +1;
+            if (gemm_segments_ok(g) && BT % 20 == 0 && (8 * H) % 4 == 0) {
+                rc = gemm_launch(g, stream);
+                if (rc) return rc;
+                const int total = 8 * H * (p.I + 2 * H);
+                ProfScope ps_(MMB_K_GEMM, stream);
+                hipLaunchKernelGGL(lstm_unpack_dw_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.d_w_cat, p.d_w_ih,
+                                   p.d_w_hh, H, p.I);
+                MMB_HIP(hipGetLastError());
+                fused = true;
+            }
         }
-        // d_w_hh[dir] (4H,H) = d_a[dir]^T . h_prev[dir];  h_prev = y shifted by one step inside each sample
-        for (int dir = 0; dir < 2; ++dir) {
-            GemmArgs g{};
-            g.A = p.d_a + (size_t)dir * 4 * H; g.B = p.y + (size_t)dir * H; g.C = p.d_w_hh + (size_t)dir * 4 * H * H;
-            g.M = 4 * H; g.N = H; g.K = BT; g.lda = 8 * H; g.ldb = 2 * H; g.ldc = H;
-            g.ta = 1; g.tb = 0; g.shiftB = dir ? +1 : -1; g.periodB = p.T;
-            rc = gemm_launch(g, stream);
-            if (rc) return rc;
+        if (!fused) {
+            // d_w_ih (2,4H,I) = d_a^T (8H x BT) . x (BT x I)
+            {
+                GemmArgs g{};
+                g.A = p.d_a; g.B = p.x; g.C = p.d_w_ih;
+                g.M = 8 * H; g.N = p.I; g.K = BT; g.lda = 8 * H; g.ldb = p.I; g.ldc = p.I;
+                g.ta = 1; g.tb = 0; g.periodB = 1;
+                rc = gemm_launch(g, stream);
+                if (rc) return rc;
+            }
+            // d_w_hh[dir] (4H,H) = d_a[dir]^T . h_prev[dir];  h_prev = y shifted by one step inside each sample
+            for (int dir = 0; dir < 2; ++dir) {
+                GemmArgs g{};
+                g.A = p.d_a + (size_t)dir * 4 * H; g.B = p.y + (size_t)dir * H; g.C = p.d_w_hh + (size_t)dir * 4 * H * H;
+                g.M = 4 * H; g.N = H; g.K = BT; g.lda = 8 * H; g.ldb = 2 * H; g.ldc = H;
+                g.ta = 1; g.tb = 0; g.shiftB = dir ? +1 : -1; g.periodB = p.T;
+                rc = gemm_launch(g, stream);
+                if (rc) return rc;
+            }
         }
         // d_x (BT,I) = sum_dir d_a[dir] (BT x 4H) . W_ih[dir] (4H x I)
         if (p.d_x) {

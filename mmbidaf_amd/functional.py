@@ -184,13 +184,15 @@ class _BiLSTMLayerFn(torch.autograd.Function):
             d_w_hh = torch.empty(2, 4 * H, H, device=dev, dtype=torch.float32)
             d_b = torch.empty(2, 4 * H, device=dev, dtype=torch.float32)
             d_a = torch.empty(B, T, 8 * H, device=dev, dtype=torch.float32)
+            d_w_cat = torch.empty(8 * H, I + 2 * H, device=dev, dtype=torch.float32)
             d = descs[i]
             d.d_y, d.d_hn, d.x, d.y, d.lengths = _ptr(d_y), _ptr(d_hn), _ptr(x), _ptr(y), _ptr(lens)
             d.w_ih[0], d.w_ih[1], d.w_hh[0], d.w_hh[1] = _ptr(w_ih_f), _ptr(w_ih_r), _ptr(w_hh_f), _ptr(w_hh_r)
             d.gates, d.cs = _ptr(gates), _ptr(cs)
             d.d_x, d.d_w_ih, d.d_w_hh, d.d_b, d.d_a = _ptr(d_x), _ptr(d_w_ih), _ptr(d_w_hh), _ptr(d_b), _ptr(d_a)
+            d.d_w_cat = _ptr(d_w_cat)
             d.B, d.T, d.I, d.H = B, T, I, H
-            keep += [d_y, d_hn, d_a]
+            keep += [d_y, d_hn, d_a, d_w_cat]
             results += [d_x, d_w_ih[0], d_w_hh[0], d_b[0], d_b[0], d_w_ih[1], d_w_hh[1], d_b[1], d_b[1]]
         rc = lib.mmb_bilstm_layer_bwd(descs, n, dev.index, _stream())
         _lib.check(rc, "mmb_bilstm_layer_bwd")
