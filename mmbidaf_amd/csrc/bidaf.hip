@@ -25,9 +25,9 @@ namespace mmb {
 
 constexpr int DT = 13;           // 16-wide feature tiles: D <= 208
 constexpr int LDP = 212;         // LDS panel row stride (floats): 848 B, 16-B aligned, odd multiple of 16 B
-constexpr int PR = 32;           // m rows per staged panel
-constexpr int NW = 4;            // waves per workgroup
-constexpr int NTHR = NW * 64;
+// Workgroup geometry is a template parameter of the tile kernels: NWv waves (16 lane-side rows each) share
+// PRv-row panels of the streamed side.  Small workgroups + short panels trade panel re-reads (served by the XCD's
+// L2, see decode_block) for more resident workgroups per CU, which is what hides staging and barrier latency here.
 constexpr float NEG = -1e30f;    // attention.py:94
 
 using side_t = f4[DT];
@@ -54,30 +54,68 @@ __device__ __forceinline__ void load_side(side_t& side, const float* src_b, int 
     }
 }
 
-// stage rows [row0,row0+PR) of a (R,D) matrix into an LDS panel [PR][LDP], zero-filled outside
+// Stage rows [row0,row0+PR) of a (R,D) matrix into an LDS panel [PR][LDP] by LDS-DMA (global_load_lds_dwordx4:
+// 16 B per lane straight into LDS, no VGPR round trip, no per-chunk VALU work in the panel loop).  The LDS image is
+// lane-linear in 16-B chunks: chunk c = tid + k*NTHR is row c / 53, columns 4*(c % 53)...; the per-lane SOURCE address
+// is free, so rows beyond R and columns beyond D (incl. the pad chunk) are simply clamped onto valid, finite data:
+// every consumer ignores them (rows via its softmax code / zero weights, columns via zero lane-side registers and
+// d < D store guards).
+template <int NTHR, int PR>
 __device__ __forceinline__ void stage_panel(float* panel, const float* src_b, int row0, int R, int D, int tid) {
-    for (int i = tid; i < PR * (DT * 4); i += NTHR) {
-        const int rr = i / (DT * 4), c = i % (DT * 4);
-        f4 v = f4{0.f, 0.f, 0.f, 0.f};
-        if (row0 + rr < R && 4 * c < D) v = *reinterpret_cast<const f4*>(src_b + (size_t)(row0 + rr) * D + 4 * c);
-        *reinterpret_cast<f4*>(panel + rr * LDP + 4 * c) = v;
+    constexpr int CPR = LDP / 4;                  // 16-B chunks per LDS row (53)
+    constexpr int NCH = PR * CPR;                 // chunks per panel
+    constexpr int NIT = (NCH + NTHR - 1) / NTHR;  // wave-instructions per wave
+    float* wave_dst = panel + (tid & ~63) * 4;    // wave-uniform: this wave's 1-KiB slot of each NTHR*16-B stripe
+#pragma unroll 1   // keep the address math inside the loop: hoisted, it costs ~50 VGPRs in the register-bound kernels
+    for (int k = 0; k < NIT; ++k) {
+        const int c = tid + k * NTHR;
+        if (NCH % NTHR == 0 || c < NCH) {
+            const int row = c / CPR, col = min(4 * (c - row * CPR), D - 4);
+            const float* src = src_b + (size_t)min(row0 + row, R - 1) * D + col;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(wave_dst + k * NTHR * 4), 16, 0, 0);
+        }
     }
 }
 
-// two independent S-type chains (m blocks 0 and 1 of the panel) against the same lane-side registers
-__device__ __forceinline__ void sprod2(const float* panel, int r, int kg, const side_t& side, f4& c0, f4& c1) {
+// NB independent S-type chains (the NB 16-row m blocks of the panel) against the same lane-side registers
+template <int NB>
+__device__ __forceinline__ void sprodN(const float* panel, int r, int kg, const side_t& side, f4 (&c)[NB]) {
     const float* p0 = panel + r * LDP + 4 * kg;
-    const float* p1 = p0 + 16 * LDP;
 #pragma unroll
     for (int s = 0; s < DT; ++s) {
-        const f4 a0 = *reinterpret_cast<const f4*>(p0 + 16 * s);
-        const f4 a1 = *reinterpret_cast<const f4*>(p1 + 16 * s);
         const f4 b = side[s];
-        c0 = mfma16(a0.x, b.x, c0); c1 = mfma16(a1.x, b.x, c1);
-        c0 = mfma16(a0.y, b.y, c0); c1 = mfma16(a1.y, b.y, c1);
-        c0 = mfma16(a0.z, b.z, c0); c1 = mfma16(a1.z, b.z, c1);
-        c0 = mfma16(a0.w, b.w, c0); c1 = mfma16(a1.w, b.w, c1);
+        f4 a[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) a[q] = *reinterpret_cast<const f4*>(p0 + q * 16 * LDP + 16 * s);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) c[q] = mfma16(a[q].x, b.x, c[q]);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) c[q] = mfma16(a[q].y, b.y, c[q]);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) c[q] = mfma16(a[q].z, b.z, c[q]);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) c[q] = mfma16(a[q].w, b.w, c[q]);
     }
+}
+
+// block index -> (lane-side tile, split, sample).  Blocks are dealt round-robin over the 8 XCDs (id % 8 labels the
+// XCD group), so all blocks of one sample are given ids with equal id % 8: the panels they all stream then stay in
+// that XCD's L2.  Purely a speed choice; any mapping is correct.
+__device__ __forceinline__ void decode_block(int tiles, int splits, int B, int& tile, int& split, int& b) {
+    const int id = blockIdx.x;
+    int slot;
+    if (B % 8 == 0) {
+        const int xcd = id & 7;
+        slot = id >> 3;
+        b = xcd + 8 * (slot % (B / 8));
+        slot /= (B / 8);
+    } else {
+        b = id % B;
+        slot = id / B;
+    }
+    tile = slot % tiles;
+    split = slot / tiles;
 }
 
 // PV-type: O[dt] += V[m = mb*16 + 4kg + e][d = 16dt + r] * W[e]   for the m block mb of the panel
@@ -154,19 +192,20 @@ struct AttFwdArgs {
     const float* text;      // (B,N,D)                      (row pass epilogue)
     float* out;             // (B,N,4D)
     float* bsave;           // (B,N,D)
-    int N, R, D, splits, rows_per_split;
+    int N, R, D, B, splits, rows_per_split;
 };
 
-// NV = 1: column pass (lane side = modality rows j, streams text rows i), produces q and the column stats.
-// NV = 2: row pass    (lane side = text rows i, streams modality rows j with values [mod | q]), produces out.
-template <int NV>
-__global__ __launch_bounds__(NTHR) void att_fwd_kernel(const AttFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// NV = 1: column pass = att_col_kernel (lane side = modality rows j, streams text rows i), produces q and the column stats.
+// NV = 2: row pass = att_row_kernel    (lane side = text rows i, streams modality rows j with values [mod | q]), produces out.
+template <int NV, int NW, int PR>
+__device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, float* smem) {
+    constexpr int NTHR = NW * 64, NB = PR / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kg = lane >> 4;
-    const int b = blockIdx.z, split = blockIdx.y;
     const int N = a.N, R = a.R, D = a.D;
-    const int n = (blockIdx.x * NW + wave) * 16 + r;
+    int tile, split, b;
+    decode_block((N + 16 * NW - 1) / (16 * NW), a.splits, a.B, tile, split, b);
+    const int n = (tile * NW + wave) * 16 + r;
 
     const bool sep_s = a.mS != a.mV0;  // dropped copy differs from the clean value panel
     float* pV0 = smem;
@@ -192,9 +231,9 @@ __global__ __launch_bounds__(NTHR) void att_fwd_kernel(const AttFwdArgs a) {
     const int row_end = min(R, row_begin + a.rows_per_split);
     for (int p0 = row_begin; p0 < row_end; p0 += PR) {
         __syncthreads();
-        stage_panel(pV0, mV0_b, p0, row_end, D, tid);
-        if (NV == 2) stage_panel(pV1, mV1_b, p0, row_end, D, tid);
-        if (sep_s) stage_panel(pS, mS_b, p0, row_end, D, tid);
+        stage_panel<NTHR, PR>(pV0, mV0_b, p0, row_end, D, tid);
+        if (NV == 2) stage_panel<NTHR, PR>(pV1, mV1_b, p0, row_end, D, tid);
+        if (sep_s) stage_panel<NTHR, PR>(pS, mS_b, p0, row_end, D, tid);
         if (tid < PR) {
             const int m = p0 + tid;
             const bool in = m < row_end;
@@ -203,26 +242,33 @@ __global__ __launch_bounds__(NTHR) void att_fwd_kernel(const AttFwdArgs a) {
         }
         __syncthreads();
 
-        f4 s0 = f4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
-        sprod2(pS, r, kg, side, s0, s1);
-        f4 v[2] = {s0, s1};
+        f4 v[NB];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int q = 0; q < NB; ++q) v[q] = f4{0.f, 0.f, 0.f, 0.f};
+        sprodN<NB>(pS, r, kg, side, v);
+        float bmax = -INFINITY;
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ml = mb * 16 + 4 * kg + e;
                 const int code = mcode_s[ml];
                 const float x = v[mb][e] + mterm_s[ml] + nterm;
                 v[mb][e] = code == 2 ? x : (code == 1 ? NEG : -INFINITY);
+                bmax = fmaxf(bmax, v[mb][e]);
             }
-        const float bmax = kg_allmax(fmaxf(f4max(v[0]), f4max(v[1])));
+        bmax = kg_allmax(bmax);
         const float m_new = fmaxf(m_run, bmax);
         const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[mb][e] = expf(v[mb][e] - m_new);
-        l_run = l_run * alpha + f4sum(v[0]) + f4sum(v[1]);
+            for (int e = 0; e < 4; ++e) {
+                v[mb][e] = expf(v[mb][e] - m_new);
+                psum += v[mb][e];
+            }
+        l_run = l_run * alpha + psum;
         if (__any(alpha != 1.0f)) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -232,7 +278,7 @@ __global__ __launch_bounds__(NTHR) void att_fwd_kernel(const AttFwdArgs a) {
         }
         m_run = m_new;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < NB; ++mb) {
             pvprod(pV0, mb, r, kg, v[mb], O0);
             if (NV == 2) pvprod(pV1, mb, r, kg, v[mb], O1);
         }
@@ -284,6 +330,17 @@ __global__ __launch_bounds__(NTHR) void att_fwd_kernel(const AttFwdArgs a) {
             }
         }
     }
+}
+
+template <int NW, int PR>
+__global__ __launch_bounds__(NW * 64) void att_col_kernel(const AttFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    att_fwd_body<1, NW, PR>(a, smem);
+}
+template <int NW, int PR>
+__global__ __launch_bounds__(NW * 64) void att_row_kernel(const AttFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    att_fwd_body<2, NW, PR>(a, smem);
 }
 
 // merge the per-split partial column softmaxes: q = sum_p O_p e^{m_p-m} / sum_p l_p e^{m_p-m}
@@ -359,7 +416,7 @@ struct AttBwdArgs {
     float *d_w_t, *d_w_m, *d_w_tm, *d_bias;          // outputs, zeroed by the prologue, accumulated with atomics
     // per-split partial sums of the j-side sweeps, (B,splits,M,D) / (B,splits,M)
     float *p_dq, *p_dmc, *p_dmd1, *p_dmd2, *p_dc1, *p_dc2;
-    int T, M, D, splits, rows_per_split;
+    int B, T, M, D, splits, rows_per_split;
     int fold;                                        // 1: no dropped copies, d_*_d folded into d_*
 };
 
@@ -374,13 +431,16 @@ __device__ __forceinline__ void store_side(float* dst_row, const side_t& v, int 
 // j-side sweep 1 (lane side = modality rows j, streams a slice of the text rows i):
 //   dq_j += sum_i P1_ij db_i ; dmodc_j += sum_i P1_ij da_i ; dS1 = P1 (dP1 - delta1_i) mask_j
 //   dmodd_j += sum_i dS1_ij text_d_i (scaled by w_tm later) ; dc_j += sum_i dS1_ij
-__global__ __launch_bounds__(NTHR) void att_bwd_j1_kernel(const AttBwdArgs a) {
+template <int NW, int PR>
+__global__ __launch_bounds__(NW * 64) void att_bwd_j1_kernel(const AttBwdArgs a) {
+    constexpr int NTHR = NW * 64, NB = PR / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kg = lane >> 4;
-    const int b = blockIdx.z, split = blockIdx.y;
     const int T = a.T, M = a.M, D = a.D;
-    const int n = (blockIdx.x * NW + wave) * 16 + r;  // modality row j
+    int tile, split, b;
+    decode_block((M + 16 * NW - 1) / (16 * NW), a.splits, a.B, tile, split, b);
+    const int n = (tile * NW + wave) * 16 + r;  // modality row j
 
     float* pTd = smem;
     float* pDa = pTd + PR * LDP;
@@ -411,26 +471,27 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j1_kernel(const AttBwdArgs a) {
     const int row_begin = split * a.rows_per_split, row_end = min(T, row_begin + a.rows_per_split);
     for (int p0 = row_begin; p0 < row_end; p0 += PR) {
         __syncthreads();
-        stage_panel(pTd, td_b, p0, row_end, D, tid);
-        stage_panel(pDa, da_b, p0, row_end, D, tid);
-        stage_panel(pDb, db_b, p0, row_end, D, tid);
+        stage_panel<NTHR, PR>(pTd, td_b, p0, row_end, D, tid);
+        stage_panel<NTHR, PR>(pDa, da_b, p0, row_end, D, tid);
+        stage_panel<NTHR, PR>(pDb, db_b, p0, row_end, D, tid);
         if (tid < PR) {
             const int i = p0 + tid;
             const bool in = i < row_end;
             rt_s[tid] = in ? a.rterm[(size_t)b * T + i] : 0.f;
-            rmax_s[tid] = in ? a.row_stat[((size_t)b * T + i) * 2] : 0.f;
+            rmax_s[tid] = in ? a.row_stat[((size_t)b * T + i) * 2] : INFINITY;   // exp(x - inf) = 0 beyond the slice
             rinv_s[tid] = in ? 1.0f / a.row_stat[((size_t)b * T + i) * 2 + 1] : 0.f;
             dl1_s[tid] = in ? a.delta1[(size_t)b * T + i] : 0.f;
         }
         __syncthreads();
-        f4 s[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-        f4 dp[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-        sprod2(pTd, r, kg, sideS, s[0], s[1]);
-        sprod2(pDa, r, kg, sideM, dp[0], dp[1]);
-        sprod2(pDb, r, kg, sideQ, dp[0], dp[1]);
-        f4 p1[2], ds[2];
+        f4 s[NB], dp[NB];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int q = 0; q < NB; ++q) s[q] = dp[q] = f4{0.f, 0.f, 0.f, 0.f};
+        sprodN<NB>(pTd, r, kg, sideS, s);
+        sprodN<NB>(pDa, r, kg, sideM, dp);
+        sprodN<NB>(pDb, r, kg, sideQ, dp);
+        f4 p1[NB], ds[NB];
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ml = mb * 16 + 4 * kg + e;
@@ -442,7 +503,7 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j1_kernel(const AttBwdArgs a) {
                 dc += g;
             }
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < NB; ++mb) {
             pvprod(pDb, mb, r, kg, p1[mb], dq);
             pvprod(pDa, mb, r, kg, p1[mb], dmc);
             pvprod(pTd, mb, r, kg, ds[mb], dmd);
@@ -460,13 +521,16 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j1_kernel(const AttBwdArgs a) {
 // j-side sweep 2 (needs the complete dq = sum of the sweep-1 partials):
 //   dS2 = P2 (dP2 - delta2_j) mask_i, dP2_ij = text_i . dq_j ; dmodd_j += sum_i dS2_ij text_d_i ; dc_j += sum_i dS2_ij
 //   split 0 also publishes dq_j and delta2_j = q_j . dq_j for the i-side pass
-__global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
+template <int NW, int PR>
+__global__ __launch_bounds__(NW * 64) void att_bwd_j2_kernel(const AttBwdArgs a) {
+    constexpr int NTHR = NW * 64, NB = PR / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kg = lane >> 4;
-    const int b = blockIdx.z, split = blockIdx.y;
     const int T = a.T, M = a.M, D = a.D;
-    const int n = (blockIdx.x * NW + wave) * 16 + r;
+    int tile, split, b;
+    decode_block((M + 16 * NW - 1) / (16 * NW), a.splits, a.B, tile, split, b);
+    const int n = (tile * NW + wave) * 16 + r;
 
     const bool sep = a.text_d != a.text;
     float* pT = smem;
@@ -509,8 +573,8 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
     const int row_begin = split * a.rows_per_split, row_end = min(T, row_begin + a.rows_per_split);
     for (int p0 = row_begin; p0 < row_end; p0 += PR) {
         __syncthreads();
-        stage_panel(pT, t_b, p0, row_end, D, tid);
-        if (sep) stage_panel(pTd, td_b, p0, row_end, D, tid);
+        stage_panel<NTHR, PR>(pT, t_b, p0, row_end, D, tid);
+        if (sep) stage_panel<NTHR, PR>(pTd, td_b, p0, row_end, D, tid);
         if (tid < PR) {
             const int i = p0 + tid;
             const bool in = i < row_end;
@@ -518,13 +582,14 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
             code_s[tid] = in ? (a.text_mask[(size_t)b * T + i] ? 2 : 1) : 0;
         }
         __syncthreads();
-        f4 s[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-        f4 dp[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-        sprod2(pTd, r, kg, sideS, s[0], s[1]);
-        sprod2(pT, r, kg, sideDq, dp[0], dp[1]);
-        f4 ds[2];
+        f4 s[NB], dp[NB];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int q = 0; q < NB; ++q) s[q] = dp[q] = f4{0.f, 0.f, 0.f, 0.f};
+        sprodN<NB>(pTd, r, kg, sideS, s);
+        sprodN<NB>(pT, r, kg, sideDq, dp);
+        f4 ds[NB];
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ml = mb * 16 + 4 * kg + e;
@@ -536,7 +601,7 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
                 dc += g;
             }
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) pvprod(pTd, mb, r, kg, ds[mb], dmd);
+        for (int mb = 0; mb < NB; ++mb) pvprod(pTd, mb, r, kg, ds[mb], dmd);
     }
     dc = kg_allsum(dc);
     if (!nin) return;
@@ -604,13 +669,16 @@ __global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a, i
 //   d_text_i += sum_j P2_ij dq_j ; dX_i = sum_j dS_ij mod_d_j ; dr_i = sum_j dS_ij
 //   d_text_d_i = dr_i w_t + w_tm * dX_i ; d_w_t += dr_i text_d_i ; d_w_tm += dX_i * text_d_i ; d_bias += dr_i
 constexpr int PI_STRIDE = 2 * DT * 16 + 16;  // per-wave partial: [d_w_t 208 | d_w_tm 208 | d_bias 1 ...]
-__global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
+template <int NW, int PR>
+__global__ __launch_bounds__(NW * 64) void att_bwd_i_kernel(const AttBwdArgs a) {
+    constexpr int NTHR = NW * 64, NB = PR / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kg = lane >> 4;
-    const int b = blockIdx.z;
     const int T = a.T, M = a.M, D = a.D;
-    const int n = (blockIdx.x * NW + wave) * 16 + r;  // text row i
+    int tile, split, b;
+    decode_block((T + 16 * NW - 1) / (16 * NW), 1, a.B, tile, split, b);
+    const int n = (tile * NW + wave) * 16 + r;  // text row i
 
     const bool sep = a.mod_d != a.mod;
     float* pM = smem;
@@ -646,10 +714,10 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
     const float* dq_b = a.dq + (size_t)b * M * D;
     for (int p0 = 0; p0 < M; p0 += PR) {
         __syncthreads();
-        stage_panel(pM, m_b, p0, M, D, tid);
-        stage_panel(pQ, q_b, p0, M, D, tid);
-        stage_panel(pDq, dq_b, p0, M, D, tid);
-        if (sep) stage_panel(pMd, md_b, p0, M, D, tid);
+        stage_panel<NTHR, PR>(pM, m_b, p0, M, D, tid);
+        stage_panel<NTHR, PR>(pQ, q_b, p0, M, D, tid);
+        stage_panel<NTHR, PR>(pDq, dq_b, p0, M, D, tid);
+        if (sep) stage_panel<NTHR, PR>(pMd, md_b, p0, M, D, tid);
         if (tid < PR) {
             const int j = p0 + tid;
             const bool in = j < M;
@@ -660,16 +728,16 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
             mmf_s[tid] = in ? (a.mod_mask[(size_t)b * M + j] ? 1.f : 0.f) : -1.f;
         }
         __syncthreads();
-        f4 s[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-        f4 dp1[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-        f4 dp2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-        sprod2(pMd, r, kg, sideS, s[0], s[1]);
-        sprod2(pM, r, kg, sideDa, dp1[0], dp1[1]);
-        sprod2(pQ, r, kg, sideDb, dp1[0], dp1[1]);
-        sprod2(pDq, r, kg, sideT, dp2[0], dp2[1]);
-        f4 p2[2], ds[2];
+        f4 s[NB], dp1[NB], dp2[NB];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int q = 0; q < NB; ++q) s[q] = dp1[q] = dp2[q] = f4{0.f, 0.f, 0.f, 0.f};
+        sprodN<NB>(pMd, r, kg, sideS, s);
+        sprodN<NB>(pM, r, kg, sideDa, dp1);
+        sprodN<NB>(pQ, r, kg, sideDb, dp1);
+        sprodN<NB>(pDq, r, kg, sideT, dp2);
+        f4 p2[NB], ds[NB];
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ml = mb * 16 + 4 * kg + e;
@@ -684,7 +752,7 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
                 dr += g1 + g2;
             }
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < NB; ++mb) {
             pvprod(pDq, mb, r, kg, p2[mb], dtx);
             pvprod(pMd, mb, r, kg, ds[mb], dX);
         }
@@ -740,14 +808,30 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ host side
-static int pick_splits(int B, int N, int R) {
+// workgroup geometries that are compiled (NW waves x PR-row panels); chosen per kernel below / by MMB_ATT_GEOM
+// (measured on MI355X, cfg2: 4 waves x 32-row panels beats 2x16, 1x16 and 2x32 on every kernel)
+enum { GEOM_4x32 = 0, GEOM_2x16 = 1, GEOM_COUNT };
+static const int kGeomNW[GEOM_COUNT] = {4, 2};
+static const int kGeomPR[GEOM_COUNT] = {32, 16};
+
+static int geom_for(int kernel_id, int deflt) {
+    // MMB_ATT_GEOM = "<col><row><j1><j2><i>" one digit per kernel (tuning aid), e.g. 11111
+    static int forced[5] = {-2, -2, -2, -2, -2};
+    if (forced[0] == -2) {
+        const char* e = getenv("MMB_ATT_GEOM");
+        for (int i = 0; i < 5; ++i) forced[i] = (e && (int)strlen(e) > i && e[i] >= '0' && e[i] < '0' + GEOM_COUNT) ? e[i] - '0' : -1;
+    }
+    return forced[kernel_id] >= 0 ? forced[kernel_id] : deflt;
+}
+
+static int pick_splits(int B, int N, int R, int PR) {
     const int waves = B * ((N + 15) / 16);
     int s = (1536 + waves - 1) / waves;  // aim at ~1.5 waves per SIMD (1024 SIMDs)
     const int smax = (R + PR - 1) / PR;
     if (s > smax) s = smax;
     return s < 1 ? 1 : s;
 }
-static int rows_per_split(int R, int splits) {
+static int rows_per_split(int R, int splits, int PR) {
     int rp = (R + splits - 1) / splits;
     return (rp + PR - 1) / PR * PR;
 }
@@ -758,7 +842,7 @@ struct BwdWs {
 };
 static BwdWs bwd_layout(int B, int T, int M, int D) {
     BwdWs w{};
-    w.splits = pick_splits(B, M, T);
+    w.splits = pick_splits(B, M, T, 16);   // upper bound over the compiled geometries (16-row panels)
     const size_t S = w.splits;
     size_t o = 0;
     auto take = [&](size_t nfloat) { size_t at = o; o += (nfloat + 3) / 4 * 4; return at; };
@@ -782,6 +866,25 @@ static int allow_lds(K kernel, size_t bytes) {
     MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return MMB_OK;
 }
+
+// launch `KERNEL<..., NW, PR>` for geometry `geom` on a 1-D grid of tiles(N) * splits * B workgroups
+#define MMB_ATT_LAUNCH(KID, GEOM, N_LANE, SPLITS, BATCH, LDS_FLOATS_EXPR, ARGS, ...)                                   \
+    do {                                                                                                               \
+        int rc_ = MMB_OK;                                                                                              \
+        auto go = [&](auto kern, int NW, int PR) {                                                                     \
+            const size_t lds = (size_t)(LDS_FLOATS_EXPR) * sizeof(float);                                              \
+            if ((rc_ = allow_lds(kern, lds))) return;                                                                  \
+            const int tiles = ((N_LANE) + 16 * NW - 1) / (16 * NW);                                                    \
+            ProfScope ps_(KID, stream);                                                                                \
+            hipLaunchKernelGGL(kern, dim3(tiles * (SPLITS) * (BATCH)), dim3(NW * 64), lds, stream, ARGS);              \
+        };                                                                                                             \
+        switch (GEOM) {                                                                                                \
+            case GEOM_2x16: go(__VA_ARGS__<2, 16>, 2, 16); break;                                                      \
+            default: go(__VA_ARGS__<4, 32>, 4, 32); break;                                                             \
+        }                                                                                                              \
+        if (rc_) return rc_;                                                                                           \
+        MMB_HIP(hipGetLastError());                                                                                    \
+    } while (0)
 
 }  // namespace mmb
 
@@ -813,21 +916,19 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
     // ---- column pass: lane side = modality rows, streams text.  (`out` is used as scratch for the split
     //      partials: it is (B,T,4D) and is only written by the row pass afterwards.)
     {
+        const int geom = geom_for(0, GEOM_4x32);
+        const int PRg = kGeomPR[geom];
         AttFwdArgs a{};
         a.side_src = mod_d; a.w_tm = w_tm; a.mS = text_d; a.mV0 = text; a.mV1 = nullptr;
         a.m_mask = text_mask; a.m_term = rterm; a.n_term = cterm; a.stat = col_stat; a.q = q;
-        a.N = M; a.R = T; a.D = D;
-        int splits = pick_splits(B, M, T);
+        a.N = M; a.R = T; a.D = D; a.B = B;
+        int splits = pick_splits(B, M, T, PRg);
         while (splits > 1 && (size_t)splits * M * (D + 2) > (size_t)T * 4 * D) --splits;
         a.splits = splits;
-        a.rows_per_split = rows_per_split(T, splits);
+        a.rows_per_split = rows_per_split(T, splits, PRg);
         a.part_o = out;
         a.part_stat = out + (size_t)B * splits * M * D;
-        const size_t lds = ((size_t)(1 + 1) * PR * LDP + 2 * PR) * sizeof(float);
-        if (int rc = allow_lds(att_fwd_kernel<1>, lds)) return rc;
-        dim3 grid((M + 16 * NW - 1) / (16 * NW), splits, B);
-        { ProfScope ps_(MMB_K_ATT_COL, stream); hipLaunchKernelGGL(att_fwd_kernel<1>, grid, dim3(NTHR), lds, stream, a); }
-        MMB_HIP(hipGetLastError());
+        MMB_ATT_LAUNCH(MMB_K_ATT_COL, geom, M, splits, B, (1 + 1) * PR * LDP + 2 * PR, a, att_col_kernel);
         if (splits > 1) {
             const size_t nthr = (size_t)B * M * (D / 4);
             { ProfScope ps_(MMB_K_ATT_COMBINE, stream); hipLaunchKernelGGL(att_combine_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, a.part_o, a.part_stat, q,
@@ -837,16 +938,13 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
     }
     // ---- row pass: lane side = text rows, streams [mod | q]
     {
+        const int geom = geom_for(1, GEOM_4x32);
         AttFwdArgs a{};
         a.side_src = text_d; a.w_tm = w_tm; a.mS = mod_d; a.mV0 = mod; a.mV1 = q;
         a.m_mask = mod_mask; a.m_term = cterm; a.n_term = rterm; a.stat = row_stat;
         a.text = text; a.out = out; a.bsave = bsave;
-        a.N = T; a.R = M; a.D = D; a.splits = 1; a.rows_per_split = rows_per_split(M, 1);
-        const size_t lds = ((size_t)(2 + 1) * PR * LDP + 2 * PR) * sizeof(float);
-        if (int rc = allow_lds(att_fwd_kernel<2>, lds)) return rc;
-        dim3 grid((T + 16 * NW - 1) / (16 * NW), 1, B);
-        { ProfScope ps_(MMB_K_ATT_ROW, stream); hipLaunchKernelGGL(att_fwd_kernel<2>, grid, dim3(NTHR), lds, stream, a); }
-        MMB_HIP(hipGetLastError());
+        a.N = T; a.R = M; a.D = D; a.B = B; a.splits = 1; a.rows_per_split = rows_per_split(M, 1, kGeomPR[geom]);
+        MMB_ATT_LAUNCH(MMB_K_ATT_ROW, geom, T, 1, B, (2 + 1) * PR * LDP + 2 * PR, a, att_row_kernel);
     }
     return MMB_OK;
 }
@@ -877,6 +975,10 @@ extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* 
                 L.total * sizeof(float));
     MMB_HIP(hipSetDevice(device));
 
+    const int geom_j1 = geom_for(2, GEOM_4x32), geom_j2 = geom_for(3, GEOM_4x32), geom_i = geom_for(4, GEOM_4x32);
+    // both j sweeps must agree on how the text rows are split (the partial buffers are indexed by split)
+    const int PRj = kGeomPR[geom_j1] > kGeomPR[geom_j2] ? kGeomPR[geom_j1] : kGeomPR[geom_j2];
+
     AttBwdArgs a{};
     a.text = text; a.mod = mod; a.text_d = drop_t ? text_d : text; a.mod_d = drop_m ? mod_d : mod;
     a.text_mask = text_mask; a.mod_mask = mod_mask; a.w_t = w_t; a.w_m = w_m; a.w_tm = w_tm;
@@ -887,38 +989,21 @@ extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* 
     a.p_dmd2 = workspace + L.p_dmd2; a.p_dc1 = workspace + L.p_dc1; a.p_dc2 = workspace + L.p_dc2;
     a.d_mod = d_mod; a.d_mod_d = d_mod_d; a.d_text = d_text; a.d_text_d = d_text_d;
     a.d_w_t = d_w_t; a.d_w_m = d_w_m; a.d_w_tm = d_w_tm; a.d_bias = d_bias;
-    a.T = T; a.M = M; a.D = D; a.fold = drop_t ? 0 : 1;
-    a.splits = L.splits;
-    a.rows_per_split = rows_per_split(T, a.splits);
+    a.B = B; a.T = T; a.M = M; a.D = D; a.fold = drop_t ? 0 : 1;
+    a.splits = pick_splits(B, M, T, PRj);
+    if (a.splits > L.splits) a.splits = L.splits;
+    a.rows_per_split = rows_per_split(T, a.splits, PRj);
 
     { ProfScope ps_(MMB_K_ATT_BWD_PRE, stream); hipLaunchKernelGGL(att_bwd_pre_kernel, dim3((B * T + 3) / 4), dim3(256), 0, stream, d_out, out, text, bsave,
                        workspace + L.da, workspace + L.db, workspace + L.delta1, d_text, d_w_t, d_w_m, d_w_tm, d_bias, B * T, D); }
     MMB_HIP(hipGetLastError());
-    {
-        const size_t lds = ((size_t)3 * PR * LDP + 4 * PR) * sizeof(float);
-        if (int rc = allow_lds(att_bwd_j1_kernel, lds)) return rc;
-        dim3 grid((M + 16 * NW - 1) / (16 * NW), a.splits, B);
-        { ProfScope ps_(MMB_K_ATT_BWD_J1, stream); hipLaunchKernelGGL(att_bwd_j1_kernel, grid, dim3(NTHR), lds, stream, a); }
-        MMB_HIP(hipGetLastError());
-    }
-    {
-        const size_t lds = ((size_t)2 * PR * LDP + 2 * PR) * sizeof(float);
-        if (int rc = allow_lds(att_bwd_j2_kernel, lds)) return rc;
-        dim3 grid((M + 16 * NW - 1) / (16 * NW), a.splits, B);
-        { ProfScope ps_(MMB_K_ATT_BWD_J2, stream); hipLaunchKernelGGL(att_bwd_j2_kernel, grid, dim3(NTHR), lds, stream, a); }
-        MMB_HIP(hipGetLastError());
-    }
+    MMB_ATT_LAUNCH(MMB_K_ATT_BWD_J1, geom_j1, M, a.splits, B, 3 * PR * LDP + 4 * PR, a, att_bwd_j1_kernel);
+    MMB_ATT_LAUNCH(MMB_K_ATT_BWD_J2, geom_j2, M, a.splits, B, 2 * PR * LDP + 2 * PR, a, att_bwd_j2_kernel);
     {
         const int chunks = (B * M + JF_ROWS - 1) / JF_ROWS;
         { ProfScope ps_(MMB_K_ATT_BWD_JFIN, stream); hipLaunchKernelGGL(att_bwd_jfin_kernel, dim3((chunks + 3) / 4), dim3(256), 0, stream, a, B); }
         MMB_HIP(hipGetLastError());
     }
-    {
-        const size_t lds = ((size_t)4 * PR * LDP + 5 * PR) * sizeof(float);
-        if (int rc = allow_lds(att_bwd_i_kernel, lds)) return rc;
-        dim3 grid((T + 16 * NW - 1) / (16 * NW), 1, B);
-        { ProfScope ps_(MMB_K_ATT_BWD_I, stream); hipLaunchKernelGGL(att_bwd_i_kernel, grid, dim3(NTHR), lds, stream, a); }
-        MMB_HIP(hipGetLastError());
-    }
+    MMB_ATT_LAUNCH(MMB_K_ATT_BWD_I, geom_i, T, 1, B, 4 * PR * LDP + 5 * PR + NW * PI_STRIDE, a, att_bwd_i_kernel);
     return MMB_OK;
 }
