@@ -47,7 +47,7 @@ const char* mmb_last_error(void);
 enum {
     MMB_K_ATT_RANK1 = 0, MMB_K_ATT_COL, MMB_K_ATT_COMBINE, MMB_K_ATT_ROW,
     MMB_K_ATT_BWD_PRE, MMB_K_ATT_BWD_J1, MMB_K_ATT_BWD_J2, MMB_K_ATT_BWD_JFIN, MMB_K_ATT_BWD_I,
-    MMB_K_GEMM, MMB_K_LSTM_REC_FWD, MMB_K_LSTM_REC_BWD, MMB_K_COUNT
+    MMB_K_GEMM, MMB_K_LSTM_REC_FWD, MMB_K_LSTM_REC_BWD, MMB_K_SPLIT, MMB_K_COUNT
 };
 int mmb_profile_enable(uint32_t kernel_mask);
 int mmb_profile_read(int kernel_id, double* total_ms, int* launches);
@@ -120,8 +120,14 @@ typedef struct {
     float* gx;                 /* (B,T,2,H,4) input projection, gate-interleaved                 */
     float* gates;              /* (B,T,2,H,4) post-activation i,f,g,o                            */
     float* cs;                 /* (B,T,2,H)   cell state after each step                         */
+    void* ws;                  /* scratch of mmb_bilstm_ws_bytes(B,T,I,H,0) bytes (bf16 operand planes) or NULL   */
     int32_t B, T, I, H;
 } mmb_lstm_fwd_desc;
+
+/* bytes of the optional operand-plane scratch of one problem (backward != 0: for mmb_bilstm_layer_bwd).  With it (and
+ * I, H multiples of 4) the layer's GEMMs run on the bf16 matrix cores from exact 3-term splits (fp32-level accuracy);
+ * without it they run on the exact-f32 MFMA kernels. */
+size_t mmb_bilstm_ws_bytes(int B, int T, int I, int H, int backward);
 
 int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* descs, int n, int device, void* stream);
 
@@ -145,6 +151,7 @@ typedef struct {
     float* d_a;                /* (B,T,2,4H) pre-activation gate gradients                       */
     float* d_w_cat;            /* (8H, I+2H) or NULL: lets the library compute d_w_ih and both   */
                                /* d_w_hh with ONE GEMM against [x | y_fwd(t-1) | y_rev(t+1)]     */
+    void* ws;                  /* scratch of mmb_bilstm_ws_bytes(B,T,I,H,1) bytes or NULL        */
     int32_t B, T, I, H;
 } mmb_lstm_bwd_desc;
 
@@ -170,6 +177,11 @@ int mmb_set_gemm_mode(int mode);
 int mmb_gemm_f32(const float* A, const float* Bm, float* C, const float* bias,
                  int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb, int accumulate,
                  int device, void* stream);
+
+/* C = A (M,K) . B (N,K)^T + bias through the operand-plane path (split passes + bf16 6-product kernel); exported for
+ * tests and tools.  ws: scratch of at least 6 * (M + N) * roundup(K,32) bytes; K % 4 == 0. */
+int mmb_gemm_nt_planes(const float* A, const float* Bm, float* C, const float* bias, int M, int N, int K,
+                       void* ws, size_t ws_bytes, int device, void* stream);
 
 #ifdef __cplusplus
 }

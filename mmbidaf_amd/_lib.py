@@ -24,7 +24,7 @@ class LstmFwdDesc(ctypes.Structure):
         ("x", c_f), ("lengths", c_f),
         ("w_ih", c_f * 2), ("w_hh", c_f * 2), ("b_ih", c_f * 2), ("b_hh", c_f * 2),
         ("y", c_f), ("h_n", c_f), ("c_n", c_f),
-        ("gx", c_f), ("gates", c_f), ("cs", c_f),
+        ("gx", c_f), ("gates", c_f), ("cs", c_f), ("ws", c_f),
         ("B", ctypes.c_int32), ("T", ctypes.c_int32), ("I", ctypes.c_int32), ("H", ctypes.c_int32),
     ]
 
@@ -34,7 +34,7 @@ class LstmBwdDesc(ctypes.Structure):
     _fields_ = [
         ("d_y", c_f), ("d_hn", c_f), ("x", c_f), ("y", c_f), ("lengths", c_f),
         ("w_ih", c_f * 2), ("w_hh", c_f * 2), ("gates", c_f), ("cs", c_f),
-        ("d_x", c_f), ("d_w_ih", c_f), ("d_w_hh", c_f), ("d_b", c_f), ("d_a", c_f), ("d_w_cat", c_f),
+        ("d_x", c_f), ("d_w_ih", c_f), ("d_w_hh", c_f), ("d_b", c_f), ("d_a", c_f), ("d_w_cat", c_f), ("ws", c_f),
         ("B", ctypes.c_int32), ("T", ctypes.c_int32), ("I", ctypes.c_int32), ("H", ctypes.c_int32),
     ]
 
@@ -53,12 +53,14 @@ SIGNATURES = {
     "mmb_bilstm_layer_bwd": (c_i, [ctypes.POINTER(LstmBwdDesc), c_i, c_i, c_f]),
     "mmb_gemm_f32": (c_i, [c_f] * 4 + [c_i] * 10 + [c_f]),
     "mmb_set_gemm_mode": (c_i, [c_i]),
+    "mmb_bilstm_ws_bytes": (ctypes.c_size_t, [c_i] * 5),
+    "mmb_gemm_nt_planes": (c_i, [c_f] * 4 + [c_i] * 3 + [c_f, ctypes.c_size_t, c_i, c_f]),
 }
 
 # kernel ids of the opt-in timing hook (enum in include/mmbidaf.h)
 KERNEL_IDS = {n: i for i, n in enumerate(
     ["att_rank1", "att_col", "att_combine", "att_row", "att_bwd_pre", "att_bwd_j1", "att_bwd_j2", "att_bwd_jfin",
-     "att_bwd_i", "gemm", "lstm_rec_fwd", "lstm_rec_bwd"])}
+     "att_bwd_i", "gemm", "lstm_rec_fwd", "lstm_rec_bwd", "split"])}
 
 _lib = None
 

@@ -612,10 +612,11 @@ __global__ __launch_bounds__(NW * 64) void att_bwd_j2_kernel(const AttBwdArgs a)
 
 // j-side epilogue: one wave per JF_ROWS modality rows, lane = 4 features.  Sums the split partials, writes
 //   d_mod_d_j = dc_j w_m + w_tm * dmodd_j ;  d_mod_j = dmodc_j (+ d_mod_d_j when folded)
-// and accumulates d_w_m += sum_j dc_j mod_d[j,:] (registers, then LDS across the 4 waves, then one atomic per feature).
-constexpr int JF_ROWS = 2;
+// and accumulates d_w_m += sum_j dc_j mod_d[j,:]: registers over the wave's rows, LDS across the 4 waves, then ONE
+// atomic per feature and workgroup with consecutive lanes on consecutive addresses.
+constexpr int JF_ROWS = 4;
 __global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a, int B) {
-    __shared__ f4 wred[4][64];
+    __shared__ float wred[4][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int chunk = blockIdx.x * 4 + wave;
     const int M = a.M, D = a.D, S = a.splits;
@@ -632,6 +633,7 @@ __global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a, i
             const int b = row / M, n = row % M;
             float dc = 0.f;
             f4 c = f4{0.f, 0.f, 0.f, 0.f}, dd = c;
+#pragma unroll 4
             for (int p = 0; p < S; ++p) {
                 const size_t prow = ((size_t)b * S + p) * M + n;
                 dc += a.p_dc1[prow] + a.p_dc2[prow];
@@ -653,15 +655,10 @@ __global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a, i
             }
         }
     }
-    wred[wave][lane] = wacc;
+    *reinterpret_cast<f4*>(&wred[wave][d]) = wacc;
     __syncthreads();
-    if (wave == 0 && din) {
-        const f4 t = wred[0][lane] + wred[1][lane] + wred[2][lane] + wred[3][lane];
-        atomicAdd(a.d_w_m + d + 0, t.x);
-        atomicAdd(a.d_w_m + d + 1, t.y);
-        atomicAdd(a.d_w_m + d + 2, t.z);
-        atomicAdd(a.d_w_m + d + 3, t.w);
-    }
+    const int t = threadIdx.x;
+    if (t < D) atomicAdd(a.d_w_m + t, (wred[0][t] + wred[1][t]) + (wred[2][t] + wred[3][t]));
 }
 
 // i-side pass (lane side = text rows i, streams all modality rows j):

@@ -87,4 +87,34 @@ int gemm_bf16_launch(const GemmArgs& g, int ns, hipStream_t stream);
 int gemm_mode();
 void set_gemm_mode(int mode);
 
+
+// ---- operand planes (planes.hip)
+typedef __bf16 bf16_t;
+struct SplitRowsArgs {
+    const float* src1; const float* src2; int R1;
+    int R, C, ld, Cp, gate_H;
+    bf16_t* planes; size_t plane_stride;
+    const float* b1a; const float* b2a; const float* b1b; const float* b2b;
+    float* bias_out;
+};
+struct SplitTArgs {
+    int nseg;
+    const float* seg_ptr[3];
+    int seg_ld[3], seg_cols[3], seg_shift[3];
+    int R, period, Rp, Ctot;
+    bf16_t* planes; size_t plane_stride;
+    const float* stack_ptr; int stack_R1;
+};
+struct PlanesGemmArgs {
+    const bf16_t* A; size_t a_plane; int lda;
+    const bf16_t* B; size_t b_plane; int ldb;
+    float* C; int ldc;
+    const float* bias;
+    int M, N, K;
+    int accumulate;
+};
+int planes_split_rows(const SplitRowsArgs& a, hipStream_t stream);
+int planes_split_transpose(const SplitTArgs& a, hipStream_t stream);
+int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream);
+
 }  // namespace mmb

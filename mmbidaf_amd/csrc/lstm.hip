@@ -377,6 +377,63 @@ __global__ __launch_bounds__(256) void lstm_unpack_dw_kernel(const float* __rest
     else if (col - I >= dir * H && col - I < (dir + 1) * H) d_w_hh[(size_t)row * H + (col - I - dir * H)] = v;
 }
 
+
+// ---- operand-plane scratch layout (planes.hip): byte offsets inside desc.ws
+static size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static bool planes_ok(int I, int H) { return I % 4 == 0 && H % 4 == 0 && gemm_mode() != 0; }
+struct WsFwd { size_t xP, wP, bias, total; int Ip; };
+static WsFwd ws_fwd_layout(long BT, int I, int H) {
+    WsFwd w{};
+    w.Ip = (int)rup(I, 32);
+    size_t o = 0;
+    w.xP = o;   o += rup((size_t)3 * BT * w.Ip * 2, 256);
+    w.wP = o;   o += rup((size_t)3 * 8 * H * w.Ip * 2, 256);
+    w.bias = o; o += rup((size_t)8 * H * 4, 256);
+    w.total = o;
+    return w;
+}
+struct WsBwd { size_t daP, daT, xcT, wT, total; int K8, BTp; };
+static WsBwd ws_bwd_layout(long BT, int I, int H) {
+    WsBwd w{};
+    w.K8 = (int)rup(8 * H, 32);
+    w.BTp = (int)rup(BT, 32);
+    size_t o = 0;
+    w.daP = o; o += rup((size_t)3 * BT * w.K8 * 2, 256);
+    w.daT = o; o += rup((size_t)3 * 8 * H * w.BTp * 2, 256);
+    w.xcT = o; o += rup((size_t)3 * (I + 2 * H) * w.BTp * 2, 256);
+    w.wT = o;  o += rup((size_t)3 * I * w.K8 * 2, 256);
+    w.total = o;
+    return w;
+}
+
+// Gx (BT, 8H gate-interleaved) = x . [W_ih_f ; W_ih_r]^T + b_ih + b_hh  through the operand planes: ONE GEMM per problem
+static int gx_planes(const mmb_lstm_fwd_desc& p, hipStream_t stream) {
+    const int H = p.H;
+    const long BT = (long)p.B * p.T;
+    const WsFwd L = ws_fwd_layout(BT, p.I, H);
+    char* ws = static_cast<char*>(p.ws);
+    bf16_t* xP = reinterpret_cast<bf16_t*>(ws + L.xP);
+    bf16_t* wP = reinterpret_cast<bf16_t*>(ws + L.wP);
+    float* bias = reinterpret_cast<float*>(ws + L.bias);
+    SplitRowsArgs sx{};
+    sx.src1 = p.x; sx.src2 = p.x; sx.R1 = (int)BT; sx.R = (int)BT; sx.C = p.I; sx.ld = p.I; sx.Cp = L.Ip; sx.gate_H = 0;
+    sx.planes = xP; sx.plane_stride = (size_t)BT * L.Ip;
+    if (int rc = planes_split_rows(sx, stream)) return rc;
+    SplitRowsArgs sw{};
+    sw.src1 = p.w_ih[0]; sw.src2 = p.w_ih[1]; sw.R1 = 4 * H; sw.R = 8 * H; sw.C = p.I; sw.ld = p.I; sw.Cp = L.Ip; sw.gate_H = H;
+    sw.planes = wP; sw.plane_stride = (size_t)8 * H * L.Ip;
+    sw.b1a = p.b_ih[0]; sw.b2a = p.b_hh[0]; sw.b1b = p.b_ih[1]; sw.b2b = p.b_hh[1]; sw.bias_out = bias;
+    if (int rc = planes_split_rows(sw, stream)) return rc;
+    PlanesGemmArgs g{};
+    g.A = xP; g.a_plane = sx.plane_stride; g.lda = L.Ip;
+    g.B = wP; g.b_plane = sw.plane_stride; g.ldb = L.Ip;
+    g.C = p.gx; g.ldc = 8 * H; g.bias = bias; g.M = (int)BT; g.N = 8 * H; g.K = L.Ip;
+    return planes_gemm(g, stream);
+}
+
+// weight and input gradients of one problem through the operand planes: 4 split passes + 2 GEMMs (+ unpack)
+static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream);
+
 template <typename ArgsT, typename K>
 static int launch_rec(K kernel, const ArgsT& a, int total_wgs, int H, hipStream_t stream, int kid) {
     const int threads = ((16 * ((H + 3) / 4) + 63) / 64) * 64;  // >= 4H, whole waves (both kernels' layouts)
@@ -393,9 +450,69 @@ static int kq_for(int H) {
     return 32;
 }
 
+
+static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream) {
+    const int H = p.H, I = p.I;
+    const long BT = (long)p.B * p.T;
+    const WsBwd L = ws_bwd_layout(BT, I, H);
+    char* ws = static_cast<char*>(p.ws);
+    bf16_t* daP = reinterpret_cast<bf16_t*>(ws + L.daP);
+    bf16_t* daT = reinterpret_cast<bf16_t*>(ws + L.daT);
+    bf16_t* xcT = reinterpret_cast<bf16_t*>(ws + L.xcT);
+    bf16_t* wT = reinterpret_cast<bf16_t*>(ws + L.wT);
+    // d_a^T planes (8H x BT): A operand of the weight-gradient GEMM
+    SplitTArgs ta{};
+    ta.nseg = 1; ta.seg_ptr[0] = p.d_a; ta.seg_ld[0] = 8 * H; ta.seg_cols[0] = 8 * H; ta.seg_shift[0] = 0;
+    ta.R = (int)BT; ta.period = 1; ta.Rp = L.BTp; ta.Ctot = 8 * H; ta.planes = daT; ta.plane_stride = (size_t)8 * H * L.BTp;
+    if (int rc = planes_split_transpose(ta, stream)) return rc;
+    // [x | y_fwd(t-1) | y_rev(t+1)]^T planes ((I+2H) x BT): h_prev is y shifted by one step inside each sample
+    SplitTArgs tx{};
+    tx.nseg = 3;
+    tx.seg_ptr[0] = p.x;     tx.seg_ld[0] = I;     tx.seg_cols[0] = I; tx.seg_shift[0] = 0;
+    tx.seg_ptr[1] = p.y;     tx.seg_ld[1] = 2 * H; tx.seg_cols[1] = H; tx.seg_shift[1] = -1;
+    tx.seg_ptr[2] = p.y + H; tx.seg_ld[2] = 2 * H; tx.seg_cols[2] = H; tx.seg_shift[2] = +1;
+    tx.R = (int)BT; tx.period = p.T; tx.Rp = L.BTp; tx.Ctot = I + 2 * H; tx.planes = xcT; tx.plane_stride = (size_t)(I + 2 * H) * L.BTp;
+    if (int rc = planes_split_transpose(tx, stream)) return rc;
+    {
+        PlanesGemmArgs g{};
+        g.A = daT; g.a_plane = ta.plane_stride; g.lda = L.BTp;
+        g.B = xcT; g.b_plane = tx.plane_stride; g.ldb = L.BTp;
+        g.C = p.d_w_cat; g.ldc = I + 2 * H; g.M = 8 * H; g.N = I + 2 * H; g.K = L.BTp;
+        if (int rc = planes_gemm(g, stream)) return rc;
+        const int total = 8 * H * (I + 2 * H);
+        ProfScope ps_(MMB_K_GEMM, stream);
+        hipLaunchKernelGGL(lstm_unpack_dw_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.d_w_cat, p.d_w_ih, p.d_w_hh, H, I);
+        MMB_HIP(hipGetLastError());
+    }
+    if (p.d_x) {
+        // d_x (BT, I) = d_a (BT x 8H) . [W_ih_f ; W_ih_r] (8H x I): one GEMM over both directions
+        SplitRowsArgs sa{};
+        sa.src1 = p.d_a; sa.src2 = p.d_a; sa.R1 = (int)BT; sa.R = (int)BT; sa.C = 8 * H; sa.ld = 8 * H; sa.Cp = L.K8; sa.gate_H = 0;
+        sa.planes = daP; sa.plane_stride = (size_t)BT * L.K8;
+        if (int rc = planes_split_rows(sa, stream)) return rc;
+        SplitTArgs tw{};
+        tw.nseg = 1; tw.seg_ptr[0] = p.w_ih[0]; tw.seg_ld[0] = I; tw.seg_cols[0] = I; tw.seg_shift[0] = 0;
+        tw.stack_ptr = p.w_ih[1]; tw.stack_R1 = 4 * H;
+        tw.R = 8 * H; tw.period = 1; tw.Rp = L.K8; tw.Ctot = I; tw.planes = wT; tw.plane_stride = (size_t)I * L.K8;
+        if (int rc = planes_split_transpose(tw, stream)) return rc;
+        PlanesGemmArgs g{};
+        g.A = daP; g.a_plane = sa.plane_stride; g.lda = L.K8;
+        g.B = wT; g.b_plane = tw.plane_stride; g.ldb = L.K8;
+        g.C = p.d_x; g.ldc = I; g.M = (int)BT; g.N = I; g.K = L.K8;
+        if (int rc = planes_gemm(g, stream)) return rc;
+    }
+    return MMB_OK;
+}
+
 }  // namespace mmb
 
 using namespace mmb;
+
+extern "C" size_t mmb_bilstm_ws_bytes(int B, int T, int I, int H, int backward) {
+    if (B < 1 || T < 1 || I < 1 || H < 1 || I % 4 || H % 4) return 0;
+    const long BT = (long)B * T;
+    return backward ? ws_bwd_layout(BT, I, H).total : ws_fwd_layout(BT, I, H).total;
+}
 
 extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -411,17 +528,23 @@ extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int devic
         MMB_REQUIRE(p.H >= 1 && p.H <= MMB_LSTM_MAX_H, "H=%d unsupported (max %d)", p.H, MMB_LSTM_MAX_H);
         MMB_REQUIRE(p.B >= 1 && p.T >= 1 && p.I >= 1, "bad LSTM sizes B=%d T=%d I=%d", p.B, p.T, p.I);
         MMB_REQUIRE(p.x && p.lengths && p.y && p.h_n && p.c_n && p.gx && p.gates && p.cs, "null pointer in desc %d", i);
-        // input projection, both directions: Gx[:, dir] = x . W_ih[dir]^T + b_ih[dir] + b_hh[dir]
-        for (int dir = 0; dir < 2; ++dir) {
+        for (int dir = 0; dir < 2; ++dir)
             MMB_REQUIRE(p.w_ih[dir] && p.w_hh[dir] && p.b_ih[dir] && p.b_hh[dir], "null weight in desc %d", i);
-            GemmArgs g{};
-            g.A = p.x; g.B = p.w_ih[dir]; g.C = p.gx + (size_t)dir * 4 * H;
-            g.bias = p.b_ih[dir]; g.bias2 = p.b_hh[dir];
-            g.M = p.B * p.T; g.N = 4 * H; g.K = p.I;
-            g.lda = p.I; g.ldb = p.I; g.ldc = 8 * H;
-            g.ta = 0; g.tb = 1; g.accumulate = 0; g.gate_H = H; g.shiftB = 0; g.periodB = 1;
-            const int rc = gemm_launch(g, stream);
+        if (p.ws && planes_ok(p.I, H)) {
+            const int rc = gx_planes(p, stream);
             if (rc) return rc;
+        } else {
+            // input projection, one GEMM per direction: Gx[:, dir] = x . W_ih[dir]^T + b_ih[dir] + b_hh[dir]
+            for (int dir = 0; dir < 2; ++dir) {
+                GemmArgs g{};
+                g.A = p.x; g.B = p.w_ih[dir]; g.C = p.gx + (size_t)dir * 4 * H;
+                g.bias = p.b_ih[dir]; g.bias2 = p.b_hh[dir];
+                g.M = p.B * p.T; g.N = 4 * H; g.K = p.I;
+                g.lda = p.I; g.ldb = p.I; g.ldc = 8 * H;
+                g.ta = 0; g.tb = 1; g.accumulate = 0; g.gate_H = H; g.shiftB = 0; g.periodB = 1;
+                const int rc = gemm_launch(g, stream);
+                if (rc) return rc;
+            }
         }
         RecFwdProb& q = ra.p[i];
         q.gx = p.gx; q.w_hh[0] = p.w_hh[0]; q.w_hh[1] = p.w_hh[1]; q.len = p.lengths;
@@ -479,6 +602,11 @@ extern "C" int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* d, int n, int devic
     for (int i = 0; i < n; ++i) {
         const mmb_lstm_bwd_desc& p = d[i];
         const int BT = p.B * p.T;
+        if (p.ws && p.d_w_cat && planes_ok(p.I, H)) {
+            rc = grads_planes(p, stream);
+            if (rc) return rc;
+            continue;
+        }
         bool fused = false;
         if (p.d_w_cat) {
             // ONE GEMM for all weight gradients of the layer: d_a^T (8H x BT) . [x | y_fwd(t-1) | y_rev(t+1)] (BT x (I+2H)).

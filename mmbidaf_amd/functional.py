@@ -133,12 +133,12 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         keep, outs, saved = [], [], []
         dev = flat[0].device
         for i in range(n):
-            x, *ws = flat[i * _PER_PROBLEM:(i + 1) * _PER_PROBLEM]
-            _require_gpu(x, *ws)
+            x, *ws_ = flat[i * _PER_PROBLEM:(i + 1) * _PER_PROBLEM]
+            _require_gpu(x, *ws_)
             x = _f32c(x)
-            ws = [_f32c(w) for w in ws]
+            ws_ = [_f32c(w) for w in ws_]
             B, T, I = x.shape
-            H = ws[1].shape[1]
+            H = ws_[1].shape[1]
             if H > _lib.LSTM_MAX_H:
                 raise RuntimeError(f"mmbidaf_amd: hidden size {H} > {_lib.LSTM_MAX_H} not supported by this build")
             y = torch.empty(B, T, 2 * H, device=dev, dtype=torch.float32)
@@ -147,16 +147,18 @@ class _BiLSTMLayerFn(torch.autograd.Function):
             gx = torch.empty(B, T, 8 * H, device=dev, dtype=torch.float32)
             gates = torch.empty(B, T, 8 * H, device=dev, dtype=torch.float32)
             cs = torch.empty(B, T, 2 * H, device=dev, dtype=torch.float32)
+            ws = torch.empty(lib.mmb_bilstm_ws_bytes(B, T, I, H, 0), device=dev, dtype=torch.uint8)
             d = descs[i]
             d.x, d.lengths = _ptr(x), _ptr(lengths_dev[i])
             for k in range(2):
-                d.w_ih[k], d.w_hh[k], d.b_ih[k], d.b_hh[k] = (_ptr(ws[4 * k]), _ptr(ws[4 * k + 1]),
-                                                              _ptr(ws[4 * k + 2]), _ptr(ws[4 * k + 3]))
+                d.w_ih[k], d.w_hh[k], d.b_ih[k], d.b_hh[k] = (_ptr(ws_[4 * k]), _ptr(ws_[4 * k + 1]),
+                                                              _ptr(ws_[4 * k + 2]), _ptr(ws_[4 * k + 3]))
             d.y, d.h_n, d.c_n, d.gx, d.gates, d.cs = _ptr(y), _ptr(h_n), _ptr(c_n), _ptr(gx), _ptr(gates), _ptr(cs)
+            d.ws = _ptr(ws) if ws.numel() else None
             d.B, d.T, d.I, d.H = B, T, I, H
-            keep += [x, gx, c_n] + ws
+            keep += [x, gx, c_n, ws] + ws_
             outs += [y, h_n]
-            saved += [x, y, gates, cs, ws[0], ws[1], ws[4], ws[5], lengths_dev[i]]
+            saved += [x, y, gates, cs, ws_[0], ws_[1], ws_[4], ws_[5], lengths_dev[i]]
         rc = lib.mmb_bilstm_layer_fwd(descs, n, dev.index, _stream())
         _lib.check(rc, "mmb_bilstm_layer_fwd")
         ctx.n = n
@@ -185,14 +187,16 @@ class _BiLSTMLayerFn(torch.autograd.Function):
             d_b = torch.empty(2, 4 * H, device=dev, dtype=torch.float32)
             d_a = torch.empty(B, T, 8 * H, device=dev, dtype=torch.float32)
             d_w_cat = torch.empty(8 * H, I + 2 * H, device=dev, dtype=torch.float32)
+            ws = torch.empty(lib.mmb_bilstm_ws_bytes(B, T, I, H, 1), device=dev, dtype=torch.uint8)
             d = descs[i]
             d.d_y, d.d_hn, d.x, d.y, d.lengths = _ptr(d_y), _ptr(d_hn), _ptr(x), _ptr(y), _ptr(lens)
             d.w_ih[0], d.w_ih[1], d.w_hh[0], d.w_hh[1] = _ptr(w_ih_f), _ptr(w_ih_r), _ptr(w_hh_f), _ptr(w_hh_r)
             d.gates, d.cs = _ptr(gates), _ptr(cs)
             d.d_x, d.d_w_ih, d.d_w_hh, d.d_b, d.d_a = _ptr(d_x), _ptr(d_w_ih), _ptr(d_w_hh), _ptr(d_b), _ptr(d_a)
             d.d_w_cat = _ptr(d_w_cat)
+            d.ws = _ptr(ws) if ws.numel() else None
             d.B, d.T, d.I, d.H = B, T, I, H
-            keep += [d_y, d_hn, d_a, d_w_cat]
+            keep += [d_y, d_hn, d_a, d_w_cat, ws]
             results += [d_x, d_w_ih[0], d_w_hh[0], d_b[0], d_b[0], d_w_ih[1], d_w_hh[1], d_b[1], d_b[1]]
         rc = lib.mmb_bilstm_layer_bwd(descs, n, dev.index, _stream())
         _lib.check(rc, "mmb_bilstm_layer_bwd")
@@ -221,4 +225,19 @@ def gemm(a, b, bias=None, ta=False, tb=False):
     rc = lib.mmb_gemm_f32(_ptr(a), _ptr(b), _ptr(c), _ptr(bias), M, N, K, a.stride(0), b.stride(0), N,
                           int(ta), int(tb), 0, a.device.index, _stream())
     _lib.check(rc, "mmb_gemm_f32")
+    return c
+
+
+def gemm_nt_planes(a, b, bias=None):
+    """C = a (M,K) . b (N,K)^T (+bias) through the operand-plane path (tests / tools)."""
+    lib = _lib.load()
+    _require_gpu(a, b)
+    a, b = _f32c(a), _f32c(b)
+    M, K = a.shape
+    N = b.shape[0]
+    Kp = (K + 31) // 32 * 32
+    ws = torch.empty(6 * (M + N) * Kp, device=a.device, dtype=torch.uint8)
+    c = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    rc = lib.mmb_gemm_nt_planes(_ptr(a), _ptr(b), _ptr(c), _ptr(bias), M, N, K, _ptr(ws), ws.numel(), a.device.index, _stream())
+    _lib.check(rc, "mmb_gemm_nt_planes")
     return c

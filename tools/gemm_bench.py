@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT)
 import torch
 
 from mmbidaf_amd import functional as MF
+from mmbidaf_amd import _lib
 
 dev = torch.device("cuda:0")
 SHAPES = [  # (name, M, N, K, ta, tb)
@@ -51,3 +52,26 @@ for name, M, N, K, ta, tb in SHAPES:
     fl = 2.0 * M * N * K
     print(f"{name}  {M:6d}x{N:4d}x{K:6d}  mine {t_mine*1e6:8.1f} us {fl/t_mine/1e12:6.1f} TF | torch.mm {t_ref*1e6:8.1f} us "
           f"{fl/t_ref/1e12:6.1f} TF | relerr {err:.1e}")
+
+print("== operand-plane path (NT form of the same products; kernel-only time from the library's event hook)")
+for name, M, N, K, ta, tb in SHAPES:
+    if ta:   # weight-gradient shapes run as NT on transposed planes: (M, K) x (N, K)
+        pass
+    a = torch.randn(M, K, device=dev)
+    b = torch.randn(N, K, device=dev)
+    ref = a @ b.t()
+    got = MF.gemm_nt_planes(a, b)
+    err = (got - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    for _ in range(3):
+        MF.gemm_nt_planes(a, b)
+    torch.cuda.synchronize()
+    _lib.profile_enable(["gemm", "split"])
+    for _ in range(10):
+        MF.gemm_nt_planes(a, b)
+    torch.cuda.synchronize()
+    _lib.profile_enable([])
+    gms, gn, _ = _lib.profile_read("gemm")
+    sms, sn, _ = _lib.profile_read("split")
+    fl = 2.0 * M * N * K
+    t = gms / gn * 1e-3
+    print(f"{name}  {M:6d}x{N:4d}x{K:6d}  planes gemm {t*1e6:8.1f} us {fl/t/1e12:6.1f} TF (+ splits {sms/10*1e3:6.1f} us) | relerr {err:.1e}")
