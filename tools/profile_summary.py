@@ -74,9 +74,10 @@ def pmc(d, cfg="cfg2"):
         old = json.load(open(path)) if os.path.exists(path) else {}
         parts = old.setdefault(cfg, {}).setdefault("_parts", {})
         for k, v in traffic.items():
-            parts.setdefault(k, {}).update(v)
-            if "fetch_bytes_corrected" in parts[k] and "write_bytes" in parts[k]:
-                old[cfg][k] = parts[k]["fetch_bytes_corrected"] + parts[k]["write_bytes"]
+            stem = re.sub(r"<.*$", "", k)            # bench.py looks kernels up by their symbol stem
+            parts.setdefault(stem, {}).update(v)
+            if "fetch_bytes_corrected" in parts[stem] and "write_bytes" in parts[stem]:
+                old[cfg][stem] = parts[stem]["fetch_bytes_corrected"] + parts[stem]["write_bytes"]
         json.dump(old, open(path, "w"), indent=1, sort_keys=True)
 
 
