@@ -136,6 +136,8 @@ def main():
         # dominant attention kernel = the row pass; its launches alternate text<->audio / text<->image
         bytes_row = sum(4 * B * (5 * T * D + 2 * M * D) for M in (Ma, Mi)) / 2.0   # per launch, averaged over the two
         flops_row = sum(2 * B * T * M * (208 + 2 * 208) for M in (Ma, Mi)) / 2.0     # S + 2 PV products at the padded D
+        # (PMC `traffic`: profiles/pmc_traffic.json = FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch, from separate
+        #  rocprofv3 --pmc passes of this same command: tools/profile_summary.py)
         avg_s = ms_row / max(n_row, 1) * 1e-3
         achieved = bytes_row / avg_s / 1e9
         traffic = None
@@ -152,6 +154,8 @@ def main():
             "value": round(world * B * a.steps / dt, 2), "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "arithmetic": "fp32 throughout: attention and recurrences on exact-f32 MFMA / VALU; LSTM projection and gradient GEMMs "
+                          "on bf16 MFMA from exact 3-term splits of the fp32 operands (6 cross products, fp32 accumulate, ~1e-7 rel. error)",
             "config": {"workload": f"{a.config}: hot-path region (3 BiLSTM enc -> 2 BiDAF att -> 2 two-layer BiLSTM) "
                                    f"B={B}/GPU T_text={T} T_aud={Ma} T_img={Mi} H={H}, "
                                    f"{'ragged U{n/2..n}' if a.ragged else 'full'} lengths, fwd+bwd"

@@ -54,6 +54,32 @@ def test_gemm(M, N, K, ta, tb):
     close(got, ref.float(), "gemm", tol=2e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 400, 100), (1000, 800, 800), (800, 1000, 1300), (64, 8, 12)])
+def test_gemm_operand_planes(M, N, K):
+    """split passes + bf16 6-product kernel: fp32-level accuracy against an fp64 reference."""
+    from mmbidaf_amd import functional as MF
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    ref = (a.double() @ b.double().t() + bias.double()).float()
+    got = MF.gemm_nt_planes(a.to(dev()), b.to(dev()), bias.to(dev()))
+    close(got, ref, "planes gemm", tol=2e-5)
+
+
+def test_gemm_modes_agree():
+    """the exact-f32 MFMA kernels and the split-bf16 kernels are interchangeable to fp32 accuracy."""
+    from mmbidaf_amd import _lib, functional as MF
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(512, 800, generator=g).to(dev()), torch.randn(400, 800, generator=g).to(dev())
+    lib = _lib.load()
+    outs = []
+    for mode in (0, 3, 1):
+        _lib.check(lib.mmb_set_gemm_mode(mode), "mmb_set_gemm_mode")
+        outs.append(MF.gemm(a, b, tb=True).cpu())
+    ref = (a.double() @ b.double().t()).float().cpu()
+    for o in outs:
+        close(o, ref, "gemm mode", tol=2e-5)
+
+
 # ------------------------------------------------------------------------------------------- attention
 def _run_att(c, drop=None):
     from mmbidaf_amd import functional as MF
