@@ -171,6 +171,23 @@ def test_attention_full_size_properties():
     close(out[sl], ref, "out slice")
 
 
+def test_attention_long_sequence_cfg4_size():
+    """cfg4 lengths (T=1600, M=1024, D=200): the similarity (209.7 MB per batch of 32 in the reference) is never
+    materialised; one sample against the oracle, forward and backward, ragged."""
+    c, _ = _random_att_case(77, 2, 1600, 1024, 200, False)
+    t_ = c["text"].clone().requires_grad_(True)
+    m_ = c["mod"].clone().requires_grad_(True)
+    ps = [c[k].clone().requires_grad_(True) for k in ("w_t", "w_m", "w_tm", "bias")]
+    ref = O.bidaf_attention(t_, m_, c["text_mask"], c["mod_mask"], *ps)
+    (ref * c["cot"]).sum().backward()
+    out, dt, dm, dps = _run_att(c)
+    close(out, ref, "out")
+    close(dt, t_.grad, "d_text")
+    close(dm, m_.grad, "d_mod")
+    for k, g, p in zip(("d_w_t", "d_w_m", "d_w_tm"), dps, ps):
+        close(g, p.grad, k)
+
+
 def test_attention_rejects_bad_width():
     from mmbidaf_amd import functional as MF
     d = dev()
@@ -255,6 +272,23 @@ def test_modelling_encoder_vs_oracle():
     close(xd.grad, dxr, "d_x")
     for n, p in e.named_parameters():
         close(p.grad, P[n[4:]].grad, "grad " + n)
+
+
+def test_rnn_encoder_long_sequence_cfg4_size():
+    """T=1600 (cfg4): y / h_n of a 1-layer encoder against torch's packed nn.LSTM (the oracle's aten path), ragged."""
+    from layers.encoding import RNNEncoder
+    torch.manual_seed(11)
+    e = RNNEncoder(100, 100, 1).to(dev())
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(4, 1600, 100, generator=g)
+    l = [1600, 801, 1333, 7]
+    y, h = e(x.to(dev()), l)
+    rnn = torch.nn.LSTM(100, 100, 1, batch_first=True, bidirectional=True)
+    rnn.load_state_dict({k[4:]: v.cpu() for k, v in e.state_dict().items()})
+    with torch.no_grad():
+        yr, hr = O.rnn_encoder_aten(x, l, rnn)
+    close(y, yr, "y")
+    close(h, hr, "h_n")
 
 
 def test_lstm_time_reversal_property_full_size():
