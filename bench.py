@@ -83,6 +83,7 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the hot path"
+    local = local % torch.cuda.device_count()   # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.load()

@@ -12,6 +12,8 @@
 //                workgroup 4 waves x (MT*16) x (NT*16), K tile 32, LDS-DMA (global_load_lds_dwordx4) into a
 //                double-buffered, XOR-swizzled [plane][row][64 B] image (swizzle applied on the per-lane SOURCE
 //                address, LDS destination linear), next tile's DMA in flight under the current tile's 6*MT*NT MFMAs.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mmb {
@@ -110,7 +112,9 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTArgs a
 // ------------------------------------------------------------------------------------------ GEMM on planes
 __device__ __forceinline__ int pl_swz(int row) { return ((row >> 3) & 1) << 1; }
 
-template <int MT, int NT>
+// STAGES = 2: next tile's DMA in flight under this tile's MFMAs (1 workgroup per CU at the large tiles);
+// STAGES = 1: DMA, wait, multiply -- latency is hidden across the 2-3 workgroups that then fit on a CU.
+template <int MT, int NT, int STAGES>
 __global__ __launch_bounds__(256) void gemm_planes_kernel(const PlanesGemmArgs g, const int kchunk) {
     constexpr int BM = 4 * MT * 16, BN = NT * 16, RT = BM + BN;  // rows per plane image
     constexpr int STAGE = 3 * RT * 64;                           // bytes per stage
@@ -168,30 +172,22 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(const PlanesGemmArgs g
         offB[j] = (BM + tr) * 64 + ((kg ^ pl_swz(tr)) << 4);
     }
 
-    int stage = 0;
-    if (kb < ke) {
-#pragma unroll
-        for (int k = 0; k < PER_WAVE; ++k) dma_piece(0, k);
-    }
-    __syncthreads();
-    constexpr int DPJ = (PER_WAVE + NT - 1) / NT;  // DMA pieces issued per n-tile of MFMAs
-    for (int k0 = kb; k0 < ke; k0 += 32) {
-        const bool more = k0 + 32 < ke;
-        const char* img = smem + stage * STAGE;
+    auto multiply = [&](const char* img, int next_stage, bool more) {
         bf16x8 a[MT][3];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int s = 0; s < 3; ++s) a[i][s] = *reinterpret_cast<const bf16x8*>(img + s * (RT * 64) + offA[i]);
+        constexpr int DPJ = (PER_WAVE + NT - 1) / NT;  // DMA pieces issued per n-tile of MFMAs
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             bf16x8 b[3];
 #pragma unroll
             for (int s = 0; s < 3; ++s) b[s] = *reinterpret_cast<const bf16x8*>(img + s * (RT * 64) + offB[j]);
-            if (more) {
+            if (STAGES == 2 && more) {
 #pragma unroll
                 for (int d = 0; d < DPJ; ++d)
-                    if (j * DPJ + d < PER_WAVE) dma_piece(stage ^ 1, j * DPJ + d);
+                    if (j * DPJ + d < PER_WAVE) dma_piece(next_stage, j * DPJ + d);
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -205,8 +201,28 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(const PlanesGemmArgs g
                 acc[i][j] = c;
             }
         }
-        __syncthreads();  // retires the DMA of the next stage (compiler's vmcnt(0)) and frees this one
-        stage ^= 1;
+    };
+
+    if (STAGES == 2) {
+        int stage = 0;
+        if (kb < ke) {
+#pragma unroll
+            for (int k = 0; k < PER_WAVE; ++k) dma_piece(0, k);
+        }
+        __syncthreads();
+        for (int k0 = kb; k0 < ke; k0 += 32) {
+            multiply(smem + stage * STAGE, stage ^ 1, k0 + 32 < ke);
+            __syncthreads();  // retires the DMA of the next stage (compiler's vmcnt(0)) and frees this one
+            stage ^= 1;
+        }
+    } else {
+        for (int k0 = kb; k0 < ke; k0 += 32) {
+#pragma unroll
+            for (int k = 0; k < PER_WAVE; ++k) dma_piece(0, k);
+            __syncthreads();
+            multiply(smem, 0, false);
+            __syncthreads();
+        }
     }
 
     const bool atomic = gridDim.z > 1;
@@ -250,11 +266,11 @@ int planes_split_transpose(const SplitTArgs& a, hipStream_t stream) {
     return MMB_OK;
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int STAGES>
 static int launch_planes(const PlanesGemmArgs& g, int splitk, hipStream_t stream) {
     constexpr int BM = 4 * MT * 16, BN = NT * 16;
-    const size_t lds = (size_t)2 * 3 * (BM + BN) * 64;
-    auto kern = gemm_planes_kernel<MT, NT>;
+    const size_t lds = (size_t)STAGES * 3 * (BM + BN) * 64;
+    auto kern = gemm_planes_kernel<MT, NT, STAGES>;
     static bool attr_set = false;
     if (!attr_set) {
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -270,10 +286,21 @@ static int launch_planes(const PlanesGemmArgs& g, int splitk, hipStream_t stream
 }
 
 int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream) {
+    static int tune = -2;   // MMB_PLANES_TUNE = <bm: 0 auto | 1 force 64 | 2 force 128><stages: 1 | 2>, e.g. "21" (tuning aid)
+    if (tune == -2) {
+        const char* e = getenv("MMB_PLANES_TUNE");
+        tune = e ? atoi(e) : -1;
+    }
     const bool narrow = g.N <= 112;
     const int bn = narrow ? 112 : 208;
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + bn - 1) / bn);
-    const bool small = tiles128 < 200 && g.K < 4096;
+    bool small = tiles128 < 200 && g.K < 4096;
+    int stages = 2;
+    if (tune >= 0) {
+        if (tune / 10 == 1) small = true;
+        if (tune / 10 == 2) small = false;
+        stages = (tune % 10 == 1) ? 1 : 2;
+    }
     const int bm = small ? 64 : 128;
     const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
     int splitk = 1;
@@ -287,11 +314,19 @@ int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream) {
     if (splitk > 1 && !g.accumulate)
         MMB_HIP(hipMemset2DAsync(g.C, (size_t)g.ldc * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream));
     const int cfg = (small ? 2 : 0) + (narrow ? 1 : 0);
+    if (stages == 1) {
+        switch (cfg) {
+            case 0: return launch_planes<2, 13, 1>(g, splitk, stream);
+            case 1: return launch_planes<2, 7, 1>(g, splitk, stream);
+            case 2: return launch_planes<1, 13, 1>(g, splitk, stream);
+            default: return launch_planes<1, 7, 1>(g, splitk, stream);
+        }
+    }
     switch (cfg) {
-        case 0: return launch_planes<2, 13>(g, splitk, stream);
-        case 1: return launch_planes<2, 7>(g, splitk, stream);
-        case 2: return launch_planes<1, 13>(g, splitk, stream);
-        default: return launch_planes<1, 7>(g, splitk, stream);
+        case 0: return launch_planes<2, 13, 2>(g, splitk, stream);
+        case 1: return launch_planes<2, 7, 2>(g, splitk, stream);
+        case 2: return launch_planes<1, 13, 2>(g, splitk, stream);
+        default: return launch_planes<1, 7, 2>(g, splitk, stream);
     }
 }
 

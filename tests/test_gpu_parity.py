@@ -390,3 +390,61 @@ def test_hot_region_cfg1_vs_oracle_with_dropout_training_mode():
     synth.region_loss(o2, gpu).backward()
     assert all(torch.isfinite(t).all() for t in o2)
     assert all(torch.isfinite(p.grad).all() for p in drop.parameters())
+
+
+# ------------------------------------------------------------------------------------------- fuzz
+def test_attention_fuzz_random_shapes_and_masks():
+    """random small shapes (every D that is a multiple of 4 up to 208 is legal), arbitrary 0/1 masks incl. empty ones"""
+    g = torch.Generator().manual_seed(2024)
+    for it in range(24):
+        B = int(torch.randint(1, 5, (1,), generator=g))
+        T = int(torch.randint(1, 75, (1,), generator=g))
+        M = int(torch.randint(1, 45, (1,), generator=g))
+        D = 4 * int(torch.randint(1, 53, (1,), generator=g))
+        use_drop = bool(it % 3 == 0)
+        c, drop = _random_att_case(9000 + it, B, T, M, D, use_drop)
+        c["text_mask"] = torch.rand(B, T, generator=g) > 0.3
+        c["mod_mask"] = torch.rand(B, M, generator=g) > 0.3
+        if it % 5 == 0:
+            c["text_mask"][0] = False      # fully masked sample (Q1: uniform softmax)
+            c["mod_mask"][-1] = False
+        t_ = c["text"].clone().requires_grad_(True)
+        m_ = c["mod"].clone().requires_grad_(True)
+        ps = [c[k].clone().requires_grad_(True) for k in ("w_t", "w_m", "w_tm", "bias")]
+        kw = dict(text_d=t_ * drop[0], mod_d=m_ * drop[1]) if use_drop else {}
+        ref = O.bidaf_attention(t_, m_, c["text_mask"], c["mod_mask"], *ps, **kw)
+        (ref * c["cot"]).sum().backward()
+        out, dt, dm, dps = _run_att(c, drop)
+        tag = f"[it {it}: B{B} T{T} M{M} D{D} drop={use_drop}]"
+        close(out, ref, "out " + tag)
+        close(dt, t_.grad, "d_text " + tag)
+        close(dm, m_.grad, "d_mod " + tag)
+        for k, gg, p in zip(("d_w_t", "d_w_m", "d_w_tm"), dps, ps):
+            close(gg, p.grad, k + " " + tag)
+
+
+def test_rnn_encoder_fuzz_random_shapes():
+    """random (B, T, I, H, L, lengths): H / I multiples of 4 take the operand-plane GEMMs, the others the f32 kernels"""
+    from layers.encoding import RNNEncoder
+    g = torch.Generator().manual_seed(77)
+    for it in range(16):
+        B = int(torch.randint(1, 6, (1,), generator=g))
+        T = int(torch.randint(1, 26, (1,), generator=g))
+        H = int(torch.randint(1, 34, (1,), generator=g)) if it % 2 else 4 * int(torch.randint(1, 9, (1,), generator=g))
+        I = int(torch.randint(1, 50, (1,), generator=g)) if it % 2 else 4 * int(torch.randint(1, 12, (1,), generator=g))
+        L = 1 + it % 2
+        lens = torch.randint(1, T + 1, (B,), generator=g).tolist()
+        torch.manual_seed(500 + it)
+        e = RNNEncoder(I, H, L).to(dev())
+        x = torch.randn(B, T, I, generator=g)
+        xd = x.to(dev()).requires_grad_(True)
+        y, h = e(xd, lens)
+        cy, ch = torch.randn(*y.shape, generator=g), torch.randn(*h.shape, generator=g)
+        ((y * cy.to(dev())).sum() + (h * ch.to(dev())).sum()).backward()
+        yr, hr, dxr, P = _oracle_encoder(e, x, lens, cy, ch)
+        tag = f"[it {it}: B{B} T{T} I{I} H{H} L{L} len{lens}]"
+        close(y, yr, "y " + tag)
+        close(h, hr, "h_n " + tag)
+        close(xd.grad, dxr, "d_x " + tag)
+        for n, p in e.named_parameters():
+            close(p.grad, P[n[4:]].grad, "grad " + n + " " + tag)
