@@ -118,15 +118,35 @@ __device__ __forceinline__ void decode_block(int tiles, int splits, int B, int& 
     split = slot / tiles;
 }
 
-// PV-type: O[dt] += V[m = mb*16 + 4kg + e][d = 16dt + r] * W[e]   for the m block mb of the panel
+// PV-type: O[dt] += V[m = mb*16 + 4kg + e][d = 16dt + r] * W[e]   for the m block mb of the panel.
+// Software-pipelined by hand: the 13 LDS reads of row e+1 are issued before the 13 MFMAs of row e (at one wave per
+// SIMD hipcc otherwise keeps only 1-2 reads in flight and every ~100-cycle LDS latency lands on the MFMA stream).
 __device__ __forceinline__ void pvprod(const float* panel, int mb, int r, int kg, const f4 w, side_t& O) {
     const float* v = panel + (mb * 16 + 4 * kg) * LDP + r;
+    float cur[DT], nxt[DT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        O[dt] = mfma16(v[0 * LDP + 16 * dt], w.x, O[dt]);
-        O[dt] = mfma16(v[1 * LDP + 16 * dt], w.y, O[dt]);
-        O[dt] = mfma16(v[2 * LDP + 16 * dt], w.z, O[dt]);
-        O[dt] = mfma16(v[3 * LDP + 16 * dt], w.w, O[dt]);
+    for (int dt = 0; dt < DT; ++dt) cur[dt] = v[16 * dt];
+    __builtin_amdgcn_sched_group_barrier(0x100, DT, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (e < 3) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) nxt[dt] = v[(e + 1) * LDP + 16 * dt];
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) O[dt] = mfma16(cur[dt], w[e], O[dt]);
+        if (e < 3) {
+            // one MFMA, then one read of the next row, ... : reads ride under the MFMAs
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) cur[dt] = nxt[dt];
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, DT, 0);
+        }
     }
 }
 
@@ -193,11 +213,13 @@ struct AttFwdArgs {
     float* out;             // (B,N,4D)
     float* bsave;           // (B,N,D)
     int N, R, D, B, splits, rows_per_split;
+    int dbg;   // timing-only ablations (MMB_ATT_DBG, never set by the product path): 1 = skip staging, 2 = skip S, 4 = skip PV, 8 = skip the epilogue
 };
 
 // NV = 1: column pass = att_col_kernel (lane side = modality rows j, streams text rows i), produces q and the column stats.
 // NV = 2: row pass = att_row_kernel    (lane side = text rows i, streams modality rows j with values [mod | q]), produces out.
-template <int NV, int NW, int PR>
+// DB: two LDS stages -- the LDS-DMA of panel p+1 is in flight under the MFMAs of panel p (one barrier per panel)
+template <int NV, int NW, int PR, bool DB>
 __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, float* smem) {
     constexpr int NTHR = NW * 64, NB = PR / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -208,11 +230,7 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, float* smem) {
     const int n = (tile * NW + wave) * 16 + r;
 
     const bool sep_s = a.mS != a.mV0;  // dropped copy differs from the clean value panel
-    float* pV0 = smem;
-    float* pV1 = pV0 + PR * LDP;                        // only touched when NV == 2
-    float* pS = sep_s ? (pV0 + NV * PR * LDP) : pV0;
-    float* mterm_s = smem + (NV + 1) * PR * LDP;        // [PR]
-    int* mcode_s = reinterpret_cast<int*>(mterm_s + PR);  // [PR] 0 = beyond R, 1 = masked, 2 = live
+    constexpr int STAGE_F = (NV + 1) * PR * LDP;   // floats per LDS stage (panels)
 
     const float* mS_b = a.mS + (size_t)b * R * D;
     const float* mV0_b = a.mV0 + (size_t)b * R * D;
@@ -222,6 +240,17 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, float* smem) {
     load_side(side, a.side_src + (size_t)b * N * D, n, N, D, kg, a.w_tm);
     const float nterm = n < N ? a.n_term[(size_t)b * N + n] : 0.f;
 
+    if (NV == 2) {
+        // the first quarter of `out` is a verbatim copy of text (attention.py:52): written here, whole rows per
+        // wave-instruction, so that these stores overlap the main loop instead of joining the epilogue burst
+        const float* tx = a.text + (size_t)b * N * D;
+        float* oo = a.out + (size_t)b * N * 4 * D;
+        for (int rr = wave; rr < 16 * NW; rr += NW) {
+            const int gn = tile * NW * 16 + rr;
+            if (gn < N && 4 * lane < D)
+                *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 4 * lane) = *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * lane);
+        }
+    }
     side_t O0, O1;
     zero_side(O0);
     zero_side(O1);
@@ -229,23 +258,46 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, float* smem) {
 
     const int row_begin = split * a.rows_per_split;
     const int row_end = min(R, row_begin + a.rows_per_split);
-    for (int p0 = row_begin; p0 < row_end; p0 += PR) {
-        __syncthreads();
+    auto stage = [&](float* base, int p0) {
+        float* pV0 = base;
         stage_panel<NTHR, PR>(pV0, mV0_b, p0, row_end, D, tid);
-        if (NV == 2) stage_panel<NTHR, PR>(pV1, mV1_b, p0, row_end, D, tid);
-        if (sep_s) stage_panel<NTHR, PR>(pS, mS_b, p0, row_end, D, tid);
-        if (tid < PR) {
-            const int m = p0 + tid;
-            const bool in = m < row_end;
-            mterm_s[tid] = in ? a.m_term[(size_t)b * R + m] : 0.f;
-            mcode_s[tid] = in ? (a.m_mask[(size_t)b * R + m] ? 2 : 1) : 0;
-        }
+        if (NV == 2) stage_panel<NTHR, PR>(pV0 + PR * LDP, mV1_b, p0, row_end, D, tid);
+        if (sep_s) stage_panel<NTHR, PR>(pV0 + NV * PR * LDP, mS_b, p0, row_end, D, tid);
+    };
+    // per-row scalars of the streamed side for the WHOLE split, loaded once (a per-panel global load in front of the
+    // panel barrier costs a full memory round trip per panel)
+    float* mterm_all = smem + (DB ? 2 : 1) * STAGE_F;                   // [rows_per_split]
+    int* mcode_all = reinterpret_cast<int*>(mterm_all + a.rows_per_split);   // 0 = beyond R, 1 = masked, 2 = live
+    for (int i = tid; i < a.rows_per_split; i += NTHR) {
+        const int m = row_begin + i;
+        const bool in = m < row_end;
+        mterm_all[i] = in ? a.m_term[(size_t)b * R + m] : 0.f;
+        mcode_all[i] = in ? (a.m_mask[(size_t)b * R + m] ? 2 : 1) : 0;
+    }
+    int cur = 0;
+    if (DB) {
+        if (row_begin < row_end) stage(smem, row_begin);
         __syncthreads();
+    }
+    for (int p0 = row_begin; p0 < row_end; p0 += PR) {
+        float* base = smem + (DB ? cur * STAGE_F : 0);
+        if (DB) {
+            if (p0 + PR < row_end) stage(smem + (cur ^ 1) * STAGE_F, p0 + PR);
+        } else {
+            __syncthreads();
+            if (!(a.dbg & 1) || p0 == row_begin) stage(base, p0);
+            __syncthreads();
+        }
+        const float* pV0 = base;
+        const float* pV1 = pV0 + PR * LDP;                       // only touched when NV == 2
+        const float* pS = sep_s ? (pV0 + NV * PR * LDP) : pV0;
+        const float* mterm_s = mterm_all + (p0 - row_begin);
+        const int* mcode_s = mcode_all + (p0 - row_begin);
 
         f4 v[NB];
 #pragma unroll
         for (int q = 0; q < NB; ++q) v[q] = f4{0.f, 0.f, 0.f, 0.f};
-        sprodN<NB>(pS, r, kg, side, v);
+        if (!(a.dbg & 2)) sprodN<NB>(pS, r, kg, side, v);
         float bmax = -INFINITY;
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb)
@@ -259,13 +311,13 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, float* smem) {
             }
         bmax = kg_allmax(bmax);
         const float m_new = fmaxf(m_run, bmax);
-        const float alpha = expf(m_run - m_new);
+        const float alpha = __expf(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[mb][e] = expf(v[mb][e] - m_new);
+                v[mb][e] = __expf(v[mb][e] - m_new);
                 psum += v[mb][e];
             }
         l_run = l_run * alpha + psum;
@@ -279,68 +331,81 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, float* smem) {
         m_run = m_new;
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb) {
+            if (a.dbg & 4) continue;
             pvprod(pV0, mb, r, kg, v[mb], O0);
             if (NV == 2) pvprod(pV1, mb, r, kg, v[mb], O1);
         }
+        if (DB) {
+            __syncthreads();   // retires the DMA of the next stage and frees this one
+            cur ^= 1;
+        }
     }
 
+    // ---- epilogue.  The accumulators hold 16 rows x 64-B pieces per store instruction; written directly that is 16
+    // partial cache lines per instruction (measured: half of this kernel's time).  Instead each wave parks its tile in
+    // LDS (the panels are dead) and the workgroup writes whole rows: one row per wave-instruction, lane = 16-B chunk.
     const float l = kg_allsum(l_run);
-    if (n >= N) return;
-    if (NV == 1 && a.splits > 1) {
-        float* po = a.part_o + (((size_t)b * a.splits + split) * N + n) * D;
+    const bool partial = NV == 1 && a.splits > 1;
+    const float inv = partial ? 1.0f : 1.0f / l;
+    if (n < N && kg == 0) {
+        float* st = partial ? a.part_stat + (((size_t)b * a.splits + split) * N + n) * 2 : a.stat + ((size_t)b * N + n) * 2;
+        st[0] = m_run;
+        st[1] = l;
+    }
+    if (a.dbg & 8) return;   // timing-only: no epilogue
+    float* et = smem;                                   // [16*NW][LDP]
+    const int row0 = tile * NW * 16;                    // first lane-side row of this workgroup
+    const int c4 = lane;                                // this lane's 16-B chunk of a row
+    auto park = [&](const side_t& O) {
+        __syncthreads();
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const int d = 16 * dt + 4 * kg;
-            if (d < D) *reinterpret_cast<f4*>(po + d) = O0[dt];
-        }
-        if (kg == 0) {
-            float* ps = a.part_stat + (((size_t)b * a.splits + split) * N + n) * 2;
-            ps[0] = m_run;
-            ps[1] = l;
-        }
-        return;
-    }
-    const float inv = 1.0f / l;
-    if (kg == 0) {
-        a.stat[((size_t)b * N + n) * 2 + 0] = m_run;
-        a.stat[((size_t)b * N + n) * 2 + 1] = l;
-    }
+        for (int dt = 0; dt < DT; ++dt)
+            *reinterpret_cast<f4*>(et + (wave * 16 + r) * LDP + 16 * dt + 4 * kg) = O[dt] * inv;
+        __syncthreads();
+    };
+    park(O0);
     if (NV == 1) {
-        float* qo = a.q + ((size_t)b * N + n) * D;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const int d = 16 * dt + 4 * kg;
-            if (d < D) *reinterpret_cast<f4*>(qo + d) = O0[dt] * inv;
+        float* dst = partial ? a.part_o + ((size_t)b * a.splits + split) * N * D : a.q + (size_t)b * N * D;
+        for (int rr = wave; rr < 16 * NW; rr += NW) {
+            const int gn = row0 + rr;
+            if (gn < N && 4 * c4 < D) *reinterpret_cast<f4*>(dst + (size_t)gn * D + 4 * c4) = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
         }
     } else {
-        const float* tx = a.text + ((size_t)b * N + n) * D;
-        float* oo = a.out + ((size_t)b * N + n) * 4 * D;
-        float* bo = a.bsave + ((size_t)b * N + n) * D;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const int d = 16 * dt + 4 * kg;
-            if (d < D) {
-                const f4 t = *reinterpret_cast<const f4*>(tx + d);
-                const f4 av = O0[dt] * inv, bv = O1[dt] * inv;
-                *reinterpret_cast<f4*>(oo + d) = t;
-                *reinterpret_cast<f4*>(oo + D + d) = av;
-                *reinterpret_cast<f4*>(oo + 2 * D + d) = t * av;
-                *reinterpret_cast<f4*>(oo + 3 * D + d) = t * bv;
-                *reinterpret_cast<f4*>(bo + d) = bv;
+        const float* tx = a.text + (size_t)b * N * D;
+        float* oo = a.out + (size_t)b * N * 4 * D;
+        float* bo = a.bsave + (size_t)b * N * D;
+        for (int rr = wave; rr < 16 * NW; rr += NW) {
+            const int gn = row0 + rr;
+            if (gn < N && 4 * c4 < D) {
+                const f4 t = *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * c4);
+                const f4 av = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
+                float* o = oo + (size_t)gn * 4 * D + 4 * c4;
+                *reinterpret_cast<f4*>(o + D) = av;
+                *reinterpret_cast<f4*>(o + 2 * D) = t * av;
+            }
+        }
+        park(O1);
+        for (int rr = wave; rr < 16 * NW; rr += NW) {
+            const int gn = row0 + rr;
+            if (gn < N && 4 * c4 < D) {
+                const f4 t = *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * c4);
+                const f4 bv = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
+                *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 3 * D + 4 * c4) = t * bv;
+                *reinterpret_cast<f4*>(bo + (size_t)gn * D + 4 * c4) = bv;
             }
         }
     }
 }
 
-template <int NW, int PR>
+template <int NW, int PR, bool DB = false>
 __global__ __launch_bounds__(NW * 64) void att_col_kernel(const AttFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    att_fwd_body<1, NW, PR>(a, smem);
+    att_fwd_body<1, NW, PR, DB>(a, smem);
 }
-template <int NW, int PR>
+template <int NW, int PR, bool DB = false>
 __global__ __launch_bounds__(NW * 64) void att_row_kernel(const AttFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    att_fwd_body<2, NW, PR>(a, smem);
+    att_fwd_body<2, NW, PR, DB>(a, smem);
 }
 
 // merge the per-split partial column softmaxes: q = sum_p O_p e^{m_p-m} / sum_p l_p e^{m_p-m}
@@ -359,7 +424,7 @@ __global__ __launch_bounds__(256) void att_combine_kernel(const float* __restric
     f4 acc = f4{0.f, 0.f, 0.f, 0.f};
     for (int p = 0; p < splits; ++p) {
         const size_t o = ((size_t)b * splits + p) * N + n;
-        const float sc = expf(part_stat[o * 2] - m);
+        const float sc = __expf(part_stat[o * 2] - m);
         l += part_stat[o * 2 + 1] * sc;
         acc += *reinterpret_cast<const f4*>(part_o + o * D + 4 * c) * sc;
     }
@@ -496,7 +561,7 @@ __global__ __launch_bounds__(NW * 64) void att_bwd_j1_kernel(const AttBwdArgs a)
             for (int e = 0; e < 4; ++e) {
                 const int ml = mb * 16 + 4 * kg + e;
                 const float x = mm ? s[mb][e] + rt_s[ml] + cterm : NEG;
-                const float p = expf(x - rmax_s[ml]) * rinv_s[ml];  // rinv = 0 beyond the slice
+                const float p = __expf(x - rmax_s[ml]) * rinv_s[ml];  // rinv = 0 beyond the slice
                 p1[mb][e] = p;
                 const float g = p * (dp[mb][e] - dl1_s[ml]) * mmf;
                 ds[mb][e] = g;
@@ -595,7 +660,7 @@ __global__ __launch_bounds__(NW * 64) void att_bwd_j2_kernel(const AttBwdArgs a)
                 const int ml = mb * 16 + 4 * kg + e;
                 const int code = code_s[ml];
                 const float x = code == 2 ? s[mb][e] + rt_s[ml] + cterm : NEG;
-                const float p = code ? expf(x - cmax) * cinv : 0.f;
+                const float p = code ? __expf(x - cmax) * cinv : 0.f;
                 const float g = code == 2 ? p * (dp[mb][e] - delta2) : 0.f;
                 ds[mb][e] = g;
                 dc += g;
@@ -740,8 +805,8 @@ __global__ __launch_bounds__(NW * 64) void att_bwd_i_kernel(const AttBwdArgs a) 
                 const int ml = mb * 16 + 4 * kg + e;
                 const float mf = mmf_s[ml];
                 const float x = s[mb][e] + rterm + ct_s[ml];
-                const float P1 = mf >= 0.f ? expf((mf > 0.f ? x : NEG) - rmax) * rinv : 0.f;
-                const float P2 = mf >= 0.f ? expf((tm ? x : NEG) - cmax_s[ml]) * cinv_s[ml] : 0.f;
+                const float P1 = mf >= 0.f ? __expf((mf > 0.f ? x : NEG) - rmax) * rinv : 0.f;
+                const float P2 = mf >= 0.f ? __expf((tm ? x : NEG) - cmax_s[ml]) * cinv_s[ml] : 0.f;
                 const float g1 = mf > 0.f ? P1 * (dp1[mb][e] - dl1) : 0.f;
                 const float g2 = P2 * (dp2[mb][e] - dl2_s[ml]) * tmf;
                 p2[mb][e] = P2;
@@ -807,9 +872,9 @@ __global__ __launch_bounds__(NW * 64) void att_bwd_i_kernel(const AttBwdArgs a) 
 // ------------------------------------------------------------------------------------------ host side
 // workgroup geometries that are compiled (NW waves x PR-row panels); chosen per kernel below / by MMB_ATT_GEOM
 // (measured on MI355X, cfg2: 4 waves x 32-row panels beats 2x16, 1x16 and 2x32 on every kernel)
-enum { GEOM_4x32 = 0, GEOM_2x16 = 1, GEOM_COUNT };
-static const int kGeomNW[GEOM_COUNT] = {4, 2};
-static const int kGeomPR[GEOM_COUNT] = {32, 16};
+enum { GEOM_4x32 = 0, GEOM_2x16 = 1, GEOM_4x16DB = 2, GEOM_COUNT };   // DB = double-buffered panels (forward kernels)
+static const int kGeomNW[GEOM_COUNT] = {4, 2, 4};
+static const int kGeomPR[GEOM_COUNT] = {32, 16, 16};
 
 static int geom_for(int kernel_id, int deflt) {
     // MMB_ATT_GEOM = "<col><row><j1><j2><i>" one digit per kernel (tuning aid), e.g. 11111
@@ -925,7 +990,15 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
         a.rows_per_split = rows_per_split(T, splits, PRg);
         a.part_o = out;
         a.part_stat = out + (size_t)B * splits * M * D;
-        MMB_ATT_LAUNCH(MMB_K_ATT_COL, geom, M, splits, B, (1 + 1) * PR * LDP + 2 * PR, a, att_col_kernel);
+        if (geom == GEOM_4x16DB) {
+            const size_t lds = ((size_t)2 * (1 + 1) * 16 * LDP + 2 * a.rows_per_split) * sizeof(float);
+            if (int rc = allow_lds(att_col_kernel<4, 16, true>, lds)) return rc;
+            ProfScope ps_(MMB_K_ATT_COL, stream);
+            hipLaunchKernelGGL((att_col_kernel<4, 16, true>), dim3(((M + 63) / 64) * splits * B), dim3(256), lds, stream, a);
+            MMB_HIP(hipGetLastError());
+        } else {
+            MMB_ATT_LAUNCH(MMB_K_ATT_COL, geom, M, splits, B, (1 + 1) * PR * LDP + 2 * a.rows_per_split, a, att_col_kernel);
+        }
         if (splits > 1) {
             const size_t nthr = (size_t)B * M * (D / 4);
             { ProfScope ps_(MMB_K_ATT_COMBINE, stream); hipLaunchKernelGGL(att_combine_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, a.part_o, a.part_stat, q,
@@ -941,7 +1014,16 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
         a.m_mask = mod_mask; a.m_term = cterm; a.n_term = rterm; a.stat = row_stat;
         a.text = text; a.out = out; a.bsave = bsave;
         a.N = T; a.R = M; a.D = D; a.B = B; a.splits = 1; a.rows_per_split = rows_per_split(M, 1, kGeomPR[geom]);
-        MMB_ATT_LAUNCH(MMB_K_ATT_ROW, geom, T, 1, B, (2 + 1) * PR * LDP + 2 * PR, a, att_row_kernel);
+        { const char* e = getenv("MMB_ATT_DBG"); a.dbg = e ? atoi(e) : 0; }
+        if (geom == GEOM_4x16DB) {
+            const size_t lds = ((size_t)2 * (2 + 1) * 16 * LDP + 2 * a.rows_per_split) * sizeof(float);
+            if (int rc = allow_lds(att_row_kernel<4, 16, true>, lds)) return rc;
+            ProfScope ps_(MMB_K_ATT_ROW, stream);
+            hipLaunchKernelGGL((att_row_kernel<4, 16, true>), dim3(((T + 63) / 64) * B), dim3(256), lds, stream, a);
+            MMB_HIP(hipGetLastError());
+        } else {
+            MMB_ATT_LAUNCH(MMB_K_ATT_ROW, geom, T, 1, B, (2 + 1) * PR * LDP + 2 * a.rows_per_split, a, att_row_kernel);
+        }
     }
     return MMB_OK;
 }
