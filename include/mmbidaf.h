@@ -179,9 +179,13 @@ int mmb_gemm_f32(const float* A, const float* Bm, float* C, const float* bias,
                  int device, void* stream);
 
 /* C = A (M,K) . B (N,K)^T + bias through the operand-plane path (split passes + bf16 6-product kernel); exported for
- * tests and tools.  ws: scratch of at least 6 * (M + N) * roundup(K,32) bytes; K % 4 == 0. */
+ * tests and tools.  ws: scratch of at least 6 * (roundup(M,16) + roundup(N,16)) * roundup(K,32) bytes; K % 4 == 0. */
 int mmb_gemm_nt_planes(const float* A, const float* Bm, float* C, const float* bias, int M, int N, int K,
                        void* ws, size_t ws_bytes, int device, void* stream);
+
+/* Tuning aid: force the operand-plane GEMM's tile configuration and K split (code = config * 100 + split, split 0 =
+ * cost model's; code < 0 = cost model for both, the default).  Results do not depend on it beyond summation order. */
+void mmb_set_planes_tune(int code);
 
 #ifdef __cplusplus
 }

@@ -89,11 +89,14 @@ void set_gemm_mode(int mode);
 
 
 // ---- operand planes (planes.hip)
+// Tiled plane storage of an (R x Kp) matrix, Kp % 32 == 0: 1-KiB chunks [row block of 16][K tile of 32][plane 0..2],
+// a chunk = 16 rows x 64 B with the 16-B octet slots XOR-swizzled by row bit 3 (exactly the LDS image the GEMM reads).
 typedef __bf16 bf16_t;
+inline size_t planes_bytes(long rows, long kp) { return (size_t)((rows + 15) / 16) * (kp / 32) * 3 * 1024; }
 struct SplitRowsArgs {
     const float* src1; const float* src2; int R1;
     int R, C, ld, Cp, gate_H;
-    bf16_t* planes; size_t plane_stride;
+    bf16_t* planes;
     const float* b1a; const float* b2a; const float* b1b; const float* b2b;
     float* bias_out;
 };
@@ -102,19 +105,22 @@ struct SplitTArgs {
     const float* seg_ptr[3];
     int seg_ld[3], seg_cols[3], seg_shift[3];
     int R, period, Rp, Ctot;
-    bf16_t* planes; size_t plane_stride;
+    bf16_t* planes;
     const float* stack_ptr; int stack_R1;
 };
 struct PlanesGemmArgs {
-    const bf16_t* A; size_t a_plane; int lda;
-    const bf16_t* B; size_t b_plane; int ldb;
+    const bf16_t* A;   // tiled planes of the (M x K) operand
+    const bf16_t* B;   // tiled planes of the (N x K) operand
     float* C; int ldc;
     const float* bias;
     int M, N, K;
     int accumulate;
+    int splitk;   // set by planes_gemm
+    int dbg;      // timing-only ablation (MMB_PLANES_DBG): 2 = no MFMA
 };
 int planes_split_rows(const SplitRowsArgs& a, hipStream_t stream);
 int planes_split_transpose(const SplitTArgs& a, hipStream_t stream);
 int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream);
+void planes_set_tune(int code);
 
 }  // namespace mmb

@@ -386,8 +386,8 @@ static WsFwd ws_fwd_layout(long BT, int I, int H) {
     WsFwd w{};
     w.Ip = (int)rup(I, 32);
     size_t o = 0;
-    w.xP = o;   o += rup((size_t)3 * BT * w.Ip * 2, 256);
-    w.wP = o;   o += rup((size_t)3 * 8 * H * w.Ip * 2, 256);
+    w.xP = o;   o += rup(planes_bytes(BT, w.Ip), 256);
+    w.wP = o;   o += rup(planes_bytes(8 * H, w.Ip), 256);
     w.bias = o; o += rup((size_t)8 * H * 4, 256);
     w.total = o;
     return w;
@@ -398,10 +398,10 @@ static WsBwd ws_bwd_layout(long BT, int I, int H) {
     w.K8 = (int)rup(8 * H, 32);
     w.BTp = (int)rup(BT, 32);
     size_t o = 0;
-    w.daP = o; o += rup((size_t)3 * BT * w.K8 * 2, 256);
-    w.daT = o; o += rup((size_t)3 * 8 * H * w.BTp * 2, 256);
-    w.xcT = o; o += rup((size_t)3 * (I + 2 * H) * w.BTp * 2, 256);
-    w.wT = o;  o += rup((size_t)3 * I * w.K8 * 2, 256);
+    w.daP = o; o += rup(planes_bytes(BT, w.K8), 256);
+    w.daT = o; o += rup(planes_bytes(8 * H, w.BTp), 256);
+    w.xcT = o; o += rup(planes_bytes(I + 2 * H, w.BTp), 256);
+    w.wT = o;  o += rup(planes_bytes(I, w.K8), 256);
     w.total = o;
     return w;
 }
@@ -417,16 +417,16 @@ static int gx_planes(const mmb_lstm_fwd_desc& p, hipStream_t stream) {
     float* bias = reinterpret_cast<float*>(ws + L.bias);
     SplitRowsArgs sx{};
     sx.src1 = p.x; sx.src2 = p.x; sx.R1 = (int)BT; sx.R = (int)BT; sx.C = p.I; sx.ld = p.I; sx.Cp = L.Ip; sx.gate_H = 0;
-    sx.planes = xP; sx.plane_stride = (size_t)BT * L.Ip;
+    sx.planes = xP;
     if (int rc = planes_split_rows(sx, stream)) return rc;
     SplitRowsArgs sw{};
     sw.src1 = p.w_ih[0]; sw.src2 = p.w_ih[1]; sw.R1 = 4 * H; sw.R = 8 * H; sw.C = p.I; sw.ld = p.I; sw.Cp = L.Ip; sw.gate_H = H;
-    sw.planes = wP; sw.plane_stride = (size_t)8 * H * L.Ip;
+    sw.planes = wP;
     sw.b1a = p.b_ih[0]; sw.b2a = p.b_hh[0]; sw.b1b = p.b_ih[1]; sw.b2b = p.b_hh[1]; sw.bias_out = bias;
     if (int rc = planes_split_rows(sw, stream)) return rc;
     PlanesGemmArgs g{};
-    g.A = xP; g.a_plane = sx.plane_stride; g.lda = L.Ip;
-    g.B = wP; g.b_plane = sw.plane_stride; g.ldb = L.Ip;
+    g.A = xP;
+    g.B = wP;
     g.C = p.gx; g.ldc = 8 * H; g.bias = bias; g.M = (int)BT; g.N = 8 * H; g.K = L.Ip;
     return planes_gemm(g, stream);
 }
@@ -463,7 +463,7 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream) {
     // d_a^T planes (8H x BT): A operand of the weight-gradient GEMM
     SplitTArgs ta{};
     ta.nseg = 1; ta.seg_ptr[0] = p.d_a; ta.seg_ld[0] = 8 * H; ta.seg_cols[0] = 8 * H; ta.seg_shift[0] = 0;
-    ta.R = (int)BT; ta.period = 1; ta.Rp = L.BTp; ta.Ctot = 8 * H; ta.planes = daT; ta.plane_stride = (size_t)8 * H * L.BTp;
+    ta.R = (int)BT; ta.period = 1; ta.Rp = L.BTp; ta.Ctot = 8 * H; ta.planes = daT;
     if (int rc = planes_split_transpose(ta, stream)) return rc;
     // [x | y_fwd(t-1) | y_rev(t+1)]^T planes ((I+2H) x BT): h_prev is y shifted by one step inside each sample
     SplitTArgs tx{};
@@ -471,12 +471,12 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream) {
     tx.seg_ptr[0] = p.x;     tx.seg_ld[0] = I;     tx.seg_cols[0] = I; tx.seg_shift[0] = 0;
     tx.seg_ptr[1] = p.y;     tx.seg_ld[1] = 2 * H; tx.seg_cols[1] = H; tx.seg_shift[1] = -1;
     tx.seg_ptr[2] = p.y + H; tx.seg_ld[2] = 2 * H; tx.seg_cols[2] = H; tx.seg_shift[2] = +1;
-    tx.R = (int)BT; tx.period = p.T; tx.Rp = L.BTp; tx.Ctot = I + 2 * H; tx.planes = xcT; tx.plane_stride = (size_t)(I + 2 * H) * L.BTp;
+    tx.R = (int)BT; tx.period = p.T; tx.Rp = L.BTp; tx.Ctot = I + 2 * H; tx.planes = xcT;
     if (int rc = planes_split_transpose(tx, stream)) return rc;
     {
         PlanesGemmArgs g{};
-        g.A = daT; g.a_plane = ta.plane_stride; g.lda = L.BTp;
-        g.B = xcT; g.b_plane = tx.plane_stride; g.ldb = L.BTp;
+        g.A = daT;
+        g.B = xcT;
         g.C = p.d_w_cat; g.ldc = I + 2 * H; g.M = 8 * H; g.N = I + 2 * H; g.K = L.BTp;
         if (int rc = planes_gemm(g, stream)) return rc;
         const int total = 8 * H * (I + 2 * H);
@@ -488,16 +488,16 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream) {
         // d_x (BT, I) = d_a (BT x 8H) . [W_ih_f ; W_ih_r] (8H x I): one GEMM over both directions
         SplitRowsArgs sa{};
         sa.src1 = p.d_a; sa.src2 = p.d_a; sa.R1 = (int)BT; sa.R = (int)BT; sa.C = 8 * H; sa.ld = 8 * H; sa.Cp = L.K8; sa.gate_H = 0;
-        sa.planes = daP; sa.plane_stride = (size_t)BT * L.K8;
+        sa.planes = daP;
         if (int rc = planes_split_rows(sa, stream)) return rc;
         SplitTArgs tw{};
         tw.nseg = 1; tw.seg_ptr[0] = p.w_ih[0]; tw.seg_ld[0] = I; tw.seg_cols[0] = I; tw.seg_shift[0] = 0;
         tw.stack_ptr = p.w_ih[1]; tw.stack_R1 = 4 * H;
-        tw.R = 8 * H; tw.period = 1; tw.Rp = L.K8; tw.Ctot = I; tw.planes = wT; tw.plane_stride = (size_t)I * L.K8;
+        tw.R = 8 * H; tw.period = 1; tw.Rp = L.K8; tw.Ctot = I; tw.planes = wT;
         if (int rc = planes_split_transpose(tw, stream)) return rc;
         PlanesGemmArgs g{};
-        g.A = daP; g.a_plane = sa.plane_stride; g.lda = L.K8;
-        g.B = wT; g.b_plane = tw.plane_stride; g.ldb = L.K8;
+        g.A = daP;
+        g.B = wT;
         g.C = p.d_x; g.ldc = I; g.M = (int)BT; g.N = I; g.K = L.K8;
         if (int rc = planes_gemm(g, stream)) return rc;
     }

@@ -1,7 +1,9 @@
 // "Planes" GEMM: fp32-accurate products on the bf16 matrix cores with operands split ONCE.
 //
 //   split pass   fp32 matrix -> three bf16 planes x = x0 + x1 + x2 (exact 8+8+8-bit split, see gemm_bf16.hip), written
-//                K-contiguous with K padded to 32.  The pass is bandwidth-bound and does every layout change the
+//                TILED: 1-KiB chunks [16-row block][32-deep K tile][plane], each the swizzled 16 x 64 B LDS image the
+//                GEMM wants, so that one LDS-DMA wave-instruction copies 8 whole, contiguous cache lines (a row-major
+//                plane made every DMA touch 16 half lines and capped the L2 -> LDS stream at ~6.5 TB/s).  The pass is bandwidth-bound and does every layout change the
 //                GEMMs need, so the GEMM kernel itself is a single "NT" form (both operands K-contiguous):
 //                  split_rows       rows as they are; optional row stacking (forward / reverse weights) and the
 //                                   LSTM gate interleave as a row permutation
@@ -9,9 +11,10 @@
 //                                   column blocks, each with its own row shift inside periods of T rows
 //                                   ([x | y_fwd(t-1) | y_rev(t+1)] for the weight gradients)
 //   gemm_planes  C (M,N) fp32 = sum over the 6 cross terms of order <= 2 of A_i . B_j^T, v_mfma_f32_16x16x32_bf16,
-//                workgroup 4 waves x (MT*16) x (NT*16), K tile 32, LDS-DMA (global_load_lds_dwordx4) into a
-//                double-buffered, XOR-swizzled [plane][row][64 B] image (swizzle applied on the per-lane SOURCE
-//                address, LDS destination linear), next tile's DMA in flight under the current tile's 6*MT*NT MFMAs.
+//                workgroup 8 waves (WM x WN, two per SIMD), wave tile (MT*16) x (NT*16), K tile 32, LDS-DMA
+//                (global_load_lds_dwordx4) into a double-buffered, XOR-swizzled [plane][row][64 B] image (swizzle
+//                applied on the per-lane SOURCE address, LDS destination linear), next tile's DMA in flight under the
+//                current tile's 6*MT*NT MFMAs; tile shape and K split picked per problem by a small cost model.
 #include <stdlib.h>
 
 #include "common.h"
@@ -34,40 +37,51 @@ __device__ __forceinline__ void split3(const float* x, bf16x8& h0, bf16x8& h1, b
 }
 
 // ------------------------------------------------------------------------------------------ split passes
-// planes[s][dst_row][Cp]; rows r < R1 come from src1, the rest from src2 (stacked); gate_H > 0 permutes each 4H block
-// of rows so that plane row u*4+g holds source row g*H+u.  Optional bias_out[dst_row] = b1[src_row] + b2[src_row].
+__device__ __forceinline__ int pl_swz(int row) { return ((row >> 3) & 1) << 1; }
+// byte offset of (row, k-octet) of plane 0 inside tiled planes with nkt K tiles; planes 1, 2 follow at +1024, +2048
+__device__ __forceinline__ size_t pl_off(int row, int oct, int nkt) {
+    const int rl = row & 15, sl = oct & 3;
+    return ((size_t)(row >> 4) * nkt + (oct >> 2)) * 3072 + rl * 64 + ((sl ^ pl_swz(rl)) << 4);
+}
+__device__ __forceinline__ void store_planes(bf16_t* planes, size_t off, const float* x) {
+    bf16x8 h0, h1, h2;
+    split3(x, h0, h1, h2);
+    char* d = reinterpret_cast<char*>(planes) + off;
+    *reinterpret_cast<bf16x8*>(d) = h0;
+    *reinterpret_cast<bf16x8*>(d + 1024) = h1;
+    *reinterpret_cast<bf16x8*>(d + 2048) = h2;
+}
+
+// One wave per (row block, K tile): 16 rows x 128 B in, three contiguous 1-KiB chunks out.  Plane rows r < R1 come from
+// src1, the rest from src2 (stacked); gate_H > 0 permutes each 4H block of rows so that plane row u*4+g holds source row
+// g*H+u.  Rows past R (padding of the last block) are written as zeros.  Optional bias_out[row] = b1[src] + b2[src].
 __global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsArgs a) {
-    const int oct_per_row = a.Cp / 8;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)a.R * oct_per_row) return;
-    const int r = idx / oct_per_row, oc = idx % oct_per_row;
-    const bool second = r >= a.R1;
-    const float* src = (second ? a.src2 + (size_t)(r - a.R1) * a.ld : a.src1 + (size_t)r * a.ld) + 8 * oc;
+    const int nkt = a.Cp / 32;
+    const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int rb = pair / nkt, kt = pair - (long)rb * nkt;
+    if (rb >= (a.R + 15) / 16) return;
+    const int dr = rb * 16 + (lane >> 2), oct = kt * 4 + (lane & 3);
+    int sr = dr;
+    if (a.gate_H > 0) {  // plane row u*4+g of a 4H block <- source row g*H+u
+        const int H = a.gate_H, blk = dr / (4 * H), rem = dr % (4 * H);
+        sr = blk * 4 * H + (rem & 3) * H + (rem >> 2);
+    }
+    const bool second = sr >= a.R1;
+    const int lr = second ? sr - a.R1 : sr;
     float x[8];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         f4 t = f4{0.f, 0.f, 0.f, 0.f};
-        if (8 * oc + 4 * h < a.C) t = *reinterpret_cast<const f4*>(src + 4 * h);
+        if (dr < a.R && 8 * oct + 4 * h < a.C) t = *reinterpret_cast<const f4*>((second ? a.src2 : a.src1) + (size_t)lr * a.ld + 8 * oct + 4 * h);
         x[4 * h] = t.x; x[4 * h + 1] = t.y; x[4 * h + 2] = t.z; x[4 * h + 3] = t.w;
     }
-    int dr = r;
-    if (a.gate_H > 0) {  // source row g*H+u of a 4H block -> plane row u*4+g
-        const int H = a.gate_H, blk = r / (4 * H), rem = r % (4 * H);
-        dr = blk * 4 * H + (rem % H) * 4 + rem / H;
-    }
-    bf16x8 h0, h1, h2;
-    split3(x, h0, h1, h2);
-    __bf16* dst = a.planes + (size_t)dr * a.Cp + 8 * oc;
-    *reinterpret_cast<bf16x8*>(dst) = h0;
-    *reinterpret_cast<bf16x8*>(dst + a.plane_stride) = h1;
-    *reinterpret_cast<bf16x8*>(dst + 2 * a.plane_stride) = h2;
-    if (a.bias_out && oc == 0) {
-        const int lr = second ? r - a.R1 : r;
-        a.bias_out[dr] = second ? a.b1b[lr] + a.b2b[lr] : a.b1a[lr] + a.b2a[lr];
-    }
+    store_planes(a.planes, pl_off(dr, oct, nkt), x);
+    if (a.bias_out && oct == 0 && dr < a.R) a.bias_out[dr] = second ? a.b1b[lr] + a.b2b[lr] : a.b1a[lr] + a.b2a[lr];
 }
 
-// planes[s][col (global, over the concatenated segments)][Rp]: the transpose of a virtual (R x sum cols) matrix.
+// Planes of the TRANSPOSE of a virtual (R x sum cols) matrix: plane row = source column (global, over the concatenated
+// segments), K = source row.  32 source rows x 64 columns per workgroup through LDS; each wave writes whole chunks.
 __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTArgs a) {
     __shared__ float tile[32][65];
     const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 64;
@@ -94,64 +108,78 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTArgs a
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     __syncthreads();
-    // each thread: one output row (source column), one k-octet
+    // each thread: one plane row (source column), one k-octet; a wave = one chunk per plane (columns past Ctot are zeros)
     const int oc = t & 3, cl = t >> 2;
     const int col = c0 + cl;
-    if (col >= a.Ctot || k0 + 8 * oc >= a.Rp) return;
+    if (col >= (a.Ctot + 15) / 16 * 16) return;
     float x[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = tile[8 * oc + j][cl];
-    bf16x8 h0, h1, h2;
-    split3(x, h0, h1, h2);
-    __bf16* dst = a.planes + (size_t)col * a.Rp + k0 + 8 * oc;
-    *reinterpret_cast<bf16x8*>(dst) = h0;
-    *reinterpret_cast<bf16x8*>(dst + a.plane_stride) = h1;
-    *reinterpret_cast<bf16x8*>(dst + 2 * a.plane_stride) = h2;
+    store_planes(a.planes, pl_off(col, (k0 >> 3) + oc, a.Rp / 32), x);
 }
 
 // ------------------------------------------------------------------------------------------ GEMM on planes
-__device__ __forceinline__ int pl_swz(int row) { return ((row >> 3) & 1) << 1; }
 
-// STAGES = 2: next tile's DMA in flight under this tile's MFMAs (1 workgroup per CU at the large tiles);
-// STAGES = 1: DMA, wait, multiply -- latency is hidden across the 2-3 workgroups that then fit on a CU.
-template <int MT, int NT, int STAGES>
-__global__ __launch_bounds__(256) void gemm_planes_kernel(const PlanesGemmArgs g, const int kchunk) {
-    constexpr int BM = 4 * MT * 16, BN = NT * 16, RT = BM + BN;  // rows per plane image
-    constexpr int STAGE = 3 * RT * 64;                           // bytes per stage
-    constexpr int NDMA = 3 * RT / 16;                            // 1-KiB wave-instructions per stage
-    constexpr int PER_WAVE = (NDMA + 3) / 4;
+// Workgroup = 8 waves (two per SIMD, so one wave's LDS waits and barrier skew sit under the other's MFMAs) arranged
+// WM x WN; each wave owns (MT*16) x (NT*16) of the BM x BN tile.  One barrier per 32-deep K tile: behind it the
+// stage just filled is read (all 3*(MT+NT) fragments up front) while the DMA of the next tile runs under this tile's
+// 6*MT*NT MFMAs.  MFMAs are issued term-major over the MT*NT accumulators, so consecutive ones are independent.
+// Operands are passed (B fragment, A fragment): lane (r, kg) then holds C[m = r][n = 4*kg .. 4*kg+3] -- float4 stores.
+// Workgroup ids are cut into 8 contiguous chunks, one per XCD (ids go round-robin over XCDs), so that the
+// workgroups that share an A row panel (same tile row, neighbouring tile columns) also share an L2.
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g, const int kchunk, const int tiles_n,
+                                                          const int ntiles) {
+    static_assert(WM * WN == 8, "8 waves");
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16, RT = BM + BN;  // rows per plane image
+    constexpr int STAGE = 3 * RT * 64;                                 // bytes per stage
+    constexpr int NDMA = 3 * RT / 16;                                  // 1-KiB wave-instructions per stage
+    constexpr int PER_WAVE = (NDMA + 7) / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, kg = lane >> 4;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kb = blockIdx.z * kchunk;
-    const int ke = min(g.K, kb + kchunk);
+    const int wm = wave % WM, wn = wave / WM;
 
-    // per-lane source pointers of this wave's DMA instructions (loop-invariant except for the K offset)
-    const __bf16* src[PER_WAVE];
+    // XCD-chunked decode of the linear workgroup id (bijective for any grid size)
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int lin = xcd * q8 + min(xcd, r8) + pos;
+    const int z = lin / ntiles, tile = lin - z * ntiles;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kb = z * kchunk;
+    const int ke = min(g.K, kb + kchunk);
+    const int nk = (ke - kb + 31) / 32;
+
+    // DMA piece q of a stage = chunk (plane q / (RT/16), row block q % (RT/16)) of the tiled planes: 1 KiB contiguous
+    // in global memory, copied lane-linear (the swizzle is already in the data); K tile kt follows at +3 KiB.
+    const int nkt = g.K / 32, nrbA = (g.M + 15) / 16, nrbB = (g.N + 15) / 16;
+    const char* src[PER_WAVE];
 #pragma unroll
     for (int k = 0; k < PER_WAVE; ++k) {
-        const int q = min(wave + 4 * k, NDMA - 1);
-        const int rr = 16 * q + (lane >> 2);        // row of the [3][RT] image
-        const int plane = rr / RT, rl = rr % RT;
-        const int slot = lane & 3;
-        if (rl < BM) {
-            const int oct = slot ^ pl_swz(rl);
-            src[k] = g.A + plane * g.a_plane + (size_t)min(m0 + rl, g.M - 1) * g.lda + kb + 8 * oct;
+        const int q = min(wave + 8 * k, NDMA - 1);
+        const int plane = q / (RT / 16), blk = q % (RT / 16);
+        const char* base;
+        size_t rbk;
+        if (blk < BM / 16) {
+            base = reinterpret_cast<const char*>(g.A);
+            rbk = (size_t)min(m0 / 16 + blk, nrbA - 1);
         } else {
-            const int tr = rl - BM;
-            const int oct = slot ^ pl_swz(tr);
-            src[k] = g.B + plane * g.b_plane + (size_t)min(n0 + tr, g.N - 1) * g.ldb + kb + 8 * oct;
+            base = reinterpret_cast<const char*>(g.B);
+            rbk = (size_t)min(n0 / 16 + blk - BM / 16, nrbB - 1);
         }
+        src[k] = base + ((rbk * nkt + kb / 32) * 3 + plane) * 1024 + lane * 16;
     }
-    // one LDS-DMA piece (1 KiB) of this wave; pieces are issued one per MFMA group inside the tile loop, not as a burst
-    auto dma_piece = [&](int stage, int k) {
-        const int q = wave + 4 * k;
-        if (NDMA % 4 == 0 || q < NDMA)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[k],
-                                             (__attribute__((address_space(3))) void*)(smem + stage * STAGE + q * 1024), 16, 0, 0);
-        src[k] += 32;
+    auto dma_stage = [&](int stage) {
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int q = wave + 8 * k;
+            if (NDMA % 8 == 0 || q < NDMA)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[k],
+                                                 (__attribute__((address_space(3))) void*)(smem + stage * STAGE + q * 1024), 16, 0, 0);
+            src[k] += 3072;
+        }
     };
 
     f4 acc[MT][NT];
@@ -163,88 +191,111 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(const PlanesGemmArgs g
     int offA[MT], offB[NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int tr = (wave * MT + i) * 16 + r;
+        const int tr = (wm * MT + i) * 16 + r;
         offA[i] = tr * 64 + ((kg ^ pl_swz(tr)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int tr = j * 16 + r;
+        const int tr = (wn * NT + j) * 16 + r;
         offB[j] = (BM + tr) * 64 + ((kg ^ pl_swz(tr)) << 4);
     }
 
-    auto multiply = [&](const char* img, int next_stage, bool more) {
-        bf16x8 a[MT][3];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int s = 0; s < 3; ++s) a[i][s] = *reinterpret_cast<const bf16x8*>(img + s * (RT * 64) + offA[i]);
-        constexpr int DPJ = (PER_WAVE + NT - 1) / NT;  // DMA pieces issued per n-tile of MFMAs
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            bf16x8 b[3];
-#pragma unroll
-            for (int s = 0; s < 3; ++s) b[s] = *reinterpret_cast<const bf16x8*>(img + s * (RT * 64) + offB[j]);
-            if (STAGES == 2 && more) {
-#pragma unroll
-                for (int d = 0; d < DPJ; ++d)
-                    if (j * DPJ + d < PER_WAVE) dma_piece(next_stage, j * DPJ + d);
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                f4 c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[0], c, 0, 0, 0);
-                acc[i][j] = c;
-            }
-        }
+    // Ping-pong schedule: the waves form two groups (one wave of each per SIMD) that run half a period apart --
+    // while one group issues its 6*MT*NT MFMAs the other reads its fragments of the tile from LDS -- kept in step by
+    // raw barriers (global barrier 2t: group 0 has read tile t; 2t+1: group 1 has, and group 0 has multiplied it).
+    // Tile t+2 is DMA'd into the stage tile t occupied once barrier 2t+1 has passed, and every wave drains its own
+    // DMA pieces (vmcnt(0)) before the barrier that precedes the first read of that tile (2t+3).
+    const int grp = wave >> 2;
+    auto bar = [] {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     };
-
-    if (STAGES == 2) {
-        int stage = 0;
-        if (kb < ke) {
+    if (nk > 0) dma_stage(0);
+    if (nk > 1) dma_stage(1);
+    __syncthreads();
+    if (grp == 1) bar();
+    bf16x8 a[MT][3], b[NT][3];
+    for (int t = 0; t < nk; ++t) {
+        if (grp == 0 && t >= 1 && t + 1 < nk && !(g.dbg & 8)) dma_stage((t + 1) & 1);
+        const char* img = smem + (t & 1) * STAGE;
+        const bool only_mfma = (g.dbg & 16) && t > 0;   // timing-only: registers of tile 0, no reads, no barriers
+        if (!only_mfma) {
 #pragma unroll
-            for (int k = 0; k < PER_WAVE; ++k) dma_piece(0, k);
-        }
-        __syncthreads();
-        for (int k0 = kb; k0 < ke; k0 += 32) {
-            multiply(smem + stage * STAGE, stage ^ 1, k0 + 32 < ke);
-            __syncthreads();  // retires the DMA of the next stage (compiler's vmcnt(0)) and frees this one
-            stage ^= 1;
-        }
-    } else {
-        for (int k0 = kb; k0 < ke; k0 += 32) {
+        for (int s = 0; s < 3; ++s) {
 #pragma unroll
-            for (int k = 0; k < PER_WAVE; ++k) dma_piece(0, k);
-            __syncthreads();
-            multiply(smem, 0, false);
-            __syncthreads();
+            for (int i = 0; i < MT; ++i) a[i][s] = *reinterpret_cast<const bf16x8*>(img + s * (RT * 64) + offA[i]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j][s] = *reinterpret_cast<const bf16x8*>(img + s * (RT * 64) + offB[j]);
         }
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bar();
+        }
+        if (grp == 1 && t + 2 < nk && !(g.dbg & 8)) dma_stage(t & 1);
+        if (!(g.dbg & 2)) {
+            // cross terms of order <= 2, smallest first: (a plane, b plane)
+            constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][TB[term]], a[i][TA[term]], acc[i][j], 0, 0, 0);
+        }
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!only_mfma) bar();
     }
+    if (grp == 0) bar();
+    __syncthreads();
 
-    const bool atomic = gridDim.z > 1;
+    // Epilogue through LDS, 16 rows of the wave tile at a time (wave-private region, so no barrier): every global
+    // store / atomic wave-instruction then covers whole contiguous row segments of C (NT*64 B per row) instead of
+    // 16 rows x 64 B; split-K partial sums are added with contiguous 256-B atomic instructions.
+    constexpr int W = NT * 16, LDW = W + 4;
+    float* stg = reinterpret_cast<float*>(smem) + wave * (16 * LDW);
+    const bool atomic = g.splitk > 1;
+    const bool vec = ((g.ldc & 3) == 0) && ((g.N & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+    const int nw0 = n0 + wn * W;
+    f4 bv[NT];
+    const bool has_bias = z == 0 && g.bias != nullptr;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int n = n0 + j * 16 + r;
-        if (n >= g.N) continue;
-        const float bv = (blockIdx.z == 0 && g.bias) ? g.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int e = 0; e < 4; ++e) {
+            const int n = nw0 + j * 16 + 4 * kg + e;
+            bv[j][e] = (has_bias && n < g.N) ? g.bias[min(n, g.N - 1)] : 0.f;
+        }
+    }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = m0 + (wave * MT + i) * 16 + 4 * kg + e;
-                if (m >= g.M) continue;
-                float* dst = g.C + (size_t)m * g.ldc + n;
-                const float v = acc[i][j][e] + bv;
-                if (atomic)
-                    atomicAdd(dst, v);
-                else if (g.accumulate)
-                    *dst += v;
-                else
-                    *dst = v;
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<f4*>(stg + r * LDW + j * 16 + 4 * kg) = acc[i][j] + bv[j];
+        const int mw0 = m0 + (wm * MT + i) * 16;
+        if (atomic || !vec) {
+#pragma unroll
+            for (int it = 0; it < (16 * W) / 64; ++it) {
+                const int u = it * 64 + lane, row = u / W, col = u - row * W;
+                const int m = mw0 + row, n = nw0 + col;
+                if (m < g.M && n < g.N) {
+                    float* dst = g.C + (size_t)m * g.ldc + n;
+                    const float v = stg[row * LDW + col];
+                    if (atomic) atomicAdd(dst, v);
+                    else *dst = g.accumulate ? *dst + v : v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < (16 * W / 4) / 64; ++it) {
+                const int u = it * 64 + lane, row = u / (W / 4), c4 = u - row * (W / 4);
+                const int m = mw0 + row, n = nw0 + 4 * c4;
+                if (m < g.M && n < g.N) {
+                    float* dst = g.C + (size_t)m * g.ldc + n;
+                    f4 v = *reinterpret_cast<const f4*>(stg + row * LDW + 4 * c4);
+                    if (g.accumulate) v += *reinterpret_cast<const f4*>(dst);
+                    *reinterpret_cast<f4*>(dst) = v;
+                }
             }
         }
     }
@@ -252,9 +303,9 @@ __global__ __launch_bounds__(256) void gemm_planes_kernel(const PlanesGemmArgs g
 
 // ------------------------------------------------------------------------------------------ host side
 int planes_split_rows(const SplitRowsArgs& a, hipStream_t stream) {
-    const long n = (long)a.R * (a.Cp / 8);
+    const long pairs = (long)((a.R + 15) / 16) * (a.Cp / 32);
     ProfScope ps_(MMB_K_SPLIT, stream);
-    hipLaunchKernelGGL(split_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((pairs + 3) / 4), dim3(256), 0, stream, a);
     MMB_HIP(hipGetLastError());
     return MMB_OK;
 }
@@ -266,92 +317,113 @@ int planes_split_transpose(const SplitTArgs& a, hipStream_t stream) {
     return MMB_OK;
 }
 
-template <int MT, int NT, int STAGES>
-static int launch_planes(const PlanesGemmArgs& g, int splitk, hipStream_t stream) {
-    constexpr int BM = 4 * MT * 16, BN = NT * 16;
-    const size_t lds = (size_t)STAGES * 3 * (BM + BN) * 64;
-    auto kern = gemm_planes_kernel<MT, NT, STAGES>;
+template <int WM, int WN, int MT, int NT>
+static int launch_planes(const PlanesGemmArgs& g, hipStream_t stream) {
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    const size_t lds = (size_t)2 * 3 * (BM + BN) * 64;
+    auto kern = gemm_planes_kernel<WM, WN, MT, NT>;
     static bool attr_set = false;
     if (!attr_set) {
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splitk);
-    int kchunk = (g.K + splitk - 1) / splitk;
+    const int tiles_n = (g.N + BN - 1) / BN, ntiles = tiles_n * ((g.M + BM - 1) / BM);
+    int kchunk = (g.K + g.splitk - 1) / g.splitk;
     kchunk = (kchunk + 31) / 32 * 32;
     ProfScope ps_(MMB_K_GEMM, stream);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g, kchunk);
+    hipLaunchKernelGGL(kern, dim3(ntiles * g.splitk), dim3(512), lds, stream, g, kchunk, tiles_n, ntiles);
     MMB_HIP(hipGetLastError());
     return MMB_OK;
 }
 
-int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream) {
-    static int tune = -2;   // MMB_PLANES_TUNE = <bm: 0 auto | 1 force 64 | 2 force 128><stages: 1 | 2>, e.g. "21" (tuning aid)
-    if (tune == -2) {
-        const char* e = getenv("MMB_PLANES_TUNE");
-        tune = e ? atoi(e) : -1;
-    }
-    const bool narrow = g.N <= 112;
-    const int bn = narrow ? 112 : 208;
-    const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + bn - 1) / bn);
-    bool small = tiles128 < 200 && g.K < 4096;
-    int stages = 2;
-    if (tune >= 0) {
-        if (tune / 10 == 1) small = true;
-        if (tune / 10 == 2) small = false;
-        stages = (tune % 10 == 1) ? 1 : 2;
-    }
-    const int bm = small ? 64 : 128;
+namespace {
+struct PlanesCfg { int wm, wn, mt, nt; };
+// tile = (wm*mt*16) x (wn*nt*16):        256x160       160x256       128x160       128x224       64x160        64x224        80x256
+constexpr PlanesCfg PLANES_CFGS[] = {{4, 2, 4, 5}, {2, 4, 5, 4}, {4, 2, 2, 5}, {4, 2, 2, 7}, {4, 2, 1, 5}, {4, 2, 1, 7}, {1, 8, 5, 2}};
+constexpr int N_PLANES_CFGS = sizeof(PLANES_CFGS) / sizeof(PLANES_CFGS[0]);
+int g_planes_force = -1;   // <config * 100 + split> from mmb_set_planes_tune / MMB_PLANES_TUNE, -1 = cost model
+
+// estimated cycles of (config, split): rounds of 256 workgroups x K tiles x max(MFMA issue of the SIMD's two waves,
+// L2 -> LDS stream of the stage at the ~29 B/clk/CU the chip sustains with every CU streaming) + fixed costs
+double planes_cost(const PlanesGemmArgs& g, const PlanesCfg& c, int splitk) {
+    const int bm = c.wm * c.mt * 16, bn = c.wn * c.nt * 16;
     const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
-    int splitk = 1;
-    if (tiles < 160 && g.K >= 1024) {
-        long s = (256 + tiles - 1) / tiles;
-        const long smax = g.K / 512;
-        if (s > smax) s = smax;
-        if (s > 32) s = 32;
-        splitk = s < 1 ? 1 : (int)s;
+    const long nk = ((g.K + splitk - 1) / splitk + 31) / 32;
+    const long rounds = (tiles * splitk + 255) / 256;
+    const double mfma = 2.0 * c.mt * c.nt * 6 * 16, dma = 3.0 * (bm + bn) * 64 / 29.0;
+    const double per_tile = (mfma > dma ? mfma + 0.25 * dma : dma + 0.25 * mfma) + 300.0;
+    double cost = (double)rounds * (nk * per_tile + 4000.0 + 1.5 * bm * bn / 8.0);   // + prologue, first DMA, epilogue stores
+    if (splitk > 1) cost += 3000.0 + 0.02 * (double)g.M * g.N * splitk / 256.0;     // zeroing + atomics
+    return cost;
+}
+}  // namespace
+
+void planes_set_tune(int code) { g_planes_force = code; }
+
+int planes_gemm(const PlanesGemmArgs& g_, hipStream_t stream) {
+    PlanesGemmArgs g = g_;
+    static int dbg = -1, verbose = 0;   // MMB_PLANES_DBG: timing-only ablations; MMB_PLANES_TUNE = <config><split, 2 digits>
+    if (dbg < 0) {
+        const char* e = getenv("MMB_PLANES_DBG");
+        dbg = e ? atoi(e) : 0;
+        const char* t = getenv("MMB_PLANES_TUNE");
+        if (t) g_planes_force = atoi(t);
+        verbose = getenv("MMB_PLANES_VERBOSE") != nullptr;
     }
-    if (splitk > 1 && !g.accumulate)
-        MMB_HIP(hipMemset2DAsync(g.C, (size_t)g.ldc * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream));
-    const int cfg = (small ? 2 : 0) + (narrow ? 1 : 0);
-    if (stages == 1) {
-        switch (cfg) {
-            case 0: return launch_planes<2, 13, 1>(g, splitk, stream);
-            case 1: return launch_planes<2, 7, 1>(g, splitk, stream);
-            case 2: return launch_planes<1, 13, 1>(g, splitk, stream);
-            default: return launch_planes<1, 7, 1>(g, splitk, stream);
+    g.dbg = dbg;
+    int best = 0, best_s = 1;
+    double best_cost = 1e300;
+    for (int c = 0; c < N_PLANES_CFGS; ++c)
+        for (int s = 1; s <= 32; ++s) {
+            if (s > 1 && g.K / s < 512) break;
+            const double cost = planes_cost(g, PLANES_CFGS[c], s);
+            if (cost < best_cost) { best_cost = cost; best = c; best_s = s; }
         }
+    if (g_planes_force >= 0) {
+        best = (g_planes_force / 100) % N_PLANES_CFGS;
+        if (g_planes_force % 100 > 0) best_s = g_planes_force % 100;
     }
-    switch (cfg) {
-        case 0: return launch_planes<2, 13, 2>(g, splitk, stream);
-        case 1: return launch_planes<2, 7, 2>(g, splitk, stream);
-        case 2: return launch_planes<1, 13, 2>(g, splitk, stream);
-        default: return launch_planes<1, 7, 2>(g, splitk, stream);
+    if (verbose)
+        fprintf(stderr, "planes_gemm %dx%dx%d: tile %dx%d split %d\n", g.M, g.N, g.K, PLANES_CFGS[best].wm * PLANES_CFGS[best].mt * 16,
+                PLANES_CFGS[best].wn * PLANES_CFGS[best].nt * 16, best_s);
+    g.splitk = best_s;
+    if (g.splitk > 1 && !g.accumulate)
+        MMB_HIP(hipMemset2DAsync(g.C, (size_t)g.ldc * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream));
+    switch (best) {
+        case 0: return launch_planes<4, 2, 4, 5>(g, stream);
+        case 1: return launch_planes<2, 4, 5, 4>(g, stream);
+        case 2: return launch_planes<4, 2, 2, 5>(g, stream);
+        case 3: return launch_planes<4, 2, 2, 7>(g, stream);
+        case 4: return launch_planes<4, 2, 1, 5>(g, stream);
+        case 5: return launch_planes<4, 2, 1, 7>(g, stream);
+        default: return launch_planes<1, 8, 5, 2>(g, stream);
     }
 }
 
 }  // namespace mmb
 
 // C = A (M,K) . B (N,K)^T + bias through the split passes and the planes kernel (tests / tools): ws needs
-// 6 * (M + N) * roundup(K, 32) bytes.
+// 6 * (roundup(M, 16) + roundup(N, 16)) * roundup(K, 32) bytes.
+extern "C" void mmb_set_planes_tune(int code) { mmb::planes_set_tune(code); }
+
 extern "C" int mmb_gemm_nt_planes(const float* A, const float* Bm, float* C, const float* bias, int M, int N, int K,
                                   void* ws, size_t ws_bytes, int device, void* stream_) {
     using namespace mmb;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MMB_REQUIRE(A && Bm && C && ws && M > 0 && N > 0 && K > 0 && K % 4 == 0, "mmb_gemm_nt_planes: bad argument");
     const int Kp = (K + 31) / 32 * 32;
-    MMB_REQUIRE(ws_bytes >= (size_t)6 * (M + N) * Kp, "mmb_gemm_nt_planes: workspace too small");
+    MMB_REQUIRE(ws_bytes >= planes_bytes(M, Kp) + planes_bytes(N, Kp), "mmb_gemm_nt_planes: workspace too small");
     MMB_HIP(hipSetDevice(device));
     bf16_t* aP = static_cast<bf16_t*>(ws);
-    bf16_t* bP = aP + (size_t)3 * M * Kp;
+    bf16_t* bP = reinterpret_cast<bf16_t*>(static_cast<char*>(ws) + planes_bytes(M, Kp));
     SplitRowsArgs sa{};
-    sa.src1 = A; sa.src2 = A; sa.R1 = M; sa.R = M; sa.C = K; sa.ld = K; sa.Cp = Kp; sa.planes = aP; sa.plane_stride = (size_t)M * Kp;
+    sa.src1 = A; sa.src2 = A; sa.R1 = M; sa.R = M; sa.C = K; sa.ld = K; sa.Cp = Kp; sa.planes = aP;
     if (int rc = planes_split_rows(sa, stream)) return rc;
     SplitRowsArgs sb{};
-    sb.src1 = Bm; sb.src2 = Bm; sb.R1 = N; sb.R = N; sb.C = K; sb.ld = K; sb.Cp = Kp; sb.planes = bP; sb.plane_stride = (size_t)N * Kp;
+    sb.src1 = Bm; sb.src2 = Bm; sb.R1 = N; sb.R = N; sb.C = K; sb.ld = K; sb.Cp = Kp; sb.planes = bP;
     if (int rc = planes_split_rows(sb, stream)) return rc;
     PlanesGemmArgs g{};
-    g.A = aP; g.a_plane = sa.plane_stride; g.lda = Kp; g.B = bP; g.b_plane = sb.plane_stride; g.ldb = Kp;
+    g.A = aP; g.B = bP;
     g.C = C; g.ldc = N; g.bias = bias; g.M = M; g.N = N; g.K = Kp;
     return planes_gemm(g, stream);
 }

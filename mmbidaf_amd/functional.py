@@ -236,7 +236,7 @@ def gemm_nt_planes(a, b, bias=None):
     M, K = a.shape
     N = b.shape[0]
     Kp = (K + 31) // 32 * 32
-    ws = torch.empty(6 * (M + N) * Kp, device=a.device, dtype=torch.uint8)
+    ws = torch.empty(6 * ((M + 15) // 16 * 16 + (N + 15) // 16 * 16) * Kp, device=a.device, dtype=torch.uint8)
     c = torch.empty(M, N, device=a.device, dtype=torch.float32)
     rc = lib.mmb_gemm_nt_planes(_ptr(a), _ptr(b), _ptr(c), _ptr(bias), M, N, K, _ptr(ws), ws.numel(), a.device.index, _stream())
     _lib.check(rc, "mmb_gemm_nt_planes")

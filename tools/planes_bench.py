@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Kernel-only timings of the operand-plane GEMM on the cfg2 hot-path shapes (GPU box only).
+MMB_PLANES_TUNE is honoured, so variants can be compared from the shell."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from mmbidaf_amd import functional as MF
+from mmbidaf_amd import _lib
+
+dev = torch.device("cuda:0")
+SHAPES = [  # (name, M, N, K) of C = A (M,K) . B (N,K)^T
+    ("gx text-enc ", 12800, 800, 300),
+    ("gx aud-enc  ", 8192, 800, 128),
+    ("gx mod L0   ", 12800, 800, 800),
+    ("gx mod L1   ", 12800, 800, 200),
+    ("dx mod L0   ", 12800, 800, 800),
+    ("dx mod L1   ", 12800, 200, 800),
+    ("dx text-enc ", 12800, 300, 800),
+    ("dW mod L0   ", 800, 1000, 12800),
+    ("dW mod L1   ", 800, 400, 12800),
+    ("dW text-enc ", 800, 500, 12800),
+    ("dW aud-enc  ", 800, 328, 8192),
+]
+tot = 0.0
+for name, M, N, K in SHAPES:
+    a = torch.randn(M, K, device=dev)
+    b = torch.randn(N, K, device=dev)
+    ref = a.double() @ b.double().t()
+    got = MF.gemm_nt_planes(a, b)
+    err = (got - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    for _ in range(3):
+        MF.gemm_nt_planes(a, b)
+    torch.cuda.synchronize()
+    _lib.profile_enable(["gemm", "split"])
+    for _ in range(10):
+        MF.gemm_nt_planes(a, b)
+    torch.cuda.synchronize()
+    _lib.profile_enable([])
+    gms, gn, _ = _lib.profile_read("gemm")
+    sms, sn, _ = _lib.profile_read("split")
+    fl = 2.0 * M * N * K
+    t = gms / gn * 1e-3
+    tot += t
+    print(f"{name} {M:6d}x{N:4d}x{K:6d}  planes gemm {t*1e6:8.1f} us  {fl/t/1e12:6.1f} TF fp32-equiv  {6*fl/t/1e15:5.2f} PF bf16 "
+          f"(+ splits {sms/10*1e3:6.1f} us) | relerr {err:.1e}", flush=True)
+print(f"sum {tot*1e6:.1f} us")

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Sweep of the operand-plane GEMM's tile configurations / K splits on the hot-path shapes (GPU box only):
+prints the kernel-only time of every (config, split) next to the cost model's own pick."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from mmbidaf_amd import functional as MF
+from mmbidaf_amd import _lib
+
+dev = torch.device("cuda:0")
+CFG = ["256x160", "160x256", "128x160", "128x224", "64x160", "64x224", "80x256"]
+SHAPES = [
+    ("gx text-enc ", 12800, 800, 300), ("gx aud-enc  ", 8192, 800, 128), ("gx mod L0   ", 12800, 800, 800),
+    ("gx mod L1   ", 12800, 800, 200), ("dx mod L1   ", 12800, 200, 800), ("dx text-enc ", 12800, 300, 800),
+    ("dW mod L0   ", 800, 1000, 12800), ("dW mod L1   ", 800, 400, 12800), ("dW text-enc ", 800, 500, 12800),
+    ("dW aud-enc  ", 800, 328, 8192),
+]
+lib = _lib.load()
+
+
+def t_us(a, b, n=6):
+    for _ in range(2):
+        MF.gemm_nt_planes(a, b)
+    torch.cuda.synchronize()
+    _lib.profile_enable(["gemm"])
+    for _ in range(n):
+        MF.gemm_nt_planes(a, b)
+    torch.cuda.synchronize()
+    _lib.profile_enable([])
+    ms, cnt, _ = _lib.profile_read("gemm")
+    return ms / cnt * 1e3
+
+
+for name, M, N, K in SHAPES:
+    a = torch.randn(M, K, device=dev)
+    b = torch.randn(N, K, device=dev)
+    lib.mmb_set_planes_tune(-1)
+    auto = t_us(a, b)
+    res = []
+    splits = [0] if K < 2048 else [1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24]
+    for c in range(len(CFG)):
+        for s in splits:
+            lib.mmb_set_planes_tune(c * 100 + s)
+            res.append((t_us(a, b), CFG[c], s))
+    lib.mmb_set_planes_tune(-1)
+    res.sort()
+    best = ", ".join(f"{n} s{s}: {t:.1f}" for t, n, s in res[:5])
+    print(f"{name} {M}x{N}x{K}: model {auto:.1f} us | best {best}", flush=True)
