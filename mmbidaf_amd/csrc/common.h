@@ -107,6 +107,7 @@ struct SplitTArgs {
     int R, period, Rp, Ctot;
     bf16_t* planes;
     const float* stack_ptr; int stack_R1;
+    float* zero_ptr; long zero_n;   // optional: this pass also zeroes zero_n floats (the split-K output of the GEMM that follows)
 };
 struct PlanesGemmArgs {
     const bf16_t* A;   // tiled planes of the (M x K) operand
@@ -115,12 +116,14 @@ struct PlanesGemmArgs {
     const float* bias;
     int M, N, K;
     int accumulate;
-    int splitk;   // set by planes_gemm
+    int prezeroed;   // C is already zero (a split pass did it): skip the memset a K split needs
+    int splitk;      // set by planes_gemm
     int dbg;      // timing-only ablation (MMB_PLANES_DBG): 2 = no MFMA
 };
 int planes_split_rows(const SplitRowsArgs& a, hipStream_t stream);
 int planes_split_transpose(const SplitTArgs& a, hipStream_t stream);
 int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream);
 void planes_set_tune(int code);
+int planes_plan_splitk(const PlanesGemmArgs& g);   // the K split planes_gemm will use for g
 
 }  // namespace mmb

@@ -186,7 +186,8 @@ struct RecBwdProb {
     const float* w_hh[2];  // (4H,H)
     const int* len;
     float* d_a;            // (B,T,2,4H) torch gate order
-    float* d_b;            // (2,4H) accumulated with atomics (pre-zeroed)
+    float* d_b;            // (2,4H) accumulated with atomics (pre-zeroed) when db_part is null
+    float* db_part;        // (2,B,4H) per-sample partial bias gradients (plain stores; reduced by lstm_unpack_dw_kernel) or null
     int B, T, H, wg_begin;
 };
 struct RecBwdArgs {
@@ -356,7 +357,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     for (; s < len; ++s) step(ld_g(s), ld_cp(s), ld_dy(s));  // tail (< PF steps): synchronous loads
 
-    if (real && valid) atomicAdd(&P.d_b[(size_t)dir * 4 * H + kq * H + u], db_acc);
+    if (real && valid) {
+        if (P.db_part) P.db_part[((size_t)dir * P.B + b) * 4 * H + kq * H + u] = db_acc;
+        else atomicAdd(&P.d_b[(size_t)dir * 4 * H + kq * H + u], db_acc);
+    }
     // dead steps contribute nothing: zero their d_a rows for the weight-gradient GEMMs
     float* da_z = P.d_a + (size_t)b * T * 8 * H + (size_t)dir * 4 * H;
     for (int i = tid; i < (T - len) * 4 * H; i += blockDim.x) {
@@ -365,18 +369,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-// d_w_cat (8H, I+2H) -> d_w_ih (2,4H,I), d_w_hh (2,4H,H): rows [dir*4H..), columns [0,I) | [I + dir*H, +H)
+// d_w_cat (8H, I+2H) -> d_w_ih (2,4H,I), d_w_hh (2,4H,H): rows [dir*4H..), columns [0,I) | [I + dir*H, +H);
+// with db_part, also d_b (2,4H) = sum over the B samples of the recurrence's per-sample partials
 __global__ __launch_bounds__(256) void lstm_unpack_dw_kernel(const float* __restrict__ cat, float* __restrict__ d_w_ih,
-                                                             float* __restrict__ d_w_hh, int H, int I) {
+                                                             float* __restrict__ d_w_hh, int H, int I,
+                                                             const float* __restrict__ db_part, float* __restrict__ d_b, int B) {
     const int ldc = I + 2 * H;
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (db_part && idx < 8 * H) {
+        const int dir = idx / (4 * H), rem = idx % (4 * H);
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += db_part[((size_t)dir * B + b) * 4 * H + rem];
+        d_b[idx] = acc;
+    }
     if (idx >= 8 * H * ldc) return;
     const int row = idx / ldc, col = idx % ldc, dir = row / (4 * H);
     const float v = cat[idx];
     if (col < I) d_w_ih[(size_t)row * I + col] = v;
     else if (col - I >= dir * H && col - I < (dir + 1) * H) d_w_hh[(size_t)row * H + (col - I - dir * H)] = v;
 }
-
 
 // ---- operand-plane scratch layout (planes.hip): byte offsets inside desc.ws
 static size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -392,8 +403,8 @@ static WsFwd ws_fwd_layout(long BT, int I, int H) {
     w.total = o;
     return w;
 }
-struct WsBwd { size_t daP, daT, xcT, wT, total; int K8, BTp; };
-static WsBwd ws_bwd_layout(long BT, int I, int H) {
+struct WsBwd { size_t daP, daT, xcT, wT, dbp, total; int K8, BTp; };
+static WsBwd ws_bwd_layout(long BT, int B, int I, int H) {
     WsBwd w{};
     w.K8 = (int)rup(8 * H, 32);
     w.BTp = (int)rup(BT, 32);
@@ -402,6 +413,7 @@ static WsBwd ws_bwd_layout(long BT, int I, int H) {
     w.daT = o; o += rup(planes_bytes(8 * H, w.BTp), 256);
     w.xcT = o; o += rup(planes_bytes(I + 2 * H, w.BTp), 256);
     w.wT = o;  o += rup(planes_bytes(I, w.K8), 256);
+    w.dbp = o; o += rup((size_t)2 * B * 4 * H * 4, 256);
     w.total = o;
     return w;
 }
@@ -454,7 +466,7 @@ static int kq_for(int H) {
 static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream) {
     const int H = p.H, I = p.I;
     const long BT = (long)p.B * p.T;
-    const WsBwd L = ws_bwd_layout(BT, I, H);
+    const WsBwd L = ws_bwd_layout(BT, p.B, I, H);
     char* ws = static_cast<char*>(p.ws);
     bf16_t* daP = reinterpret_cast<bf16_t*>(ws + L.daP);
     bf16_t* daT = reinterpret_cast<bf16_t*>(ws + L.daT);
@@ -465,6 +477,11 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream) {
     ta.nseg = 1; ta.seg_ptr[0] = p.d_a; ta.seg_ld[0] = 8 * H; ta.seg_cols[0] = 8 * H; ta.seg_shift[0] = 0;
     ta.R = (int)BT; ta.period = 1; ta.Rp = L.BTp; ta.Ctot = 8 * H; ta.planes = daT;
     if (int rc = planes_split_transpose(ta, stream)) return rc;
+    PlanesGemmArgs gw{};
+    gw.A = daT;
+    gw.B = xcT;
+    gw.C = p.d_w_cat; gw.ldc = I + 2 * H; gw.M = 8 * H; gw.N = I + 2 * H; gw.K = L.BTp;
+    const bool ksplit = planes_plan_splitk(gw) > 1;   // its zeroing rides on the split pass below
     // [x | y_fwd(t-1) | y_rev(t+1)]^T planes ((I+2H) x BT): h_prev is y shifted by one step inside each sample
     SplitTArgs tx{};
     tx.nseg = 3;
@@ -472,16 +489,14 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream) {
     tx.seg_ptr[1] = p.y;     tx.seg_ld[1] = 2 * H; tx.seg_cols[1] = H; tx.seg_shift[1] = -1;
     tx.seg_ptr[2] = p.y + H; tx.seg_ld[2] = 2 * H; tx.seg_cols[2] = H; tx.seg_shift[2] = +1;
     tx.R = (int)BT; tx.period = p.T; tx.Rp = L.BTp; tx.Ctot = I + 2 * H; tx.planes = xcT;
+    if (ksplit) { tx.zero_ptr = p.d_w_cat; tx.zero_n = (long)8 * H * (I + 2 * H); gw.prezeroed = 1; }
     if (int rc = planes_split_transpose(tx, stream)) return rc;
     {
-        PlanesGemmArgs g{};
-        g.A = daT;
-        g.B = xcT;
-        g.C = p.d_w_cat; g.ldc = I + 2 * H; g.M = 8 * H; g.N = I + 2 * H; g.K = L.BTp;
-        if (int rc = planes_gemm(g, stream)) return rc;
+        if (int rc = planes_gemm(gw, stream)) return rc;
         const int total = 8 * H * (I + 2 * H);
         ProfScope ps_(MMB_K_GEMM, stream);
-        hipLaunchKernelGGL(lstm_unpack_dw_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.d_w_cat, p.d_w_ih, p.d_w_hh, H, I);
+        hipLaunchKernelGGL(lstm_unpack_dw_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.d_w_cat, p.d_w_ih, p.d_w_hh, H, I,
+                           reinterpret_cast<const float*>(ws + L.dbp), p.d_b, p.B);
         MMB_HIP(hipGetLastError());
     }
     if (p.d_x) {
@@ -511,7 +526,7 @@ using namespace mmb;
 extern "C" size_t mmb_bilstm_ws_bytes(int B, int T, int I, int H, int backward) {
     if (B < 1 || T < 1 || I < 1 || H < 1 || I % 4 || H % 4) return 0;
     const long BT = (long)B * T;
-    return backward ? ws_bwd_layout(BT, I, H).total : ws_fwd_layout(BT, I, H).total;
+    return backward ? ws_bwd_layout(BT, B, I, H).total : ws_fwd_layout(BT, I, H).total;
 }
 
 extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int device, void* stream_) {
@@ -584,8 +599,11 @@ extern "C" int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* d, int n, int devic
         MMB_REQUIRE(p.H >= 1 && p.H <= MMB_LSTM_MAX_H, "H=%d unsupported (max %d)", p.H, MMB_LSTM_MAX_H);
         MMB_REQUIRE(p.d_y && p.x && p.y && p.lengths && p.gates && p.cs && p.d_w_ih && p.d_w_hh && p.d_b && p.d_a,
                     "null pointer in bwd desc %d", i);
-        MMB_HIP(hipMemsetAsync(p.d_b, 0, sizeof(float) * 8 * H, stream));
+        // the operand-plane path reduces per-sample bias-gradient partials in its unpack kernel; otherwise atomics
+        const bool part = p.ws && p.d_w_cat && planes_ok(p.I, H);
+        if (!part) MMB_HIP(hipMemsetAsync(p.d_b, 0, sizeof(float) * 8 * H, stream));
         RecBwdProb& q = ra.p[i];
+        q.db_part = part ? reinterpret_cast<float*>(static_cast<char*>(p.ws) + ws_bwd_layout((long)p.B * p.T, p.B, p.I, H).dbp) : nullptr;
         q.d_y = p.d_y; q.d_hn = p.d_hn; q.gates = p.gates; q.cs = p.cs;
         q.w_hh[0] = p.w_hh[0]; q.w_hh[1] = p.w_hh[1]; q.len = p.lengths;
         q.d_a = p.d_a; q.d_b = p.d_b; q.B = p.B; q.T = p.T; q.H = p.H; q.wg_begin = wg;
@@ -625,7 +643,7 @@ extern "C" int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* d, int n, int devic
                 const int total = 8 * H * (p.I + 2 * H);
                 ProfScope ps_(MMB_K_GEMM, stream);
                 hipLaunchKernelGGL(lstm_unpack_dw_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.d_w_cat, p.d_w_ih,
-                                   p.d_w_hh, H, p.I);
+                                   p.d_w_hh, H, p.I, static_cast<const float*>(nullptr), p.d_b, p.B);
                 MMB_HIP(hipGetLastError());
                 fused = true;
             }

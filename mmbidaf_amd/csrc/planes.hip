@@ -86,6 +86,10 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTArgs a
     __shared__ float tile[32][65];
     const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 64;
     const int t = threadIdx.x;
+    if (a.zero_ptr) {
+        const long total = (long)gridDim.x * gridDim.y * 256;
+        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + t; i < a.zero_n; i += total) a.zero_ptr[i] = 0.f;
+    }
     // load 32 source rows x 64 columns (two float4 per thread), per-chunk segment lookup, shifted rows, zero outside
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
         size_t rbk;
         if (blk < BM / 16) {
             base = reinterpret_cast<const char*>(g.A);
-            rbk = (size_t)min(m0 / 16 + blk, nrbA - 1);
+            rbk = (size_t)min(((g.dbg & 1) ? 0 : m0 / 16) + blk, nrbA - 1);   // dbg 1 (timing-only): every tile reads A tile 0
         } else {
             base = reinterpret_cast<const char*>(g.B);
             rbk = (size_t)min(n0 / 16 + blk - BM / 16, nrbB - 1);
@@ -343,35 +347,33 @@ constexpr PlanesCfg PLANES_CFGS[] = {{4, 2, 4, 5}, {2, 4, 5, 4}, {4, 2, 2, 5}, {
 constexpr int N_PLANES_CFGS = sizeof(PLANES_CFGS) / sizeof(PLANES_CFGS[0]);
 int g_planes_force = -1;   // <config * 100 + split> from mmb_set_planes_tune / MMB_PLANES_TUNE, -1 = cost model
 
-// estimated cycles of (config, split): rounds of 256 workgroups x K tiles x max(MFMA issue of the SIMD's two waves,
-// L2 -> LDS stream of the stage at the ~29 B/clk/CU the chip sustains with every CU streaming) + fixed costs
+// estimated cycles of (config, split): rounds of 256 workgroups x K tiles x max(MFMA issue of the SIMD's two waves at
+// the ~20 cycles an MFMA sustains under this load, L2 -> LDS stream of the stage at the ~29 B/clk/CU the chip
+// sustains with every CU streaming) + fixed costs; split-K pays the zeroing and atomics at the chip's ~1.3 TB/s
+// (~590 B/clk).  Constants fitted to tools/planes_sweep.py on the hot-path shapes (picks within ~5 % of the best).
 double planes_cost(const PlanesGemmArgs& g, const PlanesCfg& c, int splitk) {
     const int bm = c.wm * c.mt * 16, bn = c.wn * c.nt * 16;
     const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
     const long nk = ((g.K + splitk - 1) / splitk + 31) / 32;
     const long rounds = (tiles * splitk + 255) / 256;
-    const double mfma = 2.0 * c.mt * c.nt * 6 * 16, dma = 3.0 * (bm + bn) * 64 / 29.0;
+    const double mfma = 2.0 * c.mt * c.nt * 6 * 20, dma = 3.0 * (bm + bn) * 64 / 29.0;
     const double per_tile = (mfma > dma ? mfma + 0.25 * dma : dma + 0.25 * mfma) + 300.0;
-    double cost = (double)rounds * (nk * per_tile + 4000.0 + 1.5 * bm * bn / 8.0);   // + prologue, first DMA, epilogue stores
-    if (splitk > 1) cost += 3000.0 + 0.02 * (double)g.M * g.N * splitk / 256.0;     // zeroing + atomics
+    double cost = (double)rounds * (nk * per_tile + 6000.0 + 1.5 * bm * bn / 8.0);   // + prologue, first DMA, epilogue stores
+    if (splitk > 1) cost += 8000.0 + 0.0068 * (double)g.M * g.N * splitk;
     return cost;
 }
 }  // namespace
 
 void planes_set_tune(int code) { g_planes_force = code; }
 
-int planes_gemm(const PlanesGemmArgs& g_, hipStream_t stream) {
-    PlanesGemmArgs g = g_;
-    static int dbg = -1, verbose = 0;   // MMB_PLANES_DBG: timing-only ablations; MMB_PLANES_TUNE = <config><split, 2 digits>
-    if (dbg < 0) {
-        const char* e = getenv("MMB_PLANES_DBG");
-        dbg = e ? atoi(e) : 0;
+static void planes_choose(const PlanesGemmArgs& g, int& best, int& best_s) {
+    static bool env_read = false;
+    if (!env_read) {   // MMB_PLANES_TUNE = <config><split, 2 digits>
         const char* t = getenv("MMB_PLANES_TUNE");
         if (t) g_planes_force = atoi(t);
-        verbose = getenv("MMB_PLANES_VERBOSE") != nullptr;
+        env_read = true;
     }
-    g.dbg = dbg;
-    int best = 0, best_s = 1;
+    best = 0; best_s = 1;
     double best_cost = 1e300;
     for (int c = 0; c < N_PLANES_CFGS; ++c)
         for (int s = 1; s <= 32; ++s) {
@@ -383,11 +385,30 @@ int planes_gemm(const PlanesGemmArgs& g_, hipStream_t stream) {
         best = (g_planes_force / 100) % N_PLANES_CFGS;
         if (g_planes_force % 100 > 0) best_s = g_planes_force % 100;
     }
+}
+
+int planes_plan_splitk(const PlanesGemmArgs& g) {
+    int best, best_s;
+    planes_choose(g, best, best_s);
+    return best_s;
+}
+
+int planes_gemm(const PlanesGemmArgs& g_, hipStream_t stream) {
+    PlanesGemmArgs g = g_;
+    static int dbg = -1, verbose = 0;   // MMB_PLANES_DBG: timing-only ablations
+    if (dbg < 0) {
+        const char* e = getenv("MMB_PLANES_DBG");
+        dbg = e ? atoi(e) : 0;
+        verbose = getenv("MMB_PLANES_VERBOSE") != nullptr;
+    }
+    g.dbg = dbg;
+    int best, best_s;
+    planes_choose(g, best, best_s);
     if (verbose)
         fprintf(stderr, "planes_gemm %dx%dx%d: tile %dx%d split %d\n", g.M, g.N, g.K, PLANES_CFGS[best].wm * PLANES_CFGS[best].mt * 16,
                 PLANES_CFGS[best].wn * PLANES_CFGS[best].nt * 16, best_s);
     g.splitk = best_s;
-    if (g.splitk > 1 && !g.accumulate)
+    if (g.splitk > 1 && !g.accumulate && !g.prezeroed)
         MMB_HIP(hipMemset2DAsync(g.C, (size_t)g.ldc * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream));
     switch (best) {
         case 0: return launch_planes<4, 2, 4, 5>(g, stream);

@@ -17,9 +17,12 @@ SHAPES = [
     ("gx text-enc ", 12800, 800, 300), ("gx aud-enc  ", 8192, 800, 128), ("gx mod L0   ", 12800, 800, 800),
     ("gx mod L1   ", 12800, 800, 200), ("dx mod L1   ", 12800, 200, 800), ("dx text-enc ", 12800, 300, 800),
     ("dW mod L0   ", 800, 1000, 12800), ("dW mod L1   ", 800, 400, 12800), ("dW text-enc ", 800, 500, 12800),
-    ("dW aud-enc  ", 800, 328, 8192),
+    ("dW aud-enc  ", 800, 328, 8192), ("dW img-enc  ", 800, 300, 2048), ("gx img-enc  ", 2048, 800, 100),
+    ("dx aud-enc  ", 8192, 128, 800), ("gx cfg4 L0  ", 51200, 800, 800), ("dW cfg4 L0  ", 800, 1000, 51200),
+    ("gx cfg1 L0  ", 150, 800, 800), ("dW cfg1 L0  ", 800, 1000, 150),
 ]
 lib = _lib.load()
+ALL = []
 
 
 def t_us(a, b, n=6):
@@ -41,12 +44,16 @@ for name, M, N, K in SHAPES:
     lib.mmb_set_planes_tune(-1)
     auto = t_us(a, b)
     res = []
-    splits = [0] if K < 2048 else [1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24]
+    splits = [1] if K < 1024 else ([1, 2] if K < 2048 else [1, 2, 3, 4, 6, 8, 10, 12, 16, 20, 24, 32])
     for c in range(len(CFG)):
         for s in splits:
             lib.mmb_set_planes_tune(c * 100 + s)
             res.append((t_us(a, b), CFG[c], s))
     lib.mmb_set_planes_tune(-1)
+    ALL.append({"name": name.strip(), "M": M, "N": N, "K": K, "model_us": auto, "runs": [[n, sp, t] for t, n, sp in res]})
     res.sort()
     best = ", ".join(f"{n} s{s}: {t:.1f}" for t, n, s in res[:5])
     print(f"{name} {M}x{N}x{K}: model {auto:.1f} us | best {best}", flush=True)
+
+import json
+json.dump(ALL, open(os.path.join(ROOT, "gpurun_out", "planes_sweep.json"), "w"))
