@@ -27,7 +27,8 @@ extern "C" {
 #define MMB_VERSION 100            /* 0.1.0 */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
 #define MMB_ATT_MAX_D 208          /* attention feature width D = 2H supported by this build */
-#define MMB_LSTM_MAX_H 128         /* hidden size supported by the register-resident recurrence */
+#define MMB_LSTM_MAX_H 128         /* hidden size of the register-resident recurrence (one launch per layer) */
+#define MMB_LSTM_GENERAL_MAX_H 1024 /* larger H (up to this) runs the general recurrence: one launch per time step; needs ws */
 
 enum {
     MMB_OK = 0,

@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_HERE, "libmmbidaf_hip.so")
 
 MAX_GROUP = 8
 ATT_MAX_D = 208
-LSTM_MAX_H = 128
+LSTM_MAX_H = 128            # register-resident recurrence (one launch per layer)
+LSTM_GENERAL_MAX_H = 1024   # general recurrence (one launch per time step)
 
 c_f = ctypes.c_void_p  # device pointers travel as raw addresses
 c_i = ctypes.c_int

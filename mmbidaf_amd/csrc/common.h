@@ -10,6 +10,7 @@
 namespace mmb {
 
 using f4 = float __attribute__((ext_vector_type(4)));
+using f2 = float __attribute__((ext_vector_type(2)));
 
 // ---- error plumbing (thread-local message, C-ABI return codes)
 char* err_buf();
@@ -125,5 +126,11 @@ int planes_split_transpose(const SplitTArgs& a, hipStream_t stream);
 int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream);
 void planes_set_tune(int code);
 int planes_plan_splitk(const PlanesGemmArgs& g);   // the K split planes_gemm will use for g
+
+// ---- general-size LSTM recurrence (lstm_big.hip): H > MMB_LSTM_MAX_H
+size_t lstm_big_fwd_ws_bytes(int H);
+size_t lstm_big_bwd_ws_bytes(int B, int H);
+int lstm_big_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* big_ws, hipStream_t stream);
+int lstm_big_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* big_ws, hipStream_t stream);
 
 }  // namespace mmb

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void lstm_unpack_dw_kernel(const float* __rest
 // ---- operand-plane scratch layout (planes.hip): byte offsets inside desc.ws
 static size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static bool planes_ok(int I, int H) { return I % 4 == 0 && H % 4 == 0 && gemm_mode() != 0; }
-struct WsFwd { size_t xP, wP, bias, total; int Ip; };
+struct WsFwd { size_t xP, wP, bias, big, total; int Ip; };
 static WsFwd ws_fwd_layout(long BT, int I, int H) {
     WsFwd w{};
     w.Ip = (int)rup(I, 32);
@@ -400,10 +400,11 @@ static WsFwd ws_fwd_layout(long BT, int I, int H) {
     w.xP = o;   o += rup(planes_bytes(BT, w.Ip), 256);
     w.wP = o;   o += rup(planes_bytes(8 * H, w.Ip), 256);
     w.bias = o; o += rup((size_t)8 * H * 4, 256);
+    w.big = o;  if (H > MMB_LSTM_MAX_H) o += rup(lstm_big_fwd_ws_bytes(H), 256);
     w.total = o;
     return w;
 }
-struct WsBwd { size_t daP, daT, xcT, wT, dbp, total; int K8, BTp; };
+struct WsBwd { size_t daP, daT, xcT, wT, dbp, big, total; int K8, BTp; };
 static WsBwd ws_bwd_layout(long BT, int B, int I, int H) {
     WsBwd w{};
     w.K8 = (int)rup(8 * H, 32);
@@ -414,6 +415,7 @@ static WsBwd ws_bwd_layout(long BT, int B, int I, int H) {
     w.xcT = o; o += rup(planes_bytes(I + 2 * H, w.BTp), 256);
     w.wT = o;  o += rup(planes_bytes(I, w.K8), 256);
     w.dbp = o; o += rup((size_t)2 * B * 4 * H * 4, 256);
+    w.big = o; if (H > MMB_LSTM_MAX_H) o += rup(lstm_big_bwd_ws_bytes(B, H), 256);
     w.total = o;
     return w;
 }
@@ -444,7 +446,7 @@ static int gx_planes(const mmb_lstm_fwd_desc& p, hipStream_t stream) {
 }
 
 // weight and input gradients of one problem through the operand planes: 4 split passes + 2 GEMMs (+ unpack)
-static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream);
+static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_partials);
 
 template <typename ArgsT, typename K>
 static int launch_rec(K kernel, const ArgsT& a, int total_wgs, int H, hipStream_t stream, int kid) {
@@ -463,7 +465,7 @@ static int kq_for(int H) {
 }
 
 
-static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream) {
+static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_partials) {
     const int H = p.H, I = p.I;
     const long BT = (long)p.B * p.T;
     const WsBwd L = ws_bwd_layout(BT, p.B, I, H);
@@ -496,7 +498,7 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream) {
         const int total = 8 * H * (I + 2 * H);
         ProfScope ps_(MMB_K_GEMM, stream);
         hipLaunchKernelGGL(lstm_unpack_dw_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.d_w_cat, p.d_w_ih, p.d_w_hh, H, I,
-                           reinterpret_cast<const float*>(ws + L.dbp), p.d_b, p.B);
+                           db_partials ? reinterpret_cast<const float*>(ws + L.dbp) : static_cast<const float*>(nullptr), p.d_b, p.B);
         MMB_HIP(hipGetLastError());
     }
     if (p.d_x) {
@@ -540,7 +542,9 @@ extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int devic
     for (int i = 0; i < n; ++i) {
         const mmb_lstm_fwd_desc& p = d[i];
         MMB_REQUIRE(p.H == H, "grouped LSTM problems must share H (%d vs %d)", p.H, H);
-        MMB_REQUIRE(p.H >= 1 && p.H <= MMB_LSTM_MAX_H, "H=%d unsupported (max %d)", p.H, MMB_LSTM_MAX_H);
+        MMB_REQUIRE(p.H >= 1 && p.H <= MMB_LSTM_GENERAL_MAX_H, "H=%d unsupported (max %d)", p.H, MMB_LSTM_GENERAL_MAX_H);
+        MMB_REQUIRE(p.H <= MMB_LSTM_MAX_H || (p.ws && p.H % 4 == 0 && p.I % 4 == 0),
+                    "H=%d > %d runs the general recurrence, which needs desc.ws and I, H multiples of 4", p.H, MMB_LSTM_MAX_H);
         MMB_REQUIRE(p.B >= 1 && p.T >= 1 && p.I >= 1, "bad LSTM sizes B=%d T=%d I=%d", p.B, p.T, p.I);
         MMB_REQUIRE(p.x && p.lengths && p.y && p.h_n && p.c_n && p.gx && p.gates && p.cs, "null pointer in desc %d", i);
         for (int dir = 0; dir < 2; ++dir)
@@ -566,6 +570,11 @@ extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int devic
         q.y = p.y; q.gates = p.gates; q.cs = p.cs; q.h_n = p.h_n; q.c_n = p.c_n;
         q.B = p.B; q.T = p.T; q.H = p.H; q.wg_begin = wg;
         wg += 2 * p.B;
+    }
+    if (H > MMB_LSTM_MAX_H) {
+        char* big_ws[MMB_MAX_GROUP];
+        for (int i = 0; i < n; ++i) big_ws[i] = static_cast<char*>(d[i].ws) + ws_fwd_layout((long)d[i].B * d[i].T, d[i].I, H).big;
+        return lstm_big_fwd(d, n, big_ws, stream);
     }
     switch (kq_for(H)) {
         case 8: return launch_rec(lstm_rec_fwd_kernel<8>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
@@ -593,15 +602,18 @@ extern "C" int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* d, int n, int devic
     ra.n = n;
     int wg = 0;
     const int H = d[0].H;
+    const bool big = H > MMB_LSTM_MAX_H;
     for (int i = 0; i < n; ++i) {
         const mmb_lstm_bwd_desc& p = d[i];
         MMB_REQUIRE(p.H == H, "grouped LSTM problems must share H (%d vs %d)", p.H, H);
-        MMB_REQUIRE(p.H >= 1 && p.H <= MMB_LSTM_MAX_H, "H=%d unsupported (max %d)", p.H, MMB_LSTM_MAX_H);
+        MMB_REQUIRE(p.H >= 1 && p.H <= MMB_LSTM_GENERAL_MAX_H, "H=%d unsupported (max %d)", p.H, MMB_LSTM_GENERAL_MAX_H);
+        MMB_REQUIRE(p.H <= MMB_LSTM_MAX_H || (p.ws && p.H % 4 == 0 && p.I % 4 == 0),
+                    "H=%d > %d runs the general recurrence, which needs desc.ws and I, H multiples of 4", p.H, MMB_LSTM_MAX_H);
         MMB_REQUIRE(p.d_y && p.x && p.y && p.lengths && p.gates && p.cs && p.d_w_ih && p.d_w_hh && p.d_b && p.d_a,
                     "null pointer in bwd desc %d", i);
         // the operand-plane path reduces per-sample bias-gradient partials in its unpack kernel; otherwise atomics
-        const bool part = p.ws && p.d_w_cat && planes_ok(p.I, H);
-        if (!part) MMB_HIP(hipMemsetAsync(p.d_b, 0, sizeof(float) * 8 * H, stream));
+        const bool part = !big && p.ws && p.d_w_cat && planes_ok(p.I, H);
+        if (!part && !big) MMB_HIP(hipMemsetAsync(p.d_b, 0, sizeof(float) * 8 * H, stream));
         RecBwdProb& q = ra.p[i];
         q.db_part = part ? reinterpret_cast<float*>(static_cast<char*>(p.ws) + ws_bwd_layout((long)p.B * p.T, p.B, p.I, H).dbp) : nullptr;
         q.d_y = p.d_y; q.d_hn = p.d_hn; q.gates = p.gates; q.cs = p.cs;
@@ -610,6 +622,11 @@ extern "C" int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* d, int n, int devic
         wg += 2 * p.B;
     }
     int rc;
+    if (big) {
+        char* big_ws[MMB_MAX_GROUP];
+        for (int i = 0; i < n; ++i) big_ws[i] = static_cast<char*>(d[i].ws) + ws_bwd_layout((long)d[i].B * d[i].T, d[i].B, d[i].I, H).big;
+        rc = lstm_big_bwd(d, n, big_ws, stream);
+    } else
     switch (kq_for(H)) {
         case 8: rc = launch_rec(lstm_rec_bwd_kernel<8>, ra, wg, H, stream, MMB_K_LSTM_REC_BWD); break;
         case 16: rc = launch_rec(lstm_rec_bwd_kernel<16>, ra, wg, H, stream, MMB_K_LSTM_REC_BWD); break;
@@ -621,7 +638,7 @@ extern "C" int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* d, int n, int devic
         const mmb_lstm_bwd_desc& p = d[i];
         const int BT = p.B * p.T;
         if (p.ws && p.d_w_cat && planes_ok(p.I, H)) {
-            rc = grads_planes(p, stream);
+            rc = grads_planes(p, stream, !big);
             if (rc) return rc;
             continue;
         }

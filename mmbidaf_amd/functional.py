@@ -139,8 +139,9 @@ class _BiLSTMLayerFn(torch.autograd.Function):
             ws_ = [_f32c(w) for w in ws_]
             B, T, I = x.shape
             H = ws_[1].shape[1]
-            if H > _lib.LSTM_MAX_H:
-                raise RuntimeError(f"mmbidaf_amd: hidden size {H} > {_lib.LSTM_MAX_H} not supported by this build")
+            if H > _lib.LSTM_GENERAL_MAX_H or (H > _lib.LSTM_MAX_H and (H % 4 or I % 4)):
+                raise RuntimeError(f"mmbidaf_amd: hidden size {H} not supported (max {_lib.LSTM_GENERAL_MAX_H}; "
+                                   f"above {_lib.LSTM_MAX_H} the hidden and input sizes must be multiples of 4)")
             y = torch.empty(B, T, 2 * H, device=dev, dtype=torch.float32)
             h_n = torch.empty(2, B, H, device=dev, dtype=torch.float32)
             c_n = torch.empty(2, B, H, device=dev, dtype=torch.float32)

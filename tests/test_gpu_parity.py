@@ -291,6 +291,48 @@ def test_rnn_encoder_long_sequence_cfg4_size():
     close(h, hr, "h_n")
 
 
+def test_rnn_encoder_general_hidden_size_vs_oracle():
+    """H above the register-resident limit (128) runs the general recurrence (one launch per step): a 2-layer
+    encoder with H=144 (partial unit tile), ragged lengths incl. 1 and full, B=5 (partial sample tile), next to a
+    grouped pair of 1-layer encoders with H=256 and different T."""
+    from mmbidaf_amd.encoding import RNNEncoder, encode_group
+    g = torch.Generator().manual_seed(31)
+    torch.manual_seed(5)
+    e = RNNEncoder(36, 144, 2).to(dev())
+    x = torch.randn(5, 23, 36, generator=g) * 0.5
+    l = [23, 1, 17, 9, 23]
+    xd = x.to(dev()).requires_grad_(True)
+    y, h = e(xd, l)
+    cy, ch = torch.randn(*y.shape, generator=g), torch.randn(*h.shape, generator=g)
+    ((y * cy.to(dev())).sum() + (h * ch.to(dev())).sum()).backward()
+    yr, hr, dxr, P = _oracle_encoder(e, x, l, cy, ch)
+    close(y, yr, "y")
+    close(h, hr, "h_n")
+    close(xd.grad, dxr, "d_x")
+    for n, p in e.named_parameters():
+        close(p.grad, P[n[4:]].grad, "grad " + n)
+    for b, lb in enumerate(l):
+        assert (y[b, lb:] == 0).all()
+    # grouped launch, H = 256
+    encs, xs, lens = [], [], []
+    for T in (19, 11):
+        torch.manual_seed(200 + T)
+        encs.append(RNNEncoder(40, 256, 1).to(dev()))
+        xs.append(torch.randn(3, T, 40, generator=g) * 0.5)
+        lens.append([T, max(1, T // 3), T - 1])
+    xg = [x_.to(dev()).requires_grad_(True) for x_ in xs]
+    outs = encode_group(encs, xg, lens)
+    cots = [(torch.randn(*o[0].shape, generator=g), torch.randn(*o[1].shape, generator=g)) for o in outs]
+    sum((y_ * cy_.to(dev())).sum() + (h_ * ch_.to(dev())).sum() for (y_, h_), (cy_, ch_) in zip(outs, cots)).backward()
+    for e_, x_, l_, (y_, h_), (cy_, ch_), xgi in zip(encs, xs, lens, outs, cots, xg):
+        yr, hr, dxr, P = _oracle_encoder(e_, x_, l_, cy_, ch_)
+        close(y_, yr, "y")
+        close(h_, hr, "h_n")
+        close(xgi.grad, dxr, "d_x")
+        for n, p in e_.named_parameters():
+            close(p.grad, P[n[4:]].grad, "grad " + n)
+
+
 def test_lstm_time_reversal_property_full_size():
     """Full cfg2 size (B=32, T=400): with full lengths, the reverse direction of an encoder equals the
     forward direction of the same weights on the time-reversed input (size-independent check)."""
