@@ -26,7 +26,8 @@ extern "C" {
 
 #define MMB_VERSION 100            /* 0.1.0 */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
-#define MMB_ATT_MAX_D 208          /* attention feature width D = 2H supported by this build */
+#define MMB_ATT_MAX_D 208          /* attention feature width D = 2H of the fused (register-resident) kernels */
+#define MMB_ATT_GENERAL_MAX_D 4096 /* wider D (up to this) runs the general path: similarity matrix in a workspace */
 #define MMB_LSTM_MAX_H 128         /* hidden size of the register-resident recurrence (one launch per layer) */
 #define MMB_LSTM_GENERAL_MAX_H 1024 /* larger H (up to this) runs the general recurrence: one launch per time step; needs ws */
 
@@ -68,13 +69,18 @@ const char* mmb_kernel_name(int kernel_id);   /* device-side symbol stem, as roc
  *   q (B,M,D)   = s2^T . text         bsave (B,T,D) = b
  *   rterm (B,T) = text_d.w_t + bias   cterm (B,M)   = mod_d.w_m
  *   row_stat (B,T,2) = {max, sum} of the row softmax     col_stat (B,M,2) likewise
- * D must be a multiple of 4 and <= MMB_ATT_MAX_D.
+ * D must be a multiple of 4.  D <= MMB_ATT_MAX_D runs the fused kernels (no scratch); wider D (up to
+ * MMB_ATT_GENERAL_MAX_D) materialises the (B,T,M) similarity matrix in `workspace`, which must then hold
+ * mmb_bidaf_fwd_workspace_bytes(B,T,M,D) bytes (0 for the fused path; workspace may be NULL then).
  */
+size_t mmb_bidaf_fwd_workspace_bytes(int B, int T, int M, int D);
+
 int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t* text_mask, const uint8_t* mod_mask,
                   const float* text_d, const float* mod_d,
                   const float* w_t, const float* w_m, const float* w_tm, const float* bias,
                   float* out, float* q, float* bsave, float* rterm, float* cterm,
                   float* row_stat, float* col_stat,
+                  float* workspace, size_t workspace_bytes,
                   int B, int T, int M, int D, int device, void* stream);
 
 /* bytes of scratch mmb_bidaf_bwd needs (fp32 workspace, contents undefined on entry) */

@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmbidaf_hip.so")
 
 MAX_GROUP = 8
-ATT_MAX_D = 208
+ATT_MAX_D = 208              # fused attention kernels
+ATT_GENERAL_MAX_D = 4096     # general path (similarity matrix in a workspace)
 LSTM_MAX_H = 128            # register-resident recurrence (one launch per layer)
 LSTM_GENERAL_MAX_H = 1024   # general recurrence (one launch per time step)
 
@@ -47,7 +48,8 @@ SIGNATURES = {
     "mmb_profile_enable": (c_i, [ctypes.c_uint32]),
     "mmb_profile_read": (c_i, [c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i)]),
     "mmb_kernel_name": (ctypes.c_char_p, [c_i]),
-    "mmb_bidaf_fwd": (c_i, [c_f] * 17 + [c_i] * 5 + [c_f]),
+    "mmb_bidaf_fwd_workspace_bytes": (ctypes.c_size_t, [c_i] * 4),
+    "mmb_bidaf_fwd": (c_i, [c_f] * 17 + [c_f, ctypes.c_size_t] + [c_i] * 5 + [c_f]),
     "mmb_bidaf_bwd_workspace_bytes": (ctypes.c_size_t, [c_i] * 4),
     "mmb_bidaf_bwd": (c_i, [c_f] * 26 + [ctypes.c_size_t] + [c_i] * 5 + [c_f]),
     "mmb_bilstm_layer_fwd": (c_i, [ctypes.POINTER(LstmFwdDesc), c_i, c_i, c_f]),

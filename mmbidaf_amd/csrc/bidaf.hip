@@ -954,15 +954,21 @@ using namespace mmb;
 
 static int check_att_dims(int B, int T, int M, int D) {
     MMB_REQUIRE(B >= 1 && T >= 1 && M >= 1, "bidaf: bad sizes B=%d T=%d M=%d", B, T, M);
-    MMB_REQUIRE(D >= 4 && D % 4 == 0 && D <= MMB_ATT_MAX_D, "bidaf: D=%d must be a multiple of 4 and <= %d", D, MMB_ATT_MAX_D);
+    MMB_REQUIRE(D >= 4 && D % 4 == 0 && D <= MMB_ATT_GENERAL_MAX_D, "bidaf: D=%d must be a multiple of 4 and <= %d", D,
+                MMB_ATT_GENERAL_MAX_D);
     return MMB_OK;
+}
+
+extern "C" size_t mmb_bidaf_fwd_workspace_bytes(int B, int T, int M, int D) {
+    if (B < 1 || T < 1 || M < 1 || D < 4 || D <= MMB_ATT_MAX_D) return 0;   // the fused kernels need no scratch
+    return bidaf_big_fwd_ws_floats(B, T, M, D) * sizeof(float);
 }
 
 extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t* text_mask, const uint8_t* mod_mask,
                              const float* text_d, const float* mod_d, const float* w_t, const float* w_m,
                              const float* w_tm, const float* bias, float* out, float* q, float* bsave, float* rterm,
-                             float* cterm, float* row_stat, float* col_stat, int B, int T, int M, int D, int device,
-                             void* stream_) {
+                             float* cterm, float* row_stat, float* col_stat, float* workspace, size_t workspace_bytes,
+                             int B, int T, int M, int D, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (int rc = check_att_dims(B, T, M, D)) return rc;
     MMB_REQUIRE(text && mod && text_mask && mod_mask && w_t && w_m && w_tm && bias && out && q && bsave && rterm &&
@@ -974,6 +980,12 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
     { ProfScope ps_(MMB_K_ATT_RANK1, stream); hipLaunchKernelGGL(att_rank1_kernel, dim3((B * T + B * M + 3) / 4), dim3(256), 0, stream, text_d, mod_d, w_t, w_m, bias,
                        rterm, cterm, B * T, B * M, D); }
     MMB_HIP(hipGetLastError());
+    if (D > MMB_ATT_MAX_D) {   // general-size path (bidaf_big.hip): similarity matrix materialised in the workspace
+        MMB_REQUIRE(workspace && workspace_bytes >= mmb_bidaf_fwd_workspace_bytes(B, T, M, D),
+                    "mmb_bidaf_fwd: D=%d > %d needs a workspace of mmb_bidaf_fwd_workspace_bytes()", D, MMB_ATT_MAX_D);
+        return bidaf_big_fwd(text, mod, text_mask, mod_mask, text_d, mod_d, w_tm, out, q, bsave, rterm, cterm, row_stat, col_stat,
+                             workspace, B, T, M, D, stream);
+    }
 
     // ---- column pass: lane side = modality rows, streams text.  (`out` is used as scratch for the split
     //      partials: it is (B,T,4D) and is only written by the row pass afterwards.)
@@ -1030,6 +1042,7 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
 
 extern "C" size_t mmb_bidaf_bwd_workspace_bytes(int B, int T, int M, int D) {
     if (B < 1 || T < 1 || M < 1 || D < 4) return 0;
+    if (D > MMB_ATT_MAX_D) return bidaf_big_bwd_ws_floats(B, T, M, D) * sizeof(float);
     return bwd_layout(B, T, M, D).total * sizeof(float);
 }
 
@@ -1049,10 +1062,14 @@ extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* 
     MMB_REQUIRE(drop_t == drop_m, "mmb_bidaf_bwd: text_d and mod_d must both be given or both be NULL");
     MMB_REQUIRE(drop_t ? (d_text_d && d_mod_d) : (!d_text_d && !d_mod_d),
                 "mmb_bidaf_bwd: d_text_d/d_mod_d must be given exactly when text_d/mod_d are");
-    const BwdWs L = bwd_layout(B, T, M, D);
-    MMB_REQUIRE(workspace_bytes >= L.total * sizeof(float), "mmb_bidaf_bwd: workspace too small (%zu < %zu)", workspace_bytes,
-                L.total * sizeof(float));
+    MMB_REQUIRE(workspace_bytes >= mmb_bidaf_bwd_workspace_bytes(B, T, M, D), "mmb_bidaf_bwd: workspace too small (%zu < %zu)",
+                workspace_bytes, mmb_bidaf_bwd_workspace_bytes(B, T, M, D));
     MMB_HIP(hipSetDevice(device));
+    if (D > MMB_ATT_MAX_D)
+        return bidaf_big_bwd(d_out, out, text, mod, text_mask, mod_mask, text_d, mod_d, w_t, w_m, w_tm, q, bsave, rterm, cterm,
+                             row_stat, col_stat, d_text, d_mod, d_text_d, d_mod_d, d_w_t, d_w_m, d_w_tm, d_bias, workspace, B, T, M,
+                             D, stream);
+    const BwdWs L = bwd_layout(B, T, M, D);
 
     const int geom_j1 = geom_for(2, GEOM_4x32), geom_j2 = geom_for(3, GEOM_4x32), geom_i = geom_for(4, GEOM_4x32);
     // both j sweeps must agree on how the text rows are split (the partial buffers are indexed by split)

@@ -75,6 +75,16 @@ struct GemmArgs {
     int nseg;
     const float* seg_ptr[3];
     int seg_ld[3], seg_cols[3], seg_shift[3];
+    // batch > 1: `batch` independent products, operand b at A + b*sA, B + b*sB, C + b*sC (no K split, no segments)
+    int batch;
+    long sA, sB, sC;
+    // use_ptrs != 0 (with batch > 1): product b reads Ap[b], Bp[b] and writes Cp[b] instead (grouped GEMM, <= 16 products)
+    int use_ptrs;
+    int c_zeroed;   // batched only: every C is already zero, so the launcher may split K (atomic accumulation)
+    int bsplit;     // set by the launcher: K splits per product in batched mode (blockIdx.z = product * bsplit + split)
+    const float* Ap[16];
+    const float* Bp[16];
+    float* Cp[16];
 };
 // enqueue; C must be pre-zeroed by the caller when the launcher picks split-K (it tells via *needs_zero)
 int gemm_launch(const GemmArgs& g, hipStream_t stream);
@@ -127,8 +137,20 @@ int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream);
 void planes_set_tune(int code);
 int planes_plan_splitk(const PlanesGemmArgs& g);   // the K split planes_gemm will use for g
 
+// ---- general-size attention (bidaf_big.hip): D > MMB_ATT_MAX_D
+size_t bidaf_big_fwd_ws_floats(int B, int T, int M, int D);
+size_t bidaf_big_bwd_ws_floats(int B, int T, int M, int D);
+int bidaf_big_fwd(const float* text, const float* mod, const uint8_t* text_mask, const uint8_t* mod_mask, const float* text_d,
+                  const float* mod_d, const float* w_tm, float* out, float* q, float* bsave, const float* rterm,
+                  const float* cterm, float* row_stat, float* col_stat, float* ws, int B, int T, int M, int D, hipStream_t stream);
+int bidaf_big_bwd(const float* d_out, const float* out, const float* text, const float* mod, const uint8_t* text_mask,
+                  const uint8_t* mod_mask, const float* text_d, const float* mod_d, const float* w_t, const float* w_m,
+                  const float* w_tm, const float* q, const float* bsave, const float* rterm, const float* cterm,
+                  const float* row_stat, const float* col_stat, float* d_text, float* d_mod, float* d_text_d, float* d_mod_d,
+                  float* d_w_t, float* d_w_m, float* d_w_tm, float* d_bias, float* ws, int B, int T, int M, int D, hipStream_t stream);
+
 // ---- general-size LSTM recurrence (lstm_big.hip): H > MMB_LSTM_MAX_H
-size_t lstm_big_fwd_ws_bytes(int H);
+size_t lstm_big_fwd_ws_bytes(int B, int H);
 size_t lstm_big_bwd_ws_bytes(int B, int H);
 int lstm_big_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* big_ws, hipStream_t stream);
 int lstm_big_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* big_ws, hipStream_t stream);

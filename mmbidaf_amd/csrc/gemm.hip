@@ -31,6 +31,12 @@ __device__ __forceinline__ int gate_src_row(int n, int H) {
 // of tile t and written to the other LDS buffer after them; one barrier per tile.
 template <int WAVES, int MT, int NT, bool TA, bool TB>
 __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(const GemmArgs g, const int kchunk) {
+    // batched mode (g.batch > 1): blockIdx.z = product * bsplit + K split; operands advance by the batch strides / pointer table
+    const int bz = g.batch > 1 ? blockIdx.z / g.bsplit : 0, kz = g.batch > 1 ? blockIdx.z % g.bsplit : blockIdx.z;
+    const float* gA = g.use_ptrs ? g.Ap[bz] : g.A + (size_t)bz * g.sA;
+    const float* gB = g.use_ptrs ? g.Bp[bz] : g.B + (size_t)bz * g.sB;
+    float* gC = g.use_ptrs ? g.Cp[bz] : g.C + (size_t)bz * g.sC;
+
     constexpr int BM = WAVES * MT * 16;
     constexpr int BN = NT * 16;
     constexpr int NTHR = WAVES * 64;
@@ -48,11 +54,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(const GemmArgs g, cons
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kg = lane >> 4;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kb = blockIdx.z * kchunk;
+    const int kb = kz * kchunk;
     const int ke = min(g.K, kb + kchunk);
 
-    const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
-    const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+    const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(gA) & 15) == 0);
+    const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(gB) & 15) == 0);
 
     f4 ra[A_V], rb[B_V];
 
@@ -78,11 +84,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(const GemmArgs g, cons
                 if (!TA) {  // (M,K): row m, 4 consecutive k
                     const int m = c / (BK / 4), k4 = (c % (BK / 4)) * 4;
                     const int gm = m0 + m, gk = k0 + k4;
-                    if (gm < g.M && gk < ke) t = load4(g.A + (size_t)gm * g.lda + gk, a_vec, min(4, ke - gk));
+                    if (gm < g.M && gk < ke) t = load4(gA + (size_t)gm * g.lda + gk, a_vec, min(4, ke - gk));
                 } else {  // (K,M): row k, 4 consecutive m
                     const int k = c / (BM / 4), m4 = (c % (BM / 4)) * 4;
                     const int gk = k0 + k, gm = m0 + m4;
-                    if (gk < ke && gm < g.M) t = load4(g.A + (size_t)gk * g.lda + gm, a_vec, min(4, g.M - gm));
+                    if (gk < ke && gm < g.M) t = load4(gA + (size_t)gk * g.lda + gm, a_vec, min(4, g.M - gm));
                 }
             }
             ra[i] = t;
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(const GemmArgs g, cons
                     const int gn = n0 + n, gk = k0 + k4;
                     if (gn < g.N && gk < ke) {
                         const int srow = g.gate_H > 0 ? gate_src_row(gn, g.gate_H) : gn;
-                        t = load4(g.B + (size_t)srow * g.ldb + gk, b_vec, min(4, ke - gk));
+                        t = load4(gB + (size_t)srow * g.ldb + gk, b_vec, min(4, ke - gk));
                     }
                 } else {  // (K,N), optional row shift inside periods of periodB rows
                     const int k = c / (BN / 4), n4 = (c % (BN / 4)) * 4;
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(const GemmArgs g, cons
                         ok = ok && tt >= 0 && tt < g.periodB;
                         gk += g.shiftB;
                     }
-                    if (ok) t = load4(g.B + (size_t)gk * g.ldb + gn, b_vec, min(4, g.N - gn));
+                    if (ok) t = load4(gB + (size_t)gk * g.ldb + gn, b_vec, min(4, g.N - gn));
                 }
             }
             rb[i] = t;
@@ -189,13 +195,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(const GemmArgs g, cons
     }
 
     // ---- epilogue: lane (r,kg) holds C[m = 4kg+e][n = r] of each 16x16 tile
-    const bool atomic = gridDim.z > 1;
+    const bool atomic = (g.batch > 1 ? g.bsplit > 1 : gridDim.z > 1);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + j * 16 + r;
         if (n >= g.N) continue;
         float bv = 0.f;
-        if (blockIdx.z == 0 && (g.bias || g.bias2)) {
+        if (kz == 0 && (g.bias || g.bias2)) {
             const int srow = g.gate_H > 0 ? gate_src_row(n, g.gate_H) : n;
             if (g.bias) bv += g.bias[srow];
             if (g.bias2) bv += g.bias2[srow];
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(const GemmArgs g, cons
             for (int e = 0; e < 4; ++e) {
                 const int m = m0 + (wave * MT + i) * 16 + 4 * kg + e;
                 if (m >= g.M) continue;
-                float* dst = g.C + (size_t)m * g.ldc + n;
+                float* dst = gC + (size_t)m * g.ldc + n;
                 const float v = acc[i][j][e] + bv;
                 if (atomic)
                     atomicAdd(dst, v);
@@ -228,6 +234,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_kernel(const GemmArgs g, cons
 // b128 writes; the 2-way conflict of the b32 fragment reads is irrelevant next to 32-cycle MFMAs).
 template <int WAVES, int MT, int NT, bool TA, bool TB>
 __global__ __launch_bounds__(WAVES * 64) void gemm_fast_kernel(const GemmArgs g, const int kchunk) {
+    // batched mode (g.batch > 1): blockIdx.z = product * bsplit + K split; operands advance by the batch strides / pointer table
+    const int bz = g.batch > 1 ? blockIdx.z / g.bsplit : 0, kz = g.batch > 1 ? blockIdx.z % g.bsplit : blockIdx.z;
+    const float* gA = g.use_ptrs ? g.Ap[bz] : g.A + (size_t)bz * g.sA;
+    const float* gB = g.use_ptrs ? g.Bp[bz] : g.B + (size_t)bz * g.sB;
+    float* gC = g.use_ptrs ? g.Cp[bz] : g.C + (size_t)bz * g.sC;
+
     constexpr int BM = WAVES * MT * 16;
     constexpr int BN = NT * 16;
     constexpr int NTHR = WAVES * 64;
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_fast_kernel(const GemmArgs g,
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kg = lane >> 4;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kb = blockIdx.z * kchunk;
+    const int kb = kz * kchunk;
     const int ke = min(g.K, kb + kchunk);
 
     // loop-invariant per-thread source pointers / LDS offsets of this thread's float4 chunks
@@ -259,11 +271,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_fast_kernel(const GemmArgs g,
         const int c = min(tid + i * NTHR, A_CH - 1);
         if (!TA) {
             const int m = c / (BK / 4), k4 = (c % (BK / 4)) * 4;
-            pa[i] = g.A + (size_t)min(m0 + m, g.M - 1) * g.lda + kb + k4;
+            pa[i] = gA + (size_t)min(m0 + m, g.M - 1) * g.lda + kb + k4;
             la[i] = m * BK + k4;
         } else {
             const int k = c / (BM / 4), m4 = (c % (BM / 4)) * 4;
-            pa[i] = g.A + (size_t)(kb + k) * g.lda + min(m0 + m4, g.M - 4);
+            pa[i] = gA + (size_t)(kb + k) * g.lda + min(m0 + m4, g.M - 4);
             la[i] = k * BMP + m4;
         }
     }
@@ -276,14 +288,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_fast_kernel(const GemmArgs g,
             const int n = c / (BK / 4), k4 = (c % (BK / 4)) * 4;
             const int gn = min(n0 + n, g.N - 1);
             const int srow = g.gate_H > 0 ? gate_src_row(gn, g.gate_H) : gn;
-            pb[i] = g.B + (size_t)srow * g.ldb + kb + k4;
+            pb[i] = gB + (size_t)srow * g.ldb + kb + k4;
             lb[i] = n * BK + k4;
             b_stp[i] = BK;
         } else {
             const int k = c / (BN / 4), n4 = (c % (BN / 4)) * 4;
             kb_row[i] = kb + k;
             int col = min(n0 + n4, g.N - 4), ld = g.ldb;
-            const float* base = g.B;
+            const float* base = gB;
             b_sh[i] = g.shiftB;
             if (g.nseg > 0) {  // virtual concatenation: pick the segment this chunk's columns live in
                 int sg = 0;
@@ -383,13 +395,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_fast_kernel(const GemmArgs g,
         buf ^= 1;
     }
 
-    const bool atomic = gridDim.z > 1;
+    const bool atomic = (g.batch > 1 ? g.bsplit > 1 : gridDim.z > 1);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + j * 16 + r;
         if (n >= g.N) continue;
         float bv = 0.f;
-        if (blockIdx.z == 0 && (g.bias || g.bias2)) {
+        if (kz == 0 && (g.bias || g.bias2)) {
             const int srow = g.gate_H > 0 ? gate_src_row(n, g.gate_H) : n;
             if (g.bias) bv += g.bias[srow];
             if (g.bias2) bv += g.bias2[srow];
@@ -400,7 +412,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_fast_kernel(const GemmArgs g,
             for (int e = 0; e < 4; ++e) {
                 const int m = m0 + (wave * MT + i) * 16 + 4 * kg + e;
                 if (m >= g.M) continue;
-                float* dst = g.C + (size_t)m * g.ldc + n;
+                float* dst = gC + (size_t)m * g.ldc + n;
                 const float v = acc[i][j][e] + bv;
                 if (atomic)
                     atomicAdd(dst, v);
@@ -425,13 +437,14 @@ static bool fast_ok(const GemmArgs& g) {
     if (!al || g.lda % 4 || (g.nseg == 0 && g.ldb % 4) || g.K % BK) return false;
     if (g.ta && (g.M % 4 || g.M < 4)) return false;
     if (!g.tb && (g.N % 4 || g.N < 4)) return false;
+    if (g.batch > 1 && (g.use_ptrs || g.sA % 4 || g.sB % 4)) return false;   // grouped products: the general kernel
     return true;
 }
 
 template <int WAVES, int MT, int NT>
 static int launch_cfg(const GemmArgs& g, int splitk, hipStream_t stream) {
     constexpr int BM = WAVES * MT * 16, BN = NT * 16;
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splitk);
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch > 1 ? g.batch * splitk : splitk);
     int kchunk = (g.K + splitk - 1) / splitk;
     kchunk = (kchunk + BK - 1) / BK * BK;
     dim3 block(WAVES * 64);
@@ -482,7 +495,8 @@ static void pick_tile(const GemmArgs& g, int* bm, int* bn, int* cfg) {
     if (forced >= 0 && forced < kNumCfgs) {
         c = forced;
     } else {
-        const bool narrow = g.N <= 112;  // N tile 112 instead of 208
+        bool narrow = g.N <= 112;  // N tile 112 instead of 208
+        if (g.batch > 1 && (long)((g.M + 63) / 64) * ((g.N + 207) / 208) * g.batch < 200) narrow = true;   // skinny batched products
         const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + (narrow ? 111 : 207)) / (narrow ? 112 : 208));
         const bool small = tiles128 < 160 && g.K < 4096;  // too few 128-row tiles and no split-K to fill the chip
         c = (small ? 2 : 0) + (narrow ? 1 : 0);
@@ -511,22 +525,32 @@ void set_gemm_mode(int mode) { g_gemm_mode = (mode == 0 || mode == 2 || mode == 
 int gemm_launch(const GemmArgs& g, hipStream_t stream) {
     if (g.M <= 0 || g.N <= 0) return MMB_OK;
     int mode = gemm_mode();
+    if (g.batch > 1) mode = 0;   // batched products (general-size attention) always take the exact-f32 kernels
     if (mode == 1)  // auto: the split-bf16 kernel wins on wide, deep products (tools/gemm_bench.py), both are fp32-accurate
         mode = (!g.ta && g.N >= 400 && g.K >= 200) ? 3 : 0;   // transposed-A (weight-gradient) shapes: the f32 kernel is faster
     if (mode != 0 && gemm_bf16_eligible(g)) return gemm_bf16_launch(g, mode, stream);
     if (g.nseg > 0 && !fast_ok(g)) return fail(MMB_ERR_ARG, "gemm: segmented B needs the aligned fast path");
     int bm, bn, cfg;
     pick_tile(g, &bm, &bn, &cfg);
-    const int splitk = pick_splitk(g, bm, bn);
-    if (splitk > 1 && !g.accumulate)
+    int splitk = pick_splitk(g, bm, bn);
+    GemmArgs gb = g;
+    if (g.batch > 1) {   // K split only into pre-zeroed outputs; aim at ~2 workgroups per CU over all products
+        const long wgs = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.batch;
+        long sk = g.c_zeroed ? (512 + wgs - 1) / wgs : 1;
+        if (sk > g.K / 128) sk = g.K / 128;
+        if (sk > 16) sk = 16;
+        splitk = sk < 1 ? 1 : (int)sk;
+        gb.bsplit = splitk;
+    }
+    if (g.batch <= 1 && splitk > 1 && !g.accumulate)
         MMB_HIP(hipMemset2DAsync(g.C, (size_t)g.ldc * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream));
     switch (cfg) {
-        case 0: return launch_cfg<8, 1, 13>(g, splitk, stream);
-        case 1: return launch_cfg<8, 1, 7>(g, splitk, stream);
-        case 2: return launch_cfg<4, 1, 13>(g, splitk, stream);
-        case 3: return launch_cfg<4, 1, 7>(g, splitk, stream);
-        case 4: return launch_cfg<4, 2, 13>(g, splitk, stream);
-        default: return launch_cfg<4, 2, 7>(g, splitk, stream);
+        case 0: return launch_cfg<8, 1, 13>(gb, splitk, stream);
+        case 1: return launch_cfg<8, 1, 7>(gb, splitk, stream);
+        case 2: return launch_cfg<4, 1, 13>(gb, splitk, stream);
+        case 3: return launch_cfg<4, 1, 7>(gb, splitk, stream);
+        case 4: return launch_cfg<4, 2, 13>(gb, splitk, stream);
+        default: return launch_cfg<4, 2, 7>(gb, splitk, stream);
     }
 }
 

@@ -393,14 +393,14 @@ __global__ __launch_bounds__(256) void lstm_unpack_dw_kernel(const float* __rest
 static size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static bool planes_ok(int I, int H) { return I % 4 == 0 && H % 4 == 0 && gemm_mode() != 0; }
 struct WsFwd { size_t xP, wP, bias, big, total; int Ip; };
-static WsFwd ws_fwd_layout(long BT, int I, int H) {
+static WsFwd ws_fwd_layout(long BT, int B, int I, int H) {
     WsFwd w{};
     w.Ip = (int)rup(I, 32);
     size_t o = 0;
     w.xP = o;   o += rup(planes_bytes(BT, w.Ip), 256);
     w.wP = o;   o += rup(planes_bytes(8 * H, w.Ip), 256);
     w.bias = o; o += rup((size_t)8 * H * 4, 256);
-    w.big = o;  if (H > MMB_LSTM_MAX_H) o += rup(lstm_big_fwd_ws_bytes(H), 256);
+    w.big = o;  if (H > MMB_LSTM_MAX_H) o += rup(lstm_big_fwd_ws_bytes(B, H), 256);
     w.total = o;
     return w;
 }
@@ -424,7 +424,7 @@ static WsBwd ws_bwd_layout(long BT, int B, int I, int H) {
 static int gx_planes(const mmb_lstm_fwd_desc& p, hipStream_t stream) {
     const int H = p.H;
     const long BT = (long)p.B * p.T;
-    const WsFwd L = ws_fwd_layout(BT, p.I, H);
+    const WsFwd L = ws_fwd_layout(BT, p.B, p.I, H);
     char* ws = static_cast<char*>(p.ws);
     bf16_t* xP = reinterpret_cast<bf16_t*>(ws + L.xP);
     bf16_t* wP = reinterpret_cast<bf16_t*>(ws + L.wP);
@@ -528,7 +528,7 @@ using namespace mmb;
 extern "C" size_t mmb_bilstm_ws_bytes(int B, int T, int I, int H, int backward) {
     if (B < 1 || T < 1 || I < 1 || H < 1 || I % 4 || H % 4) return 0;
     const long BT = (long)B * T;
-    return backward ? ws_bwd_layout(BT, B, I, H).total : ws_fwd_layout(BT, I, H).total;
+    return backward ? ws_bwd_layout(BT, B, I, H).total : ws_fwd_layout(BT, B, I, H).total;
 }
 
 extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int device, void* stream_) {
@@ -573,7 +573,7 @@ extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int devic
     }
     if (H > MMB_LSTM_MAX_H) {
         char* big_ws[MMB_MAX_GROUP];
-        for (int i = 0; i < n; ++i) big_ws[i] = static_cast<char*>(d[i].ws) + ws_fwd_layout((long)d[i].B * d[i].T, d[i].I, H).big;
+        for (int i = 0; i < n; ++i) big_ws[i] = static_cast<char*>(d[i].ws) + ws_fwd_layout((long)d[i].B * d[i].T, d[i].B, d[i].I, H).big;
         return lstm_big_fwd(d, n, big_ws, stream);
     }
     switch (kq_for(H)) {

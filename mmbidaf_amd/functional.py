@@ -49,8 +49,8 @@ class _BiDAFAttentionFn(torch.autograd.Function):
         _require_gpu(text, mod, w_t, w_m, w_tm, bias, text_mask, mod_mask)
         B, T, D = text.shape
         M = mod.shape[1]
-        if D % 4 != 0 or D > _lib.ATT_MAX_D:
-            raise RuntimeError(f"mmbidaf_amd: attention width D=2H={D} must be a multiple of 4 and <= {_lib.ATT_MAX_D}")
+        if D % 4 != 0 or D > _lib.ATT_GENERAL_MAX_D:
+            raise RuntimeError(f"mmbidaf_amd: attention width D=2H={D} must be a multiple of 4 and <= {_lib.ATT_GENERAL_MAX_D}")
         text, mod = _f32c(text), _f32c(mod)
         has_drop = text_d is not None
         if has_drop:
@@ -66,11 +66,13 @@ class _BiDAFAttentionFn(torch.autograd.Function):
         cterm = torch.empty(B, M, device=dev, dtype=torch.float32)
         row_stat = torch.empty(B, T, 2, device=dev, dtype=torch.float32)
         col_stat = torch.empty(B, M, 2, device=dev, dtype=torch.float32)
+        ws_bytes = lib.mmb_bidaf_fwd_workspace_bytes(B, T, M, D)   # 0 for the fused kernels (D <= 208)
+        ws = torch.empty(ws_bytes // 4, device=dev, dtype=torch.float32) if ws_bytes else None
         rc = lib.mmb_bidaf_fwd(_ptr(text), _ptr(mod), _ptr(tmask), _ptr(mmask),
                                _ptr(text_d) if has_drop else None, _ptr(mod_d) if has_drop else None,
                                _ptr(w_t_), _ptr(w_m_), _ptr(w_tm_), _ptr(bias_),
                                _ptr(out), _ptr(q), _ptr(bsave), _ptr(rterm), _ptr(cterm), _ptr(row_stat), _ptr(col_stat),
-                               B, T, M, D, dev.index, _stream())
+                               _ptr(ws), ws_bytes, B, T, M, D, dev.index, _stream())
         _lib.check(rc, "mmb_bidaf_fwd")
         ctx.has_drop = has_drop
         ctx.shapes = (w_t.shape, w_m.shape, w_tm.shape, bias.shape)

@@ -7,6 +7,7 @@ CONFIGS = {
     "cfg1": (3, 50, 32, 8, 100),
     "cfg2": (32, 400, 256, 64, 100),
     "cfg4": (32, 1600, 1024, 256, 100),
+    "cfg5": (64, 400, 256, 64, 512),     # BASELINE.json's H=512 case (lengths of cfg2): general-size kernels, fp32 arithmetic
 }
 
 

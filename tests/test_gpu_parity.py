@@ -144,6 +144,27 @@ def test_attention_vs_oracle(B, T, M, D, use_drop):
         close(g, p.grad, k)
 
 
+@pytest.mark.parametrize("B,T,M,D,use_drop", [(2, 37, 29, 212, False), (3, 50, 70, 256, True), (2, 9, 300, 512, False),
+                                              (1, 70, 5, 1024, True)])
+def test_attention_general_width_vs_oracle(B, T, M, D, use_drop):
+    """D above the fused kernels' 208 runs the general path (similarity matrix in a workspace, batched f32 GEMMs);
+    ragged masks, with and without the dropped copies, up to cfg5's D = 1024."""
+    c, drop = _random_att_case(B * 77 + T + M + D, B, T, M, D, use_drop)
+    c["w_t"], c["w_m"], c["w_tm"] = c["w_t"] * 0.5, c["w_m"] * 0.5, c["w_tm"] * 0.3
+    t_ = c["text"].clone().requires_grad_(True)
+    m_ = c["mod"].clone().requires_grad_(True)
+    ps = [c[k].clone().requires_grad_(True) for k in ("w_t", "w_m", "w_tm", "bias")]
+    kw = dict(text_d=t_ * drop[0], mod_d=m_ * drop[1]) if use_drop else {}
+    ref = O.bidaf_attention(t_, m_, c["text_mask"], c["mod_mask"], *ps, **kw)
+    (ref * c["cot"]).sum().backward()
+    out, dt, dm, dps = _run_att(c, drop)
+    close(out, ref, "out")
+    close(dt, t_.grad, "d_text")
+    close(dm, m_.grad, "d_mod")
+    for k, g, p in zip(("d_w_t", "d_w_m", "d_w_tm"), dps, ps):
+        close(g, p.grad, k, tol=5e-4)      # sums over B*T*M products of O(1) terms
+
+
 def test_attention_full_size_properties():
     """cfg2 size (B=32, T=400, M=256, D=200): size-independent properties instead of the oracle."""
     B, T, M, D = 32, 400, 256, 200
@@ -399,6 +420,34 @@ def test_whole_model_golden():
         dist_e, loss_e = model(*args)
     close(dist_e, g["eval_dist"], "eval_dist")
     close(loss_e, g["eval_loss"].reshape(()), "eval_loss")
+
+
+def test_hot_region_general_hidden_size_vs_oracle():
+    """hidden_size = 136 (> 128, D = 272 > 208): the whole region on the general-size kernels (per-step recurrence,
+    workspace attention) against the CPU baseline module, all outputs and gradients; ragged lengths."""
+    from mmbidaf_amd import synth
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    H = 136
+    torch.manual_seed(224)
+    region = HotRegion(H).to(d)
+    batch = synth.make_batch((3, 21, 13, 6, H), ragged=True)
+    gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    xs = [gpu[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+    outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+    synth.region_loss(outs, gpu).backward()
+    ref = O.HotRegionCPU(region.state_dict(), H)
+    xr = [batch[k].clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+    routs = ref(*xr, batch["text_len"], batch["aud_len"], batch["img_len"])
+    synth.region_loss(routs, batch).backward()
+    for n, a, b in zip(("mod_a", "hid_a", "mod_i", "hid_i", "dec_hidden"), outs, routs):
+        close(a, b, n)
+    for n, a, b in zip(("d_x_text", "d_x_aud", "d_x_img"), xs, xr):
+        close(a.grad, b.grad, n)
+    rg = ref.named_grads()
+    for n, p in region.named_parameters():
+        if not n.endswith("bidaf_att_audio.bias") and not n.endswith("bidaf_att_image.bias"):
+            close(p.grad, rg[n], "grad " + n)
 
 
 def test_hot_region_cfg1_vs_oracle_with_dropout_training_mode():
