@@ -378,9 +378,15 @@ __global__ __launch_bounds__(256) void lstm_unpack_dw_kernel(const float* __rest
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (db_part && idx < 8 * H) {
         const int dir = idx / (4 * H), rem = idx % (4 * H);
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc += db_part[((size_t)dir * B + b) * 4 * H + rem];
-        d_b[idx] = acc;
+        const float* src = db_part + (size_t)dir * B * 4 * H + rem;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // independent chains: the B loads overlap instead of serialising
+        int b = 0;
+        for (; b + 4 <= B; b += 4) {
+            a0 += src[(size_t)b * 4 * H]; a1 += src[(size_t)(b + 1) * 4 * H];
+            a2 += src[(size_t)(b + 2) * 4 * H]; a3 += src[(size_t)(b + 3) * 4 * H];
+        }
+        for (; b < B; ++b) a0 += src[(size_t)b * 4 * H];
+        d_b[idx] = (a0 + a1) + (a2 + a3);
     }
     if (idx >= 8 * H * ldc) return;
     const int row = idx / ldc, col = idx % ldc, dir = row / (4 * H);
