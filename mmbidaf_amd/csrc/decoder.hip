@@ -1,0 +1,562 @@
+// One decode step of MultimodalAttentionDecoder.forward (reference layers/attention.py:145-186) as ONE kernel, forward
+// and backward: every quantity of the step is per sample, so a workgroup owns a sample and walks the step's stages with
+// its small vectors in LDS.  SURVEY 8(f) row N3: the stock-PyTorch step is ~60 launches of tiny kernels (0.93 ms);
+// here the (T x 2H) memories are streamed once per step and everything else is matvecs against L2-resident weights.
+//
+//   z_t   = proj_m[t] + (W_hid h + b) + cov_t * wc + bc          proj_m = W_mem . enc_m + b is loop-invariant: hoisted
+//   e_t   = v . tanh(z_t) + bv ;  alpha = softmax_t(e)  (over all T, unmasked, as the reference) ;  ctx_m = sum_t alpha_t enc_m[t]
+//   gate  : u_k = tanh(W_beta ctx_k + W_beta' h + b), e_beta_k = v_beta_k . u_k + b ;  beta = softmax_2
+//   c3    = beta_1 ctx_a + beta_2 ctx_i ;  att_cov = beta_1 alpha_a + beta_2 alpha_i ;  cov' = cov + att_cov
+//   LSTM cell on [c3 ; x], then dist = masked_softmax(W_out h' + b_out, mask)            (-1e30 blend, attention.py:78-98)
+#include "common.h"
+
+namespace mmb {
+
+constexpr int DEC_NT = 512, DEC_NW = DEC_NT / 64;
+constexpr int DEC_MAXQ = 4;   // 2H <= 1024
+
+__device__ __forceinline__ float dwave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float dwave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ float dot4(f4 a, f4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ f4 tanh4(f4 z) { return f4{tanhf(z.x), tanhf(z.y), tanhf(z.z), tanhf(z.w)}; }
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// out[r] = W[r,:] . x + bias[r] + add[r]   (one wave per row, lanes along the columns)
+__device__ void dec_matvec(const float* __restrict__ W, int ld, const float* x, int rows, int cols, float* out,
+                           const float* __restrict__ bias, const float* add) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < rows; r += DEC_NW) {
+        float acc = 0.f;
+        for (int j = lane; j < cols; j += 64) acc = fmaf(W[(size_t)r * ld + j], x[j], acc);
+        acc = dwave_sum(acc);
+        if (lane == 0) out[r] = acc + (bias ? bias[r] : 0.f) + (add ? add[r] : 0.f);
+    }
+}
+// out[r] = sum_j WT[j, r] * x[j] + bias[r] + add[r]   (WT = W transposed, (cols, rows): thread per output, the loads of a
+// thread are independent and coalesced across threads, no cross-lane reduction)
+__device__ void dec_matvec_c(const float* __restrict__ WT, const float* x, int rows, int cols, float* out,
+                             const float* __restrict__ bias, const float* add) {
+    for (int r = threadIdx.x; r < rows; r += DEC_NT) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int j = 0;
+        for (; j + 4 <= cols; j += 4) {
+            a0 = fmaf(WT[(size_t)j * rows + r], x[j], a0);
+            a1 = fmaf(WT[(size_t)(j + 1) * rows + r], x[j + 1], a1);
+            a2 = fmaf(WT[(size_t)(j + 2) * rows + r], x[j + 2], a2);
+            a3 = fmaf(WT[(size_t)(j + 3) * rows + r], x[j + 3], a3);
+        }
+        for (; j < cols; ++j) a0 = fmaf(WT[(size_t)j * rows + r], x[j], a0);
+        out[r] = (a0 + a1) + (a2 + a3) + (bias ? bias[r] : 0.f) + (add ? add[r] : 0.f);
+    }
+}
+// out[j] (+)= sum_r delta[r] * W[r, j]     (lanes along the columns: coalesced rows of W)
+__device__ void dec_matvec_t(const float* __restrict__ W, int ld, const float* delta, int rows, int cols, float* out, bool accumulate) {
+    for (int j = threadIdx.x; j < cols; j += DEC_NT) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int r = 0;
+        for (; r + 4 <= rows; r += 4) {
+            a0 = fmaf(delta[r], W[(size_t)r * ld + j], a0);
+            a1 = fmaf(delta[r + 1], W[(size_t)(r + 1) * ld + j], a1);
+            a2 = fmaf(delta[r + 2], W[(size_t)(r + 2) * ld + j], a2);
+            a3 = fmaf(delta[r + 3], W[(size_t)(r + 3) * ld + j], a3);
+        }
+        for (; r < rows; ++r) a0 = fmaf(delta[r], W[(size_t)r * ld + j], a0);
+        const float acc = (a0 + a1) + (a2 + a3);
+        out[j] = accumulate ? out[j] + acc : acc;
+    }
+}
+// block-wide sum / max of one value per thread (scratch: DEC_NW + 1 floats)
+__device__ float dec_block_sum(float v, float* scratch) {
+    v = dwave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < DEC_NW; ++w) t += scratch[w];
+    return t;
+}
+__device__ float dec_block_max(float v, float* scratch) {
+    v = dwave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < DEC_NW; ++w) t = fmaxf(t, scratch[w]);
+    return t;
+}
+
+struct DecShapes { int B, T, H, H2, E, L; };
+
+// additive attention of one modality for this sample: alpha into e[0..T), context into ctx[0..H2)
+__device__ void dec_attention(const float* __restrict__ P, const float* __restrict__ Em, const float* hm, const float* cov,
+                              const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ v, float bv,
+                              int T, int H2, float* e, float* ctx, float* wred /* [NW][H2 + 2] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -INFINITY, l = 0.f;
+    f4 cacc[DEC_MAXQ];
+#pragma unroll
+    for (int q = 0; q < DEC_MAXQ; ++q) cacc[q] = f4{0.f, 0.f, 0.f, 0.f};
+    constexpr int RB = 4;   // memory rows per wave iteration: their loads and reductions overlap
+    for (int t0 = wave * RB; t0 < T; t0 += DEC_NW * RB) {
+        float part[RB];
+        f4 ev[RB][DEC_MAXQ];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int t = min(t0 + i, T - 1);
+            const float ct = cov[t];
+            part[i] = 0.f;
+#pragma unroll
+            for (int q = 0; q < DEC_MAXQ; ++q) {
+                const int d = lane * 4 + 256 * q;
+                ev[i][q] = f4{0.f, 0.f, 0.f, 0.f};
+                if (d < H2) {
+                    const f4 z = ld4(P + (size_t)t * H2 + d) + ld4(hm + d) + ld4(wc + d) * ct + ld4(bc + d);
+                    part[i] += dot4(ld4(v + d), tanh4(z));
+                    ev[i][q] = ld4(Em + (size_t)t * H2 + d);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) part[i] += __shfl_xor(part[i], o);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            if (t0 + i < T) {
+                const float et = part[i] + bv;
+                if (lane == 0) e[t0 + i] = et;
+                const float mn = fmaxf(m, et), sc = expf(m - mn), pe = expf(et - mn);
+                l = l * sc + pe;
+#pragma unroll
+                for (int q = 0; q < DEC_MAXQ; ++q) cacc[q] = cacc[q] * sc + ev[i][q] * pe;
+                m = mn;
+            }
+        }
+    }
+    float* wr = wred + wave * (H2 + 2);
+#pragma unroll
+    for (int q = 0; q < DEC_MAXQ; ++q) {
+        const int d = lane * 4 + 256 * q;
+        if (d < H2) *reinterpret_cast<f4*>(wr + d) = cacc[q];
+    }
+    if (lane == 0) { wr[H2] = m; wr[H2 + 1] = l; }
+    __syncthreads();
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < DEC_NW; ++w) M = fmaxf(M, wred[w * (H2 + 2) + H2]);
+    float Ls = 0.f, sw[DEC_NW];
+#pragma unroll
+    for (int w = 0; w < DEC_NW; ++w) {
+        sw[w] = expf(wred[w * (H2 + 2) + H2] - M);
+        Ls += wred[w * (H2 + 2) + H2 + 1] * sw[w];
+    }
+    const float inv = 1.0f / Ls;
+    for (int d = threadIdx.x; d < H2; d += DEC_NT) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < DEC_NW; ++w) a += wred[w * (H2 + 2) + d] * sw[w];
+        ctx[d] = a * inv;
+    }
+    for (int t = threadIdx.x; t < T; t += DEC_NT) e[t] = expf(e[t] - M) * inv;
+    __syncthreads();
+}
+
+struct DecFwdArgs {
+    mmb_decoder_params w;
+    const float *enc_a, *enc_i, *proj_a, *proj_i, *h, *c, *cov, *x;
+    const uint8_t* mask;
+    float *dist, *h_out, *c_out, *att_cov, *cov_out, *saved;
+    int B, T, saved_stride;
+};
+
+// LDS carve-up shared by both kernels
+struct DecLds {
+    float *hv, *cv, *cov, *ea, *ei, *ha, *hi, *hb1, *hb2, *hh, *ctxa, *ctxi, *u1, *u2, *inp, *gates, *hnew, *logits, *wred, *scratch;
+};
+__device__ DecLds dec_carve(float* sm, int T, int H, int H2, int E, int L) {
+    DecLds s;
+    float* p = sm;
+    auto take = [&](int n) { float* r = p; p += (n + 3) & ~3; return r; };
+    s.hv = take(H); s.cv = take(H); s.cov = take(T); s.ea = take(T); s.ei = take(T);
+    s.ha = take(H2); s.hi = take(H2); s.hb1 = take(H2); s.hb2 = take(H2); s.hh = take(4 * H);
+    s.ctxa = take(H2); s.ctxi = take(H2); s.u1 = take(H2); s.u2 = take(H2);
+    s.inp = take(H2 + E); s.gates = take(4 * H); s.hnew = take(H); s.logits = take(L);
+    s.wred = take(DEC_NW * (H2 + 2)); s.scratch = take(16);
+    return s;
+}
+static size_t dec_lds_floats(int T, int H, int E, int L) {
+    const int H2 = 2 * H;
+    auto r4 = [](int n) { return (size_t)((n + 3) & ~3); };
+    return 2 * r4(H) + 3 * r4(T) + 4 * r4(H2) + r4(4 * H) + 4 * r4(H2) + r4(H2 + E) + r4(4 * H) + r4(H) + r4(L) + r4(DEC_NW * (H2 + 2)) + 16;
+}
+
+__global__ __launch_bounds__(DEC_NT) void decoder_step_fwd_kernel(const DecFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const mmb_decoder_params& w = a.w;
+    const int b = blockIdx.x, T = a.T, H = w.H, H2 = 2 * H, E = w.E, L = w.L, tid = threadIdx.x;
+    const DecLds s = dec_carve(sm, T, H, H2, E, L);
+    for (int i = tid; i < H; i += DEC_NT) { s.hv[i] = a.h[(size_t)b * H + i]; s.cv[i] = a.c[(size_t)b * H + i]; }
+    for (int i = tid; i < T; i += DEC_NT) s.cov[i] = a.cov[(size_t)b * T + i];
+    for (int i = tid; i < E; i += DEC_NT) s.inp[H2 + i] = a.x[(size_t)b * E + i];
+    __syncthreads();
+    // every product with the previous hidden state
+    dec_matvec_c(w.W2T, s.hv, H2, H, s.ha, w.b2, nullptr);
+    dec_matvec_c(w.W4T, s.hv, H2, H, s.hi, w.b4, nullptr);
+    dec_matvec_c(w.Wb2T, s.hv, H2, H, s.hb1, w.bb2, nullptr);
+    dec_matvec_c(w.Wb4T, s.hv, H2, H, s.hb2, w.bb4, nullptr);
+    dec_matvec_c(w.W_hhT, s.hv, 4 * H, H, s.hh, w.b_hh, nullptr);
+    __syncthreads();
+    dec_attention(a.proj_a + (size_t)b * T * H2, a.enc_a + (size_t)b * T * H2, s.ha, s.cov, w.wc1, w.bc1, w.v1, w.bv1[0], T, H2,
+                  s.ea, s.ctxa, s.wred);
+    dec_attention(a.proj_i + (size_t)b * T * H2, a.enc_i + (size_t)b * T * H2, s.hi, s.cov, w.wc2, w.bc2, w.v2, w.bv2[0], T, H2,
+                  s.ei, s.ctxi, s.wred);
+    // gate between the two contexts
+    dec_matvec_c(w.Wb1T, s.ctxa, H2, H2, s.u1, w.bb1, s.hb1);
+    dec_matvec_c(w.Wb3T, s.ctxi, H2, H2, s.u2, w.bb3, s.hb2);
+    __syncthreads();
+    float p1 = 0.f, p2 = 0.f;
+    for (int d = tid; d < H2; d += DEC_NT) {
+        const float t1 = tanhf(s.u1[d]), t2 = tanhf(s.u2[d]);
+        s.u1[d] = t1; s.u2[d] = t2;
+        p1 += w.vb1[d] * t1; p2 += w.vb2[d] * t2;
+    }
+    const float eb1 = dec_block_sum(p1, s.scratch) + w.bvb1[0];
+    const float eb2 = dec_block_sum(p2, s.scratch) + w.bvb2[0];
+    const float mb = fmaxf(eb1, eb2), x1 = expf(eb1 - mb), x2 = expf(eb2 - mb);
+    const float beta1 = x1 / (x1 + x2), beta2 = x2 / (x1 + x2);
+    for (int d = tid; d < H2; d += DEC_NT) s.inp[d] = beta1 * s.ctxa[d] + beta2 * s.ctxi[d];
+    for (int t = tid; t < T; t += DEC_NT) {
+        const float ac = beta1 * s.ea[t] + beta2 * s.ei[t];
+        a.att_cov[(size_t)b * T + t] = ac;
+        a.cov_out[(size_t)b * T + t] = s.cov[t] + ac;
+    }
+    __syncthreads();
+    // LSTM cell on [c3 ; x]
+    dec_matvec_c(w.W_ihT, s.inp, 4 * H, H2 + E, s.gates, w.b_ih, s.hh);
+    __syncthreads();
+    for (int u = tid; u < H; u += DEC_NT) {
+        const float gi = sigm(s.gates[u]), gf = sigm(s.gates[H + u]), gg = tanhf(s.gates[2 * H + u]), go = sigm(s.gates[3 * H + u]);
+        const float cn = gf * s.cv[u] + gi * gg;
+        const float hn = go * tanhf(cn);
+        s.hnew[u] = hn;
+        a.h_out[(size_t)b * H + u] = hn;
+        a.c_out[(size_t)b * H + u] = cn;
+        if (a.saved) {
+            float* g = a.saved + (size_t)b * a.saved_stride + 2 * T + 4 * H2;
+            g[u] = gi; g[H + u] = gf; g[2 * H + u] = gg; g[3 * H + u] = go;
+        }
+    }
+    __syncthreads();
+    // output distribution over the (padded) transcript positions
+    dec_matvec_c(w.W_outT, s.hnew, L, H, s.logits, w.b_out, nullptr);
+    __syncthreads();
+    const uint8_t* mk = a.mask + (size_t)b * L;
+    float mx = -INFINITY;
+    for (int i = tid; i < L; i += DEC_NT) {
+        const float v = mk[i] ? s.logits[i] : -1e30f;
+        s.logits[i] = v;
+        mx = fmaxf(mx, v);
+    }
+    mx = dec_block_max(mx, s.scratch);
+    float sum = 0.f;
+    for (int i = tid; i < L; i += DEC_NT) sum += expf(s.logits[i] - mx);
+    sum = dec_block_sum(sum, s.scratch);
+    for (int i = tid; i < L; i += DEC_NT) a.dist[(size_t)b * L + i] = expf(s.logits[i] - mx) / sum;
+    if (a.saved) {
+        float* sv = a.saved + (size_t)b * a.saved_stride;
+        for (int t = tid; t < T; t += DEC_NT) { sv[t] = s.ea[t]; sv[T + t] = s.ei[t]; }
+        for (int d = tid; d < H2; d += DEC_NT) {
+            sv[2 * T + d] = s.ctxa[d]; sv[2 * T + H2 + d] = s.ctxi[d];
+            sv[2 * T + 2 * H2 + d] = s.u1[d]; sv[2 * T + 3 * H2 + d] = s.u2[d];
+        }
+        if (tid == 0) { sv[2 * T + 4 * H2 + 4 * H] = beta1; sv[2 * T + 4 * H2 + 4 * H + 1] = beta2; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+struct DecBwdArgs {
+    mmb_decoder_params w;
+    const float *enc_a, *enc_i, *proj_a, *proj_i, *h, *c, *cov, *x, *saved, *dist, *c_out;
+    const uint8_t* mask;
+    const float *d_dist, *d_h_out, *d_c_out, *d_att_cov, *d_cov_out;   // any of them may be NULL (= zero)
+    float *d_h, *d_c, *d_cov, *d_x;                                     // overwritten
+    float *d_proj_a, *d_enc_a, *d_proj_i, *d_enc_i;                     // (B,T,2H) accumulated (+=)
+    float *delta_out, *delta_g, *delta_b1, *delta_b2, *delta_ha, *delta_hi;   // (B,L) (B,4H) (B,2H) x4, overwritten
+    float* vec_acc;                                                     // (B, 6*2H + 4) accumulated (+=)
+    int B, T, saved_stride;
+};
+
+// backward of dec_attention for one modality.  dact[t] = d_att_cov[t] + d_cov_out[t]; the upstream gradient of alpha_t is
+// beta * dact[t].  Accumulates d_proj, d_enc (global), dcov[t] (LDS), returns delta_h (the sum of dz over t) in dhm.
+__device__ void dec_attention_bwd(const float* __restrict__ P, const float* __restrict__ Em, const float* hm, const float* cov,
+                                  const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ v,
+                                  const float* alpha, const float* dact, float beta, const float* dctx, float Ssum,
+                                  int T, int H2, float* dP, float* dE, float* dcov, float* dhm, float* acc_wc, float* acc_v,
+                                  float* acc_bv, float* wred /* [NW][3][H2] */, float* scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f4 a_h[DEC_MAXQ], a_wc[DEC_MAXQ], a_v[DEC_MAXQ];
+#pragma unroll
+    for (int q = 0; q < DEC_MAXQ; ++q) a_h[q] = a_wc[q] = a_v[q] = f4{0.f, 0.f, 0.f, 0.f};
+    float a_bv = 0.f;
+    for (int t = wave; t < T; t += DEC_NW) {
+        const float ct = cov[t], al = alpha[t];
+        float part = 0.f;
+        f4 tz[DEC_MAXQ];
+#pragma unroll
+        for (int q = 0; q < DEC_MAXQ; ++q) {
+            const int d = lane * 4 + 256 * q;
+            tz[q] = f4{0.f, 0.f, 0.f, 0.f};
+            if (d < H2) {
+                const f4 z = ld4(P + (size_t)t * H2 + d) + ld4(hm + d) + ld4(wc + d) * ct + ld4(bc + d);
+                tz[q] = tanh4(z);
+                part += dot4(ld4(dctx + d), ld4(Em + (size_t)t * H2 + d));
+            }
+        }
+        const float da_tot = beta * dact[t] + dwave_sum(part);
+        const float de = al * (da_tot - Ssum);
+        a_bv += de;
+        float pc = 0.f;
+#pragma unroll
+        for (int q = 0; q < DEC_MAXQ; ++q) {
+            const int d = lane * 4 + 256 * q;
+            if (d < H2) {
+                const f4 dz = ld4(v + d) * (f4{1.f, 1.f, 1.f, 1.f} - tz[q] * tz[q]) * de;
+                float* gp = dP + (size_t)t * H2 + d;
+                float* ge = dE + (size_t)t * H2 + d;
+                *reinterpret_cast<f4*>(gp) = ld4(gp) + dz;
+                *reinterpret_cast<f4*>(ge) = ld4(ge) + ld4(dctx + d) * al;
+                a_h[q] += dz;
+                a_wc[q] += dz * ct;
+                a_v[q] += tz[q] * de;
+                pc += dot4(dz, ld4(wc + d));
+            }
+        }
+        pc = dwave_sum(pc);
+        if (lane == 0) dcov[t] += pc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < DEC_MAXQ; ++q) {
+        const int d = lane * 4 + 256 * q;
+        if (d < H2) {
+            *reinterpret_cast<f4*>(wred + (wave * 3 + 0) * H2 + d) = a_h[q];
+            *reinterpret_cast<f4*>(wred + (wave * 3 + 1) * H2 + d) = a_wc[q];
+            *reinterpret_cast<f4*>(wred + (wave * 3 + 2) * H2 + d) = a_v[q];
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < H2; d += DEC_NT) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < DEC_NW; ++w) {
+            s0 += wred[(w * 3 + 0) * H2 + d]; s1 += wred[(w * 3 + 1) * H2 + d]; s2 += wred[(w * 3 + 2) * H2 + d];
+        }
+        dhm[d] = s0;
+        acc_wc[d] += s1;
+        acc_v[d] += s2;
+    }
+    const float tot = dec_block_sum((lane == 0) ? a_bv : 0.f, scratch);
+    if (threadIdx.x == 0) acc_bv[0] += tot;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(DEC_NT) void decoder_step_bwd_kernel(const DecBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const mmb_decoder_params& w = a.w;
+    const int b = blockIdx.x, T = a.T, H = w.H, H2 = 2 * H, E = w.E, L = w.L, tid = threadIdx.x;
+    // carve: hv cv cov | alpha_a alpha_i dact dcov | ha hi | ctxa ctxi u1 u2 | dctxa dctxi db1 db2 dha dhi | gates dg | dhn dh | dl(L) | dinp | wred scratch
+    float* p = sm;
+    auto take = [&](int n) { float* r = p; p += (n + 3) & ~3; return r; };
+    float *hv = take(H), *cv = take(H), *cov = take(T), *ala = take(T), *ali = take(T), *dact = take(T), *dcov = take(T);
+    float *ha = take(H2), *hi = take(H2), *ctxa = take(H2), *ctxi = take(H2), *u1 = take(H2), *u2 = take(H2);
+    float *dctxa = take(H2), *dctxi = take(H2), *db1 = take(H2), *db2 = take(H2), *dha = take(H2), *dhi = take(H2);
+    float *gates = take(4 * H), *dg = take(4 * H), *dhn = take(H), *dh = take(H), *dl = take(L), *dinp = take(H2 + E);
+    float *wred = take(DEC_NW * 3 * H2), *scratch = take(16);
+    const float* sv = a.saved + (size_t)b * a.saved_stride;
+    for (int i = tid; i < H; i += DEC_NT) {
+        hv[i] = a.h[(size_t)b * H + i]; cv[i] = a.c[(size_t)b * H + i];
+        dhn[i] = a.d_h_out ? a.d_h_out[(size_t)b * H + i] : 0.f;
+    }
+    for (int t = tid; t < T; t += DEC_NT) {
+        cov[t] = a.cov[(size_t)b * T + t];
+        ala[t] = sv[t]; ali[t] = sv[T + t];
+        const float dco = a.d_cov_out ? a.d_cov_out[(size_t)b * T + t] : 0.f;
+        dact[t] = dco + (a.d_att_cov ? a.d_att_cov[(size_t)b * T + t] : 0.f);
+        dcov[t] = dco;   // cov' = cov + att_cov passes its gradient straight through
+    }
+    for (int d = tid; d < H2; d += DEC_NT) {
+        ctxa[d] = sv[2 * T + d]; ctxi[d] = sv[2 * T + H2 + d]; u1[d] = sv[2 * T + 2 * H2 + d]; u2[d] = sv[2 * T + 3 * H2 + d];
+    }
+    for (int i = tid; i < 4 * H; i += DEC_NT) gates[i] = sv[2 * T + 4 * H2 + i];
+    const float beta1 = sv[2 * T + 4 * H2 + 4 * H], beta2 = sv[2 * T + 4 * H2 + 4 * H + 1];
+    __syncthreads();
+    dec_matvec_c(w.W2T, hv, H2, H, ha, w.b2, nullptr);   // recomputed hidden-state terms of the two attentions
+    dec_matvec_c(w.W4T, hv, H2, H, hi, w.b4, nullptr);
+    // ---- output layer: dlogit = mask * dist * (d_dist - sum(dist * d_dist))
+    const uint8_t* mk = a.mask + (size_t)b * L;
+    float sd = 0.f;
+    for (int i = tid; i < L; i += DEC_NT) sd += a.d_dist ? a.dist[(size_t)b * L + i] * a.d_dist[(size_t)b * L + i] : 0.f;
+    sd = dec_block_sum(sd, scratch);
+    for (int i = tid; i < L; i += DEC_NT) {
+        const float v = (a.d_dist && mk[i]) ? a.dist[(size_t)b * L + i] * (a.d_dist[(size_t)b * L + i] - sd) : 0.f;
+        dl[i] = v;
+        a.delta_out[(size_t)b * L + i] = v;
+    }
+    __syncthreads();
+    dec_matvec_t(w.W_out, H, dl, L, H, dhn, true);       // dh' += W_out^T dlogit
+    __syncthreads();
+    // ---- LSTM cell
+    for (int u = tid; u < H; u += DEC_NT) {
+        const float gi = gates[u], gf = gates[H + u], gg = gates[2 * H + u], go = gates[3 * H + u];
+        const float cn = a.c_out[(size_t)b * H + u], tc = tanhf(cn);
+        const float dhv = dhn[u];
+        const float dcn = (a.d_c_out ? a.d_c_out[(size_t)b * H + u] : 0.f) + dhv * go * (1.0f - tc * tc);
+        dg[u] = dcn * gg * gi * (1.0f - gi);
+        dg[H + u] = dcn * cv[u] * gf * (1.0f - gf);
+        dg[2 * H + u] = dcn * gi * (1.0f - gg * gg);
+        dg[3 * H + u] = dhv * tc * go * (1.0f - go);
+        a.d_c[(size_t)b * H + u] = dcn * gf;
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * H; i += DEC_NT) a.delta_g[(size_t)b * 4 * H + i] = dg[i];
+    dec_matvec_t(w.W_ih, H2 + E, dg, 4 * H, H2 + E, dinp, false);   // d[c3 ; x]
+    dec_matvec_t(w.W_hh, H, dg, 4 * H, H, dh, false);               // dh  = W_hh^T dg
+    __syncthreads();
+    for (int i = tid; i < E; i += DEC_NT) a.d_x[(size_t)b * E + i] = dinp[H2 + i];
+    // ---- mixture: c3 = beta1 ctx_a + beta2 ctx_i, att_cov = beta1 alpha_a + beta2 alpha_i
+    float q1 = 0.f, q2 = 0.f, r1 = 0.f, r2 = 0.f;
+    for (int d = tid; d < H2; d += DEC_NT) { q1 += dinp[d] * ctxa[d]; q2 += dinp[d] * ctxi[d]; }
+    for (int t = tid; t < T; t += DEC_NT) { r1 += dact[t] * ala[t]; r2 += dact[t] * ali[t]; }
+    q1 = dec_block_sum(q1, scratch); q2 = dec_block_sum(q2, scratch);
+    r1 = dec_block_sum(r1, scratch); r2 = dec_block_sum(r2, scratch);
+    const float dbeta1 = q1 + r1, dbeta2 = q2 + r2;
+    const float s2 = beta1 * dbeta1 + beta2 * dbeta2;
+    const float de1 = beta1 * (dbeta1 - s2), de2 = beta2 * (dbeta2 - s2);
+    float* vacc = a.vec_acc + (size_t)b * (6 * H2 + 4);
+    for (int d = tid; d < H2; d += DEC_NT) {
+        db1[d] = de1 * w.vb1[d] * (1.0f - u1[d] * u1[d]);
+        db2[d] = de2 * w.vb2[d] * (1.0f - u2[d] * u2[d]);
+        a.delta_b1[(size_t)b * H2 + d] = db1[d];
+        a.delta_b2[(size_t)b * H2 + d] = db2[d];
+        vacc[4 * H2 + d] += de1 * u1[d];
+        vacc[5 * H2 + d] += de2 * u2[d];
+        dctxa[d] = beta1 * dinp[d];
+        dctxi[d] = beta2 * dinp[d];
+    }
+    if (tid == 0) { vacc[6 * H2 + 2] += de1; vacc[6 * H2 + 3] += de2; }
+    __syncthreads();
+    dec_matvec_t(w.Wb1, H2, db1, H2, H2, dctxa, true);
+    dec_matvec_t(w.Wb3, H2, db2, H2, H2, dctxi, true);
+    dec_matvec_t(w.Wb2, H, db1, H2, H, dh, true);
+    __syncthreads();
+    dec_matvec_t(w.Wb4, H, db2, H2, H, dh, true);
+    __syncthreads();
+    // ---- the two additive attentions
+    float c1 = 0.f, c2 = 0.f;
+    for (int d = tid; d < H2; d += DEC_NT) { c1 += dctxa[d] * ctxa[d]; c2 += dctxi[d] * ctxi[d]; }
+    c1 = dec_block_sum(c1, scratch); c2 = dec_block_sum(c2, scratch);
+    const float S1 = beta1 * r1 + c1, S2 = beta2 * r2 + c2;   // sum_t alpha_t * (upstream gradient of alpha_t)
+    const size_t mo = (size_t)b * T * H2;
+    dec_attention_bwd(a.proj_a + mo, a.enc_a + mo, ha, cov, w.wc1, w.bc1, w.v1, ala, dact, beta1, dctxa, S1, T, H2,
+                      a.d_proj_a + mo, a.d_enc_a + mo, dcov, dha, vacc, vacc + H2, vacc + 6 * H2, wred, scratch);
+    dec_attention_bwd(a.proj_i + mo, a.enc_i + mo, hi, cov, w.wc2, w.bc2, w.v2, ali, dact, beta2, dctxi, S2, T, H2,
+                      a.d_proj_i + mo, a.d_enc_i + mo, dcov, dhi, vacc + 2 * H2, vacc + 3 * H2, vacc + 6 * H2 + 1, wred, scratch);
+    for (int d = tid; d < H2; d += DEC_NT) { a.delta_ha[(size_t)b * H2 + d] = dha[d]; a.delta_hi[(size_t)b * H2 + d] = dhi[d]; }
+    for (int t = tid; t < T; t += DEC_NT) a.d_cov[(size_t)b * T + t] = dcov[t];
+    dec_matvec_t(w.W2, H, dha, H2, H, dh, true);
+    __syncthreads();
+    dec_matvec_t(w.W4, H, dhi, H2, H, dh, true);
+    __syncthreads();
+    for (int i = tid; i < H; i += DEC_NT) a.d_h[(size_t)b * H + i] = dh[i];
+}
+
+static size_t dec_bwd_lds_floats(int T, int H, int E, int L) {
+    const int H2 = 2 * H;
+    auto r4 = [](int n) { return (size_t)((n + 3) & ~3); };
+    return 2 * r4(H) + 5 * r4(T) + 12 * r4(H2) + 2 * r4(4 * H) + 2 * r4(H) + r4(L) + r4(H2 + E) + r4(DEC_NW * 3 * H2) + 16;
+}
+
+}  // namespace mmb
+
+using namespace mmb;
+
+extern "C" size_t mmb_decoder_saved_floats(int T, int H) { return (size_t)2 * T + 8 * H + 4 * H + 4; }
+extern "C" size_t mmb_decoder_vec_acc_floats(int H) { return (size_t)12 * H + 4; }
+
+static int dec_check(const mmb_decoder_params* w, int B, int T) {
+    MMB_REQUIRE(w && B >= 1 && T >= 1, "decoder: bad sizes B=%d T=%d", B, T);
+    MMB_REQUIRE(w->H >= 2 && w->H % 2 == 0 && w->H <= 512 && w->E >= 1 && w->L >= 1, "decoder: unsupported H=%d E=%d L=%d (H even, <= 512)",
+                w->H, w->E, w->L);
+    return MMB_OK;
+}
+
+extern "C" int mmb_decoder_step_fwd(const mmb_decoder_params* w, const float* enc_a, const float* enc_i, const float* proj_a,
+                                    const float* proj_i, const float* h, const float* c, const float* cov, const float* x,
+                                    const uint8_t* mask, float* dist, float* h_out, float* c_out, float* att_cov, float* cov_out,
+                                    float* saved, int B, int T, int device, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = dec_check(w, B, T)) return rc;
+    MMB_REQUIRE(enc_a && enc_i && proj_a && proj_i && h && c && cov && x && mask && dist && h_out && c_out && att_cov && cov_out,
+                "mmb_decoder_step_fwd: null pointer");
+    MMB_HIP(hipSetDevice(device));
+    DecFwdArgs a{};
+    a.w = *w; a.enc_a = enc_a; a.enc_i = enc_i; a.proj_a = proj_a; a.proj_i = proj_i; a.h = h; a.c = c; a.cov = cov; a.x = x;
+    a.mask = mask; a.dist = dist; a.h_out = h_out; a.c_out = c_out; a.att_cov = att_cov; a.cov_out = cov_out; a.saved = saved;
+    a.B = B; a.T = T; a.saved_stride = (int)mmb_decoder_saved_floats(T, w->H);
+    const size_t lds = dec_lds_floats(T, w->H, w->E, w->L) * sizeof(float);
+    MMB_REQUIRE(lds <= 160 * 1024, "mmb_decoder_step_fwd: T=%d L=%d too large for one workgroup's LDS", T, w->L);
+    static bool attr = false;
+    if (!attr) {
+        MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_step_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(decoder_step_fwd_kernel, dim3(B), dim3(DEC_NT), lds, stream, a);
+    MMB_HIP(hipGetLastError());
+    return MMB_OK;
+}
+
+extern "C" int mmb_decoder_step_bwd(const mmb_decoder_params* w, const float* enc_a, const float* enc_i, const float* proj_a,
+                                    const float* proj_i, const float* h, const float* c, const float* cov, const float* x,
+                                    const uint8_t* mask, const float* saved, const float* dist, const float* c_out,
+                                    const float* d_dist, const float* d_h_out, const float* d_c_out, const float* d_att_cov,
+                                    const float* d_cov_out, float* d_h, float* d_c, float* d_cov, float* d_x, float* d_proj_a,
+                                    float* d_enc_a, float* d_proj_i, float* d_enc_i, float* delta_out, float* delta_g,
+                                    float* delta_b1, float* delta_b2, float* delta_ha, float* delta_hi, float* vec_acc, int B,
+                                    int T, int device, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = dec_check(w, B, T)) return rc;
+    MMB_REQUIRE(enc_a && enc_i && proj_a && proj_i && h && c && cov && x && mask && saved && dist && c_out && d_h && d_c && d_cov &&
+                    d_x && d_proj_a && d_enc_a && d_proj_i && d_enc_i && delta_out && delta_g && delta_b1 && delta_b2 && delta_ha &&
+                    delta_hi && vec_acc, "mmb_decoder_step_bwd: null pointer");
+    MMB_HIP(hipSetDevice(device));
+    DecBwdArgs a{};
+    a.w = *w; a.enc_a = enc_a; a.enc_i = enc_i; a.proj_a = proj_a; a.proj_i = proj_i; a.h = h; a.c = c; a.cov = cov; a.x = x;
+    a.saved = saved; a.dist = dist; a.c_out = c_out; a.mask = mask;
+    a.d_dist = d_dist; a.d_h_out = d_h_out; a.d_c_out = d_c_out; a.d_att_cov = d_att_cov; a.d_cov_out = d_cov_out;
+    a.d_h = d_h; a.d_c = d_c; a.d_cov = d_cov; a.d_x = d_x;
+    a.d_proj_a = d_proj_a; a.d_enc_a = d_enc_a; a.d_proj_i = d_proj_i; a.d_enc_i = d_enc_i;
+    a.delta_out = delta_out; a.delta_g = delta_g; a.delta_b1 = delta_b1; a.delta_b2 = delta_b2; a.delta_ha = delta_ha; a.delta_hi = delta_hi;
+    a.vec_acc = vec_acc; a.B = B; a.T = T; a.saved_stride = (int)mmb_decoder_saved_floats(T, w->H);
+    const size_t lds = dec_bwd_lds_floats(T, w->H, w->E, w->L) * sizeof(float);
+    MMB_REQUIRE(lds <= 160 * 1024, "mmb_decoder_step_bwd: T=%d L=%d too large for one workgroup's LDS", T, w->L);
+    static bool attr = false;
+    if (!attr) {
+        MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_step_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(decoder_step_bwd_kernel, dim3(B), dim3(DEC_NT), lds, stream, a);
+    MMB_HIP(hipGetLastError());
+    return MMB_OK;
+}

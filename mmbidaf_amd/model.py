@@ -73,25 +73,27 @@ class MMBiDAF(nn.Module):
                            batch_target_indices, max_dec_len)
 
     def decode(self, embedded_text, T, mod_a, hid_a, mod_i, hid_i, text_mask, batch_target_indices, max_dec_len):
-        """Pointer decoder loop with coverage (reference models.py:120-206): teacher forcing when
-        training, greedy otherwise.  Surrounding graph, stock PyTorch; the per-sample loss terms
-        are gathered on the device (same values as the reference's per-sample Python loop)."""
+        """Pointer decoder loop with coverage (reference models.py:120-206): teacher forcing when training, greedy
+        otherwise.  On the GPU every decode step is ONE fused kernel (mmbidaf_amd/decoder.py) and
+        the per-sample loss terms are gathered on the device (same values as the reference's per-sample Python
+        loop); CPU tensors take the stock-PyTorch step module, as the rest of the surrounding graph does."""
         B = embedded_text.size(0)
         dev = embedded_text.device
         pad = torch.zeros(B, self.max_transcript_length - text_mask.size(1), dtype=text_mask.dtype, device=dev)
         decoder_mask = torch.cat((text_mask, pad), dim=1)
         # the reference sums the (length-sorted) hidden states over layers and directions, models.py:143
         decoder_hidden = (hid_a.sum(1) + hid_i.sum(1)).unsqueeze(1)
-        decoder_cell = torch.zeros(1, B, decoder_hidden.size(-1), device=dev)
-        decoder_input = torch.zeros(B, 1, embedded_text.size(-1), device=dev)
-        coverage = torch.zeros(B, T, 1, device=dev)
-
         eps = 1e-12
-        loss = torch.zeros((), device=dev)
-        dists = []
         rows = torch.arange(B, device=dev)
         targets = batch_target_indices.to(dev).reshape(B, -1).long()
         steps = targets.size(1) if self.training else max_dec_len
+        if embedded_text.is_cuda:
+            return self._decode_fused(embedded_text, mod_a, mod_i, decoder_hidden[:, 0], decoder_mask, targets, steps, rows, eps)
+        decoder_cell = torch.zeros(1, B, decoder_hidden.size(-1), device=dev)
+        decoder_input = torch.zeros(B, 1, embedded_text.size(-1), device=dev)
+        coverage = torch.zeros(B, T, 1, device=dev)
+        loss = torch.zeros((), device=dev)
+        dists = []
         att_cov = None
         for step in range(steps):
             dist, decoder_hidden, decoder_cell, att_cov, coverage = self.multimodal_att_decoder(
@@ -107,3 +109,19 @@ class MMBiDAF(nn.Module):
             loss = loss + torch.sum(torch.min(att_cov, coverage))
         loss = loss / steps
         return torch.stack(dists).transpose(0, 1), loss
+
+    def _decode_fused(self, embedded_text, mod_a, mod_i, h0, decoder_mask, targets, steps, rows, eps):
+        from .decoder import decoder_greedy, decoder_loop
+        dec = self.multimodal_att_decoder
+        tgt = targets[:, :steps].t()                                              # (S,B)
+        if self.training:
+            # teacher forcing (models.py:157-176): step s reads the embedding of target s-1, step 0 a zero vector
+            X = torch.cat((torch.zeros_like(embedded_text[:, :1]).transpose(0, 1),
+                           embedded_text[rows.unsqueeze(0), tgt[:-1]]), dim=0)    # (S,B,E)
+            dists, att_cov, cov = decoder_loop(dec, mod_a, mod_i, h0, X, decoder_mask)
+            loss = -torch.log(dists.gather(2, tgt.unsqueeze(2)) + eps).sum() + torch.min(att_cov, cov).sum()
+        else:
+            # greedy (models.py:178-199): coverage loss of the last step only
+            dists, att_cov, cov = decoder_greedy(dec, mod_a, mod_i, h0, embedded_text, decoder_mask, steps)
+            loss = -torch.log(dists.gather(2, tgt.unsqueeze(2)) + eps).sum() + torch.min(att_cov, cov).sum()
+        return dists.transpose(0, 1), loss / steps

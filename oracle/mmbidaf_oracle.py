@@ -341,3 +341,48 @@ class HotRegionCPU(torch.nn.Module):
         for k, p in self.att.items():
             out[k.replace("__", ".")] = p.grad
         return out
+
+
+# ------------------------------------------------------------------------------------------ decoder
+def decoder_step(P, sent_embed, hidden, cell, enc_a, enc_i, coverage, mask):
+    """One step of MultimodalAttentionDecoder.forward, reference layers/attention.py:145-186, restated op by op.
+    P: the decoder's state dict ('W1.weight', ..., 'lstm.weight_ih_l0', ..., 'out.bias').
+    sent_embed (B,1,E), hidden (B,1,H), cell (1,B,H), enc_* (B,T,2H), coverage (B,T,1), mask (B,L) bool.
+    Returns (dist (B,L), hidden (B,1,H), cell (1,B,H), att_cov (B,T,1), coverage (B,T,1))."""
+    lin = lambda n, x: F.linear(x, P[n + ".weight"], P[n + ".bias"])
+    e1 = lin("v1", torch.tanh(lin("W1", enc_a) + lin("W2", hidden) + lin("Wc1", coverage)))     # attention.py:147
+    a1 = F.softmax(e1, dim=1)                                                                      # :148
+    c1 = torch.sum(a1 * enc_a, dim=1)                                                              # :149-150
+    e2 = lin("v2", torch.tanh(lin("W3", enc_i) + lin("W4", hidden) + lin("Wc2", coverage)))       # :153
+    a2 = F.softmax(e2, dim=1)
+    c2 = torch.sum(a2 * enc_i, dim=1)
+    eb1 = lin("v_beta_1", torch.tanh(lin("W_beta_1", c1.unsqueeze(1)) + lin("W_beta_2", hidden)))  # :161
+    eb2 = lin("v_beta_2", torch.tanh(lin("W_beta_3", c2.unsqueeze(1)) + lin("W_beta_4", hidden)))  # :162
+    beta = F.softmax(torch.cat((eb1, eb2), dim=1), dim=1)                                          # :163-164
+    c3 = torch.sum(torch.stack((c1, c2), dim=1) * beta, dim=1)                                     # :165-166
+    att_cov = torch.bmm(torch.cat((a1, a2), dim=2), beta)                                          # :167
+    coverage = coverage + att_cov                                                                  # :177
+    x = torch.cat((c3.unsqueeze(1), sent_embed), dim=2)                                            # :179
+    # one step of the single-layer nn.LSTM (:181), gate order i,f,g,o
+    h, c = hidden.transpose(0, 1)[0], cell[0]
+    g = F.linear(x[:, 0], P["lstm.weight_ih_l0"], P["lstm.bias_ih_l0"]) + F.linear(h, P["lstm.weight_hh_l0"], P["lstm.bias_hh_l0"])
+    gi, gf, gg, go = g.chunk(4, dim=1)
+    c_new = torch.sigmoid(gf) * c + torch.sigmoid(gi) * torch.tanh(gg)
+    h_new = torch.sigmoid(go) * torch.tanh(c_new)
+    dist = masked_softmax(lin("out", h_new), mask)                                                 # :184
+    return dist, h_new.unsqueeze(1), c_new.unsqueeze(0), att_cov, coverage
+
+
+def decoder_loop_train(P, enc_a, enc_i, h0, X, mask):
+    """Teacher-forced loop of models.py:157-176 around decoder_step: X (S,B,E) are the decoder inputs of every step.
+    Returns dists (S,B,L), att_cov (S,B,T), coverage after each step (S,B,T)."""
+    B, T = enc_a.shape[:2]
+    hidden, cell = h0.unsqueeze(1), torch.zeros(1, B, h0.shape[1])
+    cov = torch.zeros(B, T, 1)
+    dists, acs, covs = [], [], []
+    for s in range(X.shape[0]):
+        dist, hidden, cell, ac, cov = decoder_step(P, X[s].unsqueeze(1), hidden, cell, enc_a, enc_i, cov, mask)
+        dists.append(dist)
+        acs.append(ac[:, :, 0])
+        covs.append(cov[:, :, 0])
+    return torch.stack(dists), torch.stack(acs), torch.stack(covs)

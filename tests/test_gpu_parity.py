@@ -369,6 +369,41 @@ def test_lstm_time_reversal_property_full_size():
     assert maxdiff(y[:, :, 100:].cpu(), y2[:, :, :100].flip(1).cpu()) < 1e-5
 
 
+# ------------------------------------------------------------------------------------------- decoder (row N3)
+@pytest.mark.parametrize("B,T,H,E,L,S", [(3, 17, 10, 12, 21, 4), (2, 50, 100, 300, 60, 3), (4, 9, 6, 5, 9, 6)])
+def test_decoder_loop_vs_oracle(B, T, H, E, L, S):
+    """Fused decoder step kernels (one launch per step, forward and backward) against the op-by-op restatement of
+    the reference step (attention.py:145-186) run in a teacher-forced loop: all outputs, the gradients of the
+    memories, the initial hidden state, the step inputs and all 34 decoder parameters."""
+    from mmbidaf_amd.attention import MultimodalAttentionDecoder
+    from mmbidaf_amd.decoder import decoder_loop
+    g = torch.Generator().manual_seed(B * 100 + T)
+    torch.manual_seed(3 + H)
+    dec = MultimodalAttentionDecoder(E, H, L).to(dev())
+    enc_a, enc_i = torch.randn(B, T, 2 * H, generator=g), torch.randn(B, T, 2 * H, generator=g)
+    h0, X = torch.randn(B, H, generator=g), torch.randn(S, B, E, generator=g)
+    lens = torch.randint(1, T + 1, (B,), generator=g).tolist()
+    lens[0] = T
+    mask = torch.zeros(B, L, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        mask[b, :n] = True
+    cots = [torch.randn(S, B, L, generator=g), torch.randn(S, B, T, generator=g), torch.randn(S, B, T, generator=g)]
+    ins = [t.to(dev()).requires_grad_(True) for t in (enc_a, enc_i, h0, X)]
+    outs = decoder_loop(dec, ins[0], ins[1], ins[2], ins[3], mask.to(dev()))
+    sum((o * c.to(dev())).sum() for o, c in zip(outs, cots)).backward()
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    rins = [t.clone().requires_grad_(True) for t in (enc_a, enc_i, h0, X)]
+    routs = O.decoder_loop_train(P, rins[0], rins[1], rins[2], rins[3], mask)
+    sum((o * c).sum() for o, c in zip(routs, cots)).backward()
+    for n, a, b in zip(("dists", "att_cov", "coverage"), outs, routs):
+        close(a, b, n)
+    for n, a, b in zip(("d_enc_a", "d_enc_i", "d_h0", "d_X"), ins, rins):
+        close(a.grad, b.grad, n)
+    for n, p in dec.named_parameters():
+        assert p.grad is not None, n
+        close(p.grad, P[n].grad, "grad " + n, tol=3e-4)
+
+
 # ------------------------------------------------------------------------------------------- model
 class _Stub(torch.nn.Module):
     def __init__(self, w, b):
