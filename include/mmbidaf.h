@@ -177,32 +177,35 @@ typedef struct {
     const float *vb1, *bvb1, *vb2, *bvb2;                         /* v_beta_1/2 (H2) + bias (1) */
     const float *W_ih, *W_hh, *b_ih, *b_hh;                       /* lstm: (4H, H2+E) (4H,H) (4H) (4H), gate order i,f,g,o */
     const float *W_out, *b_out;                                   /* (L,H) (L) */
-    /* transposed copies (cols, rows) of the matrices the FORWARD products read: a thread per output then streams
-     * coalesced, independent loads (made once per decode loop by the caller) */
-    const float *W2T, *W4T, *Wb2T, *Wb4T, *W_hhT, *Wb1T, *Wb3T, *W_ihT, *W_outT;
+    /* transposed copies, made once per decode loop by the caller, of the matrices the FORWARD products read (a thread
+     * per output then streams coalesced, independent loads):
+     *   WhT (H, 12H) = [W2; W4; W_beta_2; W_beta_4; W_hh]^T with bh (12H) the matching biases concatenated,
+     *   Wb1T, Wb3T (H2,H2), W_ihcT (H2, 4H) = W_ih[:, :H2]^T (the context columns), W_outT (H, L) */
+    const float *WhT, *bh, *Wb1T, *Wb3T, *W_ihcT, *W_outT;
     int32_t H, E, L;
 } mmb_decoder_params;
 
 size_t mmb_decoder_saved_floats(int T, int H);      /* per-sample floats of `saved` (alphas, contexts, gate activations, ...) */
 size_t mmb_decoder_vec_acc_floats(int H);           /* per-sample floats of `vec_acc` */
 
-/* inputs: enc_*, proj_* (B,T,H2); h, c (B,H); cov (B,T); x (B,E) decoder input; mask (B,L) u8
+/* inputs: enc_*, proj_* (B,T,H2); h, c (B,H); cov (B,T); xproj (B,4H) = W_ih[:, H2:] . x + b_ih of this step's decoder
+ * input x (hoisted: one GEMM over all teacher-forced steps); mask (B,L) u8
  * outputs: dist (B,L) = masked softmax; h_out, c_out (B,H); att_cov (B,T); cov_out (B,T) = cov + att_cov;
  * saved (B, mmb_decoder_saved_floats) for the backward, or NULL (inference). */
 int mmb_decoder_step_fwd(const mmb_decoder_params* w, const float* enc_a, const float* enc_i, const float* proj_a,
-                         const float* proj_i, const float* h, const float* c, const float* cov, const float* x,
+                         const float* proj_i, const float* h, const float* c, const float* cov, const float* xproj,
                          const uint8_t* mask, float* dist, float* h_out, float* c_out, float* att_cov, float* cov_out,
                          float* saved, int B, int T, int device, void* stream);
 
 /* Backward of one step.  Upstream gradients d_dist (B,L), d_h_out, d_c_out (B,H), d_att_cov, d_cov_out (B,T) may be NULL
- * (= zero).  Overwrites d_h, d_c (B,H), d_cov (B,T), d_x (B,E) and the pre-activation gradients delta_* (the caller turns
- * those into weight gradients with one GEMM over all steps); ACCUMULATES into d_proj_*, d_enc_* (B,T,H2) and into
+ * (= zero).  Overwrites d_h, d_c (B,H), d_cov (B,T) and the pre-activation gradients delta_* (the caller turns those into
+ * weight gradients, and delta_g into the gradient of the decoder inputs, with one GEMM over all steps); ACCUMULATES into d_proj_*, d_enc_* (B,T,H2) and into
  * vec_acc (B, mmb_decoder_vec_acc_floats): [d_wc1 | d_v1 | d_wc2 | d_v2 | d_vb1 | d_vb2 | d_bv1, d_bv2, d_bvb1, d_bvb2]. */
 int mmb_decoder_step_bwd(const mmb_decoder_params* w, const float* enc_a, const float* enc_i, const float* proj_a,
-                         const float* proj_i, const float* h, const float* c, const float* cov, const float* x,
+                         const float* proj_i, const float* h, const float* c, const float* cov,
                          const uint8_t* mask, const float* saved, const float* dist, const float* c_out,
                          const float* d_dist, const float* d_h_out, const float* d_c_out, const float* d_att_cov,
-                         const float* d_cov_out, float* d_h, float* d_c, float* d_cov, float* d_x, float* d_proj_a,
+                         const float* d_cov_out, float* d_h, float* d_c, float* d_cov, float* d_proj_a,
                          float* d_enc_a, float* d_proj_i, float* d_enc_i, float* delta_out, float* delta_g,
                          float* delta_b1, float* delta_b2, float* delta_ha, float* delta_hi, float* vec_acc, int B,
                          int T, int device, void* stream);

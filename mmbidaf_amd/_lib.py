@@ -44,7 +44,7 @@ class LstmBwdDesc(ctypes.Structure):
 DECODER_PTRS = ["W2", "b2", "W4", "b4", "wc1", "bc1", "v1", "bv1", "wc2", "bc2", "v2", "bv2",
                 "Wb1", "bb1", "Wb2", "bb2", "Wb3", "bb3", "Wb4", "bb4", "vb1", "bvb1", "vb2", "bvb2",
                 "W_ih", "W_hh", "b_ih", "b_hh", "W_out", "b_out"]
-DECODER_T_PTRS = ["W2T", "W4T", "Wb2T", "Wb4T", "W_hhT", "Wb1T", "Wb3T", "W_ihT", "W_outT"]   # transposed copies
+DECODER_T_PTRS = ["WhT", "bh", "Wb1T", "Wb3T", "W_ihcT", "W_outT"]   # derived (transposed / concatenated) copies
 
 
 class DecoderParams(ctypes.Structure):   # mmb_decoder_params
@@ -72,7 +72,7 @@ SIGNATURES = {
     "mmb_decoder_saved_floats": (ctypes.c_size_t, [c_i] * 2),
     "mmb_decoder_vec_acc_floats": (ctypes.c_size_t, [c_i]),
     "mmb_decoder_step_fwd": (c_i, [ctypes.POINTER(DecoderParams)] + [c_f] * 15 + [c_i] * 3 + [c_f]),
-    "mmb_decoder_step_bwd": (c_i, [ctypes.POINTER(DecoderParams)] + [c_f] * 32 + [c_i] * 3 + [c_f]),
+    "mmb_decoder_step_bwd": (c_i, [ctypes.POINTER(DecoderParams)] + [c_f] * 30 + [c_i] * 3 + [c_f]),
 }
 
 # kernel ids of the opt-in timing hook (enum in include/mmbidaf.h)

@@ -27,7 +27,8 @@ __device__ __forceinline__ float dwave_max(float v) {
 }
 __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ float dot4(f4 a, f4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-__device__ __forceinline__ f4 tanh4(f4 z) { return f4{tanhf(z.x), tanhf(z.y), tanhf(z.z), tanhf(z.w)}; }
+// 2 sigmoid(2x) - 1 on the hardware exp / rcp (common.h): ~1e-6 relative, and 5x fewer instructions than tanhf
+__device__ __forceinline__ f4 tanh4(f4 z) { return f4{tanhf_(z.x), tanhf_(z.y), tanhf_(z.z), tanhf_(z.w)}; }
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // out[r] = W[r,:] . x + bias[r] + add[r]   (one wave per row, lanes along the columns)
@@ -41,37 +42,70 @@ __device__ void dec_matvec(const float* __restrict__ W, int ld, const float* x, 
         if (lane == 0) out[r] = acc + (bias ? bias[r] : 0.f) + (add ? add[r] : 0.f);
     }
 }
-// out[r] = sum_j WT[j, r] * x[j] + bias[r] + add[r]   (WT = W transposed, (cols, rows): thread per output, the loads of a
-// thread are independent and coalesced across threads, no cross-lane reduction)
-__device__ void dec_matvec_c(const float* __restrict__ WT, const float* x, int rows, int cols, float* out,
+// out[r] = sum_j WT[j*ldt + r] * x[j] + bias[r] + add[r]   (WT = W transposed, ldt >= rows: thread per output; the loads of
+// a thread are independent -- 8 in flight -- and coalesced across threads, no cross-lane reduction)
+__device__ __forceinline__ float dec_col_dot(const float* __restrict__ col, int ldt, const float* x, int cols) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int j = 0;
+    for (; j + 8 <= cols; j += 8) {
+        float wv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wv[k] = col[(size_t)(j + k) * ldt];
+        a0 = fmaf(wv[0], x[j], a0); a1 = fmaf(wv[1], x[j + 1], a1); a2 = fmaf(wv[2], x[j + 2], a2); a3 = fmaf(wv[3], x[j + 3], a3);
+        a0 = fmaf(wv[4], x[j + 4], a0); a1 = fmaf(wv[5], x[j + 5], a1); a2 = fmaf(wv[6], x[j + 6], a2); a3 = fmaf(wv[7], x[j + 7], a3);
+    }
+    for (; j < cols; ++j) a0 = fmaf(col[(size_t)j * ldt], x[j], a0);
+    return (a0 + a1) + (a2 + a3);
+}
+__device__ void dec_matvec_c(const float* __restrict__ WT, int ldt, const float* x, int rows, int cols, float* out,
                              const float* __restrict__ bias, const float* add) {
-    for (int r = threadIdx.x; r < rows; r += DEC_NT) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int j = 0;
-        for (; j + 4 <= cols; j += 4) {
-            a0 = fmaf(WT[(size_t)j * rows + r], x[j], a0);
-            a1 = fmaf(WT[(size_t)(j + 1) * rows + r], x[j + 1], a1);
-            a2 = fmaf(WT[(size_t)(j + 2) * rows + r], x[j + 2], a2);
-            a3 = fmaf(WT[(size_t)(j + 3) * rows + r], x[j + 3], a3);
-        }
-        for (; j < cols; ++j) a0 = fmaf(WT[(size_t)j * rows + r], x[j], a0);
-        out[r] = (a0 + a1) + (a2 + a3) + (bias ? bias[r] : 0.f) + (add ? add[r] : 0.f);
+    for (int r = threadIdx.x; r < rows; r += DEC_NT)
+        out[r] = dec_col_dot(WT + r, ldt, x, cols) + (bias ? bias[r] : 0.f) + (add ? add[r] : 0.f);
+}
+// two products of the same shape side by side (outputs r < rows from the first, the rest from the second)
+__device__ void dec_matvec_c2(const float* __restrict__ WTa, const float* xa, float* outa, const float* __restrict__ ba, const float* adda,
+                              const float* __restrict__ WTb, const float* xb, float* outb, const float* __restrict__ bb, const float* addb,
+                              int rows, int cols) {
+    for (int t = threadIdx.x; t < 2 * rows; t += DEC_NT) {
+        const bool second = t >= rows;
+        const int r = second ? t - rows : t;
+        const float v = dec_col_dot((second ? WTb : WTa) + r, rows, second ? xb : xa, cols);
+        (second ? outb : outa)[r] = v + (second ? bb : ba)[r] + (second ? addb : adda)[r];
     }
 }
-// out[j] (+)= sum_r delta[r] * W[r, j]     (lanes along the columns: coalesced rows of W)
-__device__ void dec_matvec_t(const float* __restrict__ W, int ld, const float* delta, int rows, int cols, float* out, bool accumulate) {
-    for (int j = threadIdx.x; j < cols; j += DEC_NT) {
+// out[j] (+)= sum_r delta[r] * W[r*ld + j]   (lanes along the columns: coalesced rows of W).  With few columns the row
+// range is split over DEC_NT / cols thread groups and the partial sums meet in LDS (part: DEC_NT floats).
+__device__ void dec_matvec_t(const float* __restrict__ W, int ld, const float* delta, int rows, int cols, float* out, bool accumulate,
+                             float* part) {
+    int groups = DEC_NT / cols;
+    if (groups < 1) groups = 1;
+    if (groups > 8) groups = 8;
+    const int chunk = (rows + groups - 1) / groups;
+    for (int t = threadIdx.x; t < groups * cols; t += DEC_NT) {
+        const int g = t / cols, j = t - g * cols;
+        const int r0 = g * chunk, r1 = min(rows, r0 + chunk);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int r = 0;
-        for (; r + 4 <= rows; r += 4) {
-            a0 = fmaf(delta[r], W[(size_t)r * ld + j], a0);
-            a1 = fmaf(delta[r + 1], W[(size_t)(r + 1) * ld + j], a1);
-            a2 = fmaf(delta[r + 2], W[(size_t)(r + 2) * ld + j], a2);
-            a3 = fmaf(delta[r + 3], W[(size_t)(r + 3) * ld + j], a3);
+        int r = r0;
+        for (; r + 8 <= r1; r += 8) {
+            float wv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wv[k] = W[(size_t)(r + k) * ld + j];
+            a0 = fmaf(wv[0], delta[r], a0); a1 = fmaf(wv[1], delta[r + 1], a1); a2 = fmaf(wv[2], delta[r + 2], a2); a3 = fmaf(wv[3], delta[r + 3], a3);
+            a0 = fmaf(wv[4], delta[r + 4], a0); a1 = fmaf(wv[5], delta[r + 5], a1); a2 = fmaf(wv[6], delta[r + 6], a2); a3 = fmaf(wv[7], delta[r + 7], a3);
         }
-        for (; r < rows; ++r) a0 = fmaf(delta[r], W[(size_t)r * ld + j], a0);
+        for (; r < r1; ++r) a0 = fmaf(W[(size_t)r * ld + j], delta[r], a0);
         const float acc = (a0 + a1) + (a2 + a3);
-        out[j] = accumulate ? out[j] + acc : acc;
+        if (groups == 1) out[j] = accumulate ? out[j] + acc : acc;
+        else part[t] = acc;
+    }
+    if (groups > 1) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < cols; j += DEC_NT) {
+            float acc = 0.f;
+            for (int g = 0; g < groups; ++g) acc += part[g * cols + j];
+            out[j] = accumulate ? out[j] + acc : acc;
+        }
+        __syncthreads();   // `part` may be rewritten by the next call
     }
 }
 // block-wide sum / max of one value per thread (scratch: DEC_NW + 1 floats)
@@ -99,25 +133,26 @@ __device__ float dec_block_max(float v, float* scratch) {
 struct DecShapes { int B, T, H, H2, E, L; };
 
 // additive attention of one modality for this sample: alpha into e[0..T), context into ctx[0..H2)
-__device__ void dec_attention(const float* __restrict__ P, const float* __restrict__ Em, const float* hm, const float* cov,
+template <int NQ>
+__device__ void dec_attention_t(const float* __restrict__ P, const float* __restrict__ Em, const float* hm, const float* cov,
                               const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ v, float bv,
                               int T, int H2, float* e, float* ctx, float* wred /* [NW][H2 + 2] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float m = -INFINITY, l = 0.f;
-    f4 cacc[DEC_MAXQ];
+    f4 cacc[NQ];
 #pragma unroll
-    for (int q = 0; q < DEC_MAXQ; ++q) cacc[q] = f4{0.f, 0.f, 0.f, 0.f};
-    constexpr int RB = 4;   // memory rows per wave iteration: their loads and reductions overlap
+    for (int q = 0; q < NQ; ++q) cacc[q] = f4{0.f, 0.f, 0.f, 0.f};
+    constexpr int RB = 8;   // memory rows per wave iteration: their loads and reductions overlap
     for (int t0 = wave * RB; t0 < T; t0 += DEC_NW * RB) {
         float part[RB];
-        f4 ev[RB][DEC_MAXQ];
+        f4 ev[RB][NQ];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int t = min(t0 + i, T - 1);
             const float ct = cov[t];
             part[i] = 0.f;
 #pragma unroll
-            for (int q = 0; q < DEC_MAXQ; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int d = lane * 4 + 256 * q;
                 ev[i][q] = f4{0.f, 0.f, 0.f, 0.f};
                 if (d < H2) {
@@ -137,17 +172,17 @@ __device__ void dec_attention(const float* __restrict__ P, const float* __restri
             if (t0 + i < T) {
                 const float et = part[i] + bv;
                 if (lane == 0) e[t0 + i] = et;
-                const float mn = fmaxf(m, et), sc = expf(m - mn), pe = expf(et - mn);
+                const float mn = fmaxf(m, et), sc = __expf(m - mn), pe = __expf(et - mn);
                 l = l * sc + pe;
 #pragma unroll
-                for (int q = 0; q < DEC_MAXQ; ++q) cacc[q] = cacc[q] * sc + ev[i][q] * pe;
+                for (int q = 0; q < NQ; ++q) cacc[q] = cacc[q] * sc + ev[i][q] * pe;
                 m = mn;
             }
         }
     }
     float* wr = wred + wave * (H2 + 2);
 #pragma unroll
-    for (int q = 0; q < DEC_MAXQ; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int d = lane * 4 + 256 * q;
         if (d < H2) *reinterpret_cast<f4*>(wr + d) = cacc[q];
     }
@@ -173,9 +208,17 @@ __device__ void dec_attention(const float* __restrict__ P, const float* __restri
     __syncthreads();
 }
 
+__device__ void dec_attention(const float* __restrict__ P, const float* __restrict__ Em, const float* hm, const float* cov,
+                              const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ v, float bv,
+                              int T, int H2, float* e, float* ctx, float* wred) {
+    if (H2 <= 256) dec_attention_t<1>(P, Em, hm, cov, wc, bc, v, bv, T, H2, e, ctx, wred);
+    else if (H2 <= 512) dec_attention_t<2>(P, Em, hm, cov, wc, bc, v, bv, T, H2, e, ctx, wred);
+    else dec_attention_t<4>(P, Em, hm, cov, wc, bc, v, bv, T, H2, e, ctx, wred);
+}
+
 struct DecFwdArgs {
     mmb_decoder_params w;
-    const float *enc_a, *enc_i, *proj_a, *proj_i, *h, *c, *cov, *x;
+    const float *enc_a, *enc_i, *proj_a, *proj_i, *h, *c, *cov, *xproj;
     const uint8_t* mask;
     float *dist, *h_out, *c_out, *att_cov, *cov_out, *saved;
     int B, T, saved_stride;
@@ -192,14 +235,14 @@ __device__ DecLds dec_carve(float* sm, int T, int H, int H2, int E, int L) {
     s.hv = take(H); s.cv = take(H); s.cov = take(T); s.ea = take(T); s.ei = take(T);
     s.ha = take(H2); s.hi = take(H2); s.hb1 = take(H2); s.hb2 = take(H2); s.hh = take(4 * H);
     s.ctxa = take(H2); s.ctxi = take(H2); s.u1 = take(H2); s.u2 = take(H2);
-    s.inp = take(H2 + E); s.gates = take(4 * H); s.hnew = take(H); s.logits = take(L);
+    s.inp = take(H2); s.gates = take(4 * H); s.hnew = take(H); s.logits = take(L);
     s.wred = take(DEC_NW * (H2 + 2)); s.scratch = take(16);
     return s;
 }
 static size_t dec_lds_floats(int T, int H, int E, int L) {
     const int H2 = 2 * H;
     auto r4 = [](int n) { return (size_t)((n + 3) & ~3); };
-    return 2 * r4(H) + 3 * r4(T) + 4 * r4(H2) + r4(4 * H) + 4 * r4(H2) + r4(H2 + E) + r4(4 * H) + r4(H) + r4(L) + r4(DEC_NW * (H2 + 2)) + 16;
+    return 2 * r4(H) + 3 * r4(T) + 4 * r4(H2) + r4(4 * H) + 4 * r4(H2) + r4(H2) + r4(4 * H) + r4(H) + r4(L) + r4(DEC_NW * (H2 + 2)) + 16;
 }
 
 __global__ __launch_bounds__(DEC_NT) void decoder_step_fwd_kernel(const DecFwdArgs a) {
@@ -209,22 +252,17 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_fwd_kernel(const DecFwdAr
     const DecLds s = dec_carve(sm, T, H, H2, E, L);
     for (int i = tid; i < H; i += DEC_NT) { s.hv[i] = a.h[(size_t)b * H + i]; s.cv[i] = a.c[(size_t)b * H + i]; }
     for (int i = tid; i < T; i += DEC_NT) s.cov[i] = a.cov[(size_t)b * T + i];
-    for (int i = tid; i < E; i += DEC_NT) s.inp[H2 + i] = a.x[(size_t)b * E + i];
     __syncthreads();
     // every product with the previous hidden state
-    dec_matvec_c(w.W2T, s.hv, H2, H, s.ha, w.b2, nullptr);
-    dec_matvec_c(w.W4T, s.hv, H2, H, s.hi, w.b4, nullptr);
-    dec_matvec_c(w.Wb2T, s.hv, H2, H, s.hb1, w.bb2, nullptr);
-    dec_matvec_c(w.Wb4T, s.hv, H2, H, s.hb2, w.bb4, nullptr);
-    dec_matvec_c(w.W_hhT, s.hv, 4 * H, H, s.hh, w.b_hh, nullptr);
+    // [ha | hi | hb1 | hb2 | hh] (contiguous in LDS) = [W2; W4; W_beta_2; W_beta_4; W_hh] . h + biases, one loop over h
+    dec_matvec_c(w.WhT, 12 * H, s.hv, 12 * H, H, s.ha, w.bh, nullptr);
     __syncthreads();
     dec_attention(a.proj_a + (size_t)b * T * H2, a.enc_a + (size_t)b * T * H2, s.ha, s.cov, w.wc1, w.bc1, w.v1, w.bv1[0], T, H2,
                   s.ea, s.ctxa, s.wred);
     dec_attention(a.proj_i + (size_t)b * T * H2, a.enc_i + (size_t)b * T * H2, s.hi, s.cov, w.wc2, w.bc2, w.v2, w.bv2[0], T, H2,
                   s.ei, s.ctxi, s.wred);
     // gate between the two contexts
-    dec_matvec_c(w.Wb1T, s.ctxa, H2, H2, s.u1, w.bb1, s.hb1);
-    dec_matvec_c(w.Wb3T, s.ctxi, H2, H2, s.u2, w.bb3, s.hb2);
+    dec_matvec_c2(w.Wb1T, s.ctxa, s.u1, w.bb1, s.hb1, w.Wb3T, s.ctxi, s.u2, w.bb3, s.hb2, H2, H2);
     __syncthreads();
     float p1 = 0.f, p2 = 0.f;
     for (int d = tid; d < H2; d += DEC_NT) {
@@ -244,7 +282,8 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_fwd_kernel(const DecFwdAr
     }
     __syncthreads();
     // LSTM cell on [c3 ; x]
-    dec_matvec_c(w.W_ihT, s.inp, 4 * H, H2 + E, s.gates, w.b_ih, s.hh);
+    // gates = W_ih[:, :2H] . c3 + (W_ih[:, 2H:] . x + b_ih, hoisted by the caller: xproj) + (W_hh h + b_hh)
+    dec_matvec_c(w.W_ihcT, 4 * H, s.inp, 4 * H, H2, s.gates, a.xproj + (size_t)b * 4 * H, s.hh);
     __syncthreads();
     for (int u = tid; u < H; u += DEC_NT) {
         const float gi = sigm(s.gates[u]), gf = sigm(s.gates[H + u]), gg = tanhf(s.gates[2 * H + u]), go = sigm(s.gates[3 * H + u]);
@@ -260,7 +299,7 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_fwd_kernel(const DecFwdAr
     }
     __syncthreads();
     // output distribution over the (padded) transcript positions
-    dec_matvec_c(w.W_outT, s.hnew, L, H, s.logits, w.b_out, nullptr);
+    dec_matvec_c(w.W_outT, L, s.hnew, L, H, s.logits, w.b_out, nullptr);
     __syncthreads();
     const uint8_t* mk = a.mask + (size_t)b * L;
     float mx = -INFINITY;
@@ -288,10 +327,10 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_fwd_kernel(const DecFwdAr
 // ------------------------------------------------------------------------------------------ backward
 struct DecBwdArgs {
     mmb_decoder_params w;
-    const float *enc_a, *enc_i, *proj_a, *proj_i, *h, *c, *cov, *x, *saved, *dist, *c_out;
+    const float *enc_a, *enc_i, *proj_a, *proj_i, *h, *c, *cov, *saved, *dist, *c_out;
     const uint8_t* mask;
     const float *d_dist, *d_h_out, *d_c_out, *d_att_cov, *d_cov_out;   // any of them may be NULL (= zero)
-    float *d_h, *d_c, *d_cov, *d_x;                                     // overwritten
+    float *d_h, *d_c, *d_cov;                                           // overwritten
     float *d_proj_a, *d_enc_a, *d_proj_i, *d_enc_i;                     // (B,T,2H) accumulated (+=)
     float *delta_out, *delta_g, *delta_b1, *delta_b2, *delta_ha, *delta_hi;   // (B,L) (B,4H) (B,2H) x4, overwritten
     float* vec_acc;                                                     // (B, 6*2H + 4) accumulated (+=)
@@ -300,55 +339,80 @@ struct DecBwdArgs {
 
 // backward of dec_attention for one modality.  dact[t] = d_att_cov[t] + d_cov_out[t]; the upstream gradient of alpha_t is
 // beta * dact[t].  Accumulates d_proj, d_enc (global), dcov[t] (LDS), returns delta_h (the sum of dz over t) in dhm.
-__device__ void dec_attention_bwd(const float* __restrict__ P, const float* __restrict__ Em, const float* hm, const float* cov,
+template <int NQ>
+__device__ void dec_attention_bwd_t(const float* __restrict__ P, const float* __restrict__ Em, const float* hm, const float* cov,
                                   const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ v,
                                   const float* alpha, const float* dact, float beta, const float* dctx, float Ssum,
                                   int T, int H2, float* dP, float* dE, float* dcov, float* dhm, float* acc_wc, float* acc_v,
                                   float* acc_bv, float* wred /* [NW][3][H2] */, float* scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f4 a_h[DEC_MAXQ], a_wc[DEC_MAXQ], a_v[DEC_MAXQ];
+    f4 a_h[NQ], a_wc[NQ], a_v[NQ];
 #pragma unroll
-    for (int q = 0; q < DEC_MAXQ; ++q) a_h[q] = a_wc[q] = a_v[q] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < NQ; ++q) a_h[q] = a_wc[q] = a_v[q] = f4{0.f, 0.f, 0.f, 0.f};
     float a_bv = 0.f;
-    for (int t = wave; t < T; t += DEC_NW) {
-        const float ct = cov[t], al = alpha[t];
-        float part = 0.f;
-        f4 tz[DEC_MAXQ];
+    constexpr int RB = 4;   // memory rows per wave iteration: all loads (incl. the old gradients) issued up front
+    for (int t0 = wave * RB; t0 < T; t0 += DEC_NW * RB) {
+        float part[RB];
+        f4 tz[RB][NQ], gp[RB][NQ], ge[RB][NQ];
 #pragma unroll
-        for (int q = 0; q < DEC_MAXQ; ++q) {
-            const int d = lane * 4 + 256 * q;
-            tz[q] = f4{0.f, 0.f, 0.f, 0.f};
-            if (d < H2) {
-                const f4 z = ld4(P + (size_t)t * H2 + d) + ld4(hm + d) + ld4(wc + d) * ct + ld4(bc + d);
-                tz[q] = tanh4(z);
-                part += dot4(ld4(dctx + d), ld4(Em + (size_t)t * H2 + d));
+        for (int i = 0; i < RB; ++i) {
+            const int t = min(t0 + i, T - 1);
+            const float ct = cov[t];
+            part[i] = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int d = lane * 4 + 256 * q;
+                tz[i][q] = gp[i][q] = ge[i][q] = f4{0.f, 0.f, 0.f, 0.f};
+                if (d < H2) {
+                    const f4 z = ld4(P + (size_t)t * H2 + d) + ld4(hm + d) + ld4(wc + d) * ct + ld4(bc + d);
+                    tz[i][q] = tanh4(z);
+                    part[i] += dot4(ld4(dctx + d), ld4(Em + (size_t)t * H2 + d));
+                    gp[i][q] = ld4(dP + (size_t)t * H2 + d);
+                    ge[i][q] = ld4(dE + (size_t)t * H2 + d);
+                }
             }
         }
-        const float da_tot = beta * dact[t] + dwave_sum(part);
-        const float de = al * (da_tot - Ssum);
-        a_bv += de;
-        float pc = 0.f;
 #pragma unroll
-        for (int q = 0; q < DEC_MAXQ; ++q) {
-            const int d = lane * 4 + 256 * q;
-            if (d < H2) {
-                const f4 dz = ld4(v + d) * (f4{1.f, 1.f, 1.f, 1.f} - tz[q] * tz[q]) * de;
-                float* gp = dP + (size_t)t * H2 + d;
-                float* ge = dE + (size_t)t * H2 + d;
-                *reinterpret_cast<f4*>(gp) = ld4(gp) + dz;
-                *reinterpret_cast<f4*>(ge) = ld4(ge) + ld4(dctx + d) * al;
-                a_h[q] += dz;
-                a_wc[q] += dz * ct;
-                a_v[q] += tz[q] * de;
-                pc += dot4(dz, ld4(wc + d));
+        for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) part[i] += __shfl_xor(part[i], o);
+        }
+        float pc[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            pc[i] = 0.f;
+            if (t0 + i < T) {
+                const int t = t0 + i;
+                const float ct = cov[t], al = alpha[t];
+                const float de = al * (beta * dact[t] + part[i] - Ssum);
+                a_bv += de;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int d = lane * 4 + 256 * q;
+                    if (d < H2) {
+                        const f4 dz = ld4(v + d) * (f4{1.f, 1.f, 1.f, 1.f} - tz[i][q] * tz[i][q]) * de;
+                        *reinterpret_cast<f4*>(dP + (size_t)t * H2 + d) = gp[i][q] + dz;
+                        *reinterpret_cast<f4*>(dE + (size_t)t * H2 + d) = ge[i][q] + ld4(dctx + d) * al;
+                        a_h[q] += dz;
+                        a_wc[q] += dz * ct;
+                        a_v[q] += tz[i][q] * de;
+                        pc[i] += dot4(dz, ld4(wc + d));
+                    }
+                }
             }
         }
-        pc = dwave_sum(pc);
-        if (lane == 0) dcov[t] += pc;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) pc[i] += __shfl_xor(pc[i], o);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            if (lane == 0 && t0 + i < T) dcov[t0 + i] += pc[i];
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < DEC_MAXQ; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int d = lane * 4 + 256 * q;
         if (d < H2) {
             *reinterpret_cast<f4*>(wred + (wave * 3 + 0) * H2 + d) = a_h[q];
@@ -372,6 +436,16 @@ __device__ void dec_attention_bwd(const float* __restrict__ P, const float* __re
     __syncthreads();
 }
 
+__device__ void dec_attention_bwd(const float* __restrict__ P, const float* __restrict__ Em, const float* hm, const float* cov,
+                                  const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ v,
+                                  const float* alpha, const float* dact, float beta, const float* dctx, float Ssum,
+                                  int T, int H2, float* dP, float* dE, float* dcov, float* dhm, float* acc_wc, float* acc_v,
+                                  float* acc_bv, float* wred, float* scratch) {
+    if (H2 <= 256) dec_attention_bwd_t<1>(P, Em, hm, cov, wc, bc, v, alpha, dact, beta, dctx, Ssum, T, H2, dP, dE, dcov, dhm, acc_wc, acc_v, acc_bv, wred, scratch);
+    else if (H2 <= 512) dec_attention_bwd_t<2>(P, Em, hm, cov, wc, bc, v, alpha, dact, beta, dctx, Ssum, T, H2, dP, dE, dcov, dhm, acc_wc, acc_v, acc_bv, wred, scratch);
+    else dec_attention_bwd_t<4>(P, Em, hm, cov, wc, bc, v, alpha, dact, beta, dctx, Ssum, T, H2, dP, dE, dcov, dhm, acc_wc, acc_v, acc_bv, wred, scratch);
+}
+
 __global__ __launch_bounds__(DEC_NT) void decoder_step_bwd_kernel(const DecBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const mmb_decoder_params& w = a.w;
@@ -382,8 +456,8 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_bwd_kernel(const DecBwdAr
     float *hv = take(H), *cv = take(H), *cov = take(T), *ala = take(T), *ali = take(T), *dact = take(T), *dcov = take(T);
     float *ha = take(H2), *hi = take(H2), *ctxa = take(H2), *ctxi = take(H2), *u1 = take(H2), *u2 = take(H2);
     float *dctxa = take(H2), *dctxi = take(H2), *db1 = take(H2), *db2 = take(H2), *dha = take(H2), *dhi = take(H2);
-    float *gates = take(4 * H), *dg = take(4 * H), *dhn = take(H), *dh = take(H), *dl = take(L), *dinp = take(H2 + E);
-    float *wred = take(DEC_NW * 3 * H2), *scratch = take(16);
+    float *gates = take(4 * H), *dg = take(4 * H), *dhn = take(H), *dh = take(H), *dl = take(L), *dinp = take(H2);
+    float *wred = take(DEC_NW * 3 * H2), *scratch = take(16), *part = take(DEC_NT);
     const float* sv = a.saved + (size_t)b * a.saved_stride;
     for (int i = tid; i < H; i += DEC_NT) {
         hv[i] = a.h[(size_t)b * H + i]; cv[i] = a.c[(size_t)b * H + i];
@@ -402,8 +476,7 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_bwd_kernel(const DecBwdAr
     for (int i = tid; i < 4 * H; i += DEC_NT) gates[i] = sv[2 * T + 4 * H2 + i];
     const float beta1 = sv[2 * T + 4 * H2 + 4 * H], beta2 = sv[2 * T + 4 * H2 + 4 * H + 1];
     __syncthreads();
-    dec_matvec_c(w.W2T, hv, H2, H, ha, w.b2, nullptr);   // recomputed hidden-state terms of the two attentions
-    dec_matvec_c(w.W4T, hv, H2, H, hi, w.b4, nullptr);
+    dec_matvec_c(w.WhT, 12 * H, hv, 2 * H2, H, ha, w.bh, nullptr);   // recomputed hidden-state terms [ha | hi] of the two attentions
     // ---- output layer: dlogit = mask * dist * (d_dist - sum(dist * d_dist))
     const uint8_t* mk = a.mask + (size_t)b * L;
     float sd = 0.f;
@@ -415,7 +488,7 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_bwd_kernel(const DecBwdAr
         a.delta_out[(size_t)b * L + i] = v;
     }
     __syncthreads();
-    dec_matvec_t(w.W_out, H, dl, L, H, dhn, true);       // dh' += W_out^T dlogit
+    dec_matvec_t(w.W_out, H, dl, L, H, dhn, true, part);   // dh' += W_out^T dlogit
     __syncthreads();
     // ---- LSTM cell
     for (int u = tid; u < H; u += DEC_NT) {
@@ -431,10 +504,9 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_bwd_kernel(const DecBwdAr
     }
     __syncthreads();
     for (int i = tid; i < 4 * H; i += DEC_NT) a.delta_g[(size_t)b * 4 * H + i] = dg[i];
-    dec_matvec_t(w.W_ih, H2 + E, dg, 4 * H, H2 + E, dinp, false);   // d[c3 ; x]
-    dec_matvec_t(w.W_hh, H, dg, 4 * H, H, dh, false);               // dh  = W_hh^T dg
+    dec_matvec_t(w.W_ih, H2 + E, dg, 4 * H, H2, dinp, false, part);   // d c3 (the x columns: one GEMM over all steps, caller)
+    dec_matvec_t(w.W_hh, H, dg, 4 * H, H, dh, false, part);           // dh  = W_hh^T dg
     __syncthreads();
-    for (int i = tid; i < E; i += DEC_NT) a.d_x[(size_t)b * E + i] = dinp[H2 + i];
     // ---- mixture: c3 = beta1 ctx_a + beta2 ctx_i, att_cov = beta1 alpha_a + beta2 alpha_i
     float q1 = 0.f, q2 = 0.f, r1 = 0.f, r2 = 0.f;
     for (int d = tid; d < H2; d += DEC_NT) { q1 += dinp[d] * ctxa[d]; q2 += dinp[d] * ctxi[d]; }
@@ -457,11 +529,11 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_bwd_kernel(const DecBwdAr
     }
     if (tid == 0) { vacc[6 * H2 + 2] += de1; vacc[6 * H2 + 3] += de2; }
     __syncthreads();
-    dec_matvec_t(w.Wb1, H2, db1, H2, H2, dctxa, true);
-    dec_matvec_t(w.Wb3, H2, db2, H2, H2, dctxi, true);
-    dec_matvec_t(w.Wb2, H, db1, H2, H, dh, true);
+    dec_matvec_t(w.Wb1, H2, db1, H2, H2, dctxa, true, part);
+    dec_matvec_t(w.Wb3, H2, db2, H2, H2, dctxi, true, part);
+    dec_matvec_t(w.Wb2, H, db1, H2, H, dh, true, part);
     __syncthreads();
-    dec_matvec_t(w.Wb4, H, db2, H2, H, dh, true);
+    dec_matvec_t(w.Wb4, H, db2, H2, H, dh, true, part);
     __syncthreads();
     // ---- the two additive attentions
     float c1 = 0.f, c2 = 0.f;
@@ -475,9 +547,9 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_bwd_kernel(const DecBwdAr
                       a.d_proj_i + mo, a.d_enc_i + mo, dcov, dhi, vacc + 2 * H2, vacc + 3 * H2, vacc + 6 * H2 + 1, wred, scratch);
     for (int d = tid; d < H2; d += DEC_NT) { a.delta_ha[(size_t)b * H2 + d] = dha[d]; a.delta_hi[(size_t)b * H2 + d] = dhi[d]; }
     for (int t = tid; t < T; t += DEC_NT) a.d_cov[(size_t)b * T + t] = dcov[t];
-    dec_matvec_t(w.W2, H, dha, H2, H, dh, true);
+    dec_matvec_t(w.W2, H, dha, H2, H, dh, true, part);
     __syncthreads();
-    dec_matvec_t(w.W4, H, dhi, H2, H, dh, true);
+    dec_matvec_t(w.W4, H, dhi, H2, H, dh, true, part);
     __syncthreads();
     for (int i = tid; i < H; i += DEC_NT) a.d_h[(size_t)b * H + i] = dh[i];
 }
@@ -485,7 +557,7 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_bwd_kernel(const DecBwdAr
 static size_t dec_bwd_lds_floats(int T, int H, int E, int L) {
     const int H2 = 2 * H;
     auto r4 = [](int n) { return (size_t)((n + 3) & ~3); };
-    return 2 * r4(H) + 5 * r4(T) + 12 * r4(H2) + 2 * r4(4 * H) + 2 * r4(H) + r4(L) + r4(H2 + E) + r4(DEC_NW * 3 * H2) + 16;
+    return 2 * r4(H) + 5 * r4(T) + 12 * r4(H2) + 2 * r4(4 * H) + 2 * r4(H) + r4(L) + r4(H2) + r4(DEC_NW * 3 * H2) + 16 + DEC_NT;
 }
 
 }  // namespace mmb
@@ -503,16 +575,16 @@ static int dec_check(const mmb_decoder_params* w, int B, int T) {
 }
 
 extern "C" int mmb_decoder_step_fwd(const mmb_decoder_params* w, const float* enc_a, const float* enc_i, const float* proj_a,
-                                    const float* proj_i, const float* h, const float* c, const float* cov, const float* x,
+                                    const float* proj_i, const float* h, const float* c, const float* cov, const float* xproj,
                                     const uint8_t* mask, float* dist, float* h_out, float* c_out, float* att_cov, float* cov_out,
                                     float* saved, int B, int T, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (int rc = dec_check(w, B, T)) return rc;
-    MMB_REQUIRE(enc_a && enc_i && proj_a && proj_i && h && c && cov && x && mask && dist && h_out && c_out && att_cov && cov_out,
+    MMB_REQUIRE(enc_a && enc_i && proj_a && proj_i && h && c && cov && xproj && mask && dist && h_out && c_out && att_cov && cov_out,
                 "mmb_decoder_step_fwd: null pointer");
     MMB_HIP(hipSetDevice(device));
     DecFwdArgs a{};
-    a.w = *w; a.enc_a = enc_a; a.enc_i = enc_i; a.proj_a = proj_a; a.proj_i = proj_i; a.h = h; a.c = c; a.cov = cov; a.x = x;
+    a.w = *w; a.enc_a = enc_a; a.enc_i = enc_i; a.proj_a = proj_a; a.proj_i = proj_i; a.h = h; a.c = c; a.cov = cov; a.xproj = xproj;
     a.mask = mask; a.dist = dist; a.h_out = h_out; a.c_out = c_out; a.att_cov = att_cov; a.cov_out = cov_out; a.saved = saved;
     a.B = B; a.T = T; a.saved_stride = (int)mmb_decoder_saved_floats(T, w->H);
     const size_t lds = dec_lds_floats(T, w->H, w->E, w->L) * sizeof(float);
@@ -528,24 +600,24 @@ extern "C" int mmb_decoder_step_fwd(const mmb_decoder_params* w, const float* en
 }
 
 extern "C" int mmb_decoder_step_bwd(const mmb_decoder_params* w, const float* enc_a, const float* enc_i, const float* proj_a,
-                                    const float* proj_i, const float* h, const float* c, const float* cov, const float* x,
+                                    const float* proj_i, const float* h, const float* c, const float* cov,
                                     const uint8_t* mask, const float* saved, const float* dist, const float* c_out,
                                     const float* d_dist, const float* d_h_out, const float* d_c_out, const float* d_att_cov,
-                                    const float* d_cov_out, float* d_h, float* d_c, float* d_cov, float* d_x, float* d_proj_a,
+                                    const float* d_cov_out, float* d_h, float* d_c, float* d_cov, float* d_proj_a,
                                     float* d_enc_a, float* d_proj_i, float* d_enc_i, float* delta_out, float* delta_g,
                                     float* delta_b1, float* delta_b2, float* delta_ha, float* delta_hi, float* vec_acc, int B,
                                     int T, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (int rc = dec_check(w, B, T)) return rc;
-    MMB_REQUIRE(enc_a && enc_i && proj_a && proj_i && h && c && cov && x && mask && saved && dist && c_out && d_h && d_c && d_cov &&
-                    d_x && d_proj_a && d_enc_a && d_proj_i && d_enc_i && delta_out && delta_g && delta_b1 && delta_b2 && delta_ha &&
+    MMB_REQUIRE(enc_a && enc_i && proj_a && proj_i && h && c && cov && mask && saved && dist && c_out && d_h && d_c && d_cov &&
+                    d_proj_a && d_enc_a && d_proj_i && d_enc_i && delta_out && delta_g && delta_b1 && delta_b2 && delta_ha &&
                     delta_hi && vec_acc, "mmb_decoder_step_bwd: null pointer");
     MMB_HIP(hipSetDevice(device));
     DecBwdArgs a{};
-    a.w = *w; a.enc_a = enc_a; a.enc_i = enc_i; a.proj_a = proj_a; a.proj_i = proj_i; a.h = h; a.c = c; a.cov = cov; a.x = x;
+    a.w = *w; a.enc_a = enc_a; a.enc_i = enc_i; a.proj_a = proj_a; a.proj_i = proj_i; a.h = h; a.c = c; a.cov = cov;
     a.saved = saved; a.dist = dist; a.c_out = c_out; a.mask = mask;
     a.d_dist = d_dist; a.d_h_out = d_h_out; a.d_c_out = d_c_out; a.d_att_cov = d_att_cov; a.d_cov_out = d_cov_out;
-    a.d_h = d_h; a.d_c = d_c; a.d_cov = d_cov; a.d_x = d_x;
+    a.d_h = d_h; a.d_c = d_c; a.d_cov = d_cov;
     a.d_proj_a = d_proj_a; a.d_enc_a = d_enc_a; a.d_proj_i = d_proj_i; a.d_enc_i = d_enc_i;
     a.delta_out = delta_out; a.delta_g = delta_g; a.delta_b1 = delta_b1; a.delta_b2 = delta_b2; a.delta_ha = delta_ha; a.delta_hi = delta_hi;
     a.vec_acc = vec_acc; a.B = B; a.T = T; a.saved_stride = (int)mmb_decoder_saved_floats(T, w->H);

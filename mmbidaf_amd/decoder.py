@@ -39,10 +39,17 @@ def _params_struct(ws, H, E, L):
         keep.append(w)
         by_name[name] = w
         setattr(p, name, w.data_ptr())
-    for name in _lib.DECODER_T_PTRS:            # transposed copies for the forward products (tiny, once per loop)
-        wt = by_name[name[:-1]].t().contiguous()
-        keep.append(wt)
-        setattr(p, name, wt.data_ptr())
+    # derived copies for the forward products (tiny, once per loop): see mmb_decoder_params
+    n = by_name
+    derived = {
+        "WhT": torch.cat((n["W2"], n["W4"], n["Wb2"], n["Wb4"], n["W_hh"]), dim=0).t().contiguous(),
+        "bh": torch.cat((n["b2"], n["b4"], n["bb2"], n["bb4"], n["b_hh"])).contiguous(),
+        "Wb1T": n["Wb1"].t().contiguous(), "Wb3T": n["Wb3"].t().contiguous(),
+        "W_ihcT": n["W_ih"][:, :2 * H].t().contiguous(), "W_outT": n["W_out"].t().contiguous(),
+    }
+    for name in _lib.DECODER_T_PTRS:
+        keep.append(derived[name])
+        setattr(p, name, derived[name].data_ptr())
     p.H, p.E, p.L = H, E, L
     return p, keep
 
@@ -51,10 +58,10 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def _step_fwd(lib, P, enc_a, enc_i, proj_a, proj_i, h, c, cov, x, mask, dist, h_out, c_out, att_cov, cov_out, saved):
+def _step_fwd(lib, P, enc_a, enc_i, proj_a, proj_i, h, c, cov, xproj, mask, dist, h_out, c_out, att_cov, cov_out, saved):
     B, T = cov.shape
     rc = lib.mmb_decoder_step_fwd(ctypes.byref(P), _ptr(enc_a), _ptr(enc_i), _ptr(proj_a), _ptr(proj_i), _ptr(h), _ptr(c),
-                                  _ptr(cov), _ptr(x), _ptr(mask), _ptr(dist), _ptr(h_out), _ptr(c_out), _ptr(att_cov),
+                                  _ptr(cov), _ptr(xproj), _ptr(mask), _ptr(dist), _ptr(h_out), _ptr(c_out), _ptr(att_cov),
                                   _ptr(cov_out), _ptr(saved), B, T, cov.device.index, MF._stream())
     _lib.check(rc, "mmb_decoder_step_fwd")
 
@@ -78,8 +85,11 @@ class _DecoderLoopFn(torch.autograd.Function):
         covs[0].zero_()
         dists, att_covs = new(S, B, L), new(S, B, T)
         saved = new(S, B, lib.mmb_decoder_saved_floats(T, H))
+        # x part of the LSTM input product, hoisted: one GEMM over all steps  (W_ih = [context columns | x columns])
+        w_ihx = keep[24][:, 2 * H:].contiguous()
+        xproj = MF.gemm(X.reshape(S * B, E), w_ihx, bias=keep[26], tb=True).reshape(S, B, 4 * H)
         for s in range(S):
-            _step_fwd(lib, P, enc_a, enc_i, proj_a, proj_i, hs[s], cs[s], covs[s], X[s], mask, dists[s], hs[s + 1], cs[s + 1],
+            _step_fwd(lib, P, enc_a, enc_i, proj_a, proj_i, hs[s], cs[s], covs[s], xproj[s], mask, dists[s], hs[s + 1], cs[s + 1],
                       att_covs[s], covs[s + 1], saved[s])
         ctx.save_for_backward(enc_a, enc_i, proj_a, proj_i, X, mask, hs, cs, covs, dists, saved, *keep[:30])
         ctx.shapes = [w.shape for w in ws]
@@ -102,7 +112,6 @@ class _DecoderLoopFn(torch.autograd.Function):
         d_proj_a, d_enc_a, d_proj_i, d_enc_i = (zeros(B, T, H2) for _ in range(4))
         dl_out, dl_g = new(S, B, L), new(S, B, 4 * H)
         dl_b1, dl_b2, dl_ha, dl_hi = (new(S, B, H2) for _ in range(4))
-        d_X = new(S, B, E)
         vec = zeros(B, lib.mmb_decoder_vec_acc_floats(H))
         d_h, d_c, d_cov = [zeros(B, H), new(B, H)], [zeros(B, H), new(B, H)], [zeros(B, T), new(B, T)]
         cur = 0
@@ -110,10 +119,10 @@ class _DecoderLoopFn(torch.autograd.Function):
             d_cov_out = d_cov[cur] if d_covs is None else d_cov[cur] + d_covs[s]
             rc = lib.mmb_decoder_step_bwd(
                 ctypes.byref(P), _ptr(enc_a), _ptr(enc_i), _ptr(proj_a), _ptr(proj_i), _ptr(hs[s]), _ptr(cs[s]), _ptr(covs[s]),
-                _ptr(X[s]), _ptr(mask), _ptr(saved[s]), _ptr(dists[s]), _ptr(cs[s + 1]),
+                _ptr(mask), _ptr(saved[s]), _ptr(dists[s]), _ptr(cs[s + 1]),
                 _ptr(None if d_dists is None else d_dists[s]), _ptr(d_h[cur]), _ptr(d_c[cur]),
                 _ptr(None if d_att_covs is None else d_att_covs[s]), _ptr(d_cov_out),
-                _ptr(d_h[cur ^ 1]), _ptr(d_c[cur ^ 1]), _ptr(d_cov[cur ^ 1]), _ptr(d_X[s]),
+                _ptr(d_h[cur ^ 1]), _ptr(d_c[cur ^ 1]), _ptr(d_cov[cur ^ 1]),
                 _ptr(d_proj_a), _ptr(d_enc_a), _ptr(d_proj_i), _ptr(d_enc_i),
                 _ptr(dl_out[s]), _ptr(dl_g[s]), _ptr(dl_b1[s]), _ptr(dl_b2[s]), _ptr(dl_ha[s]), _ptr(dl_hi[s]), _ptr(vec),
                 B, T, dev.index, MF._stream())
@@ -128,6 +137,7 @@ class _DecoderLoopFn(torch.autograd.Function):
         inp = torch.cat((beta[:, 0:1] * ctx_a + beta[:, 1:2] * ctx_i, flat(X)), dim=1)     # [c3 ; x] of every step
         tg = lambda delta, act: MF.gemm(flat(delta), act.contiguous(), ta=True)           # delta^T . act
         V = vec.sum(0)
+        d_X = MF.gemm(flat(dl_g), ws[24][:, 2 * H:].contiguous()).reshape(S, B, E)      # gradient of the decoder inputs
         g = [None] * 30
         g[0], g[1] = tg(dl_ha, h_prev), flat(dl_ha).sum(0)                                  # W2, b2
         g[2], g[3] = tg(dl_hi, h_prev), flat(dl_hi).sum(0)                                  # W4, b4
@@ -173,9 +183,11 @@ def decoder_greedy(dec, enc_a, enc_i, h0, embedded_text, mask, steps):
     x = torch.zeros(B, E, device=dev)
     dists, att_cov = new(steps, B, L), new(B, T)
     rows = torch.arange(B, device=dev)
+    w_ihx, b_ih = dec.lstm.weight_ih_l0[:, 2 * H:], dec.lstm.bias_ih_l0
     cur = 0
     for s in range(steps):
-        _step_fwd(lib, P, enc_a, enc_i, proj_a, proj_i, h[cur], c[cur], cov[cur], x, mask, dists[s], h[cur ^ 1], c[cur ^ 1],
+        xproj = MF._f32c(torch.nn.functional.linear(x, w_ihx, b_ih))
+        _step_fwd(lib, P, enc_a, enc_i, proj_a, proj_i, h[cur], c[cur], cov[cur], xproj, mask, dists[s], h[cur ^ 1], c[cur ^ 1],
                   att_cov, cov[cur ^ 1], None)
         x = emb[rows, dists[s].argmax(dim=1)]
         cur ^= 1

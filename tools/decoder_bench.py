@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Decoder loop alone at cfg2 sizes (B=32, T=400, H=100, E=300, L=405, 10 steps): fused kernels vs the stock-PyTorch
+step module, forward and forward+backward, plus the kernel-only time of one step (events around the C call)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from mmbidaf_amd.attention import MultimodalAttentionDecoder
+from mmbidaf_amd.decoder import decoder_loop
+
+dev = torch.device("cuda:0")
+B, T, H, E, L, S = 32, 400, 100, 300, 405, 10
+torch.manual_seed(0)
+dec = MultimodalAttentionDecoder(E, H, L).to(dev)
+enc_a = torch.randn(B, T, 2 * H, device=dev, requires_grad=True)
+enc_i = torch.randn(B, T, 2 * H, device=dev, requires_grad=True)
+h0 = torch.randn(B, H, device=dev, requires_grad=True)
+X = torch.randn(S, B, E, device=dev)
+mask = torch.ones(B, L, dtype=torch.bool, device=dev)
+mask[:, T:] = False
+
+
+def fused(backward):
+    outs = decoder_loop(dec, enc_a, enc_i, h0, X, mask)
+    if backward:
+        sum(o.sum() for o in outs).backward()
+
+
+def stock(backward):
+    hidden, cell, cov = h0.unsqueeze(1), torch.zeros(1, B, H, device=dev), torch.zeros(B, T, 1, device=dev)
+    tot = 0
+    for s in range(S):
+        dist, hidden, cell, ac, cov = dec(X[s].unsqueeze(1), hidden, cell, enc_a, enc_i, cov, mask)
+        tot = tot + dist.sum() + ac.sum() + cov.sum()
+    if backward:
+        tot.backward()
+
+
+def timeit(fn, *a, n=10):
+    for _ in range(3):
+        fn(*a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn(*a)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+for name, fn in (("fused", fused), ("stock torch", stock)):
+    print(f"{name:12s}: forward {timeit(fn, False):7.3f} ms   forward+backward {timeit(fn, True):7.3f} ms   ({S} steps)")
+
+# kernel-only: trace one forward+backward with the profiler's kernel table
+from torch.profiler import ProfilerActivity, profile
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    fused(True)
+    torch.cuda.synchronize()
+rows = [(e.key[:60], e.device_time_total / max(e.count, 1), e.count) for e in prof.key_averages() if "decoder_step" in e.key]
+for k, us, cnt in rows:
+    print(f"  {k}: {us:.1f} us avg over {cnt} launches")
