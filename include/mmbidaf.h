@@ -211,6 +211,16 @@ int mmb_decoder_step_bwd(const mmb_decoder_params* w, const float* enc_a, const 
                          int T, int device, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Highway layer glue (reference layers/encoding.py:32-59 inside Embedding, :9-30).  The caller runs
+ * ONE GEMM per layer against the stacked [W_gate ; W_transform] (+ biases) into gt (rows, 2H); then
+ *   mmb_highway_gate_fwd: gt := [sigmoid | relu] in place, y = g*t + (1-g)*x
+ *   mmb_highway_gate_bwd: gt := [d pre_gate | d pre_transform] in place, d_x = d_y*(1-g) (the direct path; the caller
+ *                         adds gt . [W_gate ; W_transform] and forms the weight gradients gt^T . x with mmb_gemm_f32).
+ * H a multiple of 4. */
+int mmb_highway_gate_fwd(const float* x, float* gt, float* y, long rows, int H, int device, void* stream);
+int mmb_highway_gate_bwd(const float* d_y, const float* x, float* gt, float* d_x, long rows, int H, int device, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * fp32 MFMA GEMM used by the LSTM input projection / weight gradients (exported for tests and
  * for the host-side highway fusion):  C (M,N) = op(A) . op(B) [+ bias(N)]
  *   ta = 0: A is (M,K) row-major (lda)    ta = 1: A is (K,M) row-major (lda)

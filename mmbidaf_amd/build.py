@@ -4,7 +4,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["api.hip", "gemm.hip", "gemm_bf16.hip", "planes.hip", "lstm.hip", "lstm_big.hip", "bidaf.hip", "bidaf_big.hip", "decoder.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_bf16.hip", "planes.hip", "lstm.hip", "lstm_big.hip", "bidaf.hip", "bidaf_big.hip", "decoder.hip", "highway.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "mmbidaf.h")]
 LIB = os.path.join(_HERE, "libmmbidaf_hip.so")
 

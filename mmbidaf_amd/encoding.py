@@ -37,7 +37,13 @@ class Embedding(nn.Module):
         self.hwy = HighwayEncoder(2, hidden_size)
 
     def forward(self, x):
-        return self.hwy(self.proj(F.dropout(x, self.drop_prob, self.training)))
+        x = F.dropout(x, self.drop_prob, self.training)
+        H = self.proj.weight.shape[0]
+        if x.is_cuda and H % 4 == 0:
+            # one GEMM + one fused element-wise kernel per highway layer (mmbidaf_amd/functional.py)
+            from . import functional as MF
+            return MF.embedding_forward(x, self.proj.weight, self.hwy.gates, self.hwy.transforms)
+        return self.hwy(self.proj(x))
 
 
 class _DeviceCache:

@@ -217,16 +217,18 @@ def bilstm_layer(problems):
     return [(outs[2 * i], outs[2 * i + 1]) for i in range(len(problems))]
 
 
-def gemm(a, b, bias=None, ta=False, tb=False):
-    """C = op(a) . op(b) (+bias) through the library's fp32 MFMA GEMM (used by tests / tools)."""
+def gemm(a, b, bias=None, ta=False, tb=False, out=None, accumulate=False):
+    """C = op(a) . op(b) (+bias) through the library's fp32-accurate MFMA GEMM; `out` (contiguous (M,N)) receives the
+    result, with accumulate=True it is added to."""
     lib = _lib.load()
     _require_gpu(a, b)
     a, b = _f32c(a), _f32c(b)
     M, K = (a.shape[1], a.shape[0]) if ta else a.shape
     N = b.shape[0] if tb else b.shape[1]
-    c = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    c = torch.empty(M, N, device=a.device, dtype=torch.float32) if out is None else out
+    assert c.is_contiguous() and c.shape == (M, N) and c.dtype == torch.float32 and (out is not None or not accumulate)
     rc = lib.mmb_gemm_f32(_ptr(a), _ptr(b), _ptr(c), _ptr(bias), M, N, K, a.stride(0), b.stride(0), N,
-                          int(ta), int(tb), 0, a.device.index, _stream())
+                          int(ta), int(tb), int(accumulate), a.device.index, _stream())
     _lib.check(rc, "mmb_gemm_f32")
     return c
 
@@ -244,3 +246,64 @@ def gemm_nt_planes(a, b, bias=None):
     rc = lib.mmb_gemm_nt_planes(_ptr(a), _ptr(b), _ptr(c), _ptr(bias), M, N, K, _ptr(ws), ws.numel(), a.device.index, _stream())
     _lib.check(rc, "mmb_gemm_nt_planes")
     return c
+
+
+# --------------------------------------------------------------------------------------- Embedding (row N2)
+class _EmbeddingFn(torch.autograd.Function):
+    """proj (no bias) + 2-layer highway of the reference's Embedding (layers/encoding.py:9-59) after its dropout:
+    per highway layer ONE GEMM against the stacked [W_gate ; W_transform] and one fused element-wise kernel, forward
+    and backward.  args: x (R,E), w_proj (H,E), then per layer w_gate, b_gate, w_trans, b_trans."""
+
+    @staticmethod
+    def forward(ctx, x, w_proj, *layers):
+        lib = _lib.load()
+        _require_gpu(x, w_proj, *layers)
+        x, w_proj = _f32c(x), _f32c(w_proj)
+        R, H = x.shape[0], w_proj.shape[0]
+        dev = x.device
+        h = gemm(x, w_proj, tb=True)                                       # (R,H)
+        saved = []
+        for l in range(len(layers) // 4):
+            wg, bg, wt, bt = layers[4 * l:4 * l + 4]
+            wcat, bcat = torch.cat((wg, wt), dim=0).contiguous(), torch.cat((bg, bt)).contiguous()
+            gt = gemm(h, wcat, bias=bcat, tb=True)                         # (R,2H) pre-activations
+            y = torch.empty(R, H, device=dev, dtype=torch.float32)
+            _lib.check(lib.mmb_highway_gate_fwd(_ptr(h), _ptr(gt), _ptr(y), R, H, dev.index, _stream()), "mmb_highway_gate_fwd")
+            saved += [h, gt, wcat]
+            h = y
+        ctx.save_for_backward(x, w_proj, *saved)
+        ctx.need_dx = ctx.needs_input_grad[0]
+        return h
+
+    @staticmethod
+    def backward(ctx, d_y):
+        lib = _lib.load()
+        x, w_proj, *saved = ctx.saved_tensors
+        R, H = x.shape[0], w_proj.shape[0]
+        dev = x.device
+        d_h = _f32c(d_y)
+        grads = []
+        for l in reversed(range(len(saved) // 3)):
+            h_in, gt, wcat = saved[3 * l:3 * l + 3]
+            d_in = torch.empty(R, H, device=dev, dtype=torch.float32)
+            D = gt.clone()                                                 # [g | t] -> [d pre_g | d pre_t]
+            _lib.check(lib.mmb_highway_gate_bwd(_ptr(d_h), _ptr(h_in), _ptr(D), _ptr(d_in), R, H, dev.index, _stream()),
+                       "mmb_highway_gate_bwd")
+            gemm(D, wcat, out=d_in, accumulate=True)                       # d_in += D . [W_g ; W_t]
+            d_wcat = gemm(D, h_in, ta=True)                                # (2H,H)
+            d_bcat = D.sum(0)
+            grads = [d_wcat[:H], d_bcat[:H], d_wcat[H:], d_bcat[H:]] + grads
+            d_h = d_in
+        d_w_proj = gemm(d_h, x, ta=True)                                   # (H,E)
+        d_x = gemm(d_h, w_proj) if ctx.need_dx else None
+        return (d_x, d_w_proj, *grads)
+
+
+def embedding_forward(x, w_proj, gates, transforms):
+    """x (..., E) -> (..., H): projection + highway layers (dropout on x is the caller's)."""
+    flat = x.reshape(-1, x.shape[-1])
+    layers = []
+    for g, t in zip(gates, transforms):
+        layers += [g.weight, g.bias, t.weight, t.bias]
+    y = _EmbeddingFn.apply(flat, w_proj, *layers)
+    return y.reshape(*x.shape[:-1], w_proj.shape[0])

@@ -386,3 +386,15 @@ def decoder_loop_train(P, enc_a, enc_i, h0, X, mask):
         acs.append(ac[:, :, 0])
         covs.append(cov[:, :, 0])
     return torch.stack(dists), torch.stack(acs), torch.stack(covs)
+
+
+# ------------------------------------------------------------------------------------------ embedding
+def embedding(x, P, num_layers=2):
+    """Embedding.forward with drop_prob = 0: bias-free projection, then the highway layers -- reference
+    layers/encoding.py:25-30 and :52-59.  P: the module's state dict ('proj.weight', 'hwy.gates.k.*', 'hwy.transforms.k.*')."""
+    h = F.linear(x, P["proj.weight"])                                                            # encoding.py:27
+    for k in range(num_layers):
+        g = torch.sigmoid(F.linear(h, P[f"hwy.gates.{k}.weight"], P[f"hwy.gates.{k}.bias"]))      # :55
+        t = F.relu(F.linear(h, P[f"hwy.transforms.{k}.weight"], P[f"hwy.transforms.{k}.bias"]))  # :56
+        h = g * t + (1 - g) * h                                                                   # :57
+    return h

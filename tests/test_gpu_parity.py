@@ -369,6 +369,30 @@ def test_lstm_time_reversal_property_full_size():
     assert maxdiff(y[:, :, 100:].cpu(), y2[:, :, :100].flip(1).cpu()) < 1e-5
 
 
+# ------------------------------------------------------------------------------------------- embedding (row N2)
+@pytest.mark.parametrize("B,T,E,H", [(3, 17, 12, 8), (4, 50, 300, 100), (2, 33, 128, 100)])
+def test_embedding_highway_vs_oracle(B, T, E, H):
+    """Embedding = projection + 2 highway layers on one stacked GEMM + one fused element-wise kernel per layer:
+    output and the gradients of the input and of all 9 parameters against the oracle's op-by-op restatement."""
+    from mmbidaf_amd.encoding import Embedding
+    g = torch.Generator().manual_seed(B + T + E)
+    torch.manual_seed(E + H)
+    emb = Embedding(E, H, 0.0).to(dev())
+    x = torch.randn(B, T, E, generator=g)
+    cot = torch.randn(B, T, H, generator=g)
+    xd = x.to(dev()).requires_grad_(True)
+    y = emb(xd)
+    (y * cot.to(dev())).sum().backward()
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in emb.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    yr = O.embedding(xr, P)
+    (yr * cot).sum().backward()
+    close(y, yr, "y")
+    close(xd.grad, xr.grad, "d_x")
+    for n, p in emb.named_parameters():
+        close(p.grad, P[n].grad, "grad " + n, tol=3e-4)
+
+
 # ------------------------------------------------------------------------------------------- decoder (row N3)
 @pytest.mark.parametrize("B,T,H,E,L,S", [(3, 17, 10, 12, 21, 4), (2, 50, 100, 300, 60, 3), (4, 9, 6, 5, 9, 6)])
 def test_decoder_loop_vs_oracle(B, T, H, E, L, S):
