@@ -886,12 +886,22 @@ static int geom_for(int kernel_id, int deflt) {
     return forced[kernel_id] >= 0 ? forced[kernel_id] : deflt;
 }
 
-static int pick_splits(int B, int N, int R, int PR) {
-    const int waves = B * ((N + 15) / 16);
-    int s = (1536 + waves - 1) / waves;  // aim at ~1.5 waves per SIMD (1024 SIMDs)
+// How many ways to split the streamed side (R rows, PR-row panels) of a sweep whose lane side has N rows per sample:
+// the workgroups (4 waves = 64 lane-side rows each) run in rounds of `slots` (256 CUs x workgroups that fit a CU's LDS),
+// so the cost is rounds x (panels per split + fixed per-workgroup work) plus the traffic of the per-split partials.
+// (The earlier "1.5 waves per SIMD" rule gave 384 workgroups for both cfg2 attentions: 1.5 rounds.)
+static int pick_splits(int B, int N, int R, int PR, int slots = 256) {
+    const long tiles = (long)B * ((N + 63) / 64);
     const int smax = (R + PR - 1) / PR;
-    if (s > smax) s = smax;
-    return s < 1 ? 1 : s;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= smax; ++s) {
+        const long rounds = (tiles * s + slots - 1) / slots;
+        const int panels = ((R + s - 1) / s + PR - 1) / PR;
+        const double cost = (double)rounds * (panels + 1.5) + 0.15 * s;
+        if (cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
 }
 static int rows_per_split(int R, int splits, int PR) {
     int rp = (R + splits - 1) / splits;
@@ -904,7 +914,7 @@ struct BwdWs {
 };
 static BwdWs bwd_layout(int B, int T, int M, int D) {
     BwdWs w{};
-    w.splits = pick_splits(B, M, T, 16);   // upper bound over the compiled geometries (16-row panels)
+    w.splits = pick_splits(B, M, T, 16) > pick_splits(B, M, T, 32) ? pick_splits(B, M, T, 16) : pick_splits(B, M, T, 32);   // upper bound over the compiled geometries
     const size_t S = w.splits;
     size_t o = 0;
     auto take = [&](size_t nfloat) { size_t at = o; o += (nfloat + 3) / 4 * 4; return at; };
@@ -996,7 +1006,7 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
         a.side_src = mod_d; a.w_tm = w_tm; a.mS = text_d; a.mV0 = text; a.mV1 = nullptr;
         a.m_mask = text_mask; a.m_term = rterm; a.n_term = cterm; a.stat = col_stat; a.q = q;
         a.N = M; a.R = T; a.D = D; a.B = B;
-        int splits = pick_splits(B, M, T, PRg);
+        int splits = pick_splits(B, M, T, PRg, 512);   // 54 KB of LDS: two workgroups per CU
         while (splits > 1 && (size_t)splits * M * (D + 2) > (size_t)T * 4 * D) --splits;
         a.splits = splits;
         a.rows_per_split = rows_per_split(T, splits, PRg);
