@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--config", default="cfg2", choices=sorted(synth.CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--ragged", action="store_true", help="lengths ~U{n/2..n} instead of full")
+    ap.add_argument("--fresh-lengths", action="store_true",
+                    help="new ragged lengths every step (the host-derived masks / sort orders miss the device cache, as in real training)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class (perturbs the step time a little)")
     return ap.parse_args()
@@ -100,11 +102,17 @@ def main():
     batch = synth.make_batch(a.config, rank=rank, ragged=a.ragged, device=dev, batch=B)
     xs = [batch[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]  # they come from trainable embeddings
 
+    import random
+    rng = random.Random(99 + rank)
+
     def step():
         for p in params:
             p.grad = None
         for x in xs:
             x.grad = None
+        if a.fresh_lengths:
+            for key, n in (("text_len", T), ("aud_len", Ma), ("img_len", Mi)):
+                batch[key] = [n] + [rng.randint(max(1, n // 2), n) for _ in range(B - 1)]
         outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
         synth.region_loss(outs, batch).backward()
         sync()

@@ -8,6 +8,8 @@
 //   gate  : u_k = tanh(W_beta ctx_k + W_beta' h + b), e_beta_k = v_beta_k . u_k + b ;  beta = softmax_2
 //   c3    = beta_1 ctx_a + beta_2 ctx_i ;  att_cov = beta_1 alpha_a + beta_2 alpha_i ;  cov' = cov + att_cov
 //   LSTM cell on [c3 ; x], then dist = masked_softmax(W_out h' + b_out, mask)            (-1e30 blend, attention.py:78-98)
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mmb {
@@ -139,28 +141,38 @@ __device__ void dec_attention_t(const float* __restrict__ P, const float* __rest
                               int T, int H2, float* e, float* ctx, float* wred /* [NW][H2 + 2] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float m = -INFINITY, l = 0.f;
-    f4 cacc[NQ];
+    f4 cacc[NQ], hb[NQ], wcv[NQ], vv[NQ];
+    int dcl[NQ];
+    // per-lane loop invariants; lanes past the feature width read a clamped (valid) address and carry v = 0, so the
+    // row loop below has no lane-dependent branch and the loads of all its rows are issued back to back
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) cacc[q] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < NQ; ++q) {
+        const int d = lane * 4 + 256 * q;
+        dcl[q] = min(d, H2 - 4);
+        cacc[q] = f4{0.f, 0.f, 0.f, 0.f};
+        hb[q] = ld4(hm + dcl[q]) + ld4(bc + dcl[q]);
+        wcv[q] = ld4(wc + dcl[q]);
+        vv[q] = d < H2 ? ld4(v + dcl[q]) : f4{0.f, 0.f, 0.f, 0.f};
+    }
     constexpr int RB = 8;   // memory rows per wave iteration: their loads and reductions overlap
     for (int t0 = wave * RB; t0 < T; t0 += DEC_NW * RB) {
-        float part[RB];
-        f4 ev[RB][NQ];
+        f4 pv[RB][NQ], ev[RB][NQ];
+        float ct[RB], part[RB];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int t = min(t0 + i, T - 1);
-            const float ct = cov[t];
-            part[i] = 0.f;
+            ct[i] = cov[t];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const int d = lane * 4 + 256 * q;
-                ev[i][q] = f4{0.f, 0.f, 0.f, 0.f};
-                if (d < H2) {
-                    const f4 z = ld4(P + (size_t)t * H2 + d) + ld4(hm + d) + ld4(wc + d) * ct + ld4(bc + d);
-                    part[i] += dot4(ld4(v + d), tanh4(z));
-                    ev[i][q] = ld4(Em + (size_t)t * H2 + d);
-                }
+                pv[i][q] = ld4(P + (size_t)t * H2 + dcl[q]);
+                ev[i][q] = ld4(Em + (size_t)t * H2 + dcl[q]);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            part[i] = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) part[i] += dot4(vv[q], tanh4(pv[i][q] + hb[q] + wcv[q] * ct[i]));
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
@@ -169,7 +181,7 @@ __device__ void dec_attention_t(const float* __restrict__ P, const float* __rest
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            if (t0 + i < T) {
+            if (t0 + i < T) {   // wave-uniform
                 const float et = part[i] + bv;
                 if (lane == 0) e[t0 + i] = et;
                 const float mn = fmaxf(m, et), sc = __expf(m - mn), pe = __expf(et - mn);
@@ -222,6 +234,7 @@ struct DecFwdArgs {
     const uint8_t* mask;
     float *dist, *h_out, *c_out, *att_cov, *cov_out, *saved;
     int B, T, saved_stride;
+    int dbg;   // timing-only (MMB_DEC_DBG): 1 = no attention passes, 2 = no weight products
 };
 
 // LDS carve-up shared by both kernels
@@ -255,14 +268,14 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_fwd_kernel(const DecFwdAr
     __syncthreads();
     // every product with the previous hidden state
     // [ha | hi | hb1 | hb2 | hh] (contiguous in LDS) = [W2; W4; W_beta_2; W_beta_4; W_hh] . h + biases, one loop over h
-    dec_matvec_c(w.WhT, 12 * H, s.hv, 12 * H, H, s.ha, w.bh, nullptr);
+    if (!(a.dbg & 2)) dec_matvec_c(w.WhT, 12 * H, s.hv, 12 * H, H, s.ha, w.bh, nullptr);
     __syncthreads();
-    dec_attention(a.proj_a + (size_t)b * T * H2, a.enc_a + (size_t)b * T * H2, s.ha, s.cov, w.wc1, w.bc1, w.v1, w.bv1[0], T, H2,
+    if (!(a.dbg & 1)) dec_attention(a.proj_a + (size_t)b * T * H2, a.enc_a + (size_t)b * T * H2, s.ha, s.cov, w.wc1, w.bc1, w.v1, w.bv1[0], T, H2,
                   s.ea, s.ctxa, s.wred);
-    dec_attention(a.proj_i + (size_t)b * T * H2, a.enc_i + (size_t)b * T * H2, s.hi, s.cov, w.wc2, w.bc2, w.v2, w.bv2[0], T, H2,
+    if (!(a.dbg & 1)) dec_attention(a.proj_i + (size_t)b * T * H2, a.enc_i + (size_t)b * T * H2, s.hi, s.cov, w.wc2, w.bc2, w.v2, w.bv2[0], T, H2,
                   s.ei, s.ctxi, s.wred);
     // gate between the two contexts
-    dec_matvec_c2(w.Wb1T, s.ctxa, s.u1, w.bb1, s.hb1, w.Wb3T, s.ctxi, s.u2, w.bb3, s.hb2, H2, H2);
+    if (!(a.dbg & 2)) dec_matvec_c2(w.Wb1T, s.ctxa, s.u1, w.bb1, s.hb1, w.Wb3T, s.ctxi, s.u2, w.bb3, s.hb2, H2, H2);
     __syncthreads();
     float p1 = 0.f, p2 = 0.f;
     for (int d = tid; d < H2; d += DEC_NT) {
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_fwd_kernel(const DecFwdAr
     __syncthreads();
     // LSTM cell on [c3 ; x]
     // gates = W_ih[:, :2H] . c3 + (W_ih[:, 2H:] . x + b_ih, hoisted by the caller: xproj) + (W_hh h + b_hh)
-    dec_matvec_c(w.W_ihcT, 4 * H, s.inp, 4 * H, H2, s.gates, a.xproj + (size_t)b * 4 * H, s.hh);
+    if (!(a.dbg & 2)) dec_matvec_c(w.W_ihcT, 4 * H, s.inp, 4 * H, H2, s.gates, a.xproj + (size_t)b * 4 * H, s.hh);
     __syncthreads();
     for (int u = tid; u < H; u += DEC_NT) {
         const float gi = sigm(s.gates[u]), gf = sigm(s.gates[H + u]), gg = tanhf(s.gates[2 * H + u]), go = sigm(s.gates[3 * H + u]);
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_fwd_kernel(const DecFwdAr
     }
     __syncthreads();
     // output distribution over the (padded) transcript positions
-    dec_matvec_c(w.W_outT, L, s.hnew, L, H, s.logits, w.b_out, nullptr);
+    if (!(a.dbg & 2)) dec_matvec_c(w.W_outT, L, s.hnew, L, H, s.logits, w.b_out, nullptr);
     __syncthreads();
     const uint8_t* mk = a.mask + (size_t)b * L;
     float mx = -INFINITY;
@@ -346,30 +359,46 @@ __device__ void dec_attention_bwd_t(const float* __restrict__ P, const float* __
                                   int T, int H2, float* dP, float* dE, float* dcov, float* dhm, float* acc_wc, float* acc_v,
                                   float* acc_bv, float* wred /* [NW][3][H2] */, float* scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f4 a_h[NQ], a_wc[NQ], a_v[NQ];
+    f4 a_h[NQ], a_wc[NQ], a_v[NQ], hb[NQ], wcv[NQ], vv[NQ], dcx[NQ];
+    int dcl[NQ];
+    bool live[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) a_h[q] = a_wc[q] = a_v[q] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < NQ; ++q) {
+        const int d = lane * 4 + 256 * q;
+        live[q] = d < H2;
+        dcl[q] = min(d, H2 - 4);
+        a_h[q] = a_wc[q] = a_v[q] = f4{0.f, 0.f, 0.f, 0.f};
+        hb[q] = ld4(hm + dcl[q]) + ld4(bc + dcl[q]);
+        wcv[q] = ld4(wc + dcl[q]);
+        vv[q] = live[q] ? ld4(v + dcl[q]) : f4{0.f, 0.f, 0.f, 0.f};     // dz = 0 in the surplus lanes
+        dcx[q] = live[q] ? ld4(dctx + dcl[q]) : f4{0.f, 0.f, 0.f, 0.f};
+    }
     float a_bv = 0.f;
-    constexpr int RB = 4;   // memory rows per wave iteration: all loads (incl. the old gradients) issued up front
+    constexpr int RB = 4;   // memory rows per wave iteration: all loads (incl. the old gradients) issued up front, branch-free
     for (int t0 = wave * RB; t0 < T; t0 += DEC_NW * RB) {
-        float part[RB];
+        float part[RB], ct[RB];
         f4 tz[RB][NQ], gp[RB][NQ], ge[RB][NQ];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int t = min(t0 + i, T - 1);
-            const float ct = cov[t];
+            ct[i] = cov[t];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                tz[i][q] = ld4(P + (size_t)t * H2 + dcl[q]);          // P now, tanh(z) below
+                ge[i][q] = ld4(Em + (size_t)t * H2 + dcl[q]);         // E now, old dE below
+                gp[i][q] = ld4(dP + (size_t)t * H2 + dcl[q]);
+            }
+        }
+        f4 oe[RB][NQ];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int t = min(t0 + i, T - 1);
             part[i] = 0.f;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const int d = lane * 4 + 256 * q;
-                tz[i][q] = gp[i][q] = ge[i][q] = f4{0.f, 0.f, 0.f, 0.f};
-                if (d < H2) {
-                    const f4 z = ld4(P + (size_t)t * H2 + d) + ld4(hm + d) + ld4(wc + d) * ct + ld4(bc + d);
-                    tz[i][q] = tanh4(z);
-                    part[i] += dot4(ld4(dctx + d), ld4(Em + (size_t)t * H2 + d));
-                    gp[i][q] = ld4(dP + (size_t)t * H2 + d);
-                    ge[i][q] = ld4(dE + (size_t)t * H2 + d);
-                }
+                oe[i][q] = ld4(dE + (size_t)t * H2 + dcl[q]);
+                part[i] += dot4(dcx[q], ge[i][q]);
+                tz[i][q] = tanh4(tz[i][q] + hb[q] + wcv[q] * ct[i]);
             }
         }
 #pragma unroll
@@ -381,23 +410,22 @@ __device__ void dec_attention_bwd_t(const float* __restrict__ P, const float* __
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             pc[i] = 0.f;
-            if (t0 + i < T) {
+            if (t0 + i < T) {   // wave-uniform
                 const int t = t0 + i;
-                const float ct = cov[t], al = alpha[t];
+                const float al = alpha[t];
                 const float de = al * (beta * dact[t] + part[i] - Ssum);
                 a_bv += de;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int d = lane * 4 + 256 * q;
-                    if (d < H2) {
-                        const f4 dz = ld4(v + d) * (f4{1.f, 1.f, 1.f, 1.f} - tz[i][q] * tz[i][q]) * de;
-                        *reinterpret_cast<f4*>(dP + (size_t)t * H2 + d) = gp[i][q] + dz;
-                        *reinterpret_cast<f4*>(dE + (size_t)t * H2 + d) = ge[i][q] + ld4(dctx + d) * al;
-                        a_h[q] += dz;
-                        a_wc[q] += dz * ct;
-                        a_v[q] += tz[i][q] * de;
-                        pc[i] += dot4(dz, ld4(wc + d));
+                    const f4 dz = vv[q] * (f4{1.f, 1.f, 1.f, 1.f} - tz[i][q] * tz[i][q]) * de;
+                    if (live[q]) {
+                        *reinterpret_cast<f4*>(dP + (size_t)t * H2 + dcl[q]) = gp[i][q] + dz;
+                        *reinterpret_cast<f4*>(dE + (size_t)t * H2 + dcl[q]) = oe[i][q] + dcx[q] * al;
                     }
+                    a_h[q] += dz;
+                    a_wc[q] += dz * ct[i];
+                    a_v[q] += live[q] ? tz[i][q] * de : f4{0.f, 0.f, 0.f, 0.f};
+                    pc[i] += dot4(dz, wcv[q]);
                 }
             }
         }
@@ -587,6 +615,7 @@ extern "C" int mmb_decoder_step_fwd(const mmb_decoder_params* w, const float* en
     a.w = *w; a.enc_a = enc_a; a.enc_i = enc_i; a.proj_a = proj_a; a.proj_i = proj_i; a.h = h; a.c = c; a.cov = cov; a.xproj = xproj;
     a.mask = mask; a.dist = dist; a.h_out = h_out; a.c_out = c_out; a.att_cov = att_cov; a.cov_out = cov_out; a.saved = saved;
     a.B = B; a.T = T; a.saved_stride = (int)mmb_decoder_saved_floats(T, w->H);
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MMB_DEC_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     const size_t lds = dec_lds_floats(T, w->H, w->E, w->L) * sizeof(float);
     MMB_REQUIRE(lds <= 160 * 1024, "mmb_decoder_step_fwd: T=%d L=%d too large for one workgroup's LDS", T, w->L);
     static bool attr = false;
