@@ -187,15 +187,18 @@ typedef struct {
 
 size_t mmb_decoder_saved_floats(int T, int H);      /* per-sample floats of `saved` (alphas, contexts, gate activations, ...) */
 size_t mmb_decoder_vec_acc_floats(int H);           /* per-sample floats of `vec_acc` */
+size_t mmb_decoder_scratch_floats(int B, int T, int H);   /* floats of the `scratch` both step calls need (contents undefined) */
 
 /* inputs: enc_*, proj_* (B,T,H2); h, c (B,H); cov (B,T); xproj (B,4H) = W_ih[:, H2:] . x + b_ih of this step's decoder
  * input x (hoisted: one GEMM over all teacher-forced steps); mask (B,L) u8
  * outputs: dist (B,L) = masked softmax; h_out, c_out (B,H); att_cov (B,T); cov_out (B,T) = cov + att_cov;
- * saved (B, mmb_decoder_saved_floats) for the backward, or NULL (inference). */
+ * saved (B, mmb_decoder_saved_floats) for the backward, or NULL (inference).  Two launches: the attention rows are
+ * streamed by (sample, modality, T-chunk) workgroups, a per-sample workgroup combines their softmax partials and does
+ * the rest of the step. */
 int mmb_decoder_step_fwd(const mmb_decoder_params* w, const float* enc_a, const float* enc_i, const float* proj_a,
                          const float* proj_i, const float* h, const float* c, const float* cov, const float* xproj,
                          const uint8_t* mask, float* dist, float* h_out, float* c_out, float* att_cov, float* cov_out,
-                         float* saved, int B, int T, int device, void* stream);
+                         float* saved, float* scratch, int B, int T, int device, void* stream);
 
 /* Backward of one step.  Upstream gradients d_dist (B,L), d_h_out, d_c_out (B,H), d_att_cov, d_cov_out (B,T) may be NULL
  * (= zero).  Overwrites d_h, d_c (B,H), d_cov (B,T) and the pre-activation gradients delta_* (the caller turns those into
@@ -207,8 +210,8 @@ int mmb_decoder_step_bwd(const mmb_decoder_params* w, const float* enc_a, const 
                          const float* d_dist, const float* d_h_out, const float* d_c_out, const float* d_att_cov,
                          const float* d_cov_out, float* d_h, float* d_c, float* d_cov, float* d_proj_a,
                          float* d_enc_a, float* d_proj_i, float* d_enc_i, float* delta_out, float* delta_g,
-                         float* delta_b1, float* delta_b2, float* delta_ha, float* delta_hi, float* vec_acc, int B,
-                         int T, int device, void* stream);
+                         float* delta_b1, float* delta_b2, float* delta_ha, float* delta_hi, float* vec_acc,
+                         float* scratch, int B, int T, int device, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Highway layer glue (reference layers/encoding.py:32-59 inside Embedding, :9-30).  The caller runs

@@ -73,8 +73,9 @@ SIGNATURES = {
     "mmb_highway_gate_bwd": (c_i, [c_f] * 4 + [ctypes.c_long, c_i, c_i, c_f]),
     "mmb_decoder_saved_floats": (ctypes.c_size_t, [c_i] * 2),
     "mmb_decoder_vec_acc_floats": (ctypes.c_size_t, [c_i]),
-    "mmb_decoder_step_fwd": (c_i, [ctypes.POINTER(DecoderParams)] + [c_f] * 15 + [c_i] * 3 + [c_f]),
-    "mmb_decoder_step_bwd": (c_i, [ctypes.POINTER(DecoderParams)] + [c_f] * 30 + [c_i] * 3 + [c_f]),
+    "mmb_decoder_scratch_floats": (ctypes.c_size_t, [c_i] * 3),
+    "mmb_decoder_step_fwd": (c_i, [ctypes.POINTER(DecoderParams)] + [c_f] * 16 + [c_i] * 3 + [c_f]),
+    "mmb_decoder_step_bwd": (c_i, [ctypes.POINTER(DecoderParams)] + [c_f] * 31 + [c_i] * 3 + [c_f]),
 }
 
 # kernel ids of the opt-in timing hook (enum in include/mmbidaf.h)

@@ -138,7 +138,7 @@ struct DecShapes { int B, T, H, H2, E, L; };
 template <int NQ>
 __device__ void dec_attention_t(const float* __restrict__ P, const float* __restrict__ Em, const float* hm, const float* cov,
                               const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ v, float bv,
-                              int T, int H2, float* e, float* ctx, float* wred /* [NW][H2 + 2] */) {
+                              int H2, int t_lo, int t_hi, float* e_raw, float* part_out, float* wred /* [NW][H2 + 2] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float m = -INFINITY, l = 0.f;
     f4 cacc[NQ], hb[NQ], wcv[NQ], vv[NQ];
@@ -155,12 +155,12 @@ __device__ void dec_attention_t(const float* __restrict__ P, const float* __rest
         vv[q] = d < H2 ? ld4(v + dcl[q]) : f4{0.f, 0.f, 0.f, 0.f};
     }
     constexpr int RB = 8;   // memory rows per wave iteration: their loads and reductions overlap
-    for (int t0 = wave * RB; t0 < T; t0 += DEC_NW * RB) {
+    for (int t0 = t_lo + wave * RB; t0 < t_hi; t0 += DEC_NW * RB) {
         f4 pv[RB][NQ], ev[RB][NQ];
         float ct[RB], part[RB];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int t = min(t0 + i, T - 1);
+            const int t = min(t0 + i, t_hi - 1);
             ct[i] = cov[t];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -181,9 +181,9 @@ __device__ void dec_attention_t(const float* __restrict__ P, const float* __rest
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            if (t0 + i < T) {   // wave-uniform
+            if (t0 + i < t_hi) {   // wave-uniform
                 const float et = part[i] + bv;
-                if (lane == 0) e[t0 + i] = et;
+                if (lane == 0) e_raw[t0 + i] = et;
                 const float mn = fmaxf(m, et), sc = __expf(m - mn), pe = __expf(et - mn);
                 l = l * sc + pe;
 #pragma unroll
@@ -192,6 +192,7 @@ __device__ void dec_attention_t(const float* __restrict__ P, const float* __rest
             }
         }
     }
+    // this workgroup's partial: running maximum, sum and un-normalised context of its rows (combined by the rest kernel)
     float* wr = wred + wave * (H2 + 2);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -206,26 +207,44 @@ __device__ void dec_attention_t(const float* __restrict__ P, const float* __rest
     float Ls = 0.f, sw[DEC_NW];
 #pragma unroll
     for (int w = 0; w < DEC_NW; ++w) {
-        sw[w] = expf(wred[w * (H2 + 2) + H2] - M);
+        const float mw = wred[w * (H2 + 2) + H2];
+        sw[w] = mw == -INFINITY ? 0.f : __expf(mw - M);
         Ls += wred[w * (H2 + 2) + H2 + 1] * sw[w];
+    }
+    for (int d = threadIdx.x; d < H2; d += DEC_NT) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < DEC_NW; ++w) acc += wred[w * (H2 + 2) + d] * sw[w];
+        part_out[d] = acc;
+    }
+    if (threadIdx.x == 0) { part_out[H2] = M; part_out[H2 + 1] = Ls; }
+}
+__device__ void dec_attention(const float* __restrict__ P, const float* __restrict__ Em, const float* hm, const float* cov,
+                              const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ v, float bv,
+                              int H2, int t_lo, int t_hi, float* e_raw, float* part_out, float* wred) {
+    if (H2 <= 256) dec_attention_t<1>(P, Em, hm, cov, wc, bc, v, bv, H2, t_lo, t_hi, e_raw, part_out, wred);
+    else if (H2 <= 512) dec_attention_t<2>(P, Em, hm, cov, wc, bc, v, bv, H2, t_lo, t_hi, e_raw, part_out, wred);
+    else dec_attention_t<4>(P, Em, hm, cov, wc, bc, v, bv, H2, t_lo, t_hi, e_raw, part_out, wred);
+}
+// combine the per-chunk partials of one (sample, modality): alpha[0..T) (LDS) from the raw scores, context (LDS)
+__device__ void dec_combine(const float* part, int nch, const float* e_raw, int T, int H2, float* alpha, float* ctx) {
+    float M = -INFINITY;
+    for (int c = 0; c < nch; ++c) M = fmaxf(M, part[(size_t)c * (H2 + 2) + H2]);
+    float Ls = 0.f;
+    for (int c = 0; c < nch; ++c) {
+        const float mc = part[(size_t)c * (H2 + 2) + H2];
+        Ls += mc == -INFINITY ? 0.f : part[(size_t)c * (H2 + 2) + H2 + 1] * __expf(mc - M);
     }
     const float inv = 1.0f / Ls;
     for (int d = threadIdx.x; d < H2; d += DEC_NT) {
-        float a = 0.f;
-#pragma unroll
-        for (int w = 0; w < DEC_NW; ++w) a += wred[w * (H2 + 2) + d] * sw[w];
-        ctx[d] = a * inv;
+        float acc = 0.f;
+        for (int c = 0; c < nch; ++c) {
+            const float mc = part[(size_t)c * (H2 + 2) + H2];
+            acc += mc == -INFINITY ? 0.f : part[(size_t)c * (H2 + 2) + d] * __expf(mc - M);
+        }
+        ctx[d] = acc * inv;
     }
-    for (int t = threadIdx.x; t < T; t += DEC_NT) e[t] = expf(e[t] - M) * inv;
-    __syncthreads();
-}
-
-__device__ void dec_attention(const float* __restrict__ P, const float* __restrict__ Em, const float* hm, const float* cov,
-                              const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ v, float bv,
-                              int T, int H2, float* e, float* ctx, float* wred) {
-    if (H2 <= 256) dec_attention_t<1>(P, Em, hm, cov, wc, bc, v, bv, T, H2, e, ctx, wred);
-    else if (H2 <= 512) dec_attention_t<2>(P, Em, hm, cov, wc, bc, v, bv, T, H2, e, ctx, wred);
-    else dec_attention_t<4>(P, Em, hm, cov, wc, bc, v, bv, T, H2, e, ctx, wred);
+    for (int t = threadIdx.x; t < T; t += DEC_NT) alpha[t] = __expf(e_raw[t] - M) * inv;
 }
 
 struct DecFwdArgs {
@@ -233,7 +252,8 @@ struct DecFwdArgs {
     const float *enc_a, *enc_i, *proj_a, *proj_i, *h, *c, *cov, *xproj;
     const uint8_t* mask;
     float *dist, *h_out, *c_out, *att_cov, *cov_out, *saved;
-    int B, T, saved_stride;
+    float *e_raw, *part;   // scratch: raw scores (B,2,T), per-chunk softmax partials (B,2,nch,2H+2)
+    int B, T, saved_stride, nch, chunk;
     int dbg;   // timing-only (MMB_DEC_DBG): 1 = no attention passes, 2 = no weight products
 };
 
@@ -258,6 +278,28 @@ static size_t dec_lds_floats(int T, int H, int E, int L) {
     return 2 * r4(H) + 3 * r4(T) + 4 * r4(H2) + r4(4 * H) + 4 * r4(H2) + r4(H2) + r4(4 * H) + r4(H) + r4(L) + r4(DEC_NW * (H2 + 2)) + 16;
 }
 
+// forward, part 1: workgroup (sample, modality, T chunk) streams its rows of the projection / memory once
+__global__ __launch_bounds__(DEC_NT) void decoder_att_fwd_kernel(const DecFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const mmb_decoder_params& w = a.w;
+    const int b = blockIdx.x, m = blockIdx.y / a.nch, c = blockIdx.y % a.nch;
+    const int T = a.T, H = w.H, H2 = 2 * H, tid = threadIdx.x;
+    float* hv = sm;
+    float* hm = hv + ((H + 3) & ~3);
+    float* wred = hm + ((H2 + 3) & ~3);
+    for (int i = tid; i < H; i += DEC_NT) hv[i] = a.h[(size_t)b * H + i];
+    __syncthreads();
+    dec_matvec_c(w.WhT + m * H2, 12 * H, hv, H2, H, hm, w.bh + m * H2, nullptr);   // W2 h + b2  /  W4 h + b4
+    __syncthreads();
+    const int t_lo = c * a.chunk, t_hi = min(T, t_lo + a.chunk);
+    const size_t mo = (size_t)b * T * H2;
+    if (a.dbg & 1) return;
+    dec_attention((m ? a.proj_i : a.proj_a) + mo, (m ? a.enc_i : a.enc_a) + mo, hm, a.cov + (size_t)b * T, m ? w.wc2 : w.wc1,
+                  m ? w.bc2 : w.bc1, m ? w.v2 : w.v1, (m ? w.bv2 : w.bv1)[0], H2, t_lo, t_hi, a.e_raw + ((size_t)b * 2 + m) * T,
+                  a.part + (((size_t)b * 2 + m) * a.nch + c) * (H2 + 2), wred);
+}
+
+// forward, part 2: one workgroup per sample combines the partials and does the rest of the step
 __global__ __launch_bounds__(DEC_NT) void decoder_step_fwd_kernel(const DecFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const mmb_decoder_params& w = a.w;
@@ -266,14 +308,11 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_fwd_kernel(const DecFwdAr
     for (int i = tid; i < H; i += DEC_NT) { s.hv[i] = a.h[(size_t)b * H + i]; s.cv[i] = a.c[(size_t)b * H + i]; }
     for (int i = tid; i < T; i += DEC_NT) s.cov[i] = a.cov[(size_t)b * T + i];
     __syncthreads();
-    // every product with the previous hidden state
-    // [ha | hi | hb1 | hb2 | hh] (contiguous in LDS) = [W2; W4; W_beta_2; W_beta_4; W_hh] . h + biases, one loop over h
-    if (!(a.dbg & 2)) dec_matvec_c(w.WhT, 12 * H, s.hv, 12 * H, H, s.ha, w.bh, nullptr);
+    // [hb1 | hb2 | hh] (contiguous in LDS) = [W_beta_2; W_beta_4; W_hh] . h + biases, one loop over h
+    if (!(a.dbg & 2)) dec_matvec_c(w.WhT + 2 * H2, 12 * H, s.hv, 2 * H2 + 4 * H, H, s.hb1, w.bh + 2 * H2, nullptr);
+    dec_combine(a.part + ((size_t)b * 2 + 0) * a.nch * (H2 + 2), a.nch, a.e_raw + ((size_t)b * 2 + 0) * T, T, H2, s.ea, s.ctxa);
+    dec_combine(a.part + ((size_t)b * 2 + 1) * a.nch * (H2 + 2), a.nch, a.e_raw + ((size_t)b * 2 + 1) * T, T, H2, s.ei, s.ctxi);
     __syncthreads();
-    if (!(a.dbg & 1)) dec_attention(a.proj_a + (size_t)b * T * H2, a.enc_a + (size_t)b * T * H2, s.ha, s.cov, w.wc1, w.bc1, w.v1, w.bv1[0], T, H2,
-                  s.ea, s.ctxa, s.wred);
-    if (!(a.dbg & 1)) dec_attention(a.proj_i + (size_t)b * T * H2, a.enc_i + (size_t)b * T * H2, s.hi, s.cov, w.wc2, w.bc2, w.v2, w.bv2[0], T, H2,
-                  s.ei, s.ctxi, s.wred);
     // gate between the two contexts
     if (!(a.dbg & 2)) dec_matvec_c2(w.Wb1T, s.ctxa, s.u1, w.bb1, s.hb1, w.Wb3T, s.ctxi, s.u2, w.bb3, s.hb2, H2, H2);
     __syncthreads();
@@ -347,7 +386,8 @@ struct DecBwdArgs {
     float *d_proj_a, *d_enc_a, *d_proj_i, *d_enc_i;                     // (B,T,2H) accumulated (+=)
     float *delta_out, *delta_g, *delta_b1, *delta_b2, *delta_ha, *delta_hi;   // (B,L) (B,4H) (B,2H) x4, overwritten
     float* vec_acc;                                                     // (B, 6*2H + 4) accumulated (+=)
-    int B, T, saved_stride;
+    float *bs, *bpart, *dcovm;   // scratch: per-sample hand-over (B, 4H+T+4), per-chunk partials (B,2,nch,6H+4), (B,2,T)
+    int B, T, saved_stride, nch, chunk;
 };
 
 // backward of dec_attention for one modality.  dact[t] = d_att_cov[t] + d_cov_out[t]; the upstream gradient of alpha_t is
@@ -356,8 +396,8 @@ template <int NQ>
 __device__ void dec_attention_bwd_t(const float* __restrict__ P, const float* __restrict__ Em, const float* hm, const float* cov,
                                   const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ v,
                                   const float* alpha, const float* dact, float beta, const float* dctx, float Ssum,
-                                  int T, int H2, float* dP, float* dE, float* dcov, float* dhm, float* acc_wc, float* acc_v,
-                                  float* acc_bv, float* wred /* [NW][3][H2] */, float* scratch) {
+                                  int H2, int t_lo, int t_hi, float* dP, float* dE, float* dcov_out, float* bpart_out,
+                                  float* wred /* [NW][3][H2] */, float* scratch) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f4 a_h[NQ], a_wc[NQ], a_v[NQ], hb[NQ], wcv[NQ], vv[NQ], dcx[NQ];
     int dcl[NQ];
@@ -375,12 +415,12 @@ __device__ void dec_attention_bwd_t(const float* __restrict__ P, const float* __
     }
     float a_bv = 0.f;
     constexpr int RB = 4;   // memory rows per wave iteration: all loads (incl. the old gradients) issued up front, branch-free
-    for (int t0 = wave * RB; t0 < T; t0 += DEC_NW * RB) {
+    for (int t0 = t_lo + wave * RB; t0 < t_hi; t0 += DEC_NW * RB) {
         float part[RB], ct[RB];
         f4 tz[RB][NQ], gp[RB][NQ], ge[RB][NQ];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int t = min(t0 + i, T - 1);
+            const int t = min(t0 + i, t_hi - 1);
             ct[i] = cov[t];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -392,7 +432,7 @@ __device__ void dec_attention_bwd_t(const float* __restrict__ P, const float* __
         f4 oe[RB][NQ];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int t = min(t0 + i, T - 1);
+            const int t = min(t0 + i, t_hi - 1);
             part[i] = 0.f;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -410,7 +450,7 @@ __device__ void dec_attention_bwd_t(const float* __restrict__ P, const float* __
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             pc[i] = 0.f;
-            if (t0 + i < T) {   // wave-uniform
+            if (t0 + i < t_hi) {   // wave-uniform
                 const int t = t0 + i;
                 const float al = alpha[t];
                 const float de = al * (beta * dact[t] + part[i] - Ssum);
@@ -436,7 +476,7 @@ __device__ void dec_attention_bwd_t(const float* __restrict__ P, const float* __
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-            if (lane == 0 && t0 + i < T) dcov[t0 + i] += pc[i];
+            if (lane == 0 && t0 + i < t_hi) dcov_out[t0 + i] = pc[i];   // every row belongs to exactly one chunk
     }
     __syncthreads();
 #pragma unroll
@@ -449,29 +489,28 @@ __device__ void dec_attention_bwd_t(const float* __restrict__ P, const float* __
         }
     }
     __syncthreads();
+    // this workgroup's partial sums: [delta_h | d_wc | d_v | d_bv]
     for (int d = threadIdx.x; d < H2; d += DEC_NT) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int w = 0; w < DEC_NW; ++w) {
             s0 += wred[(w * 3 + 0) * H2 + d]; s1 += wred[(w * 3 + 1) * H2 + d]; s2 += wred[(w * 3 + 2) * H2 + d];
         }
-        dhm[d] = s0;
-        acc_wc[d] += s1;
-        acc_v[d] += s2;
+        bpart_out[d] = s0;
+        bpart_out[H2 + d] = s1;
+        bpart_out[2 * H2 + d] = s2;
     }
     const float tot = dec_block_sum((lane == 0) ? a_bv : 0.f, scratch);
-    if (threadIdx.x == 0) acc_bv[0] += tot;
-    __syncthreads();
+    if (threadIdx.x == 0) bpart_out[3 * H2] = tot;
 }
-
 __device__ void dec_attention_bwd(const float* __restrict__ P, const float* __restrict__ Em, const float* hm, const float* cov,
                                   const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ v,
                                   const float* alpha, const float* dact, float beta, const float* dctx, float Ssum,
-                                  int T, int H2, float* dP, float* dE, float* dcov, float* dhm, float* acc_wc, float* acc_v,
-                                  float* acc_bv, float* wred, float* scratch) {
-    if (H2 <= 256) dec_attention_bwd_t<1>(P, Em, hm, cov, wc, bc, v, alpha, dact, beta, dctx, Ssum, T, H2, dP, dE, dcov, dhm, acc_wc, acc_v, acc_bv, wred, scratch);
-    else if (H2 <= 512) dec_attention_bwd_t<2>(P, Em, hm, cov, wc, bc, v, alpha, dact, beta, dctx, Ssum, T, H2, dP, dE, dcov, dhm, acc_wc, acc_v, acc_bv, wred, scratch);
-    else dec_attention_bwd_t<4>(P, Em, hm, cov, wc, bc, v, alpha, dact, beta, dctx, Ssum, T, H2, dP, dE, dcov, dhm, acc_wc, acc_v, acc_bv, wred, scratch);
+                                  int H2, int t_lo, int t_hi, float* dP, float* dE, float* dcov_out, float* bpart_out,
+                                  float* wred, float* scratch) {
+    if (H2 <= 256) dec_attention_bwd_t<1>(P, Em, hm, cov, wc, bc, v, alpha, dact, beta, dctx, Ssum, H2, t_lo, t_hi, dP, dE, dcov_out, bpart_out, wred, scratch);
+    else if (H2 <= 512) dec_attention_bwd_t<2>(P, Em, hm, cov, wc, bc, v, alpha, dact, beta, dctx, Ssum, H2, t_lo, t_hi, dP, dE, dcov_out, bpart_out, wred, scratch);
+    else dec_attention_bwd_t<4>(P, Em, hm, cov, wc, bc, v, alpha, dact, beta, dctx, Ssum, H2, t_lo, t_hi, dP, dE, dcov_out, bpart_out, wred, scratch);
 }
 
 __global__ __launch_bounds__(DEC_NT) void decoder_step_bwd_kernel(const DecBwdArgs a) {
@@ -504,7 +543,6 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_bwd_kernel(const DecBwdAr
     for (int i = tid; i < 4 * H; i += DEC_NT) gates[i] = sv[2 * T + 4 * H2 + i];
     const float beta1 = sv[2 * T + 4 * H2 + 4 * H], beta2 = sv[2 * T + 4 * H2 + 4 * H + 1];
     __syncthreads();
-    dec_matvec_c(w.WhT, 12 * H, hv, 2 * H2, H, ha, w.bh, nullptr);   // recomputed hidden-state terms [ha | hi] of the two attentions
     // ---- output layer: dlogit = mask * dist * (d_dist - sum(dist * d_dist))
     const uint8_t* mk = a.mask + (size_t)b * L;
     float sd = 0.f;
@@ -568,13 +606,74 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_bwd_kernel(const DecBwdAr
     for (int d = tid; d < H2; d += DEC_NT) { c1 += dctxa[d] * ctxa[d]; c2 += dctxi[d] * ctxi[d]; }
     c1 = dec_block_sum(c1, scratch); c2 = dec_block_sum(c2, scratch);
     const float S1 = beta1 * r1 + c1, S2 = beta2 * r2 + c2;   // sum_t alpha_t * (upstream gradient of alpha_t)
+    // hand-over to the attention kernel (per sample): [dctx_a | dctx_i | dact | S1 S2 beta1 beta2]; d_cov starts as the
+    // pass-through gradient, d_h as everything but the two attention terms (decoder_fin_bwd_kernel adds those)
+    float* bs = a.bs + (size_t)b * (2 * H2 + T + 4);
+    for (int d = tid; d < H2; d += DEC_NT) { bs[d] = dctxa[d]; bs[H2 + d] = dctxi[d]; }
+    for (int t = tid; t < T; t += DEC_NT) { bs[2 * H2 + t] = dact[t]; a.d_cov[(size_t)b * T + t] = dcov[t]; }
+    if (tid == 0) { bs[2 * H2 + T] = S1; bs[2 * H2 + T + 1] = S2; bs[2 * H2 + T + 2] = beta1; bs[2 * H2 + T + 3] = beta2; }
+    for (int i = tid; i < H; i += DEC_NT) a.d_h[(size_t)b * H + i] = dh[i];
+}
+
+// backward, part 2: workgroup (sample, modality, T chunk): d_proj / d_enc rows, per-chunk partial sums, d_cov terms
+__global__ __launch_bounds__(DEC_NT) void decoder_att_bwd_kernel(const DecBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const mmb_decoder_params& w = a.w;
+    const int b = blockIdx.x, m = blockIdx.y / a.nch, c = blockIdx.y % a.nch;
+    const int T = a.T, H = w.H, H2 = 2 * H, tid = threadIdx.x;
+    float* hv = sm;
+    float* hm = hv + ((H + 3) & ~3);
+    float* dctx = hm + ((H2 + 3) & ~3);
+    float* wred = dctx + ((H2 + 3) & ~3);
+    float* scratch = wred + DEC_NW * 3 * H2;
+    const float* bs = a.bs + (size_t)b * (2 * H2 + T + 4);
+    for (int i = tid; i < H; i += DEC_NT) hv[i] = a.h[(size_t)b * H + i];
+    for (int d = tid; d < H2; d += DEC_NT) dctx[d] = bs[m * H2 + d];
+    __syncthreads();
+    dec_matvec_c(w.WhT + m * H2, 12 * H, hv, H2, H, hm, w.bh + m * H2, nullptr);
+    __syncthreads();
+    const int t_lo = c * a.chunk, t_hi = min(T, t_lo + a.chunk);
     const size_t mo = (size_t)b * T * H2;
-    dec_attention_bwd(a.proj_a + mo, a.enc_a + mo, ha, cov, w.wc1, w.bc1, w.v1, ala, dact, beta1, dctxa, S1, T, H2,
-                      a.d_proj_a + mo, a.d_enc_a + mo, dcov, dha, vacc, vacc + H2, vacc + 6 * H2, wred, scratch);
-    dec_attention_bwd(a.proj_i + mo, a.enc_i + mo, hi, cov, w.wc2, w.bc2, w.v2, ali, dact, beta2, dctxi, S2, T, H2,
-                      a.d_proj_i + mo, a.d_enc_i + mo, dcov, dhi, vacc + 2 * H2, vacc + 3 * H2, vacc + 6 * H2 + 1, wred, scratch);
-    for (int d = tid; d < H2; d += DEC_NT) { a.delta_ha[(size_t)b * H2 + d] = dha[d]; a.delta_hi[(size_t)b * H2 + d] = dhi[d]; }
-    for (int t = tid; t < T; t += DEC_NT) a.d_cov[(size_t)b * T + t] = dcov[t];
+    dec_attention_bwd((m ? a.proj_i : a.proj_a) + mo, (m ? a.enc_i : a.enc_a) + mo, hm, a.cov + (size_t)b * T, m ? w.wc2 : w.wc1,
+                      m ? w.bc2 : w.bc1, m ? w.v2 : w.v1, a.saved + (size_t)b * a.saved_stride + m * T, bs + 2 * H2,
+                      bs[2 * H2 + T + 2 + m], dctx, bs[2 * H2 + T + m], H2, t_lo, t_hi, (m ? a.d_proj_i : a.d_proj_a) + mo,
+                      (m ? a.d_enc_i : a.d_enc_a) + mo, a.dcovm + ((size_t)b * 2 + m) * T,
+                      a.bpart + (((size_t)b * 2 + m) * a.nch + c) * (3 * H2 + 4), wred, scratch);
+}
+
+// backward, part 3: per sample, fold the chunk partials: delta_ha / delta_hi, the small vector gradients, d_cov, d_h
+__global__ __launch_bounds__(DEC_NT) void decoder_fin_bwd_kernel(const DecBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const mmb_decoder_params& w = a.w;
+    const int b = blockIdx.x, T = a.T, H = w.H, H2 = 2 * H, tid = threadIdx.x;
+    float* dha = sm;
+    float* dhi = dha + ((H2 + 3) & ~3);
+    float* dh = dhi + ((H2 + 3) & ~3);
+    float* part = dh + ((H + 3) & ~3);
+    float* vacc = a.vec_acc + (size_t)b * (6 * H2 + 4);
+    const float* bp = a.bpart + (size_t)b * 2 * a.nch * (3 * H2 + 4);
+    for (int d = tid; d < H2; d += DEC_NT) {
+        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < a.nch; ++c) {
+            const float* pa = bp + (size_t)c * (3 * H2 + 4);
+            const float* pi = bp + (size_t)(a.nch + c) * (3 * H2 + 4);
+            s[0] += pa[d]; s[1] += pa[H2 + d]; s[2] += pa[2 * H2 + d];
+            s[3] += pi[d]; s[4] += pi[H2 + d]; s[5] += pi[2 * H2 + d];
+        }
+        dha[d] = s[0]; dhi[d] = s[3];
+        a.delta_ha[(size_t)b * H2 + d] = s[0];
+        a.delta_hi[(size_t)b * H2 + d] = s[3];
+        vacc[d] += s[1]; vacc[H2 + d] += s[2]; vacc[2 * H2 + d] += s[4]; vacc[3 * H2 + d] += s[5];
+    }
+    if (tid < 2) {
+        float t = 0.f;
+        for (int c = 0; c < a.nch; ++c) t += bp[(size_t)(tid * a.nch + c) * (3 * H2 + 4) + 3 * H2];
+        vacc[6 * H2 + tid] += t;
+    }
+    for (int t = tid; t < T; t += DEC_NT)
+        a.d_cov[(size_t)b * T + t] += a.dcovm[((size_t)b * 2) * T + t] + a.dcovm[((size_t)b * 2 + 1) * T + t];
+    for (int i = tid; i < H; i += DEC_NT) dh[i] = a.d_h[(size_t)b * H + i];
+    __syncthreads();
     dec_matvec_t(w.W2, H, dha, H2, H, dh, true, part);
     __syncthreads();
     dec_matvec_t(w.W4, H, dhi, H2, H, dh, true, part);
@@ -595,6 +694,23 @@ using namespace mmb;
 extern "C" size_t mmb_decoder_saved_floats(int T, int H) { return (size_t)2 * T + 8 * H + 4 * H + 4; }
 extern "C" size_t mmb_decoder_vec_acc_floats(int H) { return (size_t)12 * H + 4; }
 
+// T is cut into nch chunks per (sample, modality) so that the attention kernels have ~256 workgroups
+constexpr int DEC_MAX_CH = 8;
+static void dec_chunks(int B, int T, int* nch, int* chunk) {
+    int n = (256 + 2 * B - 1) / (2 * B);
+    if (n > DEC_MAX_CH) n = DEC_MAX_CH;
+    if (n > (T + 31) / 32) n = (T + 31) / 32;
+    if (n < 1) n = 1;
+    *nch = n;
+    *chunk = ((T + n - 1) / n + 7) / 8 * 8;
+}
+extern "C" size_t mmb_decoder_scratch_floats(int B, int T, int H) {
+    const size_t H2 = 2 * (size_t)H;
+    const size_t fwd = (size_t)B * 2 * T + (size_t)B * 2 * DEC_MAX_CH * (H2 + 2);
+    const size_t bwd = (size_t)B * (2 * H2 + T + 4) + (size_t)B * 2 * DEC_MAX_CH * (3 * H2 + 4) + (size_t)B * 2 * T;
+    return fwd > bwd ? fwd : bwd;
+}
+
 static int dec_check(const mmb_decoder_params* w, int B, int T) {
     MMB_REQUIRE(w && B >= 1 && T >= 1, "decoder: bad sizes B=%d T=%d", B, T);
     MMB_REQUIRE(w->H >= 2 && w->H % 2 == 0 && w->H <= 512 && w->E >= 1 && w->L >= 1, "decoder: unsupported H=%d E=%d L=%d (H even, <= 512)",
@@ -605,10 +721,10 @@ static int dec_check(const mmb_decoder_params* w, int B, int T) {
 extern "C" int mmb_decoder_step_fwd(const mmb_decoder_params* w, const float* enc_a, const float* enc_i, const float* proj_a,
                                     const float* proj_i, const float* h, const float* c, const float* cov, const float* xproj,
                                     const uint8_t* mask, float* dist, float* h_out, float* c_out, float* att_cov, float* cov_out,
-                                    float* saved, int B, int T, int device, void* stream_) {
+                                    float* saved, float* scratch, int B, int T, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (int rc = dec_check(w, B, T)) return rc;
-    MMB_REQUIRE(enc_a && enc_i && proj_a && proj_i && h && c && cov && xproj && mask && dist && h_out && c_out && att_cov && cov_out,
+    MMB_REQUIRE(enc_a && enc_i && proj_a && proj_i && h && c && cov && xproj && mask && dist && h_out && c_out && att_cov && cov_out && scratch,
                 "mmb_decoder_step_fwd: null pointer");
     MMB_HIP(hipSetDevice(device));
     DecFwdArgs a{};
@@ -616,13 +732,20 @@ extern "C" int mmb_decoder_step_fwd(const mmb_decoder_params* w, const float* en
     a.mask = mask; a.dist = dist; a.h_out = h_out; a.c_out = c_out; a.att_cov = att_cov; a.cov_out = cov_out; a.saved = saved;
     a.B = B; a.T = T; a.saved_stride = (int)mmb_decoder_saved_floats(T, w->H);
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("MMB_DEC_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
-    const size_t lds = dec_lds_floats(T, w->H, w->E, w->L) * sizeof(float);
-    MMB_REQUIRE(lds <= 160 * 1024, "mmb_decoder_step_fwd: T=%d L=%d too large for one workgroup's LDS", T, w->L);
+    dec_chunks(B, T, &a.nch, &a.chunk);
+    a.e_raw = scratch;
+    a.part = scratch + (size_t)B * 2 * T;
+    const int H = w->H, H2 = 2 * H;
+    const size_t lds = dec_lds_floats(T, H, w->E, w->L) * sizeof(float);
+    const size_t lds_att = (size_t)(((H + 3) & ~3) + ((H2 + 3) & ~3) + DEC_NW * (H2 + 2) + 16) * sizeof(float);
+    MMB_REQUIRE(lds <= 160 * 1024 && lds_att <= 160 * 1024, "mmb_decoder_step_fwd: T=%d L=%d too large for one workgroup's LDS", T, w->L);
     static bool attr = false;
     if (!attr) {
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_step_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_att_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
+    hipLaunchKernelGGL(decoder_att_fwd_kernel, dim3(B, 2 * a.nch), dim3(DEC_NT), lds_att, stream, a);
     hipLaunchKernelGGL(decoder_step_fwd_kernel, dim3(B), dim3(DEC_NT), lds, stream, a);
     MMB_HIP(hipGetLastError());
     return MMB_OK;
@@ -634,13 +757,13 @@ extern "C" int mmb_decoder_step_bwd(const mmb_decoder_params* w, const float* en
                                     const float* d_dist, const float* d_h_out, const float* d_c_out, const float* d_att_cov,
                                     const float* d_cov_out, float* d_h, float* d_c, float* d_cov, float* d_proj_a,
                                     float* d_enc_a, float* d_proj_i, float* d_enc_i, float* delta_out, float* delta_g,
-                                    float* delta_b1, float* delta_b2, float* delta_ha, float* delta_hi, float* vec_acc, int B,
-                                    int T, int device, void* stream_) {
+                                    float* delta_b1, float* delta_b2, float* delta_ha, float* delta_hi, float* vec_acc,
+                                    float* scratch, int B, int T, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (int rc = dec_check(w, B, T)) return rc;
     MMB_REQUIRE(enc_a && enc_i && proj_a && proj_i && h && c && cov && mask && saved && dist && c_out && d_h && d_c && d_cov &&
                     d_proj_a && d_enc_a && d_proj_i && d_enc_i && delta_out && delta_g && delta_b1 && delta_b2 && delta_ha &&
-                    delta_hi && vec_acc, "mmb_decoder_step_bwd: null pointer");
+                    delta_hi && vec_acc && scratch, "mmb_decoder_step_bwd: null pointer");
     MMB_HIP(hipSetDevice(device));
     DecBwdArgs a{};
     a.w = *w; a.enc_a = enc_a; a.enc_i = enc_i; a.proj_a = proj_a; a.proj_i = proj_i; a.h = h; a.c = c; a.cov = cov;
@@ -650,14 +773,24 @@ extern "C" int mmb_decoder_step_bwd(const mmb_decoder_params* w, const float* en
     a.d_proj_a = d_proj_a; a.d_enc_a = d_enc_a; a.d_proj_i = d_proj_i; a.d_enc_i = d_enc_i;
     a.delta_out = delta_out; a.delta_g = delta_g; a.delta_b1 = delta_b1; a.delta_b2 = delta_b2; a.delta_ha = delta_ha; a.delta_hi = delta_hi;
     a.vec_acc = vec_acc; a.B = B; a.T = T; a.saved_stride = (int)mmb_decoder_saved_floats(T, w->H);
-    const size_t lds = dec_bwd_lds_floats(T, w->H, w->E, w->L) * sizeof(float);
-    MMB_REQUIRE(lds <= 160 * 1024, "mmb_decoder_step_bwd: T=%d L=%d too large for one workgroup's LDS", T, w->L);
+    dec_chunks(B, T, &a.nch, &a.chunk);
+    const int H = w->H, H2 = 2 * H;
+    a.bs = scratch;
+    a.bpart = a.bs + (size_t)B * (2 * H2 + T + 4);
+    a.dcovm = a.bpart + (size_t)B * 2 * DEC_MAX_CH * (3 * H2 + 4);
+    const size_t lds = dec_bwd_lds_floats(T, H, w->E, w->L) * sizeof(float);
+    const size_t lds_att = (size_t)(((H + 3) & ~3) + 2 * ((H2 + 3) & ~3) + DEC_NW * 3 * H2 + 16) * sizeof(float);
+    const size_t lds_fin = (size_t)(2 * ((H2 + 3) & ~3) + ((H + 3) & ~3) + DEC_NT) * sizeof(float);
+    MMB_REQUIRE(lds <= 160 * 1024 && lds_att <= 160 * 1024, "mmb_decoder_step_bwd: T=%d L=%d too large for one workgroup's LDS", T, w->L);
     static bool attr = false;
     if (!attr) {
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_step_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_att_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     hipLaunchKernelGGL(decoder_step_bwd_kernel, dim3(B), dim3(DEC_NT), lds, stream, a);
+    hipLaunchKernelGGL(decoder_att_bwd_kernel, dim3(B, 2 * a.nch), dim3(DEC_NT), lds_att, stream, a);
+    hipLaunchKernelGGL(decoder_fin_bwd_kernel, dim3(B), dim3(DEC_NT), lds_fin, stream, a);
     MMB_HIP(hipGetLastError());
     return MMB_OK;
 }

@@ -58,11 +58,11 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def _step_fwd(lib, P, enc_a, enc_i, proj_a, proj_i, h, c, cov, xproj, mask, dist, h_out, c_out, att_cov, cov_out, saved):
+def _step_fwd(lib, P, enc_a, enc_i, proj_a, proj_i, h, c, cov, xproj, mask, dist, h_out, c_out, att_cov, cov_out, saved, scratch):
     B, T = cov.shape
     rc = lib.mmb_decoder_step_fwd(ctypes.byref(P), _ptr(enc_a), _ptr(enc_i), _ptr(proj_a), _ptr(proj_i), _ptr(h), _ptr(c),
                                   _ptr(cov), _ptr(xproj), _ptr(mask), _ptr(dist), _ptr(h_out), _ptr(c_out), _ptr(att_cov),
-                                  _ptr(cov_out), _ptr(saved), B, T, cov.device.index, MF._stream())
+                                  _ptr(cov_out), _ptr(saved), _ptr(scratch), B, T, cov.device.index, MF._stream())
     _lib.check(rc, "mmb_decoder_step_fwd")
 
 
@@ -88,9 +88,10 @@ class _DecoderLoopFn(torch.autograd.Function):
         # x part of the LSTM input product, hoisted: one GEMM over all steps  (W_ih = [context columns | x columns])
         w_ihx = keep[24][:, 2 * H:].contiguous()
         xproj = MF.gemm(X.reshape(S * B, E), w_ihx, bias=keep[26], tb=True).reshape(S, B, 4 * H)
+        scratch = new(lib.mmb_decoder_scratch_floats(B, T, H))
         for s in range(S):
             _step_fwd(lib, P, enc_a, enc_i, proj_a, proj_i, hs[s], cs[s], covs[s], xproj[s], mask, dists[s], hs[s + 1], cs[s + 1],
-                      att_covs[s], covs[s + 1], saved[s])
+                      att_covs[s], covs[s + 1], saved[s], scratch)
         ctx.save_for_backward(enc_a, enc_i, proj_a, proj_i, X, mask, hs, cs, covs, dists, saved, *keep[:30])
         ctx.shapes = [w.shape for w in ws]
         return dists, att_covs, covs[1:]
@@ -113,6 +114,7 @@ class _DecoderLoopFn(torch.autograd.Function):
         dl_out, dl_g = new(S, B, L), new(S, B, 4 * H)
         dl_b1, dl_b2, dl_ha, dl_hi = (new(S, B, H2) for _ in range(4))
         vec = zeros(B, lib.mmb_decoder_vec_acc_floats(H))
+        scratch = new(lib.mmb_decoder_scratch_floats(B, T, H))
         d_h, d_c, d_cov = [zeros(B, H), new(B, H)], [zeros(B, H), new(B, H)], [zeros(B, T), new(B, T)]
         cur = 0
         for s in reversed(range(S)):
@@ -124,7 +126,7 @@ class _DecoderLoopFn(torch.autograd.Function):
                 _ptr(None if d_att_covs is None else d_att_covs[s]), _ptr(d_cov_out),
                 _ptr(d_h[cur ^ 1]), _ptr(d_c[cur ^ 1]), _ptr(d_cov[cur ^ 1]),
                 _ptr(d_proj_a), _ptr(d_enc_a), _ptr(d_proj_i), _ptr(d_enc_i),
-                _ptr(dl_out[s]), _ptr(dl_g[s]), _ptr(dl_b1[s]), _ptr(dl_b2[s]), _ptr(dl_ha[s]), _ptr(dl_hi[s]), _ptr(vec),
+                _ptr(dl_out[s]), _ptr(dl_g[s]), _ptr(dl_b1[s]), _ptr(dl_b2[s]), _ptr(dl_ha[s]), _ptr(dl_hi[s]), _ptr(vec), _ptr(scratch),
                 B, T, dev.index, MF._stream())
             _lib.check(rc, "mmb_decoder_step_bwd")
             cur ^= 1
@@ -184,11 +186,12 @@ def decoder_greedy(dec, enc_a, enc_i, h0, embedded_text, mask, steps):
     dists, att_cov = new(steps, B, L), new(B, T)
     rows = torch.arange(B, device=dev)
     w_ihx, b_ih = dec.lstm.weight_ih_l0[:, 2 * H:], dec.lstm.bias_ih_l0
+    scratch = new(lib.mmb_decoder_scratch_floats(B, T, H))
     cur = 0
     for s in range(steps):
         xproj = MF._f32c(torch.nn.functional.linear(x, w_ihx, b_ih))
         _step_fwd(lib, P, enc_a, enc_i, proj_a, proj_i, h[cur], c[cur], cov[cur], xproj, mask, dists[s], h[cur ^ 1], c[cur ^ 1],
-                  att_cov, cov[cur ^ 1], None)
+                  att_cov, cov[cur ^ 1], None, scratch)
         x = emb[rows, dists[s].argmax(dim=1)]
         cur ^= 1
     return dists, att_cov, cov[cur]

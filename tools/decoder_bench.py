@@ -59,6 +59,6 @@ from torch.profiler import ProfilerActivity, profile
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     fused(True)
     torch.cuda.synchronize()
-rows = [(e.key[:60], e.device_time_total / max(e.count, 1), e.count) for e in prof.key_averages() if "decoder_step" in e.key]
+rows = [(e.key[:60], e.device_time_total / max(e.count, 1), e.count) for e in prof.key_averages() if "decoder_" in e.key]
 for k, us, cnt in rows:
     print(f"  {k}: {us:.1f} us avg over {cnt} launches")
