@@ -127,7 +127,9 @@ typedef struct {
     float* gx;                 /* (B,T,2,H,4) input projection, gate-interleaved                 */
     float* gates;              /* (B,T,2,H,4) post-activation i,f,g,o                            */
     float* cs;                 /* (B,T,2,H)   cell state after each step                         */
-    void* ws;                  /* scratch of mmb_bilstm_ws_bytes(B,T,I,H,0) bytes (bf16 operand planes) or NULL   */
+    void* ws;                  /* scratch of mmb_bilstm_ws_bytes(B,T,I,H,0) bytes (operand planes) or NULL          */
+    float* x_absmax;           /* (2) must be 0 on entry; receives [max |x|, max |W_ih|] (saved: the backward's     */
+                               /* transposed fp16 planes are scaled by them); may be NULL when ws is NULL            */
     int32_t B, T, I, H;
 } mmb_lstm_fwd_desc;
 
@@ -159,6 +161,7 @@ typedef struct {
     float* d_w_cat;            /* (8H, I+2H) or NULL: lets the library compute d_w_ih and both   */
                                /* d_w_hh with ONE GEMM against [x | y_fwd(t-1) | y_rev(t+1)]     */
     void* ws;                  /* scratch of mmb_bilstm_ws_bytes(B,T,I,H,1) bytes or NULL        */
+    const float* x_absmax;     /* (2) as left by the forward call                                 */
     int32_t B, T, I, H;
 } mmb_lstm_bwd_desc;
 
@@ -245,7 +248,8 @@ int mmb_gemm_f32(const float* A, const float* Bm, float* C, const float* bias,
                  int device, void* stream);
 
 /* C = A (M,K) . B (N,K)^T + bias through the operand-plane path (split passes + bf16 6-product kernel); exported for
- * tests and tools.  ws: scratch of at least 6 * (roundup(M,16) + roundup(N,16)) * roundup(K,32) bytes; K % 4 == 0. */
+ * tests and tools.  ws: scratch of at least 6 * (roundup(M,16) + roundup(N,16)) * roundup(K,32) + roundup(4*(M+N),256)
+ * bytes; K % 4 == 0. */
 int mmb_gemm_nt_planes(const float* A, const float* Bm, float* C, const float* bias, int M, int N, int K,
                        void* ws, size_t ws_bytes, int device, void* stream);
 

@@ -104,12 +104,18 @@ void set_gemm_mode(int mode);
 // a chunk = 16 rows x 64 B with the 16-B octet slots XOR-swizzled by row bit 3 (exactly the LDS image the GEMM reads).
 typedef __bf16 bf16_t;
 inline size_t planes_bytes(long rows, long kp) { return (size_t)((rows + 15) / 16) * (kp / 32) * 3 * 1024; }
+// np = 3: three bf16 planes (x = x0 + x1 + x2 exactly, no scaling).
+// np = 2: two fp16 planes of s*x with s a power of two per plane row (|s*x| < 2^14, so neither term over- nor underflows
+//         in a way that matters): s*x = h0 + h1 up to 2^-22 relative; the GEMM applies 1/s per output row / column.
 struct SplitRowsArgs {
     const float* src1; const float* src2; int R1;
     int R, C, ld, Cp, gate_H;
     bf16_t* planes;
     const float* b1a; const float* b2a; const float* b1b; const float* b2b;
     float* bias_out;
+    int np;
+    float* inv_out;      // np == 2: (R) 1/s of every plane row
+    float* absmax_out;   // np == 2, optional: max |x| over the whole matrix is atomically max-ed into this (pre-zeroed) float
 };
 struct SplitTArgs {
     int nseg;
@@ -119,6 +125,11 @@ struct SplitTArgs {
     bf16_t* planes;
     const float* stack_ptr; int stack_R1;
     float* zero_ptr; long zero_n;   // optional: this pass also zeroes zero_n floats (the split-K output of the GEMM that follows)
+    int np;
+    // np == 2: one power-of-two scale per SEGMENT from an upper bound of max |x| over it: the maximum of the
+    // seg_absmax_n[g] floats at seg_absmax[g] (partials written by the producer), or the constant seg_bound[g] when null
+    const float* seg_absmax[3]; int seg_absmax_n[3]; float seg_bound[3];
+    float* inv_out;      // np == 2: (Ctot) 1/s of every plane row (= source column)
 };
 struct PlanesGemmArgs {
     const bf16_t* A;   // tiled planes of the (M x K) operand
@@ -127,6 +138,9 @@ struct PlanesGemmArgs {
     const float* bias;
     int M, N, K;
     int accumulate;
+    int np;                    // planes per operand: 3 (bf16, 6 cross products) or 2 (scaled fp16, 3 cross products)
+    const float* a_inv;        // np == 2: (M) and (N) inverse scales of the operands' plane rows
+    const float* b_inv;
     int prezeroed;   // C is already zero (a split pass did it): skip the memset a K split needs
     int splitk;      // set by planes_gemm
     int dbg;      // timing-only ablation (MMB_PLANES_DBG): 2 = no MFMA
@@ -135,6 +149,7 @@ int planes_split_rows(const SplitRowsArgs& a, hipStream_t stream);
 int planes_split_transpose(const SplitTArgs& a, hipStream_t stream);
 int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream);
 void planes_set_tune(int code);
+int planes_terms();   // 2 (default) or 3 (MMB_PLANES_TERMS=3): which split the operand-plane path uses
 int planes_plan_splitk(const PlanesGemmArgs& g);   // the K split planes_gemm will use for g
 
 // ---- general-size attention (bidaf_big.hip): D > MMB_ATT_MAX_D

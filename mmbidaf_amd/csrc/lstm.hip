@@ -188,6 +188,7 @@ struct RecBwdProb {
     float* d_a;            // (B,T,2,4H) torch gate order
     float* d_b;            // (2,4H) accumulated with atomics (pre-zeroed) when db_part is null
     float* db_part;        // (2,B,4H) per-sample partial bias gradients (plain stores; reduced by lstm_unpack_dw_kernel) or null
+    float* damax_part;     // (2,B) per-workgroup max |d_a| (bounds the scale of the fp16 operand planes) or null
     int B, T, H, wg_begin;
 };
 struct RecBwdArgs {
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float c_t = len > 0 ? cs_b[t0 * 2 * H] : 0.f;
     float dh = P.d_hn ? P.d_hn[((size_t)dir * P.B + b) * H + u] : 0.f;
     float dc = 0.f;
-    float db_acc = 0.f;
+    float db_acc = 0.f, da_max = 0.f;
     int cur = 0;
     bool first = true;
     const bool o1 = (ks >> 2) & 1, o2 = (ks >> 2) & 2;   // which of the 4 sums is my unit's
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         da_off += g_step;
         db_acc += da;
+        da_max = fmaxf(da_max, fabsf(da));
         cur ^= 1;
         __syncthreads();
     };
@@ -361,6 +363,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (P.db_part) P.db_part[((size_t)dir * P.B + b) * 4 * H + kq * H + u] = db_acc;
         else atomicAdd(&P.d_b[(size_t)dir * 4 * H + kq * H + u], db_acc);
     }
+    if (P.damax_part) {   // workgroup maximum of |d_a| (dabuf is free now)
+        __syncthreads();
+        float m = da_max;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float* red = &dabuf[0][0][0];
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) {
+            float r = 0.f;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r = fmaxf(r, red[w]);
+            P.damax_part[(size_t)dir * P.B + b] = r;
+        }
+    }
     // dead steps contribute nothing: zero their d_a rows for the weight-gradient GEMMs
     float* da_z = P.d_a + (size_t)b * T * 8 * H + (size_t)dir * 4 * H;
     for (int i = tid; i < (T - len) * 4 * H; i += blockDim.x) {
@@ -395,10 +411,22 @@ __global__ __launch_bounds__(256) void lstm_unpack_dw_kernel(const float* __rest
     else if (col - I >= dir * H && col - I < (dir + 1) * H) d_w_hh[(size_t)row * H + (col - I - dir * H)] = v;
 }
 
+// out[0] = max(out[0], max |p[i]|) for up to two arrays (out pre-zeroed; non-negative floats compare as unsigned ints)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p0, const float* __restrict__ p1, long n, float* out) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        m = fmaxf(m, fabsf(p0[i]));
+        if (p1) m = fmaxf(m, fabsf(p1[i]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+
 // ---- operand-plane scratch layout (planes.hip): byte offsets inside desc.ws
 static size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static bool planes_ok(int I, int H) { return I % 4 == 0 && H % 4 == 0 && gemm_mode() != 0; }
-struct WsFwd { size_t xP, wP, bias, big, total; int Ip; };
+struct WsFwd { size_t xP, wP, bias, xinv, winv, big, total; int Ip; };
 static WsFwd ws_fwd_layout(long BT, int B, int I, int H) {
     WsFwd w{};
     w.Ip = (int)rup(I, 32);
@@ -406,11 +434,13 @@ static WsFwd ws_fwd_layout(long BT, int B, int I, int H) {
     w.xP = o;   o += rup(planes_bytes(BT, w.Ip), 256);
     w.wP = o;   o += rup(planes_bytes(8 * H, w.Ip), 256);
     w.bias = o; o += rup((size_t)8 * H * 4, 256);
+    w.xinv = o; o += rup((size_t)BT * 4, 256);          // inverse row scales of the fp16 planes (np = 2)
+    w.winv = o; o += rup((size_t)8 * H * 4, 256);
     w.big = o;  if (H > MMB_LSTM_MAX_H) o += rup(lstm_big_fwd_ws_bytes(B, H), 256);
     w.total = o;
     return w;
 }
-struct WsBwd { size_t daP, daT, xcT, wT, dbp, big, total; int K8, BTp; };
+struct WsBwd { size_t daP, daT, xcT, wT, dbp, dainv, daTinv, xcTinv, wTinv, scal, damax, big, total; int K8, BTp; };
 static WsBwd ws_bwd_layout(long BT, int B, int I, int H) {
     WsBwd w{};
     w.K8 = (int)rup(8 * H, 32);
@@ -421,6 +451,12 @@ static WsBwd ws_bwd_layout(long BT, int B, int I, int H) {
     w.xcT = o; o += rup(planes_bytes(I + 2 * H, w.BTp), 256);
     w.wT = o;  o += rup(planes_bytes(I, w.K8), 256);
     w.dbp = o; o += rup((size_t)2 * B * 4 * H * 4, 256);
+    w.dainv = o;  o += rup((size_t)BT * 4, 256);                   // inverse scales of the fp16 planes (np = 2) ...
+    w.daTinv = o; o += rup((size_t)8 * H * 4, 256);
+    w.xcTinv = o; o += rup((size_t)(I + 2 * H) * 4, 256);
+    w.wTinv = o;  o += rup((size_t)I * 4, 256);
+    w.scal = o;   o += 256;                                        // ... [max |W_ih|, max |d_a| (general recurrence)]
+    w.damax = o;  o += rup((size_t)2 * B * 4, 256);                // per-workgroup max |d_a| of the register-resident BPTT
     w.big = o; if (H > MMB_LSTM_MAX_H) o += rup(lstm_big_bwd_ws_bytes(B, H), 256);
     w.total = o;
     return w;
@@ -435,19 +471,25 @@ static int gx_planes(const mmb_lstm_fwd_desc& p, hipStream_t stream) {
     bf16_t* xP = reinterpret_cast<bf16_t*>(ws + L.xP);
     bf16_t* wP = reinterpret_cast<bf16_t*>(ws + L.wP);
     float* bias = reinterpret_cast<float*>(ws + L.bias);
+    const int np = planes_terms();
+    float* xinv = reinterpret_cast<float*>(ws + L.xinv);
+    float* winv = reinterpret_cast<float*>(ws + L.winv);
     SplitRowsArgs sx{};
     sx.src1 = p.x; sx.src2 = p.x; sx.R1 = (int)BT; sx.R = (int)BT; sx.C = p.I; sx.ld = p.I; sx.Cp = L.Ip; sx.gate_H = 0;
     sx.planes = xP;
+    sx.np = np; sx.inv_out = xinv; sx.absmax_out = p.x_absmax;   // max |x| is saved for the backward's transposed planes
     if (int rc = planes_split_rows(sx, stream)) return rc;
     SplitRowsArgs sw{};
     sw.src1 = p.w_ih[0]; sw.src2 = p.w_ih[1]; sw.R1 = 4 * H; sw.R = 8 * H; sw.C = p.I; sw.ld = p.I; sw.Cp = L.Ip; sw.gate_H = H;
     sw.planes = wP;
     sw.b1a = p.b_ih[0]; sw.b2a = p.b_hh[0]; sw.b1b = p.b_ih[1]; sw.b2b = p.b_hh[1]; sw.bias_out = bias;
+    sw.np = np; sw.inv_out = winv; sw.absmax_out = p.x_absmax ? p.x_absmax + 1 : nullptr;   // max |W_ih| for the backward's W^T planes
     if (int rc = planes_split_rows(sw, stream)) return rc;
     PlanesGemmArgs g{};
     g.A = xP;
     g.B = wP;
     g.C = p.gx; g.ldc = 8 * H; g.bias = bias; g.M = (int)BT; g.N = 8 * H; g.K = L.Ip;
+    g.np = np; g.a_inv = xinv; g.b_inv = winv;
     return planes_gemm(g, stream);
 }
 
@@ -480,15 +522,35 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
     bf16_t* daT = reinterpret_cast<bf16_t*>(ws + L.daT);
     bf16_t* xcT = reinterpret_cast<bf16_t*>(ws + L.xcT);
     bf16_t* wT = reinterpret_cast<bf16_t*>(ws + L.wT);
+    const int np = planes_terms();
+    float* dainv = reinterpret_cast<float*>(ws + L.dainv);
+    float* daTinv = reinterpret_cast<float*>(ws + L.daTinv);
+    float* xcTinv = reinterpret_cast<float*>(ws + L.xcTinv);
+    float* wTinv = reinterpret_cast<float*>(ws + L.wTinv);
+    float* scal = reinterpret_cast<float*>(ws + L.scal);        // max |d_a| when the recurrence did not track it
+    const float* damax = reinterpret_cast<const float*>(ws + L.damax);
+    int damax_n = 2 * p.B;
+    if (np == 2) {
+        MMB_REQUIRE(p.x_absmax, "mmb_bilstm_layer_bwd: desc.x_absmax (saved by the forward call) is needed by the fp16 operand planes");
+        if (!db_partials) {   // general-size recurrence: max |d_a| was not tracked by the recurrence, one reduction here
+            MMB_HIP(hipMemsetAsync(scal, 0, sizeof(float), stream));
+            hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, stream, p.d_a, static_cast<const float*>(nullptr), BT * 8 * H, scal);
+            MMB_HIP(hipGetLastError());
+            damax = scal;
+            damax_n = 1;
+        }
+    }
     // d_a^T planes (8H x BT): A operand of the weight-gradient GEMM
     SplitTArgs ta{};
     ta.nseg = 1; ta.seg_ptr[0] = p.d_a; ta.seg_ld[0] = 8 * H; ta.seg_cols[0] = 8 * H; ta.seg_shift[0] = 0;
     ta.R = (int)BT; ta.period = 1; ta.Rp = L.BTp; ta.Ctot = 8 * H; ta.planes = daT;
+    ta.np = np; ta.seg_absmax[0] = damax; ta.seg_absmax_n[0] = damax_n; ta.inv_out = daTinv;
     if (int rc = planes_split_transpose(ta, stream)) return rc;
     PlanesGemmArgs gw{};
     gw.A = daT;
     gw.B = xcT;
     gw.C = p.d_w_cat; gw.ldc = I + 2 * H; gw.M = 8 * H; gw.N = I + 2 * H; gw.K = L.BTp;
+    gw.np = np; gw.a_inv = daTinv; gw.b_inv = xcTinv;
     const bool ksplit = planes_plan_splitk(gw) > 1;   // its zeroing rides on the split pass below
     // [x | y_fwd(t-1) | y_rev(t+1)]^T planes ((I+2H) x BT): h_prev is y shifted by one step inside each sample
     SplitTArgs tx{};
@@ -497,6 +559,9 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
     tx.seg_ptr[1] = p.y;     tx.seg_ld[1] = 2 * H; tx.seg_cols[1] = H; tx.seg_shift[1] = -1;
     tx.seg_ptr[2] = p.y + H; tx.seg_ld[2] = 2 * H; tx.seg_cols[2] = H; tx.seg_shift[2] = +1;
     tx.R = (int)BT; tx.period = p.T; tx.Rp = L.BTp; tx.Ctot = I + 2 * H; tx.planes = xcT;
+    tx.np = np; tx.inv_out = xcTinv;
+    tx.seg_absmax[0] = p.x_absmax; tx.seg_absmax_n[0] = 1;       // max |x|, recorded by the forward's split pass
+    tx.seg_bound[1] = 1.0f; tx.seg_bound[2] = 1.0f;               // |h| = |o * tanh(c)| < 1
     if (ksplit) { tx.zero_ptr = p.d_w_cat; tx.zero_n = (long)8 * H * (I + 2 * H); gw.prezeroed = 1; }
     if (int rc = planes_split_transpose(tx, stream)) return rc;
     {
@@ -512,16 +577,19 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
         SplitRowsArgs sa{};
         sa.src1 = p.d_a; sa.src2 = p.d_a; sa.R1 = (int)BT; sa.R = (int)BT; sa.C = 8 * H; sa.ld = 8 * H; sa.Cp = L.K8; sa.gate_H = 0;
         sa.planes = daP;
+        sa.np = np; sa.inv_out = dainv;
         if (int rc = planes_split_rows(sa, stream)) return rc;
         SplitTArgs tw{};
         tw.nseg = 1; tw.seg_ptr[0] = p.w_ih[0]; tw.seg_ld[0] = I; tw.seg_cols[0] = I; tw.seg_shift[0] = 0;
         tw.stack_ptr = p.w_ih[1]; tw.stack_R1 = 4 * H;
         tw.R = 8 * H; tw.period = 1; tw.Rp = L.K8; tw.Ctot = I; tw.planes = wT;
+        tw.np = np; tw.seg_absmax[0] = p.x_absmax ? p.x_absmax + 1 : nullptr; tw.seg_absmax_n[0] = 1; tw.inv_out = wTinv;
         if (int rc = planes_split_transpose(tw, stream)) return rc;
         PlanesGemmArgs g{};
         g.A = daP;
         g.B = wT;
         g.C = p.d_x; g.ldc = I; g.M = (int)BT; g.N = I; g.K = L.K8;
+        g.np = np; g.a_inv = dainv; g.b_inv = wTinv;
         if (int rc = planes_gemm(g, stream)) return rc;
     }
     return MMB_OK;
@@ -622,6 +690,7 @@ extern "C" int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* d, int n, int devic
         if (!part && !big) MMB_HIP(hipMemsetAsync(p.d_b, 0, sizeof(float) * 8 * H, stream));
         RecBwdProb& q = ra.p[i];
         q.db_part = part ? reinterpret_cast<float*>(static_cast<char*>(p.ws) + ws_bwd_layout((long)p.B * p.T, p.B, p.I, H).dbp) : nullptr;
+        q.damax_part = part ? reinterpret_cast<float*>(static_cast<char*>(p.ws) + ws_bwd_layout((long)p.B * p.T, p.B, p.I, H).damax) : nullptr;
         q.d_y = p.d_y; q.d_hn = p.d_hn; q.gates = p.gates; q.cs = p.cs;
         q.w_hh[0] = p.w_hh[0]; q.w_hh[1] = p.w_hh[1]; q.len = p.lengths;
         q.d_a = p.d_a; q.d_b = p.d_b; q.B = p.B; q.T = p.T; q.H = p.H; q.wg_begin = wg;

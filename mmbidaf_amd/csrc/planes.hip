@@ -36,12 +36,38 @@ __device__ __forceinline__ void split3(const float* x, bf16x8& h0, bf16x8& h1, b
     }
 }
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+// s*x (already scaled, |.| < 2^14 by construction; clamped so that a violated bound saturates instead of becoming inf)
+__device__ __forceinline__ void split2h(const float* x, half8& h0, half8& h1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = fminf(fmaxf(x[j], -60000.0f), 60000.0f);
+        const _Float16 a = (_Float16)v;
+        h0[j] = a;
+        h1[j] = (_Float16)(v - (float)a);
+    }
+}
+// power of two s with s * amax in [2^13, 2^14)  (1 for amax = 0 or non-finite)
+__device__ __forceinline__ float pow2_scale(float amax) {
+    const unsigned u = __float_as_uint(amax);
+    int e = (int)((u >> 23) & 0xFF) - 127;
+    if (amax <= 0.0f || e > 100 || e < -100) return 1.0f;
+    return __uint_as_float((unsigned)(13 - e + 127) << 23);
+}
+
 // ------------------------------------------------------------------------------------------ split passes
 __device__ __forceinline__ int pl_swz(int row) { return ((row >> 3) & 1) << 1; }
 // byte offset of (row, k-octet) of plane 0 inside tiled planes with nkt K tiles; planes 1, 2 follow at +1024, +2048
-__device__ __forceinline__ size_t pl_off(int row, int oct, int nkt) {
+__device__ __forceinline__ size_t pl_off(int row, int oct, int nkt, int np = 3) {
     const int rl = row & 15, sl = oct & 3;
-    return ((size_t)(row >> 4) * nkt + (oct >> 2)) * 3072 + rl * 64 + ((sl ^ pl_swz(rl)) << 4);
+    return ((size_t)(row >> 4) * nkt + (oct >> 2)) * (np * 1024) + rl * 64 + ((sl ^ pl_swz(rl)) << 4);
+}
+__device__ __forceinline__ void store_planes16(bf16_t* planes, size_t off, const float* x) {
+    half8 h0, h1;
+    split2h(x, h0, h1);
+    char* d = reinterpret_cast<char*>(planes) + off;
+    *reinterpret_cast<half8*>(d) = h0;
+    *reinterpret_cast<half8*>(d + 1024) = h1;
 }
 __device__ __forceinline__ void store_planes(bf16_t* planes, size_t off, const float* x) {
     bf16x8 h0, h1, h2;
@@ -80,10 +106,124 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsArgs a) 
     if (a.bias_out && oct == 0 && dr < a.R) a.bias_out[dr] = second ? a.b1b[lr] + a.b2b[lr] : a.b1a[lr] + a.b2a[lr];
 }
 
+// np = 2 form of the above: one workgroup per 16-row block.  Pass 1 finds every row's max |x| (-> power-of-two scale, its
+// inverse to inv_out, the block maximum to absmax_out); pass 2 re-reads the block (L2-resident: 16 rows) and writes the
+// two fp16 planes of the scaled values.
+__global__ __launch_bounds__(256) void split_rows16_kernel(const SplitRowsArgs a) {
+    __shared__ float sc[16];
+    const int nkt = a.Cp / 32;
+    const int rb = blockIdx.x, t = threadIdx.x;
+    auto src_row = [&](int dr, const float*& base) {
+        int sr = dr;
+        if (a.gate_H > 0) {  // plane row u*4+g of a 4H block <- source row g*H+u
+            const int H = a.gate_H, blk = dr / (4 * H), rem = dr % (4 * H);
+            sr = blk * 4 * H + (rem & 3) * H + (rem >> 2);
+        }
+        const bool second = sr >= a.R1;
+        const int lr = second ? sr - a.R1 : sr;
+        base = (second ? a.src2 : a.src1) + (size_t)lr * a.ld;
+        return second ? -(lr + 1) : lr;   // sign tells the stacked source (for the bias)
+    };
+    {
+        const int rl = t >> 4, seg = t & 15, dr = rb * 16 + rl;
+        float amax = 0.f;
+        if (dr < a.R) {
+            const float* base;
+            src_row(dr, base);
+            for (int c = seg * 4; c < a.C; c += 64) {
+                const f4 v = *reinterpret_cast<const f4*>(base + c);
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            }
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        if (seg == 0) {
+            const float s = pow2_scale(amax);
+            sc[rl] = s;
+            if (dr < a.R) a.inv_out[dr] = 1.0f / s;
+            if (a.absmax_out && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.absmax_out), __float_as_uint(amax));
+        }
+    }
+    __syncthreads();
+    const int lane = t & 63, wave = t >> 6;
+    const int rl = lane >> 2, dr = rb * 16 + rl;
+    const float* base = nullptr;
+    int tag = 0;
+    if (dr < a.R) tag = src_row(dr, base);
+    const float s = sc[rl];
+    for (int kt = wave; kt < nkt; kt += 4) {
+        const int oct = kt * 4 + (lane & 3);
+        float x[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f4 v = f4{0.f, 0.f, 0.f, 0.f};
+            if (dr < a.R && 8 * oct + 4 * h < a.C) v = *reinterpret_cast<const f4*>(base + 8 * oct + 4 * h);
+            x[4 * h] = v.x * s; x[4 * h + 1] = v.y * s; x[4 * h + 2] = v.z * s; x[4 * h + 3] = v.w * s;
+        }
+        store_planes16(a.planes, pl_off(dr, oct, nkt, 2), x);
+    }
+    if (a.bias_out && wave == 0 && (lane & 3) == 0 && dr < a.R) {
+        const bool second = tag < 0;
+        const int lr = second ? -tag - 1 : tag;
+        a.bias_out[dr] = second ? a.b1b[lr] + a.b2b[lr] : a.b1a[lr] + a.b2a[lr];
+    }
+}
+
+// Register-resident form of split_rows16_kernel for Cp <= 32*4*ITERS: every thread keeps its (row, K octet) values of up
+// to ITERS K tiles in registers between the row-maximum pass and the split, so the source is read exactly once.
+template <int ITERS>
+__global__ __launch_bounds__(256) void split_rows16_reg_kernel(const SplitRowsArgs a) {
+    __shared__ float wmax[4][16];
+    const int nkt = a.Cp / 32;
+    const int rb = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int rl = lane >> 2, dr = rb * 16 + rl;
+    int sr = dr;
+    if (a.gate_H > 0) {  // plane row u*4+g of a 4H block <- source row g*H+u
+        const int H = a.gate_H, blk = dr / (4 * H), rem = dr % (4 * H);
+        sr = blk * 4 * H + (rem & 3) * H + (rem >> 2);
+    }
+    const bool second = sr >= a.R1;
+    const int lr = second ? sr - a.R1 : sr;
+    const float* base = (second ? a.src2 : a.src1) + (size_t)lr * a.ld;
+    float x[ITERS][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int kt = wave + 4 * it, oct = kt * 4 + (lane & 3);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f4 v = f4{0.f, 0.f, 0.f, 0.f};
+            if (kt < nkt && dr < a.R && 8 * oct + 4 * h < a.C) v = *reinterpret_cast<const f4*>(base + 8 * oct + 4 * h);
+            x[it][4 * h] = v.x; x[it][4 * h + 1] = v.y; x[it][4 * h + 2] = v.z; x[it][4 * h + 3] = v.w;
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+    }
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    if ((lane & 3) == 0) wmax[wave][rl] = amax;
+    __syncthreads();
+    const float rmax = fmaxf(fmaxf(wmax[0][rl], wmax[1][rl]), fmaxf(wmax[2][rl], wmax[3][rl]));
+    const float s = pow2_scale(rmax);
+    if (wave == 0 && (lane & 3) == 0 && dr < a.R) {
+        a.inv_out[dr] = 1.0f / s;
+        if (a.absmax_out && rmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.absmax_out), __float_as_uint(rmax));
+        if (a.bias_out) a.bias_out[dr] = second ? a.b1b[lr] + a.b2b[lr] : a.b1a[lr] + a.b2a[lr];
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int kt = wave + 4 * it, oct = kt * 4 + (lane & 3);
+        if (kt >= nkt) break;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[it][j] *= s;
+        store_planes16(a.planes, pl_off(dr, oct, nkt, 2), x[it]);
+    }
+}
+
 // Planes of the TRANSPOSE of a virtual (R x sum cols) matrix: plane row = source column (global, over the concatenated
 // segments), K = source row.  32 source rows x 64 columns per workgroup through LDS; each wave writes whole chunks.
 __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTArgs a) {
     __shared__ float tile[32][65];
+    __shared__ float segs[3];
     const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 64;
     const int t = threadIdx.x;
     if (a.zero_ptr) {
@@ -91,6 +231,7 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTArgs a
         for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + t; i < a.zero_n; i += total) a.zero_ptr[i] = 0.f;
     }
     // load 32 source rows x 64 columns (two float4 per thread), per-chunk segment lookup, shifted rows, zero outside
+    f4 vload[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int kk = (t >> 4) + 16 * h, col = c0 + (t & 15) * 4;
@@ -108,8 +249,25 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTArgs a
                 v = *reinterpret_cast<const f4*>(base + c);
             }
         }
+        vload[h] = v;
+    }
+    if (a.np == 2 && t < 64) {   // per-segment power-of-two scale from the producers' bound on max |x| (one wave, parallel scan)
+        for (int g = 0; g < 3; ++g) {
+            float amax = a.seg_bound[g];
+            if (g < a.nseg && a.seg_absmax[g]) {
+                amax = 0.f;
+                for (int i = t; i < a.seg_absmax_n[g]; i += 64) amax = fmaxf(amax, a.seg_absmax[g][i]);
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+            }
+            if (t == 0) segs[g] = pow2_scale(amax);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int kk = (t >> 4) + 16 * h;
         float* d = &tile[kk][(t & 15) * 4];
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        d[0] = vload[h].x; d[1] = vload[h].y; d[2] = vload[h].z; d[3] = vload[h].w;
     }
     __syncthreads();
     // each thread: one plane row (source column), one k-octet; a wave = one chunk per plane (columns past Ctot are zeros)
@@ -119,7 +277,17 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTArgs a
     float x[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = tile[8 * oc + j][cl];
-    store_planes(a.planes, pl_off(col, (k0 >> 3) + oc, a.Rp / 32), x);
+    if (a.np == 2) {
+        int c = col, sg = 0;
+        while (sg < a.nseg - 1 && c >= a.seg_cols[sg]) c -= a.seg_cols[sg++];
+        const float sc = segs[sg];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] *= sc;
+        store_planes16(a.planes, pl_off(col, (k0 >> 3) + oc, a.Rp / 32, 2), x);
+        if (blockIdx.x == 0 && oc == 0 && col < a.Ctot) a.inv_out[col] = 1.0f / sc;
+    } else {
+        store_planes(a.planes, pl_off(col, (k0 >> 3) + oc, a.Rp / 32), x);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ GEMM on planes
@@ -131,13 +299,13 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTArgs a
 // Operands are passed (B fragment, A fragment): lane (r, kg) then holds C[m = r][n = 4*kg .. 4*kg+3] -- float4 stores.
 // Workgroup ids are cut into 8 contiguous chunks, one per XCD (ids go round-robin over XCDs), so that the
 // workgroups that share an A row panel (same tile row, neighbouring tile columns) also share an L2.
-template <int WM, int WN, int MT, int NT>
+template <int WM, int WN, int MT, int NT, int NP>
 __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g, const int kchunk, const int tiles_n,
                                                           const int ntiles) {
     static_assert(WM * WN == 8, "8 waves");
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, RT = BM + BN;  // rows per plane image
-    constexpr int STAGE = 3 * RT * 64;                                 // bytes per stage
-    constexpr int NDMA = 3 * RT / 16;                                  // 1-KiB wave-instructions per stage
+    constexpr int STAGE = NP * RT * 64;                                // bytes per stage
+    constexpr int NDMA = NP * RT / 16;                                 // 1-KiB wave-instructions per stage
     constexpr int PER_WAVE = (NDMA + 7) / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -157,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
     const int nk = (ke - kb + 31) / 32;
 
     // DMA piece q of a stage = chunk (plane q / (RT/16), row block q % (RT/16)) of the tiled planes: 1 KiB contiguous
-    // in global memory, copied lane-linear (the swizzle is already in the data); K tile kt follows at +3 KiB.
+    // in global memory, copied lane-linear (the swizzle is already in the data); K tile kt follows at +NP KiB.
     const int nkt = g.K / 32, nrbA = (g.M + 15) / 16, nrbB = (g.N + 15) / 16;
     const char* src[PER_WAVE];
 #pragma unroll
@@ -173,7 +341,7 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
             base = reinterpret_cast<const char*>(g.B);
             rbk = (size_t)min(n0 / 16 + blk - BM / 16, nrbB - 1);
         }
-        src[k] = base + ((rbk * nkt + kb / 32) * 3 + plane) * 1024 + lane * 16;
+        src[k] = base + ((rbk * nkt + kb / 32) * NP + plane) * 1024 + lane * 16;
     }
     auto dma_stage = [&](int stage) {
 #pragma unroll
@@ -182,7 +350,7 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
             if (NDMA % 8 == 0 || q < NDMA)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[k],
                                                  (__attribute__((address_space(3))) void*)(smem + stage * STAGE + q * 1024), 16, 0, 0);
-            src[k] += 3072;
+            src[k] += NP * 1024;
         }
     };
 
@@ -238,15 +406,28 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
         }
         if (grp == 1 && t + 2 < nk && !(g.dbg & 8)) dma_stage(t & 1);
         if (!(g.dbg & 2)) {
-            // cross terms of order <= 2, smallest first: (a plane, b plane)
-            constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
+            if constexpr (NP == 3) {
+                // bf16 planes: cross terms of order <= 2, smallest first: (a plane, b plane)
+                constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-            for (int term = 0; term < 6; ++term)
+                for (int term = 0; term < 6; ++term)
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][TB[term]], a[i][TA[term]], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][TB[term]], a[i][TA[term]], acc[i][j], 0, 0, 0);
+            } else {
+                // scaled fp16 planes: a0 b1 + a1 b0 + a0 b0 (the dropped a1 b1 is below 2^-22 relative)
+                constexpr int TA[3] = {0, 1, 0}, TB[3] = {1, 0, 0};
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, b[j][TB[term]]),
+                                                                               __builtin_bit_cast(half8, a[i][TA[term]]), acc[i][j], 0, 0, 0);
+            }
         }
         if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!only_mfma) bar();
@@ -272,10 +453,21 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
             bv[j][e] = (has_bias && n < g.N) ? g.bias[min(n, g.N - 1)] : 0.f;
         }
     }
+    f4 sb[NT];   // inverse scales of this lane's 4 columns (scaled fp16 planes), 1 otherwise
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = nw0 + j * 16 + 4 * kg + e;
+            sb[j][e] = (NP == 2 && g.b_inv) ? g.b_inv[min(n, g.N - 1)] : 1.0f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+        const int mrow = min(m0 + (wm * MT + i) * 16 + r, g.M - 1);
+        const float sa = (NP == 2 && g.a_inv) ? g.a_inv[mrow] : 1.0f;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) *reinterpret_cast<f4*>(stg + r * LDW + j * 16 + 4 * kg) = acc[i][j] + bv[j];
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<f4*>(stg + r * LDW + j * 16 + 4 * kg) = acc[i][j] * (sb[j] * sa) + bv[j];
         const int mw0 = m0 + (wm * MT + i) * 16;
         if (atomic || !vec) {
 #pragma unroll
@@ -309,7 +501,15 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
 int planes_split_rows(const SplitRowsArgs& a, hipStream_t stream) {
     const long pairs = (long)((a.R + 15) / 16) * (a.Cp / 32);
     ProfScope ps_(MMB_K_SPLIT, stream);
-    hipLaunchKernelGGL(split_rows_kernel, dim3((pairs + 3) / 4), dim3(256), 0, stream, a);
+    if (a.np == 2) {
+        const int nkt = a.Cp / 32;
+        const dim3 grid((a.R + 15) / 16);
+        if (nkt <= 8) hipLaunchKernelGGL(split_rows16_reg_kernel<2>, grid, dim3(256), 0, stream, a);
+        else if (nkt <= 16) hipLaunchKernelGGL(split_rows16_reg_kernel<4>, grid, dim3(256), 0, stream, a);
+        else if (nkt <= 32) hipLaunchKernelGGL(split_rows16_reg_kernel<8>, grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(split_rows16_kernel, grid, dim3(256), 0, stream, a);
+    }
+    else hipLaunchKernelGGL(split_rows_kernel, dim3((pairs + 3) / 4), dim3(256), 0, stream, a);
     MMB_HIP(hipGetLastError());
     return MMB_OK;
 }
@@ -321,11 +521,11 @@ int planes_split_transpose(const SplitTArgs& a, hipStream_t stream) {
     return MMB_OK;
 }
 
-template <int WM, int WN, int MT, int NT>
-static int launch_planes(const PlanesGemmArgs& g, hipStream_t stream) {
+template <int WM, int WN, int MT, int NT, int NP>
+static int launch_planes_np(const PlanesGemmArgs& g, hipStream_t stream) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
-    const size_t lds = (size_t)2 * 3 * (BM + BN) * 64;
-    auto kern = gemm_planes_kernel<WM, WN, MT, NT>;
+    const size_t lds = (size_t)2 * NP * (BM + BN) * 64;
+    auto kern = gemm_planes_kernel<WM, WN, MT, NT, NP>;
     static bool attr_set = false;
     if (!attr_set) {
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -338,6 +538,20 @@ static int launch_planes(const PlanesGemmArgs& g, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(ntiles * g.splitk), dim3(512), lds, stream, g, kchunk, tiles_n, ntiles);
     MMB_HIP(hipGetLastError());
     return MMB_OK;
+}
+
+template <int WM, int WN, int MT, int NT>
+static int launch_planes(const PlanesGemmArgs& g, hipStream_t stream) {
+    return g.np == 2 ? launch_planes_np<WM, WN, MT, NT, 2>(g, stream) : launch_planes_np<WM, WN, MT, NT, 3>(g, stream);
+}
+
+int planes_terms() {
+    static int terms = 0;
+    if (!terms) {
+        const char* e = getenv("MMB_PLANES_TERMS");
+        terms = (e && atoi(e) == 3) ? 3 : 2;
+    }
+    return terms;
 }
 
 namespace {
@@ -356,7 +570,7 @@ double planes_cost(const PlanesGemmArgs& g, const PlanesCfg& c, int splitk) {
     const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
     const long nk = ((g.K + splitk - 1) / splitk + 31) / 32;
     const long rounds = (tiles * splitk + 255) / 256;
-    const double mfma = 2.0 * c.mt * c.nt * 6 * 20, dma = 3.0 * (bm + bn) * 64 / 29.0;
+    const double mfma = 2.0 * c.mt * c.nt * (g.np == 2 ? 3 : 6) * 20, dma = (double)(g.np == 2 ? 2 : 3) * (bm + bn) * 64 / 29.0;
     const double per_tile = (mfma > dma ? mfma + 0.25 * dma : dma + 0.25 * mfma) + 300.0;
     double cost = (double)rounds * (nk * per_tile + 6000.0 + 1.5 * bm * bn / 8.0);   // + prologue, first DMA, epilogue stores
     if (splitk > 1) cost += 8000.0 + 0.0068 * (double)g.M * g.N * splitk;
@@ -387,7 +601,9 @@ static void planes_choose(const PlanesGemmArgs& g, int& best, int& best_s) {
     }
 }
 
-int planes_plan_splitk(const PlanesGemmArgs& g) {
+int planes_plan_splitk(const PlanesGemmArgs& g_) {
+    PlanesGemmArgs g = g_;
+    if (g.np != 2) g.np = 3;
     int best, best_s;
     planes_choose(g, best, best_s);
     return best_s;
@@ -402,6 +618,7 @@ int planes_gemm(const PlanesGemmArgs& g_, hipStream_t stream) {
         verbose = getenv("MMB_PLANES_VERBOSE") != nullptr;
     }
     g.dbg = dbg;
+    if (g.np != 2) g.np = 3;
     int best, best_s;
     planes_choose(g, best, best_s);
     if (verbose)
@@ -424,7 +641,7 @@ int planes_gemm(const PlanesGemmArgs& g_, hipStream_t stream) {
 }  // namespace mmb
 
 // C = A (M,K) . B (N,K)^T + bias through the split passes and the planes kernel (tests / tools): ws needs
-// 6 * (roundup(M, 16) + roundup(N, 16)) * roundup(K, 32) bytes.
+// 6 * (roundup(M, 16) + roundup(N, 16)) * roundup(K, 32) + roundup(4 * (M + N), 256) bytes.
 extern "C" void mmb_set_planes_tune(int code) { mmb::planes_set_tune(code); }
 
 extern "C" int mmb_gemm_nt_planes(const float* A, const float* Bm, float* C, const float* bias, int M, int N, int K,
@@ -433,18 +650,22 @@ extern "C" int mmb_gemm_nt_planes(const float* A, const float* Bm, float* C, con
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MMB_REQUIRE(A && Bm && C && ws && M > 0 && N > 0 && K > 0 && K % 4 == 0, "mmb_gemm_nt_planes: bad argument");
     const int Kp = (K + 31) / 32 * 32;
-    MMB_REQUIRE(ws_bytes >= planes_bytes(M, Kp) + planes_bytes(N, Kp), "mmb_gemm_nt_planes: workspace too small");
+    const size_t inv_bytes = ((size_t)(M + N) * sizeof(float) + 255) / 256 * 256;
+    MMB_REQUIRE(ws_bytes >= planes_bytes(M, Kp) + planes_bytes(N, Kp) + inv_bytes, "mmb_gemm_nt_planes: workspace too small");
     MMB_HIP(hipSetDevice(device));
+    const int np = planes_terms();
     bf16_t* aP = static_cast<bf16_t*>(ws);
     bf16_t* bP = reinterpret_cast<bf16_t*>(static_cast<char*>(ws) + planes_bytes(M, Kp));
+    float* a_inv = reinterpret_cast<float*>(static_cast<char*>(ws) + planes_bytes(M, Kp) + planes_bytes(N, Kp));
+    float* b_inv = a_inv + M;
     SplitRowsArgs sa{};
-    sa.src1 = A; sa.src2 = A; sa.R1 = M; sa.R = M; sa.C = K; sa.ld = K; sa.Cp = Kp; sa.planes = aP;
+    sa.src1 = A; sa.src2 = A; sa.R1 = M; sa.R = M; sa.C = K; sa.ld = K; sa.Cp = Kp; sa.planes = aP; sa.np = np; sa.inv_out = a_inv;
     if (int rc = planes_split_rows(sa, stream)) return rc;
     SplitRowsArgs sb{};
-    sb.src1 = Bm; sb.src2 = Bm; sb.R1 = N; sb.R = N; sb.C = K; sb.ld = K; sb.Cp = Kp; sb.planes = bP;
+    sb.src1 = Bm; sb.src2 = Bm; sb.R1 = N; sb.R = N; sb.C = K; sb.ld = K; sb.Cp = Kp; sb.planes = bP; sb.np = np; sb.inv_out = b_inv;
     if (int rc = planes_split_rows(sb, stream)) return rc;
     PlanesGemmArgs g{};
     g.A = aP; g.B = bP;
-    g.C = C; g.ldc = N; g.bias = bias; g.M = M; g.N = N; g.K = Kp;
+    g.C = C; g.ldc = N; g.bias = bias; g.M = M; g.N = N; g.K = Kp; g.np = np; g.a_inv = a_inv; g.b_inv = b_inv;
     return planes_gemm(g, stream);
 }

@@ -134,6 +134,7 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         descs = (_lib.LstmFwdDesc * n)()
         keep, outs, saved = [], [], []
         dev = flat[0].device
+        x_absmax = torch.zeros(n, 2, device=dev, dtype=torch.float32)    # [max |x|, max |W_ih|] per problem, filled by the library
         for i in range(n):
             x, *ws_ = flat[i * _PER_PROBLEM:(i + 1) * _PER_PROBLEM]
             _require_gpu(x, *ws_)
@@ -158,10 +159,11 @@ class _BiLSTMLayerFn(torch.autograd.Function):
                                                               _ptr(ws_[4 * k + 2]), _ptr(ws_[4 * k + 3]))
             d.y, d.h_n, d.c_n, d.gx, d.gates, d.cs = _ptr(y), _ptr(h_n), _ptr(c_n), _ptr(gx), _ptr(gates), _ptr(cs)
             d.ws = _ptr(ws) if ws.numel() else None
+            d.x_absmax = x_absmax[i].data_ptr()
             d.B, d.T, d.I, d.H = B, T, I, H
             keep += [x, gx, c_n, ws] + ws_
             outs += [y, h_n]
-            saved += [x, y, gates, cs, ws_[0], ws_[1], ws_[4], ws_[5], lengths_dev[i]]
+            saved += [x, y, gates, cs, ws_[0], ws_[1], ws_[4], ws_[5], lengths_dev[i], x_absmax[i]]
         rc = lib.mmb_bilstm_layer_fwd(descs, n, dev.index, _stream())
         _lib.check(rc, "mmb_bilstm_layer_fwd")
         ctx.n = n
@@ -178,7 +180,7 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         keep, results = [], []
         dev = sv[0].device
         for i in range(n):
-            x, y, gates, cs, w_ih_f, w_hh_f, w_ih_r, w_hh_r, lens = sv[i * 9:(i + 1) * 9]
+            x, y, gates, cs, w_ih_f, w_hh_f, w_ih_r, w_hh_r, lens, x_absmax = sv[i * 10:(i + 1) * 10]
             B, T, I = x.shape
             H = w_hh_f.shape[1]
             d_y, d_hn = grads[2 * i], grads[2 * i + 1]
@@ -198,6 +200,7 @@ class _BiLSTMLayerFn(torch.autograd.Function):
             d.d_x, d.d_w_ih, d.d_w_hh, d.d_b, d.d_a = _ptr(d_x), _ptr(d_w_ih), _ptr(d_w_hh), _ptr(d_b), _ptr(d_a)
             d.d_w_cat = _ptr(d_w_cat)
             d.ws = _ptr(ws) if ws.numel() else None
+            d.x_absmax = _ptr(x_absmax)
             d.B, d.T, d.I, d.H = B, T, I, H
             keep += [d_y, d_hn, d_a, d_w_cat, ws]
             results += [d_x, d_w_ih[0], d_w_hh[0], d_b[0], d_b[0], d_w_ih[1], d_w_hh[1], d_b[1], d_b[1]]
@@ -241,7 +244,8 @@ def gemm_nt_planes(a, b, bias=None):
     M, K = a.shape
     N = b.shape[0]
     Kp = (K + 31) // 32 * 32
-    ws = torch.empty(6 * ((M + 15) // 16 * 16 + (N + 15) // 16 * 16) * Kp, device=a.device, dtype=torch.uint8)
+    ws = torch.empty(6 * ((M + 15) // 16 * 16 + (N + 15) // 16 * 16) * Kp + (4 * (M + N) + 255) // 256 * 256,
+                     device=a.device, dtype=torch.uint8)
     c = torch.empty(M, N, device=a.device, dtype=torch.float32)
     rc = lib.mmb_gemm_nt_planes(_ptr(a), _ptr(b), _ptr(c), _ptr(bias), M, N, K, _ptr(ws), ws.numel(), a.device.index, _stream())
     _lib.check(rc, "mmb_gemm_nt_planes")
