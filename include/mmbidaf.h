@@ -134,7 +134,7 @@ typedef struct {
 } mmb_lstm_fwd_desc;
 
 /* bytes of the optional operand-plane scratch of one problem (backward != 0: for mmb_bilstm_layer_bwd).  With it (and
- * I, H multiples of 4) the layer's GEMMs run on the bf16 matrix cores from exact 3-term splits (fp32-level accuracy);
+ * I, H multiples of 4) the layer's GEMMs run on the 16-bit matrix cores from error-compensated splits (fp32-level accuracy);
  * without it they run on the exact-f32 MFMA kernels. */
 size_t mmb_bilstm_ws_bytes(int B, int T, int I, int H, int backward);
 

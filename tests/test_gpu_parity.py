@@ -369,6 +369,31 @@ def test_lstm_time_reversal_property_full_size():
     assert maxdiff(y[:, :, 100:].cpu(), y2[:, :, :100].flip(1).cpu()) < 1e-5
 
 
+def test_planes_gemm_is_fp32_accurate_against_float64():
+    """The operand-plane GEMM (scaled two-term fp16 split, 3 MFMA cross products) must stay in the error class of an
+    fp32 GEMM: max error relative to the output scale <= 2e-6 vs a float64 reference, also for rows of wildly different
+    magnitude, wide ranges inside rows, tiny gradients and a K = 12800 contraction."""
+    from mmbidaf_amd import functional as MF
+    g = torch.Generator().manual_seed(5)
+    rn = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    cases = {
+        "plain": (rn(512, 800), 0.1 * rn(256, 800)),
+        "row scales e^-12..e^3": (rn(512, 800) * torch.exp(torch.empty(512, 1, dtype=torch.float64).uniform_(-12, 3, generator=g)), 0.1 * rn(256, 800)),
+        "element scales e^-10..1": (rn(512, 800) * torch.exp(torch.empty(512, 800, dtype=torch.float64).uniform_(-10, 0, generator=g)),
+                                    rn(256, 800) * torch.exp(torch.empty(256, 800, dtype=torch.float64).uniform_(-10, 0, generator=g))),
+        "tiny gradients": (1e-6 * rn(512, 800), 0.1 * rn(256, 800)),
+        "K = 12800": (1e-3 * rn(128, 12800), rn(96, 12800)),
+        "zero rows": (torch.cat((rn(16, 64), torch.zeros(16, 64, dtype=torch.float64))), rn(48, 64)),
+    }
+    for name, (a, b) in cases.items():
+        a32, b32 = a.float(), b.float()
+        ref = a32.double() @ b32.double().t()
+        got = MF.gemm_nt_planes(a32.to(dev()), b32.to(dev())).cpu().double()
+        assert torch.isfinite(got).all(), name
+        err = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+        assert err <= 2e-6, f"{name}: relative error {err:.2e}"
+
+
 # ------------------------------------------------------------------------------------------- embedding (row N2)
 @pytest.mark.parametrize("B,T,E,H", [(3, 17, 12, 8), (4, 50, 300, 100), (2, 33, 128, 100)])
 def test_embedding_highway_vs_oracle(B, T, E, H):
