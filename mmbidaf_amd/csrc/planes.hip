@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTArgs a
 // Operands are passed (B fragment, A fragment): lane (r, kg) then holds C[m = r][n = 4*kg .. 4*kg+3] -- float4 stores.
 // Workgroup ids are cut into 8 contiguous chunks, one per XCD (ids go round-robin over XCDs), so that the
 // workgroups that share an A row panel (same tile row, neighbouring tile columns) also share an L2.
-template <int WM, int WN, int MT, int NT, int NP>
+template <int WM, int WN, int MT, int NT, int NP, int STAGES>
 __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g, const int kchunk, const int tiles_n,
                                                           const int ntiles) {
     static_assert(WM * WN == 8, "8 waves");
@@ -346,10 +346,11 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
     auto dma_stage = [&](int stage) {
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {
-            const int q = wave + 8 * k;
-            if (NDMA % 8 == 0 || q < NDMA)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[k],
-                                                 (__attribute__((address_space(3))) void*)(smem + stage * STAGE + q * 1024), 16, 0, 0);
+            // every wave issues exactly PER_WAVE pieces (a surplus one repeats the last piece: same bytes to the same place),
+            // so that the counted vmcnt waits below are the same immediate for all waves
+            const int q = min(wave + 8 * k, NDMA - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[k],
+                                             (__attribute__((address_space(3))) void*)(smem + stage * STAGE + q * 1024), 16, 0, 0);
             src[k] += NP * 1024;
         }
     };
@@ -383,14 +384,17 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    if (nk > 0) dma_stage(0);
-    if (nk > 1) dma_stage(1);
+    // STAGES LDS stages: tile t lives in stage t % STAGES; tile t+STAGES is DMA'd into it once both groups have read tile t
+    // (global barrier 2t+1), i.e. STAGES-1 full periods before its first read
+#pragma unroll
+    for (int st = 0; st < STAGES; ++st)
+        if (st < nk) dma_stage(st);
     __syncthreads();
     if (grp == 1) bar();
     bf16x8 a[MT][3], b[NT][3];
     for (int t = 0; t < nk; ++t) {
-        if (grp == 0 && t >= 1 && t + 1 < nk && !(g.dbg & 8)) dma_stage((t + 1) & 1);
-        const char* img = smem + (t & 1) * STAGE;
+        if (grp == 0 && t >= 1 && t + STAGES - 1 < nk && !(g.dbg & 8)) dma_stage((t - 1) % STAGES);   // tile t+STAGES-1
+        const char* img = smem + (t % STAGES) * STAGE;
         const bool only_mfma = (g.dbg & 16) && t > 0;   // timing-only: registers of tile 0, no reads, no barriers
         if (!only_mfma) {
 #pragma unroll
@@ -400,11 +404,17 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
 #pragma unroll
             for (int j = 0; j < NT; ++j) b[j][s] = *reinterpret_cast<const bf16x8*>(img + s * (RT * 64) + offB[j]);
         }
-        if (grp == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // group 1 must have landed its pieces of tile t+1 (group 0 reads it after this barrier); with 3 stages its newest
+        // batch (tile t+2, issued one iteration ago) may stay in flight
+        if (grp == 1) {
+            if (STAGES == 3 && t >= 1 && t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER_WAVE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         bar();
         }
-        if (grp == 1 && t + 2 < nk && !(g.dbg & 8)) dma_stage(t & 1);
+        if (grp == 1 && t + STAGES < nk && !(g.dbg & 8)) dma_stage(t % STAGES);   // tile t+STAGES
         if (!(g.dbg & 2)) {
             if constexpr (NP == 3) {
                 // bf16 planes: cross terms of order <= 2, smallest first: (a plane, b plane)
@@ -429,7 +439,11 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
                                                                                __builtin_bit_cast(half8, a[i][TA[term]]), acc[i][j], 0, 0, 0);
             }
         }
-        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // group 0 must have landed its pieces of tile t+1 before it reads them; its newest batch (tile t+2) may stay in flight
+        if (grp == 0) {
+            if (STAGES == 3 && t >= 1 && t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (!only_mfma) bar();
     }
     if (grp == 0) bar();
@@ -524,8 +538,12 @@ int planes_split_transpose(const SplitTArgs& a, hipStream_t stream) {
 template <int WM, int WN, int MT, int NT, int NP>
 static int launch_planes_np(const PlanesGemmArgs& g, hipStream_t stream) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
-    const size_t lds = (size_t)2 * NP * (BM + BN) * 64;
-    auto kern = gemm_planes_kernel<WM, WN, MT, NT, NP>;
+    // The kernel also runs with 3 stages (counted vmcnt waits, the fp16 tiles leave room for it), but measured it brings
+    // nothing (459 vs 446 us over the hot-path shapes): the limit is L2 -> LDS throughput next to the MFMA stream, not
+    // the latency of a DMA batch.
+    constexpr int STAGES = 2;
+    const size_t lds = (size_t)STAGES * NP * (BM + BN) * 64;
+    auto kern = gemm_planes_kernel<WM, WN, MT, NT, NP, STAGES>;
     static bool attr_set = false;
     if (!attr_set) {
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
