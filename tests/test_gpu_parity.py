@@ -453,6 +453,32 @@ def test_decoder_loop_vs_oracle(B, T, H, E, L, S):
         close(p.grad, P[n].grad, "grad " + n, tol=3e-4)
 
 
+def test_decoder_greedy_matches_stock_step_loop():
+    """Evaluation mode: the fused greedy loop (argmax feedback on the device) against the stock-PyTorch step module
+    driven the way the reference's evaluation loop does (models.py:178-199); odd sizes (B=1, T=5 < one chunk, L > T)."""
+    from mmbidaf_amd.attention import MultimodalAttentionDecoder
+    from mmbidaf_amd.decoder import decoder_greedy
+    for B, T, H, E, L, S in [(1, 5, 8, 7, 9, 3), (5, 33, 10, 12, 40, 4)]:
+        g = torch.Generator().manual_seed(B + T)
+        torch.manual_seed(11 + H)
+        dec = MultimodalAttentionDecoder(E, H, L).to(dev()).eval()
+        enc_a, enc_i = torch.randn(B, T, 2 * H, generator=g).to(dev()), torch.randn(B, T, 2 * H, generator=g).to(dev())
+        h0, emb = torch.randn(B, H, generator=g).to(dev()), torch.randn(B, T, E, generator=g).to(dev())
+        mask = torch.zeros(B, L, dtype=torch.bool, device=dev())
+        mask[:, :T] = True
+        dists, att_cov, cov = decoder_greedy(dec, enc_a, enc_i, h0, emb, mask, S)
+        with torch.no_grad():
+            hidden, cell = h0.unsqueeze(1), torch.zeros(1, B, H, device=dev())
+            x, c = torch.zeros(B, 1, E, device=dev()), torch.zeros(B, T, 1, device=dev())
+            rows = torch.arange(B, device=dev())
+            for s in range(S):
+                dist, hidden, cell, ac, c = dec(x, hidden, cell, enc_a, enc_i, c, mask)
+                close(dists[s], dist.cpu(), f"dist step {s}")
+                x = emb[rows, dist.argmax(dim=1)].unsqueeze(1)
+            close(att_cov, ac[:, :, 0].cpu(), "att_cov (last step)")
+            close(cov, c[:, :, 0].cpu(), "coverage")
+
+
 # ------------------------------------------------------------------------------------------- model
 class _Stub(torch.nn.Module):
     def __init__(self, w, b):
