@@ -127,6 +127,154 @@ __global__ __launch_bounds__(256) void lstm_big_colsum_kernel(const float* __res
     atomicAdd(&d_b[c], acc);
 }
 
+// ------------------------------------------------------------------------------------------ skinny grouped product
+// C_p (M x N) = A_p (M x K) . op(B_p) for a table of products p, M <= 64 (the batch), exact f32 MFMA.  A workgroup is 4
+// independent waves; a wave owns one 16-column tile and the K range [k_lo, k_hi) (KS waves share a tile, splitting K; their
+// partial tiles meet in LDS at the end), stages its own 32-deep chunks of A and B in wave-private LDS (no block barrier in
+// the loop) and reads them back as the 8 consecutive k each lane feeds to the 8 MFMAs of a chunk.
+//   TB = 1: B is (N, K) row-major (pre = h . W_hh^T)      TB = 0: B is (K, N) row-major (dh = d_a . W_hh)
+struct SkinnyArgs {
+    const float* A[2 * MMB_MAX_GROUP];
+    const float* B[2 * MMB_MAX_GROUP];
+    float* C[2 * MMB_MAX_GROUP];
+    int M, N, K, ks;   // ks = waves sharing a column tile (1, 2 or 4)
+};
+
+template <bool TB>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
+    constexpr int LDA = 36;                       // 32 + 4 floats: 16-B aligned rows, conflict-light b128 reads
+    __shared__ __attribute__((aligned(16))) float As[4][64 * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[4][16 * LDA];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    const int p = blockIdx.y;
+    const float* A = a.A[p];
+    const float* B = a.B[p];
+    const int M = a.M, N = a.N, K = a.K, ks = a.ks;
+    const int tiles_per_wg = 4 / ks;
+    const int tile = blockIdx.x * tiles_per_wg + wave / ks, part = wave % ks;
+    const int n0 = tile * 16;
+    const int kchunk = ((K + ks - 1) / ks + 31) / 32 * 32;
+    const int k_lo = part * kchunk, k_hi = min(K, k_lo + kchunk);
+    f4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    float* as = As[wave];
+    float* bs = Bs[wave];
+    if (n0 < N && k_lo < k_hi) {
+        // every load is unconditional from a clamped address (K, N multiples of 4, so a float4 is valid or not as a whole)
+        // and zeroed by a select afterwards -- guarded loads would be waited for one by one.  The loads of chunk c+1 are
+        // issued before the fragment reads and MFMAs of chunk c (registers are the second buffer).
+        f4 va[8], vb[2];
+        auto fetch = [&](int k0) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = it * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+                va[it] = *reinterpret_cast<const f4*>(A + (size_t)min(row, M - 1) * K + min(k0 + c4, K - 4));
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int idx = it * 64 + lane;
+                if (TB) {
+                    const int col = idx >> 3, c4 = (idx & 7) * 4;
+                    vb[it] = *reinterpret_cast<const f4*>(B + (size_t)min(n0 + col, N - 1) * K + min(k0 + c4, K - 4));
+                } else {
+                    const int kk = idx >> 2, c4 = (idx & 3) * 4;
+                    vb[it] = *reinterpret_cast<const f4*>(B + (size_t)min(k0 + kk, K - 1) * N + min(n0 + c4, N - 4));
+                }
+            }
+        };
+        fetch(k_lo);
+        for (int k0 = k_lo; k0 < k_hi; k0 += 32) {
+            const f4 zero = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = it * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+                *reinterpret_cast<f4*>(as + row * LDA + c4) = (row < M && k0 + c4 < k_hi) ? va[it] : zero;
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int idx = it * 64 + lane;
+                if (TB) {
+                    const int col = idx >> 3, c4 = (idx & 7) * 4;
+                    *reinterpret_cast<f4*>(bs + col * LDA + c4) = (n0 + col < N && k0 + c4 < k_hi) ? vb[it] : zero;
+                } else {
+                    // B rows are k: 16 consecutive columns per row; transposed into [column][k] on the way to LDS
+                    const int kk = idx >> 2, c4 = (idx & 3) * 4;
+                    const f4 v = (k0 + kk < k_hi && n0 + c4 < N) ? vb[it] : zero;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bs[(c4 + e) * LDA + kk] = v[e];
+                }
+            }
+            if (k0 + 32 < k_hi) fetch(k0 + 32);
+            __builtin_amdgcn_wave_barrier();
+            // lane (r, kg) feeds k = k0 + 8*kg + s to MFMA step s: 8 consecutive floats of its A row / B column
+            f4 bq[2], aq[4][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) bq[h] = *reinterpret_cast<const f4*>(bs + r * LDA + 8 * kg + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) aq[i][h] = *reinterpret_cast<const f4*>(as + (i * 16 + r) * LDA + 8 * kg + 4 * h);
+#pragma unroll
+            for (int st = 0; st < 8; ++st)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = mfma16(aq[i][st >> 2][st & 3], bq[st >> 2][st & 3], acc[i]);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // lane (r, kg) holds C[m = 16 i + 4 kg + e][n = n0 + r]
+    float* C = a.C[p];
+    if (ks > 1) {
+        __syncthreads();
+        float* red = &As[0][0];   // [wave][64 rows][16 cols] partial tiles (4 x 4 KiB)
+        if (n0 < N) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wave * 1024 + (i * 16 + 4 * kg + e) * 16 + r] = acc[i][e];
+        }
+        __syncthreads();
+        if (part == 0 && n0 < N) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = i * 16 + 4 * kg + e;
+                    float v = 0.f;
+                    for (int q = 0; q < ks; ++q) v += red[(wave + q) * 1024 + m * 16 + r];
+                    if (m < M && n0 + r < N) C[(size_t)m * N + n0 + r] = v;
+                }
+        }
+    } else if (n0 < N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = i * 16 + 4 * kg + e;
+                if (m < M && n0 + r < N) C[(size_t)m * N + n0 + r] = acc[i][e];
+            }
+    }
+}
+
+static int skinny_launch(const float* const* A, const float* const* Bm, float* const* C, int count, int M, int N, int K, int tb,
+                         hipStream_t stream) {
+    SkinnyArgs a{};
+    for (int i = 0; i < count; ++i) { a.A[i] = A[i]; a.B[i] = Bm[i]; a.C[i] = C[i]; }
+    a.M = M; a.N = N; a.K = K;
+    const int tiles = (N + 15) / 16;
+    // as many waves as it takes to fill the chip: split K inside the workgroup while there are too few column tiles
+    a.ks = 1;
+    while (a.ks < 4 && (long)tiles * count * a.ks < 1024 && K / (a.ks * 2) >= 128) a.ks *= 2;
+    const int tiles_per_wg = 4 / a.ks;
+    const dim3 grid((tiles + tiles_per_wg - 1) / tiles_per_wg, count);
+    ProfScope ps_(MMB_K_GEMM, stream);
+    if (tb) hipLaunchKernelGGL(skinny_gemm_kernel<true>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(skinny_gemm_kernel<false>, grid, dim3(256), 0, stream, a);
+    MMB_HIP(hipGetLastError());
+    return MMB_OK;
+}
+
 // ------------------------------------------------------------------------------------------ host side
 static size_t rup256(size_t x) { return (x + 255) / 256 * 256; }
 // forward scratch of one problem: h_pack (2,B,H) | pre (2,B,4H);  backward: a_pack (2,B,4H) | dh_pack (2,B,H) | dc (2,B,H)
@@ -136,6 +284,7 @@ size_t lstm_big_bwd_ws_bytes(int B, int H) { return rup256((size_t)2 * B * 4 * H
 // one grouped product per (problem, direction): C = A . op(B)
 static int grouped_step_gemm(const float* const* A, const float* const* Bm, float* const* C, int count, int M, int N, int K,
                              int tb, hipStream_t stream) {
+    if (M <= 64) return skinny_launch(A, Bm, C, count, M, N, K, tb, stream);   // plain stores: no pre-zeroed C needed
     GemmArgs g{};
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = tb ? K : N; g.ldc = N; g.ta = 0; g.tb = tb; g.periodB = 1;
     g.batch = count; g.use_ptrs = 1; g.c_zeroed = 1;
