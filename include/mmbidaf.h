@@ -121,13 +121,16 @@ typedef struct {
     const float* b_hh[2];      /* (4H)                                                           */
     /* outputs */
     float* y;                  /* (B,T,2H) [fwd | rev], zeros at t >= len                        */
-    float* h_n;                /* (2,B,H) final hidden state per direction, batch order          */
+    float* h_n;                /* (2,B,H) final hidden state per direction, batch order -- or, with hn_pos,      */
+                               /* (B,2,H) with sample b in row hn_pos[b] (the reference returns h_n in            */
+                               /* descending-length order, encoding.py:100-101: hn_pos = inverse of that order)  */
     float* c_n;                /* (2,B,H)                                                         */
     /* saved for backward / scratch, caller-allocated */
     float* gx;                 /* (B,T,2,H,4) input projection, gate-interleaved                 */
     float* gates;              /* (B,T,2,H,4) post-activation i,f,g,o                            */
     float* cs;                 /* (B,T,2,H)   cell state after each step                         */
     void* ws;                  /* scratch of mmb_bilstm_ws_bytes(B,T,I,H,0) bytes (operand planes) or NULL          */
+    const int32_t* hn_pos;     /* (B) or NULL                                                                        */
     float* x_absmax;           /* (2) must be 0 on entry; receives [max |x|, max |W_ih|] (saved: the backward's     */
                                /* transposed fp16 planes are scaled by them); may be NULL when ws is NULL            */
     int32_t B, T, I, H;
@@ -143,7 +146,7 @@ int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* descs, int n, int device, void
 typedef struct {
     /* inputs */
     const float* d_y;          /* (B,T,2H) cotangent of y                                        */
-    const float* d_hn;         /* (2,B,H)  cotangent of h_n (batch order) or NULL                */
+    const float* d_hn;         /* (2,B,H)  cotangent of h_n (batch order; (B,2,H) rows hn_pos[b] with hn_pos) or NULL */
     const float* x;            /* (B,T,I)                                                        */
     const float* y;            /* (B,T,2H) forward output                                        */
     const int32_t* lengths;    /* (B)                                                            */
@@ -161,6 +164,7 @@ typedef struct {
     float* d_w_cat;            /* (8H, I+2H) or NULL: lets the library compute d_w_ih and both   */
                                /* d_w_hh with ONE GEMM against [x | y_fwd(t-1) | y_rev(t+1)]     */
     void* ws;                  /* scratch of mmb_bilstm_ws_bytes(B,T,I,H,1) bytes or NULL        */
+    const int32_t* hn_pos;     /* (B) or NULL: layout of d_hn, as in the forward desc             */
     const float* x_absmax;     /* (2) as left by the forward call                                 */
     int32_t B, T, I, H;
 } mmb_lstm_bwd_desc;

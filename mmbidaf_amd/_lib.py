@@ -26,7 +26,7 @@ class LstmFwdDesc(ctypes.Structure):
         ("x", c_f), ("lengths", c_f),
         ("w_ih", c_f * 2), ("w_hh", c_f * 2), ("b_ih", c_f * 2), ("b_hh", c_f * 2),
         ("y", c_f), ("h_n", c_f), ("c_n", c_f),
-        ("gx", c_f), ("gates", c_f), ("cs", c_f), ("ws", c_f), ("x_absmax", c_f),
+        ("gx", c_f), ("gates", c_f), ("cs", c_f), ("ws", c_f), ("hn_pos", c_f), ("x_absmax", c_f),
         ("B", ctypes.c_int32), ("T", ctypes.c_int32), ("I", ctypes.c_int32), ("H", ctypes.c_int32),
     ]
 
@@ -37,7 +37,7 @@ class LstmBwdDesc(ctypes.Structure):
         ("d_y", c_f), ("d_hn", c_f), ("x", c_f), ("y", c_f), ("lengths", c_f),
         ("w_ih", c_f * 2), ("w_hh", c_f * 2), ("gates", c_f), ("cs", c_f),
         ("d_x", c_f), ("d_w_ih", c_f), ("d_w_hh", c_f), ("d_b", c_f), ("d_a", c_f), ("d_w_cat", c_f), ("ws", c_f),
-        ("x_absmax", c_f),
+        ("hn_pos", c_f), ("x_absmax", c_f),
         ("B", ctypes.c_int32), ("T", ctypes.c_int32), ("I", ctypes.c_int32), ("H", ctypes.c_int32),
     ]
 

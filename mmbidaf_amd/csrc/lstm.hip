@@ -34,8 +34,9 @@ struct RecFwdProb {
     float* y;              // (B,T,2H)
     float* gates;          // (B,T,2,H,4)
     float* cs;             // (B,T,2,H)
-    float* h_n;            // (2,B,H)
+    float* h_n;            // (2,B,H), or (B,2,H) rows hn_pos[b] when hn_pos is given
     float* c_n;            // (2,B,H)
+    const int* hn_pos;     // (B) or null
     int B, T, H, wg_begin;
 };
 struct RecFwdArgs {
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (; s < len; ++s) step(gx_at(s));  // tail (< PF steps): synchronous loads
 
     if (tid < 4 * H) {
-        if (kq == 0) P.h_n[((size_t)dir * P.B + b) * H + u] = h;
+        if (kq == 0) P.h_n[(P.hn_pos ? ((size_t)P.hn_pos[b] * 2 + dir) : ((size_t)dir * P.B + b)) * H + u] = h;
         if (kq == 1) P.c_n[((size_t)dir * P.B + b) * H + u] = c;
     }
     // zero the padded tail of y (pad_packed_sequence, encoding.py:99)
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ------------------------------------------------------------------------------------------ BPTT
 struct RecBwdProb {
     const float* d_y;      // (B,T,2H)
-    const float* d_hn;     // (2,B,H) or null
+    const float* d_hn;     // (2,B,H) (or (B,2,H) rows hn_pos[b]) or null
+    const int* hn_pos;     // (B) or null
     const float* gates;    // (B,T,2,H,4)
     const float* cs;       // (B,T,2,H)
     const float* w_hh[2];  // (4H,H)
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int dstride = 16 * KQP;
 
     float c_t = len > 0 ? cs_b[t0 * 2 * H] : 0.f;
-    float dh = P.d_hn ? P.d_hn[((size_t)dir * P.B + b) * H + u] : 0.f;
+    float dh = P.d_hn ? P.d_hn[(P.hn_pos ? ((size_t)P.hn_pos[b] * 2 + dir) : ((size_t)dir * P.B + b)) * H + u] : 0.f;
     float dc = 0.f;
     float db_acc = 0.f, da_max = 0.f;
     int cur = 0;
@@ -641,7 +643,7 @@ extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int devic
         }
         RecFwdProb& q = ra.p[i];
         q.gx = p.gx; q.w_hh[0] = p.w_hh[0]; q.w_hh[1] = p.w_hh[1]; q.len = p.lengths;
-        q.y = p.y; q.gates = p.gates; q.cs = p.cs; q.h_n = p.h_n; q.c_n = p.c_n;
+        q.y = p.y; q.gates = p.gates; q.cs = p.cs; q.h_n = p.h_n; q.c_n = p.c_n; q.hn_pos = p.hn_pos;
         q.B = p.B; q.T = p.T; q.H = p.H; q.wg_begin = wg;
         wg += 2 * p.B;
     }
@@ -691,7 +693,7 @@ extern "C" int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* d, int n, int devic
         RecBwdProb& q = ra.p[i];
         q.db_part = part ? reinterpret_cast<float*>(static_cast<char*>(p.ws) + ws_bwd_layout((long)p.B * p.T, p.B, p.I, H).dbp) : nullptr;
         q.damax_part = part ? reinterpret_cast<float*>(static_cast<char*>(p.ws) + ws_bwd_layout((long)p.B * p.T, p.B, p.I, H).damax) : nullptr;
-        q.d_y = p.d_y; q.d_hn = p.d_hn; q.gates = p.gates; q.cs = p.cs;
+        q.d_y = p.d_y; q.d_hn = p.d_hn; q.hn_pos = p.hn_pos; q.gates = p.gates; q.cs = p.cs;
         q.w_hh[0] = p.w_hh[0]; q.w_hh[1] = p.w_hh[1]; q.len = p.lengths;
         q.d_a = p.d_a; q.d_b = p.d_b; q.B = p.B; q.T = p.T; q.H = p.H; q.wg_begin = wg;
         wg += 2 * p.B;

@@ -18,6 +18,7 @@ struct BigFwdProb {
     float* pre;             // (2,B,4H) this step's recurrent pre-activations, torch gate order (re-zeroed after reading)
     float* h_pack;          // (2,B,H)  h of the step before / after
     float* y; float* gates; float* cs; float* h_n; float* c_n;
+    const int* hn_pos;      // (B) or null: h_n as (B,2,H) rows hn_pos[b]
     int B, T, H;
 };
 struct BigFwdArgs { BigFwdProb p[MMB_MAX_GROUP]; int n; };
@@ -47,7 +48,10 @@ __global__ __launch_bounds__(256) void lstm_big_cell_kernel(const BigFwdArgs arg
     P.y[row * 2 * H + dir * H + u] = h;
     const size_t st = ((size_t)dir * P.B + b) * H + u;
     P.h_pack[st] = h;
-    if (s == len - 1) { P.h_n[st] = h; P.c_n[st] = c; }
+    if (s == len - 1) {
+        P.h_n[P.hn_pos ? ((size_t)P.hn_pos[b] * 2 + dir) * H + u : st] = h;
+        P.c_n[st] = c;
+    }
 }
 
 // rows t >= len[b] of a (B,T,W) tensor := 0   (y: pad_packed_sequence zeros, encoding.py:99;  d_a: dead steps)
@@ -61,15 +65,20 @@ __global__ __launch_bounds__(256) void lstm_big_zero_tail_kernel(float* __restri
 
 // samples with len == 0 never reach a last step: their h_n / c_n are zero
 __global__ __launch_bounds__(256) void lstm_big_empty_state_kernel(float* __restrict__ h_n, float* __restrict__ c_n,
-                                                                   const int* __restrict__ lens, int B, int H) {
+                                                                   const int* __restrict__ lens, const int* __restrict__ hn_pos,
+                                                                   int B, int H) {
     const int idx = blockIdx.x * 256 + threadIdx.x;   // over (dir, b, u)
     if (idx >= 2 * B * H) return;
-    const int b = (idx / H) % B;
-    if (lens[b] <= 0) { h_n[idx] = 0.f; c_n[idx] = 0.f; }
+    const int u = idx % H, b = (idx / H) % B, dir = idx / (H * B);
+    if (lens[b] <= 0) {
+        h_n[hn_pos ? ((size_t)hn_pos[b] * 2 + dir) * H + u : (size_t)idx] = 0.f;
+        c_n[idx] = 0.f;
+    }
 }
 
 struct BigBwdProb {
     const float* d_y; const float* d_hn; const float* gates; const float* cs;
+    const int* hn_pos;      // (B) or null: layout of d_hn
     const int* len;
     float* dh_pack;         // (2,B,H)  this step's recurrent dh (re-zeroed after reading)
     float* a_pack;          // (2,B,4H) d_a of the step before / after
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256) void lstm_big_dgate_kernel(const BigBwdArgs ar
     const size_t row = (size_t)b * T + t;
     float dh = dh_rec + P.d_y[row * 2 * H + dir * H + u];
     float dc = 0.f;
-    if (s == 0) { if (P.d_hn) dh += P.d_hn[st]; }
+    if (s == 0) { if (P.d_hn) dh += P.d_hn[P.hn_pos ? ((size_t)P.hn_pos[b] * 2 + dir) * H + u : st]; }
     else dc = P.dc[st];
     const f4 g4 = *reinterpret_cast<const f4*>(P.gates + (row * 2 + dir) * 4 * H + (size_t)u * 4);
     const float c_t = P.cs[row * 2 * H + dir * H + u];
@@ -307,7 +316,7 @@ int lstm_big_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* big_ws, hipStre
         MMB_HIP(hipMemsetAsync(h_pack, 0, lstm_big_fwd_ws_bytes(p.B, H), stream));   // h_pack and pre
         BigFwdProb& q = a.p[i];
         q.gx = p.gx; q.len = p.lengths; q.pre = pre; q.h_pack = h_pack;
-        q.y = p.y; q.gates = p.gates; q.cs = p.cs; q.h_n = p.h_n; q.c_n = p.c_n;
+        q.y = p.y; q.gates = p.gates; q.cs = p.cs; q.h_n = p.h_n; q.c_n = p.c_n; q.hn_pos = p.hn_pos;
         q.B = p.B; q.T = p.T; q.H = H;
         for (int dir = 0; dir < 2; ++dir) {
             Ap[2 * i + dir] = h_pack + (size_t)dir * p.B * H;
@@ -328,7 +337,7 @@ int lstm_big_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* big_ws, hipStre
     for (int i = 0; i < n; ++i) {
         const mmb_lstm_fwd_desc& p = d[i];
         hipLaunchKernelGGL(lstm_big_zero_tail_kernel, dim3(64, p.B), dim3(256), 0, stream, p.y, p.lengths, p.B, p.T, 2 * H);
-        hipLaunchKernelGGL(lstm_big_empty_state_kernel, dim3((2 * p.B * H + 255) / 256), dim3(256), 0, stream, p.h_n, p.c_n, p.lengths, p.B, H);
+        hipLaunchKernelGGL(lstm_big_empty_state_kernel, dim3((2 * p.B * H + 255) / 256), dim3(256), 0, stream, p.h_n, p.c_n, p.lengths, p.hn_pos, p.B, H);
     }
     MMB_HIP(hipGetLastError());
     return MMB_OK;
@@ -348,7 +357,7 @@ int lstm_big_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* big_ws, hipStre
         float* dc = reinterpret_cast<float*>(big_ws[i] + rup256((size_t)2 * p.B * 4 * H * 4) + rup256((size_t)2 * p.B * H * 4));
         MMB_HIP(hipMemsetAsync(a_pack, 0, lstm_big_bwd_ws_bytes(p.B, H), stream));   // a_pack, dh_pack, dc
         BigBwdProb& q = a.p[i];
-        q.d_y = p.d_y; q.d_hn = p.d_hn; q.gates = p.gates; q.cs = p.cs; q.len = p.lengths;
+        q.d_y = p.d_y; q.d_hn = p.d_hn; q.hn_pos = p.hn_pos; q.gates = p.gates; q.cs = p.cs; q.len = p.lengths;
         q.dh_pack = dh_pack; q.a_pack = a_pack; q.d_a = p.d_a; q.dc = dc;
         q.B = p.B; q.T = p.T; q.H = H;
         for (int dir = 0; dir < 2; ++dir) {

@@ -106,13 +106,21 @@ def encode_group(encoders, xs, lengths_list):
     for x, l in zip(xs, lengths_list):
         if len(l) != x.size(0) or min(l) < 1 or max(l) > x.size(1):
             raise ValueError("lengths must have one entry per sample with 1 <= len <= seq_len")
+    # position of every sample in the reference's descending-length order (Q3): the kernels write h_n straight into
+    # that order -- (B,2,H) per layer -- instead of a gather afterwards (and read its cotangent the same way)
+    def inverse_order(lengths):
+        order = sorted_order(lengths)
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(order.numel())
+        return inv.to(torch.int32)
+    pos_dev = [to_device_cached("hn_pos", l, dev, lambda l=l: inverse_order(l)) for l in lengths_list]
     inputs = list(xs)
     h_all = [[] for _ in range(n)]
     for k in range(L):
         problems = []
-        for e, inp, ld in zip(encoders, inputs, lens_dev):
+        for e, inp, ld, pd in zip(encoders, inputs, lens_dev, pos_dev):
             fwd, rev = lstm_direction_params(e.rnn, k)
-            problems.append((inp, ld, fwd, rev))
+            problems.append((inp, ld, fwd, rev, pd))
         outs = MF.bilstm_layer(problems)
         for i, (y, h_n) in enumerate(outs):
             h_all[i].append(h_n)
@@ -123,9 +131,8 @@ def encode_group(encoders, xs, lengths_list):
     results = []
     for e, y, hs, lengths in zip(encoders, inputs, h_all, lengths_list):
         y = F.dropout(y, e.drop_prob, e.training)                  # encoding.py:104, also for 1-layer encoders
-        h_n = torch.cat(hs, dim=0)                                 # (2L,B,H): [l0_fwd, l0_bwd, l1_fwd, l1_bwd] (Q4)
-        idx = to_device_cached("sort_idx", lengths, dev, lambda lengths=lengths: sorted_order(lengths))
-        results.append((y, h_n[:, idx].transpose(0, 1)))           # h_n stays in length-sorted order (Q3)
+        h_n = hs[0] if len(hs) == 1 else torch.cat(hs, dim=1)      # (B,2L,H): [l0_fwd, l0_bwd, l1_fwd, l1_bwd] (Q4),
+        results.append((y, h_n))                                   # rows already in length-sorted order (Q3)
     return results
 
 

@@ -124,10 +124,11 @@ class _BiLSTMLayerFn(torch.autograd.Function):
     """One bidirectional LSTM layer for n co-scheduled encoders (reference: nn.LSTM on a packed
     batch, layers/encoding.py:79-81,96; rows L2-L4, L-bwd).  Flat tensor args per problem:
     x, w_ih, w_hh, b_ih, b_hh (forward), w_ih, w_hh, b_ih, b_hh (reverse).
-    Returns (y_0, h_n_0, y_1, h_n_1, ...) with y (B,T,2H) and h_n (2,B,H) in batch order."""
+    Returns (y_0, h_n_0, y_1, h_n_1, ...) with y (B,T,2H) and h_n (2,B,H) in batch order -- or, for a problem with
+    an hn_pos tensor, h_n (B,2,H) with sample b in row hn_pos[b] (the reference's length-sorted h_n, written in place)."""
 
     @staticmethod
-    def forward(ctx, lengths_dev, *flat):
+    def forward(ctx, lengths_dev, hn_pos, *flat):
         lib = _lib.load()
         n = len(lengths_dev)
         assert len(flat) == n * _PER_PROBLEM and 1 <= n <= _lib.MAX_GROUP
@@ -146,7 +147,7 @@ class _BiLSTMLayerFn(torch.autograd.Function):
                 raise RuntimeError(f"mmbidaf_amd: hidden size {H} not supported (max {_lib.LSTM_GENERAL_MAX_H}; "
                                    f"above {_lib.LSTM_MAX_H} the hidden and input sizes must be multiples of 4)")
             y = torch.empty(B, T, 2 * H, device=dev, dtype=torch.float32)
-            h_n = torch.empty(2, B, H, device=dev, dtype=torch.float32)
+            h_n = torch.empty((B, 2, H) if hn_pos[i] is not None else (2, B, H), device=dev, dtype=torch.float32)
             c_n = torch.empty(2, B, H, device=dev, dtype=torch.float32)
             gx = torch.empty(B, T, 8 * H, device=dev, dtype=torch.float32)
             gates = torch.empty(B, T, 8 * H, device=dev, dtype=torch.float32)
@@ -159,6 +160,7 @@ class _BiLSTMLayerFn(torch.autograd.Function):
                                                               _ptr(ws_[4 * k + 2]), _ptr(ws_[4 * k + 3]))
             d.y, d.h_n, d.c_n, d.gx, d.gates, d.cs = _ptr(y), _ptr(h_n), _ptr(c_n), _ptr(gx), _ptr(gates), _ptr(cs)
             d.ws = _ptr(ws) if ws.numel() else None
+            d.hn_pos = _ptr(hn_pos[i])
             d.x_absmax = x_absmax[i].data_ptr()
             d.B, d.T, d.I, d.H = B, T, I, H
             keep += [x, gx, c_n, ws] + ws_
@@ -167,7 +169,8 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         rc = lib.mmb_bilstm_layer_fwd(descs, n, dev.index, _stream())
         _lib.check(rc, "mmb_bilstm_layer_fwd")
         ctx.n = n
-        ctx.need_dx = [bool(ctx.needs_input_grad[1 + i * _PER_PROBLEM]) for i in range(n)]
+        ctx.hn_pos = list(hn_pos)
+        ctx.need_dx = [bool(ctx.needs_input_grad[2 + i * _PER_PROBLEM]) for i in range(n)]
         ctx.save_for_backward(*saved)
         return tuple(outs)
 
@@ -200,23 +203,25 @@ class _BiLSTMLayerFn(torch.autograd.Function):
             d.d_x, d.d_w_ih, d.d_w_hh, d.d_b, d.d_a = _ptr(d_x), _ptr(d_w_ih), _ptr(d_w_hh), _ptr(d_b), _ptr(d_a)
             d.d_w_cat = _ptr(d_w_cat)
             d.ws = _ptr(ws) if ws.numel() else None
+            d.hn_pos = _ptr(ctx.hn_pos[i])
             d.x_absmax = _ptr(x_absmax)
             d.B, d.T, d.I, d.H = B, T, I, H
             keep += [d_y, d_hn, d_a, d_w_cat, ws]
             results += [d_x, d_w_ih[0], d_w_hh[0], d_b[0], d_b[0], d_w_ih[1], d_w_hh[1], d_b[1], d_b[1]]
         rc = lib.mmb_bilstm_layer_bwd(descs, n, dev.index, _stream())
         _lib.check(rc, "mmb_bilstm_layer_bwd")
-        return (None, *results)
+        return (None, None, *results)
 
 
 def bilstm_layer(problems):
-    """problems: list of (x, lengths_i32_device, [w_ih, w_hh, b_ih, b_hh] fwd, [..] reverse).
-    Returns list of (y, h_n) -- h_n (2,B,H) in batch order."""
+    """problems: list of (x, lengths_i32_device, [w_ih, w_hh, b_ih, b_hh] fwd, [..] reverse[, hn_pos_i32_device]).
+    Returns list of (y, h_n) -- h_n (2,B,H) in batch order, or (B,2,H) in rows hn_pos[b] when hn_pos is given."""
     lengths = [p[1] for p in problems]
+    hn_pos = [p[4] if len(p) > 4 else None for p in problems]
     flat = []
-    for x, _, wf, wr in problems:
-        flat += [x] + list(wf) + list(wr)
-    outs = _BiLSTMLayerFn.apply(lengths, *flat)
+    for p in problems:
+        flat += [p[0]] + list(p[2]) + list(p[3])
+    outs = _BiLSTMLayerFn.apply(lengths, hn_pos, *flat)
     return [(outs[2 * i], outs[2 * i + 1]) for i in range(len(problems))]
 
 

@@ -25,8 +25,8 @@ def test_cabi_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), "ctypes binding table out of sync with the header"
     assert _lib.load().mmb_version() == 100
     # struct layouts mirror the header (pointer/int counts)
-    assert ctypes.sizeof(_lib.LstmFwdDesc) == 8 * 18 + 4 * 4
-    assert ctypes.sizeof(_lib.LstmBwdDesc) == 8 * 19 + 4 * 4
+    assert ctypes.sizeof(_lib.LstmFwdDesc) == 8 * 19 + 4 * 4
+    assert ctypes.sizeof(_lib.LstmBwdDesc) == 8 * 20 + 4 * 4
 
 
 def test_product_never_imports_the_oracle():
