@@ -161,8 +161,8 @@ class _DecoderLoopFn(torch.autograd.Function):
 def decoder_loop(dec, enc_a, enc_i, h0, X, mask):
     """Teacher-forced decode: X (S,B,E) decoder inputs of every step, h0 (B,H), mask (B,L).
     Returns dists (S,B,L), att_cov (S,B,T), coverage after each step (S,B,T)."""
-    proj_a = torch.nn.functional.linear(enc_a, dec.W1.weight, dec.W1.bias)     # loop-invariant (attention.py:147)
-    proj_i = torch.nn.functional.linear(enc_i, dec.W3.weight, dec.W3.bias)     # (attention.py:153)
+    proj_a = MF.linear(enc_a, dec.W1.weight, dec.W1.bias)     # loop-invariant (attention.py:147), library GEMM
+    proj_i = MF.linear(enc_i, dec.W3.weight, dec.W3.bias)     # (attention.py:153)
     return _DecoderLoopFn.apply(enc_a, enc_i, proj_a, proj_i, h0, X, mask, *decoder_tensors(dec))
 
 
@@ -173,8 +173,8 @@ def decoder_greedy(dec, enc_a, enc_i, h0, embedded_text, mask, steps):
     lib = _lib.load()
     MF._require_gpu(enc_a, enc_i, h0, embedded_text, mask)
     enc_a, enc_i, h0, emb = (MF._f32c(t) for t in (enc_a, enc_i, h0, embedded_text))
-    proj_a = MF._f32c(torch.nn.functional.linear(enc_a, dec.W1.weight, dec.W1.bias))
-    proj_i = MF._f32c(torch.nn.functional.linear(enc_i, dec.W3.weight, dec.W3.bias))
+    proj_a = MF.linear(enc_a, dec.W1.weight, dec.W1.bias)
+    proj_i = MF.linear(enc_i, dec.W3.weight, dec.W3.bias)
     B, T, H2 = enc_a.shape
     H, E, L = h0.shape[1], emb.shape[2], dec.out.weight.shape[0]
     mask = MF._mask_u8(mask, B, L)

@@ -316,3 +316,30 @@ def embedding_forward(x, w_proj, gates, transforms):
         layers += [g.weight, g.bias, t.weight, t.bias]
     y = _EmbeddingFn.apply(flat, w_proj, *layers)
     return y.reshape(*x.shape[:-1], w_proj.shape[0])
+
+
+# --------------------------------------------------------------------------------------- plain linear layer
+class _LinearFn(torch.autograd.Function):
+    """y = x . w^T + b on the library GEMM, forward and backward (used for the decoder's hoisted memory projections,
+    attention.py:147,153: rocBLAS picks a poor tile for the 12800 x 200 x 200 shape)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = _f32c(x.reshape(-1, x.shape[-1]))
+        w = _f32c(w)
+        ctx.save_for_backward(x2, w)
+        ctx.xshape = x.shape
+        return gemm(x2, w, bias=_f32c(b), tb=True).reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x2, w = ctx.saved_tensors
+        dy = _f32c(d_y.reshape(-1, d_y.shape[-1]))
+        d_x = gemm(dy, w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        d_w = gemm(dy, x2, ta=True) if ctx.needs_input_grad[1] else None
+        d_b = dy.sum(0) if ctx.needs_input_grad[2] else None
+        return d_x, d_w, d_b
+
+
+def linear(x, w, b):
+    return _LinearFn.apply(x, w, b)
