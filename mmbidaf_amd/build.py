@@ -1,34 +1,61 @@
-"""In-tree build of libmmbidaf_hip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""In-tree build of libmmbidaf_hip.so with hipcc for gfx950 (cross-compiles without a GPU).
+Every translation unit is compiled to its own object (in parallel, rebuilt only when it or a header changed), then
+linked; objects live under mmbidaf_amd/csrc/build/ (git-ignored, like the .so)."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["api.hip", "gemm.hip", "gemm_bf16.hip", "planes.hip", "lstm.hip", "lstm_big.hip", "bidaf.hip", "bidaf_big.hip", "decoder.hip", "highway.hip"]
+OBJ = os.path.join(CSRC, "build")
+SOURCES = ["api.hip", "gemm.hip", "gemm_bf16.hip", "planes.hip", "lstm.hip", "lstm_big.hip", "bidaf.hip", "bidaf_big.hip",
+           "decoder.hip", "highway.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "mmbidaf.h")]
 LIB = os.path.join(_HERE, "libmmbidaf_hip.so")
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-result"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _headers():
+    hs = [os.path.join(CSRC, h) for h in HEADERS]
+    hs += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") and os.path.join(CSRC, f) not in hs]
+    return hs
+
+
+def _newer(path, deps):
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    t = os.path.getmtime(path)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -shared ... -> mmbidaf_amd/libmmbidaf_hip.so"""
+def _stale():
+    return _newer(LIB, [os.path.join(CSRC, s) for s in SOURCES] + _headers())
+
+
+def build_library(force=False, verbose=False, jobs=None):
+    """hipcc --offload-arch=gfx950 -c each source, then -shared -> mmbidaf_amd/libmmbidaf_hip.so"""
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
-           "-Wno-unused-result"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = _headers()
+    todo = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s + ".o")
+        if force or _newer(obj, [src] + hdrs):
+            todo.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    jobs = jobs or min(6, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
+        list(ex.map(run, todo))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJ, s + ".o") for s in SOURCES] + ["-o", LIB])
     return LIB
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,6 +1,7 @@
 // Error plumbing and version entry points of libmmbidaf_hip.so.
 #include <stdarg.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -22,24 +23,39 @@ int fail(int code, const char* fmt, ...) {
 }
 
 // ---------------------------------------------------------------- opt-in kernel timing
+// Events belong to the device that was current when they were created, so the free pool is kept per device; the mask is
+// read without the lock (atomic); the lock only guards the vectors and is never held across a HIP synchronisation.
+constexpr int MAX_DEV = 64;
 struct EvPair {
     hipEvent_t a, b;
+    int dev;
 };
 static std::mutex g_prof_mu;
-static uint32_t g_prof_mask = 0;
+static std::atomic<uint32_t> g_prof_mask{0};
 static std::vector<EvPair> g_prof_done[MMB_K_COUNT];
-static std::vector<EvPair> g_prof_pool;
+static std::vector<EvPair> g_prof_pool[MAX_DEV];
 
 ProfScope::ProfScope(int id_, hipStream_t s) : id(id_), stream(s), slot(nullptr) {
-    if (!(g_prof_mask & (1u << id))) return;
-    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!(g_prof_mask.load(std::memory_order_relaxed) & (1u << id))) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);   // entry points hipSetDevice(device) before they launch
+    dev &= MAX_DEV - 1;
     EvPair* p = new EvPair;
-    if (!g_prof_pool.empty()) {
-        *p = g_prof_pool.back();
-        g_prof_pool.pop_back();
-    } else if (hipEventCreate(&p->a) != hipSuccess || hipEventCreate(&p->b) != hipSuccess) {
-        delete p;
-        return;
+    bool have = false;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof_pool[dev].empty()) {
+            *p = g_prof_pool[dev].back();
+            g_prof_pool[dev].pop_back();
+            have = true;
+        }
+    }
+    if (!have) {
+        p->dev = dev;
+        if (hipEventCreate(&p->a) != hipSuccess || hipEventCreate(&p->b) != hipSuccess) {
+            delete p;
+            return;
+        }
     }
     (void)hipEventRecord(p->a, stream);
     slot = p;
@@ -57,25 +73,30 @@ ProfScope::~ProfScope() {
 }  // namespace mmb
 
 extern "C" int mmb_profile_enable(uint32_t kernel_mask) {
-    std::lock_guard<std::mutex> lk(mmb::g_prof_mu);
-    mmb::g_prof_mask = kernel_mask;
+    mmb::g_prof_mask.store(kernel_mask, std::memory_order_relaxed);
     return MMB_OK;
 }
 
 extern "C" int mmb_profile_read(int kernel_id, double* total_ms, int* launches) {
     MMB_REQUIRE(kernel_id >= 0 && kernel_id < MMB_K_COUNT && total_ms && launches, "mmb_profile_read: bad argument");
-    std::lock_guard<std::mutex> lk(mmb::g_prof_mu);
+    std::vector<mmb::EvPair> done;
+    {
+        std::lock_guard<std::mutex> lk(mmb::g_prof_mu);
+        done.swap(mmb::g_prof_done[kernel_id]);
+    }
     double tot = 0.0;
     int n = 0;
-    for (auto& p : mmb::g_prof_done[kernel_id]) {
+    for (auto& p : done) {   // synchronise outside the lock: concurrent launches keep recording
         float ms = 0.f;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             tot += ms;
             ++n;
         }
-        mmb::g_prof_pool.push_back(p);
     }
-    mmb::g_prof_done[kernel_id].clear();
+    {
+        std::lock_guard<std::mutex> lk(mmb::g_prof_mu);
+        for (auto& p : done) mmb::g_prof_pool[p.dev].push_back(p);
+    }
     *total_ms = tot;
     *launches = n;
     return MMB_OK;

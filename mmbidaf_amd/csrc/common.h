@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/mmbidaf.h"
 
 namespace mmb {
@@ -28,6 +30,20 @@ int fail(int code, const char* fmt, ...);
     do {                                                        \
         if (!(cond)) return mmb::fail(MMB_ERR_ARG, __VA_ARGS__); \
     } while (0)
+
+// ---- per-device one-time setup (hipFuncSetAttribute is per device; entry points hipSetDevice(device) first).
+// `pending()` is true until `mark()` has run on the calling thread's current device; a racing second thread at worst
+// repeats the (idempotent) setup before either marks it done.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    static unsigned long long bit() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return 1ull << (d & 63);
+    }
+    bool pending() const { return !(done.load(std::memory_order_acquire) & bit()); }
+    void mark() { done.fetch_or(bit(), std::memory_order_release); }
+};
 
 // ---- opt-in per-kernel timing (api.hip)
 struct ProfScope {

@@ -739,11 +739,11 @@ extern "C" int mmb_decoder_step_fwd(const mmb_decoder_params* w, const float* en
     const size_t lds = dec_lds_floats(T, H, w->E, w->L) * sizeof(float);
     const size_t lds_att = (size_t)(((H + 3) & ~3) + ((H2 + 3) & ~3) + DEC_NW * (H2 + 2) + 16) * sizeof(float);
     MMB_REQUIRE(lds <= 160 * 1024 && lds_att <= 160 * 1024, "mmb_decoder_step_fwd: T=%d L=%d too large for one workgroup's LDS", T, w->L);
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.pending()) {
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_step_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_att_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+        attr.mark();
     }
     hipLaunchKernelGGL(decoder_att_fwd_kernel, dim3(B, 2 * a.nch), dim3(DEC_NT), lds_att, stream, a);
     hipLaunchKernelGGL(decoder_step_fwd_kernel, dim3(B), dim3(DEC_NT), lds, stream, a);
@@ -782,11 +782,11 @@ extern "C" int mmb_decoder_step_bwd(const mmb_decoder_params* w, const float* en
     const size_t lds_att = (size_t)(((H + 3) & ~3) + 2 * ((H2 + 3) & ~3) + DEC_NW * 3 * H2 + 16) * sizeof(float);
     const size_t lds_fin = (size_t)(2 * ((H2 + 3) & ~3) + ((H + 3) & ~3) + DEC_NT) * sizeof(float);
     MMB_REQUIRE(lds <= 160 * 1024 && lds_att <= 160 * 1024, "mmb_decoder_step_bwd: T=%d L=%d too large for one workgroup's LDS", T, w->L);
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.pending()) {
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_step_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_att_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+        attr.mark();
     }
     hipLaunchKernelGGL(decoder_step_bwd_kernel, dim3(B), dim3(DEC_NT), lds, stream, a);
     hipLaunchKernelGGL(decoder_att_bwd_kernel, dim3(B, 2 * a.nch), dim3(DEC_NT), lds_att, stream, a);

@@ -275,11 +275,11 @@ static int launch_bf16(const GemmArgs& g, int splitk, hipStream_t stream) {
 #define MMB_L(TA_, TB_)                                                                                               \
     do {                                                                                                              \
         auto kern = gemm_bf16_kernel<WAVES, MT, NT, TA_, TB_, NS>;                                                    \
-        static bool attr_set = false;                                                                                 \
-        if (!attr_set) {                                                                                              \
+        static PerDeviceOnce attr_set;                                                                                \
+        if (attr_set.pending()) {                                                                                     \
             MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                         (int)lds));                                                                   \
-            attr_set = true;                                                                                          \
+            attr_set.mark();                                                                                          \
         }                                                                                                             \
         hipLaunchKernelGGL(kern, grid, block, lds, stream, g, kchunk);                                                \
     } while (0)

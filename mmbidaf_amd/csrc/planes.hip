@@ -544,10 +544,10 @@ static int launch_planes_np(const PlanesGemmArgs& g, hipStream_t stream) {
     constexpr int STAGES = 2;
     const size_t lds = (size_t)STAGES * NP * (BM + BN) * 64;
     auto kern = gemm_planes_kernel<WM, WN, MT, NT, NP, STAGES>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr;
+    if (attr.pending()) {
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr.mark();
     }
     const int tiles_n = (g.N + BN - 1) / BN, ntiles = tiles_n * ((g.M + BM - 1) / BM);
     int kchunk = (g.K + g.splitk - 1) / g.splitk;

@@ -1,7 +1,12 @@
-"""Batch-sharded data parallelism: one process per GPU, parameters replicated, ONE all-reduce of
-a flat fp32 gradient buffer per step over RCCL/xGMI (backend "nccl" on ROCm) -- the MI355X-native
-replacement of the reference's single-process nn.DataParallel (train.py:92).  The only exchange
-step of the hot path; with the "gloo" backend the same code runs on CPU."""
+"""Batch-sharded data parallelism: one process per GPU, parameters replicated, the gradients reduced over
+RCCL/xGMI (backend "nccl" on ROCm) through ONE flat fp32 buffer -- the MI355X-native replacement of the reference's
+single-process nn.DataParallel (train.py:92).  The only exchange step of the hot path;
+with the "gloo" backend the same code runs on CPU.
+
+The buffer is cut into buckets that follow the order in which backward finishes the gradients (modelling encoders
+first, input encoders last): with overlap=True each bucket's all-reduce is launched asynchronously from a
+post-accumulate-grad hook as soon as its last gradient exists, so the exchange of the big modelling-encoder weights
+(2.0 of the 2.4 M hot-path parameters) runs on RCCL's stream under the rest of the backward pass."""
 import os
 
 import torch
@@ -36,17 +41,96 @@ def shard_range(global_batch, rank, world):
     return rank * per, (rank + 1) * per
 
 
-class FlatGradAllReduce:
-    """Averages the gradients of `params` across ranks with a single all-reduce of one flat buffer."""
+def region_buckets(region):
+    """Parameter buckets of a HotRegion / MMBiDAF in the order backward completes them: second then first layer of the
+    two modelling encoders (grouped launches, models.py:134-135), the two attentions, the three input encoders; any
+    other trainable parameter (decoder, embeddings) goes first / last by position in the graph."""
+    named = [(n, p) for n, p in region.named_parameters() if p.requires_grad]
 
-    def __init__(self, params, group=None):
-        self.params = [p for p in params if p.requires_grad]
+    def pick(pred):
+        return [p for n, p in named if pred(n)]
+    is_mod = lambda n: n.startswith("mod_t_a.") or n.startswith("mod_t_i.")
+    is_l1 = lambda n: "_l1" in n
+    is_att = lambda n: n.startswith("bidaf_att_")
+    is_enc = lambda n: n.split(".")[0] in ("text_enc", "audio_enc", "image_enc")
+    is_dec = lambda n: n.startswith("multimodal_att_decoder.")
+    order = [pick(is_dec), pick(lambda n: is_mod(n) and is_l1(n)), pick(lambda n: is_mod(n) and not is_l1(n)),
+             pick(is_att), pick(is_enc),
+             pick(lambda n: not (is_mod(n) or is_att(n) or is_enc(n) or is_dec(n)))]
+    return [b for b in order if b]
+
+
+class FlatGradAllReduce:
+    """Reduces the gradients of `params` across ranks through one flat buffer.
+
+    average=False (default): SUM.  The reference's loss is a SUM over the samples of the batch (models.py:168-176), so
+    the gradient of the global batch is the sum of the shard gradients -- what one process on the whole batch (the
+    reference's nn.DataParallel, train.py:92) computes, and what its clip threshold and step size see.
+    average=True divides by the world size afterwards (mean-loss conventions).
+
+    buckets: optional list of parameter lists (see region_buckets); default one bucket = one all-reduce.
+    overlap=True: every bucket is packed and all-reduced asynchronously the moment backward has produced its last
+    gradient (post-accumulate-grad hooks); __call__ then only launches what is still missing, waits and copies back.
+
+    The reduced values are copied back into the tensors autograd produced (p.grad is never rebound to a view of the
+    flat buffer); a parameter without a gradient contributes zeros and keeps grad None."""
+
+    def __init__(self, params, group=None, average=False, buckets=None, overlap=False):
+        params = [p for p in params if p.requires_grad]
+        if buckets is None:
+            buckets = [params]
+        else:
+            buckets = [[p for p in b if p.requires_grad] for b in buckets]
+            seen = {id(p) for b in buckets for p in b}
+            rest = [p for p in params if id(p) not in seen]
+            if rest:
+                buckets = buckets + [rest]
+        self.buckets = [b for b in buckets if b]
+        self.params = [p for b in self.buckets for p in b]
+        assert len({id(p) for p in self.params}) == len(self.params), "a parameter appears in two buckets"
         self.group = group
-        self.numel = sum(p.numel() for p in self.params)
+        self.average = average
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        p0 = self.params[0]
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=p0.device)
-        self.sizes = [p.numel() for p in self.params]
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=self.params[0].device)
+        self.slices, self.chunks = [], []
+        o = 0
+        for b in self.buckets:
+            n = sum(p.numel() for p in b)
+            sl = self.flat[o:o + n]
+            self.slices.append(sl)
+            self.chunks.append([c.view_as(p) for c, p in zip(sl.split([p.numel() for p in b]), b)])
+            o += n
+        self.work = [None] * len(self.buckets)
+        self.pending = [0] * len(self.buckets)
+        self.overlap = bool(overlap) and self.world > 1
+        self._hooks = []
+        if self.overlap:
+            for bi, b in enumerate(self.buckets):
+                for p in b:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(lambda p_, bi=bi: self._on_grad(bi)))
+            self._arm()
+
+    def _arm(self):
+        self.pending = [len(b) for b in self.buckets]
+
+    def _on_grad(self, bi):
+        self.pending[bi] -= 1
+        if self.pending[bi] == 0 and self.work[bi] is None:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        with torch.no_grad():
+            grads = [p.grad for p in self.buckets[bi]]
+            if all(g is not None for g in grads):
+                torch.cat([g.reshape(-1) for g in grads], out=self.slices[bi])    # one packing kernel
+            else:
+                for g, c in zip(grads, self.chunks[bi]):
+                    if g is None:
+                        c.zero_()
+                    else:
+                        c.copy_(g)
+            self.work[bi] = dist.all_reduce(self.slices[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def broadcast_parameters(self, src=0):
         """Make every replica start from rank `src`'s parameters (one flat broadcast)."""
@@ -55,17 +139,30 @@ class FlatGradAllReduce:
         with torch.no_grad():
             buf = torch.cat([p.detach().reshape(-1) for p in self.params])
             dist.broadcast(buf, src, group=self.group)
-            for p, chunk in zip(self.params, buf.split(self.sizes)):
+            for p, chunk in zip(self.params, buf.split([p.numel() for p in self.params])):
                 p.copy_(chunk.view_as(p))
 
     def __call__(self):
-        """grad <- mean over ranks (in place).  Parameters without a gradient contribute zeros."""
+        """Call after backward: grad <- sum (or mean) over ranks, in place."""
         if self.world == 1:
             return
+        for bi in range(len(self.buckets)):
+            if self.work[bi] is None:
+                self._launch(bi)
         with torch.no_grad():
-            torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params],
-                      out=self.flat)
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.mul_(1.0 / self.world)
-            for p, chunk in zip(self.params, self.flat.split(self.sizes)):
-                p.grad = chunk.view_as(p)
+            for bi, b in enumerate(self.buckets):
+                self.work[bi].wait()          # the current stream waits for the collective (no host sync with nccl)
+                self.work[bi] = None
+                if self.average:
+                    self.slices[bi].mul_(1.0 / self.world)
+                dst = [p.grad for p in b if p.grad is not None]
+                src = [c for p, c in zip(b, self.chunks[bi]) if p.grad is not None]
+                if dst:
+                    torch._foreach_copy_(dst, src)
+        if self.overlap:
+            self._arm()
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

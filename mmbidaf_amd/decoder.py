@@ -143,18 +143,21 @@ class _DecoderLoopFn(torch.autograd.Function):
         g = [None] * 30
         g[0], g[1] = tg(dl_ha, h_prev), flat(dl_ha).sum(0)                                  # W2, b2
         g[2], g[3] = tg(dl_hi, h_prev), flat(dl_hi).sum(0)                                  # W4, b4
-        g[4], g[5], g[6], g[7] = V[0:H2], g[1], V[H2:2 * H2], V[6 * H2:6 * H2 + 1]          # Wc1, its bias, v1, its bias
-        g[8], g[9], g[10], g[11] = V[2 * H2:3 * H2], g[3], V[3 * H2:4 * H2], V[6 * H2 + 1:6 * H2 + 2]
+        g[4], g[5], g[6], g[7] = V[0:H2], g[1].clone(), V[H2:2 * H2], V[6 * H2:6 * H2 + 1]  # Wc1, its bias, v1, its bias
+        g[8], g[9], g[10], g[11] = V[2 * H2:3 * H2], g[3].clone(), V[3 * H2:4 * H2], V[6 * H2 + 1:6 * H2 + 2]
         g[12], g[13] = tg(dl_b1, ctx_a), flat(dl_b1).sum(0)                                 # W_beta_1
-        g[14], g[15] = tg(dl_b1, h_prev), g[13]                                             # W_beta_2
+        g[14], g[15] = tg(dl_b1, h_prev), g[13].clone()                                     # W_beta_2
         g[16], g[17] = tg(dl_b2, ctx_i), flat(dl_b2).sum(0)                                 # W_beta_3
-        g[18], g[19] = tg(dl_b2, h_prev), g[17]                                             # W_beta_4
+        g[18], g[19] = tg(dl_b2, h_prev), g[17].clone()                                     # W_beta_4
         g[20], g[21] = V[4 * H2:5 * H2], V[6 * H2 + 2:6 * H2 + 3]                           # v_beta_1
         g[22], g[23] = V[5 * H2:6 * H2], V[6 * H2 + 3:6 * H2 + 4]                           # v_beta_2
         g[24], g[25] = tg(dl_g, inp), tg(dl_g, h_prev)                                      # lstm W_ih, W_hh
-        g[26] = g[27] = flat(dl_g).sum(0)                                                   # lstm biases
+        g[26] = flat(dl_g).sum(0)                                                           # lstm biases: equal gradients,
+        g[27] = g[26].clone()                                                               # distinct storage (in-place grad ops)
         g[28], g[29] = tg(dl_out, h_new), flat(dl_out).sum(0)                               # out
-        g = [t.reshape(shape) for t, shape in zip(g, ctx.shapes)]
+        # no two gradients may share storage (AccumulateGrad keeps what it is handed; in-place grad ops such as
+        # clip_grad_norm_ would hit an aliased pair twice): shared values are cloned above, slices of `V` here
+        g = [(t.clone() if t._base is not None else t).reshape(shape) for t, shape in zip(g, ctx.shapes)]
         return (d_enc_a, d_enc_i, d_proj_a, d_proj_i, d_h[cur], d_X, None, *g)
 
 

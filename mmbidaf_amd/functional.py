@@ -182,6 +182,12 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         descs = (_lib.LstmBwdDesc * n)()
         keep, results = [], []
         dev = sv[0].device
+        # all bias gradients of the call live in one flat buffer: b_ih and b_hh have the same gradient but must not share
+        # storage (AccumulateGrad keeps the tensor it is handed; clip_grad_norm_ / accumulation would hit the pair twice),
+        # so b_hh gets views of ONE clone of that buffer
+        hs_ = [sv[i * 10 + 5].shape[1] for i in range(n)]
+        d_b_flat = torch.empty(sum(8 * h for h in hs_), device=dev, dtype=torch.float32)
+        d_b_off = [sum(8 * h for h in hs_[:i]) for i in range(n)]
         for i in range(n):
             x, y, gates, cs, w_ih_f, w_hh_f, w_ih_r, w_hh_r, lens, x_absmax = sv[i * 10:(i + 1) * 10]
             B, T, I = x.shape
@@ -192,7 +198,7 @@ class _BiLSTMLayerFn(torch.autograd.Function):
             d_x = torch.empty_like(x) if ctx.need_dx[i] else None
             d_w_ih = torch.empty(2, 4 * H, I, device=dev, dtype=torch.float32)
             d_w_hh = torch.empty(2, 4 * H, H, device=dev, dtype=torch.float32)
-            d_b = torch.empty(2, 4 * H, device=dev, dtype=torch.float32)
+            d_b = d_b_flat[d_b_off[i]:d_b_off[i] + 8 * H].view(2, 4 * H)
             d_a = torch.empty(B, T, 8 * H, device=dev, dtype=torch.float32)
             d_w_cat = torch.empty(8 * H, I + 2 * H, device=dev, dtype=torch.float32)
             ws = torch.empty(lib.mmb_bilstm_ws_bytes(B, T, I, H, 1), device=dev, dtype=torch.uint8)
@@ -207,9 +213,13 @@ class _BiLSTMLayerFn(torch.autograd.Function):
             d.x_absmax = _ptr(x_absmax)
             d.B, d.T, d.I, d.H = B, T, I, H
             keep += [d_y, d_hn, d_a, d_w_cat, ws]
-            results += [d_x, d_w_ih[0], d_w_hh[0], d_b[0], d_b[0], d_w_ih[1], d_w_hh[1], d_b[1], d_b[1]]
+            results += [d_x, d_w_ih[0], d_w_hh[0], d_b[0], None, d_w_ih[1], d_w_hh[1], d_b[1], None]
         rc = lib.mmb_bilstm_layer_bwd(descs, n, dev.index, _stream())
         _lib.check(rc, "mmb_bilstm_layer_bwd")
+        d_b_dup = d_b_flat.clone()
+        for i in range(n):
+            dup = d_b_dup[d_b_off[i]:d_b_off[i] + 8 * hs_[i]].view(2, 4 * hs_[i])
+            results[9 * i + 4], results[9 * i + 8] = dup[0], dup[1]
         return (None, None, *results)
 
 

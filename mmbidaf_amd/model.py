@@ -86,7 +86,10 @@ class MMBiDAF(nn.Module):
         eps = 1e-12
         rows = torch.arange(B, device=dev)
         targets = batch_target_indices.to(dev).reshape(B, -1).long()
-        steps = targets.size(1) if self.training else max_dec_len
+        steps = targets.size(1) if self.training else int(max_dec_len)    # train.py passes a 0-dim tensor (torch.max(...))
+        if targets.size(1) < steps:
+            # the reference indexes batch_target_indices[b][step] and raises here (models.py:188); so do both paths below
+            raise IndexError(f"max_dec_len={steps} exceeds the {targets.size(1)} target steps given")
         if embedded_text.is_cuda:
             return self._decode_fused(embedded_text, mod_a, mod_i, decoder_hidden[:, 0], decoder_mask, targets, steps, rows, eps)
         decoder_cell = torch.zeros(1, B, decoder_hidden.size(-1), device=dev)

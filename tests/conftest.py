@@ -53,3 +53,33 @@ def scaled_tol(ref, tol=1e-4):
     """north_star tolerance: 1e-4 fp32, scaled by the tensor's magnitude when that exceeds 1
     (sums over B*T terms such as weight gradients grow with the problem size)."""
     return tol * max(1.0, ref.abs().max().item())
+
+
+# ---- raw max-abs errors of every parity comparison (VERDICT r01: "print the raw max-abs per tensor so the margin is
+# visible"): tests call record_parity(); the terminal summary prints the worst tensor of every test and the full table
+# goes to gpurun_out/parity_maxabs.csv when that directory exists (GPU box).
+PARITY_LOG = []
+
+
+def record_parity(name, err, tol, ref_max):
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::")[-1]
+    PARITY_LOG.append((test, name, float(err), float(tol), float(ref_max)))
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not PARITY_LOG:
+        return
+    worst = {}
+    for test, name, err, tol, ref_max in PARITY_LOG:
+        if test not in worst or err / tol > worst[test][1] / worst[test][2]:
+            worst[test] = (name, err, tol, ref_max)
+    tr = terminalreporter
+    tr.write_sep("-", "parity: worst tensor per test (raw max-abs error, limit, max|ref|)")
+    for test, (name, err, tol, ref_max) in worst.items():
+        tr.write_line(f"{test[:70]:70s} {name[:40]:40s} err {err:.2e}  lim {tol:.2e}  max|ref| {ref_max:.2e}")
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_maxabs.csv"), "w") as f:
+            f.write("test,tensor,max_abs_err,limit,max_abs_ref\n")
+            for row in PARITY_LOG:
+                f.write("%s,%s,%.4e,%.4e,%.4e\n" % row)

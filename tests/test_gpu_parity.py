@@ -8,7 +8,7 @@ import os
 import pytest
 import torch
 
-from conftest import load_cases, load_flat, maxdiff, scaled_tol
+from conftest import load_cases, load_flat, maxdiff, record_parity, scaled_tol
 from oracle import mmbidaf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -24,6 +24,7 @@ def close(got, ref, name="", tol=TOL):
     assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
     assert torch.isfinite(got).all(), f"{name}: non-finite values"
     err = maxdiff(got, ref.detach())
+    record_parity(name, err, scaled_tol(ref.detach(), tol), ref.detach().abs().max().item() if ref.numel() else 0.0)
     assert err <= scaled_tol(ref.detach(), tol), f"{name}: max err {err:.3e} > {scaled_tol(ref.detach(), tol):.3e}"
 
 
@@ -296,20 +297,29 @@ def test_modelling_encoder_vs_oracle():
 
 
 def test_rnn_encoder_long_sequence_cfg4_size():
-    """T=1600 (cfg4): y / h_n of a 1-layer encoder against torch's packed nn.LSTM (the oracle's aten path), ragged."""
+    """T=1600 (cfg4): a 1-layer encoder against torch's packed nn.LSTM (the oracle's aten path), ragged, forward AND
+    BPTT over the 1600 dependent steps (the fast activations accumulate over the chain): y, h_n, d_x, every parameter gradient."""
     from layers.encoding import RNNEncoder
     torch.manual_seed(11)
     e = RNNEncoder(100, 100, 1).to(dev())
     g = torch.Generator().manual_seed(12)
     x = torch.randn(4, 1600, 100, generator=g)
     l = [1600, 801, 1333, 7]
-    y, h = e(x.to(dev()), l)
+    xd = x.to(dev()).requires_grad_(True)
+    y, h = e(xd, l)
+    cy, ch = torch.randn(*y.shape, generator=g), torch.randn(*h.shape, generator=g)
+    ((y * cy.to(dev())).sum() + (h * ch.to(dev())).sum()).backward()
     rnn = torch.nn.LSTM(100, 100, 1, batch_first=True, bidirectional=True)
     rnn.load_state_dict({k[4:]: v.cpu() for k, v in e.state_dict().items()})
-    with torch.no_grad():
-        yr, hr = O.rnn_encoder_aten(x, l, rnn)
+    xr = x.clone().requires_grad_(True)
+    yr, hr = O.rnn_encoder_aten(xr, l, rnn)
+    ((yr * cy).sum() + (hr * ch).sum()).backward()
     close(y, yr, "y")
     close(h, hr, "h_n")
+    close(xd.grad, xr.grad, "d_x")
+    rg = dict(rnn.named_parameters())
+    for n, p in e.named_parameters():
+        close(p.grad, rg[n[4:]].grad, "grad " + n)
 
 
 def test_rnn_encoder_general_hidden_size_vs_oracle():
@@ -591,6 +601,306 @@ def test_hot_region_cfg1_vs_oracle_with_dropout_training_mode():
     synth.region_loss(o2, gpu).backward()
     assert all(torch.isfinite(t).all() for t in o2)
     assert all(torch.isfinite(p.grad).all() for p in drop.parameters())
+
+
+# ------------------------------------------------------------------------------------------- H = 100 reference fixtures (G7, G8)
+def _close_grads(named_params, g, tol=TOL, prefix="grad__"):
+    from golden_recipe import projections
+    n = 0
+    for name, p in named_params:
+        if not any(k.startswith(f"{prefix}{name}__") for k in g):
+            continue
+        assert p.grad is not None, name
+        for kind, v in projections(name, p.grad).items():
+            close(v, g[f"{prefix}{name}__{kind}"], f"grad {name} ({kind})", tol=tol)
+            n += 1
+    return n
+
+
+def test_modelling_encoder_shape_golden_h100():
+    """G7: RNNEncoder(800, 100, 2) (mod_t_a / mod_t_i, models.py:70-78) against the reference run; ragged + tied lengths;
+    parameters by the shared recipe, weight gradients through two random projections each."""
+    from golden_recipe import fill_parameters
+    from layers.encoding import RNNEncoder
+    g = load_flat("g7_modelling_encoder_h100.npz")
+    e = RNNEncoder(800, 100, 2)
+    csum = fill_parameters(list(e.rnn.named_parameters()), seed=800)
+    assert abs(csum[1] - g["param_checksum"][1].item()) < 1e-6
+    e = e.to(dev())
+    x = g["x"].to(dev()).requires_grad_(True)
+    y, hn = e(x, g["lengths"].tolist())
+    ((y * g["cot_y"].to(dev())).sum() + (hn * g["cot_h"].to(dev())).sum()).backward()
+    close(y, g["y"], "y")
+    close(hn, g["h_n"], "h_n (length-sorted, ties)")
+    close(x.grad, g["d_x"], "d_x")
+    assert _close_grads(list(e.named_parameters()), g) >= 24
+
+
+def test_whole_model_golden_h100():
+    """G8: models.MMBiDAF at the model's hidden size (H=100, cfg-1 lengths) against the reference run: hot-path captures,
+    output distributions, loss, every parameter gradient (projections)."""
+    from golden_recipe import fill_parameters
+    from models import MMBiDAF
+    g = load_flat("g8_model_h100.npz")
+    d = dev()
+    model = MMBiDAF(100, 24, 12, 20, torch.device("cpu"), drop_prob=0.0, max_transcript_length=60, image_backbone=_Stub(g["resnet_w"], g["resnet_b"]))
+    csum = fill_parameters(list(model.named_parameters()), seed=100)
+    assert abs(csum[1] - g["param_checksum"][1].item()) < 1e-5
+    model.to(d)
+    model.device = d
+    caps = {}
+    for n in ("bidaf_att_audio", "bidaf_att_image"):
+        getattr(model, n).register_forward_hook(lambda m, i, o, n=n: caps.__setitem__(n, o))
+    tl, al, il = g["text_len"].tolist(), g["audio_len"].tolist(), g["image_len"].tolist()
+    args = (g["text"].to(d), tl, g["audio"].to(d), al, g["images"].to(d), il, g["targets"].to(d), [4] * 3, 4)
+    model.train()
+    dist, loss = model(*args)
+    close(dist, g["train_dist"], "train_dist")
+    close(loss, g["train_loss"].reshape(()), "train_loss")
+    for n in ("bidaf_att_audio", "bidaf_att_image"):
+        close(caps[n][1:2], g["cap__" + n], n)
+    with torch.no_grad():
+        mod_a, hid_a, mod_i, hid_i, _ = model.hot_path(g["cap__text_enc__x"].to(d), g["cap__audio_enc__x"].to(d),
+                                                       g["cap__image_enc__x"].to(d), tl, al, il)
+    close(mod_a, g["cap__mod_t_a__y"], "mod_t_a y")
+    close(hid_a, g["cap__mod_t_a__h"], "mod_t_a h")
+    close(mod_i, g["cap__mod_t_i__y"], "mod_t_i y")
+    close(hid_i, g["cap__mod_t_i__h"], "mod_t_i h")
+    model.zero_grad()
+    loss.backward()
+    assert _close_grads([(n, p) for n, p in model.named_parameters() if not n.startswith("image_keyframes_emb")], g, tol=3e-4) >= 100
+
+
+# ------------------------------------------------------------------------------------------- region at the BASELINE.json configs
+def _region_vs_oracle(shape, ragged=True, seed=224, lengths=None, grads=True):
+    """HotRegion on the GPU vs oracle.HotRegionCPU (the reference's op sequence on torch CPU): the 5 outputs, the input
+    gradients and every parameter gradient (the attention bias gradients are analytically 0, Q5)."""
+    from mmbidaf_amd import synth
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    H = shape[4]
+    torch.manual_seed(seed)
+    region = HotRegion(H).to(d)
+    batch = synth.make_batch(shape, ragged=ragged)
+    if lengths is not None:
+        batch["text_len"], batch["aud_len"], batch["img_len"] = lengths
+    gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    xs = [gpu[k].requires_grad_(grads) for k in ("x_text", "x_aud", "x_img")]
+    outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+    if grads:
+        synth.region_loss(outs, gpu).backward()
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    ref = O.HotRegionCPU(region.state_dict(), H)
+    xr = [batch[k].clone().requires_grad_(grads) for k in ("x_text", "x_aud", "x_img")]
+    routs = ref(*xr, batch["text_len"], batch["aud_len"], batch["img_len"])
+    for n, a, b in zip(("mod_a", "hid_a", "mod_i", "hid_i", "dec_hidden"), outs, routs):
+        close(a, b, n)
+    for b_, lb in enumerate(batch["text_len"]):      # padded rows of the modelling encoders are exactly zero
+        assert (outs[0][b_, lb:] == 0).all() and (outs[2][b_, lb:] == 0).all()
+    if not grads:
+        return region, batch, outs
+    synth.region_loss(routs, batch).backward()
+    for n, a, b in zip(("d_x_text", "d_x_aud", "d_x_img"), xs, xr):
+        close(a.grad, b.grad, n)
+    rg = ref.named_grads()
+    for n, p in region.named_parameters():
+        if not n.endswith("bidaf_att_audio.bias") and not n.endswith("bidaf_att_image.bias"):
+            close(p.grad, rg[n], "grad " + n)
+    return region, batch, outs
+
+
+def test_hot_region_cfg2_full_size_vs_oracle():
+    """BASELINE.json config 2 at FULL size (B=32, T=400/256/64, H=100), ragged lengths: every output and gradient."""
+    _region_vs_oracle((32, 400, 256, 64, 100), ragged=True)
+
+
+def test_hot_region_cfg2_full_lengths_vs_oracle():
+    """config 2 with full-length sequences (the headline bench workload) on a batch-8 slice."""
+    _region_vs_oracle((8, 400, 256, 64, 100), ragged=False)
+
+
+def test_hot_region_cfg4_lengths_vs_oracle():
+    """BASELINE.json config 4 lengths (T=1600/1024/256, H=100) at B=2: forward and the whole backward (BPTT over 1600
+    steps, attention backward at M=1024), one full-length and one ragged sample."""
+    _region_vs_oracle((2, 1600, 1024, 256, 100), ragged=True, lengths=([1600, 1203], [1024, 517], [256, 3]))
+
+
+def _region_batch_independence(shape, sub, ragged=True, tol=2e-5):
+    """Size-independent property at a full BASELINE size: every sample is processed independently, so the first `sub`
+    samples of the full batch must give the outputs / input gradients they give as a batch of their own."""
+    from mmbidaf_amd import synth
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    B, T, Ma, Mi, H = shape
+    torch.manual_seed(224)
+    region = HotRegion(H).to(d)
+    batch = synth.make_batch(shape, ragged=ragged)
+
+    def run(n):
+        xs = [batch[k][:n].to(d).requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+        outs = region(*xs, batch["text_len"][:n], batch["aud_len"][:n], batch["img_len"][:n])
+        # h_n comes back in descending-length order (Q3): compare the order-free parts
+        loss = (outs[0] * batch["r_a"][:n].to(d)).sum() + (outs[2] * batch["r_i"][:n].to(d)).sum() + outs[1].sum() + outs[3].sum()
+        loss.backward()
+        return outs, xs
+    full, fx = run(B)
+    part, px = run(sub)
+    for t in full:
+        assert torch.isfinite(t).all()
+    for b_, lb in enumerate(batch["text_len"]):
+        assert (full[0][b_, lb:] == 0).all() and (full[2][b_, lb:] == 0).all()
+    close(full[0][:sub], part[0].cpu(), "mod_a[:sub]", tol=tol)
+    close(full[2][:sub], part[2].cpu(), "mod_i[:sub]", tol=tol)
+    for n, a, b in zip(("d_x_text", "d_x_aud", "d_x_img"), fx, px):
+        close(a.grad[:sub], b.grad.cpu(), n + "[:sub]", tol=tol)
+
+
+def test_hot_region_cfg4_full_size_properties():
+    """config 4 at FULL size (B=32, T=1600, M=1024/256): finite, exact zeros in the padding, batch independence."""
+    _region_batch_independence((32, 1600, 1024, 256, 100), sub=2)
+
+
+def test_hot_region_cfg5_hidden512_vs_oracle():
+    """BASELINE.json config 5's hidden size (H=512, D=1024: general-size recurrence and attention) at reduced lengths
+    (B=4, T=48/32/8): every output and gradient against the oracle."""
+    _region_vs_oracle((4, 48, 32, 8, 512), ragged=True)
+
+
+def test_hot_region_cfg5_full_size_properties():
+    """config 5 at FULL size (B=64, T=400/256/64, H=512): finite, exact zeros in the padding, batch independence."""
+    _region_batch_independence((64, 400, 256, 64, 512), sub=2)
+
+
+# ------------------------------------------------------------------------------------------- dropout with known masks
+def test_rnn_encoder_dropout_parity_with_replayed_masks():
+    """Training-mode RNNEncoder (L=2): nn.LSTM's inter-layer dropout and the output dropout (encoding.py:81,104; Q7) draw
+    their masks from torch's device RNG on the host side of the boundary.  Replaying the generator gives the very masks,
+    which the oracle then applies: outputs and every gradient must agree (not just be finite)."""
+    import torch.nn.functional as F
+    from layers.encoding import RNNEncoder
+    d = dev()
+    g = torch.Generator().manual_seed(41)
+    torch.manual_seed(3)
+    e = RNNEncoder(20, 12, 2, drop_prob=0.3).to(d).train()
+    B, T = 5, 17
+    x = torch.randn(B, T, 20, generator=g)
+    l = [17, 3, 17, 9, 1]
+    xd = x.to(d).requires_grad_(True)
+    torch.manual_seed(1234)
+    y, h = e(xd, l)
+    torch.manual_seed(1234)                                   # same generator state -> the same two masks, in call order
+    ones = torch.ones(B, T, 24, device=d)
+    m_inter = F.dropout(ones, 0.3, True).cpu()
+    m_out = F.dropout(ones, 0.3, True).cpu()
+    assert 0.1 < (m_inter == 0).float().mean() < 0.5 and not torch.equal(m_inter, m_out)
+    cy, ch = torch.randn(*y.shape, generator=g), torch.randn(*h.shape, generator=g)
+    ((y * cy.to(d)).sum() + (h * ch.to(d)).sum()).backward()
+    P = {k[4:]: v.detach().cpu().clone().requires_grad_(True) for k, v in e.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    yr, hr = O.rnn_encoder(xr, l, P, 2, out_mask=m_out, dropout_masks=[m_inter])
+    ((yr * cy).sum() + (hr * ch).sum()).backward()
+    close(y, yr, "y (dropout)")
+    close(h, hr, "h_n (dropout)")
+    close(xd.grad, xr.grad, "d_x (dropout)")
+    for n, p in e.named_parameters():
+        close(p.grad, P[n[4:]].grad, "grad " + n)
+    # 1-layer encoders get the output dropout only (Q7)
+    torch.manual_seed(4)
+    e1 = RNNEncoder(20, 12, 1, drop_prob=0.3).to(d).train()
+    torch.manual_seed(77)
+    y1, _ = e1(x.to(d), l)
+    torch.manual_seed(77)
+    m1 = F.dropout(ones, 0.3, True).cpu()
+    P1 = {k[4:]: v.detach().cpu() for k, v in e1.state_dict().items()}
+    yr1, _ = O.rnn_encoder(x, l, P1, 1, out_mask=m1)
+    close(y1, yr1, "y (1 layer, output dropout)")
+
+
+def test_attention_module_dropout_parity_with_replayed_masks():
+    """BiDAFAttention in training mode: only the similarity sees the dropped copies (attention.py:66-67, Q6)."""
+    import torch.nn.functional as F
+    from layers.attention import BiDAFAttention
+    d = dev()
+    c, _ = _random_att_case(5, 3, 21, 13, 40, False)
+    torch.manual_seed(8)
+    att = BiDAFAttention(40, drop_prob=0.25).to(d).train()
+    text = c["text"].to(d).requires_grad_(True)
+    mod = c["mod"].to(d).requires_grad_(True)
+    torch.manual_seed(99)
+    out = att(text, mod, c["text_mask"].to(d), c["mod_mask"].to(d))
+    torch.manual_seed(99)
+    mt = F.dropout(torch.ones_like(text), 0.25, True).cpu()
+    mm = F.dropout(torch.ones_like(mod), 0.25, True).cpu()
+    (out * c["cot"].to(d)).sum().backward()
+    t_ = c["text"].clone().requires_grad_(True)
+    m_ = c["mod"].clone().requires_grad_(True)
+    ps = [p.detach().cpu().clone().requires_grad_(True) for p in (att.text_weight, att.modality_weight, att.text_modality_weight, att.bias)]
+    ref = O.bidaf_attention(t_, m_, c["text_mask"], c["mod_mask"], *ps, text_d=t_ * mt, mod_d=m_ * mm)
+    (ref * c["cot"]).sum().backward()
+    close(out, ref, "out (dropout)")
+    close(text.grad, t_.grad, "d_text (dropout)")
+    close(mod.grad, m_.grad, "d_mod (dropout)")
+    for n, p, r in zip(("text_weight", "modality_weight", "text_modality_weight"), (att.text_weight, att.modality_weight, att.text_modality_weight), ps):
+        close(p.grad, r.grad, "grad " + n)
+
+
+# ------------------------------------------------------------------------------------------- gradient storage (ADVICE r01)
+def test_no_two_gradients_share_storage_and_clipping_matches_oracle():
+    """b_ih / b_hh (and the decoder's tied biases) have equal gradients; they must still be distinct tensors, or an
+    in-place operation on the grads -- the reference's clip_grad_norm_(2.0) in train.py, or accumulation over two
+    backward passes -- hits the pair twice.  Region + decoder loop, then clip and accumulate against the oracle."""
+    from mmbidaf_amd import synth
+    from mmbidaf_amd.attention import MultimodalAttentionDecoder
+    from mmbidaf_amd.decoder import decoder_loop
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    H = 12
+    torch.manual_seed(224)
+    region = HotRegion(H).to(d)
+    batch = synth.make_batch((3, 14, 9, 5, H), ragged=True)
+    gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def backward_once():
+        outs = region(gpu["x_text"], gpu["x_aud"], gpu["x_img"], batch["text_len"], batch["aud_len"], batch["img_len"])
+        synth.region_loss(outs, gpu).backward()
+    backward_once()
+    params = [p for p in region.parameters() if p.grad is not None]
+    ptrs = [p.grad.data_ptr() for p in params]
+    assert len(set(ptrs)) == len(ptrs), "two parameter gradients share storage"
+    ref = O.HotRegionCPU(region.state_dict(), H)
+
+    def ref_backward():
+        routs = ref(batch["x_text"], batch["x_aud"], batch["x_img"], batch["text_len"], batch["aud_len"], batch["img_len"])
+        synth.region_loss(routs, batch).backward()
+    ref_backward()
+    # accumulate a second backward pass (2g, not 3g) ...
+    backward_once()
+    ref_backward()
+    rg = ref.named_grads()
+    for n, p in region.named_parameters():
+        if ".bias_" in n:
+            close(p.grad, rg[n], "accumulated grad " + n)
+    # ... then clip exactly as train.py does
+    rparams = [p for p in ref.parameters() if p.grad is not None]
+    n_gpu = torch.nn.utils.clip_grad_norm_(params, 2.0)
+    n_ref = torch.nn.utils.clip_grad_norm_(rparams, 2.0)
+    assert abs(n_gpu.item() - n_ref.item()) <= 1e-4 * max(1.0, n_ref.item())
+    assert n_ref.item() > 2.0                                   # the clip really fires
+    rg = ref.named_grads()
+    for n, p in region.named_parameters():
+        if ".bias_" in n or "weight_hh_l0" in n:
+            close(p.grad, rg[n], "clipped grad " + n)
+    # decoder: tied bias gradients are distinct tensors too
+    torch.manual_seed(5)
+    dec = MultimodalAttentionDecoder(7, H, 20).to(d)
+    g = torch.Generator().manual_seed(6)
+    enc_a, enc_i = torch.randn(3, 14, 2 * H, generator=g).to(d), torch.randn(3, 14, 2 * H, generator=g).to(d)
+    mask = torch.zeros(3, 20, dtype=torch.bool, device=d)
+    mask[:, :14] = True
+    outs = decoder_loop(dec, enc_a, enc_i, torch.randn(3, H, generator=g).to(d), torch.randn(4, 3, 7, generator=g).to(d), mask)
+    sum(o.sum() for o in outs).backward()
+    ptrs = [p.grad.data_ptr() for p in dec.parameters() if p.grad is not None]
+    assert len(set(ptrs)) == len(ptrs), "two decoder gradients share storage"
 
 
 # ------------------------------------------------------------------------------------------- fuzz

@@ -149,9 +149,16 @@ import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 from mmbidaf_amd import ddp
 rank, world, _ = ddp.init_from_env("gloo")
+mode = sys.argv[2]
 torch.manual_seed(100 + rank)                      # different replicas on purpose
-model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
-sync = ddp.FlatGradAllReduce(model.parameters())
+model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3), torch.nn.Tanh(), torch.nn.Linear(3, 3))
+unused = torch.nn.Parameter(torch.ones(4))         # never reaches the loss: its grad must stay None
+params = list(model.parameters()) + [unused]
+if mode == "flat":
+    sync = ddp.FlatGradAllReduce(params)
+else:                                              # buckets in backward order, launched from grad hooks
+    ps = list(model.parameters())
+    sync = ddp.FlatGradAllReduce(params, buckets=[ps[4:6], ps[2:4], ps[0:2]], overlap=True, average=(mode == "overlap_avg"))
 sync.broadcast_parameters(0)
 p0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
 gathered = [torch.zeros_like(p0) for _ in range(world)]
@@ -160,25 +167,38 @@ assert all(torch.equal(g, gathered[0]) for g in gathered), "broadcast_parameters
 lo, hi = ddp.shard_range(8, rank, world)
 torch.manual_seed(7)
 x, y = torch.randn(8, 5), torch.randn(8, 3)
-((model(x[lo:hi]) - y[lo:hi]) ** 2).sum().backward()
-sync()
-mine = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
-# single-process reference: whole batch, then divide by world (sum of shard losses / world)
-ref = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
+# single-process reference on the WHOLE batch with the summed loss (the reference's convention, models.py:168-176)
+ref = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3), torch.nn.Tanh(), torch.nn.Linear(3, 3))
 ref.load_state_dict(model.state_dict())
 ((ref(x) - y) ** 2).sum().backward()
-want = torch.cat([p.grad.reshape(-1) for p in ref.parameters()]) / world
-assert torch.allclose(mine, want, atol=1e-5), (mine - want).abs().max()
+want = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+if mode == "overlap_avg":
+    want = want / world
+for step in range(2):                              # twice: hooks re-arm, grads are reset between steps
+    for p in params:
+        p.grad = None
+    ((model(x[lo:hi]) - y[lo:hi]) ** 2).sum().backward()
+    before = [p.grad for p in model.parameters()]
+    sync()
+    assert all(a is b for a, b in zip(before, [p.grad for p in model.parameters()])), "p.grad was rebound"
+    assert unused.grad is None
+    ptrs = [p.grad.data_ptr() for p in model.parameters()]
+    assert len(set(ptrs)) == len(ptrs)
+    mine = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert torch.allclose(mine, want, atol=1e-5), (mode, step, (mine - want).abs().max())
 dist.barrier()
 print("rank", rank, "ok")
 '''
 
 
-def test_flat_grad_allreduce_gloo_world2(tmp_path):
+@pytest.mark.parametrize("mode,port", [("flat", 29611), ("overlap", 29612), ("overlap_avg", 29613)])
+def test_flat_grad_allreduce_gloo_world2(tmp_path, mode, port):
+    """world-size-2 gloo run of the gradient exchange: SUM semantics equal the single-process whole-batch gradient of the
+    reference's summed loss; bucketed + hook-launched (overlap) mode gives the same; grads are updated in place."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2", OMP_NUM_THREADS="1")
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, mode], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):

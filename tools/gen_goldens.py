@@ -229,7 +229,85 @@ def gen_hot_region(ref_models):
     print("wrote state_dict_keys.json", len(keys), "tensors")
 
 
+def _store_grads(out, named_params, prefix="grad__"):
+    from golden_recipe import projections
+    for n, p in named_params:
+        if p.grad is None or n.startswith("image_keyframes_emb"):
+            continue
+        for kind, v in projections(n, p.grad).items():
+            out[f"{prefix}{n}__{kind}"] = _np(v)
+
+
+def gen_rnn_modelling_shape(ref_enc):
+    """G7: the modelling-encoder shape of the model (models.py:70-78): RNNEncoder(8H=800, H=100, L=2), ragged lengths
+    with ties (Q3).  Parameters by the shared recipe (tests/golden_recipe.py), big gradients as projections."""
+    from golden_recipe import fill_parameters
+    enc = ref_enc.RNNEncoder(800, 100, 2, drop_prob=0.0)
+    enc.eval()
+    csum = fill_parameters(list(enc.named_parameters()), seed=800)
+    g = torch.Generator().manual_seed(801)
+    B, T = 4, 16
+    lengths = [16, 9, 16, 9]
+    x = (torch.randn(B, T, 800, generator=g) * 0.5).requires_grad_(True)
+    cot_y = torch.randn(B, T, 200, generator=g)
+    cot_h = torch.randn(B, 4, 100, generator=g)
+    y, hn = enc(x, lengths)
+    ((y * cot_y).sum() + (hn * cot_h).sum()).backward()
+    out = dict(x=_np(x), lengths=np.asarray(lengths, dtype=np.int64), cot_y=_np(cot_y), cot_h=_np(cot_h), y=_np(y), h_n=_np(hn),
+               d_x=_np(x.grad), param_checksum=np.asarray(csum, dtype=np.float64))
+    _store_grads(out, list(enc.named_parameters()))
+    _save("g7_modelling_encoder_h100", **out)
+
+
+def gen_model_h100(ref_models):
+    """G8: a real reference MMBiDAF at cfg-1 lengths with the MODEL's hidden size H=100 (G5 uses H=16): hot-path
+    captures, output distributions, loss and gradients (projections), train mode, drop_prob = 0."""
+    from golden_recipe import fill_parameters
+    B, T, Ma, Mi, H = 3, 50, 32, 8, 100
+    Et, Ea, Ei = 24, 12, 20
+    model = ref_models.MMBiDAF(H, Et, Ea, Ei, torch.device("cpu"), drop_prob=0.0, max_transcript_length=60)
+    csum = fill_parameters(list(model.named_parameters()), seed=100)
+    g = torch.Generator().manual_seed(101)
+    text = torch.randn(B, T, Et, generator=g)
+    audio = torch.randn(B, Ma, Ea, generator=g)
+    images = torch.randn(B, Mi, 3, 4, 4, generator=g)
+    tl, al, il = [50, 31, 17], [32, 20, 9], [8, 5, 2]
+    steps = 4
+    targets = torch.randint(0, 17, (B, steps, 1), generator=g).float()
+    caps = {}
+
+    def hook(name):
+        def fn(mod, inp, out):
+            if isinstance(out, tuple):
+                caps[name + "__y"] = _np(out[0])
+                caps[name + "__h"] = _np(out[1])
+            else:
+                caps[name] = _np(out[1:2])          # the ragged middle sample only (keeps the fixture small)
+            if name in ("text_enc", "audio_enc", "image_enc"):
+                caps[name + "__x"] = _np(inp[0])
+        return fn
+
+    hs = [getattr(model, n).register_forward_hook(hook(n)) for n in
+          ("text_enc", "audio_enc", "image_enc", "bidaf_att_audio", "bidaf_att_image", "mod_t_a", "mod_t_i")]
+    out = dict(text=_np(text), audio=_np(audio), images=_np(images), text_len=np.asarray(tl), audio_len=np.asarray(al),
+               image_len=np.asarray(il), targets=_np(targets), resnet_w=_np(model.image_keyframes_emb.resnet.fc.weight),
+               resnet_b=_np(model.image_keyframes_emb.resnet.fc.bias), param_checksum=np.asarray(csum, dtype=np.float64))
+    model.train()
+    dist, loss = model(text, tl, audio, al, images, il, targets, [steps] * B, steps)
+    out["train_dist"] = _np(dist)
+    out["train_loss"] = _np(loss)
+    for k, v in caps.items():
+        out["cap__" + k] = v
+    model.zero_grad()
+    loss.backward()
+    _store_grads(out, list(model.named_parameters()))
+    for h in hs:
+        h.remove()
+    _save("g8_model_h100", **out)
+
+
 def main():
+    sys.path.insert(0, OUT[:-len("golden")])   # tests/: golden_recipe.py
     _install_torchvision_stub()
     sys.path.insert(0, REF)
     import layers.attention as ref_att
@@ -240,6 +318,8 @@ def main():
     gen_attention(ref_att)
     gen_rnn(ref_enc)
     gen_hot_region(ref_models)
+    gen_rnn_modelling_shape(ref_enc)
+    gen_model_h100(ref_models)
 
 
 if __name__ == "__main__":
