@@ -66,24 +66,33 @@ const char* mmb_kernel_name(int kernel_id);   /* device-side symbol stem, as roc
  * outputs
  *   out (B,T,4D) = [text, a, text*a, text*b]                       (attention.py:52)
  * saved for backward (caller-allocated)
- *   q (B,M,D)   = s2^T . text         bsave (B,T,D) = b
- *   rterm (B,T) = text_d.w_t + bias   cterm (B,M)   = mod_d.w_m
+ *   bsave (B,T,D) = b                 rterm (B,T) = text_d.w_t + bias   cterm (B,M) = mod_d.w_m
  *   row_stat (B,T,2) = {max, sum} of the row softmax     col_stat (B,M,2) likewise
- * D must be a multiple of 4.  D <= MMB_ATT_MAX_D runs the fused kernels (no scratch); wider D (up to
- * MMB_ATT_GENERAL_MAX_D) materialises the (B,T,M) similarity matrix in `workspace`, which must then hold
- * mmb_bidaf_fwd_workspace_bytes(B,T,M,D) bytes (0 for the fused path; workspace may be NULL then).
+ *   saved: opaque, mmb_bidaf_saved_bytes(B,T,M,D,has_drop) bytes.  Fused path: the MFMA operand "planes" of text,
+ *          mod, q = s2^T.text (and of the dropped copies) -- every fp32 operand split once into two fp16 terms of its
+ *          power-of-two-scaled rows, tiled as the kernels' LDS image -- plus one inverse scale per row; general path:
+ *          q (B,M,D) fp32.
+ * masks: either a (B,T) / (B,M) u8 tensor (any 0/1 pattern) or -- for the prefix masks models.get_mask builds
+ *   (models.py:86-92) -- the int32 length vector text_len / mod_len (B), from which the kernels derive
+ *   mask[b,i] = i < len[b] themselves; when a length vector is given the u8 mask is ignored
+ *   and may be NULL.  The general-width path takes u8 masks only.
+ * D must be a multiple of 4.  D <= MMB_ATT_MAX_D runs the fused kernels; wider D (up to MMB_ATT_GENERAL_MAX_D)
+ * materialises the (B,T,M) similarity matrix in `workspace`.  Both paths need mmb_bidaf_fwd_workspace_bytes(B,T,M,D)
+ * bytes of scratch (fused: the per-split partial column softmaxes).
  */
+size_t mmb_bidaf_saved_bytes(int B, int T, int M, int D, int has_drop);
 size_t mmb_bidaf_fwd_workspace_bytes(int B, int T, int M, int D);
 
 int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t* text_mask, const uint8_t* mod_mask,
+                  const int32_t* text_len, const int32_t* mod_len,
                   const float* text_d, const float* mod_d,
                   const float* w_t, const float* w_m, const float* w_tm, const float* bias,
-                  float* out, float* q, float* bsave, float* rterm, float* cterm,
-                  float* row_stat, float* col_stat,
+                  float* out, float* bsave, float* rterm, float* cterm,
+                  float* row_stat, float* col_stat, void* saved, size_t saved_bytes,
                   float* workspace, size_t workspace_bytes,
                   int B, int T, int M, int D, int device, void* stream);
 
-/* bytes of scratch mmb_bidaf_bwd needs (fp32 workspace, contents undefined on entry) */
+/* bytes of scratch mmb_bidaf_bwd needs (contents undefined on entry) */
 size_t mmb_bidaf_bwd_workspace_bytes(int B, int T, int M, int D);
 
 /*
@@ -91,13 +100,14 @@ size_t mmb_bidaf_bwd_workspace_bytes(int B, int T, int M, int D);
  * d_w_t (D), d_w_m (D), d_w_tm (D), d_bias (1) (all OVERWRITTEN).  When text_d / mod_d were
  * given, d_text_d / d_mod_d receive the gradient w.r.t. the dropped copies and d_text / d_mod
  * only the clean-path part; when they are NULL everything is folded into d_text / d_mod and
- * d_text_d / d_mod_d must be NULL.
+ * d_text_d / d_mod_d must be NULL.  Masks / lengths as in the forward call.
  */
 int mmb_bidaf_bwd(const float* d_out, const float* out,
                   const float* text, const float* mod, const uint8_t* text_mask, const uint8_t* mod_mask,
+                  const int32_t* text_len, const int32_t* mod_len,
                   const float* text_d, const float* mod_d,
                   const float* w_t, const float* w_m, const float* w_tm,
-                  const float* q, const float* bsave, const float* rterm, const float* cterm,
+                  const void* saved, const float* bsave, const float* rterm, const float* cterm,
                   const float* row_stat, const float* col_stat,
                   float* d_text, float* d_mod, float* d_text_d, float* d_mod_d,
                   float* d_w_t, float* d_w_m, float* d_w_tm, float* d_bias,

@@ -59,10 +59,11 @@ SIGNATURES = {
     "mmb_profile_enable": (c_i, [ctypes.c_uint32]),
     "mmb_profile_read": (c_i, [c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i)]),
     "mmb_kernel_name": (ctypes.c_char_p, [c_i]),
+    "mmb_bidaf_saved_bytes": (ctypes.c_size_t, [c_i] * 5),
     "mmb_bidaf_fwd_workspace_bytes": (ctypes.c_size_t, [c_i] * 4),
-    "mmb_bidaf_fwd": (c_i, [c_f] * 17 + [c_f, ctypes.c_size_t] + [c_i] * 5 + [c_f]),
+    "mmb_bidaf_fwd": (c_i, [c_f] * 19 + [ctypes.c_size_t, c_f, ctypes.c_size_t] + [c_i] * 5 + [c_f]),
     "mmb_bidaf_bwd_workspace_bytes": (ctypes.c_size_t, [c_i] * 4),
-    "mmb_bidaf_bwd": (c_i, [c_f] * 26 + [ctypes.c_size_t] + [c_i] * 5 + [c_f]),
+    "mmb_bidaf_bwd": (c_i, [c_f] * 28 + [ctypes.c_size_t] + [c_i] * 5 + [c_f]),
     "mmb_bilstm_layer_fwd": (c_i, [ctypes.POINTER(LstmFwdDesc), c_i, c_i, c_f]),
     "mmb_bilstm_layer_bwd": (c_i, [ctypes.POINTER(LstmBwdDesc), c_i, c_i, c_f]),
     "mmb_gemm_f32": (c_i, [c_f] * 4 + [c_i] * 10 + [c_f]),

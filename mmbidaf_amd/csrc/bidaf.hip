@@ -1,4 +1,4 @@
-// Fused BiDAF attention for gfx950 (forward + backward), fp32 on the exact-f32 matrix cores.
+// Fused BiDAF attention for gfx950 (forward + backward) on the 16-bit matrix cores at fp32 accuracy.
 // Replaces BiDAFAttention.forward / get_similarity_matrix / masked_softmax of the reference
 // (layers/attention.py:37-98) and their autograd.  The (B,T,M) similarity matrix, both softmaxes
 // and the (B,T,T) product s1.s2^T of the reference are never materialised:
@@ -7,96 +7,308 @@
 //   P1    = softmax_j(mask_mod ? S : -1e30)   P2 = softmax_i(mask_text ? S : -1e30)   (blend, attention.py:94)
 //   q     = P2^T text      a = P1 mod      b = P1 q      out = [text, a, text*a, text*b]
 //
-// Tile engine (per wave): v_mfma_f32_16x16x4_f32; A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
-// C[row=4*(l>>4)+e][col=l&15].  A wave owns 16 rows "n" of one side (the LANE side: n = l&15) and
-// streams the other side ("m" rows) through LDS panels:
-//   S-type  C[m][n] = sum_d P[m][d] side[n][d]     A = LDS panel row (b128 reads), B = lane-side registers;
-//           feature d = 16*s + 4*kg + e is the e-th component of the s-th b128 read of lane group kg.
-//   PV-type O[d][n] += sum_m V[m][d] W[m][n]       A = LDS panel column reads, B = the S-type accumulator itself
-//           (lane (r,kg) holds W[m=4kg+e][n=r], exactly the B operand of k-group kg): no transpose, no LDS
-//           round trip for the probabilities.  The result lands as O[n=r][d=16*dt+4kg+e], the SAME layout as
-//           the lane-side registers, so an accumulated gradient (dq) is reused directly as an S-type operand.
-// All softmax statistics are lane-local in n (replicated over the 4 k-groups).
+// Arithmetic.  Every contraction runs on v_mfma_f32_16x16x32_f16 from an error-compensated split of the fp32
+// operands: x * s = h0 + h1 with h0 = fp16(x s), h1 = fp16(x s - h0), s a power of two per operand ROW chosen so
+// that the row maximum lands in [2^13, 2^14) (exact scaling; 22 significant bits); a product is the three cross
+// terms a0 b1 + a1 b0 + a0 b0 accumulated in fp32 (the dropped a1 b1 is below 2^-22), i.e. 3 MFMAs of K = 32 in 48
+// cycles where the exact-f32 MFMA needs 256: the same scheme as the LSTM GEMMs (planes.hip), 5.3x the fp32 rate at
+// fp32 error (~1e-6 of the operand scale).  Streamed operands are split ONCE by the producing kernel into "planes"
+// (tiled exactly as the LDS image, below) together with one inverse scale per row; probabilities and softmax
+// gradients are split in registers (v_cvt_pkrtz pairs) straight out of the accumulators.
+//
+// Tile engine (per wave).  A wave owns 16 rows "n" of one side (the LANE side: n = l & 15, k-group g = l >> 4) and
+// streams the other side ("m" rows) through 32-row LDS panels:
+//   S-type  C[m][n] = sum_d P[m][d] side[n][d]     A = panel rows (ds_read_b128: 8 consecutive d of one plane),
+//           B = lane-side registers (7 k-tiles x 2 planes x 4 VGPRs); accumulator lane (n, g) holds m = 4g + e.
+//   PV-type O[d][n] += sum_m V[m][d] W[m][n]       A = V^T through ds_read_b64_tr_b16 (the hardware transpose read:
+//           the same row-major panel image serves both kinds of product), B = the S-type accumulators of the
+//           panel's two 16-row blocks themselves: lane (n, g) holds rows 4g..4g+3 of each block, and the MFMA's
+//           k index is simply DEFINED as k = 8g + j <-> row (j < 4 ? 4g + j : 16 + 4g + j - 4), which the transpose
+//           reads follow.  Probabilities therefore never leave registers.  O lands as O[n][d = 16 dt + 4g + e].
+// Scales.  S-type: acc * inv_m[m] * inv_n.  PV-type: the row scale of V sits inside the K sum, so it is folded
+// into W before the split: W' = W * inv_V[m] * c with c a power of two that maps the largest possible |W inv_V|
+// of this lane's column to 2^14 (W = probabilities: c = 2^14 / max inv_V; W = softmax gradients: an a-priori
+// Cauchy-Schwarz bound from the operands' row scales -- the two-term split keeps 2^-25 absolute precision over 40
+// binary orders below the maximum, so a loose bound costs nothing); the accumulator is divided by c at the end.
+//
+// Planes layout (one tensor, one sample, R rows padded to a multiple of 32): 1-KiB chunks
+// [row block of 16][k tile of 32 features][plane 0|1], chunk = 16 rows x 64 B with the four 16-B slots of a row
+// XOR-ed by 2 * bit 2 of the row: conflict-free for the b128 row reads AND for the transpose reads (a 32-lane half
+// then covers all 64 banks exactly once).  A 32-row panel is one contiguous 28-KiB run: 28 LDS-DMA
+// wave-instructions (global_load_lds_dwordx4), no VGPR round trip, no per-element work in the panel loop.
 #include <math.h>
 
 #include "common.h"
 
 namespace mmb {
 
-constexpr int DT = 13;           // 16-wide feature tiles: D <= 208
-constexpr int LDP = 212;         // LDS panel row stride (floats): 848 B, 16-B aligned, odd multiple of 16 B
-// Workgroup geometry is a template parameter of the tile kernels: NWv waves (16 lane-side rows each) share
-// PRv-row panels of the streamed side.  Small workgroups + short panels trade panel re-reads (served by the XCD's
-// L2, see decode_block) for more resident workgroups per CU, which is what hides staging and barrier latency here.
-constexpr float NEG = -1e30f;    // attention.py:94
+constexpr int KT = 7;              // 32-deep k tiles: features padded to 224
+constexpr int DT = 13;             // 16-wide output feature tiles: D <= 208
+constexpr int PR = 32;             // rows per panel
+constexpr int NW = 4;              // waves per workgroup (64 lane-side rows)
+constexpr int NTHR = NW * 64;
+constexpr int PCH = 2048;          // bytes of one (row block, k tile): two 1-KiB planes
+constexpr int PRB = KT * PCH;      // bytes of one 16-row block of a tensor
+constexpr int PANEL_B = 2 * PRB;   // bytes of a 32-row panel (28 KiB)
+constexpr int LDP = 212;           // row stride (floats) of the epilogue's LDS staging tile
+constexpr float NEG = -1e30f;      // attention.py:94
+constexpr float WMAX = 16384.0f;   // 2^14: where the largest split operand is mapped
 
-using side_t = f4[DT];
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short s8v __attribute__((ext_vector_type(8)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void zero_side(side_t& s) {
+struct side_t {
+    half8 h[KT][2];                // [k tile][plane]: features 32 kt + 8 g .. + 7 of row n
+};
+using acc_t = f4[DT];
+
+__device__ __forceinline__ void zero_acc(acc_t& s) {
 #pragma unroll
     for (int i = 0; i < DT; ++i) s[i] = f4{0.f, 0.f, 0.f, 0.f};
 }
 
-// lane-side registers: side[s] = src[(n), 16s + 4kg .. +3]  (zero outside N x D), optionally scaled by w[d]
-__device__ __forceinline__ void load_side(side_t& side, const float* src_b, int n, int N, int D, int kg, const float* w) {
+__host__ __device__ __forceinline__ int pad32(int r) { return (r + 31) / 32 * 32; }
+// bytes of one sample's planes of an R-row tensor
+__host__ __device__ __forceinline__ size_t planes_sample_bytes(int R) { return (size_t)(pad32(R) / 16) * PRB; }
+
+__device__ __forceinline__ int att_swz(int row) { return ((row >> 2) & 1) << 1; }
+// byte offset of (row, 16-B octet 0..27) of plane 0 inside one sample's planes; plane 1 follows at +1024
+__device__ __forceinline__ int pl_off_att(int row, int oct) {
+    const int rl = row & 15;
+    return (row >> 4) * PRB + (oct >> 2) * PCH + rl * 64 + (((oct & 3) ^ att_swz(rl)) << 4);
+}
+
+// power of two s with s * amax in [2^13, 2^14)  (1 for amax = 0 or out of range)
+__device__ __forceinline__ float a_pow2_scale(float amax) {
+    const unsigned u = __float_as_uint(amax);
+    const int e = (int)((u >> 23) & 0xFF) - 127;
+    if (amax <= 0.0f || e > 100 || e < -100) return 1.0f;
+    return __uint_as_float((unsigned)(13 - e + 127) << 23);
+}
+// largest power of two <= x (x > 0 finite)
+__device__ __forceinline__ float pow2_floor(float x) { return __uint_as_float(__float_as_uint(x) & 0x7F800000u); }
+
+// two-term fp16 split of 8 already scaled values (round to nearest; clamped so a violated bound saturates)
+__device__ __forceinline__ void a_split2h(const float* x, half8& h0, half8& h1) {
 #pragma unroll
-    for (int s = 0; s < DT; ++s) {
-        const int d = 16 * s + 4 * kg;
-        f4 v = f4{0.f, 0.f, 0.f, 0.f};
-        if (n < N && d < D) {
-            v = *reinterpret_cast<const f4*>(src_b + (size_t)n * D + d);
-            if (w) {
-                const f4 ww = *reinterpret_cast<const f4*>(w + d);
-                v *= ww;
+    for (int j = 0; j < 8; ++j) {
+        const float v = fminf(fmaxf(x[j], -60000.0f), 60000.0f);
+        const _Float16 a = (_Float16)v;
+        h0[j] = a;
+        h1[j] = (_Float16)(v - (float)a);
+    }
+}
+
+__device__ __forceinline__ float kg_allsum(float v) {  // over the 4 k-groups (lanes r, r+16, r+32, r+48)
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float kg_allmax(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+__device__ __forceinline__ float r_allsum(float v) {  // over the 16 lanes of a k-group
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ float half_allsum(float v) {  // over the 32 lanes of a half wave
+    v += __shfl_xor(v, 16);
+    return r_allsum(v);
+}
+__device__ __forceinline__ float half_allmax(float v) {
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float f4sum(const f4 v) { return (v.x + v.y) + (v.z + v.w); }
+__device__ __forceinline__ float f4amax(const f4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+
+// ---- lane-side operand of row n from an fp32 row (optionally scaled feature-wise by w): the row's own power-of-two
+// scale from its maximum over the lane's 56 values and the 4 k-groups; rows n >= N come out as zeros with inv = 0
+__device__ __forceinline__ void side_from_regs(float (&x)[KT][8], side_t& sd, float& inv_n) {
+    float amax = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(x[kt][j]));
+    amax = kg_allmax(amax);
+    const float s = a_pow2_scale(amax);
+    inv_n = amax > 0.f ? 1.0f / s : 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[kt][j] *= s;
+        a_split2h(x[kt], sd.h[kt][0], sd.h[kt][1]);
+    }
+}
+__device__ __forceinline__ void load_row_regs(float (&x)[KT][8], const float* src_b, int n, int N, int D, int g, const float* w) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int d = 32 * kt + 8 * g + 4 * h;
+            f4 v = f4{0.f, 0.f, 0.f, 0.f};
+            if (n < N && d < D) {
+                v = *reinterpret_cast<const f4*>(src_b + (size_t)n * D + d);
+                if (w) v *= *reinterpret_cast<const f4*>(w + d);
             }
+            x[kt][4 * h] = v.x; x[kt][4 * h + 1] = v.y; x[kt][4 * h + 2] = v.z; x[kt][4 * h + 3] = v.w;
         }
-        side[s] = v;
+}
+__device__ __forceinline__ void load_side_f32(side_t& sd, float& inv_n, const float* src_b, int n, int N, int D, int g, const float* w) {
+    float x[KT][8];
+    load_row_regs(x, src_b, n, N, D, g, w);
+    side_from_regs(x, sd, inv_n);
+}
+// ---- lane-side operand straight from planes (already split by their producer): 14 16-B loads
+__device__ __forceinline__ void load_side_planes(side_t& sd, float& inv_n, const char* planes_b, const float* inv_b, int n, int N, int g) {
+    const int nn = min(n, pad32(N) - 1);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const char* p = planes_b + pl_off_att(nn, 4 * kt + g);
+        sd.h[kt][0] = *reinterpret_cast<const half8*>(p);
+        sd.h[kt][1] = *reinterpret_cast<const half8*>(p + 1024);
+    }
+    inv_n = n < N ? inv_b[n] : 0.f;
+}
+// value of the lane's features of a planes row, reconstructed to fp32 (x = (h0 + h1) * inv)
+__device__ __forceinline__ float side_dot_regs(const side_t& sd, float inv_n, const float (&x)[KT][8]) {
+    float acc = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += ((float)sd.h[kt][0][j] + (float)sd.h[kt][1][j]) * x[kt][j];
+    return acc * inv_n;
+}
+
+// ---- stage the 32-row panel starting at row p0 (a multiple of 32) of one sample's planes: 28 contiguous KiB,
+// 7 LDS-DMA wave-instructions per wave, LDS image lane-linear = the global image
+__device__ __forceinline__ void stage_panel(char* panel, const char* planes_b, int p0, int tid) {
+    const char* src = planes_b + (size_t)(p0 >> 4) * PRB + (tid & 63) * 16;
+    const int wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < PANEL_B / 1024 / NW; ++k) {
+        const int piece = wave + NW * k;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                         (__attribute__((address_space(3))) void*)(panel + piece * 1024), 16, 0, 0);
     }
 }
 
-// Stage rows [row0,row0+PR) of a (R,D) matrix into an LDS panel [PR][LDP] by LDS-DMA (global_load_lds_dwordx4:
-// 16 B per lane straight into LDS, no VGPR round trip, no per-chunk VALU work in the panel loop).  The LDS image is
-// lane-linear in 16-B chunks: chunk c = tid + k*NTHR is row c / 53, columns 4*(c % 53)...; the per-lane SOURCE address
-// is free, so rows beyond R and columns beyond D (incl. the pad chunk) are simply clamped onto valid, finite data:
-// every consumer ignores them (rows via its softmax code / zero weights, columns via zero lane-side registers and
-// d < D store guards).
-template <int NTHR, int PR>
-__device__ __forceinline__ void stage_panel(float* panel, const float* src_b, int row0, int R, int D, int tid) {
-    constexpr int CPR = LDP / 4;                  // 16-B chunks per LDS row (53)
-    constexpr int NCH = PR * CPR;                 // chunks per panel
-    constexpr int NIT = (NCH + NTHR - 1) / NTHR;  // wave-instructions per wave
-    float* wave_dst = panel + (tid & ~63) * 4;    // wave-uniform: this wave's 1-KiB slot of each NTHR*16-B stripe
-#pragma unroll 1   // keep the address math inside the loop: hoisted, it costs ~50 VGPRs in the register-bound kernels
-    for (int k = 0; k < NIT; ++k) {
-        const int c = tid + k * NTHR;
-        if (NCH % NTHR == 0 || c < NCH) {
-            const int row = c / CPR, col = min(4 * (c - row * CPR), D - 4);
-            const float* src = src_b + (size_t)min(row0 + row, R - 1) * D + col;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(wave_dst + k * NTHR * 4), 16, 0, 0);
+__device__ __forceinline__ f4 mfma_h(const half8 a, const half8 b, const f4 c) {
+    // v_mfma_f32_16x16x32_f16: A[row l&15][k = 8(l>>4)+j], B[k][col l&15], C[row 4(l>>4)+e][col l&15]
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// S-type product of the panel's two 16-row blocks against the lane-side registers: c[mb][e] = row 16 mb + 4g + e
+__device__ __forceinline__ void sprod2(const char* panel, int r, int g, const side_t& side, f4 (&c)[2]) {
+    const char* p = panel + r * 64 + ((g ^ att_swz(r)) << 4);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        half8 a0[2], a1[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            a0[mb] = *reinterpret_cast<const half8*>(p + (mb * KT + kt) * PCH);
+            a1[mb] = *reinterpret_cast<const half8*>(p + (mb * KT + kt) * PCH + 1024);
         }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(a0[mb], side.h[kt][1], c[mb]);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(a1[mb], side.h[kt][0], c[mb]);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(a0[mb], side.h[kt][0], c[mb]);
     }
 }
 
-// NB independent S-type chains (the NB 16-row m blocks of the panel) against the same lane-side registers
-template <int NB>
-__device__ __forceinline__ void sprodN(const float* panel, int r, int kg, const side_t& side, f4 (&c)[NB]) {
-    const float* p0 = panel + r * LDP + 4 * kg;
+// per-lane byte offsets of the transpose reads: lane 4q+p of a 16-lane group supplies row 4g+q, features 4p..4p+3 of the
+// 16-feature tile; tr[dt & 1] is the offset inside the (row block, k tile = dt >> 1) chunk of plane 0
+struct tr_off {
+    int o[2];
+};
+__device__ __forceinline__ tr_off make_tr_off(int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int row = 4 * g + q;
+    tr_off t;
 #pragma unroll
-    for (int s = 0; s < DT; ++s) {
-        const f4 b = side[s];
-        f4 a[NB];
+    for (int hlf = 0; hlf < 2; ++hlf) t.o[hlf] = row * 64 + (((2 * hlf + (p >> 1)) ^ att_swz(row)) << 4) + (p & 1) * 8;
+    return t;
+}
+__device__ __forceinline__ v4s tr16(const char* lds_addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(lds_addr));
+}
+__device__ __forceinline__ half8 cat44(const v4s lo, const v4s hi) {
+    const s8v t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(half8, t);
+}
+
+// PV-type: O[dt] += V^T[16 dt ..][32 rows] . W   with W already split into (W0, W1) (k = 8g+j <-> row as above)
+__device__ __forceinline__ void pvprod(const char* panel, const tr_off& tr, const half8 W0, const half8 W1, acc_t& O) {
 #pragma unroll
-        for (int q = 0; q < NB; ++q) a[q] = *reinterpret_cast<const f4*>(p0 + q * 16 * LDP + 16 * s);
-#pragma unroll
-        for (int q = 0; q < NB; ++q) c[q] = mfma16(a[q].x, b.x, c[q]);
-#pragma unroll
-        for (int q = 0; q < NB; ++q) c[q] = mfma16(a[q].y, b.y, c[q]);
-#pragma unroll
-        for (int q = 0; q < NB; ++q) c[q] = mfma16(a[q].z, b.z, c[q]);
-#pragma unroll
-        for (int q = 0; q < NB; ++q) c[q] = mfma16(a[q].w, b.w, c[q]);
+    for (int dt = 0; dt < DT; ++dt) {
+        const char* base = panel + (dt >> 1) * PCH + tr.o[dt & 1];
+        const half8 A0 = cat44(tr16(base), tr16(base + KT * PCH));
+        const half8 A1 = cat44(tr16(base + 1024), tr16(base + KT * PCH + 1024));
+        O[dt] = mfma_h(A0, W1, O[dt]);
+        O[dt] = mfma_h(A1, W0, O[dt]);
+        O[dt] = mfma_h(A0, W0, O[dt]);
     }
+}
+
+// two-term split of the 8 accumulator values a lane holds for the panel (w0: block 0, w1: block 1), truncating
+// conversions (v_cvt_pkrtz_f16_f32: 6 VALU per pair); |w| <= ~2^14 by construction
+__device__ __forceinline__ void split_w(const f4 w0, const f4 w1, half8& H0, half8& H1) {
+    u4v hh, ll;
+    auto pk = [](float a, float b, unsigned& h, unsigned& l) {
+        const auto h2 = __builtin_amdgcn_cvt_pkrtz(a, b);
+        const auto l2 = __builtin_amdgcn_cvt_pkrtz(a - (float)h2[0], b - (float)h2[1]);
+        h = __builtin_bit_cast(unsigned, h2);
+        l = __builtin_bit_cast(unsigned, l2);
+    };
+    unsigned h, l;
+    pk(w0.x, w0.y, h, l); hh[0] = h; ll[0] = l;
+    pk(w0.z, w0.w, h, l); hh[1] = h; ll[1] = l;
+    pk(w1.x, w1.y, h, l); hh[2] = h; ll[2] = l;
+    pk(w1.z, w1.w, h, l); hh[3] = h; ll[3] = l;
+    H0 = __builtin_bit_cast(half8, hh);
+    H1 = __builtin_bit_cast(half8, ll);
+}
+
+// workgroup-wide maximum of up to 4 non-negative per-thread values (red: >= 4 * NW floats of LDS); all threads get it
+template <int NV_>
+__device__ __forceinline__ void wg_allmax(float (&v)[NV_], float* red, int tid) {
+#pragma unroll
+    for (int k = 0; k < NV_; ++k) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v[k] = fmaxf(v[k], __shfl_xor(v[k], o));
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NV_; ++k) red[(tid >> 6) * 4 + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV_; ++k) {
+        float m = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) m = fmaxf(m, red[w * 4 + k]);
+        v[k] = m;
+    }
+}
+// power of two c with c * imax = 2^14 (imax = largest inverse scale, itself a power of two); 1 when there is none
+__device__ __forceinline__ float cmap(float imax) { return imax > 0.f ? WMAX / imax : 1.0f; }
+// power of two c <= 2^14 / (imax * bound): maps the largest possible |W inv_V| of a softmax-gradient operand to <= 2^14
+__device__ __forceinline__ float cmap_bound(float imax, float bound) {
+    const float den = imax * bound;
+    if (!(den > 0.f) || !(den < 1e37f)) return 1.0f;
+    const float c = WMAX / den;
+    return (c > 1e-30f && c < 1e30f) ? pow2_floor(c) : 1.0f;
 }
 
 // block index -> (lane-side tile, split, sample).  Blocks are dealt round-robin over the 8 XCDs (id % 8 labels the
@@ -118,60 +330,74 @@ __device__ __forceinline__ void decode_block(int tiles, int splits, int B, int& 
     split = slot / tiles;
 }
 
-// PV-type: O[dt] += V[m = mb*16 + 4kg + e][d = 16dt + r] * W[e]   for the m block mb of the panel.
-// Software-pipelined by hand: the 13 LDS reads of row e+1 are issued before the 13 MFMAs of row e (at one wave per
-// SIMD hipcc otherwise keeps only 1-2 reads in flight and every ~100-cycle LDS latency lands on the MFMA stream).
-__device__ __forceinline__ void pvprod(const float* panel, int mb, int r, int kg, const f4 w, side_t& O) {
-    const float* v = panel + (mb * 16 + 4 * kg) * LDP + r;
-    float cur[DT], nxt[DT];
+// mask code of streamed row m: 0 = beyond the range, 1 = masked, 2 = live.  Prefix masks come from the lengths
+// (models.py:86-92: mask[b, m] = m < len[b]) when given, arbitrary 0/1 masks from the u8 tensor.
+__device__ __forceinline__ int mask_code(bool in, const uint8_t* mask, const int* len, int b, int R, int m) {
+    if (!in) return 0;
+    const bool live = len ? (m < len[b]) : (mask[(size_t)b * R + m] != 0);
+    return live ? 2 : 1;
+}
+__device__ __forceinline__ bool mask_live(const uint8_t* mask, const int* len, int b, int R, int m) {
+    return len ? (m < len[b]) : (mask[(size_t)b * R + m] != 0);
+}
+
+// ------------------------------------------------------------------------------------------ split passes
+// One 32-lane half wave per row, lane = 16-B octet of the planes (8 features).  Up to 4 tensors per launch
+// (blockIdx.y).  Also the rank-1 terms of the similarity: term[b,row] = src[b,row] . w + bias.
+struct SplitSrc {
+    const float* src;     // (B,R,D)
+    char* planes;         // B x planes_sample_bytes(R)
+    float* inv;           // (B, pad32(R)) inverse row scales, 0 for all-zero and padding rows
+    const float* w;       // (D) or null
+    const float* bias;    // (1) or null
+    float* term;          // (B,R) or null
+    int R;
+};
+struct PrepArgs {
+    SplitSrc t[4];
+    int n, D, B;
+};
+__device__ __forceinline__ void store_split_row(char* planes_b, float* inv_row, int row, int oct, float (&v)[8], float amax) {
+    const float s = a_pow2_scale(amax);
+    if (oct < 4 * KT) {
+        half8 h0, h1;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) cur[dt] = v[16 * dt];
-    __builtin_amdgcn_sched_group_barrier(0x100, DT, 0);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (e < 3) {
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) nxt[dt] = v[(e + 1) * LDP + 16 * dt];
-        }
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) O[dt] = mfma16(cur[dt], w[e], O[dt]);
-        if (e < 3) {
-            // one MFMA, then one read of the next row, ... : reads ride under the MFMAs
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) cur[dt] = nxt[dt];
-        } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, DT, 0);
-        }
+        for (int j = 0; j < 8; ++j) v[j] *= s;
+        a_split2h(v, h0, h1);
+        char* d = planes_b + pl_off_att(row, oct);
+        *reinterpret_cast<half8*>(d) = h0;
+        *reinterpret_cast<half8*>(d + 1024) = h1;
     }
+    if (oct == 0) *inv_row = amax > 0.f ? 1.0f / s : 0.f;
+}
+__global__ __launch_bounds__(256) void att_prep_kernel(const PrepArgs a) {
+    const SplitSrc s = a.t[blockIdx.y];
+    const int Rp = pad32(s.R);
+    const long rowi = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (rowi >= (long)a.B * Rp) return;
+    const int b = rowi / Rp, row = rowi - (long)b * Rp, oct = threadIdx.x & 31;
+    float v[8];
+    float dot = 0.f, amax = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int d = 8 * oct + 4 * h;
+        f4 x = f4{0.f, 0.f, 0.f, 0.f};
+        if (row < s.R && d < a.D) {
+            x = *reinterpret_cast<const f4*>(s.src + ((size_t)b * s.R + row) * a.D + d);
+            if (s.w) dot += f4sum(x * *reinterpret_cast<const f4*>(s.w + d));
+        }
+        v[4 * h] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
+        amax = fmaxf(amax, f4amax(x));
+    }
+    amax = half_allmax(amax);
+    if (s.term) {
+        dot = half_allsum(dot);
+        if (oct == 0 && row < s.R) s.term[(size_t)b * s.R + row] = dot + (s.bias ? s.bias[0] : 0.f);
+    }
+    store_split_row(s.planes + (size_t)b * planes_sample_bytes(s.R), s.inv + (size_t)b * Rp + row, row, oct, v, amax);
 }
 
-__device__ __forceinline__ float kg_allsum(float v) {  // over the 4 k-groups (lanes r, r+16, r+32, r+48)
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
-}
-__device__ __forceinline__ float kg_allmax(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
-}
-__device__ __forceinline__ float r_allsum(float v) {  // over the 16 lanes of a k-group
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    return v;
-}
-__device__ __forceinline__ float f4sum(const f4 v) { return (v.x + v.y) + (v.z + v.w); }
-__device__ __forceinline__ float f4max(const f4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
-
-// ------------------------------------------------------------------------------------------ rank-1 terms
-// rterm[b,i] = text_d[b,i].w_t + bias ; cterm[b,j] = mod_d[b,j].w_m        (one wave per row)
+// rank-1 terms alone (general-width path, bidaf_big.hip): rterm[b,i] = text_d[b,i].w_t + bias ; cterm[b,j] = mod_d[b,j].w_m
 __global__ __launch_bounds__(256) void att_rank1_kernel(const float* __restrict__ text_d, const float* __restrict__ mod_d,
                                                         const float* __restrict__ w_t, const float* __restrict__ w_m,
                                                         const float* __restrict__ bias, float* __restrict__ rterm,
@@ -182,11 +408,7 @@ __global__ __launch_bounds__(256) void att_rank1_kernel(const float* __restrict_
     const float* src = is_t ? text_d + (size_t)row * D : mod_d + (size_t)(row - BT) * D;
     const float* w = is_t ? w_t : w_m;
     float acc = 0.f;
-    for (int d = lane * 4; d < D; d += 256) {
-        const f4 v = *reinterpret_cast<const f4*>(src + d);
-        const f4 ww = *reinterpret_cast<const f4*>(w + d);
-        acc += f4sum(v * ww);
-    }
+    for (int d = lane * 4; d < D; d += 256) acc += f4sum(*reinterpret_cast<const f4*>(src + d) * *reinterpret_cast<const f4*>(w + d));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) {
@@ -199,46 +421,58 @@ __global__ __launch_bounds__(256) void att_rank1_kernel(const float* __restrict_
 struct AttFwdArgs {
     const float* side_src;  // (B,N,D) lane-side S operand (dropped copy), scaled by w_tm on load
     const float* w_tm;      // (D)
-    const float* mS;        // (B,R,D) m-side S operand (dropped copy)
-    const float* mV0;       // (B,R,D) first  value panel
-    const float* mV1;       // (B,R,D) second value panel (row pass only)
-    const uint8_t* m_mask;  // (B,R)
+    const char* mS;         // planes of the streamed S operand (dropped copy)      + inverse scales (B, pad32(R))
+    const float* iS;
+    const char* mV0;        // planes of the first value tensor (== mS without dropout)
+    const float* iV0;
+    const char* mV1;        // planes of the second value tensor (row pass only)
+    const float* iV1;
+    const uint8_t* m_mask;  // (B,R) or null when m_len is given
+    const int* m_len;       // (B) prefix lengths or null
     const float* m_term;    // (B,R)
     const float* n_term;    // (B,N)
-    float* stat;            // (B,N,2) {max,sum}            (splits == 1)
-    float* part_o;          // (B,splits,N,D) unnormalised  (col pass, splits > 1)
+    float* stat;            // (B,N,2) {max,sum}                     (row pass)
+    float* part_o;          // (B,splits,N,D) unnormalised partials  (col pass)
     float* part_stat;       // (B,splits,N,2)
-    float* q;               // (B,N,D)                      (col pass, splits == 1)
-    const float* text;      // (B,N,D)                      (row pass epilogue)
+    const float* text;      // (B,N,D)                               (row pass epilogue)
     float* out;             // (B,N,4D)
     float* bsave;           // (B,N,D)
     int N, R, D, B, splits, rows_per_split;
-    int dbg;   // timing-only ablations (MMB_ATT_DBG, never set by the product path): 1 = skip staging, 2 = skip S, 4 = skip PV, 8 = skip the epilogue
 };
 
-// NV = 1: column pass = att_col_kernel (lane side = modality rows j, streams text rows i), produces q and the column stats.
+// NV = 1: column pass = att_col_kernel (lane side = modality rows j, streams text rows i), produces the partials of q.
 // NV = 2: row pass = att_row_kernel    (lane side = text rows i, streams modality rows j with values [mod | q]), produces out.
-// DB: two LDS stages -- the LDS-DMA of panel p+1 is in flight under the MFMAs of panel p (one barrier per panel)
-template <int NV, int NW, int PR, bool DB>
-__device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, float* smem) {
-    constexpr int NTHR = NW * 64, NB = PR / 16;
+template <int NV>
+__device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, kg = lane >> 4;
-    const int N = a.N, R = a.R, D = a.D;
+    const int r = lane & 15, g = lane >> 4;
+    const int N = a.N, R = a.R, D = a.D, Rp = pad32(R);
     int tile, split, b;
     decode_block((N + 16 * NW - 1) / (16 * NW), a.splits, a.B, tile, split, b);
     const int n = (tile * NW + wave) * 16 + r;
+    const int rps = a.rows_per_split;
 
     const bool sep_s = a.mS != a.mV0;  // dropped copy differs from the clean value panel
-    constexpr int STAGE_F = (NV + 1) * PR * LDP;   // floats per LDS stage (panels)
+    char* pV0 = smem;
+    char* pV1 = smem + PANEL_B;                       // only touched when NV == 2
+    char* pS = sep_s ? smem + NV * PANEL_B : pV0;
+    float* mterm_all = reinterpret_cast<float*>(smem + (NV + 1) * PANEL_B);   // per-row scalars of the WHOLE split, loaded once
+    int* mcode_all = reinterpret_cast<int*>(mterm_all + rps);
+    float* sS_all = mterm_all + 2 * rps;              // inverse row scale of the S operand
+    float* sV0_all = mterm_all + 3 * rps;             // inverse row scale of V0 times c0
+    float* sV1_all = mterm_all + 4 * rps;
+    float* red = mterm_all + 5 * rps;
 
-    const float* mS_b = a.mS + (size_t)b * R * D;
-    const float* mV0_b = a.mV0 + (size_t)b * R * D;
-    const float* mV1_b = NV == 2 ? a.mV1 + (size_t)b * R * D : nullptr;
+    const size_t szR = planes_sample_bytes(R);
+    const char* mS_b = a.mS + (size_t)b * szR;
+    const char* mV0_b = a.mV0 + (size_t)b * szR;
+    const char* mV1_b = NV == 2 ? a.mV1 + (size_t)b * szR : nullptr;
 
     side_t side;
-    load_side(side, a.side_src + (size_t)b * N * D, n, N, D, kg, a.w_tm);
+    float inv_n;
+    load_side_f32(side, inv_n, a.side_src + (size_t)b * N * D, n, N, D, g, a.w_tm);
     const float nterm = n < N ? a.n_term[(size_t)b * N + n] : 0.f;
+    const tr_off tr = make_tr_off(lane);
 
     if (NV == 2) {
         // the first quarter of `out` is a verbatim copy of text (attention.py:52): written here, whole rows per
@@ -251,61 +485,54 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, float* smem) {
                 *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 4 * lane) = *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * lane);
         }
     }
-    side_t O0, O1;
-    zero_side(O0);
-    zero_side(O1);
+    acc_t O0, O1;
+    zero_acc(O0);
+    zero_acc(O1);
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int row_begin = split * a.rows_per_split;
-    const int row_end = min(R, row_begin + a.rows_per_split);
-    auto stage = [&](float* base, int p0) {
-        float* pV0 = base;
-        stage_panel<NTHR, PR>(pV0, mV0_b, p0, row_end, D, tid);
-        if (NV == 2) stage_panel<NTHR, PR>(pV0 + PR * LDP, mV1_b, p0, row_end, D, tid);
-        if (sep_s) stage_panel<NTHR, PR>(pV0 + NV * PR * LDP, mS_b, p0, row_end, D, tid);
-    };
-    // per-row scalars of the streamed side for the WHOLE split, loaded once (a per-panel global load in front of the
-    // panel barrier costs a full memory round trip per panel)
-    float* mterm_all = smem + (DB ? 2 : 1) * STAGE_F;                   // [rows_per_split]
-    int* mcode_all = reinterpret_cast<int*>(mterm_all + a.rows_per_split);   // 0 = beyond R, 1 = masked, 2 = live
-    for (int i = tid; i < a.rows_per_split; i += NTHR) {
+    const int row_begin = split * rps;
+    const int row_end = min(R, row_begin + rps);
+    float im[2] = {0.f, 0.f};
+    for (int i = tid; i < rps; i += NTHR) {
         const int m = row_begin + i;
         const bool in = m < row_end;
         mterm_all[i] = in ? a.m_term[(size_t)b * R + m] : 0.f;
-        mcode_all[i] = in ? (a.m_mask[(size_t)b * R + m] ? 2 : 1) : 0;
-    }
-    int cur = 0;
-    if (DB) {
-        if (row_begin < row_end) stage(smem, row_begin);
-        __syncthreads();
-    }
-    for (int p0 = row_begin; p0 < row_end; p0 += PR) {
-        float* base = smem + (DB ? cur * STAGE_F : 0);
-        if (DB) {
-            if (p0 + PR < row_end) stage(smem + (cur ^ 1) * STAGE_F, p0 + PR);
-        } else {
-            __syncthreads();
-            if (!(a.dbg & 1) || p0 == row_begin) stage(base, p0);
-            __syncthreads();
+        mcode_all[i] = mask_code(in, a.m_mask, a.m_len, b, R, m);
+        sS_all[i] = in ? a.iS[(size_t)b * Rp + m] : 0.f;
+        const float v0 = in ? a.iV0[(size_t)b * Rp + m] : 0.f;
+        sV0_all[i] = v0;
+        im[0] = fmaxf(im[0], v0);
+        if (NV == 2) {
+            const float v1 = in ? a.iV1[(size_t)b * Rp + m] : 0.f;
+            sV1_all[i] = v1;
+            im[1] = fmaxf(im[1], v1);
         }
-        const float* pV0 = base;
-        const float* pV1 = pV0 + PR * LDP;                       // only touched when NV == 2
-        const float* pS = sep_s ? (pV0 + NV * PR * LDP) : pV0;
-        const float* mterm_s = mterm_all + (p0 - row_begin);
-        const int* mcode_s = mcode_all + (p0 - row_begin);
+    }
+    wg_allmax(im, red, tid);
+    const float c0 = cmap(im[0]), c1 = cmap(im[1]);
+    for (int i = tid; i < rps; i += NTHR) {   // each thread rescales the entries it wrote itself
+        sV0_all[i] *= c0;
+        if (NV == 2) sV1_all[i] *= c1;
+    }
 
-        f4 v[NB];
-#pragma unroll
-        for (int q = 0; q < NB; ++q) v[q] = f4{0.f, 0.f, 0.f, 0.f};
-        if (!(a.dbg & 2)) sprodN<NB>(pS, r, kg, side, v);
+    for (int p0 = row_begin; p0 < row_end; p0 += PR) {
+        __syncthreads();
+        stage_panel(pV0, mV0_b, p0, tid);
+        if (NV == 2) stage_panel(pV1, mV1_b, p0, tid);
+        if (sep_s) stage_panel(pS, mS_b, p0, tid);
+        __syncthreads();
+        const int i0 = p0 - row_begin;
+
+        f4 v[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+        sprod2(pS, r, g, side, v);
         float bmax = -INFINITY;
 #pragma unroll
-        for (int mb = 0; mb < NB; ++mb)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int ml = mb * 16 + 4 * kg + e;
-                const int code = mcode_s[ml];
-                const float x = v[mb][e] + mterm_s[ml] + nterm;
+                const int ml = i0 + mb * 16 + 4 * g + e;
+                const int code = mcode_all[ml];
+                const float x = v[mb][e] * (sS_all[ml] * inv_n) + mterm_all[ml] + nterm;
                 v[mb][e] = code == 2 ? x : (code == 1 ? NEG : -INFINITY);
                 bmax = fmaxf(bmax, v[mb][e]);
             }
@@ -314,7 +541,7 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, float* smem) {
         const float alpha = __expf(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
-        for (int mb = 0; mb < NB; ++mb)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 v[mb][e] = __expf(v[mb][e] - m_new);
@@ -329,43 +556,51 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, float* smem) {
             }
         }
         m_run = m_new;
+        {
+            f4 w[2];
 #pragma unroll
-        for (int mb = 0; mb < NB; ++mb) {
-            if (a.dbg & 4) continue;
-            pvprod(pV0, mb, r, kg, v[mb], O0);
-            if (NV == 2) pvprod(pV1, mb, r, kg, v[mb], O1);
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * sV0_all[i0 + mb * 16 + 4 * g + e];
+            half8 W0, W1;
+            split_w(w[0], w[1], W0, W1);
+            pvprod(pV0, tr, W0, W1, O0);
         }
-        if (DB) {
-            __syncthreads();   // retires the DMA of the next stage and frees this one
-            cur ^= 1;
+        if (NV == 2) {
+            f4 w[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * sV1_all[i0 + mb * 16 + 4 * g + e];
+            half8 W0, W1;
+            split_w(w[0], w[1], W0, W1);
+            pvprod(pV1, tr, W0, W1, O1);
         }
     }
 
     // ---- epilogue.  The accumulators hold 16 rows x 64-B pieces per store instruction; written directly that is 16
-    // partial cache lines per instruction (measured: half of this kernel's time).  Instead each wave parks its tile in
-    // LDS (the panels are dead) and the workgroup writes whole rows: one row per wave-instruction, lane = 16-B chunk.
+    // partial cache lines per instruction.  Instead each wave parks its tile in LDS (the panels are dead) and the
+    // workgroup writes whole rows: one row per wave-instruction, lane = 16-B chunk.
     const float l = kg_allsum(l_run);
-    const bool partial = NV == 1 && a.splits > 1;
-    const float inv = partial ? 1.0f : 1.0f / l;
-    if (n < N && kg == 0) {
+    const bool partial = NV == 1;
+    if (n < N && g == 0) {
         float* st = partial ? a.part_stat + (((size_t)b * a.splits + split) * N + n) * 2 : a.stat + ((size_t)b * N + n) * 2;
         st[0] = m_run;
         st[1] = l;
     }
-    if (a.dbg & 8) return;   // timing-only: no epilogue
-    float* et = smem;                                   // [16*NW][LDP]
+    float* et = reinterpret_cast<float*>(smem);          // [16*NW][LDP]
     const int row0 = tile * NW * 16;                    // first lane-side row of this workgroup
     const int c4 = lane;                                // this lane's 16-B chunk of a row
-    auto park = [&](const side_t& O) {
+    auto park = [&](const acc_t& O, float scale) {
         __syncthreads();
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
-            *reinterpret_cast<f4*>(et + (wave * 16 + r) * LDP + 16 * dt + 4 * kg) = O[dt] * inv;
+            *reinterpret_cast<f4*>(et + (wave * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
         __syncthreads();
     };
-    park(O0);
+    park(O0, partial ? 1.0f / c0 : 1.0f / (l * c0));
     if (NV == 1) {
-        float* dst = partial ? a.part_o + ((size_t)b * a.splits + split) * N * D : a.q + (size_t)b * N * D;
+        float* dst = a.part_o + ((size_t)b * a.splits + split) * N * D;
         for (int rr = wave; rr < 16 * NW; rr += NW) {
             const int gn = row0 + rr;
             if (gn < N && 4 * c4 < D) *reinterpret_cast<f4*>(dst + (size_t)gn * D + 4 * c4) = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
@@ -384,7 +619,7 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, float* smem) {
                 *reinterpret_cast<f4*>(o + 2 * D) = t * av;
             }
         }
-        park(O1);
+        park(O1, 1.0f / (l * c1));
         for (int rr = wave; rr < 16 * NW; rr += NW) {
             const int gn = row0 + rr;
             if (gn < N && 4 * c4 < D) {
@@ -397,86 +632,123 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, float* smem) {
     }
 }
 
-template <int NW, int PR, bool DB = false>
-__global__ __launch_bounds__(NW * 64) void att_col_kernel(const AttFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    att_fwd_body<1, NW, PR, DB>(a, smem);
+__global__ __launch_bounds__(NTHR) void att_col_kernel(const AttFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    att_fwd_body<1>(a, smem);
 }
-template <int NW, int PR, bool DB = false>
-__global__ __launch_bounds__(NW * 64) void att_row_kernel(const AttFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    att_fwd_body<2, NW, PR, DB>(a, smem);
+__global__ __launch_bounds__(NTHR) void att_row_kernel(const AttFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    att_fwd_body<2>(a, smem);
 }
 
-// merge the per-split partial column softmaxes: q = sum_p O_p e^{m_p-m} / sum_p l_p e^{m_p-m}
+// merge the per-split partial column softmaxes, q = sum_p O_p e^{m_p-m} / sum_p l_p e^{m_p-m}, and write q as planes
+// (it is only ever a streamed / lane-side MFMA operand): one half wave per modality row, lane = octet
 __global__ __launch_bounds__(256) void att_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_stat,
-                                                          float* __restrict__ q, float* __restrict__ stat, int B, int N, int D,
-                                                          int splits) {
-    const int d4 = D / 4;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)B * N * d4) return;
-    const int c = idx % d4;
-    const size_t bn = idx / d4;
-    const int n = bn % N, b = bn / N;
-    float m = -INFINITY;
-    for (int p = 0; p < splits; ++p) m = fmaxf(m, part_stat[(((size_t)b * splits + p) * N + n) * 2]);
-    float l = 0.f;
-    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
-    for (int p = 0; p < splits; ++p) {
-        const size_t o = ((size_t)b * splits + p) * N + n;
-        const float sc = __expf(part_stat[o * 2] - m);
-        l += part_stat[o * 2 + 1] * sc;
-        acc += *reinterpret_cast<const f4*>(part_o + o * D + 4 * c) * sc;
+                                                          char* __restrict__ q_planes, float* __restrict__ q_inv, float* __restrict__ stat,
+                                                          int B, int N, int D, int splits) {
+    const int Np = pad32(N);
+    const long rowi = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (rowi >= (long)B * Np) return;
+    const int b = rowi / Np, n = rowi - (long)b * Np, oct = threadIdx.x & 31;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float amax = 0.f;
+    if (n < N) {
+        float m = -INFINITY;
+        for (int p = 0; p < splits; ++p) m = fmaxf(m, part_stat[(((size_t)b * splits + p) * N + n) * 2]);
+        float l = 0.f;
+        for (int p = 0; p < splits; ++p) {
+            const size_t o = ((size_t)b * splits + p) * N + n;
+            const float sc = __expf(part_stat[o * 2] - m);
+            l += part_stat[o * 2 + 1] * sc;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int d = 8 * oct + 4 * h;
+                if (d < D) {
+                    const f4 x = *reinterpret_cast<const f4*>(part_o + o * D + d) * sc;
+                    v[4 * h] += x.x; v[4 * h + 1] += x.y; v[4 * h + 2] += x.z; v[4 * h + 3] += x.w;
+                }
+            }
+        }
+        const float il = 1.0f / l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] *= il;
+            amax = fmaxf(amax, fabsf(v[j]));
+        }
+        if (oct == 0) {
+            stat[((size_t)b * N + n) * 2] = m;
+            stat[((size_t)b * N + n) * 2 + 1] = l;
+        }
     }
-    *reinterpret_cast<f4*>(q + bn * D + 4 * c) = acc * (1.0f / l);
-    if (c == 0) {
-        stat[bn * 2] = m;
-        stat[bn * 2 + 1] = l;
-    }
+    amax = half_allmax(amax);
+    store_split_row(q_planes + (size_t)b * planes_sample_bytes(N), q_inv + (size_t)b * Np + n, n, oct, v, amax);
 }
 
 // ------------------------------------------------------------------------------------------ backward
-// elementwise prologue over text rows (one wave per row):
-//   da = g1 + g2*text ; db = g3*text ; delta1 = g1.a + g2.(text*a) + g3.(text*b) ; d_text = g0 + g2*a + g3*b
+// prologue over text rows (one half wave per row, lane = octet):
+//   da = g1 + g2*text ; db = g3*text  (written as planes: they are only ever MFMA operands)
+//   delta1 = da.a + db.b ; d_text = g0 + g2*a + g3*b      (a = out[:, D:2D], b = bsave)
 __global__ __launch_bounds__(256) void att_bwd_pre_kernel(const float* __restrict__ d_out, const float* __restrict__ out,
                                                           const float* __restrict__ text, const float* __restrict__ bsave,
-                                                          float* __restrict__ da, float* __restrict__ db,
+                                                          char* __restrict__ da_planes, float* __restrict__ da_inv,
+                                                          char* __restrict__ db_planes, float* __restrict__ db_inv,
                                                           float* __restrict__ delta1, float* __restrict__ d_text,
                                                           float* __restrict__ d_w_t, float* __restrict__ d_w_m,
-                                                          float* __restrict__ d_w_tm, float* __restrict__ d_bias, int rows, int D) {
+                                                          float* __restrict__ d_w_tm, float* __restrict__ d_bias, int B, int T, int D) {
     if (blockIdx.x == 0) {  // the parameter gradients are accumulated with atomics by the later kernels
         for (int i = threadIdx.x; i < D; i += 256) d_w_t[i] = d_w_m[i] = d_w_tm[i] = 0.f;
         if (threadIdx.x == 0) d_bias[0] = 0.f;
     }
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const float* g = d_out + (size_t)row * 4 * D;
-    const float* o = out + (size_t)row * 4 * D;
-    float acc = 0.f;
-    for (int d = lane * 4; d < D; d += 256) {
-        const f4 g0 = *reinterpret_cast<const f4*>(g + d), g1 = *reinterpret_cast<const f4*>(g + D + d);
-        const f4 g2 = *reinterpret_cast<const f4*>(g + 2 * D + d), g3 = *reinterpret_cast<const f4*>(g + 3 * D + d);
-        const f4 o1 = *reinterpret_cast<const f4*>(o + D + d), o2 = *reinterpret_cast<const f4*>(o + 2 * D + d);
-        const f4 o3 = *reinterpret_cast<const f4*>(o + 3 * D + d);
-        const f4 t = *reinterpret_cast<const f4*>(text + (size_t)row * D + d);
-        const f4 bv = *reinterpret_cast<const f4*>(bsave + (size_t)row * D + d);
-        *reinterpret_cast<f4*>(da + (size_t)row * D + d) = g1 + g2 * t;
-        *reinterpret_cast<f4*>(db + (size_t)row * D + d) = g3 * t;
-        *reinterpret_cast<f4*>(d_text + (size_t)row * D + d) = g0 + g2 * o1 + g3 * bv;
-        acc += f4sum(g1 * o1 + g2 * o2 + g3 * o3);
-    }
+    const int Tp = pad32(T);
+    const long rowi = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (rowi >= (long)B * Tp) return;
+    const int b = rowi / Tp, row = rowi - (long)b * Tp, oct = threadIdx.x & 31;
+    float va[8], vb[8];
+    float acc = 0.f, amax_a = 0.f, amax_b = 0.f;
 #pragma unroll
-    for (int o_ = 32; o_ >= 1; o_ >>= 1) acc += __shfl_xor(acc, o_);
-    if (lane == 0) delta1[row] = acc;
+    for (int h = 0; h < 2; ++h) {
+        const int d = 8 * oct + 4 * h;
+        f4 xa = f4{0.f, 0.f, 0.f, 0.f}, xb = xa;
+        if (row < T && d < D) {
+            const size_t rr = (size_t)b * T + row;
+            const float* g = d_out + rr * 4 * D;
+            const f4 g0 = *reinterpret_cast<const f4*>(g + d), g1 = *reinterpret_cast<const f4*>(g + D + d);
+            const f4 g2 = *reinterpret_cast<const f4*>(g + 2 * D + d), g3 = *reinterpret_cast<const f4*>(g + 3 * D + d);
+            const f4 av = *reinterpret_cast<const f4*>(out + rr * 4 * D + D + d);
+            const f4 t = *reinterpret_cast<const f4*>(text + rr * D + d);
+            const f4 bv = *reinterpret_cast<const f4*>(bsave + rr * D + d);
+            xa = g1 + g2 * t;
+            xb = g3 * t;
+            *reinterpret_cast<f4*>(d_text + rr * D + d) = g0 + g2 * av + g3 * bv;
+            acc += f4sum(xa * av + xb * bv);
+        }
+        va[4 * h] = xa.x; va[4 * h + 1] = xa.y; va[4 * h + 2] = xa.z; va[4 * h + 3] = xa.w;
+        vb[4 * h] = xb.x; vb[4 * h + 1] = xb.y; vb[4 * h + 2] = xb.z; vb[4 * h + 3] = xb.w;
+        amax_a = fmaxf(amax_a, f4amax(xa));
+        amax_b = fmaxf(amax_b, f4amax(xb));
+    }
+    amax_a = half_allmax(amax_a);
+    amax_b = half_allmax(amax_b);
+    acc = half_allsum(acc);
+    if (oct == 0 && row < T) delta1[(size_t)b * T + row] = acc;
+    const size_t sz = planes_sample_bytes(T);
+    store_split_row(da_planes + (size_t)b * sz, da_inv + (size_t)b * Tp + row, row, oct, va, amax_a);
+    store_split_row(db_planes + (size_t)b * sz, db_inv + (size_t)b * Tp + row, row, oct, vb, amax_b);
 }
 
 struct AttBwdArgs {
-    const float *text, *mod, *text_d, *mod_d;       // (B,T,D) / (B,M,D)
-    const uint8_t *text_mask, *mod_mask;            // (B,T) / (B,M)
+    const float *text, *mod, *text_d, *mod_d;       // (B,T,D) / (B,M,D) fp32 (lane-side loads)
+    const uint8_t *text_mask, *mod_mask;            // (B,T) / (B,M) or null with the lengths
+    const int *text_len, *mod_len;                  // (B) or null
     const float *w_t, *w_m, *w_tm;
-    const float *q, *rterm, *cterm, *row_stat, *col_stat;
-    const float *da, *db, *delta1;                   // workspace (B,T,D),(B,T,D),(B,T)
-    float *dq, *delta2;                              // workspace (B,M,D),(B,M)
+    const float *rterm, *cterm, *row_stat, *col_stat;
+    // planes + inverse scales (saved by the forward: text, text_d, mod, mod_d, q; workspace: da, db, dq)
+    const char *pT, *pTd, *pM, *pMd, *pQ, *pDa, *pDb;
+    const float *iT, *iTd, *iM, *iMd, *iQ, *iDa, *iDb;
+    char* pDq;
+    float* iDq;
+    const float* delta1;                             // (B,T)
+    float* delta2;                                   // (B,M)
     float *d_mod, *d_mod_d, *d_text, *d_text_d;      // outputs
     float *d_w_t, *d_w_m, *d_w_tm, *d_bias;          // outputs, zeroed by the prologue, accumulated with atomics
     // per-split partial sums of the j-side sweeps, (B,splits,M,D) / (B,splits,M)
@@ -485,194 +757,243 @@ struct AttBwdArgs {
     int fold;                                        // 1: no dropped copies, d_*_d folded into d_*
 };
 
-__device__ __forceinline__ void store_side(float* dst_row, const side_t& v, int D, int kg) {
+__device__ __forceinline__ void store_acc(float* dst_row, const acc_t& v, float scale, int D, int g) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-        const int d = 16 * dt + 4 * kg;
-        if (d < D) *reinterpret_cast<f4*>(dst_row + d) = v[dt];
+        const int d = 16 * dt + 4 * g;
+        if (d < D) *reinterpret_cast<f4*>(dst_row + d) = v[dt] * scale;
     }
 }
 
 // j-side sweep 1 (lane side = modality rows j, streams a slice of the text rows i):
 //   dq_j += sum_i P1_ij db_i ; dmodc_j += sum_i P1_ij da_i ; dS1 = P1 (dP1 - delta1_i) mask_j
 //   dmodd_j += sum_i dS1_ij text_d_i (scaled by w_tm later) ; dc_j += sum_i dS1_ij
-template <int NW, int PR>
-__global__ __launch_bounds__(NW * 64) void att_bwd_j1_kernel(const AttBwdArgs a) {
-    constexpr int NTHR = NW * 64, NB = PR / 16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__global__ __launch_bounds__(NTHR) void att_bwd_j1_kernel(const AttBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, kg = lane >> 4;
-    const int T = a.T, M = a.M, D = a.D;
+    const int r = lane & 15, g = lane >> 4;
+    const int T = a.T, M = a.M, D = a.D, Tp = pad32(T);
     int tile, split, b;
     decode_block((M + 16 * NW - 1) / (16 * NW), a.splits, a.B, tile, split, b);
     const int n = (tile * NW + wave) * 16 + r;  // modality row j
+    const int rps = a.rows_per_split;
 
-    float* pTd = smem;
-    float* pDa = pTd + PR * LDP;
-    float* pDb = pDa + PR * LDP;
-    float* rt_s = pDb + PR * LDP;   // [PR] rterm
-    float* rmax_s = rt_s + PR;      // [PR]
-    float* rinv_s = rmax_s + PR;    // [PR] 1/rowsum, 0 beyond the slice
-    float* dl1_s = rinv_s + PR;     // [PR]
+    char* pTd = smem;
+    char* pDa = smem + PANEL_B;
+    char* pDb = smem + 2 * PANEL_B;
+    float* rt_all = reinterpret_cast<float*>(smem + 3 * PANEL_B);
+    float* rmax_all = rt_all + rps;
+    float* rinv_all = rt_all + 2 * rps;    // 1/rowsum, 0 beyond the slice
+    float* dl1_all = rt_all + 3 * rps;
+    float* sTd_all = rt_all + 4 * rps;
+    float* sDa_all = rt_all + 5 * rps;
+    float* sDb_all = rt_all + 6 * rps;
+    float* red = rt_all + 7 * rps;
 
+    const size_t szT = planes_sample_bytes(T), szM = planes_sample_bytes(M);
     side_t sideS, sideM, sideQ;
-    load_side(sideS, a.mod_d + (size_t)b * M * D, n, M, D, kg, a.w_tm);
-    load_side(sideM, a.mod + (size_t)b * M * D, n, M, D, kg, nullptr);
-    load_side(sideQ, a.q + (size_t)b * M * D, n, M, D, kg, nullptr);
+    float inS, inM, inQ;
+    load_side_f32(sideS, inS, a.mod_d + (size_t)b * M * D, n, M, D, g, a.w_tm);
+    load_side_planes(sideM, inM, a.pM + (size_t)b * szM, a.iM + (size_t)b * pad32(M), n, M, g);
+    load_side_planes(sideQ, inQ, a.pQ + (size_t)b * szM, a.iQ + (size_t)b * pad32(M), n, M, g);
     const bool nin = n < M;
     const float cterm = nin ? a.cterm[(size_t)b * M + n] : 0.f;
-    const bool mm = nin ? a.mod_mask[(size_t)b * M + n] != 0 : false;
+    const bool mm = nin ? mask_live(a.mod_mask, a.mod_len, b, M, n) : false;
     const float mmf = mm ? 1.f : 0.f;
+    const tr_off tr = make_tr_off(lane);
 
-    side_t dq, dmc, dmd;
-    zero_side(dq);
-    zero_side(dmc);
-    zero_side(dmd);
+    const int row_begin = split * rps, row_end = min(T, row_begin + rps);
+    float im[3] = {0.f, 0.f, 0.f};
+    for (int i = tid; i < rps; i += NTHR) {
+        const int t = row_begin + i;
+        const bool in = t < row_end;
+        const size_t bt = (size_t)b * T + t;
+        rt_all[i] = in ? a.rterm[bt] : 0.f;
+        rmax_all[i] = in ? a.row_stat[bt * 2] : INFINITY;   // exp(x - inf) = 0 beyond the slice
+        rinv_all[i] = in ? 1.0f / a.row_stat[bt * 2 + 1] : 0.f;
+        dl1_all[i] = in ? a.delta1[bt] : 0.f;
+        const float v0 = in ? a.iTd[(size_t)b * Tp + t] : 0.f, v1 = in ? a.iDa[(size_t)b * Tp + t] : 0.f, v2 = in ? a.iDb[(size_t)b * Tp + t] : 0.f;
+        sTd_all[i] = v0; sDa_all[i] = v1; sDb_all[i] = v2;
+        im[0] = fmaxf(im[0], v0); im[1] = fmaxf(im[1], v1); im[2] = fmaxf(im[2], v2);
+    }
+    wg_allmax(im, red, tid);
+    const float cDa = cmap(im[1]), cDb = cmap(im[2]);
+    // |dS1_ij| <= |dP1_ij| + |delta1_i| <= 2 D 2^28 (inv_da_i inv_mod_j + inv_db_i inv_q_j)   (row maxima < 2^14 inv)
+    const float cS = cmap_bound(im[0], 1.3743895e11f /* 2^37 */ * (im[1] * inM + im[2] * inQ));
+
+    acc_t dq, dmc, dmd;
+    zero_acc(dq);
+    zero_acc(dmc);
+    zero_acc(dmd);
     float dc = 0.f;
 
-    const float* td_b = a.text_d + (size_t)b * T * D;
-    const float* da_b = a.da + (size_t)b * T * D;
-    const float* db_b = a.db + (size_t)b * T * D;
-    const int row_begin = split * a.rows_per_split, row_end = min(T, row_begin + a.rows_per_split);
+    const char* td_b = a.pTd + (size_t)b * szT;
+    const char* da_b = a.pDa + (size_t)b * szT;
+    const char* db_b = a.pDb + (size_t)b * szT;
     for (int p0 = row_begin; p0 < row_end; p0 += PR) {
         __syncthreads();
-        stage_panel<NTHR, PR>(pTd, td_b, p0, row_end, D, tid);
-        stage_panel<NTHR, PR>(pDa, da_b, p0, row_end, D, tid);
-        stage_panel<NTHR, PR>(pDb, db_b, p0, row_end, D, tid);
-        if (tid < PR) {
-            const int i = p0 + tid;
-            const bool in = i < row_end;
-            rt_s[tid] = in ? a.rterm[(size_t)b * T + i] : 0.f;
-            rmax_s[tid] = in ? a.row_stat[((size_t)b * T + i) * 2] : INFINITY;   // exp(x - inf) = 0 beyond the slice
-            rinv_s[tid] = in ? 1.0f / a.row_stat[((size_t)b * T + i) * 2 + 1] : 0.f;
-            dl1_s[tid] = in ? a.delta1[(size_t)b * T + i] : 0.f;
-        }
+        stage_panel(pTd, td_b, p0, tid);
+        stage_panel(pDa, da_b, p0, tid);
+        stage_panel(pDb, db_b, p0, tid);
         __syncthreads();
-        f4 s[NB], dp[NB];
+        const int i0 = p0 - row_begin;
+        f4 s[2], dpa[2], dpb[2];
 #pragma unroll
-        for (int q = 0; q < NB; ++q) s[q] = dp[q] = f4{0.f, 0.f, 0.f, 0.f};
-        sprodN<NB>(pTd, r, kg, sideS, s);
-        sprodN<NB>(pDa, r, kg, sideM, dp);
-        sprodN<NB>(pDb, r, kg, sideQ, dp);
-        f4 p1[NB], ds[NB];
+        for (int q = 0; q < 2; ++q) s[q] = dpa[q] = dpb[q] = f4{0.f, 0.f, 0.f, 0.f};
+        sprod2(pTd, r, g, sideS, s);
+        sprod2(pDa, r, g, sideM, dpa);
+        sprod2(pDb, r, g, sideQ, dpb);
+        f4 wq[2], wc[2], wd[2];
 #pragma unroll
-        for (int mb = 0; mb < NB; ++mb)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int ml = mb * 16 + 4 * kg + e;
-                const float x = mm ? s[mb][e] + rt_s[ml] + cterm : NEG;
-                const float p = __expf(x - rmax_s[ml]) * rinv_s[ml];  // rinv = 0 beyond the slice
-                p1[mb][e] = p;
-                const float g = p * (dp[mb][e] - dl1_s[ml]) * mmf;
-                ds[mb][e] = g;
-                dc += g;
+                const int ml = i0 + mb * 16 + 4 * g + e;
+                const float x = mm ? s[mb][e] * (sTd_all[ml] * inS) + rt_all[ml] + cterm : NEG;
+                const float p = __expf(x - rmax_all[ml]) * rinv_all[ml];  // rinv = 0 beyond the slice
+                const float dp = dpa[mb][e] * (sDa_all[ml] * inM) + dpb[mb][e] * (sDb_all[ml] * inQ);
+                const float gd = p * (dp - dl1_all[ml]) * mmf;
+                dc += gd;
+                wq[mb][e] = p * (sDb_all[ml] * cDb);
+                wc[mb][e] = p * (sDa_all[ml] * cDa);
+                wd[mb][e] = gd * (sTd_all[ml] * cS);
             }
-#pragma unroll
-        for (int mb = 0; mb < NB; ++mb) {
-            pvprod(pDb, mb, r, kg, p1[mb], dq);
-            pvprod(pDa, mb, r, kg, p1[mb], dmc);
-            pvprod(pTd, mb, r, kg, ds[mb], dmd);
-        }
+        half8 W0, W1;
+        split_w(wq[0], wq[1], W0, W1);
+        pvprod(pDb, tr, W0, W1, dq);
+        split_w(wc[0], wc[1], W0, W1);
+        pvprod(pDa, tr, W0, W1, dmc);
+        split_w(wd[0], wd[1], W0, W1);
+        pvprod(pTd, tr, W0, W1, dmd);
     }
     dc = kg_allsum(dc);
     if (!nin) return;
     const size_t prow = ((size_t)b * a.splits + split) * M + n;
-    store_side(a.p_dq + prow * D, dq, D, kg);
-    store_side(a.p_dmc + prow * D, dmc, D, kg);
-    store_side(a.p_dmd1 + prow * D, dmd, D, kg);
-    if (kg == 0) a.p_dc1[prow] = dc;
+    store_acc(a.p_dq + prow * D, dq, 1.0f / cDb, D, g);
+    store_acc(a.p_dmc + prow * D, dmc, 1.0f / cDa, D, g);
+    store_acc(a.p_dmd1 + prow * D, dmd, 1.0f / cS, D, g);
+    if (g == 0) a.p_dc1[prow] = dc;
 }
 
 // j-side sweep 2 (needs the complete dq = sum of the sweep-1 partials):
 //   dS2 = P2 (dP2 - delta2_j) mask_i, dP2_ij = text_i . dq_j ; dmodd_j += sum_i dS2_ij text_d_i ; dc_j += sum_i dS2_ij
-//   split 0 also publishes dq_j and delta2_j = q_j . dq_j for the i-side pass
-template <int NW, int PR>
-__global__ __launch_bounds__(NW * 64) void att_bwd_j2_kernel(const AttBwdArgs a) {
-    constexpr int NTHR = NW * 64, NB = PR / 16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+//   split 0 also publishes dq_j (as planes) and delta2_j = q_j . dq_j for the i-side pass
+__global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, kg = lane >> 4;
-    const int T = a.T, M = a.M, D = a.D;
+    const int r = lane & 15, g = lane >> 4;
+    const int T = a.T, M = a.M, D = a.D, Tp = pad32(T), Mp = pad32(M);
     int tile, split, b;
     decode_block((M + 16 * NW - 1) / (16 * NW), a.splits, a.B, tile, split, b);
     const int n = (tile * NW + wave) * 16 + r;
+    const int rps = a.rows_per_split;
 
-    const bool sep = a.text_d != a.text;
-    float* pT = smem;
-    float* pTd = sep ? pT + PR * LDP : pT;
-    float* rt_s = smem + 2 * PR * LDP;
-    int* code_s = reinterpret_cast<int*>(rt_s + PR);  // 0 beyond slice, 1 masked, 2 live
+    const bool sep = a.pTd != a.pT;
+    char* pT = smem;
+    char* pTd = sep ? smem + PANEL_B : pT;
+    float* rt_all = reinterpret_cast<float*>(smem + 2 * PANEL_B);
+    int* code_all = reinterpret_cast<int*>(rt_all + rps);   // 0 beyond slice, 1 masked, 2 live
+    float* sT_all = rt_all + 2 * rps;
+    float* sTd_all = rt_all + 3 * rps;
+    float* red = rt_all + 4 * rps;
 
+    const size_t szT = planes_sample_bytes(T), szM = planes_sample_bytes(M);
     side_t sideS, sideDq;
-    load_side(sideS, a.mod_d + (size_t)b * M * D, n, M, D, kg, a.w_tm);
-    zero_side(sideDq);
-    for (int p = 0; p < a.splits; ++p) {
-        side_t t;
-        load_side(t, a.p_dq + ((size_t)b * a.splits + p) * M * D, n, M, D, kg, nullptr);
+    float inS, inDq;
+    load_side_f32(sideS, inS, a.mod_d + (size_t)b * M * D, n, M, D, g, a.w_tm);
+    float delta2;
+    {
+        float x[KT][8];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) sideDq[dt] += t[dt];
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[kt][j] = 0.f;
+        for (int p = 0; p < a.splits; ++p) {
+            float t[KT][8];
+            load_row_regs(t, a.p_dq + ((size_t)b * a.splits + p) * M * D, n, M, D, g, nullptr);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[kt][j] += t[kt][j];
+        }
+        side_t sq;
+        float inQ;
+        load_side_planes(sq, inQ, a.pQ + (size_t)b * szM, a.iQ + (size_t)b * Mp, n, M, g);
+        delta2 = kg_allsum(side_dot_regs(sq, inQ, x));
+        side_from_regs(x, sideDq, inDq);
     }
     const bool nin = n < M;
+    if (split == 0 && n < Mp) {   // rows M..Mp-1 are written as zeros (their loads were guarded)
+        char* dst = a.pDq + (size_t)b * szM;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            char* d = dst + pl_off_att(n, 4 * kt + g);
+            *reinterpret_cast<half8*>(d) = sideDq.h[kt][0];
+            *reinterpret_cast<half8*>(d + 1024) = sideDq.h[kt][1];
+        }
+        if (g == 0) {
+            a.iDq[(size_t)b * Mp + n] = inDq;
+            if (nin) a.delta2[(size_t)b * M + n] = delta2;
+        }
+    }
     const float cterm = nin ? a.cterm[(size_t)b * M + n] : 0.f;
     const float cmax = nin ? a.col_stat[((size_t)b * M + n) * 2] : 0.f;
     const float cinv = nin ? 1.0f / a.col_stat[((size_t)b * M + n) * 2 + 1] : 0.f;
-    float delta2;
-    {
-        side_t sq;
-        load_side(sq, a.q + (size_t)b * M * D, n, M, D, kg, nullptr);
-        float acc = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) acc += f4sum(sq[dt] * sideDq[dt]);
-        delta2 = kg_allsum(acc);
-    }
-    if (split == 0 && nin) {
-        store_side(a.dq + ((size_t)b * M + n) * D, sideDq, D, kg);
-        if (kg == 0) a.delta2[(size_t)b * M + n] = delta2;
-    }
+    const tr_off tr = make_tr_off(lane);
 
-    side_t dmd;
-    zero_side(dmd);
+    const int row_begin = split * rps, row_end = min(T, row_begin + rps);
+    float im[2] = {0.f, 0.f};
+    for (int i = tid; i < rps; i += NTHR) {
+        const int t = row_begin + i;
+        const bool in = t < row_end;
+        rt_all[i] = in ? a.rterm[(size_t)b * T + t] : 0.f;
+        code_all[i] = mask_code(in, a.text_mask, a.text_len, b, T, t);
+        const float v0 = in ? a.iT[(size_t)b * Tp + t] : 0.f, v1 = in ? a.iTd[(size_t)b * Tp + t] : 0.f;
+        sT_all[i] = v0; sTd_all[i] = v1;
+        im[0] = fmaxf(im[0], v0); im[1] = fmaxf(im[1], v1);
+    }
+    wg_allmax(im, red, tid);
+    // |dS2_ij| <= |dP2_ij| + |delta2_j| <= 2 D 2^28 inv_t_i inv_dq_j
+    const float cS = cmap_bound(im[1], 1.3743895e11f * (im[0] * inDq));
+
+    acc_t dmd;
+    zero_acc(dmd);
     float dc = 0.f;
-    const float* td_b = a.text_d + (size_t)b * T * D;
-    const float* t_b = a.text + (size_t)b * T * D;
-    const int row_begin = split * a.rows_per_split, row_end = min(T, row_begin + a.rows_per_split);
+    const char* td_b = a.pTd + (size_t)b * szT;
+    const char* t_b = a.pT + (size_t)b * szT;
     for (int p0 = row_begin; p0 < row_end; p0 += PR) {
         __syncthreads();
-        stage_panel<NTHR, PR>(pT, t_b, p0, row_end, D, tid);
-        if (sep) stage_panel<NTHR, PR>(pTd, td_b, p0, row_end, D, tid);
-        if (tid < PR) {
-            const int i = p0 + tid;
-            const bool in = i < row_end;
-            rt_s[tid] = in ? a.rterm[(size_t)b * T + i] : 0.f;
-            code_s[tid] = in ? (a.text_mask[(size_t)b * T + i] ? 2 : 1) : 0;
-        }
+        stage_panel(pT, t_b, p0, tid);
+        if (sep) stage_panel(pTd, td_b, p0, tid);
         __syncthreads();
-        f4 s[NB], dp[NB];
+        const int i0 = p0 - row_begin;
+        f4 s[2], dp[2];
 #pragma unroll
-        for (int q = 0; q < NB; ++q) s[q] = dp[q] = f4{0.f, 0.f, 0.f, 0.f};
-        sprodN<NB>(pTd, r, kg, sideS, s);
-        sprodN<NB>(pT, r, kg, sideDq, dp);
-        f4 ds[NB];
+        for (int q = 0; q < 2; ++q) s[q] = dp[q] = f4{0.f, 0.f, 0.f, 0.f};
+        sprod2(pTd, r, g, sideS, s);
+        sprod2(pT, r, g, sideDq, dp);
+        f4 wd[2];
 #pragma unroll
-        for (int mb = 0; mb < NB; ++mb)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int ml = mb * 16 + 4 * kg + e;
-                const int code = code_s[ml];
-                const float x = code == 2 ? s[mb][e] + rt_s[ml] + cterm : NEG;
+                const int ml = i0 + mb * 16 + 4 * g + e;
+                const int code = code_all[ml];
+                const float x = code == 2 ? s[mb][e] * (sTd_all[ml] * inS) + rt_all[ml] + cterm : NEG;
                 const float p = code ? __expf(x - cmax) * cinv : 0.f;
-                const float g = code == 2 ? p * (dp[mb][e] - delta2) : 0.f;
-                ds[mb][e] = g;
-                dc += g;
+                const float gd = code == 2 ? p * (dp[mb][e] * (sT_all[ml] * inDq) - delta2) : 0.f;
+                dc += gd;
+                wd[mb][e] = gd * (sTd_all[ml] * cS);
             }
-#pragma unroll
-        for (int mb = 0; mb < NB; ++mb) pvprod(pTd, mb, r, kg, ds[mb], dmd);
+        half8 W0, W1;
+        split_w(wd[0], wd[1], W0, W1);
+        pvprod(pTd, tr, W0, W1, dmd);
     }
     dc = kg_allsum(dc);
     if (!nin) return;
     const size_t prow = ((size_t)b * a.splits + split) * M + n;
-    store_side(a.p_dmd2 + prow * D, dmd, D, kg);
-    if (kg == 0) a.p_dc2[prow] = dc;
+    store_acc(a.p_dmd2 + prow * D, dmd, 1.0f / cS, D, g);
+    if (g == 0) a.p_dc2[prow] = dc;
 }
 
 // j-side epilogue: one wave per JF_ROWS modality rows, lane = 4 features.  Sums the split partials, writes
@@ -731,134 +1052,152 @@ __global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a, i
 //   d_text_i += sum_j P2_ij dq_j ; dX_i = sum_j dS_ij mod_d_j ; dr_i = sum_j dS_ij
 //   d_text_d_i = dr_i w_t + w_tm * dX_i ; d_w_t += dr_i text_d_i ; d_w_tm += dX_i * text_d_i ; d_bias += dr_i
 constexpr int PI_STRIDE = 2 * DT * 16 + 16;  // per-wave partial: [d_w_t 208 | d_w_tm 208 | d_bias 1 ...]
-template <int NW, int PR>
-__global__ __launch_bounds__(NW * 64) void att_bwd_i_kernel(const AttBwdArgs a) {
-    constexpr int NTHR = NW * 64, NB = PR / 16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, kg = lane >> 4;
-    const int T = a.T, M = a.M, D = a.D;
+    const int r = lane & 15, g = lane >> 4;
+    const int T = a.T, M = a.M, D = a.D, Mp = pad32(M);
     int tile, split, b;
     decode_block((T + 16 * NW - 1) / (16 * NW), 1, a.B, tile, split, b);
     const int n = (tile * NW + wave) * 16 + r;  // text row i
 
-    const bool sep = a.mod_d != a.mod;
-    float* pM = smem;
-    float* pQ = pM + PR * LDP;
-    float* pDq = pQ + PR * LDP;
-    float* pMd = sep ? pDq + PR * LDP : pM;
-    float* ct_s = smem + 4 * PR * LDP;  // [PR] cterm
-    float* cmax_s = ct_s + PR;
-    float* cinv_s = cmax_s + PR;        // 0 beyond M
-    float* dl2_s = cinv_s + PR;
-    float* mmf_s = dl2_s + PR;          // modality mask as float, -1 beyond M
+    const bool sep = a.pMd != a.pM;
+    char* pM = smem;
+    char* pQ = smem + PANEL_B;
+    char* pDq = smem + 2 * PANEL_B;
+    char* pMd = sep ? smem + 3 * PANEL_B : pM;
+    float* ct_all = reinterpret_cast<float*>(smem + 4 * PANEL_B);   // per-row scalars of ALL modality rows
+    float* cmax_all = ct_all + Mp;
+    float* cinv_all = ct_all + 2 * Mp;     // 0 beyond M
+    float* dl2_all = ct_all + 3 * Mp;
+    float* mmf_all = ct_all + 4 * Mp;      // modality mask as float, -1 beyond M
+    float* sM_all = ct_all + 5 * Mp;
+    float* sMd_all = ct_all + 6 * Mp;
+    float* sQ_all = ct_all + 7 * Mp;
+    float* sDq_all = ct_all + 8 * Mp;
+    float* red = ct_all + 9 * Mp;
 
+    const size_t szT = planes_sample_bytes(T), szM = planes_sample_bytes(M);
     side_t sideS, sideDa, sideDb, sideT;
-    load_side(sideS, a.text_d + (size_t)b * T * D, n, T, D, kg, a.w_tm);
-    load_side(sideDa, a.da + (size_t)b * T * D, n, T, D, kg, nullptr);
-    load_side(sideDb, a.db + (size_t)b * T * D, n, T, D, kg, nullptr);
-    load_side(sideT, a.text + (size_t)b * T * D, n, T, D, kg, nullptr);
+    float inS, inDa, inDb, inT;
+    load_side_f32(sideS, inS, a.text_d + (size_t)b * T * D, n, T, D, g, a.w_tm);
+    load_side_planes(sideDa, inDa, a.pDa + (size_t)b * szT, a.iDa + (size_t)b * pad32(T), n, T, g);
+    load_side_planes(sideDb, inDb, a.pDb + (size_t)b * szT, a.iDb + (size_t)b * pad32(T), n, T, g);
+    load_side_planes(sideT, inT, a.pT + (size_t)b * szT, a.iT + (size_t)b * pad32(T), n, T, g);
     const bool nin = n < T;
     const float rterm = nin ? a.rterm[(size_t)b * T + n] : 0.f;
     const float rmax = nin ? a.row_stat[((size_t)b * T + n) * 2] : 0.f;
     const float rinv = nin ? 1.0f / a.row_stat[((size_t)b * T + n) * 2 + 1] : 0.f;
     const float dl1 = nin ? a.delta1[(size_t)b * T + n] : 0.f;
-    const bool tm = nin ? a.text_mask[(size_t)b * T + n] != 0 : false;
+    const bool tm = nin ? mask_live(a.text_mask, a.text_len, b, T, n) : false;
     const float tmf = tm ? 1.f : 0.f;
+    const tr_off tr = make_tr_off(lane);
 
-    side_t dtx, dX;
-    zero_side(dtx);
-    zero_side(dX);
+    float im[4] = {0.f, 0.f, 0.f, 0.f};   // mod, mod_d, q, dq
+    for (int j = tid; j < Mp; j += NTHR) {
+        const bool in = j < M;
+        const size_t bj = (size_t)b * M + j;
+        ct_all[j] = in ? a.cterm[bj] : 0.f;
+        cmax_all[j] = in ? a.col_stat[bj * 2] : 0.f;
+        cinv_all[j] = in ? 1.0f / a.col_stat[bj * 2 + 1] : 0.f;
+        dl2_all[j] = in ? a.delta2[bj] : 0.f;
+        mmf_all[j] = in ? (mask_live(a.mod_mask, a.mod_len, b, M, j) ? 1.f : 0.f) : -1.f;
+        const size_t pj = (size_t)b * Mp + j;
+        const float v0 = in ? a.iM[pj] : 0.f, v1 = in ? a.iMd[pj] : 0.f, v2 = in ? a.iQ[pj] : 0.f, v3 = in ? a.iDq[pj] : 0.f;
+        sM_all[j] = v0; sMd_all[j] = v1; sQ_all[j] = v2; sDq_all[j] = v3;
+        im[0] = fmaxf(im[0], v0); im[1] = fmaxf(im[1], v1); im[2] = fmaxf(im[2], v2); im[3] = fmaxf(im[3], v3);
+    }
+    wg_allmax(im, red, tid);
+    const float cDq = cmap(im[3]);
+    const float cS = cmap_bound(im[1], 1.3743895e11f * (inDa * im[0] + inDb * im[2] + im[3] * inT));
+
+    acc_t dtx, dX;
+    zero_acc(dtx);
+    zero_acc(dX);
     float dr = 0.f;
-    const float* m_b = a.mod + (size_t)b * M * D;
-    const float* md_b = a.mod_d + (size_t)b * M * D;
-    const float* q_b = a.q + (size_t)b * M * D;
-    const float* dq_b = a.dq + (size_t)b * M * D;
+    const char* m_b = a.pM + (size_t)b * szM;
+    const char* md_b = a.pMd + (size_t)b * szM;
+    const char* q_b = a.pQ + (size_t)b * szM;
+    const char* dq_b = a.pDq + (size_t)b * szM;
     for (int p0 = 0; p0 < M; p0 += PR) {
         __syncthreads();
-        stage_panel<NTHR, PR>(pM, m_b, p0, M, D, tid);
-        stage_panel<NTHR, PR>(pQ, q_b, p0, M, D, tid);
-        stage_panel<NTHR, PR>(pDq, dq_b, p0, M, D, tid);
-        if (sep) stage_panel<NTHR, PR>(pMd, md_b, p0, M, D, tid);
-        if (tid < PR) {
-            const int j = p0 + tid;
-            const bool in = j < M;
-            ct_s[tid] = in ? a.cterm[(size_t)b * M + j] : 0.f;
-            cmax_s[tid] = in ? a.col_stat[((size_t)b * M + j) * 2] : 0.f;
-            cinv_s[tid] = in ? 1.0f / a.col_stat[((size_t)b * M + j) * 2 + 1] : 0.f;
-            dl2_s[tid] = in ? a.delta2[(size_t)b * M + j] : 0.f;
-            mmf_s[tid] = in ? (a.mod_mask[(size_t)b * M + j] ? 1.f : 0.f) : -1.f;
-        }
+        stage_panel(pM, m_b, p0, tid);
+        stage_panel(pQ, q_b, p0, tid);
+        stage_panel(pDq, dq_b, p0, tid);
+        if (sep) stage_panel(pMd, md_b, p0, tid);
         __syncthreads();
-        f4 s[NB], dp1[NB], dp2[NB];
+        f4 s[2], dpa[2], dpb[2], dp2[2];
 #pragma unroll
-        for (int q = 0; q < NB; ++q) s[q] = dp1[q] = dp2[q] = f4{0.f, 0.f, 0.f, 0.f};
-        sprodN<NB>(pMd, r, kg, sideS, s);
-        sprodN<NB>(pM, r, kg, sideDa, dp1);
-        sprodN<NB>(pQ, r, kg, sideDb, dp1);
-        sprodN<NB>(pDq, r, kg, sideT, dp2);
-        f4 p2[NB], ds[NB];
+        for (int q = 0; q < 2; ++q) s[q] = dpa[q] = dpb[q] = dp2[q] = f4{0.f, 0.f, 0.f, 0.f};
+        sprod2(pMd, r, g, sideS, s);
+        sprod2(pM, r, g, sideDa, dpa);
+        sprod2(pQ, r, g, sideDb, dpb);
+        sprod2(pDq, r, g, sideT, dp2);
+        f4 wt[2], wx[2];
 #pragma unroll
-        for (int mb = 0; mb < NB; ++mb)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int ml = mb * 16 + 4 * kg + e;
-                const float mf = mmf_s[ml];
-                const float x = s[mb][e] + rterm + ct_s[ml];
+                const int ml = p0 + mb * 16 + 4 * g + e;
+                const float mf = mmf_all[ml];
+                const float x = s[mb][e] * (sMd_all[ml] * inS) + rterm + ct_all[ml];
                 const float P1 = mf >= 0.f ? __expf((mf > 0.f ? x : NEG) - rmax) * rinv : 0.f;
-                const float P2 = mf >= 0.f ? __expf((tm ? x : NEG) - cmax_s[ml]) * cinv_s[ml] : 0.f;
-                const float g1 = mf > 0.f ? P1 * (dp1[mb][e] - dl1) : 0.f;
-                const float g2 = P2 * (dp2[mb][e] - dl2_s[ml]) * tmf;
-                p2[mb][e] = P2;
-                ds[mb][e] = g1 + g2;
+                const float P2 = mf >= 0.f ? __expf((tm ? x : NEG) - cmax_all[ml]) * cinv_all[ml] : 0.f;
+                const float dp1 = dpa[mb][e] * (sM_all[ml] * inDa) + dpb[mb][e] * (sQ_all[ml] * inDb);
+                const float g1 = mf > 0.f ? P1 * (dp1 - dl1) : 0.f;
+                const float g2 = P2 * (dp2[mb][e] * (sDq_all[ml] * inT) - dl2_all[ml]) * tmf;
                 dr += g1 + g2;
+                wt[mb][e] = P2 * (sDq_all[ml] * cDq);
+                wx[mb][e] = (g1 + g2) * (sMd_all[ml] * cS);
             }
-#pragma unroll
-        for (int mb = 0; mb < NB; ++mb) {
-            pvprod(pDq, mb, r, kg, p2[mb], dtx);
-            pvprod(pMd, mb, r, kg, ds[mb], dX);
-        }
+        half8 W0, W1;
+        split_w(wt[0], wt[1], W0, W1);
+        pvprod(pDq, tr, W0, W1, dtx);
+        split_w(wx[0], wx[1], W0, W1);
+        pvprod(pMd, tr, W0, W1, dX);
     }
     dr = kg_allsum(dr);
+    const float sdtx = 1.0f / cDq, sdX = 1.0f / cS;
     // ---- epilogue: gradients of this text row; parameter-gradient partials reduced over the workgroup in LDS
     __syncthreads();  // panels are dead: reuse their memory
-    float* part = smem + wave * PI_STRIDE;
+    float* part = reinterpret_cast<float*>(smem) + wave * PI_STRIDE;
     const float* td_row = a.text_d + ((size_t)b * T + n) * D;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-        const int d = 16 * dt + 4 * kg;
+        const int d = 16 * dt + 4 * g;
         f4 pt = f4{0.f, 0.f, 0.f, 0.f}, ptm = pt;
         if (nin && d < D) {
-            const f4 wt = *reinterpret_cast<const f4*>(a.w_t + d), wtm = *reinterpret_cast<const f4*>(a.w_tm + d);
+            const f4 wt4 = *reinterpret_cast<const f4*>(a.w_t + d), wtm = *reinterpret_cast<const f4*>(a.w_tm + d);
             const f4 td = *reinterpret_cast<const f4*>(td_row + d);
-            const f4 gd = wt * dr + wtm * dX[dt];
+            const f4 dXv = dX[dt] * sdX;
+            const f4 gd = wt4 * dr + wtm * dXv;
             float* dtp = a.d_text + ((size_t)b * T + n) * D + d;
             const f4 prev = *reinterpret_cast<const f4*>(dtp);  // g0 + g2*a + g3*b from the prologue
             if (a.fold) {
-                *reinterpret_cast<f4*>(dtp) = prev + dtx[dt] + gd;
+                *reinterpret_cast<f4*>(dtp) = prev + dtx[dt] * sdtx + gd;
             } else {
-                *reinterpret_cast<f4*>(dtp) = prev + dtx[dt];
+                *reinterpret_cast<f4*>(dtp) = prev + dtx[dt] * sdtx;
                 *reinterpret_cast<f4*>(a.d_text_d + ((size_t)b * T + n) * D + d) = gd;
             }
             pt = td * dr;
-            ptm = td * dX[dt];
+            ptm = td * dXv;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float s1 = r_allsum(pt[e]), s2 = r_allsum(ptm[e]);
             if (r == 0) {
-                part[16 * dt + 4 * kg + e] = s1;
-                part[DT * 16 + 16 * dt + 4 * kg + e] = s2;
+                part[16 * dt + 4 * g + e] = s1;
+                part[DT * 16 + 16 * dt + 4 * g + e] = s2;
             }
         }
     }
-    const float sb = r_allsum(nin ? dr : 0.f);
+    const float sb = r_allsum(nin ? dr : 0.f);   // dr is replicated over the 4 k-groups: lane 0 holds the sum of the wave's 16 rows
     if (lane == 0) part[2 * DT * 16] = sb;
     __syncthreads();
     for (int i = tid; i < 2 * DT * 16 + 1; i += NTHR) {
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) acc += smem[w * PI_STRIDE + i];
+        for (int w = 0; w < NW; ++w) acc += reinterpret_cast<float*>(smem)[w * PI_STRIDE + i];
         if (i < DT * 16) {
             if (i < D) atomicAdd(a.d_w_t + i, acc);
         } else if (i < 2 * DT * 16) {
@@ -870,27 +1209,10 @@ __global__ __launch_bounds__(NW * 64) void att_bwd_i_kernel(const AttBwdArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------ host side
-// workgroup geometries that are compiled (NW waves x PR-row panels); chosen per kernel below / by MMB_ATT_GEOM
-// (measured on MI355X, cfg2: 4 waves x 32-row panels beats 2x16, 1x16 and 2x32 on every kernel)
-enum { GEOM_4x32 = 0, GEOM_2x16 = 1, GEOM_4x16DB = 2, GEOM_COUNT };   // DB = double-buffered panels (forward kernels)
-static const int kGeomNW[GEOM_COUNT] = {4, 2, 4};
-static const int kGeomPR[GEOM_COUNT] = {32, 16, 16};
-
-static int geom_for(int kernel_id, int deflt) {
-    // MMB_ATT_GEOM = "<col><row><j1><j2><i>" one digit per kernel (tuning aid), e.g. 11111
-    static int forced[5] = {-2, -2, -2, -2, -2};
-    if (forced[0] == -2) {
-        const char* e = getenv("MMB_ATT_GEOM");
-        for (int i = 0; i < 5; ++i) forced[i] = (e && (int)strlen(e) > i && e[i] >= '0' && e[i] < '0' + GEOM_COUNT) ? e[i] - '0' : -1;
-    }
-    return forced[kernel_id] >= 0 ? forced[kernel_id] : deflt;
-}
-
 // How many ways to split the streamed side (R rows, PR-row panels) of a sweep whose lane side has N rows per sample:
-// the workgroups (4 waves = 64 lane-side rows each) run in rounds of `slots` (256 CUs x workgroups that fit a CU's LDS),
+// the workgroups (4 waves = 64 lane-side rows each) run in rounds of `slots` (256 CUs x workgroups that fit a CU),
 // so the cost is rounds x (panels per split + fixed per-workgroup work) plus the traffic of the per-split partials.
-// (The earlier "1.5 waves per SIMD" rule gave 384 workgroups for both cfg2 attentions: 1.5 rounds.)
-static int pick_splits(int B, int N, int R, int PR, int slots = 256) {
+static int pick_splits(int B, int N, int R, int slots = 256) {
     const long tiles = (long)B * ((N + 63) / 64);
     const int smax = (R + PR - 1) / PR;
     int best = 1;
@@ -903,60 +1225,77 @@ static int pick_splits(int B, int N, int R, int PR, int slots = 256) {
     }
     return best;
 }
-static int rows_per_split(int R, int splits, int PR) {
+static int rows_per_split(int R, int splits) {
     int rp = (R + splits - 1) / splits;
     return (rp + PR - 1) / PR * PR;
 }
 
+static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+// saved-for-backward buffer of the fused path: planes + inverse row scales of text, mod, q (and of the dropped copies)
+struct SavedLayout {
+    size_t pT, pTd, pM, pMd, pQ, iT, iTd, iM, iMd, iQ, total;
+};
+static SavedLayout saved_layout(int B, int T, int M, int drop) {
+    SavedLayout L{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
+    const size_t szT = planes_sample_bytes(T) * B, szM = planes_sample_bytes(M) * B;
+    const size_t nT = (size_t)B * pad32(T) * sizeof(float), nM = (size_t)B * pad32(M) * sizeof(float);
+    L.pT = take(szT);
+    L.pTd = drop ? take(szT) : L.pT;
+    L.pM = take(szM);
+    L.pMd = drop ? take(szM) : L.pM;
+    L.pQ = take(szM);
+    L.iT = take(nT);
+    L.iTd = drop ? take(nT) : L.iT;
+    L.iM = take(nM);
+    L.iMd = drop ? take(nM) : L.iM;
+    L.iQ = take(nM);
+    L.total = o;
+    return L;
+}
+
 struct BwdWs {
-    size_t da, db, delta1, dq, delta2, p_dq, p_dmc, p_dmd1, p_dmd2, p_dc1, p_dc2, total;
+    size_t pDa, pDb, pDq, iDa, iDb, iDq, delta1, delta2, p_dq, p_dmc, p_dmd1, p_dmd2, p_dc1, p_dc2, total;   // bytes
     int splits;
 };
 static BwdWs bwd_layout(int B, int T, int M, int D) {
     BwdWs w{};
-    w.splits = pick_splits(B, M, T, 16) > pick_splits(B, M, T, 32) ? pick_splits(B, M, T, 16) : pick_splits(B, M, T, 32);   // upper bound over the compiled geometries
+    w.splits = pick_splits(B, M, T);
     const size_t S = w.splits;
     size_t o = 0;
-    auto take = [&](size_t nfloat) { size_t at = o; o += (nfloat + 3) / 4 * 4; return at; };
-    w.da = take((size_t)B * T * D);
-    w.db = take((size_t)B * T * D);
-    w.delta1 = take((size_t)B * T);
-    w.dq = take((size_t)B * M * D);
-    w.delta2 = take((size_t)B * M);
-    w.p_dq = take(S * B * M * D);
-    w.p_dmc = take(S * B * M * D);
-    w.p_dmd1 = take(S * B * M * D);
-    w.p_dmd2 = take(S * B * M * D);
-    w.p_dc1 = take(S * B * M);
-    w.p_dc2 = take(S * B * M);
+    auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
+    const size_t szT = planes_sample_bytes(T) * B, szM = planes_sample_bytes(M) * B;
+    w.pDa = take(szT);
+    w.pDb = take(szT);
+    w.pDq = take(szM);
+    w.iDa = take((size_t)B * pad32(T) * 4);
+    w.iDb = take((size_t)B * pad32(T) * 4);
+    w.iDq = take((size_t)B * pad32(M) * 4);
+    w.delta1 = take((size_t)B * T * 4);
+    w.delta2 = take((size_t)B * M * 4);
+    w.p_dq = take(S * B * M * D * 4);
+    w.p_dmc = take(S * B * M * D * 4);
+    w.p_dmd1 = take(S * B * M * D * 4);
+    w.p_dmd2 = take(S * B * M * D * 4);
+    w.p_dc1 = take(S * B * M * 4);
+    w.p_dc2 = take(S * B * M * 4);
     w.total = o;
     return w;
+}
+static int fwd_splits(int B, int T, int M) { return pick_splits(B, M, T, 512); }   // two workgroups per CU
+static size_t fwd_ws_bytes(int B, int T, int M, int D) {
+    const size_t S = fwd_splits(B, T, M);
+    return align256(S * B * M * D * 4) + align256(S * B * M * 2 * 4);
 }
 
 template <typename K>
 static int allow_lds(K kernel, size_t bytes) {
+    MMB_REQUIRE(bytes <= 160 * 1024, "bidaf: %zu bytes of LDS needed, 160 KiB available (sequence too long for one split)", bytes);
     MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return MMB_OK;
 }
-
-// launch `KERNEL<..., NW, PR>` for geometry `geom` on a 1-D grid of tiles(N) * splits * B workgroups
-#define MMB_ATT_LAUNCH(KID, GEOM, N_LANE, SPLITS, BATCH, LDS_FLOATS_EXPR, ARGS, ...)                                   \
-    do {                                                                                                               \
-        int rc_ = MMB_OK;                                                                                              \
-        auto go = [&](auto kern, int NW, int PR) {                                                                     \
-            const size_t lds = (size_t)(LDS_FLOATS_EXPR) * sizeof(float);                                              \
-            if ((rc_ = allow_lds(kern, lds))) return;                                                                  \
-            const int tiles = ((N_LANE) + 16 * NW - 1) / (16 * NW);                                                    \
-            ProfScope ps_(KID, stream);                                                                                \
-            hipLaunchKernelGGL(kern, dim3(tiles * (SPLITS) * (BATCH)), dim3(NW * 64), lds, stream, ARGS);              \
-        };                                                                                                             \
-        switch (GEOM) {                                                                                                \
-            case GEOM_2x16: go(__VA_ARGS__<2, 16>, 2, 16); break;                                                      \
-            default: go(__VA_ARGS__<4, 32>, 4, 32); break;                                                             \
-        }                                                                                                              \
-        if (rc_) return rc_;                                                                                           \
-        MMB_HIP(hipGetLastError());                                                                                    \
-    } while (0)
 
 }  // namespace mmb
 
@@ -969,83 +1308,115 @@ static int check_att_dims(int B, int T, int M, int D) {
     return MMB_OK;
 }
 
+extern "C" size_t mmb_bidaf_saved_bytes(int B, int T, int M, int D, int has_drop) {
+    if (B < 1 || T < 1 || M < 1 || D < 4) return 0;
+    if (D > MMB_ATT_MAX_D) return (size_t)B * M * D * sizeof(float);   // general path: q (B,M,D) fp32
+    return saved_layout(B, T, M, has_drop).total;
+}
+
 extern "C" size_t mmb_bidaf_fwd_workspace_bytes(int B, int T, int M, int D) {
-    if (B < 1 || T < 1 || M < 1 || D < 4 || D <= MMB_ATT_MAX_D) return 0;   // the fused kernels need no scratch
-    return bidaf_big_fwd_ws_floats(B, T, M, D) * sizeof(float);
+    if (B < 1 || T < 1 || M < 1 || D < 4) return 0;
+    if (D > MMB_ATT_MAX_D) return bidaf_big_fwd_ws_floats(B, T, M, D) * sizeof(float);
+    return fwd_ws_bytes(B, T, M, D);
 }
 
 extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t* text_mask, const uint8_t* mod_mask,
+                             const int32_t* text_len, const int32_t* mod_len,
                              const float* text_d, const float* mod_d, const float* w_t, const float* w_m,
-                             const float* w_tm, const float* bias, float* out, float* q, float* bsave, float* rterm,
-                             float* cterm, float* row_stat, float* col_stat, float* workspace, size_t workspace_bytes,
+                             const float* w_tm, const float* bias, float* out, float* bsave, float* rterm,
+                             float* cterm, float* row_stat, float* col_stat, void* saved, size_t saved_bytes,
+                             float* workspace, size_t workspace_bytes,
                              int B, int T, int M, int D, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (int rc = check_att_dims(B, T, M, D)) return rc;
-    MMB_REQUIRE(text && mod && text_mask && mod_mask && w_t && w_m && w_tm && bias && out && q && bsave && rterm &&
-                    cterm && row_stat && col_stat, "mmb_bidaf_fwd: null pointer");
+    MMB_REQUIRE(text && mod && w_t && w_m && w_tm && bias && out && bsave && rterm && cterm && row_stat && col_stat && saved,
+                "mmb_bidaf_fwd: null pointer");
+    MMB_REQUIRE((text_mask || text_len) && (mod_mask || mod_len), "mmb_bidaf_fwd: a mask or a length vector is needed for each side");
+    const bool drop = text_d != nullptr;
+    MMB_REQUIRE(drop == (mod_d != nullptr), "mmb_bidaf_fwd: text_d and mod_d must both be given or both be NULL");
+    MMB_REQUIRE(saved_bytes >= mmb_bidaf_saved_bytes(B, T, M, D, drop), "mmb_bidaf_fwd: saved buffer too small (%zu < %zu)",
+                saved_bytes, mmb_bidaf_saved_bytes(B, T, M, D, drop));
+    MMB_REQUIRE(workspace && workspace_bytes >= mmb_bidaf_fwd_workspace_bytes(B, T, M, D),
+                "mmb_bidaf_fwd: needs a workspace of mmb_bidaf_fwd_workspace_bytes() = %zu bytes", mmb_bidaf_fwd_workspace_bytes(B, T, M, D));
     MMB_HIP(hipSetDevice(device));
     if (!text_d) text_d = text;
     if (!mod_d) mod_d = mod;
 
-    { ProfScope ps_(MMB_K_ATT_RANK1, stream); hipLaunchKernelGGL(att_rank1_kernel, dim3((B * T + B * M + 3) / 4), dim3(256), 0, stream, text_d, mod_d, w_t, w_m, bias,
-                       rterm, cterm, B * T, B * M, D); }
-    MMB_HIP(hipGetLastError());
     if (D > MMB_ATT_MAX_D) {   // general-size path (bidaf_big.hip): similarity matrix materialised in the workspace
-        MMB_REQUIRE(workspace && workspace_bytes >= mmb_bidaf_fwd_workspace_bytes(B, T, M, D),
-                    "mmb_bidaf_fwd: D=%d > %d needs a workspace of mmb_bidaf_fwd_workspace_bytes()", D, MMB_ATT_MAX_D);
-        return bidaf_big_fwd(text, mod, text_mask, mod_mask, text_d, mod_d, w_tm, out, q, bsave, rterm, cterm, row_stat, col_stat,
-                             workspace, B, T, M, D, stream);
+        MMB_REQUIRE(text_mask && mod_mask, "mmb_bidaf_fwd: the general-width path (D > %d) takes u8 masks", MMB_ATT_MAX_D);
+        {
+            ProfScope ps_(MMB_K_ATT_RANK1, stream);
+            hipLaunchKernelGGL(att_rank1_kernel, dim3((B * T + B * M + 3) / 4), dim3(256), 0, stream, text_d, mod_d, w_t, w_m, bias, rterm, cterm,
+                               B * T, B * M, D);
+        }
+        MMB_HIP(hipGetLastError());
+        return bidaf_big_fwd(text, mod, text_mask, mod_mask, text_d, mod_d, w_tm, out, static_cast<float*>(saved), bsave, rterm, cterm,
+                             row_stat, col_stat, workspace, B, T, M, D, stream);
     }
+    const SavedLayout L = saved_layout(B, T, M, drop);
+    char* sv = static_cast<char*>(saved);
+    auto fp = [&](size_t off) { return reinterpret_cast<float*>(sv + off); };
 
-    // ---- column pass: lane side = modality rows, streams text.  (`out` is used as scratch for the split
-    //      partials: it is (B,T,4D) and is only written by the row pass afterwards.)
+    // ---- split passes: planes + inverse row scales of text / mod (and the dropped copies), rank-1 terms
     {
-        const int geom = geom_for(0, GEOM_4x32);
-        const int PRg = kGeomPR[geom];
+        PrepArgs p{};
+        p.D = D; p.B = B;
+        int k = 0;
+        p.t[k++] = SplitSrc{text_d, sv + L.pTd, fp(L.iTd), w_t, bias, rterm, T};
+        p.t[k++] = SplitSrc{mod_d, sv + L.pMd, fp(L.iMd), w_m, nullptr, cterm, M};
+        if (drop) {
+            p.t[k++] = SplitSrc{text, sv + L.pT, fp(L.iT), nullptr, nullptr, nullptr, T};
+            p.t[k++] = SplitSrc{mod, sv + L.pM, fp(L.iM), nullptr, nullptr, nullptr, M};
+        }
+        p.n = k;
+        const long rows = (long)B * pad32(T > M ? T : M);
+        ProfScope ps_(MMB_K_ATT_RANK1, stream);
+        hipLaunchKernelGGL(att_prep_kernel, dim3((unsigned)((rows + 7) / 8), k), dim3(256), 0, stream, p);
+        MMB_HIP(hipGetLastError());
+    }
+    // ---- column pass: lane side = modality rows, streams text; partials merged (and q split into planes) by the combine
+    const int splits = fwd_splits(B, T, M);
+    float* part_o = workspace;
+    float* part_stat = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align256((size_t)splits * B * M * D * 4));
+    {
         AttFwdArgs a{};
-        a.side_src = mod_d; a.w_tm = w_tm; a.mS = text_d; a.mV0 = text; a.mV1 = nullptr;
-        a.m_mask = text_mask; a.m_term = rterm; a.n_term = cterm; a.stat = col_stat; a.q = q;
-        a.N = M; a.R = T; a.D = D; a.B = B;
-        int splits = pick_splits(B, M, T, PRg, 512);   // 54 KB of LDS: two workgroups per CU
-        while (splits > 1 && (size_t)splits * M * (D + 2) > (size_t)T * 4 * D) --splits;
-        a.splits = splits;
-        a.rows_per_split = rows_per_split(T, splits, PRg);
-        a.part_o = out;
-        a.part_stat = out + (size_t)B * splits * M * D;
-        if (geom == GEOM_4x16DB) {
-            const size_t lds = ((size_t)2 * (1 + 1) * 16 * LDP + 2 * a.rows_per_split) * sizeof(float);
-            if (int rc = allow_lds(att_col_kernel<4, 16, true>, lds)) return rc;
+        a.side_src = mod_d; a.w_tm = w_tm;
+        a.mS = sv + L.pTd; a.iS = fp(L.iTd); a.mV0 = sv + L.pT; a.iV0 = fp(L.iT); a.mV1 = nullptr; a.iV1 = nullptr;
+        a.m_mask = text_len ? nullptr : text_mask; a.m_len = text_len; a.m_term = rterm; a.n_term = cterm;
+        a.part_o = part_o; a.part_stat = part_stat;
+        a.N = M; a.R = T; a.D = D; a.B = B; a.splits = splits; a.rows_per_split = rows_per_split(T, splits);
+        const size_t lds = (size_t)2 * PANEL_B + ((size_t)5 * a.rows_per_split + 16) * sizeof(float);
+        if (int rc = allow_lds(att_col_kernel, lds)) return rc;
+        {
             ProfScope ps_(MMB_K_ATT_COL, stream);
-            hipLaunchKernelGGL((att_col_kernel<4, 16, true>), dim3(((M + 63) / 64) * splits * B), dim3(256), lds, stream, a);
-            MMB_HIP(hipGetLastError());
-        } else {
-            MMB_ATT_LAUNCH(MMB_K_ATT_COL, geom, M, splits, B, (1 + 1) * PR * LDP + 2 * a.rows_per_split, a, att_col_kernel);
+            hipLaunchKernelGGL(att_col_kernel, dim3(((M + 63) / 64) * splits * B), dim3(NTHR), lds, stream, a);
         }
-        if (splits > 1) {
-            const size_t nthr = (size_t)B * M * (D / 4);
-            { ProfScope ps_(MMB_K_ATT_COMBINE, stream); hipLaunchKernelGGL(att_combine_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, a.part_o, a.part_stat, q,
-                               col_stat, B, M, D, splits); }
-            MMB_HIP(hipGetLastError());
+        MMB_HIP(hipGetLastError());
+        const long rows = (long)B * pad32(M);
+        {
+            ProfScope ps_(MMB_K_ATT_COMBINE, stream);
+            hipLaunchKernelGGL(att_combine_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, stream, part_o, part_stat, sv + L.pQ,
+                               fp(L.iQ), col_stat, B, M, D, splits);
         }
+        MMB_HIP(hipGetLastError());
     }
     // ---- row pass: lane side = text rows, streams [mod | q]
     {
-        const int geom = geom_for(1, GEOM_4x32);
         AttFwdArgs a{};
-        a.side_src = text_d; a.w_tm = w_tm; a.mS = mod_d; a.mV0 = mod; a.mV1 = q;
-        a.m_mask = mod_mask; a.m_term = cterm; a.n_term = rterm; a.stat = row_stat;
+        a.side_src = text_d; a.w_tm = w_tm;
+        a.mS = sv + L.pMd; a.iS = fp(L.iMd); a.mV0 = sv + L.pM; a.iV0 = fp(L.iM); a.mV1 = sv + L.pQ; a.iV1 = fp(L.iQ);
+        a.m_mask = mod_len ? nullptr : mod_mask; a.m_len = mod_len; a.m_term = cterm; a.n_term = rterm; a.stat = row_stat;
         a.text = text; a.out = out; a.bsave = bsave;
-        a.N = T; a.R = M; a.D = D; a.B = B; a.splits = 1; a.rows_per_split = rows_per_split(M, 1, kGeomPR[geom]);
-        { const char* e = getenv("MMB_ATT_DBG"); a.dbg = e ? atoi(e) : 0; }
-        if (geom == GEOM_4x16DB) {
-            const size_t lds = ((size_t)2 * (2 + 1) * 16 * LDP + 2 * a.rows_per_split) * sizeof(float);
-            if (int rc = allow_lds(att_row_kernel<4, 16, true>, lds)) return rc;
+        a.N = T; a.R = M; a.D = D; a.B = B; a.splits = 1; a.rows_per_split = rows_per_split(M, 1);
+        size_t lds = (size_t)3 * PANEL_B + ((size_t)5 * a.rows_per_split + 16) * sizeof(float);
+        const size_t epi = (size_t)16 * NW * LDP * sizeof(float);
+        if (lds < epi) lds = epi;
+        if (int rc = allow_lds(att_row_kernel, lds)) return rc;
+        {
             ProfScope ps_(MMB_K_ATT_ROW, stream);
-            hipLaunchKernelGGL((att_row_kernel<4, 16, true>), dim3(((T + 63) / 64) * B), dim3(256), lds, stream, a);
-            MMB_HIP(hipGetLastError());
-        } else {
-            MMB_ATT_LAUNCH(MMB_K_ATT_ROW, geom, T, 1, B, (2 + 1) * PR * LDP + 2 * a.rows_per_split, a, att_row_kernel);
+            hipLaunchKernelGGL(att_row_kernel, dim3(((T + 63) / 64) * B), dim3(NTHR), lds, stream, a);
         }
+        MMB_HIP(hipGetLastError());
     }
     return MMB_OK;
 }
@@ -1053,21 +1424,23 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
 extern "C" size_t mmb_bidaf_bwd_workspace_bytes(int B, int T, int M, int D) {
     if (B < 1 || T < 1 || M < 1 || D < 4) return 0;
     if (D > MMB_ATT_MAX_D) return bidaf_big_bwd_ws_floats(B, T, M, D) * sizeof(float);
-    return bwd_layout(B, T, M, D).total * sizeof(float);
+    return bwd_layout(B, T, M, D).total;
 }
 
 extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* text, const float* mod,
-                             const uint8_t* text_mask, const uint8_t* mod_mask, const float* text_d, const float* mod_d,
-                             const float* w_t, const float* w_m, const float* w_tm, const float* q, const float* bsave,
+                             const uint8_t* text_mask, const uint8_t* mod_mask, const int32_t* text_len, const int32_t* mod_len,
+                             const float* text_d, const float* mod_d,
+                             const float* w_t, const float* w_m, const float* w_tm, const void* saved, const float* bsave,
                              const float* rterm, const float* cterm, const float* row_stat, const float* col_stat,
                              float* d_text, float* d_mod, float* d_text_d, float* d_mod_d, float* d_w_t, float* d_w_m,
                              float* d_w_tm, float* d_bias, float* workspace, size_t workspace_bytes, int B, int T, int M,
                              int D, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (int rc = check_att_dims(B, T, M, D)) return rc;
-    MMB_REQUIRE(d_out && out && text && mod && text_mask && mod_mask && w_t && w_m && w_tm && q && bsave && rterm && cterm &&
+    MMB_REQUIRE(d_out && out && text && mod && w_t && w_m && w_tm && saved && bsave && rterm && cterm &&
                     row_stat && col_stat && d_text && d_mod && d_w_t && d_w_m && d_w_tm && d_bias && workspace,
                 "mmb_bidaf_bwd: null pointer");
+    MMB_REQUIRE((text_mask || text_len) && (mod_mask || mod_len), "mmb_bidaf_bwd: a mask or a length vector is needed for each side");
     const bool drop_t = text_d != nullptr, drop_m = mod_d != nullptr;
     MMB_REQUIRE(drop_t == drop_m, "mmb_bidaf_bwd: text_d and mod_d must both be given or both be NULL");
     MMB_REQUIRE(drop_t ? (d_text_d && d_mod_d) : (!d_text_d && !d_mod_d),
@@ -1075,41 +1448,74 @@ extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* 
     MMB_REQUIRE(workspace_bytes >= mmb_bidaf_bwd_workspace_bytes(B, T, M, D), "mmb_bidaf_bwd: workspace too small (%zu < %zu)",
                 workspace_bytes, mmb_bidaf_bwd_workspace_bytes(B, T, M, D));
     MMB_HIP(hipSetDevice(device));
-    if (D > MMB_ATT_MAX_D)
-        return bidaf_big_bwd(d_out, out, text, mod, text_mask, mod_mask, text_d, mod_d, w_t, w_m, w_tm, q, bsave, rterm, cterm,
-                             row_stat, col_stat, d_text, d_mod, d_text_d, d_mod_d, d_w_t, d_w_m, d_w_tm, d_bias, workspace, B, T, M,
-                             D, stream);
+    if (D > MMB_ATT_MAX_D) {
+        MMB_REQUIRE(text_mask && mod_mask, "mmb_bidaf_bwd: the general-width path (D > %d) takes u8 masks", MMB_ATT_MAX_D);
+        return bidaf_big_bwd(d_out, out, text, mod, text_mask, mod_mask, text_d, mod_d, w_t, w_m, w_tm, static_cast<const float*>(saved), bsave,
+                             rterm, cterm, row_stat, col_stat, d_text, d_mod, d_text_d, d_mod_d, d_w_t, d_w_m, d_w_tm, d_bias, workspace,
+                             B, T, M, D, stream);
+    }
+    const SavedLayout S = saved_layout(B, T, M, drop_t);
     const BwdWs L = bwd_layout(B, T, M, D);
-
-    const int geom_j1 = geom_for(2, GEOM_4x32), geom_j2 = geom_for(3, GEOM_4x32), geom_i = geom_for(4, GEOM_4x32);
-    // both j sweeps must agree on how the text rows are split (the partial buffers are indexed by split)
-    const int PRj = kGeomPR[geom_j1] > kGeomPR[geom_j2] ? kGeomPR[geom_j1] : kGeomPR[geom_j2];
+    const char* sv = static_cast<const char*>(saved);
+    char* ws = reinterpret_cast<char*>(workspace);
+    auto sf = [&](size_t off) { return reinterpret_cast<const float*>(sv + off); };
+    auto wf = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
 
     AttBwdArgs a{};
     a.text = text; a.mod = mod; a.text_d = drop_t ? text_d : text; a.mod_d = drop_m ? mod_d : mod;
-    a.text_mask = text_mask; a.mod_mask = mod_mask; a.w_t = w_t; a.w_m = w_m; a.w_tm = w_tm;
-    a.q = q; a.rterm = rterm; a.cterm = cterm; a.row_stat = row_stat; a.col_stat = col_stat;
-    a.da = workspace + L.da; a.db = workspace + L.db; a.delta1 = workspace + L.delta1;
-    a.dq = workspace + L.dq; a.delta2 = workspace + L.delta2;
-    a.p_dq = workspace + L.p_dq; a.p_dmc = workspace + L.p_dmc; a.p_dmd1 = workspace + L.p_dmd1;
-    a.p_dmd2 = workspace + L.p_dmd2; a.p_dc1 = workspace + L.p_dc1; a.p_dc2 = workspace + L.p_dc2;
+    a.text_mask = text_len ? nullptr : text_mask; a.mod_mask = mod_len ? nullptr : mod_mask;
+    a.text_len = text_len; a.mod_len = mod_len;
+    a.w_t = w_t; a.w_m = w_m; a.w_tm = w_tm;
+    a.rterm = rterm; a.cterm = cterm; a.row_stat = row_stat; a.col_stat = col_stat;
+    a.pT = sv + S.pT; a.pTd = sv + S.pTd; a.pM = sv + S.pM; a.pMd = sv + S.pMd; a.pQ = sv + S.pQ;
+    a.iT = sf(S.iT); a.iTd = sf(S.iTd); a.iM = sf(S.iM); a.iMd = sf(S.iMd); a.iQ = sf(S.iQ);
+    a.pDa = ws + L.pDa; a.pDb = ws + L.pDb; a.pDq = ws + L.pDq;
+    a.iDa = wf(L.iDa); a.iDb = wf(L.iDb); a.iDq = wf(L.iDq);
+    a.delta1 = wf(L.delta1); a.delta2 = wf(L.delta2);
+    a.p_dq = wf(L.p_dq); a.p_dmc = wf(L.p_dmc); a.p_dmd1 = wf(L.p_dmd1);
+    a.p_dmd2 = wf(L.p_dmd2); a.p_dc1 = wf(L.p_dc1); a.p_dc2 = wf(L.p_dc2);
     a.d_mod = d_mod; a.d_mod_d = d_mod_d; a.d_text = d_text; a.d_text_d = d_text_d;
     a.d_w_t = d_w_t; a.d_w_m = d_w_m; a.d_w_tm = d_w_tm; a.d_bias = d_bias;
     a.B = B; a.T = T; a.M = M; a.D = D; a.fold = drop_t ? 0 : 1;
-    a.splits = pick_splits(B, M, T, PRj);
-    if (a.splits > L.splits) a.splits = L.splits;
-    a.rows_per_split = rows_per_split(T, a.splits, PRj);
+    a.splits = L.splits;
+    a.rows_per_split = rows_per_split(T, a.splits);
 
-    { ProfScope ps_(MMB_K_ATT_BWD_PRE, stream); hipLaunchKernelGGL(att_bwd_pre_kernel, dim3((B * T + 3) / 4), dim3(256), 0, stream, d_out, out, text, bsave,
-                       workspace + L.da, workspace + L.db, workspace + L.delta1, d_text, d_w_t, d_w_m, d_w_tm, d_bias, B * T, D); }
+    {
+        const long rows = (long)B * pad32(T);
+        ProfScope ps_(MMB_K_ATT_BWD_PRE, stream);
+        hipLaunchKernelGGL(att_bwd_pre_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, stream, d_out, out, text, bsave,
+                           ws + L.pDa, wf(L.iDa), ws + L.pDb, wf(L.iDb), wf(L.delta1), d_text, d_w_t, d_w_m, d_w_tm, d_bias, B, T, D);
+    }
     MMB_HIP(hipGetLastError());
-    MMB_ATT_LAUNCH(MMB_K_ATT_BWD_J1, geom_j1, M, a.splits, B, 3 * PR * LDP + 4 * PR, a, att_bwd_j1_kernel);
-    MMB_ATT_LAUNCH(MMB_K_ATT_BWD_J2, geom_j2, M, a.splits, B, 2 * PR * LDP + 2 * PR, a, att_bwd_j2_kernel);
+    const int tiles_m = (M + 63) / 64, tiles_t = (T + 63) / 64;
+    {
+        const size_t lds = (size_t)3 * PANEL_B + ((size_t)7 * a.rows_per_split + 16) * sizeof(float);
+        if (int rc = allow_lds(att_bwd_j1_kernel, lds)) return rc;
+        ProfScope ps_(MMB_K_ATT_BWD_J1, stream);
+        hipLaunchKernelGGL(att_bwd_j1_kernel, dim3(tiles_m * a.splits * B), dim3(NTHR), lds, stream, a);
+    }
+    MMB_HIP(hipGetLastError());
+    {
+        const size_t lds = (size_t)2 * PANEL_B + ((size_t)4 * a.rows_per_split + 16) * sizeof(float);
+        if (int rc = allow_lds(att_bwd_j2_kernel, lds)) return rc;
+        ProfScope ps_(MMB_K_ATT_BWD_J2, stream);
+        hipLaunchKernelGGL(att_bwd_j2_kernel, dim3(tiles_m * a.splits * B), dim3(NTHR), lds, stream, a);
+    }
+    MMB_HIP(hipGetLastError());
     {
         const int chunks = (B * M + JF_ROWS - 1) / JF_ROWS;
-        { ProfScope ps_(MMB_K_ATT_BWD_JFIN, stream); hipLaunchKernelGGL(att_bwd_jfin_kernel, dim3((chunks + 3) / 4), dim3(256), 0, stream, a, B); }
-        MMB_HIP(hipGetLastError());
+        ProfScope ps_(MMB_K_ATT_BWD_JFIN, stream);
+        hipLaunchKernelGGL(att_bwd_jfin_kernel, dim3((chunks + 3) / 4), dim3(256), 0, stream, a, B);
     }
-    MMB_ATT_LAUNCH(MMB_K_ATT_BWD_I, geom_i, T, 1, B, 4 * PR * LDP + 5 * PR + NW * PI_STRIDE, a, att_bwd_i_kernel);
+    MMB_HIP(hipGetLastError());
+    {
+        size_t lds = (size_t)4 * PANEL_B + ((size_t)9 * pad32(M) + 16) * sizeof(float);
+        const size_t epi = (size_t)NW * PI_STRIDE * sizeof(float);
+        if (lds < epi) lds = epi;
+        if (int rc = allow_lds(att_bwd_i_kernel, lds)) return rc;
+        ProfScope ps_(MMB_K_ATT_BWD_I, stream);
+        hipLaunchKernelGGL(att_bwd_i_kernel, dim3(tiles_t * B), dim3(NTHR), lds, stream, a);
+    }
+    MMB_HIP(hipGetLastError());
     return MMB_OK;
 }

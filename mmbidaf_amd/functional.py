@@ -40,13 +40,35 @@ def _mask_u8(mask, B, n):
     return (m != 0).contiguous()
 
 
+class PrefixMask:
+    """The prefix mask models.get_mask builds (reference models.py:86-92: mask[b, i] = i < len[b]) carried as its
+    LENGTHS: the attention kernels derive the mask from the int32 length vector themselves, so
+    nothing is built on the host or copied per step; `.tensor()` materialises the bool (B, n) tensor on the device for
+    code that wants one (the decoder), once."""
+
+    def __init__(self, lengths, n, lengths_dev):
+        self.lengths = list(lengths)
+        self.n = n
+        self.lengths_dev = lengths_dev          # int32 (B) on the device
+        self._tensor = None
+
+    def size(self, dim=None):
+        shape = (len(self.lengths), self.n)
+        return shape if dim is None else shape[dim]
+
+    def tensor(self):
+        if self._tensor is None:
+            self._tensor = torch.arange(self.n, device=self.lengths_dev.device).unsqueeze(0) < self.lengths_dev.unsqueeze(1)
+        return self._tensor
+
+
 class _BiDAFAttentionFn(torch.autograd.Function):
     """out = BiDAFAttention(text, mod)  -- reference layers/attention.py:37-75 (A1-A5, A-bwd)."""
 
     @staticmethod
     def forward(ctx, text, mod, text_d, mod_d, w_t, w_m, w_tm, bias, text_mask, mod_mask):
         lib = _lib.load()
-        _require_gpu(text, mod, w_t, w_m, w_tm, bias, text_mask, mod_mask)
+        _require_gpu(text, mod, w_t, w_m, w_tm, bias)
         B, T, D = text.shape
         M = mod.shape[1]
         if D % 4 != 0 or D > _lib.ATT_GENERAL_MAX_D:
@@ -57,33 +79,45 @@ class _BiDAFAttentionFn(torch.autograd.Function):
             text_d, mod_d = _f32c(text_d), _f32c(mod_d)
         w_t_, w_m_, w_tm_, bias_ = (_f32c(w_t.reshape(-1)), _f32c(w_m.reshape(-1)),
                                     _f32c(w_tm.reshape(-1)), _f32c(bias.reshape(-1)))
-        tmask, mmask = _mask_u8(text_mask, B, T), _mask_u8(mod_mask, B, M)
+        fused = D <= _lib.ATT_MAX_D
+
+        def mask_args(mask, n):
+            """(u8 mask or None, int32 lengths or None): prefix masks travel as lengths on the fused path"""
+            if isinstance(mask, PrefixMask):
+                if fused:
+                    return None, mask.lengths_dev
+                mask = mask.tensor()
+            _require_gpu(mask)
+            return _mask_u8(mask, B, n), None
+        tmask, tlen = mask_args(text_mask, T)
+        mmask, mlen = mask_args(mod_mask, M)
         dev = text.device
         out = torch.empty(B, T, 4 * D, device=dev, dtype=torch.float32)
-        q = torch.empty(B, M, D, device=dev, dtype=torch.float32)
         bsave = torch.empty(B, T, D, device=dev, dtype=torch.float32)
         rterm = torch.empty(B, T, device=dev, dtype=torch.float32)
         cterm = torch.empty(B, M, device=dev, dtype=torch.float32)
         row_stat = torch.empty(B, T, 2, device=dev, dtype=torch.float32)
         col_stat = torch.empty(B, M, 2, device=dev, dtype=torch.float32)
-        ws_bytes = lib.mmb_bidaf_fwd_workspace_bytes(B, T, M, D)   # 0 for the fused kernels (D <= 208)
-        ws = torch.empty(ws_bytes // 4, device=dev, dtype=torch.float32) if ws_bytes else None
-        rc = lib.mmb_bidaf_fwd(_ptr(text), _ptr(mod), _ptr(tmask), _ptr(mmask),
+        saved_bytes = lib.mmb_bidaf_saved_bytes(B, T, M, D, int(has_drop))
+        saved = torch.empty(saved_bytes, device=dev, dtype=torch.uint8)      # operand planes + row scales (or q, general path)
+        ws_bytes = lib.mmb_bidaf_fwd_workspace_bytes(B, T, M, D)
+        ws = torch.empty(max(ws_bytes, 4) // 4, device=dev, dtype=torch.float32)
+        rc = lib.mmb_bidaf_fwd(_ptr(text), _ptr(mod), _ptr(tmask), _ptr(mmask), _ptr(tlen), _ptr(mlen),
                                _ptr(text_d) if has_drop else None, _ptr(mod_d) if has_drop else None,
                                _ptr(w_t_), _ptr(w_m_), _ptr(w_tm_), _ptr(bias_),
-                               _ptr(out), _ptr(q), _ptr(bsave), _ptr(rterm), _ptr(cterm), _ptr(row_stat), _ptr(col_stat),
-                               _ptr(ws), ws_bytes, B, T, M, D, dev.index, _stream())
+                               _ptr(out), _ptr(bsave), _ptr(rterm), _ptr(cterm), _ptr(row_stat), _ptr(col_stat),
+                               _ptr(saved), saved_bytes, _ptr(ws), ws_bytes, B, T, M, D, dev.index, _stream())
         _lib.check(rc, "mmb_bidaf_fwd")
         ctx.has_drop = has_drop
         ctx.shapes = (w_t.shape, w_m.shape, w_tm.shape, bias.shape)
         ctx.save_for_backward(text, mod, text_d if has_drop else None, mod_d if has_drop else None,
-                              w_t_, w_m_, w_tm_, tmask, mmask, out, q, bsave, rterm, cterm, row_stat, col_stat)
+                              w_t_, w_m_, w_tm_, tmask, mmask, tlen, mlen, out, saved, bsave, rterm, cterm, row_stat, col_stat)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         lib = _lib.load()
-        (text, mod, text_d, mod_d, w_t, w_m, w_tm, tmask, mmask, out, q, bsave, rterm, cterm,
+        (text, mod, text_d, mod_d, w_t, w_m, w_tm, tmask, mmask, tlen, mlen, out, saved, bsave, rterm, cterm,
          row_stat, col_stat) = ctx.saved_tensors
         B, T, D = text.shape
         M = mod.shape[1]
@@ -97,9 +131,9 @@ class _BiDAFAttentionFn(torch.autograd.Function):
         d_w_t, d_w_m, d_w_tm, d_bias = d_w[0:D], d_w[D:2 * D], d_w[2 * D:3 * D], d_w[3 * D:3 * D + 1]
         ws_bytes = lib.mmb_bidaf_bwd_workspace_bytes(B, T, M, D)
         ws = torch.empty(ws_bytes // 4, device=dev, dtype=torch.float32)
-        rc = lib.mmb_bidaf_bwd(_ptr(d_out), _ptr(out), _ptr(text), _ptr(mod), _ptr(tmask), _ptr(mmask),
+        rc = lib.mmb_bidaf_bwd(_ptr(d_out), _ptr(out), _ptr(text), _ptr(mod), _ptr(tmask), _ptr(mmask), _ptr(tlen), _ptr(mlen),
                                _ptr(text_d), _ptr(mod_d), _ptr(w_t), _ptr(w_m), _ptr(w_tm),
-                               _ptr(q), _ptr(bsave), _ptr(rterm), _ptr(cterm), _ptr(row_stat), _ptr(col_stat),
+                               _ptr(saved), _ptr(bsave), _ptr(rterm), _ptr(cterm), _ptr(row_stat), _ptr(col_stat),
                                _ptr(d_text), _ptr(d_mod), _ptr(d_text_d), _ptr(d_mod_d),
                                _ptr(d_w_t), _ptr(d_w_m), _ptr(d_w_tm), _ptr(d_bias),
                                _ptr(ws), ws_bytes, B, T, M, D, dev.index, _stream())
@@ -110,7 +144,8 @@ class _BiDAFAttentionFn(torch.autograd.Function):
 
 
 def bidaf_attention(text, mod, text_mask, mod_mask, w_t, w_m, w_tm, bias, text_d=None, mod_d=None):
-    """Fused BiDAF attention.  text_d / mod_d: dropped copies seen only by the similarity (Q6)."""
+    """Fused BiDAF attention.  text_d / mod_d: dropped copies seen only by the similarity (Q6).
+    text_mask / mod_mask: (B,T) / (B,M) 0/1 tensors, or PrefixMask objects (lengths only)."""
     if (text_d is None) != (mod_d is None):
         raise ValueError("text_d and mod_d must be given together")
     return _BiDAFAttentionFn.apply(text, mod, text_d, mod_d, w_t, w_m, w_tm, bias, text_mask, mod_mask)

@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from .attention import BiDAFAttention, MultimodalAttentionDecoder
 from .encoding import Embedding, ImageEmbedding, RNNEncoder, encode_group, to_device_cached
+from .functional import PrefixMask
 
 
 class MMBiDAF(nn.Module):
@@ -46,9 +47,14 @@ class MMBiDAF(nn.Module):
             [self.text_enc, self.audio_enc, self.image_enc], [text_emb, audio_emb, image_emb],
             [text_lengths, audio_lengths, image_lengths])
         dev = text_emb.device
-        # masks are built on the host like the reference (models.py:116-118,126-128) and cached on the device
+        # the reference builds bool prefix masks on the host and copies them every forward (models.py:116-118,126-128);
+        # here a prefix mask travels as its int32 length vector (already on the device for the encoders) and the
+        # attention kernels derive mask[b, i] = i < len[b] themselves
         def mask(x, lengths):
-            return to_device_cached(("mask", x.size(1)), lengths, dev, lambda: self.get_mask(x, lengths))
+            if dev.type != "cuda":
+                return self.get_mask(x, lengths).to(dev)
+            lens_dev = to_device_cached("len_i32", lengths, dev, lambda: torch.tensor(list(lengths), dtype=torch.int32))
+            return PrefixMask(lengths, x.size(1), lens_dev)
         text_mask, audio_mask, image_mask = mask(text_emb, text_lengths), mask(audio_emb, audio_lengths), mask(image_emb, image_lengths)
         att_audio = self.bidaf_att_audio(text_enc, audio_enc, text_mask, audio_mask)
         att_image = self.bidaf_att_image(text_enc, image_enc, text_mask, image_mask)
@@ -79,6 +85,8 @@ class MMBiDAF(nn.Module):
         loop); CPU tensors take the stock-PyTorch step module, as the rest of the surrounding graph does."""
         B = embedded_text.size(0)
         dev = embedded_text.device
+        if isinstance(text_mask, PrefixMask):
+            text_mask = text_mask.tensor()
         pad = torch.zeros(B, self.max_transcript_length - text_mask.size(1), dtype=text_mask.dtype, device=dev)
         decoder_mask = torch.cat((text_mask, pad), dim=1)
         # the reference sums the (length-sorted) hidden states over layers and directions, models.py:143

@@ -210,6 +210,35 @@ def test_attention_long_sequence_cfg4_size():
         close(g, p.grad, k)
 
 
+def test_attention_prefix_masks_from_lengths_match_u8_masks():
+    """for the prefix masks models.get_mask builds (models.py:86-92) the kernels derive
+    mask[b,i] = i < len[b] from the int32 length vector; output and every gradient must be IDENTICAL to the run with the
+    materialised u8 masks (same arithmetic, only the mask source differs)."""
+    from mmbidaf_amd import functional as MF
+    d = dev()
+    c, drop = _random_att_case(31, 5, 77, 41, 200, True)
+    tl = [int(m.sum()) for m in c["text_mask"]]
+    ml = [int(m.sum()) for m in c["mod_mask"]]
+    assert torch.equal(c["text_mask"], O.get_mask(77, tl)) and torch.equal(c["mod_mask"], O.get_mask(41, ml))
+
+    def run(tm, mm):
+        text = c["text"].to(d).requires_grad_(True)
+        mod = c["mod"].to(d).requires_grad_(True)
+        ps = [c[k].to(d).requires_grad_(True) for k in ("w_t", "w_m", "w_tm", "bias")]
+        out = MF.bidaf_attention(text, mod, tm, mm, *ps, text_d=text * drop[0].to(d), mod_d=mod * drop[1].to(d))
+        (out * c["cot"].to(d)).sum().backward()
+        return [out, text.grad, mod.grad] + [p.grad for p in ps[:3]]
+    a = run(c["text_mask"].to(d), c["mod_mask"].to(d))
+    lens = lambda l: torch.tensor(l, dtype=torch.int32, device=d)
+    b = run(MF.PrefixMask(tl, 77, lens(tl)), MF.PrefixMask(ml, 41, lens(ml)))
+    for x, y, n in zip(a, b, ("out", "d_text", "d_mod", "d_w_t", "d_w_m", "d_w_tm")):
+        if n.startswith("d_w"):       # accumulated with atomics: order-dependent last bits
+            close(y, x.detach().cpu(), n + " (lengths vs masks)", tol=1e-6)
+        else:
+            assert torch.equal(x, y), n
+    assert torch.equal(MF.PrefixMask(tl, 77, lens(tl)).tensor().cpu(), c["text_mask"])
+
+
 def test_attention_rejects_bad_width():
     from mmbidaf_amd import functional as MF
     d = dev()
