@@ -27,10 +27,23 @@ from mmbidaf_amd import _lib, ddp, synth
 from mmbidaf_amd.hot_region import HotRegion
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP32_MFMA_PEAK_TF = 157.3    # exact-f32 MFMA / vector peak
+F16_MFMA_PEAK_TF = 2500.0    # dense fp16/bf16 MFMA peak (the fused attention issues 3 fp16 MFMAs per fp32-accurate product)
 ATT_FWD_KERNELS = ["att_rank1", "att_col", "att_combine", "att_row"]
 ATT_BWD_KERNELS = ["att_bwd_pre", "att_bwd_j1", "att_bwd_j2", "att_bwd_jfin", "att_bwd_i"]
-ALL_KERNELS = ATT_FWD_KERNELS + ATT_BWD_KERNELS + ["gemm", "lstm_rec_fwd", "lstm_rec_bwd"]
+ATT_KERNELS = ATT_FWD_KERNELS + ATT_BWD_KERNELS
+ALL_KERNELS = ATT_KERNELS + ["gemm", "lstm_rec_fwd", "lstm_rec_bwd"]
+
+
+def source_hash():
+    """sha1 over the kernel sources: stamps PMC traffic files so that bench.py only quotes traffic measured on the
+    very kernels it is timing (the GPU box has no .git to ask for the head)."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "mmbidaf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -49,13 +62,13 @@ def parse():
 
 
 def cpu_baseline(region, cfg, ragged):
-    """The oracle's CPU path (torch's own packed nn.LSTM + bmm/softmax attention, i.e. what the
-    reference's modules execute) timed on the host cores on a bounded sample of the workload."""
+    """The oracle's CPU path (torch's own packed nn.LSTM + bmm/softmax attention, i.e. what the reference's modules
+    execute -- SURVEY 8(d)) timed on the host cores of this box on the SAME workload (full batch), every core the
+    process may use, 1 warm-up step, then timed steps for about 20 s (at least 2)."""
     from oracle import mmbidaf_oracle as O
-    B_s = 8
-    batch = synth.make_batch(cfg, rank=0, ragged=ragged, device="cpu", batch=B_s)
-    H = batch["H"]
-    threads = min(16, len(os.sched_getaffinity(0)))   # the GPU box gives one GPU a 16-core share
+    batch = synth.make_batch(cfg, rank=0, ragged=ragged, device="cpu")
+    B_s, H = batch["B"], batch["H"]
+    threads = len(os.sched_getaffinity(0))
     torch.set_num_threads(threads)
     ref = O.HotRegionCPU({k: v.detach().cpu() for k, v in region.state_dict().items()}, H)
     xs = [batch[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
@@ -69,14 +82,64 @@ def cpu_baseline(region, cfg, ragged):
 
     step()
     n, t0 = 0, time.perf_counter()
-    while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 10):
+    while n < 2 or (time.perf_counter() - t0 < 20.0 and n < 10):
         step()
         n += 1
     dt = time.perf_counter() - t0
+    cpu = "?"
+    try:
+        cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
     return {"value": round(B_s * n / dt, 3), "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"{n} fwd+bwd steps of the same workload at batch {B_s} (of {synth.CONFIGS[cfg][0]}) after 1 warm-up, "
+            "sample": f"{n} fwd+bwd steps of the same workload at the full batch {B_s} after 1 warm-up ({dt:.1f} s), "
                       f"oracle HotRegionCPU = torch {torch.__version__} CPU packed nn.LSTM + bmm/softmax attention, "
-                      f"{threads} threads; the reference's own Python does not travel to this box"}
+                      f"{threads} threads on {cpu}; the reference's own Python does not travel to this box"}
+
+
+def attention_roofline(a, prof, B, T, Ma, Mi, D, fused):
+    """roofline.achieved = algorithmic bytes / kernel time / HBM peak for the fused BiDAF attention, forward
+    and backward of BOTH attentions of a step (nine kernels each); algorithmic bytes fwd 4B(5TD+MD), bwd 4B(6TD+2MD).
+    Times are HIP events recorded by the library around every launch on the launch stream, over the timed region."""
+    if not fused:
+        return None       # D > 208 runs the general-width kernels (bidaf_big.hip: batched GEMMs + softmax kernels)
+    steps = max(a.steps, 1)
+    per = {k: (prof[k][0] / steps * 1e3, prof[k][1] / steps, prof[k][2]) for k in ATT_KERNELS}   # us per step, launches per step, symbol
+    fwd_us = sum(per[k][0] for k in ATT_FWD_KERNELS)
+    bwd_us = sum(per[k][0] for k in ATT_BWD_KERNELS)
+    fwd_b = sum(synth.attention_algorithmic_bytes(B, T, M, D) for M in (Ma, Mi))
+    bwd_b = sum(synth.attention_algorithmic_bytes(B, T, M, D, backward=True) for M in (Ma, Mi))
+    tot_us = fwd_us + bwd_us
+    ach = (fwd_b + bwd_b) / (tot_us * 1e-6) / 1e9 if tot_us else 0.0
+    slow = max(ATT_KERNELS, key=lambda k: per[k][0])
+    # matrix-core work of the fused kernels: S-type and PV-type products at the padded sizes (7 k tiles / 13 feature
+    # tiles), 3 fp16 MFMAs per product, per (16 lane rows x 32 streamed rows): col 81, row 120 (+42 with two waves per
+    # SIMD), j1 243, j2 123, i 246 MFMAs of 16x16x32
+    units = lambda M: B * ((M + 15) // 16) * ((T + 31) // 32) * (81 + 243 + 123) + B * ((T + 15) // 16) * ((M + 31) // 32) * (162 + 246)
+    flops = sum(units(M) for M in (Ma, Mi)) * 2 * 16 * 16 * 32
+    traffic, traffic_note = None, "no PMC file stamped with these kernel sources"
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            t = json.load(open(tpath))
+            if t.get("source_hash") == source_hash() and a.config in t:
+                traffic = sum(t[a.config].get(per[k][2], 0.0) * per[k][1] for k in ATT_KERNELS)
+                traffic_note = "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per step over the nine kernels, separate rocprofv3 --pmc passes of this command (tools/run_round_profiles.sh)"
+        except Exception:
+            pass
+    return {"bound": "hbm", "kernel": "fused BiDAF attention, forward + backward of both attentions (9 kernels each)",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "traffic_note": traffic_note,
+            "algorithmic_bytes_per_step": int(fwd_b + bwd_b), "us_per_step": round(tot_us, 1),
+            "forward": {"us_per_step": round(fwd_us, 1), "algorithmic_bytes": int(fwd_b),
+                        "frac": round(fwd_b / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if fwd_us else None},
+            "backward": {"us_per_step": round(bwd_us, 1), "algorithmic_bytes": int(bwd_b),
+                         "frac": round(bwd_b / (bwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if bwd_us else None},
+            "slowest_kernel": {"name": per[slow][2], "us_per_step": round(per[slow][0], 1), "launches_per_step": per[slow][1]},
+            "kernel_us_per_launch": {per[k][2]: round(per[k][0] / max(per[k][1], 1), 2) for k in ATT_KERNELS},
+            "mfma_f16": {"achieved_tflops": round(flops / (tot_us * 1e-6) / 1e12, 1) if tot_us else None, "peak_tflops": F16_MFMA_PEAK_TF,
+                         "frac": round(flops / (tot_us * 1e-6) / 1e12 / F16_MFMA_PEAK_TF, 4) if tot_us else None,
+                         "note": "fp16 MFMA issued (3 per fp32-accurate product), all nine kernels' time in the denominator"}}
 
 
 def main():
@@ -97,7 +160,9 @@ def main():
     torch.manual_seed(224)  # the reference's seed (args.py:45): identical replicas on every rank
     region = HotRegion(H).to(dev)
     params = list(region.parameters())
-    sync = ddp.FlatGradAllReduce(params)
+    # gradient exchange: SUM over ranks (the reference's loss is a sum over samples), bucketed in backward order and
+    # launched from grad hooks so that it overlaps the rest of the backward pass
+    sync = ddp.FlatGradAllReduce(params, buckets=ddp.region_buckets(region), overlap=True)
     sync.broadcast_parameters()
     batch = synth.make_batch(a.config, rank=rank, ragged=a.ragged, device=dev, batch=B)
     xs = [batch[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]  # they come from trainable embeddings
@@ -125,7 +190,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    timed = ALL_KERNELS if a.profile_all else ATT_FWD_KERNELS
+    timed = ALL_KERNELS if a.profile_all else ATT_KERNELS
     fence()
     _lib.profile_enable(timed)
     t0 = time.perf_counter()
@@ -134,52 +199,36 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     _lib.profile_enable([])
+    devices = [f"cuda:{local}"]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, f"rank{rank}:cuda:{local}:{torch.cuda.get_device_name(local)}")
+        devices = gathered
     prof = {k: _lib.profile_read(k) for k in timed}
 
     if rank == 0:
-        ms_row, n_row, sym = prof["att_row"]
-        # dominant attention kernel = the row pass; its launches alternate text<->audio / text<->image
-        bytes_row = sum(4 * B * (5 * T * D + 2 * M * D) for M in (Ma, Mi)) / 2.0   # per launch, averaged over the two
-        flops_row = sum(2 * B * T * M * (208 + 2 * 208) for M in (Ma, Mi)) / 2.0     # S + 2 PV products at the padded D
-        # (PMC `traffic`: profiles/pmc_traffic.json = FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch, from separate
-        #  rocprofv3 --pmc passes of this same command: tools/profile_summary.py)
-        avg_s = ms_row / max(n_row, 1) * 1e-3
-        achieved = bytes_row / avg_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(a.config, {}).get(sym)
-            except Exception:
-                traffic = None
-        fwd_ms = sum(prof[k][0] for k in ATT_FWD_KERNELS) / max(a.steps, 1)
-        fwd_bytes = sum(synth.attention_algorithmic_bytes(B, T, M, D) for M in (Ma, Mi))
         out = {
             "metric": "samples/sec fwd+bwd, synthetic T_text=400 H=100, at 1/2/4/8 MI355X",
             "value": round(world * B * a.steps / dt, 2), "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 throughout: attention and recurrences on exact-f32 MFMA / VALU; LSTM projection and gradient GEMMs "
-                          "on fp16 MFMA from an error-compensated split of the fp32 operands (two fp16 terms of the power-of-two-scaled "
-                          "value, 3 cross products, fp32 accumulate: max error vs float64 3-8e-7 of the output scale, the same as an fp32 GEMM)",
+            "arithmetic": "fp32 in, fp32 out, fp32 accumulation throughout; recurrences on fp32 VALU; every dense contraction (attention "
+                          "similarity / context products, LSTM projection and gradient GEMMs) on fp16 MFMA from an error-compensated split of "
+                          "the fp32 operands (two fp16 terms of the power-of-two-scaled rows, 3 cross products: max error ~1e-6 of the "
+                          "operand scale, the error class of an fp32 GEMM)",
             "config": {"workload": f"{a.config}: hot-path region (3 BiLSTM enc -> 2 BiDAF att -> 2 two-layer BiLSTM) "
                                    f"B={B}/GPU T_text={T} T_aud={Ma} T_img={Mi} H={H}, "
                                    f"{'ragged U{n/2..n}' if a.ragged else 'full'} lengths, fwd+bwd"
-                                   f"{' + flat-grad all-reduce' if world > 1 else ''}",
+                                   f"{' + bucketed gradient all-reduce (sum)' if world > 1 else ''}",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "hbm", "kernel": sym, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": n_row,
-                         "algorithmic_bytes_per_launch": int(bytes_row),
-                         "mfma_f32": {"achieved_tflops": round(flops_row / avg_s / 1e12, 2), "peak_tflops": FP32_MFMA_PEAK_TF,
-                                      "frac": round(flops_row / avg_s / 1e12 / FP32_MFMA_PEAK_TF, 4)},
-                         "fused_fwd_both_attentions": {"ms_per_step": round(fwd_ms, 4), "algorithmic_bytes": int(fwd_bytes),
-                                                       "achieved_GBs": round(fwd_bytes / (fwd_ms * 1e-3) / 1e9, 1) if fwd_ms else None}},
+            "roofline": attention_roofline(a, prof, B, T, Ma, Mi, D, fused=D <= _lib.ATT_MAX_D),
         }
+        if world > 1:
+            out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": devices,
+                           "grad_buckets": len(sync.buckets), "grad_elems": sync.numel}
         if a.profile_all:
             out["kernel_ms_per_step"] = {k: round(v[0] / a.steps, 4) for k, v in prof.items()}
             out["kernel_launches_per_step"] = {k: v[1] / a.steps for k, v in prof.items()}

@@ -81,6 +81,11 @@ const char* mmb_kernel_name(int kernel_id);   /* device-side symbol stem, as roc
  * bytes of scratch (fused: the per-split partial column softmaxes).
  */
 size_t mmb_bidaf_saved_bytes(int B, int T, int M, int D, int has_drop);
+
+/* Timing-only ablations of the fused attention kernels for tools/att_bench.py (results are then WRONG; 0 = off, the
+ * default; also env MMB_ATT_DBG at first use): 1 = stage only the first panel, 2 = no S-type products, 4 = no PV-type
+ * products, 8 = no epilogue stores, 16 = no panel loop. */
+void mmb_set_att_debug(int mask);
 size_t mmb_bidaf_fwd_workspace_bytes(int B, int T, int M, int D);
 
 int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t* text_mask, const uint8_t* mod_mask,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "mmb_profile_read": (c_i, [c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i)]),
     "mmb_kernel_name": (ctypes.c_char_p, [c_i]),
     "mmb_bidaf_saved_bytes": (ctypes.c_size_t, [c_i] * 5),
+    "mmb_set_att_debug": (None, [c_i]),
     "mmb_bidaf_fwd_workspace_bytes": (ctypes.c_size_t, [c_i] * 4),
     "mmb_bidaf_fwd": (c_i, [c_f] * 19 + [ctypes.c_size_t, c_f, ctypes.c_size_t] + [c_i] * 5 + [c_f]),
     "mmb_bidaf_bwd_workspace_bytes": (ctypes.c_size_t, [c_i] * 4),

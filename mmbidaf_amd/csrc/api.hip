@@ -104,7 +104,7 @@ extern "C" int mmb_profile_read(int kernel_id, double* total_ms, int* launches) 
 
 extern "C" const char* mmb_kernel_name(int kernel_id) {
     static const char* names[MMB_K_COUNT] = {
-        "att_rank1_kernel", "att_col_kernel", "att_combine_kernel", "att_row_kernel",
+        "att_prep_kernel", "att_col_kernel", "att_combine_kernel", "att_row8_kernel",
         "att_bwd_pre_kernel", "att_bwd_j1_kernel", "att_bwd_j2_kernel", "att_bwd_jfin_kernel", "att_bwd_i_kernel",
         "gemm_kernel", "lstm_rec_fwd_kernel", "lstm_rec_bwd_kernel", "split_"};
     return (kernel_id >= 0 && kernel_id < MMB_K_COUNT) ? names[kernel_id] : "";

@@ -37,6 +37,7 @@
 // then covers all 64 banks exactly once).  A 32-row panel is one contiguous 28-KiB run: 28 LDS-DMA
 // wave-instructions (global_load_lds_dwordx4), no VGPR round trip, no per-element work in the panel loop.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -53,6 +54,18 @@ constexpr int PANEL_B = 2 * PRB;   // bytes of a 32-row panel (28 KiB)
 constexpr int LDP = 212;           // row stride (floats) of the epilogue's LDS staging tile
 constexpr float NEG = -1e30f;      // attention.py:94
 constexpr float WMAX = 16384.0f;   // 2^14: where the largest split operand is mapped
+
+// timing-only ablations (mmb_set_att_debug / MMB_ATT_DBG; never set by the product path; results are then WRONG):
+// 1 = stage only the first panel, 2 = no S-type products, 4 = no PV-type products, 8 = no epilogue stores,
+// 16 = no panel loop at all (prologue + epilogue only)
+static int g_att_dbg = -1;
+static int att_dbg() {
+    if (g_att_dbg < 0) {
+        const char* e = getenv("MMB_ATT_DBG");
+        g_att_dbg = e ? atoi(e) : 0;
+    }
+    return g_att_dbg;
+}
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
@@ -101,15 +114,31 @@ __device__ __forceinline__ void a_split2h(const float* x, half8& h0, half8& h1) 
     }
 }
 
-__device__ __forceinline__ float kg_allsum(float v) {  // over the 4 k-groups (lanes r, r+16, r+32, r+48)
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+// reductions over the 4 k-groups of a row (lanes r, r+16, r+32, r+48) with the gfx950 half / row swaps: one VALU
+// instruction per step instead of a ds_bpermute round trip.  v_permlane32_swap(x, x) leaves [lo | lo] and [hi | hi],
+// v_permlane16_swap(x, x) leaves rows [0 0 2 2] and [1 1 3 3]: combining the pair is the xor-32 / xor-16 exchange.
+// Inline asm, not __builtin_amdgcn_permlane{16,32}_swap: hipcc (ROCm 7.2) copy-propagates across the builtin as if
+// its second operand were not written (a swap of two copies of one value then yields "p + p"); the two v_nop are the
+// wait states a VALU write of an operand needs before the swap reads it.
+__device__ __forceinline__ void kg_pairs(float v, int step, float& p, float& q) {
+    p = v;
+    q = v;
+    if (step == 32) asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+    else asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+}
+__device__ __forceinline__ float kg_allsum(float v) {
+    float p, q;
+    kg_pairs(v, 32, p, q);
+    v = p + q;
+    kg_pairs(v, 16, p, q);
+    return p + q;
 }
 __device__ __forceinline__ float kg_allmax(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
+    float p, q;
+    kg_pairs(v, 32, p, q);
+    v = fmaxf(p, q);
+    kg_pairs(v, 16, p, q);
+    return fmaxf(p, q);
 }
 __device__ __forceinline__ float r_allsum(float v) {  // over the 16 lanes of a k-group
     v += __shfl_xor(v, 1);
@@ -206,23 +235,57 @@ __device__ __forceinline__ f4 mfma_h(const half8 a, const half8 b, const f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// S-type product of the panel's two 16-row blocks against the lane-side registers: c[mb][e] = row 16 mb + 4g + e
+// S-type product of the panel's two 16-row blocks against the lane-side registers: c[mb][e] = row 16 mb + 4g + e.
+// Software-pipelined by hand: the 4 b128 reads of k tile kt+1 are issued before the 6 MFMAs of k tile kt and interleaved
+// with them (at one wave per SIMD hipcc otherwise waits out every LDS latency in front of the MFMAs that need it).
+template <bool PIPE = true>
 __device__ __forceinline__ void sprod2(const char* panel, int r, int g, const side_t& side, f4 (&c)[2]) {
     const char* p = panel + r * 64 + ((g ^ att_swz(r)) << 4);
+    if (!PIPE) {   // register-starved kernels (3-4 lane-side operands): plain order, the compiler schedules
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        half8 a0[2], a1[2];
+        for (int kt = 0; kt < KT; ++kt) {
+            half8 a0[2], a1[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                a0[mb] = *reinterpret_cast<const half8*>(p + (mb * KT + kt) * PCH);
+                a1[mb] = *reinterpret_cast<const half8*>(p + (mb * KT + kt) * PCH + 1024);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(a0[mb], side.h[kt][1], c[mb]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(a1[mb], side.h[kt][0], c[mb]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(a0[mb], side.h[kt][0], c[mb]);
+        }
+        return;
+    }
+    half8 fr[2][4];   // [buffer][mb * 2 + plane]
+    auto ld = [&](int kt, half8 (&x)[4]) {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
-            a0[mb] = *reinterpret_cast<const half8*>(p + (mb * KT + kt) * PCH);
-            a1[mb] = *reinterpret_cast<const half8*>(p + (mb * KT + kt) * PCH + 1024);
+            x[2 * mb] = *reinterpret_cast<const half8*>(p + (mb * KT + kt) * PCH);
+            x[2 * mb + 1] = *reinterpret_cast<const half8*>(p + (mb * KT + kt) * PCH + 1024);
         }
+    };
+    ld(0, fr[0]);
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(a0[mb], side.h[kt][1], c[mb]);
+    for (int kt = 0; kt < KT; ++kt) {
+        const half8(&x)[4] = fr[kt & 1];
+        if (kt + 1 < KT) ld(kt + 1, fr[(kt + 1) & 1]);
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(a1[mb], side.h[kt][0], c[mb]);
+        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(x[2 * mb], side.h[kt][1], c[mb]);
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(a0[mb], side.h[kt][0], c[mb]);
+        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(x[2 * mb + 1], side.h[kt][0], c[mb]);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(x[2 * mb], side.h[kt][0], c[mb]);
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
     }
 }
 
@@ -247,16 +310,35 @@ __device__ __forceinline__ half8 cat44(const v4s lo, const v4s hi) {
     return __builtin_bit_cast(half8, t);
 }
 
-// PV-type: O[dt] += V^T[16 dt ..][32 rows] . W   with W already split into (W0, W1) (k = 8g+j <-> row as above)
+// PV-type: O[dt] += V^T[16 dt ..][32 rows] . W   with W already split into (W0, W1) (k = 8g+j <-> row as above).
+// The 4 transpose reads of feature tile dt+PVD run ahead of the 3 MFMAs of tile dt (ring of PVD+1 fragment sets).
+template <int PVD = 3>
 __device__ __forceinline__ void pvprod(const char* panel, const tr_off& tr, const half8 W0, const half8 W1, acc_t& O) {
+    v4s fr[PVD + 1][4];
+    auto ld = [&](int dt, v4s (&x)[4]) {
+        const char* base = panel + (dt >> 1) * PCH + tr.o[dt & 1];
+        x[0] = tr16(base);
+        x[1] = tr16(base + KT * PCH);
+        x[2] = tr16(base + 1024);
+        x[3] = tr16(base + KT * PCH + 1024);
+    };
+#pragma unroll
+    for (int d = 0; d < PVD; ++d) ld(d, fr[d]);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-        const char* base = panel + (dt >> 1) * PCH + tr.o[dt & 1];
-        const half8 A0 = cat44(tr16(base), tr16(base + KT * PCH));
-        const half8 A1 = cat44(tr16(base + 1024), tr16(base + KT * PCH + 1024));
+        if (dt + PVD < DT) ld(dt + PVD, fr[(dt + PVD) % (PVD + 1)]);
+        const v4s(&x)[4] = fr[dt % (PVD + 1)];
+        const half8 A0 = cat44(x[0], x[1]), A1 = cat44(x[2], x[3]);
         O[dt] = mfma_h(A0, W1, O[dt]);
         O[dt] = mfma_h(A1, W0, O[dt]);
         O[dt] = mfma_h(A0, W0, O[dt]);
+        if (dt + PVD < DT) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
     }
 }
 
@@ -342,8 +424,7 @@ __device__ __forceinline__ bool mask_live(const uint8_t* mask, const int* len, i
 }
 
 // ------------------------------------------------------------------------------------------ split passes
-// One 32-lane half wave per row, lane = 16-B octet of the planes (8 features).  Up to 4 tensors per launch
-// (blockIdx.y).  Also the rank-1 terms of the similarity: term[b,row] = src[b,row] . w + bias.
+// One wave per row, lane = 4 features (coalesced 16 B per lane).  Up to 4 tensors per launch (blockIdx.y).  Also the rank-1 terms of the similarity: term[b,row] = src[b,row] . w + bias.
 struct SplitSrc {
     const float* src;     // (B,R,D)
     char* planes;         // B x planes_sample_bytes(R)
@@ -357,44 +438,55 @@ struct PrepArgs {
     SplitSrc t[4];
     int n, D, B;
 };
-__device__ __forceinline__ void store_split_row(char* planes_b, float* inv_row, int row, int oct, float (&v)[8], float amax) {
-    const float s = a_pow2_scale(amax);
-    if (oct < 4 * KT) {
-        half8 h0, h1;
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float wave_allmax(float v) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= s;
-        a_split2h(v, h0, h1);
-        char* d = planes_b + pl_off_att(row, oct);
-        *reinterpret_cast<half8*>(d) = h0;
-        *reinterpret_cast<half8*>(d + 1024) = h1;
-    }
-    if (oct == 0) *inv_row = amax > 0.f ? 1.0f / s : 0.f;
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
 }
+__device__ __forceinline__ float wave_allsum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// lane c (< 8 KT) holds features 4c..4c+3 of `row`; amax = the row's max |x| (wave-uniform)
+__device__ __forceinline__ void store_split_row(char* planes_b, float* inv_row, int row, int c, f4 x, float amax) {
+    const float s = a_pow2_scale(amax);
+    if (c < 8 * KT) {
+        x = x * s;
+        half4 h0, h1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = fminf(fmaxf(x[j], -60000.0f), 60000.0f);
+            const _Float16 a = (_Float16)v;
+            h0[j] = a;
+            h1[j] = (_Float16)(v - (float)a);
+        }
+        char* d = planes_b + pl_off_att(row, c >> 1) + (c & 1) * 8;
+        *reinterpret_cast<half4*>(d) = h0;
+        *reinterpret_cast<half4*>(d + 1024) = h1;
+    }
+    if (c == 0) *inv_row = amax > 0.f ? 1.0f / s : 0.f;
+}
+// One wave per row (fully coalesced 16 B per lane), 4 rows per workgroup; blockIdx.y = tensor
 __global__ __launch_bounds__(256) void att_prep_kernel(const PrepArgs a) {
     const SplitSrc s = a.t[blockIdx.y];
     const int Rp = pad32(s.R);
-    const long rowi = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const long rowi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rowi >= (long)a.B * Rp) return;
-    const int b = rowi / Rp, row = rowi - (long)b * Rp, oct = threadIdx.x & 31;
-    float v[8];
-    float dot = 0.f, amax = 0.f;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int d = 8 * oct + 4 * h;
-        f4 x = f4{0.f, 0.f, 0.f, 0.f};
-        if (row < s.R && d < a.D) {
-            x = *reinterpret_cast<const f4*>(s.src + ((size_t)b * s.R + row) * a.D + d);
-            if (s.w) dot += f4sum(x * *reinterpret_cast<const f4*>(s.w + d));
-        }
-        v[4 * h] = x.x; v[4 * h + 1] = x.y; v[4 * h + 2] = x.z; v[4 * h + 3] = x.w;
-        amax = fmaxf(amax, f4amax(x));
+    const int b = rowi / Rp, row = rowi - (long)b * Rp, c = threadIdx.x & 63, d = 4 * c;
+    f4 x = f4{0.f, 0.f, 0.f, 0.f};
+    float dot = 0.f;
+    if (row < s.R && d < a.D) {
+        x = *reinterpret_cast<const f4*>(s.src + ((size_t)b * s.R + row) * a.D + d);
+        if (s.w) dot = f4sum(x * *reinterpret_cast<const f4*>(s.w + d));
     }
-    amax = half_allmax(amax);
+    const float amax = wave_allmax(f4amax(x));
     if (s.term) {
-        dot = half_allsum(dot);
-        if (oct == 0 && row < s.R) s.term[(size_t)b * s.R + row] = dot + (s.bias ? s.bias[0] : 0.f);
+        dot = wave_allsum(dot);
+        if (c == 0 && row < s.R) s.term[(size_t)b * s.R + row] = dot + (s.bias ? s.bias[0] : 0.f);
     }
-    store_split_row(s.planes + (size_t)b * planes_sample_bytes(s.R), s.inv + (size_t)b * Rp + row, row, oct, v, amax);
+    store_split_row(s.planes + (size_t)b * planes_sample_bytes(s.R), s.inv + (size_t)b * Rp + row, row, c, x, amax);
 }
 
 // rank-1 terms alone (general-width path, bidaf_big.hip): rterm[b,i] = text_d[b,i].w_t + bias ; cterm[b,j] = mod_d[b,j].w_m
@@ -438,12 +530,15 @@ struct AttFwdArgs {
     float* out;             // (B,N,4D)
     float* bsave;           // (B,N,D)
     int N, R, D, B, splits, rows_per_split;
+    int nstage;             // LDS stages of the panel loop (1 or 2)
+    int dbg;
 };
 
 // NV = 1: column pass = att_col_kernel (lane side = modality rows j, streams text rows i), produces the partials of q.
 // NV = 2: row pass = att_row_kernel    (lane side = text rows i, streams modality rows j with values [mod | q]), produces out.
-template <int NV>
+template <int NV, bool DBG>
 __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
+    const int dbg = DBG ? a.dbg : 0;   // timing-only ablations are compiled into their own kernel instances
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int N = a.N, R = a.R, D = a.D, Rp = pad32(R);
@@ -453,10 +548,11 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
     const int rps = a.rows_per_split;
 
     const bool sep_s = a.mS != a.mV0;  // dropped copy differs from the clean value panel
-    char* pV0 = smem;
-    char* pV1 = smem + PANEL_B;                       // only touched when NV == 2
-    char* pS = sep_s ? smem + NV * PANEL_B : pV0;
-    float* mterm_all = reinterpret_cast<float*>(smem + (NV + 1) * PANEL_B);   // per-row scalars of the WHOLE split, loaded once
+    // LDS: nstage stages of [V0 | V1 (NV == 2) | S (dropped copy)] panels, then the per-row scalars of the WHOLE split
+    const int npan = NV + (sep_s ? 1 : 0);
+    const int stage_b = npan * PANEL_B;
+    const bool db = a.nstage == 2;     // two stages: the LDS-DMA of panel p+1 is in flight under the MFMAs of panel p
+    float* mterm_all = reinterpret_cast<float*>(smem + a.nstage * stage_b);
     int* mcode_all = reinterpret_cast<int*>(mterm_all + rps);
     float* sS_all = mterm_all + 2 * rps;              // inverse row scale of the S operand
     float* sV0_all = mterm_all + 3 * rps;             // inverse row scale of V0 times c0
@@ -474,15 +570,23 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
     const float nterm = n < N ? a.n_term[(size_t)b * N + n] : 0.f;
     const tr_off tr = make_tr_off(lane);
 
+    // row pass: the workgroup's 64 text rows, one row per wave-instruction (lane = 16-B chunk), are read ONCE into
+    // registers (16 independent loads in flight), copied out at once as the first quarter of `out` (a verbatim copy of
+    // text, attention.py:52 -- these stores overlap the main loop) and kept for the epilogue's text*a, text*b
+    f4 trow[16];
     if (NV == 2) {
-        // the first quarter of `out` is a verbatim copy of text (attention.py:52): written here, whole rows per
-        // wave-instruction, so that these stores overlap the main loop instead of joining the epilogue burst
         const float* tx = a.text + (size_t)b * N * D;
         float* oo = a.out + (size_t)b * N * 4 * D;
-        for (int rr = wave; rr < 16 * NW; rr += NW) {
-            const int gn = tile * NW * 16 + rr;
-            if (gn < N && 4 * lane < D)
-                *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 4 * lane) = *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * lane);
+        const bool cin = 4 * lane < D;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int gn = tile * NW * 16 + wave + NW * k;
+            trow[k] = (gn < N && cin) ? *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * lane) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int gn = tile * NW * 16 + wave + NW * k;
+            if (gn < N && cin) *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 4 * lane) = trow[k];
         }
     }
     acc_t O0, O1;
@@ -491,11 +595,11 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int row_begin = split * rps;
-    const int row_end = min(R, row_begin + rps);
+    const int row_end = (dbg & 16) ? row_begin : min(R, row_begin + rps);
     float im[2] = {0.f, 0.f};
     for (int i = tid; i < rps; i += NTHR) {
         const int m = row_begin + i;
-        const bool in = m < row_end;
+        const bool in = m < min(R, row_begin + rps);
         mterm_all[i] = in ? a.m_term[(size_t)b * R + m] : 0.f;
         mcode_all[i] = mask_code(in, a.m_mask, a.m_len, b, R, m);
         sS_all[i] = in ? a.iS[(size_t)b * Rp + m] : 0.f;
@@ -515,16 +619,33 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
         if (NV == 2) sV1_all[i] *= c1;
     }
 
+    auto stage = [&](char* base, int p0) {
+        if ((dbg & 1) && p0 != row_begin) return;
+        stage_panel(base, mV0_b, p0, tid);
+        if (NV == 2) stage_panel(base + PANEL_B, mV1_b, p0, tid);
+        if (sep_s) stage_panel(base + NV * PANEL_B, mS_b, p0, tid);
+    };
+    int cur = 0;
+    if (db) {
+        if (row_begin < row_end) stage(smem, row_begin);
+        __syncthreads();
+    }
     for (int p0 = row_begin; p0 < row_end; p0 += PR) {
-        __syncthreads();
-        stage_panel(pV0, mV0_b, p0, tid);
-        if (NV == 2) stage_panel(pV1, mV1_b, p0, tid);
-        if (sep_s) stage_panel(pS, mS_b, p0, tid);
-        __syncthreads();
+        char* base = smem + (db ? cur * stage_b : 0);
+        if (db) {
+            if (p0 + PR < row_end) stage(smem + (cur ^ 1) * stage_b, p0 + PR);
+        } else {
+            __syncthreads();
+            stage(base, p0);
+            __syncthreads();
+        }
+        const char* pV0 = base;
+        const char* pV1 = base + PANEL_B;                 // only touched when NV == 2
+        const char* pS = sep_s ? base + NV * PANEL_B : pV0;
         const int i0 = p0 - row_begin;
 
         f4 v[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-        sprod2(pS, r, g, side, v);
+        if (!(dbg & 2)) sprod2(pS, r, g, side, v);
         float bmax = -INFINITY;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -564,7 +685,7 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
                 for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * sV0_all[i0 + mb * 16 + 4 * g + e];
             half8 W0, W1;
             split_w(w[0], w[1], W0, W1);
-            pvprod(pV0, tr, W0, W1, O0);
+            if (!(dbg & 4)) pvprod(pV0, tr, W0, W1, O0);
         }
         if (NV == 2) {
             f4 w[2];
@@ -574,7 +695,11 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
                 for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * sV1_all[i0 + mb * 16 + 4 * g + e];
             half8 W0, W1;
             split_w(w[0], w[1], W0, W1);
-            pvprod(pV1, tr, W0, W1, O1);
+            if (!(dbg & 4)) pvprod(pV1, tr, W0, W1, O1);
+        }
+        if (db) {
+            __syncthreads();   // retires the DMA of the next stage and frees this one
+            cur ^= 1;
         }
     }
 
@@ -588,6 +713,7 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
         st[0] = m_run;
         st[1] = l;
     }
+    if (dbg & 8) return;
     float* et = reinterpret_cast<float*>(smem);          // [16*NW][LDP]
     const int row0 = tile * NW * 16;                    // first lane-side row of this workgroup
     const int c4 = lane;                                // this lane's 16-B chunk of a row
@@ -601,91 +727,291 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
     park(O0, partial ? 1.0f / c0 : 1.0f / (l * c0));
     if (NV == 1) {
         float* dst = a.part_o + ((size_t)b * a.splits + split) * N * D;
-        for (int rr = wave; rr < 16 * NW; rr += NW) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int rr = wave + NW * k;
             const int gn = row0 + rr;
             if (gn < N && 4 * c4 < D) *reinterpret_cast<f4*>(dst + (size_t)gn * D + 4 * c4) = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
         }
     } else {
-        const float* tx = a.text + (size_t)b * N * D;
         float* oo = a.out + (size_t)b * N * 4 * D;
         float* bo = a.bsave + (size_t)b * N * D;
-        for (int rr = wave; rr < 16 * NW; rr += NW) {
-            const int gn = row0 + rr;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int rr = wave + NW * k, gn = row0 + rr;
             if (gn < N && 4 * c4 < D) {
-                const f4 t = *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * c4);
                 const f4 av = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
                 float* o = oo + (size_t)gn * 4 * D + 4 * c4;
                 *reinterpret_cast<f4*>(o + D) = av;
-                *reinterpret_cast<f4*>(o + 2 * D) = t * av;
+                *reinterpret_cast<f4*>(o + 2 * D) = trow[k] * av;
             }
         }
         park(O1, 1.0f / (l * c1));
-        for (int rr = wave; rr < 16 * NW; rr += NW) {
-            const int gn = row0 + rr;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int rr = wave + NW * k, gn = row0 + rr;
             if (gn < N && 4 * c4 < D) {
-                const f4 t = *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * c4);
                 const f4 bv = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
-                *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 3 * D + 4 * c4) = t * bv;
+                *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 3 * D + 4 * c4) = trow[k] * bv;
                 *reinterpret_cast<f4*>(bo + (size_t)gn * D + 4 * c4) = bv;
             }
         }
     }
 }
 
+template <bool DBG>
 __global__ __launch_bounds__(NTHR) void att_col_kernel(const AttFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    att_fwd_body<1>(a, smem);
+    att_fwd_body<1, DBG>(a, smem);
 }
+template <bool DBG>
 __global__ __launch_bounds__(NTHR) void att_row_kernel(const AttFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    att_fwd_body<2>(a, smem);
+    att_fwd_body<2, DBG>(a, smem);
+}
+
+// Row pass with TWO waves per SIMD (8 waves per workgroup): waves w and w+4 own the same 16 text rows and split the
+// two value products between them -- role 0 accumulates a = P1.mod, role 1 accumulates b = P1.q -- so each wave needs
+// one accumulator set (<= 256 registers) and the pair hides each other's LDS / softmax / barrier latencies; both compute
+// S and the online softmax of the panel (42 of the 81 MFMAs a wave issues per panel are redundant: the price).
+template <bool DBG>
+__global__ __launch_bounds__(2 * NTHR) void att_row8_kernel(const AttFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dbg = DBG ? a.dbg : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int role = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
+    const int r = lane & 15, g = lane >> 4;
+    const int N = a.N, R = a.R, D = a.D, Rp = pad32(R);
+    int tile, split, b;
+    decode_block((N + 16 * NW - 1) / (16 * NW), 1, a.B, tile, split, b);
+    const int n = (tile * NW + w4) * 16 + r;
+    const int rps = a.rows_per_split;   // = pad32(R): one split
+
+    const bool sep_s = a.mS != a.mV0;
+    const int npan = 2 + (sep_s ? 1 : 0);
+    const int stage_b = npan * PANEL_B;
+    const bool db = a.nstage == 2;
+    float* mterm_all = reinterpret_cast<float*>(smem + a.nstage * stage_b);
+    int* mcode_all = reinterpret_cast<int*>(mterm_all + rps);
+    float* sS_all = mterm_all + 2 * rps;
+    float* sV_all[2] = {mterm_all + 3 * rps, mterm_all + 4 * rps};
+    float* red = mterm_all + 5 * rps;
+
+    const size_t szR = planes_sample_bytes(R);
+    const char* mS_b = a.mS + (size_t)b * szR;
+    const char* mV0_b = a.mV0 + (size_t)b * szR;
+    const char* mV1_b = a.mV1 + (size_t)b * szR;
+
+    side_t side;
+    float inv_n;
+    load_side_f32(side, inv_n, a.side_src + (size_t)b * N * D, n, N, D, g, a.w_tm);
+    const float nterm = n < N ? a.n_term[(size_t)b * N + n] : 0.f;
+    const tr_off tr = make_tr_off(lane);
+
+    // first quarter of `out` = verbatim copy of text (attention.py:52): 8 rows per wave, loads batched, stores at once
+    {
+        const float* tx = a.text + (size_t)b * N * D;
+        float* oo = a.out + (size_t)b * N * 4 * D;
+        const bool cin = 4 * lane < D;
+        f4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int gn = tile * NW * 16 + wave + 8 * k;
+            t[k] = (gn < N && cin) ? *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * lane) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int gn = tile * NW * 16 + wave + 8 * k;
+            if (gn < N && cin) *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 4 * lane) = t[k];
+        }
+    }
+    acc_t O;
+    zero_acc(O);
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int row_end = (dbg & 16) ? 0 : R;
+    float im[2] = {0.f, 0.f};
+    for (int i = tid; i < rps; i += 2 * NTHR) {
+        const bool in = i < R;
+        mterm_all[i] = in ? a.m_term[(size_t)b * R + i] : 0.f;
+        mcode_all[i] = mask_code(in, a.m_mask, a.m_len, b, R, i);
+        sS_all[i] = in ? a.iS[(size_t)b * Rp + i] : 0.f;
+        const float v0 = in ? a.iV0[(size_t)b * Rp + i] : 0.f, v1 = in ? a.iV1[(size_t)b * Rp + i] : 0.f;
+        sV_all[0][i] = v0;
+        sV_all[1][i] = v1;
+        im[0] = fmaxf(im[0], v0);
+        im[1] = fmaxf(im[1], v1);
+    }
+    {   // workgroup maximum over the 8 waves
+#pragma unroll
+        for (int k = 0; k < 2; ++k) im[k] = wave_allmax(im[k]);
+        __syncthreads();
+        if (lane == 0) { red[wave * 2] = im[0]; red[wave * 2 + 1] = im[1]; }
+        __syncthreads();
+        im[0] = im[1] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { im[0] = fmaxf(im[0], red[w * 2]); im[1] = fmaxf(im[1], red[w * 2 + 1]); }
+    }
+    const float cv[2] = {cmap(im[0]), cmap(im[1])};
+    for (int i = tid; i < rps; i += 2 * NTHR) {
+        sV_all[0][i] *= cv[0];
+        sV_all[1][i] *= cv[1];
+    }
+    const float c_mine = role ? cv[1] : cv[0];
+    const float* sV_mine = role ? sV_all[1] : sV_all[0];
+
+    // staging: waves 0-3 bring the mod panel, waves 4-7 the q panel (7 pieces each); a separate S panel: all 8 waves
+    auto stage = [&](char* base, int p0) {
+        if ((dbg & 1) && p0 != 0) return;
+        stage_panel(base + role * PANEL_B, role ? mV1_b : mV0_b, p0, tid & (NTHR - 1));
+        if (sep_s) {
+            const char* src = mS_b + (size_t)(p0 >> 4) * PRB + lane * 16;
+            char* dst = base + 2 * PANEL_B;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int piece = wave + 8 * k;
+                if (piece < PANEL_B / 1024)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                                     (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+            }
+        }
+    };
+    int cur = 0;
+    if (db) {
+        if (0 < row_end) stage(smem, 0);
+        __syncthreads();
+    }
+    for (int p0 = 0; p0 < row_end; p0 += PR) {
+        char* base = smem + (db ? cur * stage_b : 0);
+        if (db) {
+            if (p0 + PR < row_end) stage(smem + (cur ^ 1) * stage_b, p0 + PR);
+        } else {
+            __syncthreads();
+            stage(base, p0);
+            __syncthreads();
+        }
+        const char* pS = sep_s ? base + 2 * PANEL_B : base;
+        const char* pV = base + role * PANEL_B;
+
+        f4 v[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+        if (!(dbg & 2)) sprod2(pS, r, g, side, v);
+        float bmax = -INFINITY;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ml = p0 + mb * 16 + 4 * g + e;
+                const int code = mcode_all[ml];
+                const float x = v[mb][e] * (sS_all[ml] * inv_n) + mterm_all[ml] + nterm;
+                v[mb][e] = code == 2 ? x : (code == 1 ? NEG : -INFINITY);
+                bmax = fmaxf(bmax, v[mb][e]);
+            }
+        bmax = kg_allmax(bmax);
+        const float m_new = fmaxf(m_run, bmax);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+        f4 w[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pv = __expf(v[mb][e] - m_new);
+                psum += pv;
+                w[mb][e] = pv * sV_mine[p0 + mb * 16 + 4 * g + e];
+            }
+        l_run = l_run * alpha + psum;
+        if (__any(alpha != 1.0f)) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) O[dt] *= alpha;
+        }
+        m_run = m_new;
+        half8 W0, W1;
+        split_w(w[0], w[1], W0, W1);
+        if (!(dbg & 4)) pvprod(pV, tr, W0, W1, O);
+        if (db) {
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // ---- epilogue: every wave parks its tile (role 0: a, role 1: b) in its role's LDS region, then the workgroup writes
+    // whole rows: role 0 the a and text*a quarters, role 1 the text*b quarter and the saved b
+    const float l = kg_allsum(l_run);
+    if (role == 0 && n < N && g == 0) {
+        float* st = a.stat + ((size_t)b * N + n) * 2;
+        st[0] = m_run;
+        st[1] = l;
+    }
+    if (dbg & 8) return;
+    float* et = reinterpret_cast<float*>(smem) + role * (16 * NW * LDP);
+    const int row0 = tile * NW * 16;
+    const int c4 = lane;
+    const float* tx = a.text + (size_t)b * N * D;
+    f4 trow[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int gn = row0 + w4 + NW * k;
+        trow[k] = (gn < N && 4 * c4 < D) ? *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * c4) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    {
+        const float scale = 1.0f / (l * c_mine);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(et + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
+    }
+    __syncthreads();
+    float* oo = a.out + (size_t)b * N * 4 * D;
+    float* bo = a.bsave + (size_t)b * N * D;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int rr = w4 + NW * k, gn = row0 + rr;
+        if (gn < N && 4 * c4 < D) {
+            const f4 ov = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
+            float* o = oo + (size_t)gn * 4 * D + 4 * c4;
+            if (role == 0) {
+                *reinterpret_cast<f4*>(o + D) = ov;
+                *reinterpret_cast<f4*>(o + 2 * D) = trow[k] * ov;
+            } else {
+                *reinterpret_cast<f4*>(o + 3 * D) = trow[k] * ov;
+                *reinterpret_cast<f4*>(bo + (size_t)gn * D + 4 * c4) = ov;
+            }
+        }
+    }
 }
 
 // merge the per-split partial column softmaxes, q = sum_p O_p e^{m_p-m} / sum_p l_p e^{m_p-m}, and write q as planes
-// (it is only ever a streamed / lane-side MFMA operand): one half wave per modality row, lane = octet
+// (it is only ever a streamed / lane-side MFMA operand): one wave per modality row, lane = float4 chunk
 __global__ __launch_bounds__(256) void att_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_stat,
                                                           char* __restrict__ q_planes, float* __restrict__ q_inv, float* __restrict__ stat,
                                                           int B, int N, int D, int splits) {
     const int Np = pad32(N);
-    const long rowi = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const long rowi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rowi >= (long)B * Np) return;
-    const int b = rowi / Np, n = rowi - (long)b * Np, oct = threadIdx.x & 31;
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float amax = 0.f;
+    const int b = rowi / Np, n = rowi - (long)b * Np, c = threadIdx.x & 63, d = 4 * c;
+    f4 v = f4{0.f, 0.f, 0.f, 0.f};
     if (n < N) {
         float m = -INFINITY;
         for (int p = 0; p < splits; ++p) m = fmaxf(m, part_stat[(((size_t)b * splits + p) * N + n) * 2]);
         float l = 0.f;
+#pragma unroll 4
         for (int p = 0; p < splits; ++p) {
             const size_t o = ((size_t)b * splits + p) * N + n;
             const float sc = __expf(part_stat[o * 2] - m);
             l += part_stat[o * 2 + 1] * sc;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int d = 8 * oct + 4 * h;
-                if (d < D) {
-                    const f4 x = *reinterpret_cast<const f4*>(part_o + o * D + d) * sc;
-                    v[4 * h] += x.x; v[4 * h + 1] += x.y; v[4 * h + 2] += x.z; v[4 * h + 3] += x.w;
-                }
-            }
+            if (d < D) v += *reinterpret_cast<const f4*>(part_o + o * D + d) * sc;
         }
-        const float il = 1.0f / l;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            v[j] *= il;
-            amax = fmaxf(amax, fabsf(v[j]));
-        }
-        if (oct == 0) {
+        v = v * (1.0f / l);
+        if (c == 0) {
             stat[((size_t)b * N + n) * 2] = m;
             stat[((size_t)b * N + n) * 2 + 1] = l;
         }
     }
-    amax = half_allmax(amax);
-    store_split_row(q_planes + (size_t)b * planes_sample_bytes(N), q_inv + (size_t)b * Np + n, n, oct, v, amax);
+    const float amax = wave_allmax(f4amax(v));
+    store_split_row(q_planes + (size_t)b * planes_sample_bytes(N), q_inv + (size_t)b * Np + n, n, c, v, amax);
 }
 
 // ------------------------------------------------------------------------------------------ backward
-// prologue over text rows (one half wave per row, lane = octet):
+// prologue over text rows (one wave per row, lane = float4 chunk: every access a coalesced 16 B per lane):
 //   da = g1 + g2*text ; db = g3*text  (written as planes: they are only ever MFMA operands)
 //   delta1 = da.a + db.b ; d_text = g0 + g2*a + g3*b      (a = out[:, D:2D], b = bsave)
 __global__ __launch_bounds__(256) void att_bwd_pre_kernel(const float* __restrict__ d_out, const float* __restrict__ out,
@@ -700,40 +1026,30 @@ __global__ __launch_bounds__(256) void att_bwd_pre_kernel(const float* __restric
         if (threadIdx.x == 0) d_bias[0] = 0.f;
     }
     const int Tp = pad32(T);
-    const long rowi = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const long rowi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rowi >= (long)B * Tp) return;
-    const int b = rowi / Tp, row = rowi - (long)b * Tp, oct = threadIdx.x & 31;
-    float va[8], vb[8];
-    float acc = 0.f, amax_a = 0.f, amax_b = 0.f;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int d = 8 * oct + 4 * h;
-        f4 xa = f4{0.f, 0.f, 0.f, 0.f}, xb = xa;
-        if (row < T && d < D) {
-            const size_t rr = (size_t)b * T + row;
-            const float* g = d_out + rr * 4 * D;
-            const f4 g0 = *reinterpret_cast<const f4*>(g + d), g1 = *reinterpret_cast<const f4*>(g + D + d);
-            const f4 g2 = *reinterpret_cast<const f4*>(g + 2 * D + d), g3 = *reinterpret_cast<const f4*>(g + 3 * D + d);
-            const f4 av = *reinterpret_cast<const f4*>(out + rr * 4 * D + D + d);
-            const f4 t = *reinterpret_cast<const f4*>(text + rr * D + d);
-            const f4 bv = *reinterpret_cast<const f4*>(bsave + rr * D + d);
-            xa = g1 + g2 * t;
-            xb = g3 * t;
-            *reinterpret_cast<f4*>(d_text + rr * D + d) = g0 + g2 * av + g3 * bv;
-            acc += f4sum(xa * av + xb * bv);
-        }
-        va[4 * h] = xa.x; va[4 * h + 1] = xa.y; va[4 * h + 2] = xa.z; va[4 * h + 3] = xa.w;
-        vb[4 * h] = xb.x; vb[4 * h + 1] = xb.y; vb[4 * h + 2] = xb.z; vb[4 * h + 3] = xb.w;
-        amax_a = fmaxf(amax_a, f4amax(xa));
-        amax_b = fmaxf(amax_b, f4amax(xb));
+    const int b = rowi / Tp, row = rowi - (long)b * Tp, c = threadIdx.x & 63, d = 4 * c;
+    f4 xa = f4{0.f, 0.f, 0.f, 0.f}, xb = xa;
+    float acc = 0.f;
+    if (row < T && d < D) {
+        const size_t rr = (size_t)b * T + row;
+        const float* g = d_out + rr * 4 * D;
+        const f4 g0 = *reinterpret_cast<const f4*>(g + d), g1 = *reinterpret_cast<const f4*>(g + D + d);
+        const f4 g2 = *reinterpret_cast<const f4*>(g + 2 * D + d), g3 = *reinterpret_cast<const f4*>(g + 3 * D + d);
+        const f4 av = *reinterpret_cast<const f4*>(out + rr * 4 * D + D + d);
+        const f4 t = *reinterpret_cast<const f4*>(text + rr * D + d);
+        const f4 bv = *reinterpret_cast<const f4*>(bsave + rr * D + d);
+        xa = g1 + g2 * t;
+        xb = g3 * t;
+        *reinterpret_cast<f4*>(d_text + rr * D + d) = g0 + g2 * av + g3 * bv;
+        acc = f4sum(xa * av + xb * bv);
     }
-    amax_a = half_allmax(amax_a);
-    amax_b = half_allmax(amax_b);
-    acc = half_allsum(acc);
-    if (oct == 0 && row < T) delta1[(size_t)b * T + row] = acc;
+    const float amax_a = wave_allmax(f4amax(xa)), amax_b = wave_allmax(f4amax(xb));
+    acc = wave_allsum(acc);
+    if (c == 0 && row < T) delta1[(size_t)b * T + row] = acc;
     const size_t sz = planes_sample_bytes(T);
-    store_split_row(da_planes + (size_t)b * sz, da_inv + (size_t)b * Tp + row, row, oct, va, amax_a);
-    store_split_row(db_planes + (size_t)b * sz, db_inv + (size_t)b * Tp + row, row, oct, vb, amax_b);
+    store_split_row(da_planes + (size_t)b * sz, da_inv + (size_t)b * Tp + row, row, c, xa, amax_a);
+    store_split_row(db_planes + (size_t)b * sz, db_inv + (size_t)b * Tp + row, row, c, xb, amax_b);
 }
 
 struct AttBwdArgs {
@@ -755,6 +1071,8 @@ struct AttBwdArgs {
     float *p_dq, *p_dmc, *p_dmd1, *p_dmd2, *p_dc1, *p_dc2;
     int B, T, M, D, splits, rows_per_split;
     int fold;                                        // 1: no dropped copies, d_*_d folded into d_*
+    int nstage_j2;                                   // LDS stages of the second j sweep (1 or 2)
+    int dbg;
 };
 
 __device__ __forceinline__ void store_acc(float* dst_row, const acc_t& v, float scale, int D, int g) {
@@ -768,8 +1086,10 @@ __device__ __forceinline__ void store_acc(float* dst_row, const acc_t& v, float 
 // j-side sweep 1 (lane side = modality rows j, streams a slice of the text rows i):
 //   dq_j += sum_i P1_ij db_i ; dmodc_j += sum_i P1_ij da_i ; dS1 = P1 (dP1 - delta1_i) mask_j
 //   dmodd_j += sum_i dS1_ij text_d_i (scaled by w_tm later) ; dc_j += sum_i dS1_ij
+template <bool DBG>
 __global__ __launch_bounds__(NTHR) void att_bwd_j1_kernel(const AttBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dbg = DBG ? a.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int T = a.T, M = a.M, D = a.D, Tp = pad32(T);
@@ -802,11 +1122,11 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j1_kernel(const AttBwdArgs a) {
     const float mmf = mm ? 1.f : 0.f;
     const tr_off tr = make_tr_off(lane);
 
-    const int row_begin = split * rps, row_end = min(T, row_begin + rps);
+    const int row_begin = split * rps, row_end = (dbg & 16) ? row_begin : min(T, row_begin + rps);
     float im[3] = {0.f, 0.f, 0.f};
     for (int i = tid; i < rps; i += NTHR) {
         const int t = row_begin + i;
-        const bool in = t < row_end;
+        const bool in = t < min(T, row_begin + rps);
         const size_t bt = (size_t)b * T + t;
         rt_all[i] = in ? a.rterm[bt] : 0.f;
         rmax_all[i] = in ? a.row_stat[bt * 2] : INFINITY;   // exp(x - inf) = 0 beyond the slice
@@ -832,17 +1152,21 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j1_kernel(const AttBwdArgs a) {
     const char* db_b = a.pDb + (size_t)b * szT;
     for (int p0 = row_begin; p0 < row_end; p0 += PR) {
         __syncthreads();
-        stage_panel(pTd, td_b, p0, tid);
-        stage_panel(pDa, da_b, p0, tid);
-        stage_panel(pDb, db_b, p0, tid);
+        if (!(dbg & 1) || p0 == row_begin) {
+            stage_panel(pTd, td_b, p0, tid);
+            stage_panel(pDa, da_b, p0, tid);
+            stage_panel(pDb, db_b, p0, tid);
+        }
         __syncthreads();
         const int i0 = p0 - row_begin;
         f4 s[2], dpa[2], dpb[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) s[q] = dpa[q] = dpb[q] = f4{0.f, 0.f, 0.f, 0.f};
-        sprod2(pTd, r, g, sideS, s);
-        sprod2(pDa, r, g, sideM, dpa);
-        sprod2(pDb, r, g, sideQ, dpb);
+        if (!(dbg & 2)) {
+            sprod2<false>(pTd, r, g, sideS, s);
+            sprod2<false>(pDa, r, g, sideM, dpa);
+            sprod2<false>(pDb, r, g, sideQ, dpb);
+        }
         f4 wq[2], wc[2], wd[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -860,14 +1184,14 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j1_kernel(const AttBwdArgs a) {
             }
         half8 W0, W1;
         split_w(wq[0], wq[1], W0, W1);
-        pvprod(pDb, tr, W0, W1, dq);
+        if (!(dbg & 4)) pvprod<1>(pDb, tr, W0, W1, dq);
         split_w(wc[0], wc[1], W0, W1);
-        pvprod(pDa, tr, W0, W1, dmc);
+        if (!(dbg & 4)) pvprod<1>(pDa, tr, W0, W1, dmc);
         split_w(wd[0], wd[1], W0, W1);
-        pvprod(pTd, tr, W0, W1, dmd);
+        if (!(dbg & 4)) pvprod<1>(pTd, tr, W0, W1, dmd);
     }
     dc = kg_allsum(dc);
-    if (!nin) return;
+    if (!nin || (dbg & 8)) return;
     const size_t prow = ((size_t)b * a.splits + split) * M + n;
     store_acc(a.p_dq + prow * D, dq, 1.0f / cDb, D, g);
     store_acc(a.p_dmc + prow * D, dmc, 1.0f / cDa, D, g);
@@ -878,8 +1202,10 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j1_kernel(const AttBwdArgs a) {
 // j-side sweep 2 (needs the complete dq = sum of the sweep-1 partials):
 //   dS2 = P2 (dP2 - delta2_j) mask_i, dP2_ij = text_i . dq_j ; dmodd_j += sum_i dS2_ij text_d_i ; dc_j += sum_i dS2_ij
 //   split 0 also publishes dq_j (as planes) and delta2_j = q_j . dq_j for the i-side pass
+template <bool DBG>
 __global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dbg = DBG ? a.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int T = a.T, M = a.M, D = a.D, Tp = pad32(T), Mp = pad32(M);
@@ -889,9 +1215,9 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
     const int rps = a.rows_per_split;
 
     const bool sep = a.pTd != a.pT;
-    char* pT = smem;
-    char* pTd = sep ? smem + PANEL_B : pT;
-    float* rt_all = reinterpret_cast<float*>(smem + 2 * PANEL_B);
+    const int stage_b = (sep ? 2 : 1) * PANEL_B;
+    const bool db = a.nstage_j2 == 2;
+    float* rt_all = reinterpret_cast<float*>(smem + a.nstage_j2 * stage_b);
     int* code_all = reinterpret_cast<int*>(rt_all + rps);   // 0 beyond slice, 1 masked, 2 live
     float* sT_all = rt_all + 2 * rps;
     float* sTd_all = rt_all + 3 * rps;
@@ -941,11 +1267,11 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
     const float cinv = nin ? 1.0f / a.col_stat[((size_t)b * M + n) * 2 + 1] : 0.f;
     const tr_off tr = make_tr_off(lane);
 
-    const int row_begin = split * rps, row_end = min(T, row_begin + rps);
+    const int row_begin = split * rps, row_end = (dbg & 16) ? row_begin : min(T, row_begin + rps);
     float im[2] = {0.f, 0.f};
     for (int i = tid; i < rps; i += NTHR) {
         const int t = row_begin + i;
-        const bool in = t < row_end;
+        const bool in = t < min(T, row_begin + rps);
         rt_all[i] = in ? a.rterm[(size_t)b * T + t] : 0.f;
         code_all[i] = mask_code(in, a.text_mask, a.text_len, b, T, t);
         const float v0 = in ? a.iT[(size_t)b * Tp + t] : 0.f, v1 = in ? a.iTd[(size_t)b * Tp + t] : 0.f;
@@ -961,17 +1287,35 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
     float dc = 0.f;
     const char* td_b = a.pTd + (size_t)b * szT;
     const char* t_b = a.pT + (size_t)b * szT;
+    auto stage = [&](char* base, int p0) {
+        if ((dbg & 1) && p0 != row_begin) return;
+        stage_panel(base, t_b, p0, tid);
+        if (sep) stage_panel(base + PANEL_B, td_b, p0, tid);
+    };
+    int cur = 0;
+    if (db) {
+        if (row_begin < row_end) stage(smem, row_begin);
+        __syncthreads();
+    }
     for (int p0 = row_begin; p0 < row_end; p0 += PR) {
-        __syncthreads();
-        stage_panel(pT, t_b, p0, tid);
-        if (sep) stage_panel(pTd, td_b, p0, tid);
-        __syncthreads();
+        char* base = smem + (db ? cur * stage_b : 0);
+        if (db) {
+            if (p0 + PR < row_end) stage(smem + (cur ^ 1) * stage_b, p0 + PR);
+        } else {
+            __syncthreads();
+            stage(base, p0);
+            __syncthreads();
+        }
+        const char* pT = base;
+        const char* pTd = sep ? base + PANEL_B : pT;
         const int i0 = p0 - row_begin;
         f4 s[2], dp[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) s[q] = dp[q] = f4{0.f, 0.f, 0.f, 0.f};
-        sprod2(pTd, r, g, sideS, s);
-        sprod2(pT, r, g, sideDq, dp);
+        if (!(dbg & 2)) {
+            sprod2(pTd, r, g, sideS, s);
+            sprod2(pT, r, g, sideDq, dp);
+        }
         f4 wd[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -987,10 +1331,14 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
             }
         half8 W0, W1;
         split_w(wd[0], wd[1], W0, W1);
-        pvprod(pTd, tr, W0, W1, dmd);
+        if (!(dbg & 4)) pvprod(pTd, tr, W0, W1, dmd);
+        if (db) {
+            __syncthreads();
+            cur ^= 1;
+        }
     }
     dc = kg_allsum(dc);
-    if (!nin) return;
+    if (!nin || (dbg & 8)) return;
     const size_t prow = ((size_t)b * a.splits + split) * M + n;
     store_acc(a.p_dmd2 + prow * D, dmd, 1.0f / cS, D, g);
     if (g == 0) a.p_dc2[prow] = dc;
@@ -1000,7 +1348,7 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
 //   d_mod_d_j = dc_j w_m + w_tm * dmodd_j ;  d_mod_j = dmodc_j (+ d_mod_d_j when folded)
 // and accumulates d_w_m += sum_j dc_j mod_d[j,:]: registers over the wave's rows, LDS across the 4 waves, then ONE
 // atomic per feature and workgroup with consecutive lanes on consecutive addresses.
-constexpr int JF_ROWS = 4;
+template <int JF_ROWS>
 __global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a, int B) {
     __shared__ float wred[4][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1008,37 +1356,45 @@ __global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a, i
     const int M = a.M, D = a.D, S = a.splits;
     const int rows = B * M;
     const int d = lane * 4;
-    f4 wacc = f4{0.f, 0.f, 0.f, 0.f};
     const bool din = d < D;
     const f4 wm = din ? *reinterpret_cast<const f4*>(a.w_m + d) : f4{0.f, 0.f, 0.f, 0.f};
     const f4 wtm = din ? *reinterpret_cast<const f4*>(a.w_tm + d) : f4{0.f, 0.f, 0.f, 0.f};
+    float dc[JF_ROWS];
+    f4 c[JF_ROWS], dd[JF_ROWS];
+    size_t base[JF_ROWS];
+#pragma unroll
+    for (int rr = 0; rr < JF_ROWS; ++rr) {
+        const int row = min(chunk * JF_ROWS + rr, rows - 1);
+        const int b = row / M, n = row % M;
+        base[rr] = (size_t)b * S * M + n;
+        dc[rr] = 0.f;
+        c[rr] = dd[rr] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int p = 0; p < S; ++p) {   // the 8 rows' loads of one split are independent: all in flight together
+#pragma unroll
+        for (int rr = 0; rr < JF_ROWS; ++rr) {
+            const size_t prow = base[rr] + (size_t)p * M;
+            dc[rr] += a.p_dc1[prow] + a.p_dc2[prow];
+            if (din) {
+                c[rr] += *reinterpret_cast<const f4*>(a.p_dmc + prow * D + d);
+                dd[rr] += *reinterpret_cast<const f4*>(a.p_dmd1 + prow * D + d);
+                dd[rr] += *reinterpret_cast<const f4*>(a.p_dmd2 + prow * D + d);
+            }
+        }
+    }
+    f4 wacc = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rr = 0; rr < JF_ROWS; ++rr) {
         const int row = chunk * JF_ROWS + rr;
-        if (row < rows) {
-            const int b = row / M, n = row % M;
-            float dc = 0.f;
-            f4 c = f4{0.f, 0.f, 0.f, 0.f}, dd = c;
-#pragma unroll 4
-            for (int p = 0; p < S; ++p) {
-                const size_t prow = ((size_t)b * S + p) * M + n;
-                dc += a.p_dc1[prow] + a.p_dc2[prow];
-                if (din) {
-                    c += *reinterpret_cast<const f4*>(a.p_dmc + prow * D + d);
-                    dd += *reinterpret_cast<const f4*>(a.p_dmd1 + prow * D + d);
-                    dd += *reinterpret_cast<const f4*>(a.p_dmd2 + prow * D + d);
-                }
+        if (row < rows && din) {
+            const f4 gd = wm * dc[rr] + wtm * dd[rr];
+            if (a.fold) {
+                *reinterpret_cast<f4*>(a.d_mod + (size_t)row * D + d) = c[rr] + gd;
+            } else {
+                *reinterpret_cast<f4*>(a.d_mod + (size_t)row * D + d) = c[rr];
+                *reinterpret_cast<f4*>(a.d_mod_d + (size_t)row * D + d) = gd;
             }
-            if (din) {
-                const f4 gd = wm * dc + wtm * dd;
-                if (a.fold) {
-                    *reinterpret_cast<f4*>(a.d_mod + (size_t)row * D + d) = c + gd;
-                } else {
-                    *reinterpret_cast<f4*>(a.d_mod + (size_t)row * D + d) = c;
-                    *reinterpret_cast<f4*>(a.d_mod_d + (size_t)row * D + d) = gd;
-                }
-                wacc += *reinterpret_cast<const f4*>(a.mod_d + (size_t)row * D + d) * dc;
-            }
+            wacc += *reinterpret_cast<const f4*>(a.mod_d + (size_t)row * D + d) * dc[rr];
         }
     }
     *reinterpret_cast<f4*>(&wred[wave][d]) = wacc;
@@ -1052,8 +1408,10 @@ __global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a, i
 //   d_text_i += sum_j P2_ij dq_j ; dX_i = sum_j dS_ij mod_d_j ; dr_i = sum_j dS_ij
 //   d_text_d_i = dr_i w_t + w_tm * dX_i ; d_w_t += dr_i text_d_i ; d_w_tm += dX_i * text_d_i ; d_bias += dr_i
 constexpr int PI_STRIDE = 2 * DT * 16 + 16;  // per-wave partial: [d_w_t 208 | d_w_tm 208 | d_bias 1 ...]
+template <bool DBG>
 __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dbg = DBG ? a.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int T = a.T, M = a.M, D = a.D, Mp = pad32(M);
@@ -1119,20 +1477,25 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
     const char* md_b = a.pMd + (size_t)b * szM;
     const char* q_b = a.pQ + (size_t)b * szM;
     const char* dq_b = a.pDq + (size_t)b * szM;
-    for (int p0 = 0; p0 < M; p0 += PR) {
+    const int Mloop = (dbg & 16) ? 0 : M;
+    for (int p0 = 0; p0 < Mloop; p0 += PR) {
         __syncthreads();
-        stage_panel(pM, m_b, p0, tid);
-        stage_panel(pQ, q_b, p0, tid);
-        stage_panel(pDq, dq_b, p0, tid);
-        if (sep) stage_panel(pMd, md_b, p0, tid);
+        if (!(dbg & 1) || p0 == 0) {
+            stage_panel(pM, m_b, p0, tid);
+            stage_panel(pQ, q_b, p0, tid);
+            stage_panel(pDq, dq_b, p0, tid);
+            if (sep) stage_panel(pMd, md_b, p0, tid);
+        }
         __syncthreads();
         f4 s[2], dpa[2], dpb[2], dp2[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) s[q] = dpa[q] = dpb[q] = dp2[q] = f4{0.f, 0.f, 0.f, 0.f};
-        sprod2(pMd, r, g, sideS, s);
-        sprod2(pM, r, g, sideDa, dpa);
-        sprod2(pQ, r, g, sideDb, dpb);
-        sprod2(pDq, r, g, sideT, dp2);
+        if (!(dbg & 2)) {
+            sprod2<false>(pMd, r, g, sideS, s);
+            sprod2<false>(pM, r, g, sideDa, dpa);
+            sprod2<false>(pQ, r, g, sideDb, dpb);
+            sprod2<false>(pDq, r, g, sideT, dp2);
+        }
         f4 wt[2], wx[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -1152,11 +1515,12 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
             }
         half8 W0, W1;
         split_w(wt[0], wt[1], W0, W1);
-        pvprod(pDq, tr, W0, W1, dtx);
+        if (!(dbg & 4)) pvprod<1>(pDq, tr, W0, W1, dtx);
         split_w(wx[0], wx[1], W0, W1);
-        pvprod(pMd, tr, W0, W1, dX);
+        if (!(dbg & 4)) pvprod<1>(pMd, tr, W0, W1, dX);
     }
     dr = kg_allsum(dr);
+    if (dbg & 8) return;
     const float sdtx = 1.0f / cDq, sdX = 1.0f / cS;
     // ---- epilogue: gradients of this text row; parameter-gradient partials reduced over the workgroup in LDS
     __syncthreads();  // panels are dead: reuse their memory
@@ -1225,6 +1589,13 @@ static int pick_splits(int B, int N, int R, int slots = 256) {
     }
     return best;
 }
+// tuning aid (tools/att_bench.py): MMB_ATT_FSPLIT / MMB_ATT_BSPLIT force the number of splits of the column pass / of
+// the backward j sweeps (read at every call)
+static int forced_splits(const char* name, int R) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? (v < (R + PR - 1) / PR ? v : (R + PR - 1) / PR) : 0;
+}
 static int rows_per_split(int R, int splits) {
     int rp = (R + splits - 1) / splits;
     return (rp + PR - 1) / PR * PR;
@@ -1263,6 +1634,7 @@ struct BwdWs {
 static BwdWs bwd_layout(int B, int T, int M, int D) {
     BwdWs w{};
     w.splits = pick_splits(B, M, T);
+    if (int f = forced_splits("MMB_ATT_BSPLIT", T)) w.splits = f;
     const size_t S = w.splits;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
@@ -1284,7 +1656,10 @@ static BwdWs bwd_layout(int B, int T, int M, int D) {
     w.total = o;
     return w;
 }
-static int fwd_splits(int B, int T, int M) { return pick_splits(B, M, T, 512); }   // two workgroups per CU
+static int fwd_splits(int B, int T, int M) {
+    if (int f = forced_splits("MMB_ATT_FSPLIT", T)) return f;
+    return pick_splits(B, M, T, 512);   // two workgroups per CU
+}
 static size_t fwd_ws_bytes(int B, int T, int M, int D) {
     const size_t S = fwd_splits(B, T, M);
     return align256(S * B * M * D * 4) + align256(S * B * M * 2 * 4);
@@ -1307,6 +1682,8 @@ static int check_att_dims(int B, int T, int M, int D) {
                 MMB_ATT_GENERAL_MAX_D);
     return MMB_OK;
 }
+
+extern "C" void mmb_set_att_debug(int mask) { mmb::g_att_dbg = mask; }
 
 extern "C" size_t mmb_bidaf_saved_bytes(int B, int T, int M, int D, int has_drop) {
     if (B < 1 || T < 1 || M < 1 || D < 4) return 0;
@@ -1371,7 +1748,7 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
         p.n = k;
         const long rows = (long)B * pad32(T > M ? T : M);
         ProfScope ps_(MMB_K_ATT_RANK1, stream);
-        hipLaunchKernelGGL(att_prep_kernel, dim3((unsigned)((rows + 7) / 8), k), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(att_prep_kernel, dim3((unsigned)((rows + 3) / 4), k), dim3(256), 0, stream, p);
         MMB_HIP(hipGetLastError());
     }
     // ---- column pass: lane side = modality rows, streams text; partials merged (and q split into planes) by the combine
@@ -1385,17 +1762,22 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
         a.m_mask = text_len ? nullptr : text_mask; a.m_len = text_len; a.m_term = rterm; a.n_term = cterm;
         a.part_o = part_o; a.part_stat = part_stat;
         a.N = M; a.R = T; a.D = D; a.B = B; a.splits = splits; a.rows_per_split = rows_per_split(T, splits);
-        const size_t lds = (size_t)2 * PANEL_B + ((size_t)5 * a.rows_per_split + 16) * sizeof(float);
-        if (int rc = allow_lds(att_col_kernel, lds)) return rc;
+        a.dbg = att_dbg();
+        const size_t arr = ((size_t)5 * a.rows_per_split + 16) * sizeof(float), stage_b = (size_t)(drop ? 2 : 1) * PANEL_B;
+        a.nstage = (2 * stage_b + arr <= 80 * 1024 && a.rows_per_split > PR) ? 2 : 1;   // keep two workgroups per CU
+        size_t lds = a.nstage * stage_b + arr;
+        if (lds < (size_t)16 * NW * LDP * sizeof(float)) lds = (size_t)16 * NW * LDP * sizeof(float);   // epilogue staging tile
+        auto kern = a.dbg ? att_col_kernel<true> : att_col_kernel<false>;
+        if (int rc = allow_lds(kern, lds)) return rc;
         {
             ProfScope ps_(MMB_K_ATT_COL, stream);
-            hipLaunchKernelGGL(att_col_kernel, dim3(((M + 63) / 64) * splits * B), dim3(NTHR), lds, stream, a);
+            hipLaunchKernelGGL(kern, dim3(((M + 63) / 64) * splits * B), dim3(NTHR), lds, stream, a);
         }
         MMB_HIP(hipGetLastError());
         const long rows = (long)B * pad32(M);
         {
             ProfScope ps_(MMB_K_ATT_COMBINE, stream);
-            hipLaunchKernelGGL(att_combine_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, stream, part_o, part_stat, sv + L.pQ,
+            hipLaunchKernelGGL(att_combine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, part_o, part_stat, sv + L.pQ,
                                fp(L.iQ), col_stat, B, M, D, splits);
         }
         MMB_HIP(hipGetLastError());
@@ -1408,13 +1790,19 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
         a.m_mask = mod_len ? nullptr : mod_mask; a.m_len = mod_len; a.m_term = cterm; a.n_term = rterm; a.stat = row_stat;
         a.text = text; a.out = out; a.bsave = bsave;
         a.N = T; a.R = M; a.D = D; a.B = B; a.splits = 1; a.rows_per_split = rows_per_split(M, 1);
-        size_t lds = (size_t)3 * PANEL_B + ((size_t)5 * a.rows_per_split + 16) * sizeof(float);
+        a.dbg = att_dbg();
+        const size_t arr = ((size_t)5 * a.rows_per_split + 16) * sizeof(float), stage_b = (size_t)(drop ? 3 : 2) * PANEL_B;
+        a.nstage = (2 * stage_b + arr <= 160 * 1024 && a.rows_per_split > PR) ? 2 : 1;
+        size_t lds = a.nstage * stage_b + arr;
         const size_t epi = (size_t)16 * NW * LDP * sizeof(float);
         if (lds < epi) lds = epi;
-        if (int rc = allow_lds(att_row_kernel, lds)) return rc;
+        static const bool row8 = [] { const char* e = getenv("MMB_ATT_ROW8"); return !e || atoi(e) != 0; }();
+        if (row8 && lds < 2 * epi) lds = 2 * epi;   // the two roles' epilogue staging tiles
+        auto kern = row8 ? (a.dbg ? att_row8_kernel<true> : att_row8_kernel<false>) : (a.dbg ? att_row_kernel<true> : att_row_kernel<false>);
+        if (int rc = allow_lds(kern, lds)) return rc;
         {
             ProfScope ps_(MMB_K_ATT_ROW, stream);
-            hipLaunchKernelGGL(att_row_kernel, dim3(((T + 63) / 64) * B), dim3(NTHR), lds, stream, a);
+            hipLaunchKernelGGL(kern, dim3(((T + 63) / 64) * B), dim3(row8 ? 2 * NTHR : NTHR), lds, stream, a);
         }
         MMB_HIP(hipGetLastError());
     }
@@ -1479,42 +1867,57 @@ extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* 
     a.B = B; a.T = T; a.M = M; a.D = D; a.fold = drop_t ? 0 : 1;
     a.splits = L.splits;
     a.rows_per_split = rows_per_split(T, a.splits);
+    a.dbg = att_dbg();
 
     {
         const long rows = (long)B * pad32(T);
         ProfScope ps_(MMB_K_ATT_BWD_PRE, stream);
-        hipLaunchKernelGGL(att_bwd_pre_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, stream, d_out, out, text, bsave,
+        hipLaunchKernelGGL(att_bwd_pre_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, d_out, out, text, bsave,
                            ws + L.pDa, wf(L.iDa), ws + L.pDb, wf(L.iDb), wf(L.delta1), d_text, d_w_t, d_w_m, d_w_tm, d_bias, B, T, D);
     }
     MMB_HIP(hipGetLastError());
     const int tiles_m = (M + 63) / 64, tiles_t = (T + 63) / 64;
     {
         const size_t lds = (size_t)3 * PANEL_B + ((size_t)7 * a.rows_per_split + 16) * sizeof(float);
-        if (int rc = allow_lds(att_bwd_j1_kernel, lds)) return rc;
+        auto kern = a.dbg ? att_bwd_j1_kernel<true> : att_bwd_j1_kernel<false>;
+        if (int rc = allow_lds(kern, lds)) return rc;
         ProfScope ps_(MMB_K_ATT_BWD_J1, stream);
-        hipLaunchKernelGGL(att_bwd_j1_kernel, dim3(tiles_m * a.splits * B), dim3(NTHR), lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3(tiles_m * a.splits * B), dim3(NTHR), lds, stream, a);
     }
     MMB_HIP(hipGetLastError());
     {
-        const size_t lds = (size_t)2 * PANEL_B + ((size_t)4 * a.rows_per_split + 16) * sizeof(float);
-        if (int rc = allow_lds(att_bwd_j2_kernel, lds)) return rc;
+        const size_t arr = ((size_t)4 * a.rows_per_split + 16) * sizeof(float), stage_b = (size_t)(drop_t ? 2 : 1) * PANEL_B;
+        a.nstage_j2 = (2 * stage_b + arr <= 160 * 1024 && a.rows_per_split > PR) ? 2 : 1;
+        const size_t lds = a.nstage_j2 * stage_b + arr;
+        auto kern = a.dbg ? att_bwd_j2_kernel<true> : att_bwd_j2_kernel<false>;
+        if (int rc = allow_lds(kern, lds)) return rc;
         ProfScope ps_(MMB_K_ATT_BWD_J2, stream);
-        hipLaunchKernelGGL(att_bwd_j2_kernel, dim3(tiles_m * a.splits * B), dim3(NTHR), lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3(tiles_m * a.splits * B), dim3(NTHR), lds, stream, a);
     }
     MMB_HIP(hipGetLastError());
     {
-        const int chunks = (B * M + JF_ROWS - 1) / JF_ROWS;
+        // rows per wave: enough waves to fill the chip, few enough workgroups that the d_w_m atomics stay cheap
+        const int rows = B * M;
+        const int jf = rows >= 8192 ? 8 : rows >= 4096 ? 4 : rows >= 2048 ? 2 : 1;
+        const int chunks = (rows + jf - 1) / jf;
         ProfScope ps_(MMB_K_ATT_BWD_JFIN, stream);
-        hipLaunchKernelGGL(att_bwd_jfin_kernel, dim3((chunks + 3) / 4), dim3(256), 0, stream, a, B);
+        const dim3 grid((chunks + 3) / 4), block(256);
+        switch (jf) {
+            case 8: hipLaunchKernelGGL(att_bwd_jfin_kernel<8>, grid, block, 0, stream, a, B); break;
+            case 4: hipLaunchKernelGGL(att_bwd_jfin_kernel<4>, grid, block, 0, stream, a, B); break;
+            case 2: hipLaunchKernelGGL(att_bwd_jfin_kernel<2>, grid, block, 0, stream, a, B); break;
+            default: hipLaunchKernelGGL(att_bwd_jfin_kernel<1>, grid, block, 0, stream, a, B); break;
+        }
     }
     MMB_HIP(hipGetLastError());
     {
         size_t lds = (size_t)4 * PANEL_B + ((size_t)9 * pad32(M) + 16) * sizeof(float);
         const size_t epi = (size_t)NW * PI_STRIDE * sizeof(float);
         if (lds < epi) lds = epi;
-        if (int rc = allow_lds(att_bwd_i_kernel, lds)) return rc;
+        auto kern = a.dbg ? att_bwd_i_kernel<true> : att_bwd_i_kernel<false>;
+        if (int rc = allow_lds(kern, lds)) return rc;
         ProfScope ps_(MMB_K_ATT_BWD_I, stream);
-        hipLaunchKernelGGL(att_bwd_i_kernel, dim3(tiles_t * B), dim3(NTHR), lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3(tiles_t * B), dim3(NTHR), lds, stream, a);
     }
     MMB_HIP(hipGetLastError());
     return MMB_OK;

@@ -70,8 +70,20 @@ def pmc(d, cfg="cfg2"):
         print("\nHBM-side traffic per launch (bytes; FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE as is):")
         for k, v in traffic.items():
             print(f"- `{k[:80]}`: " + ", ".join(f"{n} {x:.4g}" for n, x in v.items()))
-        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        path = os.path.join(root, "profiles", "pmc_traffic.json")
         old = json.load(open(path)) if os.path.exists(path) else {}
+        # the file is stamped with a hash of the kernel sources it was measured on (bench.py quotes it only when that
+        # matches the sources it is running): measurements of other sources are dropped
+        import hashlib
+        h = hashlib.sha1()
+        d = os.path.join(root, "mmbidaf_amd", "csrc")
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".h")):
+                h.update(open(os.path.join(d, f), "rb").read())
+        stamp = h.hexdigest()[:16]
+        if old.get("source_hash") != stamp:
+            old = {"source_hash": stamp}
         parts = old.setdefault(cfg, {}).setdefault("_parts", {})
         for k, v in traffic.items():
             stem = re.sub(r"<.*$", "", k)            # bench.py looks kernels up by their symbol stem

@@ -25,6 +25,6 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_V
 python3 $R/tools/profile_summary.py pmc $R/gpurun_out/prof_pmc > $R/gpurun_out/${TAG}_pmc_SQ.md
 rm -rf $R/gpurun_out/prof_pmc
 echo "pmc SQ done"
-cp $R/profiles/pmc_traffic.json $R/gpurun_out/pmc_traffic.json
+cp $R/profiles/pmc_traffic.json $R/gpurun_out/${TAG}_pmc_traffic.json
 cd $R && python3 bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 tail -c 600 gpurun_out/${TAG}_bench_default.json
