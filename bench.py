@@ -63,12 +63,14 @@ def parse():
 
 def cpu_baseline(region, cfg, ragged):
     """The oracle's CPU path (torch's own packed nn.LSTM + bmm/softmax attention, i.e. what the reference's modules
-    execute -- SURVEY 8(d)) timed on the host cores of this box on the SAME workload (full batch), every core the
-    process may use, 1 warm-up step, then timed steps for about 20 s (at least 2)."""
+    execute -- SURVEY 8(d)) timed on the host cores of this box on the SAME workload (full batch), on the 16-core host
+    share of one GPU, 1 warm-up step, then timed steps for about 20 s (at least 2)."""
     from oracle import mmbidaf_oracle as O
     batch = synth.make_batch(cfg, rank=0, ragged=ragged, device="cpu")
     B_s, H = batch["B"], batch["H"]
-    threads = len(os.sched_getaffinity(0))
+    # the GPU box gives one GPU a 16-core share of the host (a cgroup quota: the affinity mask still lists every core
+    # of the machine, and one thread per listed core thrashes inside the quota)
+    threads = min(16, len(os.sched_getaffinity(0)))
     torch.set_num_threads(threads)
     ref = O.HotRegionCPU({k: v.detach().cpu() for k, v in region.state_dict().items()}, H)
     xs = [batch[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
