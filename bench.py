@@ -164,7 +164,8 @@ def main():
     params = list(region.parameters())
     # gradient exchange: SUM over ranks (the reference's loss is a sum over samples), bucketed in backward order and
     # launched from grad hooks so that it overlaps the rest of the backward pass
-    sync = ddp.FlatGradAllReduce(params, buckets=ddp.region_buckets(region), overlap=True)
+    from mmbidaf_amd import functional as MF
+    sync = ddp.FlatGradAllReduce(params, buckets=ddp.region_buckets(region), overlap=True, stream_fn=MF.side_stream)
     sync.broadcast_parameters()
     batch = synth.make_batch(a.config, rank=rank, ragged=a.ragged, device=dev, batch=B)
     xs = [batch[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]  # they come from trainable embeddings

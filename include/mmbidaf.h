@@ -186,6 +186,14 @@ typedef struct {
 
 int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* descs, int n, int device, void* stream);
 
+/* The same in two separately enqueued parts, so that a caller can put the part that is OFF the critical path of the
+ * backward pass on a second stream (event-ordered behind phase 1 of the same descs) where it runs under the recurrence
+ * of the next layer / encoder group -- which occupies only 2*B of the 256 CUs:
+ *   phase 1: BPTT recurrence (d_a) + input gradient d_x       phase 2: weight and bias gradients (d_w_ih, d_w_hh, d_b)
+ *   phase 3: both, in that order (= mmb_bilstm_layer_bwd).
+ * Problems that do not run on the operand planes (no ws, or I / H not multiples of 4) do all their work in phase 1. */
+int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* descs, int n, int phase, int device, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Decoder step.  Replaces MultimodalAttentionDecoder.forward (reference
  * layers/attention.py:145-186) for one decode step of the whole batch, and its autograd: one kernel launch per

@@ -67,6 +67,7 @@ SIGNATURES = {
     "mmb_bidaf_bwd": (c_i, [c_f] * 28 + [ctypes.c_size_t] + [c_i] * 5 + [c_f]),
     "mmb_bilstm_layer_fwd": (c_i, [ctypes.POINTER(LstmFwdDesc), c_i, c_i, c_f]),
     "mmb_bilstm_layer_bwd": (c_i, [ctypes.POINTER(LstmBwdDesc), c_i, c_i, c_f]),
+    "mmb_bilstm_layer_bwd_phase": (c_i, [ctypes.POINTER(LstmBwdDesc), c_i, c_i, c_i, c_f]),
     "mmb_gemm_f32": (c_i, [c_f] * 4 + [c_i] * 10 + [c_f]),
     "mmb_set_gemm_mode": (c_i, [c_i]),
     "mmb_bilstm_ws_bytes": (ctypes.c_size_t, [c_i] * 5),

@@ -496,7 +496,7 @@ static int gx_planes(const mmb_lstm_fwd_desc& p, hipStream_t stream) {
 }
 
 // weight and input gradients of one problem through the operand planes: 4 split passes + 2 GEMMs (+ unpack)
-static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_partials);
+static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_partials, int phase);
 
 template <typename ArgsT, typename K>
 static int launch_rec(K kernel, const ArgsT& a, int total_wgs, int H, hipStream_t stream, int kid) {
@@ -515,7 +515,8 @@ static int kq_for(int H) {
 }
 
 
-static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_partials) {
+// phase bit 1: input gradient d_x (on the critical path of the backward pass); bit 2: weight and bias gradients
+static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_partials, int phase) {
     const int H = p.H, I = p.I;
     const long BT = (long)p.B * p.T;
     const WsBwd L = ws_bwd_layout(BT, p.B, I, H);
@@ -534,7 +535,7 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
     int damax_n = 2 * p.B;
     if (np == 2) {
         MMB_REQUIRE(p.x_absmax, "mmb_bilstm_layer_bwd: desc.x_absmax (saved by the forward call) is needed by the fp16 operand planes");
-        if (!db_partials) {   // general-size recurrence: max |d_a| was not tracked by the recurrence, one reduction here
+        if (!db_partials && (phase & 2)) {   // general-size recurrence: max |d_a| was not tracked by the recurrence, one reduction here
             MMB_HIP(hipMemsetAsync(scal, 0, sizeof(float), stream));
             hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, stream, p.d_a, static_cast<const float*>(nullptr), BT * 8 * H, scal);
             MMB_HIP(hipGetLastError());
@@ -542,6 +543,7 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
             damax_n = 1;
         }
     }
+    if (phase & 2) {
     // d_a^T planes (8H x BT): A operand of the weight-gradient GEMM
     SplitTArgs ta{};
     ta.nseg = 1; ta.seg_ptr[0] = p.d_a; ta.seg_ld[0] = 8 * H; ta.seg_cols[0] = 8 * H; ta.seg_shift[0] = 0;
@@ -574,7 +576,8 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
                            db_partials ? reinterpret_cast<const float*>(ws + L.dbp) : static_cast<const float*>(nullptr), p.d_b, p.B);
         MMB_HIP(hipGetLastError());
     }
-    if (p.d_x) {
+    }
+    if (p.d_x && (phase & 1)) {
         // d_x (BT, I) = d_a (BT x 8H) . [W_ih_f ; W_ih_r] (8H x I): one GEMM over both directions
         SplitRowsArgs sa{};
         sa.src1 = p.d_a; sa.src2 = p.d_a; sa.R1 = (int)BT; sa.R = (int)BT; sa.C = 8 * H; sa.ld = 8 * H; sa.Cp = L.K8; sa.gate_H = 0;
@@ -671,9 +674,21 @@ extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int devic
 }
 
 extern "C" int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* d, int n, int device, void* stream_) {
+    return mmb_bilstm_layer_bwd_phase(d, n, 3, device, stream_);
+}
+
+extern "C" int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* d, int n, int phase, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MMB_REQUIRE(d && n >= 1 && n <= MMB_MAX_GROUP, "mmb_bilstm_layer_bwd: n=%d out of range", n);
+    MMB_REQUIRE(phase >= 1 && phase <= 3, "mmb_bilstm_layer_bwd_phase: phase=%d (1 = BPTT + input gradient, 2 = weight gradients, 3 = both)", phase);
     MMB_HIP(hipSetDevice(device));
+    if (phase == 2) {   // weight / bias gradients of the problems that run on the operand planes (the others did them in phase 1)
+        const int H2 = d[0].H;
+        for (int i = 0; i < n; ++i)
+            if (d[i].ws && d[i].d_w_cat && planes_ok(d[i].I, H2))
+                if (int rc = grads_planes(d[i], stream, !(H2 > MMB_LSTM_MAX_H), 2)) return rc;
+        return MMB_OK;
+    }
     RecBwdArgs ra{};
     ra.n = n;
     int wg = 0;
@@ -715,7 +730,7 @@ extern "C" int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* d, int n, int devic
         const mmb_lstm_bwd_desc& p = d[i];
         const int BT = p.B * p.T;
         if (p.ws && p.d_w_cat && planes_ok(p.I, H)) {
-            rc = grads_planes(p, stream, !big);
+            rc = grads_planes(p, stream, !big, phase);
             if (rc) return rc;
             continue;
         }

@@ -71,11 +71,12 @@ class FlatGradAllReduce:
     buckets: optional list of parameter lists (see region_buckets); default one bucket = one all-reduce.
     overlap=True: every bucket is packed and all-reduced asynchronously the moment backward has produced its last
     gradient (post-accumulate-grad hooks); __call__ then only launches what is still missing, waits and copies back.
+    stream_fn: see __init__ (gradients finished on a side stream).
 
     The reduced values are copied back into the tensors autograd produced (p.grad is never rebound to a view of the
     flat buffer); a parameter without a gradient contributes zeros and keeps grad None."""
 
-    def __init__(self, params, group=None, average=False, buckets=None, overlap=False):
+    def __init__(self, params, group=None, average=False, buckets=None, overlap=False, stream_fn=None):
         params = [p for p in params if p.requires_grad]
         if buckets is None:
             buckets = [params]
@@ -90,6 +91,10 @@ class FlatGradAllReduce:
         assert len({id(p) for p in self.params}) == len(self.params), "a parameter appears in two buckets"
         self.group = group
         self.average = average
+        # stream_fn(device) -> the stream on which the gradients become final (mmbidaf_amd.functional.side_stream: the
+        # weight-gradient GEMMs run on a side stream): packing + all-reduce are enqueued there, behind them, so that the
+        # main stream is not held up
+        self.stream_fn = stream_fn
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=self.params[0].device)
@@ -120,6 +125,15 @@ class FlatGradAllReduce:
             self._launch(bi)
 
     def _launch(self, bi):
+        if self.stream_fn is not None and self.flat.is_cuda:
+            s = self.stream_fn(self.flat.device)
+            s.wait_stream(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(s):
+                self._launch_here(bi)
+        else:
+            self._launch_here(bi)
+
+    def _launch_here(self, bi):
         with torch.no_grad():
             grads = [p.grad for p in self.buckets[bi]]
             if all(g is not None for g in grads):

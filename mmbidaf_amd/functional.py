@@ -5,6 +5,7 @@ the library never owns memory; kernels are enqueued on torch's current stream.  
 on the autograd worker thread: the device ordinal is passed explicitly on every call.
 """
 import ctypes
+import os
 
 import torch
 
@@ -17,6 +18,48 @@ def _ptr(t):
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+# ---- second stream for work that is off the critical path of the backward pass (weight-gradient GEMMs and their split
+# passes): it runs under the recurrences, which occupy only 2*B of the 256 CUs.  MMB_SIDE_STREAM=0 disables it.
+_side_streams = {}
+_join_pending = set()
+_USE_SIDE = os.environ.get("MMB_SIDE_STREAM", "1") != "0"
+
+
+def side_stream(device):
+    """The per-device side stream (created on first use)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    s = _side_streams.get(key)
+    if s is None:
+        s = _side_streams[key] = torch.cuda.Stream(device=key)
+    return s
+
+
+def join_side_stream(device=None):
+    """Make the current stream wait for everything enqueued on the side stream so far."""
+    for key, s in _side_streams.items():
+        if device is None or torch.device(device).index == key:
+            torch.cuda.current_stream(key).wait_stream(s)
+
+
+def _join_at_end_of_backward(dev_index):
+    """Queue an engine callback (one per backward pass and device): when autograd has finished, the main stream waits for
+    the side stream, so whoever consumes the gradients next (optimizer, clipping, all-reduce wait) is ordered behind them."""
+    task = getattr(torch._C, "_current_graph_task_id", lambda: None)()
+    key = (dev_index, task)
+    if task is not None and task >= 0 and key in _join_pending:
+        return
+
+    def cb():
+        _join_pending.discard(key)
+        torch.cuda.current_stream(dev_index).wait_stream(_side_streams[dev_index])
+    if task is not None and task >= 0:
+        _join_pending.add(key)
+        if len(_join_pending) > 64:          # passes that died before their callback ran
+            _join_pending.clear()
+            _join_pending.add(key)
+    torch.autograd.Variable._execution_engine.queue_callback(cb)
 
 
 def _require_gpu(*tensors):
@@ -205,6 +248,7 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         _lib.check(rc, "mmb_bilstm_layer_fwd")
         ctx.n = n
         ctx.hn_pos = list(hn_pos)
+        ctx.params = [t for t in flat if isinstance(t, torch.nn.Parameter)]    # to see whether gradients are being accumulated
         ctx.need_dx = [bool(ctx.needs_input_grad[2 + i * _PER_PROBLEM]) for i in range(n)]
         ctx.save_for_backward(*saved)
         return tuple(outs)
@@ -249,9 +293,27 @@ class _BiLSTMLayerFn(torch.autograd.Function):
             d.B, d.T, d.I, d.H = B, T, I, H
             keep += [d_y, d_hn, d_a, d_w_cat, ws]
             results += [d_x, d_w_ih[0], d_w_hh[0], d_b[0], None, d_w_ih[1], d_w_hh[1], d_b[1], None]
-        rc = lib.mmb_bilstm_layer_bwd(descs, n, dev.index, _stream())
-        _lib.check(rc, "mmb_bilstm_layer_bwd")
-        d_b_dup = d_b_flat.clone()
+        # (not when a parameter already holds a gradient: AccumulateGrad then adds on the main stream right after this
+        #  function returns, i.e. possibly before the side stream has written the new one)
+        if _USE_SIDE and not torch.is_grad_enabled() and all(p.grad is None for p in ctx.params):
+            # BPTT + input gradients on the current stream (the critical path: the next layer's backward waits for d_x);
+            # weight / bias gradients on the side stream, ordered behind this call's recurrence, overlapping whatever
+            # the main stream does next.  Every buffer the side stream touches is marked so that the caching allocator
+            # does not recycle it early; the main stream re-joins once, when autograd has finished.
+            main, side = torch.cuda.current_stream(dev), side_stream(dev)
+            _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 1, dev.index, main.cuda_stream), "mmb_bilstm_layer_bwd_phase(1)")
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 2, dev.index, side.cuda_stream), "mmb_bilstm_layer_bwd_phase(2)")
+                d_b_dup = d_b_flat.clone()
+            for t in keep + list(sv) + [d_b_flat, d_b_dup] + [r for r in results if r is not None]:
+                if t is not None and t.is_cuda:
+                    t.record_stream(side)
+            _join_at_end_of_backward(dev.index)
+        else:
+            rc = lib.mmb_bilstm_layer_bwd(descs, n, dev.index, _stream())
+            _lib.check(rc, "mmb_bilstm_layer_bwd")
+            d_b_dup = d_b_flat.clone()
         for i in range(n):
             dup = d_b_dup[d_b_off[i]:d_b_off[i] + 8 * hs_[i]].view(2, 4 * hs_[i])
             results[9 * i + 4], results[9 * i + 8] = dup[0], dup[1]
