@@ -21,10 +21,14 @@ def _stream():
 
 
 # ---- second stream for work that is off the critical path of the backward pass (weight-gradient GEMMs and their split
-# passes): it runs under the recurrences, which occupy only 2*B of the 256 CUs.  MMB_SIDE_STREAM=0 disables it.
+# passes), so that it can run under the recurrences, which occupy only 2*B of the 256 CUs.  OFF by default
+# (MMB_SIDE_STREAM=1 enables it): measured on cfg2 (profiles/r02_side_stream.md) the side stream's GEMMs mostly land
+# beside the attention backward and the next layer's own GEMMs -- two full-chip kernels slow each other down -- and the
+# step got 2 % SLOWER (3.55 vs 3.48 ms); the recurrences leave 64-128 CUs free for ~240 us each, room for at most
+# ~0.15 ms of the 1.2 ms of GEMM + split work per step.
 _side_streams = {}
 _join_pending = set()
-_USE_SIDE = os.environ.get("MMB_SIDE_STREAM", "1") != "0"
+_USE_SIDE = os.environ.get("MMB_SIDE_STREAM", "0") == "1"
 
 
 def side_stream(device):
