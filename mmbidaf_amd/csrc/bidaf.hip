@@ -429,13 +429,14 @@ struct SplitSrc {
     const float* src;     // (B,R,D)
     char* planes;         // B x planes_sample_bytes(R)
     float* inv;           // (B, pad32(R)) inverse row scales, 0 for all-zero and padding rows
-    const float* w;       // (D) or null
+    const float* w;       // (D) or null: rank-1 weight of `term`
     const float* bias;    // (1) or null
     float* term;          // (B,R) or null
+    const float* mul;     // (D) or null: the planes hold src * mul feature-wise (the w_tm-folded lane-side operands)
     int R;
 };
 struct PrepArgs {
-    SplitSrc t[4];
+    SplitSrc t[6];
     int n, D, B;
 };
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -480,6 +481,7 @@ __global__ __launch_bounds__(256) void att_prep_kernel(const PrepArgs a) {
     if (row < s.R && d < a.D) {
         x = *reinterpret_cast<const f4*>(s.src + ((size_t)b * s.R + row) * a.D + d);
         if (s.w) dot = f4sum(x * *reinterpret_cast<const f4*>(s.w + d));
+        if (s.mul) x = x * *reinterpret_cast<const f4*>(s.mul + d);
     }
     const float amax = wave_allmax(f4amax(x));
     if (s.term) {
@@ -511,8 +513,8 @@ __global__ __launch_bounds__(256) void att_rank1_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------ forward
 struct AttFwdArgs {
-    const float* side_src;  // (B,N,D) lane-side S operand (dropped copy), scaled by w_tm on load
-    const float* w_tm;      // (D)
+    const char* side_p;     // planes of the lane-side S operand (dropped copy * w_tm)   + inverse scales (B, pad32(N))
+    const float* side_i;
     const char* mS;         // planes of the streamed S operand (dropped copy)      + inverse scales (B, pad32(R))
     const float* iS;
     const char* mV0;        // planes of the first value tensor (== mS without dropout)
@@ -566,7 +568,7 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
 
     side_t side;
     float inv_n;
-    load_side_f32(side, inv_n, a.side_src + (size_t)b * N * D, n, N, D, g, a.w_tm);
+    load_side_planes(side, inv_n, a.side_p + (size_t)b * planes_sample_bytes(N), a.side_i + (size_t)b * pad32(N), n, N, g);
     const float nterm = n < N ? a.n_term[(size_t)b * N + n] : 0.f;
     const tr_off tr = make_tr_off(lane);
 
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(2 * NTHR) void att_row8_kernel(const AttFwdArgs a) 
 
     side_t side;
     float inv_n;
-    load_side_f32(side, inv_n, a.side_src + (size_t)b * N * D, n, N, D, g, a.w_tm);
+    load_side_planes(side, inv_n, a.side_p + (size_t)b * planes_sample_bytes(N), a.side_i + (size_t)b * pad32(N), n, N, g);
     const float nterm = n < N ? a.n_term[(size_t)b * N + n] : 0.f;
     const tr_off tr = make_tr_off(lane);
 
@@ -1059,8 +1061,8 @@ struct AttBwdArgs {
     const float *w_t, *w_m, *w_tm;
     const float *rterm, *cterm, *row_stat, *col_stat;
     // planes + inverse scales (saved by the forward: text, text_d, mod, mod_d, q; workspace: da, db, dq)
-    const char *pT, *pTd, *pM, *pMd, *pQ, *pDa, *pDb;
-    const float *iT, *iTd, *iM, *iMd, *iQ, *iDa, *iDb;
+    const char *pT, *pTd, *pM, *pMd, *pQ, *pDa, *pDb, *pTw, *pMw;   // pTw / pMw: text_d * w_tm, mod_d * w_tm (lane-side S operands)
+    const float *iT, *iTd, *iM, *iMd, *iQ, *iDa, *iDb, *iTw, *iMw;
     char* pDq;
     float* iDq;
     const float* delta1;                             // (B,T)
@@ -1075,6 +1077,21 @@ struct AttBwdArgs {
     int dbg;
 };
 
+// Accumulator tiles hold 16 rows x 64-B pieces per store instruction (16 partial cache lines); instead every wave parks
+// its tile in LDS and the workgroup stores its 64 rows whole: one row per wave-instruction, lane = 16-B chunk.
+// et: [64][LDP] floats of LDS that no wave still reads (the panels are dead); dst: row `row0` of a (rows, D) matrix.
+__device__ __forceinline__ void park_store(float* et, const acc_t& O, float scale, float* dst, int nrows, int D, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(et + (wave * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int rr = wave + NW * k;
+        if (rr < nrows && 4 * lane < D) *reinterpret_cast<f4*>(dst + (size_t)rr * D + 4 * lane) = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * lane);
+    }
+}
 __device__ __forceinline__ void store_acc(float* dst_row, const acc_t& v, float scale, int D, int g) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
@@ -1113,7 +1130,7 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j1_kernel(const AttBwdArgs a) {
     const size_t szT = planes_sample_bytes(T), szM = planes_sample_bytes(M);
     side_t sideS, sideM, sideQ;
     float inS, inM, inQ;
-    load_side_f32(sideS, inS, a.mod_d + (size_t)b * M * D, n, M, D, g, a.w_tm);
+    load_side_planes(sideS, inS, a.pMw + (size_t)b * szM, a.iMw + (size_t)b * pad32(M), n, M, g);
     load_side_planes(sideM, inM, a.pM + (size_t)b * szM, a.iM + (size_t)b * pad32(M), n, M, g);
     load_side_planes(sideQ, inQ, a.pQ + (size_t)b * szM, a.iQ + (size_t)b * pad32(M), n, M, g);
     const bool nin = n < M;
@@ -1191,12 +1208,16 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j1_kernel(const AttBwdArgs a) {
         if (!(dbg & 4)) pvprod<1>(pTd, tr, W0, W1, dmd);
     }
     dc = kg_allsum(dc);
-    if (!nin || (dbg & 8)) return;
-    const size_t prow = ((size_t)b * a.splits + split) * M + n;
-    store_acc(a.p_dq + prow * D, dq, 1.0f / cDb, D, g);
-    store_acc(a.p_dmc + prow * D, dmc, 1.0f / cDa, D, g);
-    store_acc(a.p_dmd1 + prow * D, dmd, 1.0f / cS, D, g);
-    if (g == 0) a.p_dc1[prow] = dc;
+    if (dbg & 8) return;
+    {
+        float* et = reinterpret_cast<float*>(smem);
+        const int row0 = tile * NW * 16;
+        const size_t prow0 = ((size_t)b * a.splits + split) * M + row0;
+        park_store(et, dq, 1.0f / cDb, a.p_dq + prow0 * D, M - row0, D, tid);
+        park_store(et, dmc, 1.0f / cDa, a.p_dmc + prow0 * D, M - row0, D, tid);
+        park_store(et, dmd, 1.0f / cS, a.p_dmd1 + prow0 * D, M - row0, D, tid);
+        if (nin && g == 0) a.p_dc1[prow0 + (n - row0)] = dc;
+    }
 }
 
 // j-side sweep 2 (needs the complete dq = sum of the sweep-1 partials):
@@ -1226,7 +1247,7 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
     const size_t szT = planes_sample_bytes(T), szM = planes_sample_bytes(M);
     side_t sideS, sideDq;
     float inS, inDq;
-    load_side_f32(sideS, inS, a.mod_d + (size_t)b * M * D, n, M, D, g, a.w_tm);
+    load_side_planes(sideS, inS, a.pMw + (size_t)b * szM, a.iMw + (size_t)b * Mp, n, M, g);
     float delta2;
     {
         float x[KT][8];
@@ -1338,10 +1359,14 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
         }
     }
     dc = kg_allsum(dc);
-    if (!nin || (dbg & 8)) return;
-    const size_t prow = ((size_t)b * a.splits + split) * M + n;
-    store_acc(a.p_dmd2 + prow * D, dmd, 1.0f / cS, D, g);
-    if (g == 0) a.p_dc2[prow] = dc;
+    if (dbg & 8) return;
+    {
+        float* et = reinterpret_cast<float*>(smem);
+        const int row0 = tile * NW * 16;
+        const size_t prow0 = ((size_t)b * a.splits + split) * M + row0;
+        park_store(et, dmd, 1.0f / cS, a.p_dmd2 + prow0 * D, M - row0, D, tid);
+        if (nin && g == 0) a.p_dc2[prow0 + (n - row0)] = dc;
+    }
 }
 
 // j-side epilogue: one wave per JF_ROWS modality rows, lane = 4 features.  Sums the split partials, writes
@@ -1438,7 +1463,7 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
     const size_t szT = planes_sample_bytes(T), szM = planes_sample_bytes(M);
     side_t sideS, sideDa, sideDb, sideT;
     float inS, inDa, inDb, inT;
-    load_side_f32(sideS, inS, a.text_d + (size_t)b * T * D, n, T, D, g, a.w_tm);
+    load_side_planes(sideS, inS, a.pTw + (size_t)b * szT, a.iTw + (size_t)b * pad32(T), n, T, g);
     load_side_planes(sideDa, inDa, a.pDa + (size_t)b * szT, a.iDa + (size_t)b * pad32(T), n, T, g);
     load_side_planes(sideDb, inDb, a.pDb + (size_t)b * szT, a.iDb + (size_t)b * pad32(T), n, T, g);
     load_side_planes(sideT, inT, a.pT + (size_t)b * szT, a.iT + (size_t)b * pad32(T), n, T, g);
@@ -1605,7 +1630,7 @@ static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 // saved-for-backward buffer of the fused path: planes + inverse row scales of text, mod, q (and of the dropped copies)
 struct SavedLayout {
-    size_t pT, pTd, pM, pMd, pQ, iT, iTd, iM, iMd, iQ, total;
+    size_t pT, pTd, pM, pMd, pQ, pTw, pMw, iT, iTd, iM, iMd, iQ, iTw, iMw, total;
 };
 static SavedLayout saved_layout(int B, int T, int M, int drop) {
     SavedLayout L{};
@@ -1618,11 +1643,15 @@ static SavedLayout saved_layout(int B, int T, int M, int drop) {
     L.pM = take(szM);
     L.pMd = drop ? take(szM) : L.pM;
     L.pQ = take(szM);
+    L.pTw = take(szT);
+    L.pMw = take(szM);
     L.iT = take(nT);
     L.iTd = drop ? take(nT) : L.iT;
     L.iM = take(nM);
     L.iMd = drop ? take(nM) : L.iM;
     L.iQ = take(nM);
+    L.iTw = take(nT);
+    L.iMw = take(nM);
     L.total = o;
     return L;
 }
@@ -1739,11 +1768,13 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
         PrepArgs p{};
         p.D = D; p.B = B;
         int k = 0;
-        p.t[k++] = SplitSrc{text_d, sv + L.pTd, fp(L.iTd), w_t, bias, rterm, T};
-        p.t[k++] = SplitSrc{mod_d, sv + L.pMd, fp(L.iMd), w_m, nullptr, cterm, M};
+        p.t[k++] = SplitSrc{text_d, sv + L.pTd, fp(L.iTd), w_t, bias, rterm, nullptr, T};
+        p.t[k++] = SplitSrc{mod_d, sv + L.pMd, fp(L.iMd), w_m, nullptr, cterm, nullptr, M};
+        p.t[k++] = SplitSrc{text_d, sv + L.pTw, fp(L.iTw), nullptr, nullptr, nullptr, w_tm, T};   // lane-side S operands: w_tm folded in
+        p.t[k++] = SplitSrc{mod_d, sv + L.pMw, fp(L.iMw), nullptr, nullptr, nullptr, w_tm, M};
         if (drop) {
-            p.t[k++] = SplitSrc{text, sv + L.pT, fp(L.iT), nullptr, nullptr, nullptr, T};
-            p.t[k++] = SplitSrc{mod, sv + L.pM, fp(L.iM), nullptr, nullptr, nullptr, M};
+            p.t[k++] = SplitSrc{text, sv + L.pT, fp(L.iT), nullptr, nullptr, nullptr, nullptr, T};
+            p.t[k++] = SplitSrc{mod, sv + L.pM, fp(L.iM), nullptr, nullptr, nullptr, nullptr, M};
         }
         p.n = k;
         const long rows = (long)B * pad32(T > M ? T : M);
@@ -1757,7 +1788,7 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
     float* part_stat = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align256((size_t)splits * B * M * D * 4));
     {
         AttFwdArgs a{};
-        a.side_src = mod_d; a.w_tm = w_tm;
+        a.side_p = sv + L.pMw; a.side_i = fp(L.iMw);
         a.mS = sv + L.pTd; a.iS = fp(L.iTd); a.mV0 = sv + L.pT; a.iV0 = fp(L.iT); a.mV1 = nullptr; a.iV1 = nullptr;
         a.m_mask = text_len ? nullptr : text_mask; a.m_len = text_len; a.m_term = rterm; a.n_term = cterm;
         a.part_o = part_o; a.part_stat = part_stat;
@@ -1785,7 +1816,7 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
     // ---- row pass: lane side = text rows, streams [mod | q]
     {
         AttFwdArgs a{};
-        a.side_src = text_d; a.w_tm = w_tm;
+        a.side_p = sv + L.pTw; a.side_i = fp(L.iTw);
         a.mS = sv + L.pMd; a.iS = fp(L.iMd); a.mV0 = sv + L.pM; a.iV0 = fp(L.iM); a.mV1 = sv + L.pQ; a.iV1 = fp(L.iQ);
         a.m_mask = mod_len ? nullptr : mod_mask; a.m_len = mod_len; a.m_term = cterm; a.n_term = rterm; a.stat = row_stat;
         a.text = text; a.out = out; a.bsave = bsave;
@@ -1855,8 +1886,8 @@ extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* 
     a.text_len = text_len; a.mod_len = mod_len;
     a.w_t = w_t; a.w_m = w_m; a.w_tm = w_tm;
     a.rterm = rterm; a.cterm = cterm; a.row_stat = row_stat; a.col_stat = col_stat;
-    a.pT = sv + S.pT; a.pTd = sv + S.pTd; a.pM = sv + S.pM; a.pMd = sv + S.pMd; a.pQ = sv + S.pQ;
-    a.iT = sf(S.iT); a.iTd = sf(S.iTd); a.iM = sf(S.iM); a.iMd = sf(S.iMd); a.iQ = sf(S.iQ);
+    a.pT = sv + S.pT; a.pTd = sv + S.pTd; a.pM = sv + S.pM; a.pMd = sv + S.pMd; a.pQ = sv + S.pQ; a.pTw = sv + S.pTw; a.pMw = sv + S.pMw;
+    a.iT = sf(S.iT); a.iTd = sf(S.iTd); a.iM = sf(S.iM); a.iMd = sf(S.iMd); a.iQ = sf(S.iQ); a.iTw = sf(S.iTw); a.iMw = sf(S.iMw);
     a.pDa = ws + L.pDa; a.pDb = ws + L.pDb; a.pDq = ws + L.pDq;
     a.iDa = wf(L.iDa); a.iDb = wf(L.iDb); a.iDq = wf(L.iDq);
     a.delta1 = wf(L.delta1); a.delta2 = wf(L.delta2);
@@ -1888,7 +1919,8 @@ extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* 
     {
         const size_t arr = ((size_t)4 * a.rows_per_split + 16) * sizeof(float), stage_b = (size_t)(drop_t ? 2 : 1) * PANEL_B;
         a.nstage_j2 = (2 * stage_b + arr <= 160 * 1024 && a.rows_per_split > PR) ? 2 : 1;
-        const size_t lds = a.nstage_j2 * stage_b + arr;
+        size_t lds = a.nstage_j2 * stage_b + arr;
+        if (lds < (size_t)16 * NW * LDP * sizeof(float)) lds = (size_t)16 * NW * LDP * sizeof(float);   // epilogue staging tile
         auto kern = a.dbg ? att_bwd_j2_kernel<true> : att_bwd_j2_kernel<false>;
         if (int rc = allow_lds(kern, lds)) return rc;
         ProfScope ps_(MMB_K_ATT_BWD_J2, stream);
