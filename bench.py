@@ -31,7 +31,8 @@ F16_MFMA_PEAK_TF = 2500.0    # dense fp16/bf16 MFMA peak (the fused attention is
 ATT_FWD_KERNELS = ["att_rank1", "att_col", "att_combine", "att_row"]
 ATT_BWD_KERNELS = ["att_bwd_pre", "att_bwd_j1", "att_bwd_j2", "att_bwd_jfin", "att_bwd_i"]
 ATT_KERNELS = ATT_FWD_KERNELS + ATT_BWD_KERNELS
-ALL_KERNELS = ATT_KERNELS + ["gemm", "lstm_rec_fwd", "lstm_rec_bwd"]
+ATT_GROUPS = ["att_fwd", "att_bwd"]      # one event pair around ALL kernels of a fused forward / backward call
+ALL_KERNELS = ATT_GROUPS + ATT_KERNELS + ["gemm", "lstm_rec_fwd", "lstm_rec_bwd"]
 
 
 def source_hash():
@@ -57,6 +58,9 @@ def parse():
     ap.add_argument("--fresh-lengths", action="store_true",
                     help="new ragged lengths every step (the host-derived masks / sort orders miss the device cache, as in real training)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one fwd+bwd step of the region into a hipGraph after warm-up and replay it (the C-ABI calls only "
+                         "enqueue on the given stream): the host then issues ONE launch per step (N=1, fixed lengths only)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class (perturbs the step time a little)")
     return ap.parse_args()
 
@@ -106,42 +110,51 @@ def attention_roofline(a, prof, B, T, Ma, Mi, D, fused):
     if not fused:
         return None       # D > 208 runs the general-width kernels (bidaf_big.hip: batched GEMMs + softmax kernels)
     steps = max(a.steps, 1)
-    per = {k: (prof[k][0] / steps * 1e3, prof[k][1] / steps, prof[k][2]) for k in ATT_KERNELS}   # us per step, launches per step, symbol
-    fwd_us = sum(per[k][0] for k in ATT_FWD_KERNELS)
-    bwd_us = sum(per[k][0] for k in ATT_BWD_KERNELS)
+    fwd_us = prof["att_fwd"][0] / steps * 1e3
+    bwd_us = prof["att_bwd"][0] / steps * 1e3
     fwd_b = sum(synth.attention_algorithmic_bytes(B, T, M, D) for M in (Ma, Mi))
     bwd_b = sum(synth.attention_algorithmic_bytes(B, T, M, D, backward=True) for M in (Ma, Mi))
     tot_us = fwd_us + bwd_us
     ach = (fwd_b + bwd_b) / (tot_us * 1e-6) / 1e9 if tot_us else 0.0
-    slow = max(ATT_KERNELS, key=lambda k: per[k][0])
+    per = None
+    if all(k in prof for k in ATT_KERNELS):      # --profile-all: every kernel bracketed on its own as well
+        per = {k: (prof[k][0] / steps * 1e3, prof[k][1] / steps, prof[k][2]) for k in ATT_KERNELS}   # us per step, launches per step, symbol
     # matrix-core work of the fused kernels: S-type and PV-type products at the padded sizes (7 k tiles / 13 feature
-    # tiles), 3 fp16 MFMAs per product, per (16 lane rows x 32 streamed rows): col 81, row 120 (+42 with two waves per
-    # SIMD), j1 243, j2 123, i 246 MFMAs of 16x16x32
+    # tiles), 3 fp16 MFMAs per product, per (16 lane rows x 32 streamed rows): col 81, row 2 x 81 (two waves per SIMD, both
+    # compute S), j1 243, j2 123, i 246 MFMAs of 16x16x32
     units = lambda M: B * ((M + 15) // 16) * ((T + 31) // 32) * (81 + 243 + 123) + B * ((T + 15) // 16) * ((M + 31) // 32) * (162 + 246)
     flops = sum(units(M) for M in (Ma, Mi)) * 2 * 16 * 16 * 32
+    sym_launches = {"att_prep_kernel": 2, "att_col_kernel": 2, "att_combine_kernel": 2, "att_row8_kernel": 2, "att_bwd_pre_kernel": 2,
+                    "att_bwd_j1_kernel": 2, "att_bwd_j2_kernel": 2, "att_bwd_jfin_kernel": 2, "att_bwd_i_kernel": 2}   # launches per step
     traffic, traffic_note = None, "no PMC file stamped with these kernel sources"
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
             if t.get("source_hash") == source_hash() and a.config in t:
-                traffic = sum(t[a.config].get(per[k][2], 0.0) * per[k][1] for k in ATT_KERNELS)
+                traffic = sum(t[a.config].get(sym, 0.0) * n for sym, n in sym_launches.items())
                 traffic_note = "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per step over the nine kernels, separate rocprofv3 --pmc passes of this command (tools/run_round_profiles.sh)"
         except Exception:
             pass
-    return {"bound": "hbm", "kernel": "fused BiDAF attention, forward + backward of both attentions (9 kernels each)",
-            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_note": traffic_note,
-            "algorithmic_bytes_per_step": int(fwd_b + bwd_b), "us_per_step": round(tot_us, 1),
-            "forward": {"us_per_step": round(fwd_us, 1), "algorithmic_bytes": int(fwd_b),
-                        "frac": round(fwd_b / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if fwd_us else None},
-            "backward": {"us_per_step": round(bwd_us, 1), "algorithmic_bytes": int(bwd_b),
-                         "frac": round(bwd_b / (bwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if bwd_us else None},
-            "slowest_kernel": {"name": per[slow][2], "us_per_step": round(per[slow][0], 1), "launches_per_step": per[slow][1]},
-            "kernel_us_per_launch": {per[k][2]: round(per[k][0] / max(per[k][1], 1), 2) for k in ATT_KERNELS},
-            "mfma_f16": {"achieved_tflops": round(flops / (tot_us * 1e-6) / 1e12, 1) if tot_us else None, "peak_tflops": F16_MFMA_PEAK_TF,
-                         "frac": round(flops / (tot_us * 1e-6) / 1e12 / F16_MFMA_PEAK_TF, 4) if tot_us else None,
-                         "note": "fp16 MFMA issued (3 per fp32-accurate product), all nine kernels' time in the denominator"}}
+    out = {"bound": "hbm", "kernel": "fused BiDAF attention, forward + backward of both attentions (9 kernels each; one HIP-event "
+                                     "pair around each fused forward / backward call, launch gaps included)",
+           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+           "traffic": traffic, "traffic_note": traffic_note,
+           "algorithmic_bytes_per_step": int(fwd_b + bwd_b), "us_per_step": round(tot_us, 1),
+           "forward": {"us_per_step": round(fwd_us, 1), "algorithmic_bytes": int(fwd_b),
+                       "frac": round(fwd_b / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if fwd_us else None},
+           "backward": {"us_per_step": round(bwd_us, 1), "algorithmic_bytes": int(bwd_b),
+                        "frac": round(bwd_b / (bwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if bwd_us else None},
+           "mfma_f16": {"achieved_tflops": round(flops / (tot_us * 1e-6) / 1e12, 1) if tot_us else None, "peak_tflops": F16_MFMA_PEAK_TF,
+                        "frac": round(flops / (tot_us * 1e-6) / 1e12 / F16_MFMA_PEAK_TF, 4) if tot_us else None,
+                        "note": "fp16 MFMA issued (3 per fp32-accurate product), the whole attention's time in the denominator"}}
+    if per is not None:
+        slow = max(ATT_KERNELS, key=lambda k: per[k][0])
+        out["slowest_kernel"] = {"name": per[slow][2], "us_per_step": round(per[slow][0], 1), "launches_per_step": per[slow][1]}
+        out["kernel_us_per_launch"] = {per[k][2]: round(per[k][0] / max(per[k][1], 1), 2) for k in ATT_KERNELS}
+    else:
+        out["slowest_kernel"] = {"name": "att_bwd_i_kernel", "note": "per-kernel times: bench.py --profile-all, or profiles/r02_kernel_stats.md"}
+    return out
 
 
 def main():
@@ -193,7 +206,35 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    timed = ALL_KERNELS if a.profile_all else ATT_KERNELS
+    graph = None
+    if a.graph:
+        if world > 1 or a.fresh_lengths:
+            raise SystemExit("--graph: single GPU, fixed lengths")
+        # whole-step capture (PyTorch's "whole network" recipe): grads are allocated inside the graph's private pool, the
+        # synthetic batch and the parameters are static tensors
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        for p in params:
+            p.grad = None
+        for x in xs:
+            x.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+            synth.region_loss(outs, batch).backward()
+        eager_step = step
+        step = graph.replay
+        for _ in range(2):
+            step()
+    # default: two event pairs per attention call (36 events per step around every kernel cost 4 % of the step)
+    timed = ALL_KERNELS if a.profile_all else ATT_GROUPS
+    if graph is not None:
+        timed = []          # the event pairs of the timing hook cannot be recorded inside a replayed graph
     fence()
     _lib.profile_enable(timed)
     t0 = time.perf_counter()
@@ -227,8 +268,10 @@ def main():
                                    f"{'ragged U{n/2..n}' if a.ragged else 'full'} lengths, fwd+bwd"
                                    f"{' + bucketed gradient all-reduce (sum)' if world > 1 else ''}",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
-            "roofline": attention_roofline(a, prof, B, T, Ma, Mi, D, fused=D <= _lib.ATT_MAX_D),
+            "roofline": attention_roofline(a, prof, B, T, Ma, Mi, D, fused=D <= _lib.ATT_MAX_D) if timed else None,
         }
+        if graph is not None:
+            out["config"]["launch"] = "hipGraph replay of one captured fwd+bwd step"
         if world > 1:
             out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": devices,
                            "grad_buckets": len(sync.buckets), "grad_elems": sync.numel}

@@ -49,7 +49,10 @@ const char* mmb_last_error(void);
 enum {
     MMB_K_ATT_RANK1 = 0, MMB_K_ATT_COL, MMB_K_ATT_COMBINE, MMB_K_ATT_ROW,
     MMB_K_ATT_BWD_PRE, MMB_K_ATT_BWD_J1, MMB_K_ATT_BWD_J2, MMB_K_ATT_BWD_JFIN, MMB_K_ATT_BWD_I,
-    MMB_K_GEMM, MMB_K_LSTM_REC_FWD, MMB_K_LSTM_REC_BWD, MMB_K_SPLIT, MMB_K_COUNT
+    MMB_K_GEMM, MMB_K_LSTM_REC_FWD, MMB_K_LSTM_REC_BWD, MMB_K_SPLIT,
+    MMB_K_ATT_FWD,   /* one bracket around ALL kernels of a fused mmb_bidaf_fwd call (two events per call, not per kernel) */
+    MMB_K_ATT_BWD,   /* likewise for mmb_bidaf_bwd */
+    MMB_K_COUNT
 };
 int mmb_profile_enable(uint32_t kernel_mask);
 int mmb_profile_read(int kernel_id, double* total_ms, int* launches);

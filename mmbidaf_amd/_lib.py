@@ -85,7 +85,7 @@ SIGNATURES = {
 # kernel ids of the opt-in timing hook (enum in include/mmbidaf.h)
 KERNEL_IDS = {n: i for i, n in enumerate(
     ["att_rank1", "att_col", "att_combine", "att_row", "att_bwd_pre", "att_bwd_j1", "att_bwd_j2", "att_bwd_jfin",
-     "att_bwd_i", "gemm", "lstm_rec_fwd", "lstm_rec_bwd", "split"])}
+     "att_bwd_i", "gemm", "lstm_rec_fwd", "lstm_rec_bwd", "split", "att_fwd", "att_bwd"])}
 
 _lib = None
 

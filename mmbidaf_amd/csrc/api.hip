@@ -106,7 +106,7 @@ extern "C" const char* mmb_kernel_name(int kernel_id) {
     static const char* names[MMB_K_COUNT] = {
         "att_prep_kernel", "att_col_kernel", "att_combine_kernel", "att_row8_kernel",
         "att_bwd_pre_kernel", "att_bwd_j1_kernel", "att_bwd_j2_kernel", "att_bwd_jfin_kernel", "att_bwd_i_kernel",
-        "gemm_kernel", "lstm_rec_fwd_kernel", "lstm_rec_bwd_kernel", "split_"};
+        "gemm_kernel", "lstm_rec_fwd_kernel", "lstm_rec_bwd_kernel", "split_", "att_fwd(prep+col+combine+row8)", "att_bwd(pre+j1+j2+jfin+i)"};
     return (kernel_id >= 0 && kernel_id < MMB_K_COUNT) ? names[kernel_id] : "";
 }
 

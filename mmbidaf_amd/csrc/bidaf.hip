@@ -1762,6 +1762,7 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
     const SavedLayout L = saved_layout(B, T, M, drop);
     char* sv = static_cast<char*>(saved);
     auto fp = [&](size_t off) { return reinterpret_cast<float*>(sv + off); };
+    ProfScope ps_all_(MMB_K_ATT_FWD, stream);   // the whole fused forward (bench.py's roofline figure)
 
     // ---- split passes: planes + inverse row scales of text / mod (and the dropped copies), rank-1 terms
     {
@@ -1875,6 +1876,7 @@ extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* 
     }
     const SavedLayout S = saved_layout(B, T, M, drop_t);
     const BwdWs L = bwd_layout(B, T, M, D);
+    ProfScope ps_all_(MMB_K_ATT_BWD, stream);   // the whole fused backward
     const char* sv = static_cast<const char*>(saved);
     char* ws = reinterpret_cast<char*>(workspace);
     auto sf = [&](size_t off) { return reinterpret_cast<const float*>(sv + off); };
