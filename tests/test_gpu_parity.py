@@ -932,6 +932,132 @@ def test_no_two_gradients_share_storage_and_clipping_matches_oracle():
     assert len(set(ptrs)) == len(ptrs), "two decoder gradients share storage"
 
 
+# ------------------------------------------------------------------------------------------- streams and graphs
+def _region_grads(region, batch, gpu):
+    for p in region.parameters():
+        p.grad = None
+    xs = [gpu[k].detach().clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+    outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+    from mmbidaf_amd import synth
+    synth.region_loss(outs, gpu).backward()
+    torch.cuda.synchronize()
+    return [o.detach().clone() for o in outs], [x.grad.clone() for x in xs], {n: p.grad.clone() for n, p in region.named_parameters()}
+
+
+def test_weight_gradients_on_the_side_stream_give_identical_results(monkeypatch):
+    """mmb_bilstm_layer_bwd_phase: BPTT + input gradient on the current stream, weight gradients on the side stream
+    (joined by an engine callback at the end of backward) must reproduce the single-stream backward bit for bit
+    (same kernels, same order per buffer), also when the gradients are consumed right after backward returns."""
+    from mmbidaf_amd import functional as MF, synth
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    torch.manual_seed(224)
+    region = HotRegion(100).to(d)
+    batch = synth.make_batch((4, 60, 40, 12, 100), ragged=True)
+    gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    monkeypatch.setattr(MF, "_USE_SIDE", False)
+    o0, gx0, gp0 = _region_grads(region, batch, gpu)
+    monkeypatch.setattr(MF, "_USE_SIDE", True)
+    for _ in range(3):                                    # repeated: allocator reuse across streams
+        o1, gx1, gp1 = _region_grads(region, batch, gpu)
+        norm = torch.nn.utils.clip_grad_norm_(list(region.parameters()), 1e9)   # consumes every grad right away
+        assert torch.isfinite(norm)
+    for a, b in zip(o0 + gx0, o1 + gx1):
+        assert torch.equal(a, b)
+    for n in gp0:
+        if "bidaf_att" in n:                              # accumulated with atomics: order-dependent last bits
+            close(gp1[n], gp0[n].cpu(), "side-stream grad " + n, tol=1e-6)
+        else:
+            assert torch.equal(gp0[n], gp1[n]), n
+
+
+def test_region_step_replays_from_a_hipgraph():
+    """The C-ABI calls only enqueue on the given stream: a whole fwd+bwd step of the region captured into a hipGraph
+    (bench.py --graph) must replay to the same outputs and gradients as the eager step."""
+    from mmbidaf_amd import synth
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    torch.manual_seed(224)
+    region = HotRegion(100).to(d)
+    batch = synth.make_batch((4, 60, 40, 12, 100), ragged=True)
+    gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    xs = [gpu[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+    params = list(region.parameters())
+
+    def step():
+        outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+        synth.region_loss(outs, gpu).backward()
+        return outs
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            for t in params + xs:
+                t.grad = None
+            eager = step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ref_out = [o.detach().clone() for o in eager]
+    ref_g = [t.grad.clone() for t in params + xs]
+    for t in params + xs:
+        t.grad = None
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = step()
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(ref_out, outs):
+        assert torch.equal(a, b)
+    for (n, p), r in zip(list(region.named_parameters()) + [("x_text", xs[0]), ("x_aud", xs[1]), ("x_img", xs[2])], ref_g):
+        if "bidaf_att" in n:
+            close(p.grad, r.cpu(), "graph grad " + n, tol=1e-6)
+        else:
+            assert torch.equal(p.grad, r), n
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on the box (the gradient exchange over RCCL)")
+def test_gradient_allreduce_over_rccl_world2(tmp_path):
+    """world-size-2 `nccl` (= RCCL) run of the bucketed, hook-launched gradient exchange when the box has two GPUs
+    (a gpurun box has one: skipped there; the gloo twin of this test runs on CPU)."""
+    import subprocess
+    import sys
+    script = tmp_path / "w.py"
+    script.write_text("""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from mmbidaf_amd import ddp, synth, functional as MF
+from mmbidaf_amd.hot_region import HotRegion
+rank, world, local = ddp.init_from_env("nccl")
+dev = torch.device("cuda", local)
+torch.manual_seed(224)
+region = HotRegion(16).to(dev)
+sync = ddp.FlatGradAllReduce(list(region.parameters()), buckets=ddp.region_buckets(region), overlap=True, stream_fn=MF.side_stream)
+sync.broadcast_parameters()
+batch = synth.make_batch((4, 20, 12, 6, 16), rank=0, ragged=True, device=dev)
+lo, hi = ddp.shard_range(4, rank, world)
+sl = lambda t: t[lo:hi]
+outs = region(sl(batch["x_text"]), sl(batch["x_aud"]), sl(batch["x_img"]), batch["text_len"][lo:hi], batch["aud_len"][lo:hi], batch["img_len"][lo:hi])
+((outs[0] * sl(batch["r_a"])).sum() + (outs[2] * sl(batch["r_i"])).sum()).backward()
+sync()
+mine = torch.cat([p.grad.reshape(-1) for p in region.parameters()])
+ref = HotRegion(16).to(dev); ref.load_state_dict(region.state_dict())
+o = ref(batch["x_text"], batch["x_aud"], batch["x_img"], batch["text_len"], batch["aud_len"], batch["img_len"])
+((o[0] * batch["r_a"]).sum() + (o[2] * batch["r_i"]).sum()).backward()
+want = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+assert torch.allclose(mine, want, atol=1e-4 * max(1.0, want.abs().max().item())), (mine - want).abs().max()
+assert dist.get_backend() == "nccl"
+dist.barrier(); print("rank", rank, "ok")
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
 # ------------------------------------------------------------------------------------------- fuzz
 def test_attention_fuzz_random_shapes_and_masks():
     """random small shapes (every D that is a multiple of 4 up to 208 is legal), arbitrary 0/1 masks incl. empty ones"""
