@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
-SOURCES = ["api.hip", "gemm.hip", "gemm_bf16.hip", "planes.hip", "lstm.hip", "lstm_big.hip", "bidaf.hip", "bidaf_big.hip",
+SOURCES = ["api.hip", "gemm.hip", "gemm_bf16.hip", "planes.hip", "lstm.hip", "lstm_big.hip", "lstm_fs.hip", "bidaf.hip", "bidaf_big.hip",
            "decoder.hip", "highway.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "mmbidaf.h")]
 LIB = os.path.join(_HERE, "libmmbidaf_hip.so")

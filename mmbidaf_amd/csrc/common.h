@@ -182,7 +182,12 @@ int bidaf_big_bwd(const float* d_out, const float* out, const float* text, const
 
 // ---- general-size LSTM recurrence (lstm_big.hip): H > MMB_LSTM_MAX_H
 size_t lstm_big_fwd_ws_bytes(int B, int H);
-size_t lstm_big_bwd_ws_bytes(int B, int H);
+size_t lstm_big_bwd_ws_bytes(int B, int T, int H);
+// fused-step recurrence (lstm_fs.hip): one kernel per time step on the 16-bit matrix cores; prep + time loop only
+size_t lstm_fs_fwd_ws_bytes(int B, int H);
+size_t lstm_fs_bwd_ws_bytes(int B, int T, int H);
+int lstm_fs_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* ws, hipStream_t stream);
+int lstm_fs_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* ws, hipStream_t stream);
 int lstm_big_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* big_ws, hipStream_t stream);
 int lstm_big_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* big_ws, hipStream_t stream);
 

@@ -459,7 +459,7 @@ static WsBwd ws_bwd_layout(long BT, int B, int I, int H) {
     w.wTinv = o;  o += rup((size_t)I * 4, 256);
     w.scal = o;   o += 256;                                        // ... [max |W_ih|, max |d_a| (general recurrence)]
     w.damax = o;  o += rup((size_t)2 * B * 4, 256);                // per-workgroup max |d_a| of the register-resident BPTT
-    w.big = o; if (H > MMB_LSTM_MAX_H) o += rup(lstm_big_bwd_ws_bytes(B, H), 256);
+    w.big = o; if (H > MMB_LSTM_MAX_H) o += rup(lstm_big_bwd_ws_bytes(B, (int)(BT / (B > 0 ? B : 1)), H), 256);
     w.total = o;
     return w;
 }
