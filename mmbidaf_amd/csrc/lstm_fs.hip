@@ -114,17 +114,31 @@ __global__ __launch_bounds__(512) void lstm_fs_fwd_kernel(const FsFwdArgs args, 
     const char* Bq[2] = {hprev + fs_off(b0 + r, g, nkt), hprev + fs_off(b0 + 16 + r, g, nkt)};
     f4 c[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
     if (s > 0) {   // h_{-1} = 0
-#pragma unroll 4
-        for (int kt = 0; kt < nkt; ++kt) {
-            const half8 a0 = *reinterpret_cast<const half8*>(A + (size_t)kt * 2048);
-            const half8 a1 = *reinterpret_cast<const half8*>(A + (size_t)kt * 2048 + 1024);
+        // 4 k tiles per trip, all 24 fragment loads issued before the first MFMA (hipcc does not unroll this loop by
+        // itself, and 6 loads in flight per wave leave the kernel waiting on L2 latency)
+        const half8 z8 = {};
+        for (int kt0 = 0; kt0 < nkt; kt0 += 4) {
+            half8 a0[4], a1[4], h0[4][2], h1[4][2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const half8 h0 = *reinterpret_cast<const half8*>(Bq[j] + (size_t)kt * 2048);
-                const half8 h1 = *reinterpret_cast<const half8*>(Bq[j] + (size_t)kt * 2048 + 1024);
-                c[j] = fs_mfma(a0, h1, c[j]);
-                c[j] = fs_mfma(a1, h0, c[j]);
-                c[j] = fs_mfma(a0, h0, c[j]);
+            for (int q = 0; q < 4; ++q) {
+                const size_t o = (size_t)min(kt0 + q, nkt - 1) * 2048;
+                a0[q] = *reinterpret_cast<const half8*>(A + o);
+                a1[q] = *reinterpret_cast<const half8*>(A + o + 1024);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    h0[q][j] = *reinterpret_cast<const half8*>(Bq[j] + o);
+                    h1[q][j] = *reinterpret_cast<const half8*>(Bq[j] + o + 1024);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (kt0 + q >= nkt) { a0[q] = z8; a1[q] = z8; }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    c[j] = fs_mfma(a0[q], h1[q][j], c[j]);
+                    c[j] = fs_mfma(a1[q], h0[q][j], c[j]);
+                    c[j] = fs_mfma(a0[q], h0[q][j], c[j]);
+                }
             }
         }
     }
@@ -204,15 +218,24 @@ __global__ __launch_bounds__(512) void lstm_fs_bwd_kernel(const FsBwdArgs args, 
     if (s > 0) {
         const char* A = P.wtp[dir] + fs_off(32 * blockIdx.x + 16 * mt + r, g, nkt);
         const char* Bq = P.ap[dir][(s + 1) & 1] + fs_off(64 * blockIdx.z + 16 * nt + r, g, nkt);
-#pragma unroll 4
-        for (int kt = 0; kt < nkt; ++kt) {
-            const half8 a0 = *reinterpret_cast<const half8*>(A + (size_t)kt * 2048);
-            const half8 a1 = *reinterpret_cast<const half8*>(A + (size_t)kt * 2048 + 1024);
-            const half8 d0 = *reinterpret_cast<const half8*>(Bq + (size_t)kt * 2048);
-            const half8 d1 = *reinterpret_cast<const half8*>(Bq + (size_t)kt * 2048 + 1024);
-            c = fs_mfma(a0, d1, c);
-            c = fs_mfma(a1, d0, c);
-            c = fs_mfma(a0, d0, c);
+        const half8 z8 = {};
+        for (int kt0 = 0; kt0 < nkt; kt0 += 8) {   // 8 k tiles per trip: 32 fragment loads in flight
+            half8 a0[8], a1[8], d0[8], d1[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const size_t o = (size_t)min(kt0 + q, nkt - 1) * 2048;
+                a0[q] = *reinterpret_cast<const half8*>(A + o);
+                a1[q] = *reinterpret_cast<const half8*>(A + o + 1024);
+                d0[q] = *reinterpret_cast<const half8*>(Bq + o);
+                d1[q] = *reinterpret_cast<const half8*>(Bq + o + 1024);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (kt0 + q >= nkt) { a0[q] = z8; a1[q] = z8; }
+                c = fs_mfma(a0[q], d1[q], c);
+                c = fs_mfma(a1[q], d0[q], c);
+                c = fs_mfma(a0[q], d0[q], c);
+            }
         }
     }
     const float inv_prev = s > 0 ? 1.0f / fs_da_scale(P, dir, s - 1) : 0.f;
