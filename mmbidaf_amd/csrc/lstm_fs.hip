@@ -20,7 +20,7 @@
 // recurrent operand 128 / 512 KB), 16 B per lane, exactly the fragment shape -- no LDS at all.
 //
 // STATUS: opt-in (MMB_LSTM_FS=1), parity-tested at H = 136 / 144 / 256 / 512, and SLOWER than lstm_big.hip's two launches
-// per step at cfg5 (B=64, H=512): 134 vs 92 ms per region step (r02).  Why: with W_hh not resident, every workgroup
+// per step at cfg5 (B=64, H=512): 119 vs 92 ms per region step (r02; 134 ms before the fragment loads were batched by hand).  Why: with W_hh not resident, every workgroup
 // re-reads its 128-KB W slice AND the whole recurrent operand of its chain every step -- 768 KB per workgroup and step
 // forward (147 MB chip-wide), 4x that in the BPTT where K = 4H -- and one CU takes in ~100 GB/s from L2: ~8 us per
 // forward step, more backward.  Staging through LDS would cut the forward to 256 KB per workgroup (~4 us); the BPTT
