@@ -36,7 +36,11 @@ def side_stream(device):
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     s = _side_streams.get(key)
     if s is None:
-        s = _side_streams[key] = torch.cuda.Stream(device=key)
+        # LOWEST priority: the dispatcher then hands CUs to the main stream's (critical-path) kernels first and the side
+        # stream's work only fills what they leave free (MMB_SIDE_PRIORITY overrides the value)
+        lo, hi = torch.cuda.Stream.priority_range()          # (least, greatest); numerically greater = lower priority
+        pr = int(os.environ.get("MMB_SIDE_PRIORITY", lo))
+        s = _side_streams[key] = torch.cuda.Stream(device=key, priority=pr)
     return s
 
 
