@@ -283,6 +283,13 @@ int mmb_gemm_f32(const float* A, const float* Bm, float* C, const float* bias,
 int mmb_gemm_nt_planes(const float* A, const float* Bm, float* C, const float* bias, int M, int N, int K,
                        void* ws, size_t ws_bytes, int device, void* stream);
 
+/* C (M,N) = At (K,M)^T . B (N,K)^T with the A operand split once row-major (one power-of-two scale for the tensor) and read
+ * k-major by the kernel through transposing LDS reads -- the form the LSTM weight gradient d_a^T . [x | h_prev] uses
+ * (reference: autograd of nn.LSTM, layers/encoding.py:41-62).  Exported for tests and tools.  M % 4 == 0, K % 4 == 0; ws:
+ * 6 * (roundup(K,32) * roundup(M,32) + roundup(N,16) * roundup(K,32)) + roundup(4*(K+N),256) + 256 bytes. */
+int mmb_gemm_tn_planes(const float* At, const float* Bm, float* C, int M, int N, int K, void* ws, size_t ws_bytes,
+                       int device, void* stream);
+
 /* Tuning aid: force the operand-plane GEMM's tile configuration and K split (code = config * 100 + split, split 0 =
  * cost model's; code < 0 = cost model for both, the default).  Results do not depend on it beyond summation order. */
 void mmb_set_planes_tune(int code);

@@ -132,6 +132,11 @@ struct SplitRowsArgs {
     int np;
     float* inv_out;      // np == 2: (R) 1/s of every plane row
     float* absmax_out;   // np == 2, optional: max |x| over the whole matrix is atomically max-ed into this (pre-zeroed) float
+    // np == 2, optional: ONE power-of-two scale for the whole tensor from an upper bound of max |x| = the maximum of the
+    // tensor_absmax_n floats at tensor_absmax (partials written by the producer) instead of one scale per row: such planes
+    // can also be read k-major (transpose reads) by a GEMM that contracts over the ROWS (PlanesGemmArgs::ta)
+    const float* tensor_absmax; int tensor_absmax_n;
+    int Rpad;            // rows of zeros written beyond R up to this many rows (0: to the end of the last 16-row block)
 };
 struct SplitTArgs {
     int nseg;
@@ -157,11 +162,15 @@ struct PlanesGemmArgs {
     int np;                    // planes per operand: 3 (bf16, 6 cross products) or 2 (scaled fp16, 3 cross products)
     const float* a_inv;        // np == 2: (M) and (N) inverse scales of the operands' plane rows
     const float* b_inv;
+    int ta;          // A is given K-MAJOR: tiled planes of the (K x M) matrix (rows = k, one scale for the whole tensor); the kernel
+                     // then forms its A fragments with transposing LDS reads (ds_read_b64_tr_b16).  np == 2 only; K % 32 == 0
+                     // rows must exist (zero padding); tile shapes with BM % 32 == 0
     int prezeroed;   // C is already zero (a split pass did it): skip the memset a K split needs
     int splitk;      // set by planes_gemm
     int dbg;      // timing-only ablation (MMB_PLANES_DBG): 2 = no MFMA
 };
 int planes_split_rows(const SplitRowsArgs& a, hipStream_t stream);
+bool planes_one_split();   // MMB_PLANES_ONE_SPLIT (default 1): the LSTM backward splits d_a once (k-major read in the weight-gradient GEMM)
 int planes_split_transpose(const SplitTArgs& a, hipStream_t stream);
 int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream);
 void planes_set_tune(int code);

@@ -448,7 +448,7 @@ static WsBwd ws_bwd_layout(long BT, int B, int I, int H) {
     w.K8 = (int)rup(8 * H, 32);
     w.BTp = (int)rup(BT, 32);
     size_t o = 0;
-    w.daP = o; o += rup(planes_bytes(BT, w.K8), 256);
+    w.daP = o; o += rup(planes_bytes(w.BTp, w.K8), 256);   // rows padded to the K step of the k-major read
     w.daT = o; o += rup(planes_bytes(8 * H, w.BTp), 256);
     w.xcT = o; o += rup(planes_bytes(I + 2 * H, w.BTp), 256);
     w.wT = o;  o += rup(planes_bytes(I, w.K8), 256);
@@ -533,9 +533,13 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
     float* scal = reinterpret_cast<float*>(ws + L.scal);        // max |d_a| when the recurrence did not track it
     const float* damax = reinterpret_cast<const float*>(ws + L.damax);
     int damax_n = 2 * p.B;
+    // ONE split of d_a (row-major planes, one scale for the tensor) serves both GEMMs: the input gradient reads its rows,
+    // the weight gradient reads it k-major through transposing LDS reads (PlanesGemmArgs::ta) -- instead of a row split
+    // plus a transposing split (d_a is the largest tensor of the layer: 82 MB at the metric configuration)
+    const bool one_split = np == 2 && phase == 3 && planes_one_split();
     if (np == 2) {
         MMB_REQUIRE(p.x_absmax, "mmb_bilstm_layer_bwd: desc.x_absmax (saved by the forward call) is needed by the fp16 operand planes");
-        if (!db_partials && (phase & 2)) {   // general-size recurrence: max |d_a| was not tracked by the recurrence, one reduction here
+        if (!db_partials && ((phase & 2) || one_split)) {   // general-size recurrence: max |d_a| was not tracked by the recurrence, one reduction here
             MMB_HIP(hipMemsetAsync(scal, 0, sizeof(float), stream));
             hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, stream, p.d_a, static_cast<const float*>(nullptr), BT * 8 * H, scal);
             MMB_HIP(hipGetLastError());
@@ -543,18 +547,29 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
             damax_n = 1;
         }
     }
+    if (one_split) {
+        SplitRowsArgs sa{};
+        sa.src1 = p.d_a; sa.src2 = p.d_a; sa.R1 = (int)BT; sa.R = (int)BT; sa.C = 8 * H; sa.ld = 8 * H; sa.Cp = L.K8; sa.gate_H = 0;
+        sa.planes = daP; sa.Rpad = L.BTp;
+        sa.np = np; sa.inv_out = dainv; sa.tensor_absmax = damax; sa.tensor_absmax_n = damax_n;
+        if (int rc = planes_split_rows(sa, stream)) return rc;
+    }
     if (phase & 2) {
-    // d_a^T planes (8H x BT): A operand of the weight-gradient GEMM
-    SplitTArgs ta{};
-    ta.nseg = 1; ta.seg_ptr[0] = p.d_a; ta.seg_ld[0] = 8 * H; ta.seg_cols[0] = 8 * H; ta.seg_shift[0] = 0;
-    ta.R = (int)BT; ta.period = 1; ta.Rp = L.BTp; ta.Ctot = 8 * H; ta.planes = daT;
-    ta.np = np; ta.seg_absmax[0] = damax; ta.seg_absmax_n[0] = damax_n; ta.inv_out = daTinv;
-    if (int rc = planes_split_transpose(ta, stream)) return rc;
     PlanesGemmArgs gw{};
-    gw.A = daT;
+    if (one_split) {
+        gw.A = daP; gw.ta = 1; gw.a_inv = dainv;
+    } else {
+        // d_a^T planes (8H x BT): A operand of the weight-gradient GEMM
+        SplitTArgs ta{};
+        ta.nseg = 1; ta.seg_ptr[0] = p.d_a; ta.seg_ld[0] = 8 * H; ta.seg_cols[0] = 8 * H; ta.seg_shift[0] = 0;
+        ta.R = (int)BT; ta.period = 1; ta.Rp = L.BTp; ta.Ctot = 8 * H; ta.planes = daT;
+        ta.np = np; ta.seg_absmax[0] = damax; ta.seg_absmax_n[0] = damax_n; ta.inv_out = daTinv;
+        if (int rc = planes_split_transpose(ta, stream)) return rc;
+        gw.A = daT; gw.a_inv = daTinv;
+    }
     gw.B = xcT;
     gw.C = p.d_w_cat; gw.ldc = I + 2 * H; gw.M = 8 * H; gw.N = I + 2 * H; gw.K = L.BTp;
-    gw.np = np; gw.a_inv = daTinv; gw.b_inv = xcTinv;
+    gw.np = np; gw.b_inv = xcTinv;
     const bool ksplit = planes_plan_splitk(gw) > 1;   // its zeroing rides on the split pass below
     // [x | y_fwd(t-1) | y_rev(t+1)]^T planes ((I+2H) x BT): h_prev is y shifted by one step inside each sample
     SplitTArgs tx{};
@@ -583,7 +598,9 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
         sa.src1 = p.d_a; sa.src2 = p.d_a; sa.R1 = (int)BT; sa.R = (int)BT; sa.C = 8 * H; sa.ld = 8 * H; sa.Cp = L.K8; sa.gate_H = 0;
         sa.planes = daP;
         sa.np = np; sa.inv_out = dainv;
-        if (int rc = planes_split_rows(sa, stream)) return rc;
+        if (!one_split) {
+            if (int rc = planes_split_rows(sa, stream)) return rc;
+        }
         SplitTArgs tw{};
         tw.nseg = 1; tw.seg_ptr[0] = p.w_ih[0]; tw.seg_ld[0] = I; tw.seg_cols[0] = I; tw.seg_shift[0] = 0;
         tw.stack_ptr = p.w_ih[1]; tw.stack_R1 = 4 * H;

@@ -138,6 +138,10 @@ __global__ __launch_bounds__(256) void split_rows16_kernel(const SplitRowsArgs a
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
         if (seg == 0) {
+            if (a.tensor_absmax) {   // one scale for the whole tensor (see SplitRowsArgs)
+                amax = 0.f;
+                for (int i = 0; i < a.tensor_absmax_n; ++i) amax = fmaxf(amax, a.tensor_absmax[i]);
+            }
             const float s = pow2_scale(amax);
             sc[rl] = s;
             if (dr < a.R) a.inv_out[dr] = 1.0f / s;
@@ -202,7 +206,12 @@ __global__ __launch_bounds__(256) void split_rows16_reg_kernel(const SplitRowsAr
     amax = fmaxf(amax, __shfl_xor(amax, 2));
     if ((lane & 3) == 0) wmax[wave][rl] = amax;
     __syncthreads();
-    const float rmax = fmaxf(fmaxf(wmax[0][rl], wmax[1][rl]), fmaxf(wmax[2][rl], wmax[3][rl]));
+    float rmax = fmaxf(fmaxf(wmax[0][rl], wmax[1][rl]), fmaxf(wmax[2][rl], wmax[3][rl]));
+    if (a.tensor_absmax) {   // one scale for the whole tensor, from the producer's bound (every lane reduces the short list)
+        float tm = 0.f;
+        for (int i = 0; i < a.tensor_absmax_n; ++i) tm = fmaxf(tm, a.tensor_absmax[i]);
+        rmax = tm;
+    }
     const float s = pow2_scale(rmax);
     if (wave == 0 && (lane & 3) == 0 && dr < a.R) {
         a.inv_out[dr] = 1.0f / s;
@@ -299,10 +308,26 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTArgs a
 // Operands are passed (B fragment, A fragment): lane (r, kg) then holds C[m = r][n = 4*kg .. 4*kg+3] -- float4 stores.
 // Workgroup ids are cut into 8 contiguous chunks, one per XCD (ids go round-robin over XCDs), so that the
 // workgroups that share an A row panel (same tile row, neighbouring tile columns) also share an L2.
-template <int WM, int WN, int MT, int NT, int NP, int STAGES>
+typedef short v4s_t __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short s8v_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 tr_frag(const char* lo, const char* hi) {
+    const v4s_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(lo));
+    const v4s_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(hi));
+    const s8v_t t = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, t);
+}
+
+// TA: the A operand is given k-major (tiled planes of the (K x M) matrix, e.g. d_a (B*T x 8H) for the weight gradient
+// d_a^T . [x | h_prev]): per 32-deep K step the stage holds, in the BM/16 KiB the row-major form uses for BM rows, the
+// 2 x BM/32 chunks [16 k rows][32 columns] of the tile, and an A fragment (16 columns m, 8 consecutive k per lane) is two
+// transposing reads ds_read_b64_tr_b16 (4 k rows each).  With the planes' slot XOR (bit 3 of the row) those reads are
+// conflict-free as well: the two 16-lane groups of a half read rows r0..r0+3 and r0+8..r0+11 of one chunk, i.e. the same
+// 64-B sub-rows with slots that differ by the XOR.
+template <int WM, int WN, int MT, int NT, int NP, int STAGES, bool TA = false>
 __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g, const int kchunk, const int tiles_n,
                                                           const int ntiles) {
     static_assert(WM * WN == 8, "8 waves");
+    static_assert(!TA || (NP == 2 && (WM * MT * 16) % 32 == 0), "k-major A: fp16 planes, BM a multiple of 32");
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, RT = BM + BN;  // rows per plane image
     constexpr int STAGE = NP * RT * 64;                                // bytes per stage
     constexpr int NDMA = NP * RT / 16;                                 // 1-KiB wave-instructions per stage
@@ -327,15 +352,24 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
     // DMA piece q of a stage = chunk (plane q / (RT/16), row block q % (RT/16)) of the tiled planes: 1 KiB contiguous
     // in global memory, copied lane-linear (the swizzle is already in the data); K tile kt follows at +NP KiB.
     const int nkt = g.K / 32, nrbA = (g.M + 15) / 16, nrbB = (g.N + 15) / 16;
+    const int nctA = (g.M + 31) / 32;   // TA: 32-column chunks per row block of the k-major A planes
     const char* src[PER_WAVE];
+    int adv[PER_WAVE];                  // bytes to the same piece of the next K step
 #pragma unroll
     for (int k = 0; k < PER_WAVE; ++k) {
         const int q = min(wave + 8 * k, NDMA - 1);
         const int plane = q / (RT / 16), blk = q % (RT / 16);
         const char* base;
         size_t rbk;
+        adv[k] = NP * 1024;
         if (blk < BM / 16) {
             base = reinterpret_cast<const char*>(g.A);
+            if (TA) {   // chunk (k row block kb/16 + rb2, column chunk m0/32 + ct)
+                const int rb2 = blk / (BM / 32), ct = blk % (BM / 32);
+                src[k] = base + (((size_t)(kb / 16 + rb2) * nctA + min(m0 / 32 + ct, nctA - 1)) * NP + plane) * 1024 + lane * 16;
+                adv[k] = 2 * nctA * NP * 1024;
+                continue;
+            }
             rbk = (size_t)min(((g.dbg & 1) ? 0 : m0 / 16) + blk, nrbA - 1);   // dbg 1 (timing-only): every tile reads A tile 0
         } else {
             base = reinterpret_cast<const char*>(g.B);
@@ -351,7 +385,7 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
             const int q = min(wave + 8 * k, NDMA - 1);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[k],
                                              (__attribute__((address_space(3))) void*)(smem + stage * STAGE + q * 1024), 16, 0, 0);
-            src[k] += NP * 1024;
+            src[k] += adv[k];
         }
     };
 
@@ -366,6 +400,12 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
     for (int i = 0; i < MT; ++i) {
         const int tr = (wm * MT + i) * 16 + r;
         offA[i] = tr * 64 + ((kg ^ pl_swz(tr)) << 4);
+        if (TA) {
+            // lane 4q+p of a 16-lane group supplies k row 8(kg&1)+q (the second read: +4) and columns 4p..4p+3 of the m tile
+            const int ml = (wm * MT + i) * 16, ct = ml >> 5, hsel = (ml >> 4) & 1;
+            const int q4 = (lane >> 2) & 3, p4 = lane & 3, row = 8 * (kg & 1) + q4;
+            offA[i] = ((kg >> 1) * (BM / 32) + ct) * 1024 + row * 64 + (((2 * hsel + (p4 >> 1)) ^ pl_swz(row)) << 4) + (p4 & 1) * 8;
+        }
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -400,7 +440,10 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) a[i][s] = *reinterpret_cast<const bf16x8*>(img + s * (RT * 64) + offA[i]);
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (TA) a[i][s] = tr_frag(img + s * (RT * 64) + offA[i], img + s * (RT * 64) + offA[i] + 4 * 64);
+                else a[i][s] = *reinterpret_cast<const bf16x8*>(img + s * (RT * 64) + offA[i]);
+            }
 #pragma unroll
             for (int j = 0; j < NT; ++j) b[j][s] = *reinterpret_cast<const bf16x8*>(img + s * (RT * 64) + offB[j]);
         }
@@ -418,17 +461,17 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
         if (!(g.dbg & 2)) {
             if constexpr (NP == 3) {
                 // bf16 planes: cross terms of order <= 2, smallest first: (a plane, b plane)
-                constexpr int TA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
+                constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
                 for (int term = 0; term < 6; ++term)
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][TB[term]], a[i][TA[term]], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][TB[term]], a[i][PA[term]], acc[i][j], 0, 0, 0);
             } else {
                 // scaled fp16 planes: a0 b1 + a1 b0 + a0 b0 (the dropped a1 b1 is below 2^-22 relative)
-                constexpr int TA[3] = {0, 1, 0}, TB[3] = {1, 0, 0};
+                constexpr int PA[3] = {0, 1, 0}, TB[3] = {1, 0, 0};
 #pragma unroll
                 for (int term = 0; term < 3; ++term)
 #pragma unroll
@@ -436,7 +479,7 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, b[j][TB[term]]),
-                                                                               __builtin_bit_cast(half8, a[i][TA[term]]), acc[i][j], 0, 0, 0);
+                                                                               __builtin_bit_cast(half8, a[i][PA[term]]), acc[i][j], 0, 0, 0);
             }
         }
         // group 0 must have landed its pieces of tile t+1 before it reads them; its newest batch (tile t+2) may stay in flight
@@ -479,7 +522,7 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int mrow = min(m0 + (wm * MT + i) * 16 + r, g.M - 1);
-        const float sa = (NP == 2 && g.a_inv) ? g.a_inv[mrow] : 1.0f;
+        const float sa = (NP == 2 && g.a_inv) ? g.a_inv[TA ? 0 : mrow] : 1.0f;
 #pragma unroll
         for (int j = 0; j < NT; ++j) *reinterpret_cast<f4*>(stg + r * LDW + j * 16 + 4 * kg) = acc[i][j] * (sb[j] * sa) + bv[j];
         const int mw0 = m0 + (wm * MT + i) * 16;
@@ -517,7 +560,7 @@ int planes_split_rows(const SplitRowsArgs& a, hipStream_t stream) {
     ProfScope ps_(MMB_K_SPLIT, stream);
     if (a.np == 2) {
         const int nkt = a.Cp / 32;
-        const dim3 grid((a.R + 15) / 16);
+        const dim3 grid(((a.Rpad > a.R ? a.Rpad : a.R) + 15) / 16);
         if (nkt <= 8) hipLaunchKernelGGL(split_rows16_reg_kernel<2>, grid, dim3(256), 0, stream, a);
         else if (nkt <= 16) hipLaunchKernelGGL(split_rows16_reg_kernel<4>, grid, dim3(256), 0, stream, a);
         else if (nkt <= 32) hipLaunchKernelGGL(split_rows16_reg_kernel<8>, grid, dim3(256), 0, stream, a);
@@ -535,7 +578,7 @@ int planes_split_transpose(const SplitTArgs& a, hipStream_t stream) {
     return MMB_OK;
 }
 
-template <int WM, int WN, int MT, int NT, int NP>
+template <int WM, int WN, int MT, int NT, int NP, bool TA = false>
 static int launch_planes_np(const PlanesGemmArgs& g, hipStream_t stream) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     // The kernel also runs with 3 stages (counted vmcnt waits, the fp16 tiles leave room for it), but measured it brings
@@ -543,7 +586,7 @@ static int launch_planes_np(const PlanesGemmArgs& g, hipStream_t stream) {
     // the latency of a DMA batch.
     constexpr int STAGES = 2;
     const size_t lds = (size_t)STAGES * NP * (BM + BN) * 64;
-    auto kern = gemm_planes_kernel<WM, WN, MT, NT, NP, STAGES>;
+    auto kern = gemm_planes_kernel<WM, WN, MT, NT, NP, STAGES, TA>;
     static PerDeviceOnce attr;
     if (attr.pending()) {
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -560,7 +603,19 @@ static int launch_planes_np(const PlanesGemmArgs& g, hipStream_t stream) {
 
 template <int WM, int WN, int MT, int NT>
 static int launch_planes(const PlanesGemmArgs& g, hipStream_t stream) {
+    if constexpr ((WM * MT * 16) % 32 == 0) {
+        if (g.ta) return launch_planes_np<WM, WN, MT, NT, 2, true>(g, stream);
+    }
     return g.np == 2 ? launch_planes_np<WM, WN, MT, NT, 2>(g, stream) : launch_planes_np<WM, WN, MT, NT, 3>(g, stream);
+}
+
+bool planes_one_split() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MMB_PLANES_ONE_SPLIT");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v == 1;
 }
 
 int planes_terms() {
@@ -609,11 +664,12 @@ static void planes_choose(const PlanesGemmArgs& g, int& best, int& best_s) {
     double best_cost = 1e300;
     for (int c = 0; c < N_PLANES_CFGS; ++c)
         for (int s = 1; s <= 32; ++s) {
+            if (g.ta && (PLANES_CFGS[c].wm * PLANES_CFGS[c].mt * 16) % 32) break;   // k-major A: BM a multiple of 32
             if (s > 1 && g.K / s < 512) break;
             const double cost = planes_cost(g, PLANES_CFGS[c], s);
             if (cost < best_cost) { best_cost = cost; best = c; best_s = s; }
         }
-    if (g_planes_force >= 0) {
+    if (g_planes_force >= 0 && !(g.ta && (PLANES_CFGS[(g_planes_force / 100) % N_PLANES_CFGS].wm * PLANES_CFGS[(g_planes_force / 100) % N_PLANES_CFGS].mt * 16) % 32)) {
         best = (g_planes_force / 100) % N_PLANES_CFGS;
         if (g_planes_force % 100 > 0) best_s = g_planes_force % 100;
     }
@@ -637,6 +693,7 @@ int planes_gemm(const PlanesGemmArgs& g_, hipStream_t stream) {
     }
     g.dbg = dbg;
     if (g.np != 2) g.np = 3;
+    MMB_REQUIRE(!g.ta || (g.np == 2 && g.K % 32 == 0), "planes_gemm: a k-major A operand needs the fp16 planes and K %% 32 == 0");
     int best, best_s;
     planes_choose(g, best, best_s);
     if (verbose)
@@ -685,5 +742,40 @@ extern "C" int mmb_gemm_nt_planes(const float* A, const float* Bm, float* C, con
     PlanesGemmArgs g{};
     g.A = aP; g.B = bP;
     g.C = C; g.ldc = N; g.bias = bias; g.M = M; g.N = N; g.K = Kp; g.np = np; g.a_inv = a_inv; g.b_inv = b_inv;
+    return planes_gemm(g, stream);
+}
+
+// C (M,N) = At (K,M)^T . B (N,K)^T: the A operand is split ONCE row-major with a tensor-wide scale and read k-major by the
+// kernel (transposing LDS reads), as the LSTM weight gradient does with d_a (tests / tools).  M % 4 == 0, K % 4 == 0;
+// ws: planes_bytes(roundup(K,32), roundup(M,32)) + planes_bytes(N, roundup(K,32)) + roundup(4*(K+N),256) + 256 bytes
+// = 6 * (roundup(K,32) * roundup(M,32) + roundup(N,16) * roundup(K,32)) + ...
+extern "C" int mmb_gemm_tn_planes(const float* At, const float* Bm, float* C, int M, int N, int K, void* ws, size_t ws_bytes,
+                                  int device, void* stream_) {
+    using namespace mmb;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MMB_REQUIRE(At && Bm && C && ws && M > 0 && N > 0 && K > 0 && K % 4 == 0 && M % 4 == 0, "mmb_gemm_tn_planes: bad argument");
+    const int Kp = (K + 31) / 32 * 32, Mp = (M + 31) / 32 * 32;
+    const size_t inv_bytes = ((size_t)(K + N) * sizeof(float) + 255) / 256 * 256;
+    MMB_REQUIRE(ws_bytes >= planes_bytes(Kp, Mp) + planes_bytes(N, Kp) + inv_bytes + 256, "mmb_gemm_tn_planes: workspace too small");
+    MMB_HIP(hipSetDevice(device));
+    char* w = static_cast<char*>(ws);
+    bf16_t* aP = reinterpret_cast<bf16_t*>(w);
+    bf16_t* bP = reinterpret_cast<bf16_t*>(w + planes_bytes(Kp, Mp));
+    float* a_inv = reinterpret_cast<float*>(w + planes_bytes(Kp, Mp) + planes_bytes(N, Kp));
+    float* b_inv = a_inv + K;
+    float* amax = reinterpret_cast<float*>(w + planes_bytes(Kp, Mp) + planes_bytes(N, Kp) + inv_bytes);
+    MMB_HIP(hipMemsetAsync(amax, 0, sizeof(float), stream));
+    SplitRowsArgs sa{};
+    sa.src1 = At; sa.src2 = At; sa.R1 = K; sa.R = K; sa.C = M; sa.ld = M; sa.Cp = Mp; sa.planes = aP; sa.np = 2; sa.inv_out = a_inv;
+    sa.absmax_out = amax;                                   // pass 1 (per-row scales, discarded): finds max |At|
+    if (int rc = planes_split_rows(sa, stream)) return rc;
+    sa.absmax_out = nullptr; sa.tensor_absmax = amax; sa.tensor_absmax_n = 1; sa.Rpad = Kp;
+    if (int rc = planes_split_rows(sa, stream)) return rc;  // pass 2: one scale for the tensor, zero rows up to Kp
+    SplitRowsArgs sb{};
+    sb.src1 = Bm; sb.src2 = Bm; sb.R1 = N; sb.R = N; sb.C = K; sb.ld = K; sb.Cp = Kp; sb.planes = bP; sb.np = 2; sb.inv_out = b_inv;
+    if (int rc = planes_split_rows(sb, stream)) return rc;
+    PlanesGemmArgs g{};
+    g.A = aP; g.B = bP; g.ta = 1;
+    g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = Kp; g.np = 2; g.a_inv = a_inv; g.b_inv = b_inv;
     return planes_gemm(g, stream);
 }

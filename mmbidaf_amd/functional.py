@@ -372,6 +372,22 @@ def gemm_nt_planes(a, b, bias=None):
     return c
 
 
+def gemm_tn_planes(at, b):
+    """C (M,N) = at (K,M)^T . b (N,K)^T with `at` split once row-major and read k-major by the kernel (tests / tools)."""
+    lib = _lib.load()
+    _require_gpu(at, b)
+    at, b = _f32c(at), _f32c(b)
+    K, M = at.shape
+    N = b.shape[0]
+    Kp, Mp = (K + 31) // 32 * 32, (M + 31) // 32 * 32
+    ws = torch.empty(6 * (Kp * Mp + (N + 15) // 16 * 16 * Kp) + (4 * (K + N) + 255) // 256 * 256 + 256,
+                     device=at.device, dtype=torch.uint8)
+    c = torch.empty(M, N, device=at.device, dtype=torch.float32)
+    rc = lib.mmb_gemm_tn_planes(_ptr(at), _ptr(b), _ptr(c), M, N, K, _ptr(ws), ws.numel(), at.device.index, _stream())
+    _lib.check(rc, "mmb_gemm_tn_planes")
+    return c
+
+
 # --------------------------------------------------------------------------------------- Embedding (row N2)
 class _EmbeddingFn(torch.autograd.Function):
     """proj (no bias) + 2-layer highway of the reference's Embedding (layers/encoding.py:9-59) after its dropout:

@@ -66,6 +66,18 @@ def test_gemm_operand_planes(M, N, K):
     close(got, ref, "planes gemm", tol=2e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(800, 400, 25600), (800, 500, 1000), (96, 40, 36), (32, 8, 4), (2048, 1536, 3204), (160, 300, 700)])
+def test_gemm_operand_planes_k_major(M, N, K):
+    """the k-major A operand (one tensor-scaled row split, transposing LDS reads): the LSTM weight-gradient form."""
+    from mmbidaf_amd import functional as MF
+    g = torch.Generator().manual_seed(M + N + K)
+    at, b = torch.randn(K, M, generator=g), torch.randn(N, K, generator=g)
+    at *= torch.exp(2.0 * torch.randn(K, 1, generator=g))          # rows of very different magnitude under one scale
+    ref = (at.double().t() @ b.double().t()).float()
+    got = MF.gemm_tn_planes(at.to(dev()), b.to(dev()))
+    close(got, ref, "planes gemm k-major", tol=2e-5)
+
+
 def test_gemm_modes_agree():
     """the exact-f32 MFMA kernels and the split-bf16 kernels are interchangeable to fp32 accuracy."""
     from mmbidaf_amd import _lib, functional as MF
