@@ -178,7 +178,7 @@ def main():
     # gradient exchange: SUM over ranks (the reference's loss is a sum over samples), bucketed in backward order and
     # launched from grad hooks so that it overlaps the rest of the backward pass
     from mmbidaf_amd import functional as MF
-    sync = ddp.FlatGradAllReduce(params, buckets=ddp.region_buckets(region), overlap=True, stream_fn=MF.side_stream)
+    sync = ddp.FlatGradAllReduce(params, buckets=ddp.region_buckets(region), overlap=True, defer_fn=MF.defer_grad_work)
     sync.broadcast_parameters()
     batch = synth.make_batch(a.config, rank=rank, ragged=a.ragged, device=dev, batch=B)
     xs = [batch[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]  # they come from trainable embeddings

@@ -197,6 +197,14 @@ int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* descs, int n, int device, void
  * Problems that do not run on the operand planes (no ws, or I / H not multiples of 4) do all their work in phase 1. */
 int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* descs, int n, int phase, int device, void* stream);
 
+/* A stream restricted to the compute units whose bits are set in mask (n_words x 32 bits; the HSA queue CU mask:
+ * consecutive bit indices rotate over the XCDs, then over the shader engines of an XCD).  The host side puts the
+ * weight-gradient phase of mmb_bilstm_layer_bwd_phase on such a stream (half of every XCD) so that it runs beside the
+ * NEXT layer's recurrence (2*B of the 256 CUs busy) without ever taking a CU the recurrence needs.  The reference has no
+ * counterpart (single stream, train.py:136-152). */
+int mmb_stream_create_cu_mask(int device, const uint32_t* mask, int n_words, void** stream_out);
+int mmb_stream_destroy(int device, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Decoder step.  Replaces MultimodalAttentionDecoder.forward (reference
  * layers/attention.py:145-186) for one decode step of the whole batch, and its autograd: one kernel launch per

@@ -112,3 +112,25 @@ extern "C" const char* mmb_kernel_name(int kernel_id) {
 
 extern "C" int mmb_version(void) { return MMB_VERSION; }
 extern "C" const char* mmb_last_error(void) { return mmb::err_buf(); }
+
+// A stream whose kernels may only run on the compute units whose bits are set in `mask` (n_words x 32 bits, HSA queue CU
+// mask; consecutive bit indices rotate over the XCDs, then over the shader engines, so a contiguous half of the bits is
+// half of every XCD).  Used for the side stream that carries the weight-gradient GEMMs beside the recurrences: the
+// recurrence kernels then always find their CUs free.
+extern "C" int mmb_stream_create_cu_mask(int device, const uint32_t* mask, int n_words, void** stream_out) {
+    MMB_REQUIRE(mask && n_words >= 1 && n_words <= 32 && stream_out, "mmb_stream_create_cu_mask: bad argument");
+    bool any = false;
+    for (int i = 0; i < n_words; ++i) any = any || mask[i] != 0;
+    MMB_REQUIRE(any, "mmb_stream_create_cu_mask: empty mask");
+    MMB_HIP(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    MMB_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask));
+    *stream_out = s;
+    return MMB_OK;
+}
+extern "C" int mmb_stream_destroy(int device, void* stream) {
+    MMB_REQUIRE(stream, "mmb_stream_destroy: null stream");
+    MMB_HIP(hipSetDevice(device));
+    MMB_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return MMB_OK;
+}

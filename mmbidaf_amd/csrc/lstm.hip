@@ -536,10 +536,13 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
     // ONE split of d_a (row-major planes, one scale for the tensor) serves both GEMMs: the input gradient reads its rows,
     // the weight gradient reads it k-major through transposing LDS reads (PlanesGemmArgs::ta) -- instead of a row split
     // plus a transposing split (d_a is the largest tensor of the layer: 82 MB at the metric configuration)
-    const bool one_split = np == 2 && phase == 3 && planes_one_split();
+    // (split calls: phase 1 makes the planes when there is an input gradient to compute, and phase 2 -- which always follows
+    //  phase 1 of the same descriptors -- then finds them in the workspace)
+    const bool one_split = np == 2 && planes_one_split();
+    const bool split_now = one_split && (phase == 3 || (phase == 1 && p.d_x) || (phase == 2 && !p.d_x));
     if (np == 2) {
         MMB_REQUIRE(p.x_absmax, "mmb_bilstm_layer_bwd: desc.x_absmax (saved by the forward call) is needed by the fp16 operand planes");
-        if (!db_partials && ((phase & 2) || one_split)) {   // general-size recurrence: max |d_a| was not tracked by the recurrence, one reduction here
+        if (!db_partials && ((phase & 2) || split_now)) {   // general-size recurrence: max |d_a| was not tracked by the recurrence, one reduction here
             MMB_HIP(hipMemsetAsync(scal, 0, sizeof(float), stream));
             hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, stream, p.d_a, static_cast<const float*>(nullptr), BT * 8 * H, scal);
             MMB_HIP(hipGetLastError());
@@ -547,7 +550,7 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
             damax_n = 1;
         }
     }
-    if (one_split) {
+    if (split_now) {
         SplitRowsArgs sa{};
         sa.src1 = p.d_a; sa.src2 = p.d_a; sa.R1 = (int)BT; sa.R = (int)BT; sa.C = 8 * H; sa.ld = 8 * H; sa.Cp = L.K8; sa.gate_H = 0;
         sa.planes = daP; sa.Rpad = L.BTp;

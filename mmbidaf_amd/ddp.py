@@ -71,12 +71,12 @@ class FlatGradAllReduce:
     buckets: optional list of parameter lists (see region_buckets); default one bucket = one all-reduce.
     overlap=True: every bucket is packed and all-reduced asynchronously the moment backward has produced its last
     gradient (post-accumulate-grad hooks); __call__ then only launches what is still missing, waits and copies back.
-    stream_fn: see __init__ (gradients finished on a side stream).
+    stream_fn / defer_fn: see __init__ (gradients finished on a side stream).
 
     The reduced values are copied back into the tensors autograd produced (p.grad is never rebound to a view of the
     flat buffer); a parameter without a gradient contributes zeros and keeps grad None."""
 
-    def __init__(self, params, group=None, average=False, buckets=None, overlap=False, stream_fn=None):
+    def __init__(self, params, group=None, average=False, buckets=None, overlap=False, stream_fn=None, defer_fn=None):
         params = [p for p in params if p.requires_grad]
         if buckets is None:
             buckets = [params]
@@ -95,6 +95,10 @@ class FlatGradAllReduce:
         # weight-gradient GEMMs run on a side stream): packing + all-reduce are enqueued there, behind them, so that the
         # main stream is not held up
         self.stream_fn = stream_fn
+        # defer_fn(device, fn): runs fn(stream) on the stream -- and at the moment -- the gradients of the bucket become
+        # final (mmbidaf_amd.functional.defer_grad_work: the weight-gradient phase may itself be deferred to run beside the
+        # next layer's recurrence; the bucket's packing + all-reduce are queued right behind it)
+        self.defer_fn = defer_fn
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=self.params[0].device)
@@ -125,12 +129,18 @@ class FlatGradAllReduce:
             self._launch(bi)
 
     def _launch(self, bi):
-        if self.stream_fn is not None and self.flat.is_cuda:
+        if self.defer_fn is not None and self.flat.is_cuda:
+            self.work[bi] = False        # claimed: the launch is queued behind the kernels that fill the bucket
+            self.defer_fn(self.flat.device, lambda stream, bi=bi: self._launch_on(bi, stream))
+        elif self.stream_fn is not None and self.flat.is_cuda:
             s = self.stream_fn(self.flat.device)
             s.wait_stream(torch.cuda.current_stream(self.flat.device))
-            with torch.cuda.stream(s):
-                self._launch_here(bi)
+            self._launch_on(bi, s)
         else:
+            self._launch_here(bi)
+
+    def _launch_on(self, bi, stream):
+        with torch.cuda.stream(stream):
             self._launch_here(bi)
 
     def _launch_here(self, bi):
@@ -165,6 +175,7 @@ class FlatGradAllReduce:
                 self._launch(bi)
         with torch.no_grad():
             for bi, b in enumerate(self.buckets):
+                assert self.work[bi] is not False, "a deferred bucket launch did not run before the gradients were consumed"
                 self.work[bi].wait()          # the current stream waits for the collective (no host sync with nccl)
                 self.work[bi] = None
                 if self.average:

@@ -20,40 +20,107 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# ---- second stream for work that is off the critical path of the backward pass (weight-gradient GEMMs and their split
-# passes), so that it can run under the recurrences, which occupy only 2*B of the 256 CUs.  OFF by default
-# (MMB_SIDE_STREAM=1 enables it): measured on cfg2 (profiles/r02_side_stream.md) the side stream's GEMMs mostly land
-# beside the attention backward and the next layer's own GEMMs -- two full-chip kernels slow each other down -- and the
-# step got 2 % SLOWER (3.55 vs 3.48 ms); the recurrences leave 64-128 CUs free for ~240 us each, room for at most
-# ~0.15 ms of the 1.2 ms of GEMM + split work per step.
+# ---- second stream for work that is off the critical path of the backward pass: the weight-gradient phase of the LSTM
+# layers (2 split passes, 1 GEMM, 1 unpack per encoder), which can run under the recurrences -- these occupy only 2*B
+# workgroups of the 256 CUs, and a GEMM workgroup cannot share a CU with a recurrence workgroup (registers), so the two
+# kernels partition the chip by themselves.  MMB_SIDE_STREAM selects the mode:
+#   0  everything on the caller's stream;
+#   1  phase 2 goes to the side stream right behind phase 1 of the same layer (first attempt; 2-3 % SLOWER than mode 0: the
+#      side work of the layer below the attention lands beside the attention backward -- two full-chip kernels time-slice);
+#   2  (default) phase 2 is DEFERRED until the next LSTM layer's backward call, whose first kernel is a recurrence; whatever
+#      is still deferred when autograd finishes (the input encoders' phase 2) runs on the caller's stream.  cfg2: 3.26 ->
+#      3.12 ms/step (profiles/r02_side_stream.md).
+# MMB_SIDE_CU_MASK=half|lo:hi restricts the side stream to a set of CUs (mmb_stream_create_cu_mask).  Measured: ANY stream
+# made by hipExtStreamCreateWithCUMask -- even with all 256 bits set -- runs the step at 5.0-5.3 ms, so it is not used.
 _side_streams = {}
+_side_handles = {}
+_deferred = {}            # device index -> list of (fn(stream), tensors the fn touches)
 _join_pending = set()
-_USE_SIDE = os.environ.get("MMB_SIDE_STREAM", "0") == "1"
+_SIDE_MODE = int(os.environ.get("MMB_SIDE_STREAM", "2"))
+_USE_SIDE = _SIDE_MODE != 0
+
+
+def _dev_index(device):
+    d = torch.device(device)
+    return d.index if d.index is not None else torch.cuda.current_device()
 
 
 def side_stream(device):
     """The per-device side stream (created on first use)."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = _dev_index(device)
     s = _side_streams.get(key)
     if s is None:
-        # LOWEST priority: the dispatcher then hands CUs to the main stream's (critical-path) kernels first and the side
-        # stream's work only fills what they leave free (MMB_SIDE_PRIORITY overrides the value)
-        lo, hi = torch.cuda.Stream.priority_range()          # (least, greatest); numerically greater = lower priority
-        pr = int(os.environ.get("MMB_SIDE_PRIORITY", lo))
-        s = _side_streams[key] = torch.cuda.Stream(device=key, priority=pr)
+        mask = os.environ.get("MMB_SIDE_CU_MASK", "none")
+        if mask != "none":
+            # the upper half of the CU-mask bits = half of the CUs of every XCD and shader engine
+            n_cu = torch.cuda.get_device_properties(key).multi_processor_count
+            words = (ctypes.c_uint32 * ((n_cu + 31) // 32))()
+            lo, hi = (n_cu // 2, n_cu) if mask == "half" else tuple(int(v) for v in mask.split(":"))
+            for b in range(lo, hi):
+                words[b // 32] |= 1 << (b % 32)
+            handle = ctypes.c_void_p()
+            lib = _lib.load()
+            _lib.check(lib.mmb_stream_create_cu_mask(key, words, len(words), ctypes.byref(handle)), "mmb_stream_create_cu_mask")
+            _side_handles[key] = handle
+            s = torch.cuda.ExternalStream(handle.value, device=key)
+        else:
+            # LOWEST priority: the dispatcher then hands CUs to the main stream's (critical-path) kernels first
+            lo, hi = torch.cuda.Stream.priority_range()          # (least, greatest); numerically greater = lower priority
+            pr = int(os.environ.get("MMB_SIDE_PRIORITY", lo))
+            s = torch.cuda.Stream(device=key, priority=pr)
+        _side_streams[key] = s
     return s
 
 
+def flush_deferred(device, to_side=True):
+    """Enqueue the deferred weight-gradient work of `device`: on the side stream, ordered behind everything the current
+    stream holds so far (to_side=True), or on the current stream itself."""
+    key = _dev_index(device)
+    todo = _deferred.get(key)
+    if not todo:
+        return
+    _deferred[key] = []
+    main = torch.cuda.current_stream(key)
+    if to_side:
+        side = side_stream(key)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for fn, tensors in todo:
+                fn(side)
+                for t in tensors:
+                    t.record_stream(side)
+    else:
+        for fn, _ in todo:
+            fn(main)
+
+
+def defer_grad_work(device, fn):
+    """Run fn(stream) where and when the parameter gradients produced so far are final (ddp.FlatGradAllReduce(defer_fn=...)):
+    inside a backward pass in mode 2 it joins the deferred queue, right behind the weight-gradient phase that fills the
+    bucket; otherwise it runs now, on the side stream, ordered behind the current stream."""
+    key = _dev_index(device)
+    task = getattr(torch._C, "_current_graph_task_id", lambda: -1)()
+    if _SIDE_MODE == 2 and task is not None and task >= 0:
+        _deferred.setdefault(key, []).append((fn, []))
+        _join_at_end_of_backward(key)
+    else:
+        s = side_stream(key)
+        s.wait_stream(torch.cuda.current_stream(key))
+        fn(s)
+
+
 def join_side_stream(device=None):
-    """Make the current stream wait for everything enqueued on the side stream so far."""
-    for key, s in _side_streams.items():
-        if device is None or torch.device(device).index == key:
+    """Make the current stream wait for everything enqueued on the side stream so far (deferred work included)."""
+    for key, s in list(_side_streams.items()):
+        if device is None or _dev_index(device) == key:
+            flush_deferred(key, to_side=False)
             torch.cuda.current_stream(key).wait_stream(s)
 
 
 def _join_at_end_of_backward(dev_index):
-    """Queue an engine callback (one per backward pass and device): when autograd has finished, the main stream waits for
-    the side stream, so whoever consumes the gradients next (optimizer, clipping, all-reduce wait) is ordered behind them."""
+    """Queue an engine callback (one per backward pass and device): when autograd has finished, what is still deferred runs
+    on the main stream and the main stream waits for the side stream, so whoever consumes the gradients next (optimizer,
+    clipping, all-reduce wait) is ordered behind them."""
     task = getattr(torch._C, "_current_graph_task_id", lambda: None)()
     key = (dev_index, task)
     if task is not None and task >= 0 and key in _join_pending:
@@ -61,7 +128,9 @@ def _join_at_end_of_backward(dev_index):
 
     def cb():
         _join_pending.discard(key)
-        torch.cuda.current_stream(dev_index).wait_stream(_side_streams[dev_index])
+        flush_deferred(dev_index, to_side=False)
+        if dev_index in _side_streams:
+            torch.cuda.current_stream(dev_index).wait_stream(_side_streams[dev_index])
     if task is not None and task >= 0:
         _join_pending.add(key)
         if len(_join_pending) > 64:          # passes that died before their callback ran
@@ -299,23 +368,37 @@ class _BiLSTMLayerFn(torch.autograd.Function):
             d.hn_pos = _ptr(ctx.hn_pos[i])
             d.x_absmax = _ptr(x_absmax)
             d.B, d.T, d.I, d.H = B, T, I, H
-            keep += [d_y, d_hn, d_a, d_w_cat, ws]
+            keep += [d_y, d_hn, d_a, d_w_cat, ws, d_w_ih, d_w_hh]
             results += [d_x, d_w_ih[0], d_w_hh[0], d_b[0], None, d_w_ih[1], d_w_hh[1], d_b[1], None]
         # (not when a parameter already holds a gradient: AccumulateGrad then adds on the main stream right after this
         #  function returns, i.e. possibly before the side stream has written the new one)
         if _USE_SIDE and not torch.is_grad_enabled() and all(p.grad is None for p in ctx.params):
             # BPTT + input gradients on the current stream (the critical path: the next layer's backward waits for d_x);
-            # weight / bias gradients on the side stream, ordered behind this call's recurrence, overlapping whatever
-            # the main stream does next.  Every buffer the side stream touches is marked so that the caching allocator
-            # does not recycle it early; the main stream re-joins once, when autograd has finished.
-            main, side = torch.cuda.current_stream(dev), side_stream(dev)
-            _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 1, dev.index, main.cuda_stream), "mmb_bilstm_layer_bwd_phase(1)")
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 2, dev.index, side.cuda_stream), "mmb_bilstm_layer_bwd_phase(2)")
-                d_b_dup = d_b_flat.clone()
-            for t in keep + list(sv) + [d_b_flat, d_b_dup] + [r for r in results if r is not None]:
-                if t is not None and t.is_cuda:
+            # weight / bias gradients on the side stream.  Every buffer the side stream touches is marked so that the
+            # caching allocator does not recycle it early; the main stream re-joins once, when autograd has finished.
+            main = torch.cuda.current_stream(dev)
+            # (the whole buffers, never the views handed to autograd: AccumulateGrad keeps a gradient it is given only while
+            #  nobody else holds that tensor object, and would otherwise copy it -- before the side stream has filled it)
+            touched = [t for t in keep + list(sv) + [d_b_flat] if t is not None and t.is_cuda]
+            if _SIDE_MODE == 2:
+                # the work deferred by the previous layer starts now, beside this layer's recurrence (first kernel of phase 1)
+                flush_deferred(dev, to_side=True)
+                _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 1, dev.index, main.cuda_stream), "mmb_bilstm_layer_bwd_phase(1)")
+                d_b_dup = torch.empty_like(d_b_flat)
+
+                def phase2(stream, descs=descs, n=n, d_b_dup=d_b_dup, d_b_flat=d_b_flat, dev=dev):
+                    _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 2, dev.index, stream.cuda_stream), "mmb_bilstm_layer_bwd_phase(2)")
+                    with torch.cuda.stream(stream):
+                        d_b_dup.copy_(d_b_flat)
+                _deferred.setdefault(dev.index, []).append((phase2, touched + [d_b_dup]))
+            else:
+                side = side_stream(dev)
+                _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 1, dev.index, main.cuda_stream), "mmb_bilstm_layer_bwd_phase(1)")
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 2, dev.index, side.cuda_stream), "mmb_bilstm_layer_bwd_phase(2)")
+                    d_b_dup = d_b_flat.clone()
+                for t in touched + [d_b_dup]:
                     t.record_stream(side)
             _join_at_end_of_backward(dev.index)
         else:

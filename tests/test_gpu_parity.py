@@ -956,10 +956,13 @@ def _region_grads(region, batch, gpu):
     return [o.detach().clone() for o in outs], [x.grad.clone() for x in xs], {n: p.grad.clone() for n, p in region.named_parameters()}
 
 
-def test_weight_gradients_on_the_side_stream_give_identical_results(monkeypatch):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_weight_gradients_on_the_side_stream_give_identical_results(monkeypatch, mode):
     """mmb_bilstm_layer_bwd_phase: BPTT + input gradient on the current stream, weight gradients on the side stream
     (joined by an engine callback at the end of backward) must reproduce the single-stream backward bit for bit
-    (same kernels, same order per buffer), also when the gradients are consumed right after backward returns."""
+    (same kernels, same order per buffer), also when the gradients are consumed right after backward returns.
+    mode 2: the weight-gradient phase is deferred to the next layer's backward call and the side stream is restricted to
+    half of the CUs (mmb_stream_create_cu_mask)."""
     from mmbidaf_amd import functional as MF, synth
     from mmbidaf_amd.hot_region import HotRegion
     d = dev()
@@ -968,8 +971,11 @@ def test_weight_gradients_on_the_side_stream_give_identical_results(monkeypatch)
     batch = synth.make_batch((4, 60, 40, 12, 100), ragged=True)
     gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
     monkeypatch.setattr(MF, "_USE_SIDE", False)
+    monkeypatch.setattr(MF, "_SIDE_MODE", 0)
     o0, gx0, gp0 = _region_grads(region, batch, gpu)
     monkeypatch.setattr(MF, "_USE_SIDE", True)
+    monkeypatch.setattr(MF, "_SIDE_MODE", mode)
+    monkeypatch.setattr(MF, "_side_streams", {})          # the stream is made for the mode (CU mask)
     for _ in range(3):                                    # repeated: allocator reuse across streams
         o1, gx1, gp1 = _region_grads(region, batch, gpu)
         norm = torch.nn.utils.clip_grad_norm_(list(region.parameters()), 1e9)   # consumes every grad right away
@@ -981,6 +987,7 @@ def test_weight_gradients_on_the_side_stream_give_identical_results(monkeypatch)
             close(gp1[n], gp0[n].cpu(), "side-stream grad " + n, tol=1e-6)
         else:
             assert torch.equal(gp0[n], gp1[n]), n
+    assert not any(MF._deferred.values()), "deferred work left behind"
 
 
 def test_region_step_replays_from_a_hipgraph():
@@ -1028,46 +1035,67 @@ def test_region_step_replays_from_a_hipgraph():
             assert torch.equal(p.grad, r), n
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on the box (the gradient exchange over RCCL)")
-def test_gradient_allreduce_over_rccl_world2(tmp_path):
-    """world-size-2 `nccl` (= RCCL) run of the bucketed, hook-launched gradient exchange when the box has two GPUs
-    (a gpurun box has one: skipped there; the gloo twin of this test runs on CPU)."""
-    import subprocess
-    import sys
-    script = tmp_path / "w.py"
-    script.write_text("""
+_WORLD2_SCRIPT = """
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
+backend = sys.argv[2]
 from mmbidaf_amd import ddp, synth, functional as MF
 from mmbidaf_amd.hot_region import HotRegion
-rank, world, local = ddp.init_from_env("nccl")
+rank, world, local = ddp.init_from_env(backend)
 dev = torch.device("cuda", local)
 torch.manual_seed(224)
 region = HotRegion(16).to(dev)
-sync = ddp.FlatGradAllReduce(list(region.parameters()), buckets=ddp.region_buckets(region), overlap=True, stream_fn=MF.side_stream)
+sync = ddp.FlatGradAllReduce(list(region.parameters()), buckets=ddp.region_buckets(region), overlap=True, defer_fn=MF.defer_grad_work)
 sync.broadcast_parameters()
 batch = synth.make_batch((4, 20, 12, 6, 16), rank=0, ragged=True, device=dev)
 lo, hi = ddp.shard_range(4, rank, world)
 sl = lambda t: t[lo:hi]
-outs = region(sl(batch["x_text"]), sl(batch["x_aud"]), sl(batch["x_img"]), batch["text_len"][lo:hi], batch["aud_len"][lo:hi], batch["img_len"][lo:hi])
-((outs[0] * sl(batch["r_a"])).sum() + (outs[2] * sl(batch["r_i"])).sum()).backward()
-sync()
+for it in range(3):
+    for p in region.parameters():
+        p.grad = None
+    outs = region(sl(batch["x_text"]), sl(batch["x_aud"]), sl(batch["x_img"]), batch["text_len"][lo:hi], batch["aud_len"][lo:hi], batch["img_len"][lo:hi])
+    ((outs[0] * sl(batch["r_a"])).sum() + (outs[2] * sl(batch["r_i"])).sum()).backward()
+    sync()
+    assert not any(MF._deferred.values())
 mine = torch.cat([p.grad.reshape(-1) for p in region.parameters()])
 ref = HotRegion(16).to(dev); ref.load_state_dict(region.state_dict())
 o = ref(batch["x_text"], batch["x_aud"], batch["x_img"], batch["text_len"], batch["aud_len"], batch["img_len"])
 ((o[0] * batch["r_a"]).sum() + (o[2] * batch["r_i"]).sum()).backward()
 want = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
 assert torch.allclose(mine, want, atol=1e-4 * max(1.0, want.abs().max().item())), (mine - want).abs().max()
-assert dist.get_backend() == "nccl"
+assert dist.get_backend() == backend
 dist.barrier(); print("rank", rank, "ok")
-""")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))],
-                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+"""
+
+
+def _run_world2(tmp_path, backend, port, local_ranks, extra_env):
+    import subprocess
+    import sys
+    script = tmp_path / "w.py"
+    script.write_text(_WORLD2_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", **extra_env)
+    procs = [subprocess.Popen([sys.executable, str(script), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), backend],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(local_ranks[r])), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on the box (the gradient exchange over RCCL)")
+def test_gradient_allreduce_over_rccl_world2(tmp_path):
+    """world-size-2 `nccl` (= RCCL) run of the bucketed, hook-launched gradient exchange when the box has two GPUs
+    (a gpurun box has one: skipped there; the gloo twins of this test run on CPU and, below, on one GPU)."""
+    _run_world2(tmp_path, "nccl", 29631, [0, 1], {})
+
+
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_gradient_allreduce_world2_on_one_gpu_gloo(tmp_path, mode):
+    """two ranks on the ONE GPU of the box, `gloo` carrying the exchange: the device side of the N > 1 path (grad hooks ->
+    bucket launches queued behind the deferred weight-gradient phase on the side stream -> wait -> copy back) as bench.py
+    runs it, against one process on the whole batch."""
+    _run_world2(tmp_path, "gloo", 29633 + int(mode), [0, 0], {"MMB_SIDE_STREAM": mode})
 
 
 # ------------------------------------------------------------------------------------------- fuzz
