@@ -1432,7 +1432,6 @@ __global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a, i
 //   dS = P1 (dP1 - delta1_i) mask_j + P2 (dP2 - delta2_j) mask_i
 //   d_text_i += sum_j P2_ij dq_j ; dX_i = sum_j dS_ij mod_d_j ; dr_i = sum_j dS_ij
 //   d_text_d_i = dr_i w_t + w_tm * dX_i ; d_w_t += dr_i text_d_i ; d_w_tm += dX_i * text_d_i ; d_bias += dr_i
-constexpr int PI_STRIDE = 2 * DT * 16 + 16;  // per-wave partial: [d_w_t 208 | d_w_tm 208 | d_bias 1 ...]
 template <bool DBG>
 __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1547,53 +1546,74 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
     dr = kg_allsum(dr);
     if (dbg & 8) return;
     const float sdtx = 1.0f / cDq, sdX = 1.0f / cS;
-    // ---- epilogue: gradients of this text row; parameter-gradient partials reduced over the workgroup in LDS
-    __syncthreads();  // panels are dead: reuse their memory
-    float* part = reinterpret_cast<float*>(smem) + wave * PI_STRIDE;
-    const float* td_row = a.text_d + ((size_t)b * T + n) * D;
+    // ---- epilogue.  The accumulator tiles hold 16 rows x 64-B pieces per instruction; the workgroup parks dX and the
+    // P2.dq sum in LDS (the panels are dead) and then works on whole rows -- one text row per wave-instruction, lane = 16-B
+    // chunk -- so that text_d, the d_text read-modify-write and d_text_d are fully coalesced, and the parameter-gradient
+    // sums over rows (d_w_t, d_w_tm) are plain per-lane accumulations over the wave's 16 rows (no cross-lane reduction).
+    float* eX = reinterpret_cast<float*>(smem);                 // [64][LDP]  dX
+    float* eT = eX + 16 * NW * LDP;                             // [64][LDP]  sum_j P2 dq
+    float* drs = eT + 16 * NW * LDP;                            // [64]       dr
+    float* part = drs + 16 * NW;                                // [NW][2][256] per-wave partial sums of d_w_t, d_w_tm
+    __syncthreads();
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-        const int d = 16 * dt + 4 * g;
-        f4 pt = f4{0.f, 0.f, 0.f, 0.f}, ptm = pt;
-        if (nin && d < D) {
-            const f4 wt4 = *reinterpret_cast<const f4*>(a.w_t + d), wtm = *reinterpret_cast<const f4*>(a.w_tm + d);
-            const f4 td = *reinterpret_cast<const f4*>(td_row + d);
-            const f4 dXv = dX[dt] * sdX;
-            const f4 gd = wt4 * dr + wtm * dXv;
-            float* dtp = a.d_text + ((size_t)b * T + n) * D + d;
-            const f4 prev = *reinterpret_cast<const f4*>(dtp);  // g0 + g2*a + g3*b from the prologue
-            if (a.fold) {
-                *reinterpret_cast<f4*>(dtp) = prev + dtx[dt] * sdtx + gd;
-            } else {
-                *reinterpret_cast<f4*>(dtp) = prev + dtx[dt] * sdtx;
-                *reinterpret_cast<f4*>(a.d_text_d + ((size_t)b * T + n) * D + d) = gd;
-            }
-            pt = td * dr;
-            ptm = td * dXv;
-        }
+        *reinterpret_cast<f4*>(eX + (wave * 16 + r) * LDP + 16 * dt + 4 * g) = dX[dt] * sdX;
+        *reinterpret_cast<f4*>(eT + (wave * 16 + r) * LDP + 16 * dt + 4 * g) = dtx[dt] * sdtx;
+    }
+    if (g == 0) drs[wave * 16 + r] = nin ? dr : 0.f;
+    __syncthreads();
+    const int row0 = tile * NW * 16, d4 = 4 * lane;
+    const bool cin = d4 < D;
+    const f4 wt4 = cin ? *reinterpret_cast<const f4*>(a.w_t + d4) : f4{0.f, 0.f, 0.f, 0.f};
+    const f4 wtm = cin ? *reinterpret_cast<const f4*>(a.w_tm + d4) : f4{0.f, 0.f, 0.f, 0.f};
+    f4 pt = f4{0.f, 0.f, 0.f, 0.f}, ptm = pt;
+    f4 tdv[16], prev[16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float s1 = r_allsum(pt[e]), s2 = r_allsum(ptm[e]);
-            if (r == 0) {
-                part[16 * dt + 4 * g + e] = s1;
-                part[DT * 16 + 16 * dt + 4 * g + e] = s2;
+    for (int k = 0; k < 16; ++k) {   // all loads of the wave's 16 rows in flight together
+        const int gn = row0 + wave + NW * k;
+        const bool ok = gn < T && cin;
+        const size_t o = ((size_t)b * T + min(gn, T - 1)) * D + d4;
+        tdv[k] = ok ? *reinterpret_cast<const f4*>(a.text_d + o) : f4{0.f, 0.f, 0.f, 0.f};
+        prev[k] = ok ? *reinterpret_cast<const f4*>(a.d_text + o) : f4{0.f, 0.f, 0.f, 0.f};   // g0 + g2*a + g3*b from the prologue
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int rr = wave + NW * k, gn = row0 + rr;
+        if (gn < T && cin) {
+            const f4 dXv = *reinterpret_cast<const f4*>(eX + rr * LDP + d4);
+            const f4 dtv = *reinterpret_cast<const f4*>(eT + rr * LDP + d4);
+            const float drr = drs[rr];
+            const f4 gd = wt4 * drr + wtm * dXv;
+            const size_t o = ((size_t)b * T + gn) * D + d4;
+            if (a.fold) {
+                *reinterpret_cast<f4*>(a.d_text + o) = prev[k] + dtv + gd;
+            } else {
+                *reinterpret_cast<f4*>(a.d_text + o) = prev[k] + dtv;
+                *reinterpret_cast<f4*>(a.d_text_d + o) = gd;
+            }
+            pt += tdv[k] * drr;
+            ptm += tdv[k] * dXv;
+        }
+    }
+    *reinterpret_cast<f4*>(part + (wave * 2 + 0) * 256 + d4) = pt;
+    *reinterpret_cast<f4*>(part + (wave * 2 + 1) * 256 + d4) = ptm;
+    __syncthreads();
+    {
+        const int which = tid >> 7 ? 1 : 0, i = tid & 127;   // 2 x 128 threads x 2 features cover d_w_t | d_w_tm (D <= 208)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int d = i + 128 * h;
+            if (d < D) {
+                float acc = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) acc += part[(w * 2 + which) * 256 + d];
+                atomicAdd((which ? a.d_w_tm : a.d_w_t) + d, acc);
             }
         }
     }
-    const float sb = r_allsum(nin ? dr : 0.f);   // dr is replicated over the 4 k-groups: lane 0 holds the sum of the wave's 16 rows
-    if (lane == 0) part[2 * DT * 16] = sb;
-    __syncthreads();
-    for (int i = tid; i < 2 * DT * 16 + 1; i += NTHR) {
-        float acc = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) acc += reinterpret_cast<float*>(smem)[w * PI_STRIDE + i];
-        if (i < DT * 16) {
-            if (i < D) atomicAdd(a.d_w_t + i, acc);
-        } else if (i < 2 * DT * 16) {
-            if (i - DT * 16 < D) atomicAdd(a.d_w_tm + (i - DT * 16), acc);
-        } else {
-            atomicAdd(a.d_bias, acc);
-        }
+    if (wave == 0) {
+        const float sb = wave_allsum(drs[lane]);
+        if (lane == 0) atomicAdd(a.d_bias, sb);
     }
 }
 
@@ -1946,7 +1966,7 @@ extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* 
     MMB_HIP(hipGetLastError());
     {
         size_t lds = (size_t)4 * PANEL_B + ((size_t)9 * pad32(M) + 16) * sizeof(float);
-        const size_t epi = (size_t)NW * PI_STRIDE * sizeof(float);
+        const size_t epi = ((size_t)2 * 16 * NW * LDP + 16 * NW + NW * 2 * 256) * sizeof(float);   // parked dX, P2.dq tiles + dr + partial sums
         if (lds < epi) lds = epi;
         auto kern = a.dbg ? att_bwd_i_kernel<true> : att_bwd_i_kernel<false>;
         if (int rc = allow_lds(kern, lds)) return rc;
