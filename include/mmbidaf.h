@@ -205,6 +205,17 @@ int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* descs, int n, int phase,
 int mmb_stream_create_cu_mask(int device, const uint32_t* mask, int n_words, void** stream_out);
 int mmb_stream_destroy(int device, void* stream);
 
+/* loss = sum_k <x_k, w_k> over up to MMB_WSUM_MAX tensors of n[k] floats (w_k null: plain sum of x_k) into out[0], and its
+ * gradient dx_k = g[0] * w_k (g a device scalar).  This is the synthetic objective of the throughput measurement (SURVEY.md
+ * section 8(d)); the reference's objective is the decoder's summed NLL (models.py:168-176).  One launch each way, deterministic
+ * (fixed-order sum of per-workgroup partials).  ws: mmb_weighted_sums_ws_bytes() bytes whose first 4 are ZERO before the first
+ * call (the kernel leaves them zero); all pointers 16-byte aligned. */
+#define MMB_WSUM_MAX 8
+size_t mmb_weighted_sums_ws_bytes(const long* n, int k);
+int mmb_weighted_sums_fwd(const float* const* x, const float* const* w, const long* n, int k, float* out,
+                          void* ws, size_t ws_bytes, int device, void* stream);
+int mmb_weighted_sums_bwd(const float* g, const float* const* w, float* const* dx, const long* n, int k, int device, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Decoder step.  Replaces MultimodalAttentionDecoder.forward (reference
  * layers/attention.py:145-186) for one decode step of the whole batch, and its autograd: one kernel launch per

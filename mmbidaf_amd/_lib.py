@@ -72,6 +72,11 @@ SIGNATURES = {
     "mmb_set_gemm_mode": (c_i, [c_i]),
     "mmb_bilstm_ws_bytes": (ctypes.c_size_t, [c_i] * 5),
     "mmb_gemm_nt_planes": (c_i, [c_f] * 4 + [c_i] * 3 + [c_f, ctypes.c_size_t, c_i, c_f]),
+    "mmb_weighted_sums_ws_bytes": (ctypes.c_size_t, [ctypes.POINTER(ctypes.c_long), c_i]),
+    "mmb_weighted_sums_fwd": (c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_long), c_i,
+                                    c_f, c_f, ctypes.c_size_t, c_i, c_f]),
+    "mmb_weighted_sums_bwd": (c_i, [c_f, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_long), c_i,
+                                    c_i, c_f]),
     "mmb_stream_create_cu_mask": (c_i, [c_i, ctypes.POINTER(ctypes.c_uint32), c_i, ctypes.POINTER(ctypes.c_void_p)]),
     "mmb_stream_destroy": (c_i, [c_i, c_f]),
     "mmb_gemm_tn_planes": (c_i, [c_f] * 3 + [c_i] * 3 + [c_f, ctypes.c_size_t, c_i, c_f]),

@@ -1,0 +1,152 @@
+// Weighted sums of a few tensors into one scalar, and its gradient: loss = sum_k <x_k, w_k> (w_k = null: plain sum).
+// The synthetic objective the throughput measurement back-propagates (<y_a,R_a> + <y_i,R_i> +
+// sum(h_a) + sum(h_i)) -- in the reference the objective is the decoder's summed negative log-likelihood
+// (models.py:168-176); written as stock torch ops it costs ~20 tiny launches per step around a 3-ms step.
+// One launch each way: per-workgroup partial sums, the LAST workgroup to finish (ticket counter) adds them up in a fixed
+// order, so the result is deterministic; the counter resets itself.
+#include "common.h"
+
+namespace mmb {
+
+struct WSumArgs {
+    const float* x[MMB_WSUM_MAX];
+    const float* w[MMB_WSUM_MAX];
+    float* dx[MMB_WSUM_MAX];
+    long n[MMB_WSUM_MAX];
+    int blk_begin[MMB_WSUM_MAX + 1];
+    int k;
+};
+constexpr int WS_PER_BLOCK = 256 * 4 * 8;   // elements one workgroup covers
+__device__ __forceinline__ float f4sum(const f4 v) { return (v.x + v.y) + (v.z + v.w); }
+
+__global__ __launch_bounds__(256) void wsum_fwd_kernel(const WSumArgs a, float* partial, unsigned* ticket, float* out) {
+    __shared__ float red[4];
+    __shared__ bool last;
+    int k = 0;
+    for (int i = 1; i < a.k; ++i)
+        if ((int)blockIdx.x >= a.blk_begin[i]) k = i;
+    const long base = (long)(blockIdx.x - a.blk_begin[k]) * WS_PER_BLOCK;
+    const float* x = a.x[k];
+    const float* w = a.w[k];
+    const long n = a.n[k];
+    float acc = 0.f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+        if (i + 3 < n) {
+            const f4 v = *reinterpret_cast<const f4*>(x + i);
+            if (w) acc += f4sum(v * *reinterpret_cast<const f4*>(w + i));
+            else acc += f4sum(v);
+        } else {
+            for (long j = i; j < n; ++j) acc += x[j] * (w ? w[j] : 1.0f);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float s = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) s += __builtin_nontemporal_load(partial + i);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+        *ticket = 0u;
+    }
+}
+
+// dx_k = g * w_k (or g where w_k is null), g a device scalar
+__global__ __launch_bounds__(256) void wsum_bwd_kernel(const WSumArgs a, const float* g_ptr) {
+    int k = 0;
+    for (int i = 1; i < a.k; ++i)
+        if ((int)blockIdx.x >= a.blk_begin[i]) k = i;
+    const long base = (long)(blockIdx.x - a.blk_begin[k]) * WS_PER_BLOCK;
+    const float g = g_ptr[0];
+    const float* w = a.w[k];
+    float* dx = a.dx[k];
+    const long n = a.n[k];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+        if (i + 3 < n) {
+            f4 v = f4{g, g, g, g};
+            if (w) v = *reinterpret_cast<const f4*>(w + i) * g;
+            *reinterpret_cast<f4*>(dx + i) = v;
+        } else {
+            for (long j = i; j < n; ++j) dx[j] = g * (w ? w[j] : 1.0f);
+        }
+    }
+}
+
+static int fill_args(WSumArgs& a, const float* const* x, const float* const* w, float* const* dx, const long* n, int k) {
+    MMB_REQUIRE(k >= 1 && k <= MMB_WSUM_MAX && n, "mmb_weighted_sums: 1..%d tensors", MMB_WSUM_MAX);
+    a.k = k;
+    int blk = 0;
+    for (int i = 0; i < k; ++i) {
+        MMB_REQUIRE(n[i] >= 0 && (!x || x[i]) && (!dx || dx[i]), "mmb_weighted_sums: null tensor %d", i);
+        MMB_REQUIRE(((x ? (uintptr_t)x[i] : 0) | (w && w[i] ? (uintptr_t)w[i] : 0) | (dx ? (uintptr_t)dx[i] : 0)) % 16 == 0,
+                    "mmb_weighted_sums: tensor %d is not 16-byte aligned", i);
+        a.x[i] = x ? x[i] : nullptr;
+        a.w[i] = w ? w[i] : nullptr;
+        a.dx[i] = dx ? dx[i] : nullptr;
+        a.n[i] = n[i];
+        a.blk_begin[i] = blk;
+        blk += (int)((n[i] + WS_PER_BLOCK - 1) / WS_PER_BLOCK);
+    }
+    a.blk_begin[k] = blk;
+    return MMB_OK;
+}
+
+}  // namespace mmb
+
+using namespace mmb;
+
+extern "C" size_t mmb_weighted_sums_ws_bytes(const long* n, int k) {
+    size_t blk = 0;
+    for (int i = 0; n && i < k; ++i) blk += (size_t)((n[i] + WS_PER_BLOCK - 1) / WS_PER_BLOCK);
+    return 256 + 4 * blk;
+}
+
+extern "C" int mmb_weighted_sums_fwd(const float* const* x, const float* const* w, const long* n, int k, float* out,
+                                     void* ws, size_t ws_bytes, int device, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    WSumArgs a{};
+    MMB_REQUIRE(x && out && ws, "mmb_weighted_sums_fwd: null argument");
+    if (int rc = fill_args(a, x, w, nullptr, n, k)) return rc;
+    MMB_REQUIRE(ws_bytes >= mmb_weighted_sums_ws_bytes(n, k), "mmb_weighted_sums_fwd: workspace too small");
+    MMB_HIP(hipSetDevice(device));
+    const int blocks = a.blk_begin[k];
+    if (blocks == 0) {
+        MMB_HIP(hipMemsetAsync(out, 0, sizeof(float), stream));
+        return MMB_OK;
+    }
+    // ws: [ticket (zero before the first use; the kernel leaves it zero) | pad to 256 B | partials]
+    hipLaunchKernelGGL(wsum_fwd_kernel, dim3(blocks), dim3(256), 0, stream, a, reinterpret_cast<float*>(static_cast<char*>(ws) + 256),
+                       static_cast<unsigned*>(ws), out);
+    MMB_HIP(hipGetLastError());
+    return MMB_OK;
+}
+
+extern "C" int mmb_weighted_sums_bwd(const float* g, const float* const* w, float* const* dx, const long* n, int k, int device,
+                                     void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    WSumArgs a{};
+    MMB_REQUIRE(g && dx, "mmb_weighted_sums_bwd: null argument");
+    if (int rc = fill_args(a, nullptr, w, dx, n, k)) return rc;
+    MMB_HIP(hipSetDevice(device));
+    if (a.blk_begin[k] == 0) return MMB_OK;
+    hipLaunchKernelGGL(wsum_bwd_kernel, dim3(a.blk_begin[k]), dim3(256), 0, stream, a, g);
+    MMB_HIP(hipGetLastError());
+    return MMB_OK;
+}

@@ -290,6 +290,7 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         descs = (_lib.LstmFwdDesc * n)()
         keep, outs, saved = [], [], []
         dev = flat[0].device
+        ctx.set_materialize_grads(False)     # an unused output (h_n of the input encoders) arrives as None, not as a zero fill
         x_absmax = torch.zeros(n, 2, device=dev, dtype=torch.float32)    # [max |x|, max |W_ih|] per problem, filled by the library
         for i in range(n):
             x, *ws_ = flat[i * _PER_PROBLEM:(i + 1) * _PER_PROBLEM]
@@ -469,6 +470,60 @@ def gemm_tn_planes(at, b):
     rc = lib.mmb_gemm_tn_planes(_ptr(at), _ptr(b), _ptr(c), M, N, K, _ptr(ws), ws.numel(), at.device.index, _stream())
     _lib.check(rc, "mmb_gemm_tn_planes")
     return c
+
+
+# --------------------------------------------------------------------------------------- weighted sums (synthetic objective)
+_wsum_ws = {}
+
+
+class _WeightedSumsFn(torch.autograd.Function):
+    """loss = sum_k <x_k, w_k> (w_k None: plain sum) in ONE launch, gradient dx_k = g * w_k in one launch
+    (mmb_weighted_sums_fwd / _bwd): the synthetic objective of SURVEY 8(d) that bench.py back-propagates."""
+
+    @staticmethod
+    def forward(ctx, weights, *xs):
+        lib = _lib.load()
+        _require_gpu(*xs)
+        dev = xs[0].device
+        xs = [_f32c(x) for x in xs]
+        weights = [None if w is None else _f32c(w) for w in weights]
+        k = len(xs)
+        for x, w in zip(xs, weights):
+            assert w is None or w.numel() == x.numel(), "weighted_sums: a weight must have its tensor's size"
+        n = (ctypes.c_long * k)(*[x.numel() for x in xs])
+        need = lib.mmb_weighted_sums_ws_bytes(n, k)
+        ws = _wsum_ws.get(dev.index)
+        if ws is None or ws.numel() < need:
+            ws = _wsum_ws[dev.index] = torch.zeros(max(need, 1 << 16), device=dev, dtype=torch.uint8)   # ticket starts at zero
+        xp = (ctypes.c_void_p * k)(*[x.data_ptr() for x in xs])
+        wp = (ctypes.c_void_p * k)(*[None if w is None else w.data_ptr() for w in weights])
+        out = torch.empty(1, device=dev, dtype=torch.float32)
+        _lib.check(lib.mmb_weighted_sums_fwd(xp, wp, n, k, _ptr(out), _ptr(ws), ws.numel(), dev.index, _stream()), "mmb_weighted_sums_fwd")
+        ctx.weights = weights
+        ctx.shapes = [x.shape for x in xs]
+        ctx.set_materialize_grads(False)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) + (None,) * len(ctx.shapes)
+        lib = _lib.load()
+        k = len(ctx.shapes)
+        dev = g.device
+        g = _f32c(g).reshape(1)
+        dxs = [torch.empty(sh, device=dev, dtype=torch.float32) for sh in ctx.shapes]
+        n = (ctypes.c_long * k)(*[d.numel() for d in dxs])
+        wp = (ctypes.c_void_p * k)(*[None if w is None else w.data_ptr() for w in ctx.weights])
+        dp = (ctypes.c_void_p * k)(*[d.data_ptr() for d in dxs])
+        _lib.check(lib.mmb_weighted_sums_bwd(_ptr(g), wp, dp, n, k, dev.index, _stream()), "mmb_weighted_sums_bwd")
+        return (None, *dxs)
+
+
+def weighted_sums(xs, weights):
+    """sum_k <xs[k], weights[k]> (weights[k] None: sum of xs[k]) as a 0-dim tensor; differentiable in xs only."""
+    assert 1 <= len(xs) <= 8 and len(xs) == len(weights)
+    return _WeightedSumsFn.apply(list(weights), *xs)
 
 
 # --------------------------------------------------------------------------------------- Embedding (row N2)

@@ -78,6 +78,24 @@ def test_gemm_operand_planes_k_major(M, N, K):
     close(got, ref, "planes gemm k-major", tol=2e-5)
 
 
+def test_weighted_sums_objective_and_gradient():
+    """mmb_weighted_sums_fwd/_bwd (the synthetic objective of bench.py): value against float64, gradients exact."""
+    from mmbidaf_amd import functional as MF
+    g = torch.Generator().manual_seed(3)
+    shapes = [(32, 400, 200), (5, 7, 3), (32, 4, 100), (1,)]
+    xs = [torch.randn(*sh, generator=g).to(dev()).requires_grad_(True) for sh in shapes]
+    ws = [torch.randn(*shapes[0], generator=g).to(dev()), torch.randn(*shapes[1], generator=g).to(dev()), None, None]
+    for rep in range(3):                                   # the ticket counter must reset itself
+        for x in xs:
+            x.grad = None
+        loss = MF.weighted_sums(xs, ws)
+        ref = sum(((x.double() * w.double()).sum() if w is not None else x.double().sum()) for x, w in zip(xs, ws))
+        assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()), float(sum(x.abs().sum() for x in xs)) * 1e-2)
+        (loss * 0.5).backward()
+        for x, w in zip(xs, ws):
+            assert torch.equal(x.grad, (w * 0.5) if w is not None else torch.full_like(x, 0.5))
+
+
 def test_gemm_modes_agree():
     """the exact-f32 MFMA kernels and the split-bf16 kernels are interchangeable to fp32 accuracy."""
     from mmbidaf_amd import _lib, functional as MF

@@ -4,6 +4,7 @@ under profiles/.  Usage on the GPU box (after rocprofv3 ... --output-format csv 
 
     python tools/profile_summary.py stats DIR  > profiles/rNN_kernel_stats.md
     python tools/profile_summary.py pmc DIR    > profiles/rNN_pmc.md   (also rewrites profiles/pmc_traffic.json)
+    python tools/profile_summary.py timeline DIR > profiles/rNN_timeline.md   (one step: order, queues, overlap)
 """
 import csv
 import glob
@@ -38,6 +39,56 @@ def stats(d):
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"| `{k[:90]}` | {a[0]} | {a[1]:.1f} | {a[1] / a[0]:.2f} | {a[2]:.2f} | {a[3]:.2f} | {100 * a[1] / tot:.1f} |")
     print(f"\ntotal kernel time {tot / 1e3:.3f} ms over {sum(a[0] for a in agg.values())} dispatches")
+
+
+def timeline(d, which=-2):
+    """One step of the kernel trace as a timeline (start offset, duration, queue) + how much of it ran two-deep.
+    A step ends with the last `lstm_unpack_dw_kernel` before the first forward recurrence that follows a backward one."""
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        rows += list(csv.DictReader(open(f)))
+    ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?")) for r in rows))
+    cuts, seen_bwd = [0], False
+    for i, e in enumerate(ev):
+        if e[2].startswith("lstm_rec_bwd"):
+            seen_bwd = True
+        if e[2].startswith("lstm_rec_fwd") and seen_bwd:
+            # the previous step ends with the last weight-gradient unpack kernel before this recurrence
+            j = i
+            while j > 0 and not ev[j - 1][2].startswith("lstm_unpack_dw"):
+                j -= 1
+            j = j if j > 0 else i
+            cuts.append(j)
+            seen_bwd = False
+    cuts.append(len(ev))
+    steps = [ev[a:b] for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    st = steps[which] if len(steps) >= abs(which) else steps[-1]
+    t0 = st[0][0]
+    queues = sorted({e[3] for e in st})
+    print(f"step with {len(st)} dispatches on {len(queues)} queue(s); t = start offset from the step's first dispatch\n")
+    print("| t us | dur us | queue | kernel | runs beside |")
+    print("|---:|---:|---|---|---|")
+    points = []
+    for i, (a, b, k, q) in enumerate(st):
+        beside = sorted({k2[:28] for (a2, b2, k2, q2) in st if q2 != q and a2 < b and b2 > a})
+        print(f"| {(a - t0) / 1e3:.1f} | {(b - a) / 1e3:.1f} | {queues.index(q)} | `{k[:70]}` | {', '.join(beside)} |")
+        points += [(a, 1), (b, -1)]
+    points.sort()
+    depth, last, busy1, busy2 = 0, points[0][0], 0, 0
+    for t, dlt in points:
+        if depth >= 1:
+            busy1 += t - last
+        if depth >= 2:
+            busy2 += t - last
+        depth += dlt
+        last = t
+    span = max(e[1] for e in st) - t0
+    ksum = sum(b - a for a, b, _, _ in st)
+    print(f"\nstep span {span / 1e3:.1f} us; sum of kernel durations {ksum / 1e3:.1f} us; some kernel running {busy1 / 1e3:.1f} us; "
+          f"two or more kernels running {busy2 / 1e3:.1f} us")
+    side = [e for e in st if queues.index(e[3]) != queues.index(st[0][3])]
+    if side:
+        print(f"dispatches off the main queue: {len(side)}, {sum(b - a for a, b, _, _ in side) / 1e3:.1f} us of kernel time")
 
 
 def pmc(d, cfg="cfg2"):
@@ -94,4 +145,4 @@ def pmc(d, cfg="cfg2"):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
+    {"stats": stats, "pmc": pmc, "timeline": timeline}[sys.argv[1]](sys.argv[2])
