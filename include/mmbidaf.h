@@ -194,7 +194,15 @@ int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* descs, int n, int device, void
  * of the next layer / encoder group -- which occupies only 2*B of the 256 CUs:
  *   phase 1: BPTT recurrence (d_a) + input gradient d_x       phase 2: weight and bias gradients (d_w_ih, d_w_hh, d_b)
  *   phase 3: both, in that order (= mmb_bilstm_layer_bwd).
- * Problems that do not run on the operand planes (no ws, or I / H not multiples of 4) do all their work in phase 1. */
+ * Problems that do not run on the operand planes (no ws, or I / H not multiples of 4) do all their work in phase 1.
+ *   phase MMB_LSTM_BWD_PREPARE: only the operand planes that depend on nothing the backward pass computes --
+ *     [x | y(t-1) | y(t+1)]^T (and the zeroing of d_w_cat a K-split needs; skipped with | MMB_LSTM_BWD_HAVE_XC) and W_ih^T
+ *     (skipped with | MMB_LSTM_BWD_HAVE_WT) -- are written to desc.ws; needs x, y, w_ih, x_absmax, ws, d_w_cat and the sizes only.  The host side runs this for ALL layers beside the
+ *     first recurrence of the backward pass and then passes MMB_LSTM_BWD_HAVE_XC / MMB_LSTM_BWD_HAVE_WT (or-ed into phase
+ *     1 / 2 / 3) with the same ws and d_w_cat, so that those split passes leave the critical path. */
+#define MMB_LSTM_BWD_PREPARE 4
+#define MMB_LSTM_BWD_HAVE_XC 8
+#define MMB_LSTM_BWD_HAVE_WT 16
 int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* descs, int n, int phase, int device, void* stream);
 
 /* A stream restricted to the compute units whose bits are set in mask (n_words x 32 bits; the HSA queue CU mask:

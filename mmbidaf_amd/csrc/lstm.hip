@@ -516,7 +516,7 @@ static int kq_for(int H) {
 
 
 // phase bit 1: input gradient d_x (on the critical path of the backward pass); bit 2: weight and bias gradients
-static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_partials, int phase) {
+static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_partials, int phase_bits) {
     const int H = p.H, I = p.I;
     const long BT = (long)p.B * p.T;
     const WsBwd L = ws_bwd_layout(BT, p.B, I, H);
@@ -533,22 +533,65 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
     float* scal = reinterpret_cast<float*>(ws + L.scal);        // max |d_a| when the recurrence did not track it
     const float* damax = reinterpret_cast<const float*>(ws + L.damax);
     int damax_n = 2 * p.B;
+    // phase bits: 1 input gradient, 2 weight gradients, 4 PREPARE (only the operand planes that depend on nothing the
+    // backward pass computes: [x | y(t-1) | y(t+1)]^T and W_ih^T), 8 / 16: those planes are already in the workspace
+    const int phase = phase_bits & 3;
+    const bool prepare = phase_bits & MMB_LSTM_BWD_PREPARE;
+    const bool have_xc = phase_bits & MMB_LSTM_BWD_HAVE_XC, have_wt = phase_bits & MMB_LSTM_BWD_HAVE_WT;
+    if (np == 2)
+        MMB_REQUIRE(p.x_absmax, "mmb_bilstm_layer_bwd: desc.x_absmax (saved by the forward call) is needed by the fp16 operand planes");
+
+    // weight-gradient GEMM: d_a^T (8H x BT) . [x | y_fwd(t-1) | y_rev(t+1)] (BT x (I+2H))
+    PlanesGemmArgs gw{};
+    gw.B = xcT;
+    gw.C = p.d_w_cat; gw.ldc = I + 2 * H; gw.M = 8 * H; gw.N = I + 2 * H; gw.K = L.BTp;
+    gw.np = np; gw.b_inv = xcTinv;
+    const bool one_split = np == 2 && planes_one_split();
+    gw.ta = one_split ? 1 : 0;
+    const bool ksplit = planes_plan_splitk(gw) > 1;   // its zeroing rides on the split pass of the second operand
+    auto split_xc = [&]() -> int {
+        // [x | y_fwd(t-1) | y_rev(t+1)]^T planes ((I+2H) x BT): h_prev is y shifted by one step inside each sample
+        SplitTArgs tx{};
+        tx.nseg = 3;
+        tx.seg_ptr[0] = p.x;     tx.seg_ld[0] = I;     tx.seg_cols[0] = I; tx.seg_shift[0] = 0;
+        tx.seg_ptr[1] = p.y;     tx.seg_ld[1] = 2 * H; tx.seg_cols[1] = H; tx.seg_shift[1] = -1;
+        tx.seg_ptr[2] = p.y + H; tx.seg_ld[2] = 2 * H; tx.seg_cols[2] = H; tx.seg_shift[2] = +1;
+        tx.R = (int)BT; tx.period = p.T; tx.Rp = L.BTp; tx.Ctot = I + 2 * H; tx.planes = xcT;
+        tx.np = np; tx.inv_out = xcTinv;
+        tx.seg_absmax[0] = p.x_absmax; tx.seg_absmax_n[0] = 1;       // max |x|, recorded by the forward's split pass
+        tx.seg_bound[1] = 1.0f; tx.seg_bound[2] = 1.0f;               // |h| = |o * tanh(c)| < 1
+        if (ksplit) { tx.zero_ptr = p.d_w_cat; tx.zero_n = (long)8 * H * (I + 2 * H); }
+        return planes_split_transpose(tx, stream);
+    };
+    auto split_wt = [&]() -> int {
+        SplitTArgs tw{};
+        tw.nseg = 1; tw.seg_ptr[0] = p.w_ih[0]; tw.seg_ld[0] = I; tw.seg_cols[0] = I; tw.seg_shift[0] = 0;
+        tw.stack_ptr = p.w_ih[1]; tw.stack_R1 = 4 * H;
+        tw.R = 8 * H; tw.period = 1; tw.Rp = L.K8; tw.Ctot = I; tw.planes = wT;
+        tw.np = np; tw.seg_absmax[0] = p.x_absmax ? p.x_absmax + 1 : nullptr; tw.seg_absmax_n[0] = 1; tw.inv_out = wTinv;
+        return planes_split_transpose(tw, stream);
+    };
+    if (prepare) {
+        if (!have_xc)
+            if (int rc = split_xc()) return rc;
+        if (!have_wt)
+            if (int rc = split_wt()) return rc;
+        return MMB_OK;
+    }
+
     // ONE split of d_a (row-major planes, one scale for the tensor) serves both GEMMs: the input gradient reads its rows,
     // the weight gradient reads it k-major through transposing LDS reads (PlanesGemmArgs::ta) -- instead of a row split
     // plus a transposing split (d_a is the largest tensor of the layer: 82 MB at the metric configuration)
     // (split calls: phase 1 makes the planes when there is an input gradient to compute, and phase 2 -- which always follows
     //  phase 1 of the same descriptors -- then finds them in the workspace)
-    const bool one_split = np == 2 && planes_one_split();
     const bool split_now = one_split && (phase == 3 || (phase == 1 && p.d_x) || (phase == 2 && !p.d_x));
-    if (np == 2) {
-        MMB_REQUIRE(p.x_absmax, "mmb_bilstm_layer_bwd: desc.x_absmax (saved by the forward call) is needed by the fp16 operand planes");
-        if (!db_partials && ((phase & 2) || split_now)) {   // general-size recurrence: max |d_a| was not tracked by the recurrence, one reduction here
-            MMB_HIP(hipMemsetAsync(scal, 0, sizeof(float), stream));
-            hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, stream, p.d_a, static_cast<const float*>(nullptr), BT * 8 * H, scal);
-            MMB_HIP(hipGetLastError());
-            damax = scal;
-            damax_n = 1;
-        }
+    if (np == 2 && !db_partials && ((phase & 2) || split_now)) {
+        // general-size recurrence: max |d_a| was not tracked by the recurrence, one reduction here
+        MMB_HIP(hipMemsetAsync(scal, 0, sizeof(float), stream));
+        hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, stream, p.d_a, static_cast<const float*>(nullptr), BT * 8 * H, scal);
+        MMB_HIP(hipGetLastError());
+        damax = scal;
+        damax_n = 1;
     }
     if (split_now) {
         SplitRowsArgs sa{};
@@ -558,35 +601,20 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
         if (int rc = planes_split_rows(sa, stream)) return rc;
     }
     if (phase & 2) {
-    PlanesGemmArgs gw{};
-    if (one_split) {
-        gw.A = daP; gw.ta = 1; gw.a_inv = dainv;
-    } else {
-        // d_a^T planes (8H x BT): A operand of the weight-gradient GEMM
-        SplitTArgs ta{};
-        ta.nseg = 1; ta.seg_ptr[0] = p.d_a; ta.seg_ld[0] = 8 * H; ta.seg_cols[0] = 8 * H; ta.seg_shift[0] = 0;
-        ta.R = (int)BT; ta.period = 1; ta.Rp = L.BTp; ta.Ctot = 8 * H; ta.planes = daT;
-        ta.np = np; ta.seg_absmax[0] = damax; ta.seg_absmax_n[0] = damax_n; ta.inv_out = daTinv;
-        if (int rc = planes_split_transpose(ta, stream)) return rc;
-        gw.A = daT; gw.a_inv = daTinv;
-    }
-    gw.B = xcT;
-    gw.C = p.d_w_cat; gw.ldc = I + 2 * H; gw.M = 8 * H; gw.N = I + 2 * H; gw.K = L.BTp;
-    gw.np = np; gw.b_inv = xcTinv;
-    const bool ksplit = planes_plan_splitk(gw) > 1;   // its zeroing rides on the split pass below
-    // [x | y_fwd(t-1) | y_rev(t+1)]^T planes ((I+2H) x BT): h_prev is y shifted by one step inside each sample
-    SplitTArgs tx{};
-    tx.nseg = 3;
-    tx.seg_ptr[0] = p.x;     tx.seg_ld[0] = I;     tx.seg_cols[0] = I; tx.seg_shift[0] = 0;
-    tx.seg_ptr[1] = p.y;     tx.seg_ld[1] = 2 * H; tx.seg_cols[1] = H; tx.seg_shift[1] = -1;
-    tx.seg_ptr[2] = p.y + H; tx.seg_ld[2] = 2 * H; tx.seg_cols[2] = H; tx.seg_shift[2] = +1;
-    tx.R = (int)BT; tx.period = p.T; tx.Rp = L.BTp; tx.Ctot = I + 2 * H; tx.planes = xcT;
-    tx.np = np; tx.inv_out = xcTinv;
-    tx.seg_absmax[0] = p.x_absmax; tx.seg_absmax_n[0] = 1;       // max |x|, recorded by the forward's split pass
-    tx.seg_bound[1] = 1.0f; tx.seg_bound[2] = 1.0f;               // |h| = |o * tanh(c)| < 1
-    if (ksplit) { tx.zero_ptr = p.d_w_cat; tx.zero_n = (long)8 * H * (I + 2 * H); gw.prezeroed = 1; }
-    if (int rc = planes_split_transpose(tx, stream)) return rc;
-    {
+        if (one_split) {
+            gw.A = daP; gw.a_inv = dainv;
+        } else {
+            // d_a^T planes (8H x BT): A operand of the weight-gradient GEMM
+            SplitTArgs ta{};
+            ta.nseg = 1; ta.seg_ptr[0] = p.d_a; ta.seg_ld[0] = 8 * H; ta.seg_cols[0] = 8 * H; ta.seg_shift[0] = 0;
+            ta.R = (int)BT; ta.period = 1; ta.Rp = L.BTp; ta.Ctot = 8 * H; ta.planes = daT;
+            ta.np = np; ta.seg_absmax[0] = damax; ta.seg_absmax_n[0] = damax_n; ta.inv_out = daTinv;
+            if (int rc = planes_split_transpose(ta, stream)) return rc;
+            gw.A = daT; gw.a_inv = daTinv;
+        }
+        if (!have_xc)
+            if (int rc = split_xc()) return rc;
+        gw.prezeroed = ksplit ? 1 : 0;
         if (int rc = planes_gemm(gw, stream)) return rc;
         const int total = 8 * H * (I + 2 * H);
         ProfScope ps_(MMB_K_GEMM, stream);
@@ -594,22 +622,17 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
                            db_partials ? reinterpret_cast<const float*>(ws + L.dbp) : static_cast<const float*>(nullptr), p.d_b, p.B);
         MMB_HIP(hipGetLastError());
     }
-    }
     if (p.d_x && (phase & 1)) {
         // d_x (BT, I) = d_a (BT x 8H) . [W_ih_f ; W_ih_r] (8H x I): one GEMM over both directions
-        SplitRowsArgs sa{};
-        sa.src1 = p.d_a; sa.src2 = p.d_a; sa.R1 = (int)BT; sa.R = (int)BT; sa.C = 8 * H; sa.ld = 8 * H; sa.Cp = L.K8; sa.gate_H = 0;
-        sa.planes = daP;
-        sa.np = np; sa.inv_out = dainv;
         if (!one_split) {
+            SplitRowsArgs sa{};
+            sa.src1 = p.d_a; sa.src2 = p.d_a; sa.R1 = (int)BT; sa.R = (int)BT; sa.C = 8 * H; sa.ld = 8 * H; sa.Cp = L.K8; sa.gate_H = 0;
+            sa.planes = daP;
+            sa.np = np; sa.inv_out = dainv;
             if (int rc = planes_split_rows(sa, stream)) return rc;
         }
-        SplitTArgs tw{};
-        tw.nseg = 1; tw.seg_ptr[0] = p.w_ih[0]; tw.seg_ld[0] = I; tw.seg_cols[0] = I; tw.seg_shift[0] = 0;
-        tw.stack_ptr = p.w_ih[1]; tw.stack_R1 = 4 * H;
-        tw.R = 8 * H; tw.period = 1; tw.Rp = L.K8; tw.Ctot = I; tw.planes = wT;
-        tw.np = np; tw.seg_absmax[0] = p.x_absmax ? p.x_absmax + 1 : nullptr; tw.seg_absmax_n[0] = 1; tw.inv_out = wTinv;
-        if (int rc = planes_split_transpose(tw, stream)) return rc;
+        if (!have_wt)
+            if (int rc = split_wt()) return rc;
         PlanesGemmArgs g{};
         g.A = daP;
         g.B = wT;
@@ -700,13 +723,20 @@ extern "C" int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* d, int n, int devic
 extern "C" int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* d, int n, int phase, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MMB_REQUIRE(d && n >= 1 && n <= MMB_MAX_GROUP, "mmb_bilstm_layer_bwd: n=%d out of range", n);
-    MMB_REQUIRE(phase >= 1 && phase <= 3, "mmb_bilstm_layer_bwd_phase: phase=%d (1 = BPTT + input gradient, 2 = weight gradients, 3 = both)", phase);
+    const int phase_bits = phase;
+    phase &= 3;
+    const bool prep = (phase_bits & MMB_LSTM_BWD_PREPARE) != 0;
+    MMB_REQUIRE(!(phase_bits & ~(7 | MMB_LSTM_BWD_HAVE_XC | MMB_LSTM_BWD_HAVE_WT)) && (prep ? phase == 0 : phase >= 1),
+                "mmb_bilstm_layer_bwd_phase: phase=%d (1 = BPTT + input gradient, 2 = weight gradients, 3 = both, optionally | "
+                "MMB_LSTM_BWD_HAVE_XC | MMB_LSTM_BWD_HAVE_WT; or MMB_LSTM_BWD_PREPARE | the planes NOT to prepare)", phase_bits);
     MMB_HIP(hipSetDevice(device));
-    if (phase == 2) {   // weight / bias gradients of the problems that run on the operand planes (the others did them in phase 1)
+    if (phase == 2 || prep) {
+        // weight / bias gradients (or the preparation of their operands) of the problems that run on the operand planes (the
+        // others do all their work in phase 1)
         const int H2 = d[0].H;
         for (int i = 0; i < n; ++i)
             if (d[i].ws && d[i].d_w_cat && planes_ok(d[i].I, H2))
-                if (int rc = grads_planes(d[i], stream, !(H2 > MMB_LSTM_MAX_H), 2)) return rc;
+                if (int rc = grads_planes(d[i], stream, !(H2 > MMB_LSTM_MAX_H), phase_bits)) return rc;
         return MMB_OK;
     }
     RecBwdArgs ra{};
@@ -750,7 +780,7 @@ extern "C" int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* d, int n, int
         const mmb_lstm_bwd_desc& p = d[i];
         const int BT = p.B * p.T;
         if (p.ws && p.d_w_cat && planes_ok(p.I, H)) {
-            rc = grads_planes(p, stream, !big, phase);
+            rc = grads_planes(p, stream, !big, phase_bits);
             if (rc) return rc;
             continue;
         }

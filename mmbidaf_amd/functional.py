@@ -6,6 +6,7 @@ on the autograd worker thread: the device ordinal is passed explicitly on every 
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -90,6 +91,8 @@ def flush_deferred(device, to_side=True):
                 for t in tensors:
                     t.record_stream(side)
     else:
+        if key in _side_streams:
+            main.wait_stream(_side_streams[key])     # operands prepared on the side stream
         for fn, _ in todo:
             fn(main)
 
@@ -137,6 +140,79 @@ def _join_at_end_of_backward(dev_index):
             _join_pending.clear()
             _join_pending.add(key)
     torch.autograd.Variable._execution_engine.queue_callback(cb)
+
+
+class _BwdPrep:
+    """What one LSTM layer call's backward can prepare before any gradient exists: the transposed operand planes
+    [x | y(t-1) | y(t+1)]^T (and W_ih^T) in the call's backward workspace.  Created by the forward call (mode 2 only), kept
+    alive by its autograd context; the first LSTM backward call of a pass runs the preparation of ALL live records on the side
+    stream, beside its own recurrence -- the one recurrence of the backward pass that has nothing else to run beside it."""
+
+    def __init__(self, dev, probs, need_dx):
+        self.dev, self.probs, self.need_dx = dev, probs, need_dx    # probs: [(x, y, w_ih_f, w_ih_r, x_absmax)]
+        self.ws = self.d_w_cat = None
+        self.have_xc = self.have_wt = False
+        self.event = None
+
+
+_bwd_preps = {}           # device index -> list of weakrefs to _BwdPrep (forward order)
+PREPARE, HAVE_XC, HAVE_WT = 4, 8, 16
+
+
+def _prep_descs(rec, idx):
+    lib = _lib.load()
+    descs = (_lib.LstmBwdDesc * len(idx))()
+    for k, i in enumerate(idx):
+        x, y, w_ih_f, w_ih_r, x_absmax = rec.probs[i]
+        d = descs[k]
+        B, T, I = x.shape
+        H = w_ih_f.shape[0] // 4
+        d.x, d.y = _ptr(x), _ptr(y)
+        d.w_ih[0], d.w_ih[1] = _ptr(w_ih_f), _ptr(w_ih_r)
+        d.x_absmax = _ptr(x_absmax)
+        d.ws = _ptr(rec.ws[i]) if rec.ws[i].numel() else None
+        d.d_w_cat = _ptr(rec.d_w_cat[i])
+        d.B, d.T, d.I, d.H = B, T, I, H
+    return descs
+
+
+def _prepare_pending(dev, current):
+    """Enqueue, on the side stream (behind everything the current stream holds so far), the preparation of every live
+    record of `dev` that has not been prepared: all of them get their [x | y | y]^T planes; W_ih^T only for the records other
+    than `current`, whose input-gradient GEMM follows its recurrence on the main stream within one library call."""
+    lib = _lib.load()
+    refs = _bwd_preps.get(dev.index, [])
+    recs = [r() for r in refs]
+    todo = [r for r in recs if r is not None and not r.have_xc]
+    _bwd_preps[dev.index] = []         # prepared records need no tracking, dead ones are gone
+    if not todo:
+        return
+    main, side = torch.cuda.current_stream(dev), side_stream(dev)
+    for rec in todo:    # allocations belong to the main stream's pool; marked for the side stream below
+        rec.ws, rec.d_w_cat = [], []
+        for x, y, w_ih_f, w_ih_r, x_absmax in rec.probs:
+            B, T, I = x.shape
+            H = w_ih_f.shape[0] // 4
+            rec.ws.append(torch.empty(lib.mmb_bilstm_ws_bytes(B, T, I, H, 1), device=dev, dtype=torch.uint8))
+            rec.d_w_cat.append(torch.empty(8 * H, I + 2 * H, device=dev, dtype=torch.float32))
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for rec in todo:
+            n = len(rec.probs)
+            _lib.check(lib.mmb_bilstm_layer_bwd_phase(_prep_descs(rec, list(range(n))), n, PREPARE | HAVE_WT, dev.index, side.cuda_stream),
+                       "mmb_bilstm_layer_bwd_phase(prepare x)")
+            rec.have_xc = True
+            dx = [i for i in range(n) if rec.need_dx[i]]
+            if rec is not current and dx:
+                _lib.check(lib.mmb_bilstm_layer_bwd_phase(_prep_descs(rec, dx), len(dx), PREPARE | HAVE_XC, dev.index, side.cuda_stream),
+                           "mmb_bilstm_layer_bwd_phase(prepare w)")
+                rec.have_wt = True
+            for t in rec.ws + rec.d_w_cat + [t for p_ in rec.probs for t in p_]:
+                t.record_stream(side)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    for rec in todo:
+        rec.event = ev
 
 
 def _require_gpu(*tensors):
@@ -329,6 +405,14 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         ctx.params = [t for t in flat if isinstance(t, torch.nn.Parameter)]    # to see whether gradients are being accumulated
         ctx.need_dx = [bool(ctx.needs_input_grad[2 + i * _PER_PROBLEM]) for i in range(n)]
         ctx.save_for_backward(*saved)
+        ctx.prep = None
+        if _SIDE_MODE == 2 and torch.is_grad_enabled() and any(t.requires_grad for t in flat if torch.is_tensor(t)):
+            # (detached aliases: a record that held the output y itself would close a reference cycle through its grad_fn)
+            ctx.prep = _BwdPrep(dev, [tuple(saved[10 * i + k].detach() for k in (0, 1, 4, 6, 9)) for i in range(n)], list(ctx.need_dx))
+            refs = _bwd_preps.setdefault(dev.index, [])
+            refs.append(weakref.ref(ctx.prep))
+            if len(refs) > 256:            # forwards whose graphs were dropped without a backward pass
+                _bwd_preps[dev.index] = [r for r in refs if r() is not None][-256:]
         return tuple(outs)
 
     @staticmethod
@@ -343,6 +427,14 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         # storage (AccumulateGrad keeps the tensor it is handed; clip_grad_norm_ / accumulation would hit the pair twice),
         # so b_hh gets views of ONE clone of that buffer
         hs_ = [sv[i * 10 + 5].shape[1] for i in range(n)]
+        side_ok = _USE_SIDE and not torch.is_grad_enabled() and all(p.grad is None for p in ctx.params)
+        prep, flags = ctx.prep, 0
+        if _SIDE_MODE == 2 and side_ok and prep is not None:
+            _prepare_pending(dev, prep)         # first LSTM backward call of the pass: every layer's preparation starts now
+            if prep.have_xc:
+                flags = HAVE_XC | (HAVE_WT if prep.have_wt else 0)
+                if prep.have_wt:   # prepared during an earlier call of this pass (long finished); the call that has just
+                    torch.cuda.current_stream(dev).wait_event(prep.event)   # started its own uses them on the side stream only
         d_b_flat = torch.empty(sum(8 * h for h in hs_), device=dev, dtype=torch.float32)
         d_b_off = [sum(8 * h for h in hs_[:i]) for i in range(n)]
         for i in range(n):
@@ -357,8 +449,11 @@ class _BiLSTMLayerFn(torch.autograd.Function):
             d_w_hh = torch.empty(2, 4 * H, H, device=dev, dtype=torch.float32)
             d_b = d_b_flat[d_b_off[i]:d_b_off[i] + 8 * H].view(2, 4 * H)
             d_a = torch.empty(B, T, 8 * H, device=dev, dtype=torch.float32)
-            d_w_cat = torch.empty(8 * H, I + 2 * H, device=dev, dtype=torch.float32)
-            ws = torch.empty(lib.mmb_bilstm_ws_bytes(B, T, I, H, 1), device=dev, dtype=torch.uint8)
+            if flags:
+                d_w_cat, ws = prep.d_w_cat[i], prep.ws[i]
+            else:
+                d_w_cat = torch.empty(8 * H, I + 2 * H, device=dev, dtype=torch.float32)
+                ws = torch.empty(lib.mmb_bilstm_ws_bytes(B, T, I, H, 1), device=dev, dtype=torch.uint8)
             d = descs[i]
             d.d_y, d.d_hn, d.x, d.y, d.lengths = _ptr(d_y), _ptr(d_hn), _ptr(x), _ptr(y), _ptr(lens)
             d.w_ih[0], d.w_ih[1], d.w_hh[0], d.w_hh[1] = _ptr(w_ih_f), _ptr(w_ih_r), _ptr(w_hh_f), _ptr(w_hh_r)
@@ -373,7 +468,7 @@ class _BiLSTMLayerFn(torch.autograd.Function):
             results += [d_x, d_w_ih[0], d_w_hh[0], d_b[0], None, d_w_ih[1], d_w_hh[1], d_b[1], None]
         # (not when a parameter already holds a gradient: AccumulateGrad then adds on the main stream right after this
         #  function returns, i.e. possibly before the side stream has written the new one)
-        if _USE_SIDE and not torch.is_grad_enabled() and all(p.grad is None for p in ctx.params):
+        if side_ok:
             # BPTT + input gradients on the current stream (the critical path: the next layer's backward waits for d_x);
             # weight / bias gradients on the side stream.  Every buffer the side stream touches is marked so that the
             # caching allocator does not recycle it early; the main stream re-joins once, when autograd has finished.
@@ -384,11 +479,11 @@ class _BiLSTMLayerFn(torch.autograd.Function):
             if _SIDE_MODE == 2:
                 # the work deferred by the previous layer starts now, beside this layer's recurrence (first kernel of phase 1)
                 flush_deferred(dev, to_side=True)
-                _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 1, dev.index, main.cuda_stream), "mmb_bilstm_layer_bwd_phase(1)")
+                _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 1 | flags, dev.index, main.cuda_stream), "mmb_bilstm_layer_bwd_phase(1)")
                 d_b_dup = torch.empty_like(d_b_flat)
 
-                def phase2(stream, descs=descs, n=n, d_b_dup=d_b_dup, d_b_flat=d_b_flat, dev=dev):
-                    _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 2, dev.index, stream.cuda_stream), "mmb_bilstm_layer_bwd_phase(2)")
+                def phase2(stream, descs=descs, n=n, d_b_dup=d_b_dup, d_b_flat=d_b_flat, dev=dev, flags=flags):
+                    _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 2 | flags, dev.index, stream.cuda_stream), "mmb_bilstm_layer_bwd_phase(2)")
                     with torch.cuda.stream(stream):
                         d_b_dup.copy_(d_b_flat)
                 _deferred.setdefault(dev.index, []).append((phase2, touched + [d_b_dup]))
