@@ -406,7 +406,7 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         ctx.need_dx = [bool(ctx.needs_input_grad[2 + i * _PER_PROBLEM]) for i in range(n)]
         ctx.save_for_backward(*saved)
         ctx.prep = None
-        if _SIDE_MODE == 2 and torch.is_grad_enabled() and any(t.requires_grad for t in flat if torch.is_tensor(t)):
+        if _SIDE_MODE == 2 and any(ctx.needs_input_grad):    # (grad mode is off inside forward: ask the context)
             # (detached aliases: a record that held the output y itself would close a reference cycle through its grad_fn)
             ctx.prep = _BwdPrep(dev, [tuple(saved[10 * i + k].detach() for k in (0, 1, 4, 6, 9)) for i in range(n)], list(ctx.need_dx))
             refs = _bwd_preps.setdefault(dev.index, [])
