@@ -992,16 +992,37 @@ __global__ __launch_bounds__(256) void att_combine_kernel(const float* __restric
     const int b = rowi / Np, n = rowi - (long)b * Np, c = threadIdx.x & 63, d = 4 * c;
     f4 v = f4{0.f, 0.f, 0.f, 0.f};
     if (n < N) {
-        float m = -INFINITY;
-        for (int p = 0; p < splits; ++p) m = fmaxf(m, part_stat[(((size_t)b * splits + p) * N + n) * 2]);
-        float l = 0.f;
-#pragma unroll 4
-        for (int p = 0; p < splits; ++p) {
-            const size_t o = ((size_t)b * splits + p) * N + n;
-            const float sc = __expf(part_stat[o * 2] - m);
-            l += part_stat[o * 2 + 1] * sc;
-            if (d < D) v += *reinterpret_cast<const f4*>(part_o + o * D + d) * sc;
+        // four splits per trip: their statistics and partial rows are loaded together (independent of the running values),
+        // lanes beyond D read column 0 and drop it -- no branch around the loads
+        const int dsafe = d < D ? d : 0;
+        float m = -INFINITY, l = 0.f;
+        for (int p0 = 0; p0 < splits; p0 += 4) {
+            float pm[4], pl[4];
+            f4 po[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t o = ((size_t)b * splits + min(p0 + k, splits - 1)) * N + n;
+                pm[k] = part_stat[o * 2];
+                pl[k] = part_stat[o * 2 + 1];
+                po[k] = *reinterpret_cast<const f4*>(part_o + o * D + dsafe);
+            }
+            float mn = m;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (p0 + k < splits) mn = fmaxf(mn, pm[k]);
+            const float resc = __expf(m - mn);   // exp(-inf) = 0 on the first trip
+            l *= resc;
+            v = v * resc;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (p0 + k < splits) {
+                    const float sc = __expf(pm[k] - mn);
+                    l += pl[k] * sc;
+                    v += po[k] * sc;
+                }
+            m = mn;
         }
+        if (d >= D) v = f4{0.f, 0.f, 0.f, 0.f};
         v = v * (1.0f / l);
         if (c == 0) {
             stat[((size_t)b * N + n) * 2] = m;
@@ -1395,16 +1416,26 @@ __global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a, i
         dc[rr] = 0.f;
         c[rr] = dd[rr] = f4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int p = 0; p < S; ++p) {   // the 8 rows' loads of one split are independent: all in flight together
+    const int dsafe = din ? d : 0;   // lanes beyond D read column 0 and drop it: no branch around the loads, so that all
+                                     // 3 * JF_ROWS vector loads of a split are in flight together
+    for (int p = 0; p < S; ++p) {
+        f4 vc[JF_ROWS], v1[JF_ROWS], v2[JF_ROWS];
+        float s1[JF_ROWS], s2[JF_ROWS];
 #pragma unroll
         for (int rr = 0; rr < JF_ROWS; ++rr) {
             const size_t prow = base[rr] + (size_t)p * M;
-            dc[rr] += a.p_dc1[prow] + a.p_dc2[prow];
-            if (din) {
-                c[rr] += *reinterpret_cast<const f4*>(a.p_dmc + prow * D + d);
-                dd[rr] += *reinterpret_cast<const f4*>(a.p_dmd1 + prow * D + d);
-                dd[rr] += *reinterpret_cast<const f4*>(a.p_dmd2 + prow * D + d);
-            }
+            s1[rr] = a.p_dc1[prow];
+            s2[rr] = a.p_dc2[prow];
+            vc[rr] = *reinterpret_cast<const f4*>(a.p_dmc + prow * D + dsafe);
+            v1[rr] = *reinterpret_cast<const f4*>(a.p_dmd1 + prow * D + dsafe);
+            v2[rr] = *reinterpret_cast<const f4*>(a.p_dmd2 + prow * D + dsafe);
+        }
+#pragma unroll
+        for (int rr = 0; rr < JF_ROWS; ++rr) {
+            dc[rr] += s1[rr] + s2[rr];
+            c[rr] += vc[rr];
+            dd[rr] += v1[rr];
+            dd[rr] += v2[rr];
         }
     }
     f4 wacc = f4{0.f, 0.f, 0.f, 0.f};
