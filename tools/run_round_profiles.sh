@@ -11,6 +11,7 @@ B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 rm -rf $R/gpurun_out/prof_stats
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats -o trace --output-format csv -- $B > $R/gpurun_out/${TAG}_rocprof_bench.json 2> $R/gpurun_out/${TAG}_rocprof.err
 python3 $R/tools/profile_summary.py stats $R/gpurun_out/prof_stats > $R/gpurun_out/${TAG}_kernel_stats.md
+python3 $R/tools/profile_summary.py timeline $R/gpurun_out/prof_stats > $R/gpurun_out/${TAG}_timeline.md
 rm -rf $R/gpurun_out/prof_stats
 echo "stats done"
 for C in FETCH_SIZE WRITE_SIZE; do
