@@ -73,9 +73,9 @@ def side_stream(device):
     return s
 
 
-def flush_deferred(device, to_side=True):
+def flush_deferred(device, to_side=True, after=None):
     """Enqueue the deferred weight-gradient work of `device`: on the side stream, ordered behind everything the current
-    stream holds so far (to_side=True), or on the current stream itself."""
+    stream holds so far -- or behind the event `after` only -- (to_side=True), or on the current stream itself."""
     key = _dev_index(device)
     todo = _deferred.get(key)
     if not todo:
@@ -84,7 +84,10 @@ def flush_deferred(device, to_side=True):
     main = torch.cuda.current_stream(key)
     if to_side:
         side = side_stream(key)
-        side.wait_stream(main)
+        if after is not None:
+            side.wait_event(after)
+        else:
+            side.wait_stream(main)
         with torch.cuda.stream(side):
             for fn, tensors in todo:
                 fn(side)
@@ -176,26 +179,32 @@ def _prep_descs(rec, idx):
     return descs
 
 
-def _prepare_pending(dev, current):
-    """Enqueue, on the side stream (behind everything the current stream holds so far), the preparation of every live
-    record of `dev` that has not been prepared: all of them get their [x | y | y]^T planes; W_ih^T only for the records other
-    than `current`, whose input-gradient GEMM follows its recurrence on the main stream within one library call."""
+def _prepare_alloc(dev):
+    """Records of `dev` that still need their preparation, with their backward workspaces allocated (main stream's pool)."""
     lib = _lib.load()
     refs = _bwd_preps.get(dev.index, [])
     recs = [r() for r in refs]
-    todo = [r for r in recs if r is not None and not r.have_xc]
+    todo = [r for r in recs if r is not None and not r.have_xc and r.ws is None]
     _bwd_preps[dev.index] = []         # prepared records need no tracking, dead ones are gone
-    if not todo:
-        return
-    main, side = torch.cuda.current_stream(dev), side_stream(dev)
-    for rec in todo:    # allocations belong to the main stream's pool; marked for the side stream below
+    for rec in todo:
         rec.ws, rec.d_w_cat = [], []
         for x, y, w_ih_f, w_ih_r, x_absmax in rec.probs:
             B, T, I = x.shape
             H = w_ih_f.shape[0] // 4
             rec.ws.append(torch.empty(lib.mmb_bilstm_ws_bytes(B, T, I, H, 1), device=dev, dtype=torch.uint8))
             rec.d_w_cat.append(torch.empty(8 * H, I + 2 * H, device=dev, dtype=torch.float32))
-    side.wait_stream(main)
+    return todo
+
+
+def _prepare_enqueue(dev, todo, current, after):
+    """Enqueue, on the side stream behind the event `after`, the preparation of the records `todo`: all of them get their
+    [x | y | y]^T planes; W_ih^T only the records other than `current`, whose input-gradient GEMM follows its recurrence on
+    the main stream within one library call."""
+    lib = _lib.load()
+    if not todo:
+        return
+    side = side_stream(dev)
+    side.wait_event(after)
     with torch.cuda.stream(side):
         for rec in todo:
             n = len(rec.probs)
@@ -428,13 +437,15 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         # so b_hh gets views of ONE clone of that buffer
         hs_ = [sv[i * 10 + 5].shape[1] for i in range(n)]
         side_ok = _USE_SIDE and not torch.is_grad_enabled() and all(p.grad is None for p in ctx.params)
-        prep, flags = ctx.prep, 0
+        prep, flags, prep_todo = ctx.prep, 0, []
         if _SIDE_MODE == 2 and side_ok and prep is not None:
-            _prepare_pending(dev, prep)         # first LSTM backward call of the pass: every layer's preparation starts now
-            if prep.have_xc:
+            # first LSTM backward call of the pass: every layer's preparation is enqueued below, right after this call's
+            # recurrence (its own planes included: only its weight-gradient phase, on the side stream, reads them)
+            prep_todo = _prepare_alloc(dev)
+            if prep.have_xc or prep in prep_todo:
                 flags = HAVE_XC | (HAVE_WT if prep.have_wt else 0)
-                if prep.have_wt:   # prepared during an earlier call of this pass (long finished); the call that has just
-                    torch.cuda.current_stream(dev).wait_event(prep.event)   # started its own uses them on the side stream only
+                if prep.have_wt:   # prepared during an earlier call of this pass: long finished
+                    torch.cuda.current_stream(dev).wait_event(prep.event)
         d_b_flat = torch.empty(sum(8 * h for h in hs_), device=dev, dtype=torch.float32)
         d_b_off = [sum(8 * h for h in hs_[:i]) for i in range(n)]
         for i in range(n):
@@ -477,9 +488,14 @@ class _BiLSTMLayerFn(torch.autograd.Function):
             #  nobody else holds that tensor object, and would otherwise copy it -- before the side stream has filled it)
             touched = [t for t in keep + list(sv) + [d_b_flat] if t is not None and t.is_cuda]
             if _SIDE_MODE == 2:
-                # the work deferred by the previous layer starts now, beside this layer's recurrence (first kernel of phase 1)
-                flush_deferred(dev, to_side=True)
+                # the work deferred by the previous layer runs beside this layer's recurrence (first kernel of phase 1): it is
+                # ordered behind the main stream's state BEFORE that kernel but enqueued after it, so that the recurrence's
+                # workgroups are dispatched first and the side stream's kernels take the CUs that are left
+                before = torch.cuda.Event()
+                before.record(main)
                 _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 1 | flags, dev.index, main.cuda_stream), "mmb_bilstm_layer_bwd_phase(1)")
+                flush_deferred(dev, to_side=True, after=before)
+                _prepare_enqueue(dev, prep_todo, prep, before)
                 d_b_dup = torch.empty_like(d_b_flat)
 
                 def phase2(stream, descs=descs, n=n, d_b_dup=d_b_dup, d_b_flat=d_b_flat, dev=dev, flags=flags):
