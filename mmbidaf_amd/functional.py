@@ -100,6 +100,19 @@ def flush_deferred(device, to_side=True, after=None):
             fn(main)
 
 
+def _in_backward():
+    task = getattr(torch._C, "_current_graph_task_id", lambda: -1)()
+    return task is not None and task >= 0
+
+
+def _drop_stale_deferred(dev_index):
+    """A forward call outside any backward pass finds deferred work: the pass that queued it died (an exception between
+    two layers' backward calls) and its end-of-backward callback never ran.  The work belongs to a dead graph: drop it."""
+    if _deferred.get(dev_index) and not _in_backward():
+        _deferred[dev_index] = []
+        _join_pending.clear()
+
+
 def defer_grad_work(device, fn):
     """Run fn(stream) where and when the parameter gradients produced so far are final (ddp.FlatGradAllReduce(defer_fn=...)):
     inside a backward pass in mode 2 it joins the deferred queue, right behind the weight-gradient phase that fills the
@@ -376,6 +389,7 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         keep, outs, saved = [], [], []
         dev = flat[0].device
         ctx.set_materialize_grads(False)     # an unused output (h_n of the input encoders) arrives as None, not as a zero fill
+        _drop_stale_deferred(dev.index)
         x_absmax = torch.zeros(n, 2, device=dev, dtype=torch.float32)    # [max |x|, max |W_ih|] per problem, filled by the library
         for i in range(n):
             x, *ws_ = flat[i * _PER_PROBLEM:(i + 1) * _PER_PROBLEM]

@@ -203,3 +203,14 @@ def test_flat_grad_allreduce_gloo_world2(tmp_path, mode, port):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+def test_deferred_work_of_a_dead_backward_pass_is_dropped():
+    """functional._drop_stale_deferred: work queued by a backward pass that died before its end-of-backward callback must
+    not run in a later pass (host logic only: no GPU needed)."""
+    from mmbidaf_amd import functional as MF
+    ran = []
+    MF._deferred[0] = [(lambda stream: ran.append(1), [])]
+    MF._join_pending.add((0, 7))
+    MF._drop_stale_deferred(0)            # called from a forward outside any backward pass
+    assert MF._deferred[0] == [] and not MF._join_pending and not ran
