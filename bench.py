@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--fresh-lengths", action="store_true",
                     help="new ragged lengths every step (the host-derived masks / sort orders miss the device cache, as in real training)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
+                    help="arithmetic of the LSTM layers' matrix-core products: f32 = fp32-accurate split (default; the metric "
+                         "configuration), bf16 = bf16 operands, one product (default for cfg5, which BASELINE.json names as bf16)")
     ap.add_argument("--graph", action="store_true",
                     help="capture one fwd+bwd step of the region into a hipGraph after warm-up and replay it (the C-ABI calls only "
                          "enqueue on the given stream): the host then issues ONE launch per step (N=1, fixed lengths only)")
@@ -178,6 +181,8 @@ def main():
     # gradient exchange: SUM over ranks (the reference's loss is a sum over samples), bucketed in backward order and
     # launched from grad hooks so that it overlaps the rest of the backward pass
     from mmbidaf_amd import functional as MF
+    dtype = a.dtype or ("bf16" if a.config == "cfg5" else "f32")
+    MF.set_precision("bf16" if dtype == "bf16" else "fp32")
     sync = ddp.FlatGradAllReduce(params, buckets=ddp.region_buckets(region), overlap=True, defer_fn=MF.defer_grad_work)
     sync.broadcast_parameters()
     batch = synth.make_batch(a.config, rank=rank, ragged=a.ragged, device=dev, batch=B)
@@ -258,11 +263,15 @@ def main():
             "metric": "samples/sec fwd+bwd, synthetic T_text=400 H=100, at 1/2/4/8 MI355X",
             "value": round(world * B * a.steps / dt, 2), "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 in, fp32 out, fp32 accumulation throughout; recurrences on fp32 VALU; every dense contraction (attention "
-                          "similarity / context products, LSTM projection and gradient GEMMs) on fp16 MFMA from an error-compensated split of "
-                          "the fp32 operands (two fp16 terms of the power-of-two-scaled rows, 3 cross products: max error ~1e-6 of the "
-                          "operand scale, the error class of an fp32 GEMM)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "arithmetic": ("fp32 in, fp32 out, fp32 accumulation throughout; recurrences on fp32 VALU; every dense contraction (attention "
+                           "similarity / context products, LSTM projection and gradient GEMMs) on fp16 MFMA from an error-compensated split of "
+                           "the fp32 operands (two fp16 terms of the power-of-two-scaled rows, 3 cross products: max error ~1e-6 of the "
+                           "operand scale, the error class of an fp32 GEMM)") if dtype == "f32" else
+                          ("fp32 in, fp32 out, fp32 accumulation and cell update; every matrix-core product of the LSTM layers (input "
+                           "projection, recurrent product, input / weight gradients) on v_mfma_f32_16x16x32_bf16 from bf16-rounded operands "
+                           "(mmb_set_precision(1); tolerance 3e-2 of the tensor scale vs the fp32 oracle, tests/test_gpu_parity.py); the "
+                           "attention keeps its fp32-accurate arithmetic"),
             "config": {"workload": f"{a.config}: hot-path region (3 BiLSTM enc -> 2 BiDAF att -> 2 two-layer BiLSTM) "
                                    f"B={B}/GPU T_text={T} T_aud={Ma} T_img={Mi} H={H}, "
                                    f"{'ragged U{n/2..n}' if a.ragged else 'full'} lengths, fwd+bwd"

@@ -300,6 +300,17 @@ int mmb_highway_gate_bwd(const float* d_y, const float* x, float* gt, float* d_x
  */
 int mmb_set_gemm_mode(int mode);
 
+/* Arithmetic of every matrix-core product of the LSTM layers (input projection, recurrent product of the general-size
+ * path, input and weight gradients):
+ *   0  fp32-accurate (default): two-term fp16 split of both operands, three products, fp32 accumulation;
+ *   1  bf16 operands (round to nearest), ONE product, fp32 accumulation -- the "hidden=512 bf16, MFMA LSTM gate GEMMs"
+ *      form of BASELINE.json's last configuration; the reference itself is fp32 throughout (layers/encoding.py:79-81), so
+ *      this mode is outside the 1e-4 parity bar: tests/test_gpu_parity.py states and checks its tolerance (3e-2 of the
+ *      tensor's scale).  Inputs, outputs, saved tensors, the cell update and all accumulation stay fp32.
+ * Process-wide (also MMB_PRECISION=bf16 in the environment); read at every call. */
+int mmb_set_precision(int mode);
+int mmb_get_precision(void);
+
 int mmb_gemm_f32(const float* A, const float* Bm, float* C, const float* bias,
                  int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb, int accumulate,
                  int device, void* stream);

@@ -134,3 +134,13 @@ extern "C" int mmb_stream_destroy(int device, void* stream) {
     MMB_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
     return MMB_OK;
 }
+
+// Arithmetic of the LSTM layers' matrix-core products: 0 = fp32-accurate (two-term fp16 split, three products; default),
+// 1 = plain bf16 operands with fp32 accumulation (one product) -- the "bf16, MFMA LSTM gate GEMMs" form BASELINE.json's
+// H = 512 configuration names.  Process-wide; takes effect at the next call (operand planes are made per call).
+extern "C" int mmb_set_precision(int mode) {
+    MMB_REQUIRE(mode == 0 || mode == 1, "mmb_set_precision: mode must be 0 (fp32-accurate) or 1 (bf16 operands)");
+    mmb::set_precision_mode(mode);
+    return MMB_OK;
+}
+extern "C" int mmb_get_precision(void) { return mmb::precision_mode(); }

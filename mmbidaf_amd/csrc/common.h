@@ -170,6 +170,8 @@ struct PlanesGemmArgs {
     int dbg;      // timing-only ablation (MMB_PLANES_DBG): 2 = no MFMA
 };
 int planes_split_rows(const SplitRowsArgs& a, hipStream_t stream);
+int precision_mode();            // 0: fp32-accurate products (default); 1: bf16 operands in every matrix-core product of the LSTM layers
+void set_precision_mode(int mode);
 bool planes_one_split();   // MMB_PLANES_ONE_SPLIT (default 1): the LSTM backward splits d_a once (k-major read in the weight-gradient GEMM)
 int planes_split_transpose(const SplitTArgs& a, hipStream_t stream);
 int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream);

@@ -151,7 +151,17 @@ struct SkinnyArgs {
     int M, N, K, ks;   // ks = waves sharing a column tile (1, 2 or 4)
 };
 
-template <bool TB>
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8_t to_bf16x8(const f4 lo, const f4 hi) {
+    bf16x8_t v;
+    v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
+    v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
+    return v;
+}
+
+// BF = true (mmb_set_precision(1)): the lane's 8 consecutive k of a chunk are rounded to bf16 and fed to ONE
+// v_mfma_f32_16x16x32_bf16 per 16-row tile (same operand layout: k = 8 kg + j) instead of 8 exact-f32 MFMAs of K = 4.
+template <bool TB, bool BF = false>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
     constexpr int LDA = 36;                       // 32 + 4 floats: 16-B aligned rows, conflict-light b128 reads
     __shared__ __attribute__((aligned(16))) float As[4][64 * LDA];
@@ -227,10 +237,17 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const SkinnyArgs a) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) aq[i][h] = *reinterpret_cast<const f4*>(as + (i * 16 + r) * LDA + 8 * kg + 4 * h);
+            if constexpr (BF) {
+                const bf16x8_t bb = to_bf16x8(bq[0], bq[1]);
 #pragma unroll
-            for (int st = 0; st < 8; ++st)
+                for (int i = 0; i < 4; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(to_bf16x8(aq[i][0], aq[i][1]), bb, acc[i], 0, 0, 0);
+            } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = mfma16(aq[i][st >> 2][st & 3], bq[st >> 2][st & 3], acc[i]);
+                for (int st = 0; st < 8; ++st)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = mfma16(aq[i][st >> 2][st & 3], bq[st >> 2][st & 3], acc[i]);
+            }
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -280,8 +297,11 @@ static int skinny_launch(const float* const* A, const float* const* Bm, float* c
     const int tiles_per_wg = 4 / a.ks;
     const dim3 grid((tiles + tiles_per_wg - 1) / tiles_per_wg, count);
     ProfScope ps_(MMB_K_GEMM, stream);
-    if (tb) hipLaunchKernelGGL(skinny_gemm_kernel<true>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(skinny_gemm_kernel<false>, grid, dim3(256), 0, stream, a);
+    if (precision_mode() == 1) {
+        if (tb) hipLaunchKernelGGL((skinny_gemm_kernel<true, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((skinny_gemm_kernel<false, true>), grid, dim3(256), 0, stream, a);
+    } else if (tb) hipLaunchKernelGGL((skinny_gemm_kernel<true, false>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((skinny_gemm_kernel<false, false>), grid, dim3(256), 0, stream, a);
     MMB_HIP(hipGetLastError());
     return MMB_OK;
 }

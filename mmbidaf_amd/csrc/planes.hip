@@ -17,6 +17,8 @@
 //                current tile's 6*MT*NT MFMAs; tile shape and K split picked per problem by a small cost model.
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "common.h"
 
 namespace mmb {
@@ -78,7 +80,15 @@ __device__ __forceinline__ void store_planes(bf16_t* planes, size_t off, const f
     *reinterpret_cast<bf16x8*>(d + 2048) = h2;
 }
 
-// One wave per (row block, K tile): 16 rows x 128 B in, three contiguous 1-KiB chunks out.  Plane rows r < R1 come from
+// np = 1: the single bf16 term (plain round-to-nearest bf16 operands: the reduced-precision mode, mmb_set_precision)
+__device__ __forceinline__ void store_planes1(bf16_t* planes, size_t off, const float* x) {
+    bf16x8 h0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h0[j] = (__bf16)x[j];
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(planes) + off) = h0;
+}
+
+// One wave per (row block, K tile): 16 rows x 128 B in, three (np = 1: one) contiguous 1-KiB chunks out.  Plane rows r < R1 come from
 // src1, the rest from src2 (stacked); gate_H > 0 permutes each 4H block of rows so that plane row u*4+g holds source row
 // g*H+u.  Rows past R (padding of the last block) are written as zeros.  Optional bias_out[row] = b1[src] + b2[src].
 __global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsArgs a) {
@@ -102,7 +112,8 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsArgs a) 
         if (dr < a.R && 8 * oct + 4 * h < a.C) t = *reinterpret_cast<const f4*>((second ? a.src2 : a.src1) + (size_t)lr * a.ld + 8 * oct + 4 * h);
         x[4 * h] = t.x; x[4 * h + 1] = t.y; x[4 * h + 2] = t.z; x[4 * h + 3] = t.w;
     }
-    store_planes(a.planes, pl_off(dr, oct, nkt), x);
+    if (a.np == 1) store_planes1(a.planes, pl_off(dr, oct, nkt, 1), x);
+    else store_planes(a.planes, pl_off(dr, oct, nkt), x);
     if (a.bias_out && oct == 0 && dr < a.R) a.bias_out[dr] = second ? a.b1b[lr] + a.b2b[lr] : a.b1a[lr] + a.b2a[lr];
 }
 
@@ -294,6 +305,8 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTArgs a
         for (int j = 0; j < 8; ++j) x[j] *= sc;
         store_planes16(a.planes, pl_off(col, (k0 >> 3) + oc, a.Rp / 32, 2), x);
         if (blockIdx.x == 0 && oc == 0 && col < a.Ctot) a.inv_out[col] = 1.0f / sc;
+    } else if (a.np == 1) {
+        store_planes1(a.planes, pl_off(col, (k0 >> 3) + oc, a.Rp / 32, 1), x);
     } else {
         store_planes(a.planes, pl_off(col, (k0 >> 3) + oc, a.Rp / 32), x);
     }
@@ -459,7 +472,14 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
         }
         if (grp == 1 && t + STAGES < nk && !(g.dbg & 8)) dma_stage(t % STAGES);   // tile t+STAGES
         if (!(g.dbg & 2)) {
-            if constexpr (NP == 3) {
+            if constexpr (NP == 1) {
+                // single bf16 term: one product (reduced-precision mode)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][0], a[i][0], acc[i][j], 0, 0, 0);
+            } else if constexpr (NP == 3) {
                 // bf16 planes: cross terms of order <= 2, smallest first: (a plane, b plane)
                 constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, TB[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
@@ -585,7 +605,9 @@ static int launch_planes_np(const PlanesGemmArgs& g, hipStream_t stream) {
     // nothing (459 vs 446 us over the hot-path shapes): the limit is L2 -> LDS throughput next to the MFMA stream, not
     // the latency of a DMA batch.
     constexpr int STAGES = 2;
-    const size_t lds = (size_t)STAGES * NP * (BM + BN) * 64;
+    constexpr size_t lds_stages = (size_t)STAGES * NP * (BM + BN) * 64;
+    constexpr size_t lds_epilogue = (size_t)8 * 16 * (NT * 16 + 4) * sizeof(float);   // the waves' private C staging rows
+    const size_t lds = lds_stages > lds_epilogue ? lds_stages : lds_epilogue;
     auto kern = gemm_planes_kernel<WM, WN, MT, NT, NP, STAGES, TA>;
     static PerDeviceOnce attr;
     if (attr.pending()) {
@@ -606,6 +628,7 @@ static int launch_planes(const PlanesGemmArgs& g, hipStream_t stream) {
     if constexpr ((WM * MT * 16) % 32 == 0) {
         if (g.ta) return launch_planes_np<WM, WN, MT, NT, 2, true>(g, stream);
     }
+    if (g.np == 1) return launch_planes_np<WM, WN, MT, NT, 1>(g, stream);
     return g.np == 2 ? launch_planes_np<WM, WN, MT, NT, 2>(g, stream) : launch_planes_np<WM, WN, MT, NT, 3>(g, stream);
 }
 
@@ -618,7 +641,20 @@ bool planes_one_split() {
     return v == 1;
 }
 
+static std::atomic<int> g_precision{-1};   // 0 = fp32-accurate, 1 = bf16 operands (mmb_set_precision / MMB_PRECISION=bf16)
+int precision_mode() {
+    int v = g_precision.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("MMB_PRECISION");
+        v = (e && (!strcmp(e, "bf16") || !strcmp(e, "1"))) ? 1 : 0;
+        g_precision.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+void set_precision_mode(int mode) { g_precision.store(mode ? 1 : 0, std::memory_order_relaxed); }
+
 int planes_terms() {
+    if (precision_mode() == 1) return 1;
     static int terms = 0;
     if (!terms) {
         const char* e = getenv("MMB_PLANES_TERMS");
@@ -643,7 +679,7 @@ double planes_cost(const PlanesGemmArgs& g, const PlanesCfg& c, int splitk) {
     const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
     const long nk = ((g.K + splitk - 1) / splitk + 31) / 32;
     const long rounds = (tiles * splitk + 255) / 256;
-    const double mfma = 2.0 * c.mt * c.nt * (g.np == 2 ? 3 : 6) * 20, dma = (double)(g.np == 2 ? 2 : 3) * (bm + bn) * 64 / 29.0;
+    const double mfma = 2.0 * c.mt * c.nt * (g.np == 2 ? 3 : g.np == 1 ? 1 : 6) * 20, dma = (double)g.np * (bm + bn) * 64 / 29.0;
     const double per_tile = (mfma > dma ? mfma + 0.25 * dma : dma + 0.25 * mfma) + 300.0;
     double cost = (double)rounds * (nk * per_tile + 6000.0 + 1.5 * bm * bn / 8.0);   // + prologue, first DMA, epilogue stores
     if (splitk > 1) cost += 8000.0 + 0.0068 * (double)g.M * g.N * splitk;
@@ -677,7 +713,7 @@ static void planes_choose(const PlanesGemmArgs& g, int& best, int& best_s) {
 
 int planes_plan_splitk(const PlanesGemmArgs& g_) {
     PlanesGemmArgs g = g_;
-    if (g.np != 2) g.np = 3;
+    if (g.np != 2 && g.np != 1) g.np = 3;
     int best, best_s;
     planes_choose(g, best, best_s);
     return best_s;
@@ -692,7 +728,7 @@ int planes_gemm(const PlanesGemmArgs& g_, hipStream_t stream) {
         verbose = getenv("MMB_PLANES_VERBOSE") != nullptr;
     }
     g.dbg = dbg;
-    if (g.np != 2) g.np = 3;
+    if (g.np != 2 && g.np != 1) g.np = 3;
     MMB_REQUIRE(!g.ta || (g.np == 2 && g.K % 32 == 0), "planes_gemm: a k-major A operand needs the fp16 planes and K %% 32 == 0");
     int best, best_s;
     planes_choose(g, best, best_s);

@@ -549,6 +549,17 @@ def bilstm_layer(problems):
     return [(outs[2 * i], outs[2 * i + 1]) for i in range(len(problems))]
 
 
+def set_precision(mode):
+    """'fp32' (default: fp32-accurate products) or 'bf16' (bf16 operands, one product, fp32 accumulation) for every
+    matrix-core product of the LSTM layers (mmb_set_precision)."""
+    code = {"fp32": 0, "f32": 0, 0: 0, "bf16": 1, 1: 1}[mode]
+    _lib.check(_lib.load().mmb_set_precision(code), "mmb_set_precision")
+
+
+def get_precision():
+    return "bf16" if _lib.load().mmb_get_precision() == 1 else "fp32"
+
+
 def gemm(a, b, bias=None, ta=False, tb=False, out=None, accumulate=False):
     """C = op(a) . op(b) (+bias) through the library's fp32-accurate MFMA GEMM; `out` (contiguous (M,N)) receives the
     result, with accumulate=True it is added to."""

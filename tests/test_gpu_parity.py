@@ -731,7 +731,7 @@ def test_whole_model_golden_h100():
 
 
 # ------------------------------------------------------------------------------------------- region at the BASELINE.json configs
-def _region_vs_oracle(shape, ragged=True, seed=224, lengths=None, grads=True):
+def _region_vs_oracle(shape, ragged=True, seed=224, lengths=None, grads=True, tol=TOL):
     """HotRegion on the GPU vs oracle.HotRegionCPU (the reference's op sequence on torch CPU): the 5 outputs, the input
     gradients and every parameter gradient (the attention bias gradients are analytically 0, Q5)."""
     from mmbidaf_amd import synth
@@ -753,18 +753,18 @@ def _region_vs_oracle(shape, ragged=True, seed=224, lengths=None, grads=True):
     xr = [batch[k].clone().requires_grad_(grads) for k in ("x_text", "x_aud", "x_img")]
     routs = ref(*xr, batch["text_len"], batch["aud_len"], batch["img_len"])
     for n, a, b in zip(("mod_a", "hid_a", "mod_i", "hid_i", "dec_hidden"), outs, routs):
-        close(a, b, n)
+        close(a, b, n, tol=tol)
     for b_, lb in enumerate(batch["text_len"]):      # padded rows of the modelling encoders are exactly zero
         assert (outs[0][b_, lb:] == 0).all() and (outs[2][b_, lb:] == 0).all()
     if not grads:
         return region, batch, outs
     synth.region_loss(routs, batch).backward()
     for n, a, b in zip(("d_x_text", "d_x_aud", "d_x_img"), xs, xr):
-        close(a.grad, b.grad, n)
+        close(a.grad, b.grad, n, tol=tol)
     rg = ref.named_grads()
     for n, p in region.named_parameters():
         if not n.endswith("bidaf_att_audio.bias") and not n.endswith("bidaf_att_image.bias"):
-            close(p.grad, rg[n], "grad " + n)
+            close(p.grad, rg[n], "grad " + n, tol=tol)
     return region, batch, outs
 
 
@@ -828,6 +828,52 @@ def test_hot_region_cfg5_hidden512_vs_oracle():
 def test_hot_region_cfg5_full_size_properties():
     """config 5 at FULL size (B=64, T=400/256/64, H=512): finite, exact zeros in the padding, batch independence."""
     _region_batch_independence((64, 400, 256, 64, 512), sub=2)
+
+
+# ------------------------------------------------------------------------------------------- bf16 operand mode
+# mmb_set_precision(1): bf16 operands (round to nearest), one MFMA product, fp32 accumulation in every matrix-core product of
+# the LSTM layers -- BASELINE.json's "hidden=512 bf16, MFMA LSTM gate GEMMs".  The reference is fp32, so this mode is outside
+# the 1e-4 bar; its stated tolerance: 3e-2 of the tensor's scale (max(1, max |ref|)) on every output and gradient.
+BF16_TOL = 3e-2
+
+
+@pytest.fixture
+def bf16_mode():
+    from mmbidaf_amd import functional as MF
+    MF.set_precision("bf16")
+    assert MF.get_precision() == "bf16"
+    yield
+    MF.set_precision("fp32")
+
+
+def test_bf16_mode_gemm_is_the_product_of_the_rounded_operands(bf16_mode):
+    """operand planes with ONE bf16 term: the GEMM must equal the exact product of the bf16-rounded operands (fp32
+    accumulation), i.e. the only error of the mode is the operand rounding."""
+    from mmbidaf_amd import functional as MF
+    g = torch.Generator().manual_seed(11)
+    for M, N, K in ((300, 400, 100), (1000, 800, 800), (64, 2048, 512)):
+        a, b, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+        ref = (a.bfloat16().double() @ b.bfloat16().double().t() + bias.double()).float()
+        close(MF.gemm_nt_planes(a.to(dev()), b.to(dev()), bias.to(dev())), ref, "bf16 planes gemm", tol=2e-5)
+        full = (a.double() @ b.double().t() + bias.double()).float()
+        assert (ref - full).abs().max() > 1e-3          # and that rounding is visible: the mode really is bf16
+
+
+def test_bf16_mode_hot_region_vs_oracle(bf16_mode):
+    """the register-resident recurrence (H = 100, fp32 VALU) with bf16 input-projection / gradient GEMMs"""
+    _region_vs_oracle((4, 60, 40, 12, 100), ragged=True, tol=BF16_TOL)
+
+
+def test_bf16_mode_hot_region_cfg5_hidden512_vs_oracle(bf16_mode):
+    """config 5's hidden size with the bf16 recurrent product (one v_mfma_f32_16x16x32_bf16 per tile and 32-deep chunk)"""
+    _region_vs_oracle((4, 48, 32, 8, 512), ragged=True, tol=BF16_TOL)
+
+
+def test_bf16_mode_cfg5_full_size_properties(bf16_mode):
+    """config 5 at FULL size in the bf16 mode: finite, exact zeros in the padding, and batch independence up to the mode's own
+    granularity (a different tiling changes fp32 sums in their last bit, which can move a downstream operand across a bf16
+    rounding boundary: differences of a bf16 ulp on single elements, not 2e-5)."""
+    _region_batch_independence((64, 400, 256, 64, 512), sub=2, tol=BF16_TOL / 10)
 
 
 # ------------------------------------------------------------------------------------------- dropout with known masks
