@@ -309,11 +309,11 @@ static int skinny_launch(const float* const* A, const float* const* Bm, float* c
 // ------------------------------------------------------------------------------------------ host side
 static size_t rup256(size_t x) { return (x + 255) / 256 * 256; }
 // forward scratch of one problem: h_pack (2,B,H) | pre (2,B,4H);  backward: a_pack (2,B,4H) | dh_pack (2,B,H) | dc (2,B,H)
-// ... each followed, with MMB_LSTM_FS=1, by the scratch of the fused-step recurrence (lstm_fs.hip: ONE kernel per step
-// on the 16-bit matrix cores).  That variant passes the same parity tests but is NOT the default: at cfg5 it measured
-// 134 ms/step against 92 ms for the two launches per step below (see lstm_fs.hip's header for why).
+// ... each followed by the scratch of the fused-step recurrence (lstm_fs.hip: ONE kernel per step on the 16-bit matrix
+// cores, the default since its workgroups split K over their waves and read every operand fragment once: cfg5 86 vs 92
+// ms/step fp32-accurate, 55 vs 65 ms/step with bf16 operands).  MMB_LSTM_FS=0 selects the two launches per step below.
 static bool use_fused_step() {
-    static const bool v = [] { const char* e = getenv("MMB_LSTM_FS"); return e && atoi(e) != 0; }();
+    static const bool v = [] { const char* e = getenv("MMB_LSTM_FS"); return !(e && atoi(e) == 0); }();
     return v;
 }
 static size_t big_fwd_own(int B, int H) { return rup256((size_t)2 * B * H * 4) + rup256((size_t)2 * B * 4 * H * 4); }

@@ -10,35 +10,44 @@
 // Arithmetic: the error-compensated two-term fp16 split of bidaf.hip / planes.hip (x s = h0 + h1, three MFMA cross
 // products, fp32 accumulate: fp32-level accuracy).  W_hh is split ONCE per layer call into planes whose ROWS are in
 // unit-major order (row 4u + gate), so the 16x16 accumulator tile of v_mfma_f32_16x16x32_f16 -- lane (n, g) holds rows
-// 4g..4g+3 of column n -- gives every lane the FOUR GATES of one (unit, sample) pair: the cell update is lane-local, no
-// LDS exchange, no barrier in the kernel at all.  The recurrent operand travels between steps as planes too:
+// 4g..4g+3 of column n -- holds the FOUR GATES of one (unit, sample) pair as one float4.  The recurrent operand travels between steps as planes too:
 //   h      : |h| < 1, fixed scale 2^13, each lane stores its own two halfs into the next step's planes (ping-pong)
 //   d_a    : scale 2^4 / max(previous step's max |d_a|, max |d_y|) tracked per (problem, direction) by atomicMax -- 2^10 of
 //            head-room for growth between consecutive steps, 2^-29 of the maximum as absolute precision floor; the very
 //            first step uses the true bound max |d_y| + max |d_hn|.
 // Operand fragments are read straight from global memory (L2-resident: W planes 4 MB per chain at H = 512, the
-// recurrent operand 128 / 512 KB), 16 B per lane, exactly the fragment shape -- no LDS at all.
+// recurrent operand 128 / 512 KB), 16 B per lane, exactly the fragment shape -- LDS only carries the partial tiles.
 //
-// STATUS: opt-in (MMB_LSTM_FS=1), parity-tested at H = 136 / 144 / 256 / 512, and SLOWER than lstm_big.hip's two launches
-// per step at cfg5 (B=64, H=512): 119 vs 92 ms per region step (r02; 134 ms before the fragment loads were batched by hand).  Why: with W_hh not resident, every workgroup
-// re-reads its 128-KB W slice AND the whole recurrent operand of its chain every step -- 768 KB per workgroup and step
-// forward (147 MB chip-wide), 4x that in the BPTT where K = 4H -- and one CU takes in ~100 GB/s from L2: ~8 us per
-// forward step, more backward.  Staging through LDS would cut the forward to 256 KB per workgroup (~4 us); the BPTT
-// operand (512 KB per chain and step, needed by every workgroup of the chain) does not fit.  Only a persistent kernel
-// with W_hh resident in LDS avoids the reload -- and needs a per-step barrier across the 32 workgroups of a chain.
+// Workgroup = 16 units x 4 gates x 64 samples (forward) / 32 units x 64 samples (BPTT); its 8 waves SPLIT K and each
+// computes the whole workgroup tile on its K part, so every fragment of W_hh and of the recurrent operand is read exactly
+// once per workgroup (the first version gave each wave its own tile and full K: 768 KB of fragment reads per workgroup
+// and step, 119 ms per cfg5 step); the partial tiles meet in LDS, laid out so that the cell / gate-gradient part then runs
+// with consecutive lanes on consecutive UNITS (contiguous gates / gx / cs / y / d_a accesses instead of one cache line per
+// lane), and that part's own operands (len -> gx, c_prev, d_y, gates, ...) are requested before the K loop.  Workgroup ids
+// are dealt so that all slices of one (encoder, direction) chain run on ONE XCD: its W_hh planes (1-4 MB) and recurrent
+// operand stay in that XCD's L2.  NPL = 2: fp16 two-term planes (fp32-accurate); NPL = 1: one bf16 plane (mmb_set_precision).
+//
+// STATUS: the default for H > MMB_LSTM_MAX_H (MMB_LSTM_FS=0: lstm_big.hip's two launches per step).  cfg5 (B=64, H=512):
+// 86.4 ms per region step fp32-accurate (two launches: 92.2), 54.6 ms with bf16 operands (65.3); forward step ~9 us, BPTT
+// step ~16 us, of which ~5 us are the launch-to-launch floor of a dependent chain; what remains beyond that is the
+// persistent form (W_hh resident, per-step barrier across the workgroups of a chain).
 #include "common.h"
 
 namespace mmb {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
 
-constexpr float FS_HSCALE = 8192.0f;   // 2^13: |h| < 1
+constexpr float FS_HSCALE = 8192.0f;   // 2^13: |h| < 1   (fp16 planes; the bf16 plane is unscaled)
 
-// planes of an (R x K) operand: [row block of 16][k tile of 32][plane 0|1][16 rows x 64 B], no swizzle (never in LDS)
-__host__ __device__ __forceinline__ size_t fs_planes_bytes(int rows, int nkt) { return (size_t)((rows + 15) / 16) * nkt * 2048; }
-__device__ __forceinline__ size_t fs_off(int row, int oct, int nkt) {
-    return ((size_t)(row >> 4) * nkt + (oct >> 2)) * 2048 + (row & 15) * 64 + (oct & 3) * 16;
+// planes of an (R x K) operand: [row block of 16][k tile of 32][plane 0..NPL-1][16 rows x 64 B], no swizzle (never in LDS).
+// NPL = 2: two fp16 terms of the scaled value (fp32-accurate products, 3 MFMAs); NPL = 1: one bf16 term (mmb_set_precision(1)).
+__host__ __device__ __forceinline__ size_t fs_planes_bytes(int rows, int nkt, int npl) { return (size_t)((rows + 15) / 16) * nkt * npl * 1024; }
+__device__ __forceinline__ size_t fs_off(int row, int oct, int nkt, int npl) {
+    return ((size_t)(row >> 4) * nkt + (oct >> 2)) * (npl * 1024) + (row & 15) * 64 + (oct & 3) * 16;
 }
 __device__ __forceinline__ float fs_pow2_scale(float amax, int target_exp) {   // power of two s: s * amax in [2^(t-1), 2^t)
     const unsigned u = __float_as_uint(amax);
@@ -46,15 +55,26 @@ __device__ __forceinline__ float fs_pow2_scale(float amax, int target_exp) {   /
     if (!(amax > 0.0f) || e > 100 || e < -100) return 1.0f;
     return __uint_as_float((unsigned)(target_exp - 1 - e + 127) << 23);
 }
-__device__ __forceinline__ f4 fs_mfma(const half8 a, const half8 b, const f4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+// one K tile of a 16x16 tile: three fp16 cross products (a0 b1 + a1 b0 + a0 b0) or one bf16 product
+template <int NPL>
+__device__ __forceinline__ f4 fs_prod(const u4 (&a)[NPL], const u4 (&b)[NPL], f4 c) {
+    if constexpr (NPL == 2) {
+        const half8 a0 = __builtin_bit_cast(half8, a[0]), a1 = __builtin_bit_cast(half8, a[1]);
+        const half8 b0 = __builtin_bit_cast(half8, b[0]), b1 = __builtin_bit_cast(half8, b[1]);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a[0]), __builtin_bit_cast(bf8, b[0]), c, 0, 0, 0);
+    }
 }
 
 // ---- W_hh planes.  mode 0 (forward): plane row 4u+gate holds W_hh[gate*H+u][0..H)          (rows 4H, K = H)
 //                    mode 1 (BPTT):    plane row u holds W_hh[gate*H+u'][u] at k = 4u'+gate     (rows H,  K = 4H)
-// one wave per plane row: row maximum -> power-of-two scale (max to [2^13, 2^14)) -> two fp16 terms; padding = zeros
+// one wave per plane row: NPL = 2: row maximum -> power-of-two scale (max to [2^13, 2^14)) -> two fp16 terms;
+// NPL = 1: plain bf16, inverse scale 1; padding = zeros
 __global__ __launch_bounds__(256) void lstm_fs_wprep_kernel(const float* __restrict__ w_hh, char* __restrict__ planes,
-                                                            float* __restrict__ inv, int H, int mode, int rows_p, int nkt) {
+                                                            float* __restrict__ inv, int H, int mode, int rows_p, int nkt, int npl) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows_p) return;
     const int rows = mode ? H : 4 * H, K = mode ? 4 * H : H;
@@ -63,25 +83,46 @@ __global__ __launch_bounds__(256) void lstm_fs_wprep_kernel(const float* __restr
         if (mode == 0) return w_hh[(size_t)((row & 3) * H + (row >> 2)) * H + k];
         return w_hh[(size_t)((k & 3) * H + (k >> 2)) * H + row];
     };
-    float amax = 0.f;
-    for (int k = lane; k < K; k += 64) amax = fmaxf(amax, fabsf(elem(k)));
+    float s = 1.0f;
+    if (npl == 2) {
+        float amax = 0.f;
+        for (int k = lane; k < K; k += 64) amax = fmaxf(amax, fabsf(elem(k)));
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    const float s = fs_pow2_scale(amax, 14);
-    if (lane == 0) inv[row] = amax > 0.f ? 1.0f / s : 0.f;
-    for (int oct = lane; oct < nkt * 4; oct += 64) {
-        half8 h0, h1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = elem(8 * oct + j) * s;
-            const _Float16 a = (_Float16)v;
-            h0[j] = a;
-            h1[j] = (_Float16)(v - (float)a);
-        }
-        char* d = planes + fs_off(row, oct, nkt);
-        *reinterpret_cast<half8*>(d) = h0;
-        *reinterpret_cast<half8*>(d + 1024) = h1;
+        for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        s = fs_pow2_scale(amax, 14);
+        if (lane == 0) inv[row] = amax > 0.f ? 1.0f / s : 0.f;
+    } else if (lane == 0) {
+        inv[row] = 1.0f;
     }
+    for (int oct = lane; oct < nkt * 4; oct += 64) {
+        char* d = planes + fs_off(row, oct, nkt, npl);
+        if (npl == 2) {
+            half8 h0, h1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = elem(8 * oct + j) * s;
+                const _Float16 a = (_Float16)v;
+                h0[j] = a;
+                h1[j] = (_Float16)(v - (float)a);
+            }
+            *reinterpret_cast<half8*>(d) = h0;
+            *reinterpret_cast<half8*>(d + 1024) = h1;
+        } else {
+            bf8 h0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h0[j] = (__bf16)elem(8 * oct + j);
+            *reinterpret_cast<bf8*>(d) = h0;
+        }
+    }
+}
+
+// block id -> (chain, slice): workgroup ids go round-robin over the 8 XCDs, so giving all slices of chain c the ids
+// c + slots * slice (slots = chains rounded up to 8) keeps one chain's weights and recurrent operand in ONE XCD's L2
+__device__ __forceinline__ bool fs_decode(int nchains, int& chain, int& slice) {
+    const int slots = (nchains + 7) & ~7;
+    chain = blockIdx.x % slots;
+    slice = blockIdx.x / slots;
+    return chain < nchains;
 }
 
 // ------------------------------------------------------------------------------------------ forward step
@@ -95,70 +136,95 @@ struct FsFwdProb {
     char* hp[2][2];         // h planes [direction][step parity], rows = samples padded to 64, zero at entry
     int B, T, H;
 };
-struct FsFwdArgs { FsFwdProb p[MMB_MAX_GROUP]; int n, nkt; };
+struct FsFwdArgs { FsFwdProb p[MMB_MAX_GROUP]; int n, nkt, nslices, nsb; };
 
-// grid (unit slices of 16, chains = 2 * problems, sample blocks of 64); 8 waves: wave = (m tile of 4 units, half of the
-// sample block); no LDS, no barrier
+// One workgroup = 16 units x 4 gates (64 plane rows) x 64 samples; its 8 waves SPLIT K (wave w takes k tiles w, w+8, ...)
+// and each computes all 4 x 4 tiles of the workgroup tile on its K part, so every operand fragment is read exactly once per
+// workgroup; the 8 partial tiles meet in LDS (128 KiB) and each thread then owns two (unit, sample) pairs with their four
+// gates: the cell update is thread-local.
+template <int NPL>
 __global__ __launch_bounds__(512) void lstm_fs_fwd_kernel(const FsFwdArgs args, const int s) {
-    const FsFwdProb& P = args.p[blockIdx.y >> 1];
-    const int dir = blockIdx.y & 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int chain, sl;
+    if (!fs_decode(2 * args.n, chain, sl)) return;
+    const int slice = sl % args.nslices, sblk = sl / args.nslices;
+    const FsFwdProb& P = args.p[chain >> 1];
+    const int dir = chain & 1;
     const int H = P.H, T = P.T, nkt = args.nkt;
-    if (s >= T) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, g = lane >> 4, mt = wave & 3, nh = wave >> 2;
-    const int b0 = 64 * blockIdx.z + 32 * nh;
-    if (b0 >= P.B) return;
-    const int rowA = 64 * blockIdx.x + 16 * mt + r;
-    const char* A = P.wp[dir] + fs_off(rowA, g, nkt);
-    const char* hprev = P.hp[dir][(s + 1) & 1];
-    const char* Bq[2] = {hprev + fs_off(b0 + r, g, nkt), hprev + fs_off(b0 + 16 + r, g, nkt)};
-    f4 c[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-    if (s > 0) {   // h_{-1} = 0
-        // 4 k tiles per trip, all 24 fragment loads issued before the first MFMA (hipcc does not unroll this loop by
-        // itself, and 6 loads in flight per wave leave the kernel waiting on L2 latency)
-        const half8 z8 = {};
-        for (int kt0 = 0; kt0 < nkt; kt0 += 4) {
-            half8 a0[4], a1[4], h0[4][2], h1[4][2];
+    if (s >= T || 64 * sblk >= P.B) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    f4* part = reinterpret_cast<f4*>(smem);               // [wave][sample 64][17] quads
+    // the cell update's own operands (thread -> two (unit, sample) pairs, units fastest) are requested FIRST: their two
+    // dependent global latencies (len -> gx / c_prev) then run under the operand loads, the MFMAs and the reduction
+    int e_t[2], e_len[2];
+    bool e_on[2];
+    f4 e_gx[2];
+    float e_cp[2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const size_t o = (size_t)min(kt0 + q, nkt - 1) * 2048;
-                a0[q] = *reinterpret_cast<const half8*>(A + o);
-                a1[q] = *reinterpret_cast<const half8*>(A + o + 1024);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    h0[q][j] = *reinterpret_cast<const half8*>(Bq[j] + o);
-                    h1[q][j] = *reinterpret_cast<const half8*>(Bq[j] + o + 1024);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (kt0 + q >= nkt) { a0[q] = z8; a1[q] = z8; }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    c[j] = fs_mfma(a0[q], h1[q][j], c[j]);
-                    c[j] = fs_mfma(a1[q], h0[q][j], c[j]);
-                    c[j] = fs_mfma(a0[q], h0[q][j], c[j]);
-                }
-            }
+    for (int q = 0; q < 2; ++q) {
+        const int pair = tid + 512 * q, u = 16 * slice + (pair & 15), b = 64 * sblk + (pair >> 4);
+        const int len = (u < H && b < P.B) ? min(max(P.len[b], 0), T) : 0;
+        e_len[q] = len;
+        e_on[q] = s < len;
+        e_t[q] = dir ? len - 1 - s : s;
+        e_gx[q] = f4{0.f, 0.f, 0.f, 0.f};
+        e_cp[q] = 0.f;
+        if (e_on[q]) {
+            const size_t row = (size_t)b * T + e_t[q];
+            e_gx[q] = *reinterpret_cast<const f4*>(P.gx + (row * 2 + dir) * 4 * H + (size_t)u * 4);
+            if (s > 0) e_cp[q] = P.cs[((size_t)b * T + (dir ? e_t[q] + 1 : e_t[q] - 1)) * 2 * H + dir * H + u];
         }
     }
-    // lane (n = r, g) holds rows 4g..4g+3 of the tile = gates i,f,g,o of unit u for sample b
-    const int u = 16 * blockIdx.x + 4 * mt + g;
-    if (u >= H) return;
-    const f4 wi = *reinterpret_cast<const f4*>(P.winv[dir] + 4 * u);
+    f4 c[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {   // h_{-1} = 0
+        const char* A = P.wp[dir] + fs_off(64 * slice + r, g, nkt, NPL);
+        const char* Bh = P.hp[dir][(s + 1) & 1] + fs_off(64 * sblk + r, g, nkt, NPL);
+        const size_t rbA = (size_t)nkt * NPL * 1024;     // bytes from one 16-row block to the next
+        for (int kt = wave; kt < nkt; kt += 8) {
+            u4 a[4][NPL], b[4][NPL];
+            const size_t o = (size_t)kt * NPL * 1024;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    a[i][pl] = *reinterpret_cast<const u4*>(A + i * rbA + o + pl * 1024);
+                    b[i][pl] = *reinterpret_cast<const u4*>(Bh + i * rbA + o + pl * 1024);
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[i][j] = fs_prod<NPL>(a[i], b[j], c[i][j]);
+        }
+    }
+    // partial tiles to LDS as [wave][sample 64][unit 16 (+1 pad)] quads (the 4 gates of a (unit, sample) pair), so that the
+    // update below runs with consecutive lanes on consecutive UNITS: every global access of it is then contiguous
+    // (16 units x 16 B of gates / gx, 16 x 4 B of cs / y per sample), not one cache line per lane
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[(wave * 64 + 16 * j + r) * 17 + 4 * i + g] = c[i][j];
+    __syncthreads();
     char* hnext = P.hp[dir][s & 1];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int b = b0 + 16 * j + r;
-        if (b >= P.B) continue;
-        const int len = min(max(P.len[b], 0), T);
-        if (s >= len) continue;
-        const int t = dir ? len - 1 - s : s;
+    for (int q = 0; q < 2; ++q) {
+        const int pair = tid + 512 * q, ul = pair & 15, bl = pair >> 4;
+        f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 8; ++w) acc += part[(w * 64 + bl) * 17 + ul];
+        const int u = 16 * slice + ul;
+        const int b = 64 * sblk + bl;
+        if (!e_on[q]) continue;
+        const int t = e_t[q];
         const size_t row = (size_t)b * T + t;
-        const f4 pre = c[j] * wi * (1.0f / FS_HSCALE);
-        const f4 gx = *reinterpret_cast<const f4*>(P.gx + (row * 2 + dir) * 4 * H + (size_t)u * 4);
-        float c_prev = 0.f;
-        if (s > 0) c_prev = P.cs[((size_t)b * T + (dir ? t + 1 : t - 1)) * 2 * H + dir * H + u];
+        f4 pre = acc;
+        if (NPL == 2) pre = acc * *reinterpret_cast<const f4*>(P.winv[dir] + 4 * u) * (1.0f / FS_HSCALE);
+        const f4 gx = e_gx[q];
+        const float c_prev = e_cp[q];
         const float gi = sigmoidf_(pre.x + gx.x), gf = sigmoidf_(pre.y + gx.y);
         const float gg = tanhf_(pre.z + gx.z), go = sigmoidf_(pre.w + gx.w);
         const float cc = fmaf(gf, c_prev, gi * gg);
@@ -166,15 +232,18 @@ __global__ __launch_bounds__(512) void lstm_fs_fwd_kernel(const FsFwdArgs args, 
         *reinterpret_cast<f4*>(P.gates + (row * 2 + dir) * 4 * H + (size_t)u * 4) = f4{gi, gf, gg, go};
         P.cs[row * 2 * H + dir * H + u] = cc;
         P.y[row * 2 * H + dir * H + u] = h;
-        {   // this lane's element of the next step's operand planes
-            const float hv = h * FS_HSCALE;
-            const _Float16 h0 = (_Float16)hv;
-            const _Float16 h1 = (_Float16)(hv - (float)h0);
-            char* d = hnext + fs_off(b, u >> 3, nkt) + (u & 7) * 2;
-            *reinterpret_cast<_Float16*>(d) = h0;
-            *reinterpret_cast<_Float16*>(d + 1024) = h1;
+        {   // this thread's element of the next step's operand planes
+            char* d = hnext + fs_off(b, u >> 3, nkt, NPL) + (u & 7) * 2;
+            if (NPL == 2) {
+                const float hv = h * FS_HSCALE;
+                const _Float16 h0 = (_Float16)hv;
+                *reinterpret_cast<_Float16*>(d) = h0;
+                *reinterpret_cast<_Float16*>(d + 1024) = (_Float16)(hv - (float)h0);
+            } else {
+                *reinterpret_cast<__bf16*>(d) = (__bf16)h;
+            }
         }
-        if (s == len - 1) {
+        if (s == e_len[q] - 1) {
             const size_t st = ((size_t)dir * P.B + b) * H + u;
             P.h_n[P.hn_pos ? ((size_t)P.hn_pos[b] * 2 + dir) * H + u : st] = h;
             P.c_n[st] = cc;
@@ -195,84 +264,137 @@ struct FsBwdProb {
     const float* bound;     // [2]: max |d_y|, max |d_hn| over the whole problem
     int B, T, H;
 };
-struct FsBwdArgs { FsBwdProb p[MMB_MAX_GROUP]; int n, nkt4; };
+struct FsBwdArgs { FsBwdProb p[MMB_MAX_GROUP]; int n, nkt4, nslices, nsb; };
 
-// scale of the d_a planes WRITTEN at step s (and read at step s+1): every lane derives the same power of two
+// scale of the d_a planes WRITTEN at step s (and read at step s+1): every lane derives the same power of two (fp16 planes)
 __device__ __forceinline__ float fs_da_scale(const FsBwdProb& P, int dir, int s) {
     const float y = P.bound[0];
     const float ref = s == 0 ? y + P.bound[1] : fmaxf(P.amax[dir][s - 1], y);
     return fs_pow2_scale(ref, 5);      // reference magnitude to [2^4, 2^5): 2^10 of head-room below the 2^15 clamp
 }
 
-// grid (unit slices of 32, chains, sample blocks of 64); 8 waves: wave = (m tile of 16 units, n tile of 16 samples), full K
+// One workgroup = 32 units (2 m tiles) x 64 samples, K = 4H split over its 8 waves (k tiles w, w+8, ...): every fragment
+// of W_hh^T and of the previous step's d_a is read once per workgroup; partial tiles meet in LDS (64 KiB); each thread then
+// owns 4 units of one sample.
+template <int NPL>
 __global__ __launch_bounds__(512) void lstm_fs_bwd_kernel(const FsBwdArgs args, const int s) {
-    const FsBwdProb& P = args.p[blockIdx.y >> 1];
-    const int dir = blockIdx.y & 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int chain, sl;
+    if (!fs_decode(2 * args.n, chain, sl)) return;
+    const int slice = sl % args.nslices, sblk = sl / args.nslices;
+    const FsBwdProb& P = args.p[chain >> 1];
+    const int dir = chain & 1;
     const int H = P.H, T = P.T, nkt = args.nkt4;
-    if (s >= T) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, g = lane >> 4, mt = wave & 1, nt = wave >> 1;
-    const int b = 64 * blockIdx.z + 16 * nt + r;
-    if (64 * blockIdx.z + 16 * nt >= P.B) return;
-    f4 c = f4{0.f, 0.f, 0.f, 0.f};
-    if (s > 0) {
-        const char* A = P.wtp[dir] + fs_off(32 * blockIdx.x + 16 * mt + r, g, nkt);
-        const char* Bq = P.ap[dir][(s + 1) & 1] + fs_off(64 * blockIdx.z + 16 * nt + r, g, nkt);
-        const half8 z8 = {};
-        for (int kt0 = 0; kt0 < nkt; kt0 += 8) {   // 8 k tiles per trip: 32 fragment loads in flight
-            half8 a0[8], a1[8], d0[8], d1[8];
+    if (s >= T || 64 * sblk >= P.B) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    // the gate-gradient part's own operands (thread -> one unit of 4 samples, units fastest) are requested FIRST: their two
+    // dependent global latencies (len -> d_y / gates / cs / dc) then run under the operand loads, the MFMAs and the reduction
+    const int ul = tid & 31, u = 32 * slice + ul;
+    int e_t[4], e_len[4];
+    bool e_on[4];
+    float e_dy[4], e_dcs[4], e_ct[4], e_cp[4];
+    f4 e_g4[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const size_t o = (size_t)min(kt0 + q, nkt - 1) * 2048;
-                a0[q] = *reinterpret_cast<const half8*>(A + o);
-                a1[q] = *reinterpret_cast<const half8*>(A + o + 1024);
-                d0[q] = *reinterpret_cast<const half8*>(Bq + o);
-                d1[q] = *reinterpret_cast<const half8*>(Bq + o + 1024);
+    for (int k = 0; k < 4; ++k) {
+        const int b = 64 * sblk + (tid >> 5) + 16 * k;
+        const int len = (b < P.B && u < H) ? min(max(P.len[b], 0), T) : 0;
+        e_len[k] = len;
+        e_on[k] = s < len;
+        const int t = dir ? s : len - 1 - s;       // BPTT visits the forward processing order backwards
+        e_t[k] = t;
+        e_dy[k] = e_dcs[k] = e_ct[k] = e_cp[k] = 0.f;
+        e_g4[k] = f4{0.f, 0.f, 0.f, 0.f};
+        if (e_on[k]) {
+            const size_t row = (size_t)b * T + t;
+            const size_t st = ((size_t)dir * P.B + b) * H + u;
+            e_dy[k] = P.d_y[row * 2 * H + dir * H + u];
+            if (s == 0) { if (P.d_hn) e_dy[k] += P.d_hn[P.hn_pos ? ((size_t)P.hn_pos[b] * 2 + dir) * H + u : st]; }
+            else e_dcs[k] = P.dc[st];
+            e_g4[k] = *reinterpret_cast<const f4*>(P.gates + (row * 2 + dir) * 4 * H + (size_t)u * 4);
+            e_ct[k] = P.cs[row * 2 * H + dir * H + u];
+            const bool has_prev = dir ? (t + 1 < len) : (t > 0);
+            if (has_prev) e_cp[k] = P.cs[((size_t)b * T + (dir ? t + 1 : t - 1)) * 2 * H + dir * H + u];
+        }
+    }
+    f4 c[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+        const char* A = P.wtp[dir] + fs_off(32 * slice + r, g, nkt, NPL);
+        const char* Bq = P.ap[dir][(s + 1) & 1] + fs_off(64 * sblk + r, g, nkt, NPL);
+        const size_t rb = (size_t)nkt * NPL * 1024;
+        for (int kt0 = wave; kt0 < nkt; kt0 += 16) {   // two k tiles per trip: 12 * NPL fragment loads in flight
+            u4 a[2][2][NPL], b[2][4][NPL];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const size_t o = (size_t)min(kt0 + 8 * q, nkt - 1) * NPL * 1024;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) a[q][i][pl] = *reinterpret_cast<const u4*>(A + i * rb + o + pl * 1024);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[q][j][pl] = *reinterpret_cast<const u4*>(Bq + j * rb + o + pl * 1024);
+                }
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (kt0 + q >= nkt) { a0[q] = z8; a1[q] = z8; }
-                c = fs_mfma(a0[q], d1[q], c);
-                c = fs_mfma(a1[q], d0[q], c);
-                c = fs_mfma(a0[q], d0[q], c);
+            for (int q = 0; q < 2; ++q) {
+                if (kt0 + 8 * q >= nkt) continue;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) c[i][j] = fs_prod<NPL>(a[q][i], b[q][j], c[i][j]);
             }
         }
     }
-    const float inv_prev = s > 0 ? 1.0f / fs_da_scale(P, dir, s - 1) : 0.f;
-    const float sc = fs_da_scale(P, dir, s);
+    // partial tiles to LDS as [wave][sample 64][unit 32 (+1 pad)] floats: the gate-gradient part below then runs with
+    // consecutive lanes on consecutive units (contiguous d_y / cs / gates / d_a / plane accesses)
+    float* partf = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) partf[(wave * 64 + 16 * j + r) * 33 + 16 * i + 4 * g + e] = c[i][j][e];
+    __syncthreads();
+    float inv_prev = 1.0f, sc = 1.0f;
+    if (NPL == 2) {
+        inv_prev = s > 0 ? 1.0f / fs_da_scale(P, dir, s - 1) : 0.f;
+        sc = fs_da_scale(P, dir, s);
+    }
     char* anext = P.ap[dir][s & 1];
     float lmax = 0.f;
-    const int len = b < P.B ? min(max(P.len[b], 0), T) : 0;
-    if (b < P.B && s < len) {
-        // BPTT visits the forward processing order backwards: forward direction t = len-1-s, reverse direction t = s
-        const int t = dir ? s : len - 1 - s;
-        const size_t row = (size_t)b * T + t;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int u = 32 * blockIdx.x + 16 * mt + 4 * g + e;
-            if (u >= H) continue;
-            const size_t st = ((size_t)dir * P.B + b) * H + u;
-            float dh = c[e] * P.wtinv[dir][u] * inv_prev + P.d_y[row * 2 * H + dir * H + u];
-            float dcs = 0.f;
-            if (s == 0) { if (P.d_hn) dh += P.d_hn[P.hn_pos ? ((size_t)P.hn_pos[b] * 2 + dir) * H + u : st]; }
-            else dcs = P.dc[st];
-            const f4 g4 = *reinterpret_cast<const f4*>(P.gates + (row * 2 + dir) * 4 * H + (size_t)u * 4);
-            const float c_t = P.cs[row * 2 * H + dir * H + u];
-            const bool has_prev = dir ? (t + 1 < len) : (t > 0);
-            const float c_prev = has_prev ? P.cs[((size_t)b * T + (dir ? t + 1 : t - 1)) * 2 * H + dir * H + u] : 0.f;
-            const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
-            const float tc = tanhf_(c_t);
-            const float dc_t = fmaf(dh * go, 1.0f - tc * tc, dcs);
-            const float da0 = dc_t * gg * gi * (1.0f - gi), da1 = dc_t * c_prev * gf * (1.0f - gf);
-            const float da2 = dc_t * gi * (1.0f - gg * gg), da3 = dh * tc * go * (1.0f - go);
-            float* da = P.d_a + row * 8 * H + (size_t)dir * 4 * H + u;
-            da[0] = da0;
-            da[(size_t)H] = da1;
-            da[(size_t)2 * H] = da2;
-            da[(size_t)3 * H] = da3;
-            P.dc[st] = dc_t * gf;
+    for (int k = 0; k < 4; ++k) {
+        const int bl = (tid >> 5) + 16 * k, b = 64 * sblk + bl;
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) acc += partf[(w * 64 + bl) * 33 + ul];
+        if (!e_on[k]) continue;
+        const int t = e_t[k];
+        const size_t row = (size_t)b * T + t;
+        const size_t st = ((size_t)dir * P.B + b) * H + u;
+        const float dh = (NPL == 2 ? acc * P.wtinv[dir][u] * inv_prev : acc) + e_dy[k];
+        const float dcs = e_dcs[k];
+        const f4 g4 = e_g4[k];
+        const float c_t = e_ct[k], c_prev = e_cp[k];
+        const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
+        const float tc = tanhf_(c_t);
+        const float dc_t = fmaf(dh * go, 1.0f - tc * tc, dcs);
+        const float da0 = dc_t * gg * gi * (1.0f - gi), da1 = dc_t * c_prev * gf * (1.0f - gf);
+        const float da2 = dc_t * gi * (1.0f - gg * gg), da3 = dh * tc * go * (1.0f - go);
+        float* da = P.d_a + row * 8 * H + (size_t)dir * 4 * H + u;
+        da[0] = da0;
+        da[(size_t)H] = da1;
+        da[(size_t)2 * H] = da2;
+        da[(size_t)3 * H] = da3;
+        P.dc[st] = dc_t * gf;
+        // the four gates of unit u are 4 consecutive k of the next step's operand: one 8-B store per plane
+        char* d = anext + fs_off(b, u >> 1, nkt, NPL) + (u & 1) * 8;
+        if (NPL == 2) {
             lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(da0), fabsf(da1)), fmaxf(fabsf(da2), fabsf(da3))));
-            // the four gates of unit u are 4 consecutive k of the next step's operand: one 8-B store per plane
             const float v[4] = {da0 * sc, da1 * sc, da2 * sc, da3 * sc};
             half4 h0, h1;
 #pragma unroll
@@ -282,15 +404,19 @@ __global__ __launch_bounds__(512) void lstm_fs_bwd_kernel(const FsBwdArgs args, 
                 h0[q] = a;
                 h1[q] = (_Float16)(x - (float)a);
             }
-            char* d = anext + fs_off(b, u >> 1, nkt) + (u & 1) * 8;
             *reinterpret_cast<half4*>(d) = h0;
             *reinterpret_cast<half4*>(d + 1024) = h1;
+        } else {
+            const bf4 h0 = {(__bf16)da0, (__bf16)da1, (__bf16)da2, (__bf16)da3};
+            *reinterpret_cast<bf4*>(d) = h0;
         }
     }
     // (a sample whose chain has ended keeps stale but finite planes: whatever the later steps compute for it is ignored)
+    if (NPL == 2) {
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-    if (lane == 0 && lmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(&P.amax[dir][s]), __float_as_uint(lmax));
+        for (int o = 32; o >= 1; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+        if (lane == 0 && lmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(&P.amax[dir][s]), __float_as_uint(lmax));
+    }
 }
 
 // out[0] = max(out[0], max |p[i]|)  (out pre-zeroed)
@@ -313,11 +439,11 @@ static FsFwdWs fs_fwd_layout(int B, int H) {
     w.nkt = fs_pad(H, 32) / 32;
     const int rows_p = fs_pad(4 * H, 64), Bp = fs_pad(B, 64);
     size_t o = 0;
-    for (int d = 0; d < 2; ++d) { w.wp[d] = o; o += fs_rup(fs_planes_bytes(rows_p, w.nkt)); }
+    for (int d = 0; d < 2; ++d) { w.wp[d] = o; o += fs_rup(fs_planes_bytes(rows_p, w.nkt, 2)); }
     for (int d = 0; d < 2; ++d) { w.winv[d] = o; o += fs_rup((size_t)rows_p * 4); }
     w.zero_from = o;
     for (int d = 0; d < 2; ++d)
-        for (int q = 0; q < 2; ++q) { w.hp[d][q] = o; o += fs_rup(fs_planes_bytes(Bp, w.nkt)); }
+        for (int q = 0; q < 2; ++q) { w.hp[d][q] = o; o += fs_rup(fs_planes_bytes(Bp, w.nkt, 2)); }
     w.total = o;
     return w;
 }
@@ -327,14 +453,14 @@ static FsBwdWs fs_bwd_layout(int B, int T, int H) {
     w.nkt4 = fs_pad(4 * H, 32) / 32;
     const int rows_p = fs_pad(H, 32), Bp = fs_pad(B, 64);
     size_t o = 0;
-    for (int d = 0; d < 2; ++d) { w.wtp[d] = o; o += fs_rup(fs_planes_bytes(rows_p, w.nkt4)); }
+    for (int d = 0; d < 2; ++d) { w.wtp[d] = o; o += fs_rup(fs_planes_bytes(rows_p, w.nkt4, 2)); }
     for (int d = 0; d < 2; ++d) { w.wtinv[d] = o; o += fs_rup((size_t)rows_p * 4); }
     w.zero_from = o;
     w.bound = o; o += 256;
     for (int d = 0; d < 2; ++d) { w.amax[d] = o; o += fs_rup((size_t)(T + 1) * 4); }
     w.dc = o; o += fs_rup((size_t)2 * B * H * 4);
     for (int d = 0; d < 2; ++d)
-        for (int q = 0; q < 2; ++q) { w.ap[d][q] = o; o += fs_rup(fs_planes_bytes(Bp, w.nkt4)); }
+        for (int q = 0; q < 2; ++q) { w.ap[d][q] = o; o += fs_rup(fs_planes_bytes(Bp, w.nkt4, 2)); }
     w.total = o;
     return w;
 }
@@ -345,6 +471,7 @@ size_t lstm_fs_bwd_ws_bytes(int B, int T, int H) { return fs_bwd_layout(B, T, H)
 int lstm_fs_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* ws, hipStream_t stream) {
     FsFwdArgs a{};
     a.n = n;
+    const int npl = precision_mode() == 1 ? 1 : 2;
     const int H = d[0].H;
     int maxT = 0, maxB = 0;
     for (int i = 0; i < n; ++i) {
@@ -362,16 +489,28 @@ int lstm_fs_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* ws, hipStream_t 
             q.hp[dir][0] = ws[i] + L.hp[dir][0];
             q.hp[dir][1] = ws[i] + L.hp[dir][1];
             hipLaunchKernelGGL(lstm_fs_wprep_kernel, dim3((rows_p + 3) / 4), dim3(256), 0, stream, p.w_hh[dir], ws[i] + L.wp[dir],
-                               reinterpret_cast<float*>(ws[i] + L.winv[dir]), H, 0, rows_p, L.nkt);
+                               reinterpret_cast<float*>(ws[i] + L.winv[dir]), H, 0, rows_p, L.nkt, npl);
         }
         maxT = max(maxT, p.T);
         maxB = max(maxB, p.B);
     }
     MMB_HIP(hipGetLastError());
-    const dim3 grid((H + 15) / 16, 2 * n, (maxB + 63) / 64);
+    a.nslices = (H + 15) / 16;
+    a.nsb = (maxB + 63) / 64;
+    const int slots = (2 * n + 7) & ~7;
+    const dim3 grid(slots * a.nslices * a.nsb);
+    constexpr int lds = 8 * 64 * 17 * 16;   // 8 partial tiles of 64 samples x (16 + 1) gate quads
+    auto kern = npl == 2 ? lstm_fs_fwd_kernel<2> : lstm_fs_fwd_kernel<1>;
+    {
+        static PerDeviceOnce attr[2];
+        if (attr[npl - 1].pending()) {
+            MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr[npl - 1].mark();
+        }
+    }
     {
         ProfScope ps_(MMB_K_LSTM_REC_FWD, stream);
-        for (int s = 0; s < maxT; ++s) hipLaunchKernelGGL(lstm_fs_fwd_kernel, grid, dim3(512), 0, stream, a, s);
+        for (int s = 0; s < maxT; ++s) hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a, s);
     }
     MMB_HIP(hipGetLastError());
     return MMB_OK;
@@ -380,6 +519,7 @@ int lstm_fs_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* ws, hipStream_t 
 int lstm_fs_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* ws, hipStream_t stream) {
     FsBwdArgs a{};
     a.n = n;
+    const int npl = precision_mode() == 1 ? 1 : 2;
     const int H = d[0].H;
     int maxT = 0, maxB = 0;
     for (int i = 0; i < n; ++i) {
@@ -393,8 +533,10 @@ int lstm_fs_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* ws, hipStream_t 
         float* bound = reinterpret_cast<float*>(ws[i] + L.bound);
         q.bound = bound;
         q.B = p.B; q.T = p.T; q.H = H;
-        hipLaunchKernelGGL(lstm_fs_absmax_kernel, dim3(256), dim3(256), 0, stream, p.d_y, (long)p.B * p.T * 2 * H, bound);
-        hipLaunchKernelGGL(lstm_fs_absmax_kernel, dim3(16), dim3(256), 0, stream, p.d_hn, (long)2 * p.B * H, bound + 1);
+        if (npl == 2) {   // the fp16 planes of d_a need its magnitude bound; the bf16 plane is unscaled
+            hipLaunchKernelGGL(lstm_fs_absmax_kernel, dim3(256), dim3(256), 0, stream, p.d_y, (long)p.B * p.T * 2 * H, bound);
+            hipLaunchKernelGGL(lstm_fs_absmax_kernel, dim3(16), dim3(256), 0, stream, p.d_hn, (long)2 * p.B * H, bound + 1);
+        }
         const int rows_p = fs_pad(H, 32);
         for (int dir = 0; dir < 2; ++dir) {
             q.wtp[dir] = ws[i] + L.wtp[dir];
@@ -403,16 +545,28 @@ int lstm_fs_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* ws, hipStream_t 
             q.ap[dir][1] = ws[i] + L.ap[dir][1];
             q.amax[dir] = reinterpret_cast<float*>(ws[i] + L.amax[dir]);
             hipLaunchKernelGGL(lstm_fs_wprep_kernel, dim3((rows_p + 3) / 4), dim3(256), 0, stream, p.w_hh[dir], ws[i] + L.wtp[dir],
-                               reinterpret_cast<float*>(ws[i] + L.wtinv[dir]), H, 1, rows_p, L.nkt4);
+                               reinterpret_cast<float*>(ws[i] + L.wtinv[dir]), H, 1, rows_p, L.nkt4, npl);
         }
         maxT = max(maxT, p.T);
         maxB = max(maxB, p.B);
     }
     MMB_HIP(hipGetLastError());
-    const dim3 grid((H + 31) / 32, 2 * n, (maxB + 63) / 64);
+    a.nslices = (H + 31) / 32;
+    a.nsb = (maxB + 63) / 64;
+    const int slots = (2 * n + 7) & ~7;
+    const dim3 grid(slots * a.nslices * a.nsb);
+    constexpr int lds = 8 * 64 * 33 * 4;    // 8 partial tiles of 64 samples x (32 + 1) floats
+    auto kern = npl == 2 ? lstm_fs_bwd_kernel<2> : lstm_fs_bwd_kernel<1>;
+    {
+        static PerDeviceOnce attr[2];
+        if (attr[npl - 1].pending()) {
+            MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr[npl - 1].mark();
+        }
+    }
     {
         ProfScope ps_(MMB_K_LSTM_REC_BWD, stream);
-        for (int s = 0; s < maxT; ++s) hipLaunchKernelGGL(lstm_fs_bwd_kernel, grid, dim3(512), 0, stream, a, s);
+        for (int s = 0; s < maxT; ++s) hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a, s);
     }
     MMB_HIP(hipGetLastError());
     return MMB_OK;
