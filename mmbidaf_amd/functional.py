@@ -169,6 +169,7 @@ class _BwdPrep:
         self.ws = self.d_w_cat = None
         self.have_xc = self.have_wt = False
         self.event = None
+        self.consumed = False     # a backward pass has used (and overwritten) the prepared buffers
 
 
 _bwd_preps = {}           # device index -> list of weakrefs to _BwdPrep (forward order)
@@ -452,12 +453,15 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         hs_ = [sv[i * 10 + 5].shape[1] for i in range(n)]
         side_ok = _USE_SIDE and not torch.is_grad_enabled() and all(p.grad is None for p in ctx.params)
         prep, flags, prep_todo = ctx.prep, 0, []
+        if prep is not None and prep.consumed:      # a second backward through a retained graph: prepare nothing, split inline
+            prep = None
         if _SIDE_MODE == 2 and side_ok and prep is not None:
             # first LSTM backward call of the pass: every layer's preparation is enqueued below, right after this call's
             # recurrence (its own planes included: only its weight-gradient phase, on the side stream, reads them)
             prep_todo = _prepare_alloc(dev)
             if prep.have_xc or prep in prep_todo:
                 flags = HAVE_XC | (HAVE_WT if prep.have_wt else 0)
+                prep.consumed = True
                 if prep.have_wt:   # prepared during an earlier call of this pass: long finished
                     torch.cuda.current_stream(dev).wait_event(prep.event)
         d_b_flat = torch.empty(sum(8 * h for h in hs_), device=dev, dtype=torch.float32)

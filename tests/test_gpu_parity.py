@@ -1054,6 +1054,53 @@ def test_weight_gradients_on_the_side_stream_give_identical_results(monkeypatch,
     assert not any(MF._deferred.values()), "deferred work left behind"
 
 
+def test_second_backward_through_a_retained_graph():
+    """retain_graph=True and a second backward: the operand planes prepared for the first pass (and the pre-zeroed split-K
+    output) have been consumed; the second pass must redo them and give the same gradients."""
+    from layers.encoding import RNNEncoder
+    d = dev()
+    torch.manual_seed(5)
+    e = RNNEncoder(16, 12, 2, drop_prob=0.).to(d)
+    x = torch.randn(3, 40, 16, device=d, requires_grad=True)
+    y, h = e(x, [40, 17, 33])
+    loss = (y * y).sum() + h.sum()
+    loss.backward(retain_graph=True)
+    g1 = [p.grad.clone() for p in e.parameters()] + [x.grad.clone()]
+    for p in e.parameters():
+        p.grad = None
+    x.grad = None
+    loss.backward()
+    g2 = [p.grad for p in e.parameters()] + [x.grad]
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+
+
+def test_cu_masked_stream_runs_kernels():
+    """mmb_stream_create_cu_mask / mmb_stream_destroy: a stream restricted to half of the CUs computes the same GEMM
+    (the option is measured and not used by default, profiles/r02_side_stream.md; the entry points stay covered)."""
+    import ctypes
+    from mmbidaf_amd import _lib, functional as MF
+    lib = _lib.load()
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (ctypes.c_uint32 * ((n_cu + 31) // 32))()
+    for b in range(n_cu // 2, n_cu):
+        words[b // 32] |= 1 << (b % 32)
+    handle = ctypes.c_void_p()
+    _lib.check(lib.mmb_stream_create_cu_mask(0, words, len(words), ctypes.byref(handle)), "mmb_stream_create_cu_mask")
+    assert lib.mmb_stream_create_cu_mask(0, (ctypes.c_uint32 * 1)(0), 1, ctypes.byref(ctypes.c_void_p())) != 0   # empty mask refused
+    g = torch.Generator().manual_seed(2)
+    a, b = torch.randn(300, 96, generator=g).to(dev()), torch.randn(200, 96, generator=g).to(dev())
+    ref = MF.gemm(a, b, tb=True)
+    torch.cuda.synchronize()
+    s = torch.cuda.ExternalStream(handle.value, device=0)
+    with torch.cuda.stream(s):
+        got = MF.gemm(a, b, tb=True)
+    s.synchronize()
+    assert torch.equal(got, ref)
+    del s
+    _lib.check(lib.mmb_stream_destroy(0, handle), "mmb_stream_destroy")
+
+
 def test_region_step_replays_from_a_hipgraph():
     """The C-ABI calls only enqueue on the given stream: a whole fwd+bwd step of the region captured into a hipGraph
     (bench.py --graph) must replay to the same outputs and gradients as the eager step."""
