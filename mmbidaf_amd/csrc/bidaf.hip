@@ -1095,6 +1095,8 @@ struct AttBwdArgs {
     int B, T, M, D, splits, rows_per_split;
     int fold;                                        // 1: no dropped copies, d_*_d folded into d_*
     int nstage_j2;                                   // LDS stages of the second j sweep (1 or 2)
+    int jf_rows;                                     // rows per wave of the j-side epilogue (1, 2, 4 or 8)
+    int i_blocks;                                    // workgroups of the i-side pass; ids beyond them run the j-side epilogue
     int dbg;
 };
 
@@ -1395,10 +1397,9 @@ __global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
 // and accumulates d_w_m += sum_j dc_j mod_d[j,:]: registers over the wave's rows, LDS across the 4 waves, then ONE
 // atomic per feature and workgroup with consecutive lanes on consecutive addresses.
 template <int JF_ROWS>
-__global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a, int B) {
-    __shared__ float wred[4][256];
+__device__ __forceinline__ void att_bwd_jfin_body(const AttBwdArgs& a, int B, int block, float (*wred)[256]) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int chunk = blockIdx.x * 4 + wave;
+    const int chunk = block * 4 + wave;
     const int M = a.M, D = a.D, S = a.splits;
     const int rows = B * M;
     const int d = lane * 4;
@@ -1458,6 +1459,20 @@ __global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a, i
     const int t = threadIdx.x;
     if (t < D) atomicAdd(a.d_w_m + t, (wred[0][t] + wred[1][t]) + (wred[2][t] + wred[3][t]));
 }
+__device__ __forceinline__ void att_bwd_jfin_dispatch(const AttBwdArgs& a, int block, float (*wred)[256]) {
+    switch (a.jf_rows) {
+        case 8: att_bwd_jfin_body<8>(a, a.B, block, wred); break;
+        case 4: att_bwd_jfin_body<4>(a, a.B, block, wred); break;
+        case 2: att_bwd_jfin_body<2>(a, a.B, block, wred); break;
+        default: att_bwd_jfin_body<1>(a, a.B, block, wred); break;
+    }
+}
+// stand-alone launch of the j-side epilogue (timing tools, MMB_ATT_JFIN_SEPARATE=1); by default its workgroups ride in the
+// launch of att_bwd_i_kernel, which leaves 32 of the 256 CUs idle and does not depend on them
+__global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a) {
+    __shared__ float wred[4][256];
+    att_bwd_jfin_dispatch(a, blockIdx.x, wred);
+}
 
 // i-side pass (lane side = text rows i, streams all modality rows j):
 //   dS = P1 (dP1 - delta1_i) mask_j + P2 (dP2 - delta2_j) mask_i
@@ -1470,6 +1485,12 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int T = a.T, M = a.M, D = a.D, Mp = pad32(M);
+    if ((int)blockIdx.x >= a.i_blocks) {
+        // passenger workgroups: the j-side epilogue (sums of the split partials -> d_mod, d_mod_d, d_w_m).  It depends on the
+        // two j sweeps only, like this pass, whose T/64 * B workgroups (224 at the metric configuration) leave CUs idle.
+        att_bwd_jfin_dispatch(a, blockIdx.x - a.i_blocks, reinterpret_cast<float(*)[256]>(smem));
+        return;
+    }
     int tile, split, b;
     decode_block((T + 16 * NW - 1) / (16 * NW), 1, a.B, tile, split, b);
     const int n = (tile * NW + wave) * 16 + r;  // text row i
@@ -1980,29 +2001,28 @@ extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* 
         hipLaunchKernelGGL(kern, dim3(tiles_m * a.splits * B), dim3(NTHR), lds, stream, a);
     }
     MMB_HIP(hipGetLastError());
-    {
-        // rows per wave: enough waves to fill the chip, few enough workgroups that the d_w_m atomics stay cheap
-        const int rows = B * M;
-        const int jf = rows >= 8192 ? 8 : rows >= 4096 ? 4 : rows >= 2048 ? 2 : 1;
-        const int chunks = (rows + jf - 1) / jf;
+    // j-side epilogue: rows per wave such that there are enough waves to fill the chip and few enough workgroups that the
+    // d_w_m atomics stay cheap.  Its workgroups ride in the i-side launch (same block size, needs only the j sweeps) unless
+    // the timing tools ask for their own launch.
+    const int rows = B * M;
+    a.jf_rows = rows >= 8192 ? 8 : rows >= 4096 ? 4 : rows >= 2048 ? 2 : 1;
+    const int jf_blocks = ((rows + a.jf_rows - 1) / a.jf_rows + 3) / 4;
+    static const bool jf_separate = [] { const char* e = getenv("MMB_ATT_JFIN_SEPARATE"); return e && atoi(e) != 0; }();
+    const bool separate = jf_separate || a.dbg != 0;
+    if (separate) {
         ProfScope ps_(MMB_K_ATT_BWD_JFIN, stream);
-        const dim3 grid((chunks + 3) / 4), block(256);
-        switch (jf) {
-            case 8: hipLaunchKernelGGL(att_bwd_jfin_kernel<8>, grid, block, 0, stream, a, B); break;
-            case 4: hipLaunchKernelGGL(att_bwd_jfin_kernel<4>, grid, block, 0, stream, a, B); break;
-            case 2: hipLaunchKernelGGL(att_bwd_jfin_kernel<2>, grid, block, 0, stream, a, B); break;
-            default: hipLaunchKernelGGL(att_bwd_jfin_kernel<1>, grid, block, 0, stream, a, B); break;
-        }
+        hipLaunchKernelGGL(att_bwd_jfin_kernel, dim3(jf_blocks), dim3(256), 0, stream, a);
+        MMB_HIP(hipGetLastError());
     }
-    MMB_HIP(hipGetLastError());
     {
         size_t lds = (size_t)4 * PANEL_B + ((size_t)9 * pad32(M) + 16) * sizeof(float);
         const size_t epi = ((size_t)2 * 16 * NW * LDP + 16 * NW + NW * 2 * 256) * sizeof(float);   // parked dX, P2.dq tiles + dr + partial sums
         if (lds < epi) lds = epi;
         auto kern = a.dbg ? att_bwd_i_kernel<true> : att_bwd_i_kernel<false>;
         if (int rc = allow_lds(kern, lds)) return rc;
+        a.i_blocks = tiles_t * B;
         ProfScope ps_(MMB_K_ATT_BWD_I, stream);
-        hipLaunchKernelGGL(kern, dim3(tiles_t * B), dim3(NTHR), lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3(a.i_blocks + (separate ? 0 : jf_blocks)), dim3(NTHR), lds, stream, a);
     }
     MMB_HIP(hipGetLastError());
     return MMB_OK;
