@@ -170,11 +170,15 @@ struct PlanesGemmArgs {
     int dbg;      // timing-only ablation (MMB_PLANES_DBG): 2 = no MFMA
 };
 int planes_split_rows(const SplitRowsArgs& a, hipStream_t stream);
+int planes_split_rows_group(const SplitRowsArgs* as, int n, hipStream_t stream);      // same-variant passes share a launch
+int planes_split_transpose_group(const SplitTArgs* as, int n, hipStream_t stream);
 int precision_mode();            // 0: fp32-accurate products (default); 1: bf16 operands in every matrix-core product of the LSTM layers
 void set_precision_mode(int mode);
 bool planes_one_split();   // MMB_PLANES_ONE_SPLIT (default 1): the LSTM backward splits d_a once (k-major read in the weight-gradient GEMM)
 int planes_split_transpose(const SplitTArgs& a, hipStream_t stream);
 int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream);
+// up to MMB_MAX_GROUP independent products (same plane format) in ONE launch with one tile shape
+int planes_gemm_group(const PlanesGemmArgs* gs, int n, hipStream_t stream);
 void planes_set_tune(int code);
 int planes_terms();   // 2 (default) or 3 (MMB_PLANES_TERMS=3): which split the operand-plane path uses
 int planes_plan_splitk(const PlanesGemmArgs& g);   // the K split planes_gemm will use for g

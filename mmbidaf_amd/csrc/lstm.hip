@@ -464,39 +464,50 @@ static WsBwd ws_bwd_layout(long BT, int B, int I, int H) {
     return w;
 }
 
-// Gx (BT, 8H gate-interleaved) = x . [W_ih_f ; W_ih_r]^T + b_ih + b_hh  through the operand planes: ONE GEMM per problem
-static int gx_planes(const mmb_lstm_fwd_desc& p, hipStream_t stream) {
-    const int H = p.H;
-    const long BT = (long)p.B * p.T;
-    const WsFwd L = ws_fwd_layout(BT, p.B, p.I, H);
-    char* ws = static_cast<char*>(p.ws);
-    bf16_t* xP = reinterpret_cast<bf16_t*>(ws + L.xP);
-    bf16_t* wP = reinterpret_cast<bf16_t*>(ws + L.wP);
-    float* bias = reinterpret_cast<float*>(ws + L.bias);
+// Gx (BT, 8H gate-interleaved) = x . [W_ih_f ; W_ih_r]^T + b_ih + b_hh  through the operand planes, for all the m
+// problems of the layer call at once: the x splits, the weight splits and the GEMMs are ONE launch each (grid slices per
+// problem) instead of 3 m launches that each drain the chip before the next starts
+static int gx_planes_group(const mmb_lstm_fwd_desc* d, const int* idx, int m, hipStream_t stream) {
+    if (m == 0) return MMB_OK;
     const int np = planes_terms();
-    float* xinv = reinterpret_cast<float*>(ws + L.xinv);
-    float* winv = reinterpret_cast<float*>(ws + L.winv);
-    SplitRowsArgs sx{};
-    sx.src1 = p.x; sx.src2 = p.x; sx.R1 = (int)BT; sx.R = (int)BT; sx.C = p.I; sx.ld = p.I; sx.Cp = L.Ip; sx.gate_H = 0;
-    sx.planes = xP;
-    sx.np = np; sx.inv_out = xinv; sx.absmax_out = p.x_absmax;   // max |x| is saved for the backward's transposed planes
-    if (int rc = planes_split_rows(sx, stream)) return rc;
-    SplitRowsArgs sw{};
-    sw.src1 = p.w_ih[0]; sw.src2 = p.w_ih[1]; sw.R1 = 4 * H; sw.R = 8 * H; sw.C = p.I; sw.ld = p.I; sw.Cp = L.Ip; sw.gate_H = H;
-    sw.planes = wP;
-    sw.b1a = p.b_ih[0]; sw.b2a = p.b_hh[0]; sw.b1b = p.b_ih[1]; sw.b2b = p.b_hh[1]; sw.bias_out = bias;
-    sw.np = np; sw.inv_out = winv; sw.absmax_out = p.x_absmax ? p.x_absmax + 1 : nullptr;   // max |W_ih| for the backward's W^T planes
-    if (int rc = planes_split_rows(sw, stream)) return rc;
-    PlanesGemmArgs g{};
-    g.A = xP;
-    g.B = wP;
-    g.C = p.gx; g.ldc = 8 * H; g.bias = bias; g.M = (int)BT; g.N = 8 * H; g.K = L.Ip;
-    g.np = np; g.a_inv = xinv; g.b_inv = winv;
-    return planes_gemm(g, stream);
+    SplitRowsArgs sx[MMB_MAX_GROUP], sw[MMB_MAX_GROUP];
+    PlanesGemmArgs gs[MMB_MAX_GROUP];
+    for (int k = 0; k < m; ++k) {
+        const mmb_lstm_fwd_desc& p = d[idx[k]];
+        const int H = p.H;
+        const long BT = (long)p.B * p.T;
+        const WsFwd L = ws_fwd_layout(BT, p.B, p.I, H);
+        char* ws = static_cast<char*>(p.ws);
+        bf16_t* xP = reinterpret_cast<bf16_t*>(ws + L.xP);
+        bf16_t* wP = reinterpret_cast<bf16_t*>(ws + L.wP);
+        float* bias = reinterpret_cast<float*>(ws + L.bias);
+        float* xinv = reinterpret_cast<float*>(ws + L.xinv);
+        float* winv = reinterpret_cast<float*>(ws + L.winv);
+        SplitRowsArgs& x = sx[k];
+        x = SplitRowsArgs{};
+        x.src1 = p.x; x.src2 = p.x; x.R1 = (int)BT; x.R = (int)BT; x.C = p.I; x.ld = p.I; x.Cp = L.Ip; x.gate_H = 0;
+        x.planes = xP;
+        x.np = np; x.inv_out = xinv; x.absmax_out = p.x_absmax;   // max |x| is saved for the backward's transposed planes
+        SplitRowsArgs& w = sw[k];
+        w = SplitRowsArgs{};
+        w.src1 = p.w_ih[0]; w.src2 = p.w_ih[1]; w.R1 = 4 * H; w.R = 8 * H; w.C = p.I; w.ld = p.I; w.Cp = L.Ip; w.gate_H = H;
+        w.planes = wP;
+        w.b1a = p.b_ih[0]; w.b2a = p.b_hh[0]; w.b1b = p.b_ih[1]; w.b2b = p.b_hh[1]; w.bias_out = bias;
+        w.np = np; w.inv_out = winv; w.absmax_out = p.x_absmax ? p.x_absmax + 1 : nullptr;   // max |W_ih| for the backward's W^T planes
+        PlanesGemmArgs& g = gs[k];
+        g = PlanesGemmArgs{};
+        g.A = xP;
+        g.B = wP;
+        g.C = p.gx; g.ldc = 8 * H; g.bias = bias; g.M = (int)BT; g.N = 8 * H; g.K = L.Ip;
+        g.np = np; g.a_inv = xinv; g.b_inv = winv;
+    }
+    if (int rc = planes_split_rows_group(sx, m, stream)) return rc;
+    if (int rc = planes_split_rows_group(sw, m, stream)) return rc;
+    return planes_gemm_group(gs, m, stream);
 }
 
-// weight and input gradients of one problem through the operand planes: 4 split passes + 2 GEMMs (+ unpack)
-static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_partials, int phase);
+// weight and input gradients of the layer call's problems through the operand planes (defined below)
+static int grads_planes_group(const mmb_lstm_bwd_desc* d, const int* idx, int m, hipStream_t stream, bool db_partials, int phase_bits);
 
 template <typename ArgsT, typename K>
 static int launch_rec(K kernel, const ArgsT& a, int total_wgs, int H, hipStream_t stream, int kid) {
@@ -515,61 +526,85 @@ static int kq_for(int H) {
 }
 
 
-// phase bit 1: input gradient d_x (on the critical path of the backward pass); bit 2: weight and bias gradients
-static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_partials, int phase_bits) {
-    const int H = p.H, I = p.I;
-    const long BT = (long)p.B * p.T;
-    const WsBwd L = ws_bwd_layout(BT, p.B, I, H);
-    char* ws = static_cast<char*>(p.ws);
-    bf16_t* daP = reinterpret_cast<bf16_t*>(ws + L.daP);
-    bf16_t* daT = reinterpret_cast<bf16_t*>(ws + L.daT);
-    bf16_t* xcT = reinterpret_cast<bf16_t*>(ws + L.xcT);
-    bf16_t* wT = reinterpret_cast<bf16_t*>(ws + L.wT);
+// phase bit 1: input gradient d_x (on the critical path of the backward pass); bit 2: weight and bias gradients;
+// 4 PREPARE (only the operand planes that depend on nothing the backward pass computes: [x | y(t-1) | y(t+1)]^T and
+// W_ih^T); 8 / 16: those planes are already in the workspace.  Every stage is ONE launch for all m problems.
+static int grads_planes_group(const mmb_lstm_bwd_desc* d, const int* idx, int m, hipStream_t stream, bool db_partials, int phase_bits) {
+    if (m == 0) return MMB_OK;
     const int np = planes_terms();
-    float* dainv = reinterpret_cast<float*>(ws + L.dainv);
-    float* daTinv = reinterpret_cast<float*>(ws + L.daTinv);
-    float* xcTinv = reinterpret_cast<float*>(ws + L.xcTinv);
-    float* wTinv = reinterpret_cast<float*>(ws + L.wTinv);
-    float* scal = reinterpret_cast<float*>(ws + L.scal);        // max |d_a| when the recurrence did not track it
-    const float* damax = reinterpret_cast<const float*>(ws + L.damax);
-    int damax_n = 2 * p.B;
-    // phase bits: 1 input gradient, 2 weight gradients, 4 PREPARE (only the operand planes that depend on nothing the
-    // backward pass computes: [x | y(t-1) | y(t+1)]^T and W_ih^T), 8 / 16: those planes are already in the workspace
     const int phase = phase_bits & 3;
     const bool prepare = phase_bits & MMB_LSTM_BWD_PREPARE;
     const bool have_xc = phase_bits & MMB_LSTM_BWD_HAVE_XC, have_wt = phase_bits & MMB_LSTM_BWD_HAVE_WT;
-    if (np == 2)
-        MMB_REQUIRE(p.x_absmax, "mmb_bilstm_layer_bwd: desc.x_absmax (saved by the forward call) is needed by the fp16 operand planes");
-
-    // weight-gradient GEMM: d_a^T (8H x BT) . [x | y_fwd(t-1) | y_rev(t+1)] (BT x (I+2H))
-    PlanesGemmArgs gw{};
-    gw.B = xcT;
-    gw.C = p.d_w_cat; gw.ldc = I + 2 * H; gw.M = 8 * H; gw.N = I + 2 * H; gw.K = L.BTp;
-    gw.np = np; gw.b_inv = xcTinv;
+    // ONE split of d_a (row-major planes, one scale for the tensor) serves both GEMMs: the input gradient reads its rows,
+    // the weight gradient reads it k-major through transposing LDS reads (PlanesGemmArgs::ta) -- instead of a row split
+    // plus a transposing split (d_a is the largest tensor of the layer: 82 MB at the metric configuration)
     const bool one_split = np == 2 && planes_one_split();
-    gw.ta = one_split ? 1 : 0;
-    const bool ksplit = planes_plan_splitk(gw) > 1;   // its zeroing rides on the split pass of the second operand
+
+    WsBwd L[MMB_MAX_GROUP];
+    char* ws[MMB_MAX_GROUP];
+    const float* damax[MMB_MAX_GROUP];
+    int damax_n[MMB_MAX_GROUP];
+    PlanesGemmArgs gw[MMB_MAX_GROUP];
+    bool ksplit[MMB_MAX_GROUP];
+    for (int k = 0; k < m; ++k) {
+        const mmb_lstm_bwd_desc& p = d[idx[k]];
+        const int H = p.H, I = p.I;
+        const long BT = (long)p.B * p.T;
+        L[k] = ws_bwd_layout(BT, p.B, I, H);
+        ws[k] = static_cast<char*>(p.ws);
+        damax[k] = reinterpret_cast<const float*>(ws[k] + L[k].damax);
+        damax_n[k] = 2 * p.B;
+        if (np == 2)
+            MMB_REQUIRE(p.x_absmax, "mmb_bilstm_layer_bwd: desc.x_absmax (saved by the forward call) is needed by the fp16 operand planes");
+        // weight-gradient GEMM: d_a^T (8H x BT) . [x | y_fwd(t-1) | y_rev(t+1)] (BT x (I+2H))
+        PlanesGemmArgs& g = gw[k];
+        g = PlanesGemmArgs{};
+        g.B = reinterpret_cast<bf16_t*>(ws[k] + L[k].xcT);
+        g.C = p.d_w_cat; g.ldc = I + 2 * H; g.M = 8 * H; g.N = I + 2 * H; g.K = L[k].BTp;
+        g.np = np; g.b_inv = reinterpret_cast<float*>(ws[k] + L[k].xcTinv);
+        g.ta = one_split ? 1 : 0;
+        ksplit[k] = planes_plan_splitk(g) > 1;   // its zeroing rides on the split pass of the second operand
+    }
     auto split_xc = [&]() -> int {
         // [x | y_fwd(t-1) | y_rev(t+1)]^T planes ((I+2H) x BT): h_prev is y shifted by one step inside each sample
-        SplitTArgs tx{};
-        tx.nseg = 3;
-        tx.seg_ptr[0] = p.x;     tx.seg_ld[0] = I;     tx.seg_cols[0] = I; tx.seg_shift[0] = 0;
-        tx.seg_ptr[1] = p.y;     tx.seg_ld[1] = 2 * H; tx.seg_cols[1] = H; tx.seg_shift[1] = -1;
-        tx.seg_ptr[2] = p.y + H; tx.seg_ld[2] = 2 * H; tx.seg_cols[2] = H; tx.seg_shift[2] = +1;
-        tx.R = (int)BT; tx.period = p.T; tx.Rp = L.BTp; tx.Ctot = I + 2 * H; tx.planes = xcT;
-        tx.np = np; tx.inv_out = xcTinv;
-        tx.seg_absmax[0] = p.x_absmax; tx.seg_absmax_n[0] = 1;       // max |x|, recorded by the forward's split pass
-        tx.seg_bound[1] = 1.0f; tx.seg_bound[2] = 1.0f;               // |h| = |o * tanh(c)| < 1
-        if (ksplit) { tx.zero_ptr = p.d_w_cat; tx.zero_n = (long)8 * H * (I + 2 * H); }
-        return planes_split_transpose(tx, stream);
+        SplitTArgs tx[MMB_MAX_GROUP];
+        for (int k = 0; k < m; ++k) {
+            const mmb_lstm_bwd_desc& p = d[idx[k]];
+            const int H = p.H, I = p.I;
+            SplitTArgs& t = tx[k];
+            t = SplitTArgs{};
+            t.nseg = 3;
+            t.seg_ptr[0] = p.x;     t.seg_ld[0] = I;     t.seg_cols[0] = I; t.seg_shift[0] = 0;
+            t.seg_ptr[1] = p.y;     t.seg_ld[1] = 2 * H; t.seg_cols[1] = H; t.seg_shift[1] = -1;
+            t.seg_ptr[2] = p.y + H; t.seg_ld[2] = 2 * H; t.seg_cols[2] = H; t.seg_shift[2] = +1;
+            t.R = p.B * p.T; t.period = p.T; t.Rp = L[k].BTp; t.Ctot = I + 2 * H; t.planes = reinterpret_cast<bf16_t*>(ws[k] + L[k].xcT);
+            t.np = np; t.inv_out = reinterpret_cast<float*>(ws[k] + L[k].xcTinv);
+            t.seg_absmax[0] = p.x_absmax; t.seg_absmax_n[0] = 1;       // max |x|, recorded by the forward's split pass
+            t.seg_bound[1] = 1.0f; t.seg_bound[2] = 1.0f;               // |h| = |o * tanh(c)| < 1
+            if (ksplit[k]) { t.zero_ptr = p.d_w_cat; t.zero_n = (long)8 * H * (I + 2 * H); }
+        }
+        return planes_split_transpose_group(tx, m, stream);
     };
+    // problems that want an input gradient (W_ih^T planes + the d_x GEMM); a PREPARE call names them all
+    int dxi[MMB_MAX_GROUP], ndx = 0;
+    for (int k = 0; k < m; ++k)
+        if (d[idx[k]].d_x || prepare) dxi[ndx++] = k;
     auto split_wt = [&]() -> int {
-        SplitTArgs tw{};
-        tw.nseg = 1; tw.seg_ptr[0] = p.w_ih[0]; tw.seg_ld[0] = I; tw.seg_cols[0] = I; tw.seg_shift[0] = 0;
-        tw.stack_ptr = p.w_ih[1]; tw.stack_R1 = 4 * H;
-        tw.R = 8 * H; tw.period = 1; tw.Rp = L.K8; tw.Ctot = I; tw.planes = wT;
-        tw.np = np; tw.seg_absmax[0] = p.x_absmax ? p.x_absmax + 1 : nullptr; tw.seg_absmax_n[0] = 1; tw.inv_out = wTinv;
-        return planes_split_transpose(tw, stream);
+        if (ndx == 0) return MMB_OK;
+        SplitTArgs tw[MMB_MAX_GROUP];
+        for (int q = 0; q < ndx; ++q) {
+            const int k = dxi[q];
+            const mmb_lstm_bwd_desc& p = d[idx[k]];
+            const int H = p.H, I = p.I;
+            SplitTArgs& t = tw[q];
+            t = SplitTArgs{};
+            t.nseg = 1; t.seg_ptr[0] = p.w_ih[0]; t.seg_ld[0] = I; t.seg_cols[0] = I; t.seg_shift[0] = 0;
+            t.stack_ptr = p.w_ih[1]; t.stack_R1 = 4 * H;
+            t.R = 8 * H; t.period = 1; t.Rp = L[k].K8; t.Ctot = I; t.planes = reinterpret_cast<bf16_t*>(ws[k] + L[k].wT);
+            t.np = np; t.seg_absmax[0] = p.x_absmax ? p.x_absmax + 1 : nullptr; t.seg_absmax_n[0] = 1;
+            t.inv_out = reinterpret_cast<float*>(ws[k] + L[k].wTinv);
+        }
+        return planes_split_transpose_group(tw, ndx, stream);
     };
     if (prepare) {
         if (!have_xc)
@@ -579,66 +614,105 @@ static int grads_planes(const mmb_lstm_bwd_desc& p, hipStream_t stream, bool db_
         return MMB_OK;
     }
 
-    // ONE split of d_a (row-major planes, one scale for the tensor) serves both GEMMs: the input gradient reads its rows,
-    // the weight gradient reads it k-major through transposing LDS reads (PlanesGemmArgs::ta) -- instead of a row split
-    // plus a transposing split (d_a is the largest tensor of the layer: 82 MB at the metric configuration)
-    // (split calls: phase 1 makes the planes when there is an input gradient to compute, and phase 2 -- which always follows
-    //  phase 1 of the same descriptors -- then finds them in the workspace)
-    const bool split_now = one_split && (phase == 3 || (phase == 1 && p.d_x) || (phase == 2 && !p.d_x));
-    if (np == 2 && !db_partials && ((phase & 2) || split_now)) {
-        // general-size recurrence: max |d_a| was not tracked by the recurrence, one reduction here
-        MMB_HIP(hipMemsetAsync(scal, 0, sizeof(float), stream));
-        hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, stream, p.d_a, static_cast<const float*>(nullptr), BT * 8 * H, scal);
-        MMB_HIP(hipGetLastError());
-        damax = scal;
-        damax_n = 1;
+    // (split calls: phase 1 makes the d_a planes when there is an input gradient to compute, and phase 2 -- which always
+    //  follows phase 1 of the same descriptors -- then finds them in the workspace)
+    bool split_now[MMB_MAX_GROUP];
+    for (int k = 0; k < m; ++k) {
+        const mmb_lstm_bwd_desc& p = d[idx[k]];
+        split_now[k] = one_split && (phase == 3 || (phase == 1 && p.d_x) || (phase == 2 && !p.d_x));
+        if (np == 2 && !db_partials && ((phase & 2) || split_now[k])) {
+            // general-size recurrence: max |d_a| was not tracked by the recurrence, one reduction here
+            float* scal = reinterpret_cast<float*>(ws[k] + L[k].scal);
+            MMB_HIP(hipMemsetAsync(scal, 0, sizeof(float), stream));
+            hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, stream, p.d_a, static_cast<const float*>(nullptr),
+                               (long)p.B * p.T * 8 * p.H, scal);
+            MMB_HIP(hipGetLastError());
+            damax[k] = scal;
+            damax_n[k] = 1;
+        }
     }
-    if (split_now) {
+    auto row_split_args = [&](int k, bool tensor_scale) {
+        const mmb_lstm_bwd_desc& p = d[idx[k]];
+        const int H = p.H;
+        const long BT = (long)p.B * p.T;
         SplitRowsArgs sa{};
-        sa.src1 = p.d_a; sa.src2 = p.d_a; sa.R1 = (int)BT; sa.R = (int)BT; sa.C = 8 * H; sa.ld = 8 * H; sa.Cp = L.K8; sa.gate_H = 0;
-        sa.planes = daP; sa.Rpad = L.BTp;
-        sa.np = np; sa.inv_out = dainv; sa.tensor_absmax = damax; sa.tensor_absmax_n = damax_n;
-        if (int rc = planes_split_rows(sa, stream)) return rc;
+        sa.src1 = p.d_a; sa.src2 = p.d_a; sa.R1 = (int)BT; sa.R = (int)BT; sa.C = 8 * H; sa.ld = 8 * H; sa.Cp = L[k].K8; sa.gate_H = 0;
+        sa.planes = reinterpret_cast<bf16_t*>(ws[k] + L[k].daP);
+        sa.np = np; sa.inv_out = reinterpret_cast<float*>(ws[k] + L[k].dainv);
+        if (tensor_scale) { sa.Rpad = L[k].BTp; sa.tensor_absmax = damax[k]; sa.tensor_absmax_n = damax_n[k]; }
+        return sa;
+    };
+    {
+        SplitRowsArgs sa[MMB_MAX_GROUP];
+        int ns = 0;
+        for (int k = 0; k < m; ++k)
+            if (split_now[k]) sa[ns++] = row_split_args(k, true);
+        if (ns)
+            if (int rc = planes_split_rows_group(sa, ns, stream)) return rc;
     }
     if (phase & 2) {
         if (one_split) {
-            gw.A = daP; gw.a_inv = dainv;
+            for (int k = 0; k < m; ++k) {
+                gw[k].A = reinterpret_cast<bf16_t*>(ws[k] + L[k].daP);
+                gw[k].a_inv = reinterpret_cast<float*>(ws[k] + L[k].dainv);
+            }
         } else {
             // d_a^T planes (8H x BT): A operand of the weight-gradient GEMM
-            SplitTArgs ta{};
-            ta.nseg = 1; ta.seg_ptr[0] = p.d_a; ta.seg_ld[0] = 8 * H; ta.seg_cols[0] = 8 * H; ta.seg_shift[0] = 0;
-            ta.R = (int)BT; ta.period = 1; ta.Rp = L.BTp; ta.Ctot = 8 * H; ta.planes = daT;
-            ta.np = np; ta.seg_absmax[0] = damax; ta.seg_absmax_n[0] = damax_n; ta.inv_out = daTinv;
-            if (int rc = planes_split_transpose(ta, stream)) return rc;
-            gw.A = daT; gw.a_inv = daTinv;
+            SplitTArgs ta[MMB_MAX_GROUP];
+            for (int k = 0; k < m; ++k) {
+                const mmb_lstm_bwd_desc& p = d[idx[k]];
+                const int H = p.H;
+                SplitTArgs& t = ta[k];
+                t = SplitTArgs{};
+                t.nseg = 1; t.seg_ptr[0] = p.d_a; t.seg_ld[0] = 8 * H; t.seg_cols[0] = 8 * H; t.seg_shift[0] = 0;
+                t.R = p.B * p.T; t.period = 1; t.Rp = L[k].BTp; t.Ctot = 8 * H; t.planes = reinterpret_cast<bf16_t*>(ws[k] + L[k].daT);
+                t.np = np; t.seg_absmax[0] = damax[k]; t.seg_absmax_n[0] = damax_n[k];
+                t.inv_out = reinterpret_cast<float*>(ws[k] + L[k].daTinv);
+                gw[k].A = t.planes; gw[k].a_inv = t.inv_out;
+            }
+            if (int rc = planes_split_transpose_group(ta, m, stream)) return rc;
         }
         if (!have_xc)
             if (int rc = split_xc()) return rc;
-        gw.prezeroed = ksplit ? 1 : 0;
-        if (int rc = planes_gemm(gw, stream)) return rc;
-        const int total = 8 * H * (I + 2 * H);
+        for (int k = 0; k < m; ++k) gw[k].prezeroed = ksplit[k] ? 1 : 0;
+        if (int rc = planes_gemm_group(gw, m, stream)) return rc;
         ProfScope ps_(MMB_K_GEMM, stream);
-        hipLaunchKernelGGL(lstm_unpack_dw_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.d_w_cat, p.d_w_ih, p.d_w_hh, H, I,
-                           db_partials ? reinterpret_cast<const float*>(ws + L.dbp) : static_cast<const float*>(nullptr), p.d_b, p.B);
+        for (int k = 0; k < m; ++k) {
+            const mmb_lstm_bwd_desc& p = d[idx[k]];
+            const int H = p.H, I = p.I;
+            const int total = 8 * H * (I + 2 * H);
+            hipLaunchKernelGGL(lstm_unpack_dw_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.d_w_cat, p.d_w_ih, p.d_w_hh, H, I,
+                               db_partials ? reinterpret_cast<const float*>(ws[k] + L[k].dbp) : static_cast<const float*>(nullptr), p.d_b, p.B);
+        }
         MMB_HIP(hipGetLastError());
     }
-    if (p.d_x && (phase & 1)) {
+    if (phase & 1) {
         // d_x (BT, I) = d_a (BT x 8H) . [W_ih_f ; W_ih_r] (8H x I): one GEMM over both directions
-        if (!one_split) {
-            SplitRowsArgs sa{};
-            sa.src1 = p.d_a; sa.src2 = p.d_a; sa.R1 = (int)BT; sa.R = (int)BT; sa.C = 8 * H; sa.ld = 8 * H; sa.Cp = L.K8; sa.gate_H = 0;
-            sa.planes = daP;
-            sa.np = np; sa.inv_out = dainv;
-            if (int rc = planes_split_rows(sa, stream)) return rc;
+        int nd = 0;
+        for (int k = 0; k < m; ++k)
+            if (d[idx[k]].d_x) dxi[nd++] = k;
+        ndx = nd;
+        if (ndx) {
+            if (!one_split) {
+                SplitRowsArgs sa[MMB_MAX_GROUP];
+                for (int q = 0; q < ndx; ++q) sa[q] = row_split_args(dxi[q], false);
+                if (int rc = planes_split_rows_group(sa, ndx, stream)) return rc;
+            }
+            if (!have_wt)
+                if (int rc = split_wt()) return rc;
+            PlanesGemmArgs gx[MMB_MAX_GROUP];
+            for (int q = 0; q < ndx; ++q) {
+                const int k = dxi[q];
+                const mmb_lstm_bwd_desc& p = d[idx[k]];
+                PlanesGemmArgs& g = gx[q];
+                g = PlanesGemmArgs{};
+                g.A = reinterpret_cast<bf16_t*>(ws[k] + L[k].daP);
+                g.B = reinterpret_cast<bf16_t*>(ws[k] + L[k].wT);
+                g.C = p.d_x; g.ldc = p.I; g.M = p.B * p.T; g.N = p.I; g.K = L[k].K8;
+                g.np = np; g.a_inv = reinterpret_cast<float*>(ws[k] + L[k].dainv); g.b_inv = reinterpret_cast<float*>(ws[k] + L[k].wTinv);
+            }
+            if (int rc = planes_gemm_group(gx, ndx, stream)) return rc;
         }
-        if (!have_wt)
-            if (int rc = split_wt()) return rc;
-        PlanesGemmArgs g{};
-        g.A = daP;
-        g.B = wT;
-        g.C = p.d_x; g.ldc = I; g.M = (int)BT; g.N = I; g.K = L.K8;
-        g.np = np; g.a_inv = dainv; g.b_inv = wTinv;
-        if (int rc = planes_gemm(g, stream)) return rc;
     }
     return MMB_OK;
 }
@@ -661,6 +735,7 @@ extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int devic
     ra.n = n;
     int wg = 0;
     const int H = d[0].H;
+    int pl_idx[MMB_MAX_GROUP], npl = 0;
     for (int i = 0; i < n; ++i) {
         const mmb_lstm_fwd_desc& p = d[i];
         MMB_REQUIRE(p.H == H, "grouped LSTM problems must share H (%d vs %d)", p.H, H);
@@ -672,8 +747,7 @@ extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int devic
         for (int dir = 0; dir < 2; ++dir)
             MMB_REQUIRE(p.w_ih[dir] && p.w_hh[dir] && p.b_ih[dir] && p.b_hh[dir], "null weight in desc %d", i);
         if (p.ws && planes_ok(p.I, H)) {
-            const int rc = gx_planes(p, stream);
-            if (rc) return rc;
+            pl_idx[npl++] = i;      // all of them in one set of launches below
         } else {
             // input projection, one GEMM per direction: Gx[:, dir] = x . W_ih[dir]^T + b_ih[dir] + b_hh[dir]
             for (int dir = 0; dir < 2; ++dir) {
@@ -693,6 +767,7 @@ extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int devic
         q.B = p.B; q.T = p.T; q.H = p.H; q.wg_begin = wg;
         wg += 2 * p.B;
     }
+    if (int rc = gx_planes_group(d, pl_idx, npl, stream)) return rc;
     if (H > MMB_LSTM_MAX_H) {
         char* big_ws[MMB_MAX_GROUP];
         for (int i = 0; i < n; ++i) big_ws[i] = static_cast<char*>(d[i].ws) + ws_fwd_layout((long)d[i].B * d[i].T, d[i].B, d[i].I, H).big;
@@ -734,10 +809,10 @@ extern "C" int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* d, int n, int
         // weight / bias gradients (or the preparation of their operands) of the problems that run on the operand planes (the
         // others do all their work in phase 1)
         const int H2 = d[0].H;
+        int pl_idx[MMB_MAX_GROUP], npl = 0;
         for (int i = 0; i < n; ++i)
-            if (d[i].ws && d[i].d_w_cat && planes_ok(d[i].I, H2))
-                if (int rc = grads_planes(d[i], stream, !(H2 > MMB_LSTM_MAX_H), phase_bits)) return rc;
-        return MMB_OK;
+            if (d[i].ws && d[i].d_w_cat && planes_ok(d[i].I, H2)) pl_idx[npl++] = i;
+        return grads_planes_group(d, pl_idx, npl, stream, !(H2 > MMB_LSTM_MAX_H), phase_bits);
     }
     RecBwdArgs ra{};
     ra.n = n;
@@ -776,14 +851,17 @@ extern "C" int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* d, int n, int
         default: rc = launch_rec(lstm_rec_bwd_kernel<32>, ra, wg, H, stream, MMB_K_LSTM_REC_BWD); break;
     }
     if (rc) return rc;
+    {
+        int pl_idx[MMB_MAX_GROUP], npl = 0;
+        for (int i = 0; i < n; ++i)
+            if (d[i].ws && d[i].d_w_cat && planes_ok(d[i].I, H)) pl_idx[npl++] = i;
+        rc = grads_planes_group(d, pl_idx, npl, stream, !big, phase_bits);
+        if (rc) return rc;
+    }
     for (int i = 0; i < n; ++i) {
         const mmb_lstm_bwd_desc& p = d[i];
         const int BT = p.B * p.T;
-        if (p.ws && p.d_w_cat && planes_ok(p.I, H)) {
-            rc = grads_planes(p, stream, !big, phase_bits);
-            if (rc) return rc;
-            continue;
-        }
+        if (p.ws && p.d_w_cat && planes_ok(p.I, H)) continue;
         bool fused = false;
         if (p.d_w_cat) {
             // ONE GEMM for all weight gradients of the layer: d_a^T (8H x BT) . [x | y_fwd(t-1) | y_rev(t+1)] (BT x (I+2H)).

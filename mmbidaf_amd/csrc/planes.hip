@@ -19,6 +19,8 @@
 
 #include <string.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace mmb {
@@ -88,10 +90,15 @@ __device__ __forceinline__ void store_planes1(bf16_t* planes, size_t off, const 
     *reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(planes) + off) = h0;
 }
 
+// Up to MMB_MAX_GROUP independent split passes ride in one launch: the last grid dimension is the pass
+struct SplitRowsGroup { SplitRowsArgs a[MMB_MAX_GROUP]; };
+struct SplitTGroup { SplitTArgs a[MMB_MAX_GROUP]; };
+
 // One wave per (row block, K tile): 16 rows x 128 B in, three (np = 1: one) contiguous 1-KiB chunks out.  Plane rows r < R1 come from
 // src1, the rest from src2 (stacked); gate_H > 0 permutes each 4H block of rows so that plane row u*4+g holds source row
 // g*H+u.  Rows past R (padding of the last block) are written as zeros.  Optional bias_out[row] = b1[src] + b2[src].
-__global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsArgs a) {
+__global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsGroup G) {
+    const SplitRowsArgs& a = G.a[blockIdx.y];
     const int nkt = a.Cp / 32;
     const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -120,10 +127,12 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsArgs a) 
 // np = 2 form of the above: one workgroup per 16-row block.  Pass 1 finds every row's max |x| (-> power-of-two scale, its
 // inverse to inv_out, the block maximum to absmax_out); pass 2 re-reads the block (L2-resident: 16 rows) and writes the
 // two fp16 planes of the scaled values.
-__global__ __launch_bounds__(256) void split_rows16_kernel(const SplitRowsArgs a) {
+__global__ __launch_bounds__(256) void split_rows16_kernel(const SplitRowsGroup G) {
     __shared__ float sc[16];
+    const SplitRowsArgs& a = G.a[blockIdx.y];
     const int nkt = a.Cp / 32;
     const int rb = blockIdx.x, t = threadIdx.x;
+    if (rb >= ((a.Rpad > a.R ? a.Rpad : a.R) + 15) / 16) return;
     auto src_row = [&](int dr, const float*& base) {
         int sr = dr;
         if (a.gate_H > 0) {  // plane row u*4+g of a 4H block <- source row g*H+u
@@ -187,10 +196,12 @@ __global__ __launch_bounds__(256) void split_rows16_kernel(const SplitRowsArgs a
 // Register-resident form of split_rows16_kernel for Cp <= 32*4*ITERS: every thread keeps its (row, K octet) values of up
 // to ITERS K tiles in registers between the row-maximum pass and the split, so the source is read exactly once.
 template <int ITERS>
-__global__ __launch_bounds__(256) void split_rows16_reg_kernel(const SplitRowsArgs a) {
+__global__ __launch_bounds__(256) void split_rows16_reg_kernel(const SplitRowsGroup G) {
     __shared__ float wmax[4][16];
+    const SplitRowsArgs& a = G.a[blockIdx.y];
     const int nkt = a.Cp / 32;
     const int rb = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (rb >= ((a.Rpad > a.R ? a.Rpad : a.R) + 15) / 16) return;
     const int rl = lane >> 2, dr = rb * 16 + rl;
     int sr = dr;
     if (a.gate_H > 0) {  // plane row u*4+g of a 4H block <- source row g*H+u
@@ -241,15 +252,17 @@ __global__ __launch_bounds__(256) void split_rows16_reg_kernel(const SplitRowsAr
 
 // Planes of the TRANSPOSE of a virtual (R x sum cols) matrix: plane row = source column (global, over the concatenated
 // segments), K = source row.  32 source rows x 64 columns per workgroup through LDS; each wave writes whole chunks.
-__global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTArgs a) {
+__global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTGroup G) {
     __shared__ float tile[32][65];
     __shared__ float segs[3];
+    const SplitTArgs& a = G.a[blockIdx.z];
     const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 64;
     const int t = threadIdx.x;
-    if (a.zero_ptr) {
+    if (a.zero_ptr) {   // (every workgroup of the pass's grid slice takes part, also those beyond its own extent)
         const long total = (long)gridDim.x * gridDim.y * 256;
         for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + t; i < a.zero_n; i += total) a.zero_ptr[i] = 0.f;
     }
+    if (k0 >= a.Rp || c0 >= (a.Ctot + 15) / 16 * 16) return;
     // load 32 source rows x 64 columns (two float4 per thread), per-chunk segment lookup, shifted rows, zero outside
     f4 vload[2];
 #pragma unroll
@@ -336,10 +349,25 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lo, const char* hi) {
 // transposing reads ds_read_b64_tr_b16 (4 k rows each).  With the planes' slot XOR (bit 3 of the row) those reads are
 // conflict-free as well: the two 16-lane groups of a half read rows r0..r0+3 and r0+8..r0+11 of one chunk, i.e. the same
 // 64-B sub-rows with slots that differ by the XOR.
+// A launch carries up to MMB_MAX_GROUP independent products (the encoders of one LSTM layer call): workgroup ids
+// [blk_begin[p], blk_begin[p+1]) belong to product p; the ranges start at multiples of 8 so that a workgroup's XCD (id % 8)
+// is also its local id % 8, and the few padding ids at the end of a range exit at once.
+struct PlanesGroup {
+    PlanesGemmArgs g[MMB_MAX_GROUP];
+    int kchunk[MMB_MAX_GROUP], tiles_n[MMB_MAX_GROUP], ntiles[MMB_MAX_GROUP], blk_begin[MMB_MAX_GROUP + 1];
+    int n;
+};
+
 template <int WM, int WN, int MT, int NT, int NP, int STAGES, bool TA = false>
-__global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g, const int kchunk, const int tiles_n,
-                                                          const int ntiles) {
+__global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGroup G) {
     static_assert(WM * WN == 8, "8 waves");
+    int prob = 0;
+    for (int i = 1; i < G.n; ++i)
+        if ((int)blockIdx.x >= G.blk_begin[i]) prob = i;
+    const PlanesGemmArgs& g = G.g[prob];
+    const int kchunk = G.kchunk[prob], tiles_n = G.tiles_n[prob], ntiles = G.ntiles[prob];
+    const int lid = blockIdx.x - G.blk_begin[prob];
+    if (lid >= ntiles * g.splitk) return;
     static_assert(!TA || (NP == 2 && (WM * MT * 16) % 32 == 0), "k-major A: fp16 planes, BM a multiple of 32");
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, RT = BM + BN;  // rows per plane image
     constexpr int STAGE = NP * RT * 64;                                // bytes per stage
@@ -351,8 +379,8 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
     const int r = lane & 15, kg = lane >> 4;
     const int wm = wave % WM, wn = wave / WM;
 
-    // XCD-chunked decode of the linear workgroup id (bijective for any grid size)
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    // XCD-chunked decode of the product's linear workgroup id (bijective for any count)
+    const int nwg = ntiles * g.splitk, xcd = lid & 7, pos = lid >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int lin = xcd * q8 + min(xcd, r8) + pos;
     const int z = lin / ntiles, tile = lin - z * ntiles;
@@ -575,31 +603,63 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGemmArgs g
 }
 
 // ------------------------------------------------------------------------------------------ host side
-int planes_split_rows(const SplitRowsArgs& a, hipStream_t stream) {
-    const long pairs = (long)((a.R + 15) / 16) * (a.Cp / 32);
-    ProfScope ps_(MMB_K_SPLIT, stream);
-    if (a.np == 2) {
-        const int nkt = a.Cp / 32;
-        const dim3 grid(((a.Rpad > a.R ? a.Rpad : a.R) + 15) / 16);
-        if (nkt <= 8) hipLaunchKernelGGL(split_rows16_reg_kernel<2>, grid, dim3(256), 0, stream, a);
-        else if (nkt <= 16) hipLaunchKernelGGL(split_rows16_reg_kernel<4>, grid, dim3(256), 0, stream, a);
-        else if (nkt <= 32) hipLaunchKernelGGL(split_rows16_reg_kernel<8>, grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL(split_rows16_kernel, grid, dim3(256), 0, stream, a);
+static int split_rows_variant(const SplitRowsArgs& a) {   // which kernel splits this pass
+    if (a.np != 2) return 0;
+    const int nkt = a.Cp / 32;
+    return nkt <= 8 ? 1 : nkt <= 16 ? 2 : nkt <= 32 ? 3 : 4;
+}
+// passes with the same kernel variant share a launch (grid.y = pass); rows beyond a pass's extent exit at once
+int planes_split_rows_group(const SplitRowsArgs* as, int n, hipStream_t stream) {
+    MMB_REQUIRE(as && n >= 1 && n <= MMB_MAX_GROUP, "planes_split_rows_group: 1..%d passes", MMB_MAX_GROUP);
+    bool done[MMB_MAX_GROUP] = {};
+    for (int i = 0; i < n; ++i) {
+        if (done[i]) continue;
+        const int v = split_rows_variant(as[i]);
+        SplitRowsGroup G{};
+        int m = 0;
+        long blocks = 0;
+        for (int j = i; j < n; ++j) {
+            if (done[j] || split_rows_variant(as[j]) != v) continue;
+            const SplitRowsArgs& a = as[j];
+            G.a[m++] = a;
+            done[j] = true;
+            const long rbs = ((a.Rpad > a.R ? a.Rpad : a.R) + 15) / 16;
+            const long b = v == 0 ? (((long)((a.R + 15) / 16) * (a.Cp / 32)) + 3) / 4 : rbs;
+            blocks = b > blocks ? b : blocks;
+        }
+        ProfScope ps_(MMB_K_SPLIT, stream);
+        const dim3 grid((unsigned)blocks, m), block(256);
+        switch (v) {
+            case 1: hipLaunchKernelGGL(split_rows16_reg_kernel<2>, grid, block, 0, stream, G); break;
+            case 2: hipLaunchKernelGGL(split_rows16_reg_kernel<4>, grid, block, 0, stream, G); break;
+            case 3: hipLaunchKernelGGL(split_rows16_reg_kernel<8>, grid, block, 0, stream, G); break;
+            case 4: hipLaunchKernelGGL(split_rows16_kernel, grid, block, 0, stream, G); break;
+            default: hipLaunchKernelGGL(split_rows_kernel, grid, block, 0, stream, G); break;
+        }
+        MMB_HIP(hipGetLastError());
     }
-    else hipLaunchKernelGGL(split_rows_kernel, dim3((pairs + 3) / 4), dim3(256), 0, stream, a);
-    MMB_HIP(hipGetLastError());
     return MMB_OK;
 }
+int planes_split_rows(const SplitRowsArgs& a, hipStream_t stream) { return planes_split_rows_group(&a, 1, stream); }
 
-int planes_split_transpose(const SplitTArgs& a, hipStream_t stream) {
+int planes_split_transpose_group(const SplitTArgs* as, int n, hipStream_t stream) {
+    MMB_REQUIRE(as && n >= 1 && n <= MMB_MAX_GROUP, "planes_split_transpose_group: 1..%d passes", MMB_MAX_GROUP);
+    SplitTGroup G{};
+    unsigned gx = 1, gy = 1;
+    for (int i = 0; i < n; ++i) {
+        G.a[i] = as[i];
+        gx = std::max(gx, (unsigned)((as[i].Rp + 31) / 32));
+        gy = std::max(gy, (unsigned)((as[i].Ctot + 63) / 64));
+    }
     ProfScope ps_(MMB_K_SPLIT, stream);
-    hipLaunchKernelGGL(split_transpose_kernel, dim3((a.Rp + 31) / 32, (a.Ctot + 63) / 64), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(split_transpose_kernel, dim3(gx, gy, n), dim3(256), 0, stream, G);
     MMB_HIP(hipGetLastError());
     return MMB_OK;
 }
+int planes_split_transpose(const SplitTArgs& a, hipStream_t stream) { return planes_split_transpose_group(&a, 1, stream); }
 
 template <int WM, int WN, int MT, int NT, int NP, bool TA = false>
-static int launch_planes_np(const PlanesGemmArgs& g, hipStream_t stream) {
+static int launch_planes_np(PlanesGroup& G, hipStream_t stream) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
     // The kernel also runs with 3 stages (counted vmcnt waits, the fp16 tiles leave room for it), but measured it brings
     // nothing (459 vs 446 us over the hot-path shapes): the limit is L2 -> LDS throughput next to the MFMA stream, not
@@ -614,22 +674,30 @@ static int launch_planes_np(const PlanesGemmArgs& g, hipStream_t stream) {
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr.mark();
     }
-    const int tiles_n = (g.N + BN - 1) / BN, ntiles = tiles_n * ((g.M + BM - 1) / BM);
-    int kchunk = (g.K + g.splitk - 1) / g.splitk;
-    kchunk = (kchunk + 31) / 32 * 32;
+    int blk = 0;
+    for (int p = 0; p < G.n; ++p) {
+        const PlanesGemmArgs& g = G.g[p];
+        G.tiles_n[p] = (g.N + BN - 1) / BN;
+        G.ntiles[p] = G.tiles_n[p] * ((g.M + BM - 1) / BM);
+        G.kchunk[p] = ((g.K + g.splitk - 1) / g.splitk + 31) / 32 * 32;
+        G.blk_begin[p] = blk;
+        blk += (G.ntiles[p] * g.splitk + 7) & ~7;
+    }
+    G.blk_begin[G.n] = blk;
     ProfScope ps_(MMB_K_GEMM, stream);
-    hipLaunchKernelGGL(kern, dim3(ntiles * g.splitk), dim3(512), lds, stream, g, kchunk, tiles_n, ntiles);
+    hipLaunchKernelGGL(kern, dim3(blk), dim3(512), lds, stream, G);
     MMB_HIP(hipGetLastError());
     return MMB_OK;
 }
 
 template <int WM, int WN, int MT, int NT>
-static int launch_planes(const PlanesGemmArgs& g, hipStream_t stream) {
+static int launch_planes(PlanesGroup& G, hipStream_t stream) {
+    const PlanesGemmArgs& g = G.g[0];    // np / ta are the same for the whole group
     if constexpr ((WM * MT * 16) % 32 == 0) {
-        if (g.ta) return launch_planes_np<WM, WN, MT, NT, 2, true>(g, stream);
+        if (g.ta) return launch_planes_np<WM, WN, MT, NT, 2, true>(G, stream);
     }
-    if (g.np == 1) return launch_planes_np<WM, WN, MT, NT, 1>(g, stream);
-    return g.np == 2 ? launch_planes_np<WM, WN, MT, NT, 2>(g, stream) : launch_planes_np<WM, WN, MT, NT, 3>(g, stream);
+    if (g.np == 1) return launch_planes_np<WM, WN, MT, NT, 1>(G, stream);
+    return g.np == 2 ? launch_planes_np<WM, WN, MT, NT, 2>(G, stream) : launch_planes_np<WM, WN, MT, NT, 3>(G, stream);
 }
 
 bool planes_one_split() {
@@ -689,7 +757,8 @@ double planes_cost(const PlanesGemmArgs& g, const PlanesCfg& c, int splitk) {
 
 void planes_set_tune(int code) { g_planes_force = code; }
 
-static void planes_choose(const PlanesGemmArgs& g, int& best, int& best_s) {
+// best (config, split) by the cost model; only_cfg >= 0 restricts the search to that config (grouped launches)
+static double planes_choose(const PlanesGemmArgs& g, int& best, int& best_s, int only_cfg = -1) {
     static bool env_read = false;
     if (!env_read) {   // MMB_PLANES_TUNE = <config><split, 2 digits>
         const char* t = getenv("MMB_PLANES_TUNE");
@@ -700,15 +769,18 @@ static void planes_choose(const PlanesGemmArgs& g, int& best, int& best_s) {
     double best_cost = 1e300;
     for (int c = 0; c < N_PLANES_CFGS; ++c)
         for (int s = 1; s <= 32; ++s) {
+            if (only_cfg >= 0 && c != only_cfg) break;
             if (g.ta && (PLANES_CFGS[c].wm * PLANES_CFGS[c].mt * 16) % 32) break;   // k-major A: BM a multiple of 32
             if (s > 1 && g.K / s < 512) break;
             const double cost = planes_cost(g, PLANES_CFGS[c], s);
             if (cost < best_cost) { best_cost = cost; best = c; best_s = s; }
         }
-    if (g_planes_force >= 0 && !(g.ta && (PLANES_CFGS[(g_planes_force / 100) % N_PLANES_CFGS].wm * PLANES_CFGS[(g_planes_force / 100) % N_PLANES_CFGS].mt * 16) % 32)) {
+    if (only_cfg < 0 && g_planes_force >= 0 &&
+        !(g.ta && (PLANES_CFGS[(g_planes_force / 100) % N_PLANES_CFGS].wm * PLANES_CFGS[(g_planes_force / 100) % N_PLANES_CFGS].mt * 16) % 32)) {
         best = (g_planes_force / 100) % N_PLANES_CFGS;
         if (g_planes_force % 100 > 0) best_s = g_planes_force % 100;
     }
+    return best_cost;
 }
 
 int planes_plan_splitk(const PlanesGemmArgs& g_) {
@@ -719,35 +791,60 @@ int planes_plan_splitk(const PlanesGemmArgs& g_) {
     return best_s;
 }
 
-int planes_gemm(const PlanesGemmArgs& g_, hipStream_t stream) {
-    PlanesGemmArgs g = g_;
+int planes_gemm_group(const PlanesGemmArgs* gs, int n, hipStream_t stream) {
     static int dbg = -1, verbose = 0;   // MMB_PLANES_DBG: timing-only ablations
     if (dbg < 0) {
         const char* e = getenv("MMB_PLANES_DBG");
         dbg = e ? atoi(e) : 0;
         verbose = getenv("MMB_PLANES_VERBOSE") != nullptr;
     }
-    g.dbg = dbg;
-    if (g.np != 2 && g.np != 1) g.np = 3;
-    MMB_REQUIRE(!g.ta || (g.np == 2 && g.K % 32 == 0), "planes_gemm: a k-major A operand needs the fp16 planes and K %% 32 == 0");
-    int best, best_s;
-    planes_choose(g, best, best_s);
-    if (verbose)
-        fprintf(stderr, "planes_gemm %dx%dx%d: tile %dx%d split %d\n", g.M, g.N, g.K, PLANES_CFGS[best].wm * PLANES_CFGS[best].mt * 16,
-                PLANES_CFGS[best].wn * PLANES_CFGS[best].nt * 16, best_s);
-    g.splitk = best_s;
-    if (g.splitk > 1 && !g.accumulate && !g.prezeroed)
-        MMB_HIP(hipMemset2DAsync(g.C, (size_t)g.ldc * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream));
+    MMB_REQUIRE(gs && n >= 1 && n <= MMB_MAX_GROUP, "planes_gemm_group: 1..%d products", MMB_MAX_GROUP);
+    PlanesGroup G{};
+    G.n = n;
+    for (int p = 0; p < n; ++p) {
+        PlanesGemmArgs& g = G.g[p];
+        g = gs[p];
+        g.dbg = dbg;
+        if (g.np != 2 && g.np != 1) g.np = 3;
+        MMB_REQUIRE(!g.ta || (g.np == 2 && g.K % 32 == 0), "planes_gemm: a k-major A operand needs the fp16 planes and K %% 32 == 0");
+        MMB_REQUIRE(g.np == G.g[0].np && g.ta == G.g[0].ta, "planes_gemm_group: the products of a group share the plane format");
+    }
+    // one tile shape for the launch: the one that minimises the summed cost estimate with each product's best K split
+    int best = 0;
+    {
+        double best_cost = 1e300;
+        for (int c = 0; c < N_PLANES_CFGS; ++c) {
+            if (n == 1) { int s_; planes_choose(G.g[0], best, s_); break; }
+            if (G.g[0].ta && (PLANES_CFGS[c].wm * PLANES_CFGS[c].mt * 16) % 32) continue;
+            double cost = 0;
+            for (int p = 0; p < n; ++p) { int b_, s_; cost += planes_choose(G.g[p], b_, s_, c); }
+            if (cost < best_cost) { best_cost = cost; best = c; }
+        }
+    }
+    for (int p = 0; p < n; ++p) {
+        PlanesGemmArgs& g = G.g[p];
+        int b_, s_;
+        if (n == 1) planes_choose(g, b_, s_);   // honours MMB_PLANES_TUNE
+        else planes_choose(g, b_, s_, best);
+        g.splitk = s_;
+        if (verbose)
+            fprintf(stderr, "planes_gemm %dx%dx%d: tile %dx%d split %d%s\n", g.M, g.N, g.K, PLANES_CFGS[best].wm * PLANES_CFGS[best].mt * 16,
+                    PLANES_CFGS[best].wn * PLANES_CFGS[best].nt * 16, s_, n > 1 ? " (grouped)" : "");
+        if (g.splitk > 1 && !g.accumulate && !g.prezeroed)
+            MMB_HIP(hipMemset2DAsync(g.C, (size_t)g.ldc * sizeof(float), 0, (size_t)g.N * sizeof(float), g.M, stream));
+    }
     switch (best) {
-        case 0: return launch_planes<4, 2, 4, 5>(g, stream);
-        case 1: return launch_planes<2, 4, 5, 4>(g, stream);
-        case 2: return launch_planes<4, 2, 2, 5>(g, stream);
-        case 3: return launch_planes<4, 2, 2, 7>(g, stream);
-        case 4: return launch_planes<4, 2, 1, 5>(g, stream);
-        case 5: return launch_planes<4, 2, 1, 7>(g, stream);
-        default: return launch_planes<1, 8, 5, 2>(g, stream);
+        case 0: return launch_planes<4, 2, 4, 5>(G, stream);
+        case 1: return launch_planes<2, 4, 5, 4>(G, stream);
+        case 2: return launch_planes<4, 2, 2, 5>(G, stream);
+        case 3: return launch_planes<4, 2, 2, 7>(G, stream);
+        case 4: return launch_planes<4, 2, 1, 5>(G, stream);
+        case 5: return launch_planes<4, 2, 1, 7>(G, stream);
+        default: return launch_planes<1, 8, 5, 2>(G, stream);
     }
 }
+
+int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream) { return planes_gemm_group(&g, 1, stream); }
 
 }  // namespace mmb
 
