@@ -612,14 +612,22 @@ static int split_rows_variant(const SplitRowsArgs& a) {   // which kernel splits
 int planes_split_rows_group(const SplitRowsArgs* as, int n, hipStream_t stream) {
     MMB_REQUIRE(as && n >= 1 && n <= MMB_MAX_GROUP, "planes_split_rows_group: 1..%d passes", MMB_MAX_GROUP);
     bool done[MMB_MAX_GROUP] = {};
+    // the register-resident variants (1..3: up to 8 / 16 / 32 K tiles) are merged into the widest one present (narrower
+    // passes just skip its extra trips), so that e.g. the three input encoders' x splits are one launch
+    int vreg = 0;
+    for (int i = 0; i < n; ++i) {
+        const int v = split_rows_variant(as[i]);
+        if (v >= 1 && v <= 3) vreg = std::max(vreg, v);
+    }
+    auto variant = [&](const SplitRowsArgs& a) { const int v = split_rows_variant(a); return (v >= 1 && v <= 3) ? vreg : v; };
     for (int i = 0; i < n; ++i) {
         if (done[i]) continue;
-        const int v = split_rows_variant(as[i]);
+        const int v = variant(as[i]);
         SplitRowsGroup G{};
         int m = 0;
         long blocks = 0;
         for (int j = i; j < n; ++j) {
-            if (done[j] || split_rows_variant(as[j]) != v) continue;
+            if (done[j] || variant(as[j]) != v) continue;
             const SplitRowsArgs& a = as[j];
             G.a[m++] = a;
             done[j] = true;
