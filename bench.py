@@ -50,8 +50,8 @@ def source_hash():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg2", choices=sorted(synth.CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--ragged", action="store_true", help="lengths ~U{n/2..n} instead of full")
