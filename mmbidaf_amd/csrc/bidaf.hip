@@ -1478,7 +1478,10 @@ __global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a) {
 //   dS = P1 (dP1 - delta1_i) mask_j + P2 (dP2 - delta2_j) mask_i
 //   d_text_i += sum_j P2_ij dq_j ; dX_i = sum_j dS_ij mod_d_j ; dr_i = sum_j dS_ij
 //   d_text_d_i = dr_i w_t + w_tm * dX_i ; d_w_t += dr_i text_d_i ; d_w_tm += dX_i * text_d_i ; d_bias += dr_i
-template <bool DBG>
+// SAME = no dropped copies (text_d == text, mod_d == mod): the similarity is then formed as text . (mod * w_tm) -- lane side
+// = the text planes the dP2 product needs anyway, streamed side = the w_tm-folded modality planes -- so the pass carries
+// three lane-side operands (168 registers) instead of four and reads one 11.5-MB plane set less.
+template <bool DBG, bool SAME>
 __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int dbg = DBG ? a.dbg : 0;
@@ -1500,6 +1503,7 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
     char* pQ = smem + PANEL_B;
     char* pDq = smem + 2 * PANEL_B;
     char* pMd = sep ? smem + 3 * PANEL_B : pM;
+    char* pSp = SAME ? smem + 3 * PANEL_B : pMd;      // streamed S operand: mod * w_tm (SAME) or the dropped copy mod_d
     float* ct_all = reinterpret_cast<float*>(smem + 4 * PANEL_B);   // per-row scalars of ALL modality rows
     float* cmax_all = ct_all + Mp;
     float* cinv_all = ct_all + 2 * Mp;     // 0 beyond M
@@ -1509,15 +1513,18 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
     float* sMd_all = ct_all + 6 * Mp;
     float* sQ_all = ct_all + 7 * Mp;
     float* sDq_all = ct_all + 8 * Mp;
-    float* red = ct_all + 9 * Mp;
+    float* sSp_all = ct_all + 9 * Mp;      // inverse row scales of the streamed S operand
+    float* red = ct_all + 10 * Mp;
 
     const size_t szT = planes_sample_bytes(T), szM = planes_sample_bytes(M);
-    side_t sideS, sideDa, sideDb, sideT;
-    float inS, inDa, inDb, inT;
-    load_side_planes(sideS, inS, a.pTw + (size_t)b * szT, a.iTw + (size_t)b * pad32(T), n, T, g);
+    side_t sideS_, sideDa, sideDb, sideT;
+    float inS_ = 0.f, inDa, inDb, inT;
+    if (!SAME) load_side_planes(sideS_, inS_, a.pTw + (size_t)b * szT, a.iTw + (size_t)b * pad32(T), n, T, g);
     load_side_planes(sideDa, inDa, a.pDa + (size_t)b * szT, a.iDa + (size_t)b * pad32(T), n, T, g);
     load_side_planes(sideDb, inDb, a.pDb + (size_t)b * szT, a.iDb + (size_t)b * pad32(T), n, T, g);
     load_side_planes(sideT, inT, a.pT + (size_t)b * szT, a.iT + (size_t)b * pad32(T), n, T, g);
+    const side_t& sideS = SAME ? sideT : sideS_;
+    const float inS = SAME ? inT : inS_;
     const bool nin = n < T;
     const float rterm = nin ? a.rterm[(size_t)b * T + n] : 0.f;
     const float rmax = nin ? a.row_stat[((size_t)b * T + n) * 2] : 0.f;
@@ -1539,6 +1546,7 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
         const size_t pj = (size_t)b * Mp + j;
         const float v0 = in ? a.iM[pj] : 0.f, v1 = in ? a.iMd[pj] : 0.f, v2 = in ? a.iQ[pj] : 0.f, v3 = in ? a.iDq[pj] : 0.f;
         sM_all[j] = v0; sMd_all[j] = v1; sQ_all[j] = v2; sDq_all[j] = v3;
+        sSp_all[j] = SAME ? (in ? a.iMw[pj] : 0.f) : v1;
         im[0] = fmaxf(im[0], v0); im[1] = fmaxf(im[1], v1); im[2] = fmaxf(im[2], v2); im[3] = fmaxf(im[3], v3);
     }
     wg_allmax(im, red, tid);
@@ -1553,6 +1561,7 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
     const char* md_b = a.pMd + (size_t)b * szM;
     const char* q_b = a.pQ + (size_t)b * szM;
     const char* dq_b = a.pDq + (size_t)b * szM;
+    const char* sp_b = a.pMw + (size_t)b * szM;
     const int Mloop = (dbg & 16) ? 0 : M;
     for (int p0 = 0; p0 < Mloop; p0 += PR) {
         __syncthreads();
@@ -1560,14 +1569,15 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
             stage_panel(pM, m_b, p0, tid);
             stage_panel(pQ, q_b, p0, tid);
             stage_panel(pDq, dq_b, p0, tid);
-            if (sep) stage_panel(pMd, md_b, p0, tid);
+            if (SAME) stage_panel(pSp, sp_b, p0, tid);
+            else if (sep) stage_panel(pMd, md_b, p0, tid);
         }
         __syncthreads();
         f4 s[2], dpa[2], dpb[2], dp2[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) s[q] = dpa[q] = dpb[q] = dp2[q] = f4{0.f, 0.f, 0.f, 0.f};
         if (!(dbg & 2)) {
-            sprod2<false>(pMd, r, g, sideS, s);
+            sprod2<false>(pSp, r, g, sideS, s);
             sprod2<false>(pM, r, g, sideDa, dpa);
             sprod2<false>(pQ, r, g, sideDb, dpb);
             sprod2<false>(pDq, r, g, sideT, dp2);
@@ -1579,7 +1589,7 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
             for (int e = 0; e < 4; ++e) {
                 const int ml = p0 + mb * 16 + 4 * g + e;
                 const float mf = mmf_all[ml];
-                const float x = s[mb][e] * (sMd_all[ml] * inS) + rterm + ct_all[ml];
+                const float x = s[mb][e] * (sSp_all[ml] * inS) + rterm + ct_all[ml];
                 const float P1 = mf >= 0.f ? __expf((mf > 0.f ? x : NEG) - rmax) * rinv : 0.f;
                 const float P2 = mf >= 0.f ? __expf((tm ? x : NEG) - cmax_all[ml]) * cinv_all[ml] : 0.f;
                 const float dp1 = dpa[mb][e] * (sM_all[ml] * inDa) + dpb[mb][e] * (sQ_all[ml] * inDb);
@@ -2015,10 +2025,12 @@ extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* 
         MMB_HIP(hipGetLastError());
     }
     {
-        size_t lds = (size_t)4 * PANEL_B + ((size_t)9 * pad32(M) + 16) * sizeof(float);
+        size_t lds = (size_t)4 * PANEL_B + ((size_t)10 * pad32(M) + 16) * sizeof(float);
         const size_t epi = ((size_t)2 * 16 * NW * LDP + 16 * NW + NW * 2 * 256) * sizeof(float);   // parked dX, P2.dq tiles + dr + partial sums
         if (lds < epi) lds = epi;
-        auto kern = a.dbg ? att_bwd_i_kernel<true> : att_bwd_i_kernel<false>;
+        const bool same = a.fold && a.pMd == a.pM && a.pTd == a.pT;
+        auto kern = a.dbg ? (same ? att_bwd_i_kernel<true, true> : att_bwd_i_kernel<true, false>)
+                          : (same ? att_bwd_i_kernel<false, true> : att_bwd_i_kernel<false, false>);
         if (int rc = allow_lds(kern, lds)) return rc;
         a.i_blocks = tiles_t * B;
         ProfScope ps_(MMB_K_ATT_BWD_I, stream);
