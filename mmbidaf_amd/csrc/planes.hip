@@ -741,8 +741,9 @@ int planes_terms() {
 
 namespace {
 struct PlanesCfg { int wm, wn, mt, nt; };
-// tile = (wm*mt*16) x (wn*nt*16):        256x160       160x256       128x160       128x224       64x160        64x224        80x256
-constexpr PlanesCfg PLANES_CFGS[] = {{4, 2, 4, 5}, {2, 4, 5, 4}, {4, 2, 2, 5}, {4, 2, 2, 7}, {4, 2, 1, 5}, {4, 2, 1, 7}, {1, 8, 5, 2}};
+// tile = (wm*mt*16) x (wn*nt*16):        256x160       160x256       128x160       128x224       64x160        64x224        80x256        256x256
+constexpr PlanesCfg PLANES_CFGS[] = {{4, 2, 4, 5}, {2, 4, 5, 4}, {4, 2, 2, 5}, {4, 2, 2, 7}, {4, 2, 1, 5}, {4, 2, 1, 7}, {1, 8, 5, 2},
+                                     {4, 2, 4, 8}};   // 256x256: single-plane (bf16 mode) products only, see planes_choose
 constexpr int N_PLANES_CFGS = sizeof(PLANES_CFGS) / sizeof(PLANES_CFGS[0]);
 int g_planes_force = -1;   // <config * 100 + split> from mmb_set_planes_tune / MMB_PLANES_TUNE, -1 = cost model
 
@@ -778,6 +779,7 @@ static double planes_choose(const PlanesGemmArgs& g, int& best, int& best_s, int
     for (int c = 0; c < N_PLANES_CFGS; ++c)
         for (int s = 1; s <= 32; ++s) {
             if (only_cfg >= 0 && c != only_cfg) break;
+            if (c == 7 && g.np != 1) break;   // the 256x256 tile: 64 KB of LDS stages with one plane; the cost model was not fitted to it for the others
             if (g.ta && (PLANES_CFGS[c].wm * PLANES_CFGS[c].mt * 16) % 32) break;   // k-major A: BM a multiple of 32
             if (s > 1 && g.K / s < 512) break;
             const double cost = planes_cost(g, PLANES_CFGS[c], s);
@@ -848,7 +850,8 @@ int planes_gemm_group(const PlanesGemmArgs* gs, int n, hipStream_t stream) {
         case 3: return launch_planes<4, 2, 2, 7>(G, stream);
         case 4: return launch_planes<4, 2, 1, 5>(G, stream);
         case 5: return launch_planes<4, 2, 1, 7>(G, stream);
-        default: return launch_planes<1, 8, 5, 2>(G, stream);
+        case 6: return launch_planes<1, 8, 5, 2>(G, stream);
+        default: return launch_planes_np<4, 2, 4, 8, 1>(G, stream);
     }
 }
 
