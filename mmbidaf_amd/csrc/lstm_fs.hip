@@ -276,8 +276,11 @@ __device__ __forceinline__ float fs_da_scale(const FsBwdProb& P, int dir, int s)
 // One workgroup = 32 units (2 m tiles) x 64 samples, K = 4H split over its 8 waves (k tiles w, w+8, ...): every fragment
 // of W_hh^T and of the previous step's d_a is read once per workgroup; partial tiles meet in LDS (64 KiB); each thread then
 // owns 4 units of one sample.
-template <int NPL>
+// MU = 16-unit m tiles per workgroup: 2 (32 units) reads the recurrent operand half as often over the chain, 1 doubles the
+// number of workgroups when a layer call has too few chains to fill the XCDs they are pinned to
+template <int NPL, int MU>
 __global__ __launch_bounds__(512) void lstm_fs_bwd_kernel(const FsBwdArgs args, const int s) {
+    constexpr int UW = 16 * MU, NP_T = 2 * MU, ROWS = 512 / UW;   // units per workgroup, (unit, sample) pairs per thread, samples per pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int chain, sl;
     if (!fs_decode(2 * args.n, chain, sl)) return;
@@ -290,14 +293,14 @@ __global__ __launch_bounds__(512) void lstm_fs_bwd_kernel(const FsBwdArgs args, 
     const int r = lane & 15, g = lane >> 4;
     // the gate-gradient part's own operands (thread -> one unit of 4 samples, units fastest) are requested FIRST: their two
     // dependent global latencies (len -> d_y / gates / cs / dc) then run under the operand loads, the MFMAs and the reduction
-    const int ul = tid & 31, u = 32 * slice + ul;
-    int e_t[4], e_len[4];
-    bool e_on[4];
-    float e_dy[4], e_dcs[4], e_ct[4], e_cp[4];
-    f4 e_g4[4];
+    const int ul = tid & (UW - 1), u = UW * slice + ul;
+    int e_t[NP_T], e_len[NP_T];
+    bool e_on[NP_T];
+    float e_dy[NP_T], e_dcs[NP_T], e_ct[NP_T], e_cp[NP_T];
+    f4 e_g4[NP_T];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int b = 64 * sblk + (tid >> 5) + 16 * k;
+    for (int k = 0; k < NP_T; ++k) {
+        const int b = 64 * sblk + tid / UW + ROWS * k;
         const int len = (b < P.B && u < H) ? min(max(P.len[b], 0), T) : 0;
         e_len[k] = len;
         e_on[k] = s < len;
@@ -317,24 +320,24 @@ __global__ __launch_bounds__(512) void lstm_fs_bwd_kernel(const FsBwdArgs args, 
             if (has_prev) e_cp[k] = P.cs[((size_t)b * T + (dir ? t + 1 : t - 1)) * 2 * H + dir * H + u];
         }
     }
-    f4 c[2][4];
+    f4 c[MU][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MU; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) c[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
-        const char* A = P.wtp[dir] + fs_off(32 * slice + r, g, nkt, NPL);
+        const char* A = P.wtp[dir] + fs_off(UW * slice + r, g, nkt, NPL);
         const char* Bq = P.ap[dir][(s + 1) & 1] + fs_off(64 * sblk + r, g, nkt, NPL);
         const size_t rb = (size_t)nkt * NPL * 1024;
         for (int kt0 = wave; kt0 < nkt; kt0 += 16) {   // two k tiles per trip: 12 * NPL fragment loads in flight
-            u4 a[2][2][NPL], b[2][4][NPL];
+            u4 a[2][MU][NPL], b[2][4][NPL];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const size_t o = (size_t)min(kt0 + 8 * q, nkt - 1) * NPL * 1024;
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) a[q][i][pl] = *reinterpret_cast<const u4*>(A + i * rb + o + pl * 1024);
+                    for (int i = 0; i < MU; ++i) a[q][i][pl] = *reinterpret_cast<const u4*>(A + i * rb + o + pl * 1024);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) b[q][j][pl] = *reinterpret_cast<const u4*>(Bq + j * rb + o + pl * 1024);
                 }
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(512) void lstm_fs_bwd_kernel(const FsBwdArgs args, 
             for (int q = 0; q < 2; ++q) {
                 if (kt0 + 8 * q >= nkt) continue;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MU; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) c[i][j] = fs_prod<NPL>(a[q][i], b[q][j], c[i][j]);
             }
@@ -353,11 +356,11 @@ __global__ __launch_bounds__(512) void lstm_fs_bwd_kernel(const FsBwdArgs args, 
     // consecutive lanes on consecutive units (contiguous d_y / cs / gates / d_a / plane accesses)
     float* partf = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MU; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) partf[(wave * 64 + 16 * j + r) * 33 + 16 * i + 4 * g + e] = c[i][j][e];
+            for (int e = 0; e < 4; ++e) partf[(wave * 64 + 16 * j + r) * (UW + 1) + 16 * i + 4 * g + e] = c[i][j][e];
     __syncthreads();
     float inv_prev = 1.0f, sc = 1.0f;
     if (NPL == 2) {
@@ -367,11 +370,11 @@ __global__ __launch_bounds__(512) void lstm_fs_bwd_kernel(const FsBwdArgs args, 
     char* anext = P.ap[dir][s & 1];
     float lmax = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int bl = (tid >> 5) + 16 * k, b = 64 * sblk + bl;
+    for (int k = 0; k < NP_T; ++k) {
+        const int bl = tid / UW + ROWS * k, b = 64 * sblk + bl;
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) acc += partf[(w * 64 + bl) * 33 + ul];
+        for (int w = 0; w < 8; ++w) acc += partf[(w * 64 + bl) * (UW + 1) + ul];
         if (!e_on[k]) continue;
         const int t = e_t[k];
         const size_t row = (size_t)b * T + t;
@@ -551,17 +554,22 @@ int lstm_fs_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* ws, hipStream_t 
         maxB = max(maxB, p.B);
     }
     MMB_HIP(hipGetLastError());
-    a.nslices = (H + 31) / 32;
     a.nsb = (maxB + 63) / 64;
+    // 32 units per workgroup unless that leaves fewer than ~192 workgroups (the XCDs the chains are pinned to hold 32 CUs each)
+    static const int mu_env = [] { const char* e = getenv("MMB_LSTM_FS_MU"); return e ? atoi(e) : 0; }();
+    const int mu = mu_env == 1 || mu_env == 2 ? mu_env : ((long)2 * n * ((H + 31) / 32) * a.nsb >= 192 ? 2 : 1);
+    a.nslices = (H + 16 * mu - 1) / (16 * mu);
     const int slots = (2 * n + 7) & ~7;
     const dim3 grid(slots * a.nslices * a.nsb);
-    constexpr int lds = 8 * 64 * 33 * 4;    // 8 partial tiles of 64 samples x (32 + 1) floats
-    auto kern = npl == 2 ? lstm_fs_bwd_kernel<2> : lstm_fs_bwd_kernel<1>;
+    const int lds = 8 * 64 * (16 * mu + 1) * 4;    // 8 partial tiles of 64 samples x (units + 1) floats
+    auto kern = npl == 2 ? (mu == 2 ? lstm_fs_bwd_kernel<2, 2> : lstm_fs_bwd_kernel<2, 1>)
+                         : (mu == 2 ? lstm_fs_bwd_kernel<1, 2> : lstm_fs_bwd_kernel<1, 1>);
     {
-        static PerDeviceOnce attr[2];
-        if (attr[npl - 1].pending()) {
-            MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr[npl - 1].mark();
+        static PerDeviceOnce attr[4];
+        const int ai = (npl - 1) * 2 + (mu - 1);
+        if (attr[ai].pending()) {
+            MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 33 * 4));
+            attr[ai].mark();
         }
     }
     {
