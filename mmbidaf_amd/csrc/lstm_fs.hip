@@ -142,8 +142,10 @@ struct FsFwdArgs { FsFwdProb p[MMB_MAX_GROUP]; int n, nkt, nslices, nsb; };
 // and each computes all 4 x 4 tiles of the workgroup tile on its K part, so every operand fragment is read exactly once per
 // workgroup; the 8 partial tiles meet in LDS (128 KiB) and each thread then owns two (unit, sample) pairs with their four
 // gates: the cell update is thread-local.
-template <int NPL>
+// NS = 16-sample n tiles per workgroup: 4 (64 samples), or 2 when a layer call has too few chains to fill its XCDs
+template <int NPL, int NS>
 __global__ __launch_bounds__(512) void lstm_fs_fwd_kernel(const FsFwdArgs args, const int s) {
+    constexpr int SW = 16 * NS, NQ = NS / 2;   // samples per workgroup, (unit, sample) pairs per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int chain, sl;
     if (!fs_decode(2 * args.n, chain, sl)) return;
@@ -151,19 +153,19 @@ __global__ __launch_bounds__(512) void lstm_fs_fwd_kernel(const FsFwdArgs args, 
     const FsFwdProb& P = args.p[chain >> 1];
     const int dir = chain & 1;
     const int H = P.H, T = P.T, nkt = args.nkt;
-    if (s >= T || 64 * sblk >= P.B) return;
+    if (s >= T || SW * sblk >= P.B) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     f4* part = reinterpret_cast<f4*>(smem);               // [wave][sample 64][17] quads
     // the cell update's own operands (thread -> two (unit, sample) pairs, units fastest) are requested FIRST: their two
     // dependent global latencies (len -> gx / c_prev) then run under the operand loads, the MFMAs and the reduction
-    int e_t[2], e_len[2];
-    bool e_on[2];
-    f4 e_gx[2];
-    float e_cp[2];
+    int e_t[NQ], e_len[NQ];
+    bool e_on[NQ];
+    f4 e_gx[NQ];
+    float e_cp[NQ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int pair = tid + 512 * q, u = 16 * slice + (pair & 15), b = 64 * sblk + (pair >> 4);
+    for (int q = 0; q < NQ; ++q) {
+        const int pair = tid + 512 * q, u = 16 * slice + (pair & 15), b = SW * sblk + (pair >> 4);
         const int len = (u < H && b < P.B) ? min(max(P.len[b], 0), T) : 0;
         e_len[q] = len;
         e_on[q] = s < len;
@@ -176,29 +178,29 @@ __global__ __launch_bounds__(512) void lstm_fs_fwd_kernel(const FsFwdArgs args, 
             if (s > 0) e_cp[q] = P.cs[((size_t)b * T + (dir ? e_t[q] + 1 : e_t[q] - 1)) * 2 * H + dir * H + u];
         }
     }
-    f4 c[4][4];
+    f4 c[4][NS];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) c[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NS; ++j) c[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     if (s > 0) {   // h_{-1} = 0
         const char* A = P.wp[dir] + fs_off(64 * slice + r, g, nkt, NPL);
-        const char* Bh = P.hp[dir][(s + 1) & 1] + fs_off(64 * sblk + r, g, nkt, NPL);
+        const char* Bh = P.hp[dir][(s + 1) & 1] + fs_off(SW * sblk + r, g, nkt, NPL);
         const size_t rbA = (size_t)nkt * NPL * 1024;     // bytes from one 16-row block to the next
         for (int kt = wave; kt < nkt; kt += 8) {
-            u4 a[4][NPL], b[4][NPL];
+            u4 a[4][NPL], b[NS][NPL];
             const size_t o = (size_t)kt * NPL * 1024;
 #pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i][pl] = *reinterpret_cast<const u4*>(A + i * rbA + o + pl * 1024);
+#pragma unroll
+                for (int j = 0; j < NS; ++j) b[j][pl] = *reinterpret_cast<const u4*>(Bh + j * rbA + o + pl * 1024);
+            }
+#pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) {
-                    a[i][pl] = *reinterpret_cast<const u4*>(A + i * rbA + o + pl * 1024);
-                    b[i][pl] = *reinterpret_cast<const u4*>(Bh + i * rbA + o + pl * 1024);
-                }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) c[i][j] = fs_prod<NPL>(a[i], b[j], c[i][j]);
+                for (int j = 0; j < NS; ++j) c[i][j] = fs_prod<NPL>(a[i], b[j], c[i][j]);
         }
     }
     // partial tiles to LDS as [wave][sample 64][unit 16 (+1 pad)] quads (the 4 gates of a (unit, sample) pair), so that the
@@ -207,17 +209,17 @@ __global__ __launch_bounds__(512) void lstm_fs_fwd_kernel(const FsFwdArgs args, 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) part[(wave * 64 + 16 * j + r) * 17 + 4 * i + g] = c[i][j];
+        for (int j = 0; j < NS; ++j) part[(wave * SW + 16 * j + r) * 17 + 4 * i + g] = c[i][j];
     __syncthreads();
     char* hnext = P.hp[dir][s & 1];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int pair = tid + 512 * q, ul = pair & 15, bl = pair >> 4;
         f4 acc = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < 8; ++w) acc += part[(w * 64 + bl) * 17 + ul];
+        for (int w = 0; w < 8; ++w) acc += part[(w * SW + bl) * 17 + ul];
         const int u = 16 * slice + ul;
-        const int b = 64 * sblk + bl;
+        const int b = SW * sblk + bl;
         if (!e_on[q]) continue;
         const int t = e_t[q];
         const size_t row = (size_t)b * T + t;
@@ -499,16 +501,22 @@ int lstm_fs_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* ws, hipStream_t 
     }
     MMB_HIP(hipGetLastError());
     a.nslices = (H + 15) / 16;
-    a.nsb = (maxB + 63) / 64;
+    // 64 samples per workgroup; 32 (MMB_LSTM_FS_NS=2: twice the workgroups, each reading the W_hh slice again) measured
+    // slower at cfg5 (50.8 vs 49.3 ms/step)
+    static const int ns_env = [] { const char* e = getenv("MMB_LSTM_FS_NS"); return e ? atoi(e) : 0; }();
+    const int ns = ns_env == 2 ? 2 : 4;
+    a.nsb = (maxB + 16 * ns - 1) / (16 * ns);
     const int slots = (2 * n + 7) & ~7;
     const dim3 grid(slots * a.nslices * a.nsb);
-    constexpr int lds = 8 * 64 * 17 * 16;   // 8 partial tiles of 64 samples x (16 + 1) gate quads
-    auto kern = npl == 2 ? lstm_fs_fwd_kernel<2> : lstm_fs_fwd_kernel<1>;
+    constexpr int lds = 8 * 64 * 17 * 16;   // 8 partial tiles of (up to) 64 samples x (16 + 1) gate quads
+    auto kern = npl == 2 ? (ns == 4 ? lstm_fs_fwd_kernel<2, 4> : lstm_fs_fwd_kernel<2, 2>)
+                         : (ns == 4 ? lstm_fs_fwd_kernel<1, 4> : lstm_fs_fwd_kernel<1, 2>);
     {
-        static PerDeviceOnce attr[2];
-        if (attr[npl - 1].pending()) {
+        static PerDeviceOnce attr[4];
+        const int ai = (npl - 1) * 2 + (ns == 4 ? 1 : 0);
+        if (attr[ai].pending()) {
             MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr[npl - 1].mark();
+            attr[ai].mark();
         }
     }
     {
