@@ -28,8 +28,8 @@
 // operand stay in that XCD's L2.  NPL = 2: fp16 two-term planes (fp32-accurate); NPL = 1: one bf16 plane (mmb_set_precision).
 //
 // STATUS: the default for H > MMB_LSTM_MAX_H (MMB_LSTM_FS=0: lstm_big.hip's two launches per step).  cfg5 (B=64, H=512):
-// 86.4 ms per region step fp32-accurate (two launches: 92.2), 54.6 ms with bf16 operands (65.3); forward step ~9 us, BPTT
-// step ~16 us, of which ~5 us are the launch-to-launch floor of a dependent chain; what remains beyond that is the
+// ~86 ms per region step fp32-accurate (two launches: 92.2), 49.2 ms with bf16 operands (65.3); forward step ~9 us, BPTT
+// step ~14 us, of which ~5 us are the launch-to-launch floor of a dependent chain; what remains beyond that is the
 // persistent form (W_hh resident, per-step barrier across the workgroups of a chain).
 #include "common.h"
 
