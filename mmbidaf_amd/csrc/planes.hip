@@ -785,7 +785,7 @@ static double planes_choose(const PlanesGemmArgs& g, int& best, int& best_s, int
             const double cost = planes_cost(g, PLANES_CFGS[c], s);
             if (cost < best_cost) { best_cost = cost; best = c; best_s = s; }
         }
-    if (only_cfg < 0 && g_planes_force >= 0 &&
+    if (only_cfg < 0 && g_planes_force >= 0 && !((g_planes_force / 100) % N_PLANES_CFGS == 7 && g.np != 1) &&
         !(g.ta && (PLANES_CFGS[(g_planes_force / 100) % N_PLANES_CFGS].wm * PLANES_CFGS[(g_planes_force / 100) % N_PLANES_CFGS].mt * 16) % 32)) {
         best = (g_planes_force / 100) % N_PLANES_CFGS;
         if (g_planes_force % 100 > 0) best_s = g_planes_force % 100;
