@@ -36,15 +36,9 @@ ALL_KERNELS = ATT_GROUPS + ATT_KERNELS + ["gemm", "lstm_rec_fwd", "lstm_rec_bwd"
 
 
 def source_hash():
-    """sha1 over the kernel sources: stamps PMC traffic files so that bench.py only quotes traffic measured on the
-    very kernels it is timing (the GPU box has no .git to ask for the head)."""
-    import hashlib
-    h = hashlib.sha1()
-    d = os.path.join(ROOT, "mmbidaf_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    """sha1 over the kernel sources = the hash compiled into the loaded library (checked equal at load): stamps the JSON
+    line and the PMC traffic files, so that bench.py only quotes traffic measured on the very kernels it is timing."""
+    return _lib.build_hash()
 
 
 def parse():
@@ -65,7 +59,68 @@ def parse():
                     help="capture one fwd+bwd step of the region into a hipGraph after warm-up and replay it (the C-ABI calls only "
                          "enqueue on the given stream): the host then issues ONE launch per step (N=1, fixed lengths only)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class (perturbs the step time a little)")
+    ap.add_argument("--drop-prob", type=float, default=0.0,
+                    help="train the region with this dropout probability (the reference trains at 0.2, train.py:210): dropped "
+                         "similarity copies in the attentions, inter-layer and output dropout in the encoders")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="NOT a measurement: launcher + rendezvous + flat gradient exchange over gloo on CPU tensors with no hot-path "
+                         "compute at all (the hot path has no CPU form); what tests/ use to drive the --gpus N entry without GPUs")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE): start `python -m torch.distributed.run` with one rank
+    per GPU as a CHILD process and exit with its code.  This process has not touched the GPU (importing torch and
+    counting arguments does not initialise HIP) and never will; rank 0 of the child prints the JSON line on the inherited
+    stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def rehearse_cpu(a):
+    """--rehearse-cpu: every rank fills the flat gradient of a HotRegion-shaped parameter set with rank-dependent values,
+    runs the bucketed exchange K times over gloo and checks the sums.  No kernels, no oracle: plumbing only."""
+    rank, world, _ = ddp.init_from_env(backend="gloo")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    H = synth.CONFIGS[a.config][4]
+    torch.manual_seed(224)
+    region = HotRegion(H)
+    params = list(region.parameters())
+    sync = ddp.FlatGradAllReduce(params, buckets=ddp.region_buckets(region))
+    sync.broadcast_parameters()
+    t0 = time.perf_counter()
+    for k in range(a.warmup + a.steps):
+        if k == a.warmup:
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+        for i, p in enumerate(params):
+            p.grad = torch.full_like(p, float(rank + 1) * (1 + i % 3))
+        sync()
+        for i, p in enumerate(params):
+            want = (1 + i % 3) * world * (world + 1) / 2
+            assert torch.all(p.grad == want), f"rank {rank}: gradient sum {p.grad.flatten()[0].item()} != {want}"
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": "REHEARSAL of the --gpus N entry on CPU/gloo: launcher, rendezvous and gradient exchange only; "
+                                    "no hot-path compute, not a measurement", "value": None, "unit": "samples/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / max(a.steps, 1) * 1e3, 3),
+                          "rehearsal": True, "dist": {"backend": dist.get_backend() if world > 1 else None, "world_size": world,
+                                                      "grad_buckets": len(sync.buckets), "grad_elems": sync.numel}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def cpu_baseline(region, cfg, ragged):
@@ -162,6 +217,10 @@ def attention_roofline(a, prof, B, T, Ma, Mi, D, fused):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))      # before anything touches the GPU
+    if a.rehearse_cpu:
+        return rehearse_cpu(a)
     rank, world, local = ddp.init_from_env()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
@@ -176,7 +235,8 @@ def main():
         B = a.batch
     D = 2 * H
     torch.manual_seed(224)  # the reference's seed (args.py:45): identical replicas on every rank
-    region = HotRegion(H).to(dev)
+    region = HotRegion(H, drop_prob=a.drop_prob).to(dev)
+    region.train(a.drop_prob > 0.0)      # drop_prob 0: train and eval mode are the same graph
     params = list(region.parameters())
     # gradient exchange: SUM over ranks (the reference's loss is a sum over samples), bucketed in backward order and
     # launched from grad hooks so that it overlaps the rest of the backward pass
@@ -264,6 +324,7 @@ def main():
             "value": round(world * B * a.steps / dt, 2), "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "build_hash": source_hash(),
             "arithmetic": ("fp32 in, fp32 out, fp32 accumulation throughout; recurrences on fp32 VALU; every dense contraction (attention "
                            "similarity / context products, LSTM projection and gradient GEMMs) on fp16 MFMA from an error-compensated split of "
                            "the fp32 operands (two fp16 terms of the power-of-two-scaled rows, 3 cross products: max error ~1e-6 of the "
@@ -274,7 +335,9 @@ def main():
                            "attention keeps its fp32-accurate arithmetic"),
             "config": {"workload": f"{a.config}: hot-path region (3 BiLSTM enc -> 2 BiDAF att -> 2 two-layer BiLSTM) "
                                    f"B={B}/GPU T_text={T} T_aud={Ma} T_img={Mi} H={H}, "
-                                   f"{'ragged U{n/2..n}' if a.ragged else 'full'} lengths, fwd+bwd"
+                                   f"{'ragged U{n/2..n}' if a.ragged else 'full'} lengths, "
+                                   f"{'training mode drop_prob=%g (dropped similarity copies, inter-layer + output dropout), ' % a.drop_prob if a.drop_prob > 0 else ''}"
+                                   f"fwd+bwd"
                                    f"{' + bucketed gradient all-reduce (sum)' if world > 1 else ''}",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": attention_roofline(a, prof, B, T, Ma, Mi, D, fused=D <= _lib.ATT_MAX_D) if timed else None,
@@ -287,7 +350,7 @@ def main():
         if a.profile_all:
             out["kernel_ms_per_step"] = {k: round(v[0] / a.steps, 4) for k, v in prof.items()}
             out["kernel_launches_per_step"] = {k: v[1] / a.steps for k, v in prof.items()}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.drop_prob == 0.0:     # (the CPU port is timed on the dropout-free graph)
             out["cpu_baseline"] = cpu_baseline(region, a.config, a.ragged)
         print(json.dumps(out), flush=True)
     if world > 1:

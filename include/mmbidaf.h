@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMB_VERSION 100            /* 0.1.0 */
+#define MMB_VERSION 300            /* round 3 ABI: grouped attention entry points, build hash */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
 #define MMB_ATT_MAX_D 208          /* attention feature width D = 2H of the fused (register-resident) kernels */
 #define MMB_ATT_GENERAL_MAX_D 4096 /* wider D (up to this) runs the general path: similarity matrix in a workspace */
@@ -39,6 +39,8 @@ enum {
 
 int mmb_version(void);
 const char* mmb_last_error(void);
+/* 16 hex digits: sha1 prefix of the kernel sources the binary was compiled from (stamped by mmbidaf_amd/build.py) */
+const char* mmb_build_hash(void);
 
 /* ------------------------------------------------------------------------------------------
  * Opt-in kernel timing (the reference has no tracing at all).  When bit k of

@@ -16,6 +16,8 @@ ATT_GENERAL_MAX_D = 4096     # general path (similarity matrix in a workspace)
 LSTM_MAX_H = 128            # register-resident recurrence (one launch per layer)
 LSTM_GENERAL_MAX_H = 1024   # general recurrence (one launch per time step)
 
+ABI_VERSION = 300           # MMB_VERSION the signatures below were written for (include/mmbidaf.h)
+
 c_f = ctypes.c_void_p  # device pointers travel as raw addresses
 c_i = ctypes.c_int
 
@@ -56,6 +58,7 @@ class DecoderParams(ctypes.Structure):   # mmb_decoder_params
 SIGNATURES = {
     "mmb_version": (c_i, []),
     "mmb_last_error": (ctypes.c_char_p, []),
+    "mmb_build_hash": (ctypes.c_char_p, []),
     "mmb_profile_enable": (c_i, [ctypes.c_uint32]),
     "mmb_profile_read": (c_i, [c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i)]),
     "mmb_kernel_name": (ctypes.c_char_p, [c_i]),
@@ -115,8 +118,21 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.mmb_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} implements C-ABI version {lib.mmb_version()}, the Python host binds version {ABI_VERSION}: "
+                           "stale library -- rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
+    from .build import source_hash
+    built, here = lib.mmb_build_hash().decode(), source_hash()
+    if built != here:
+        raise RuntimeError(f"{LIB_PATH} was compiled from kernel sources with hash {built}, the sources beside it hash to {here}: "
+                           "stale library -- rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
     _lib = lib
     return lib
+
+
+def build_hash():
+    """Hash of the kernel sources the loaded library was compiled from (== build.source_hash(), checked at load)."""
+    return load().mmb_build_hash().decode()
 
 
 def check(rc, what):

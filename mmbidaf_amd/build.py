@@ -1,6 +1,7 @@
 """In-tree build of libmmbidaf_hip.so with hipcc for gfx950 (cross-compiles without a GPU).
 Every translation unit is compiled to its own object (in parallel, rebuilt only when it or a header changed), then
 linked; objects live under mmbidaf_amd/csrc/build/ (git-ignored, like the .so)."""
+import hashlib
 import os
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
@@ -28,8 +29,30 @@ def _newer(path, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash():
+    """sha1 (16 hex digits) over every kernel source and header the library is built from.  It is compiled into the
+    library (mmb_build_hash()); _lib.load() refuses a library whose hash differs from the sources beside it, bench.py
+    prints it and stamps the PMC traffic files with it."""
+    h = hashlib.sha1()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    for f in files + [os.path.normpath(os.path.join(CSRC, HEADERS[1]))]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+HASH_FILE = os.path.join(OBJ, "source_hash.txt")
+
+
+def _built_hash():
+    try:
+        return open(HASH_FILE).read().strip()
+    except OSError:
+        return ""
+
+
 def _stale():
-    return _newer(LIB, [os.path.join(CSRC, s) for s in SOURCES] + _headers())
+    return not os.path.exists(LIB) or _built_hash() != source_hash()
 
 
 def build_library(force=False, verbose=False, jobs=None):
@@ -39,11 +62,14 @@ def build_library(force=False, verbose=False, jobs=None):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
     hdrs = _headers()
+    stamp = source_hash()
     todo = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s + ".o")
-        if force or _newer(obj, [src] + hdrs):
-            todo.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+        # api.hip carries the hash of ALL sources (mmb_build_hash): recompiled whenever any of them changed
+        if force or _newer(obj, [src] + hdrs) or (s == "api.hip" and _built_hash() != stamp):
+            extra = [f'-DMMB_BUILD_HASH="{stamp}"'] if s == "api.hip" else []
+            todo.append([hipcc] + FLAGS + extra + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -53,6 +79,8 @@ def build_library(force=False, verbose=False, jobs=None):
     with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
         list(ex.map(run, todo))
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJ, s + ".o") for s in SOURCES] + ["-o", LIB])
+    with open(HASH_FILE, "w") as f:
+        f.write(stamp + "\n")
     return LIB
 
 

@@ -111,6 +111,12 @@ extern "C" const char* mmb_kernel_name(int kernel_id) {
 }
 
 extern "C" int mmb_version(void) { return MMB_VERSION; }
+#ifndef MMB_BUILD_HASH
+#define MMB_BUILD_HASH "unstamped"
+#endif
+// sha1 prefix of the kernel sources this binary was compiled from (mmbidaf_amd/build.py stamps it): the Python host refuses
+// a library whose hash differs from the sources it sits beside, so a stale prebuilt .so cannot pass for the current code
+extern "C" const char* mmb_build_hash(void) { return MMB_BUILD_HASH; }
 extern "C" const char* mmb_last_error(void) { return mmb::err_buf(); }
 
 // A stream whose kernels may only run on the compute units whose bits are set in `mask` (n_words x 32 bits, HSA queue CU

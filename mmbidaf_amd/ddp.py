@@ -71,12 +71,14 @@ class FlatGradAllReduce:
     buckets: optional list of parameter lists (see region_buckets); default one bucket = one all-reduce.
     overlap=True: every bucket is packed and all-reduced asynchronously the moment backward has produced its last
     gradient (post-accumulate-grad hooks); __call__ then only launches what is still missing, waits and copies back.
-    stream_fn / defer_fn: see __init__ (gradients finished on a side stream).
+    On the GPU the LSTM weight gradients are finished by DEFERRED side-stream work (functional.py, MMB_SIDE_STREAM=2), so a
+    bucket launched from a hook must queue behind that work: defer_fn defaults to functional.defer_grad_work, which is
+    correct in every side-stream mode (it runs the launch at once, behind the current stream, when nothing is deferred).
 
     The reduced values are copied back into the tensors autograd produced (p.grad is never rebound to a view of the
     flat buffer); a parameter without a gradient contributes zeros and keeps grad None."""
 
-    def __init__(self, params, group=None, average=False, buckets=None, overlap=False, stream_fn=None, defer_fn=None):
+    def __init__(self, params, group=None, average=False, buckets=None, overlap=False, defer_fn=None):
         params = [p for p in params if p.requires_grad]
         if buckets is None:
             buckets = [params]
@@ -91,13 +93,14 @@ class FlatGradAllReduce:
         assert len({id(p) for p in self.params}) == len(self.params), "a parameter appears in two buckets"
         self.group = group
         self.average = average
-        # stream_fn(device) -> the stream on which the gradients become final (mmbidaf_amd.functional.side_stream: the
-        # weight-gradient GEMMs run on a side stream): packing + all-reduce are enqueued there, behind them, so that the
-        # main stream is not held up
-        self.stream_fn = stream_fn
         # defer_fn(device, fn): runs fn(stream) on the stream -- and at the moment -- the gradients of the bucket become
         # final (mmbidaf_amd.functional.defer_grad_work: the weight-gradient phase may itself be deferred to run beside the
-        # next layer's recurrence; the bucket's packing + all-reduce are queued right behind it)
+        # next layer's recurrence; the bucket's packing + all-reduce are queued right behind it).  Default on CUDA with
+        # overlap: exactly that function -- a hook that packed p.grad at once would read gradients the side stream has
+        # not written yet.
+        if defer_fn is None and overlap and params[0].is_cuda:
+            from . import functional as _MF
+            defer_fn = _MF.defer_grad_work
         self.defer_fn = defer_fn
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.numel = sum(p.numel() for p in self.params)
@@ -118,6 +121,8 @@ class FlatGradAllReduce:
             for bi, b in enumerate(self.buckets):
                 for p in b:
                     self._hooks.append(p.register_post_accumulate_grad_hook(lambda p_, bi=bi: self._on_grad(bi)))
+                    if self.defer_fn is not None:
+                        p._mmb_deferral_aware = True     # functional._side_safe: these hooks queue behind deferred gradient work
             self._arm()
 
     def _arm(self):
@@ -132,10 +137,6 @@ class FlatGradAllReduce:
         if self.defer_fn is not None and self.flat.is_cuda:
             self.work[bi] = False        # claimed: the launch is queued behind the kernels that fill the bucket
             self.defer_fn(self.flat.device, lambda stream, bi=bi: self._launch_on(bi, stream))
-        elif self.stream_fn is not None and self.flat.is_cuda:
-            s = self.stream_fn(self.flat.device)
-            s.wait_stream(torch.cuda.current_stream(self.flat.device))
-            self._launch_on(bi, s)
         else:
             self._launch_here(bi)
 
@@ -191,3 +192,6 @@ class FlatGradAllReduce:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.params:
+            if hasattr(p, "_mmb_deferral_aware"):
+                del p._mmb_deferral_aware

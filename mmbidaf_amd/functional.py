@@ -374,6 +374,20 @@ def bidaf_attention(text, mod, text_mask, mod_mask, w_t, w_m, w_tm, bias, text_d
 _PER_PROBLEM = 9  # x + (w_ih, w_hh, b_ih, b_hh) x 2 directions
 
 
+def _side_safe(t):
+    """May the gradient of weight input `t` be returned to autograd BEFORE the side stream has written it?  Only when the
+    sole consumer is AccumulateGrad storing the tensor object as `t.grad` (no arithmetic on the main stream):
+      * t is a leaf (a derived weight -- weight norm, a cast or masked master weight -- has a grad_fn whose backward would
+        read the gradient at once),
+      * t.grad is None (otherwise AccumulateGrad adds, on the main stream, right away),
+      * no tensor hooks, and no post-accumulate-grad hooks except the deferral-aware ones of ddp.FlatGradAllReduce.
+    Anything else takes the one-stream order (mmb_bilstm_layer_bwd inline)."""
+    if not t.is_leaf or t.grad is not None or t._backward_hooks:
+        return False
+    post = getattr(t, "_post_accumulate_grad_hooks", None)
+    return not post or getattr(t, "_mmb_deferral_aware", False)
+
+
 class _BiLSTMLayerFn(torch.autograd.Function):
     """One bidirectional LSTM layer for n co-scheduled encoders (reference: nn.LSTM on a packed
     batch, layers/encoding.py:79-81,96; rows L2-L4, L-bwd).  Flat tensor args per problem:
@@ -426,7 +440,9 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         _lib.check(rc, "mmb_bilstm_layer_fwd")
         ctx.n = n
         ctx.hn_pos = list(hn_pos)
-        ctx.params = [t for t in flat if isinstance(t, torch.nn.Parameter)]    # to see whether gradients are being accumulated
+        # weight / bias inputs whose gradients this call produces: the side-stream schedule hands autograd tensors that are
+        # still being written, which is only safe when nothing but AccumulateGrad of a leaf consumes them (see _side_safe)
+        ctx.wparams = [t for k, t in enumerate(flat) if k % _PER_PROBLEM != 0 and ctx.needs_input_grad[2 + k]]
         ctx.need_dx = [bool(ctx.needs_input_grad[2 + i * _PER_PROBLEM]) for i in range(n)]
         ctx.save_for_backward(*saved)
         ctx.prep = None
@@ -451,7 +467,7 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         # storage (AccumulateGrad keeps the tensor it is handed; clip_grad_norm_ / accumulation would hit the pair twice),
         # so b_hh gets views of ONE clone of that buffer
         hs_ = [sv[i * 10 + 5].shape[1] for i in range(n)]
-        side_ok = _USE_SIDE and not torch.is_grad_enabled() and all(p.grad is None for p in ctx.params)
+        side_ok = _USE_SIDE and not torch.is_grad_enabled() and all(_side_safe(p) for p in ctx.wparams)
         prep, flags, prep_todo = ctx.prep, 0, []
         if prep is not None and prep.consumed:      # a second backward through a retained graph: prepare nothing, split inline
             prep = None

@@ -30,9 +30,14 @@ def close(got, ref, name="", tol=TOL):
 
 def test_native_library_is_the_one_loaded():
     from mmbidaf_amd import _lib
-    _lib.load()
+    from mmbidaf_amd.build import source_hash
+    lib = _lib.load()
     maps = open("/proc/self/maps").read()
     assert "libmmbidaf_hip.so" in maps
+    # the mapped binary was compiled from exactly the kernel sources in this tree (a stale prebuilt .so fails here,
+    # and already in _lib.load())
+    assert lib.mmb_build_hash().decode() == source_hash()
+    assert lib.mmb_version() == _lib.ABI_VERSION
 
 
 def test_smoke_entry():
@@ -1054,6 +1059,51 @@ def test_weight_gradients_on_the_side_stream_give_identical_results(monkeypatch,
     assert not any(MF._deferred.values()), "deferred work left behind"
 
 
+def _lstm_leaf_problem(d, as_parameters):
+    torch.manual_seed(11)
+    I, H, B, T = 12, 8, 3, 21
+    mk = (lambda *sh: torch.nn.Parameter(0.3 * torch.randn(*sh, device=d))) if as_parameters else \
+         (lambda *sh: (0.3 * torch.randn(*sh, device=d)).requires_grad_(True))
+    ws = [[mk(4 * H, I), mk(4 * H, H), mk(4 * H), mk(4 * H)] for _ in range(2)]
+    x = torch.randn(B, T, I, device=d, requires_grad=True)
+    lens = torch.tensor([T, 9, 15], dtype=torch.int32, device=d)
+    return x, lens, ws
+
+
+@pytest.mark.parametrize("kind", ["plain_leaf_accumulate", "derived_weight", "tensor_hook"])
+def test_side_stream_schedule_is_only_taken_for_plain_leaf_weights(monkeypatch, kind):
+    """with MMB_SIDE_STREAM=2 the weight gradients are handed to autograd before the side stream has written
+    them, which is only sound when AccumulateGrad of a fresh leaf is the sole consumer.  Weights that are plain
+    requires_grad leaves accumulating over two backward passes, derived (non-leaf) weights and weights with tensor hooks
+    must take the one-stream order and give the gradients of the side-stream-free run."""
+    from mmbidaf_amd import functional as MF
+    d = dev()
+
+    def run(side):
+        monkeypatch.setattr(MF, "_USE_SIDE", side)
+        monkeypatch.setattr(MF, "_SIDE_MODE", 2 if side else 0)
+        x, lens, ws = _lstm_leaf_problem(d, as_parameters=False)
+        seen = []
+        if kind == "derived_weight":
+            use = [[w * 1.5 for w in dirw] for dirw in ws]          # non-leaf: MulBackward consumes the gradient at once
+        else:
+            use = ws
+        if kind == "tensor_hook":
+            ws[0][0].register_hook(lambda g: seen.append(g.abs().sum().item()) or g * 2.0)
+        passes = 2 if kind == "plain_leaf_accumulate" else 1
+        for _ in range(passes):
+            (y, h), = MF.bilstm_layer([(x, lens, use[0], use[1])])
+            ((y * y).sum() + h.sum()).backward()
+        torch.cuda.synchronize()
+        return [w.grad.clone() for dirw in ws for w in dirw] + [x.grad.clone()], seen
+
+    ref, seen0 = run(False)
+    got, seen1 = run(True)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    assert seen0 == seen1
+
+
 def test_second_backward_through_a_retained_graph():
     """retain_graph=True and a second backward: the operand planes prepared for the first pass (and the pre-zeroed split-K
     output) have been consumed; the second pass must redo them and give the same gradients."""
@@ -1156,7 +1206,11 @@ rank, world, local = ddp.init_from_env(backend)
 dev = torch.device("cuda", local)
 torch.manual_seed(224)
 region = HotRegion(16).to(dev)
-sync = ddp.FlatGradAllReduce(list(region.parameters()), buckets=ddp.region_buckets(region), overlap=True, defer_fn=MF.defer_grad_work)
+# argv[3] = "default": overlap=True with DEFAULT arguments must be correct by itself (ADVICE r02: a hook that packed p.grad at
+# once would ship gradients the side stream has not written); "explicit": the wiring bench.py passes
+kw = dict(defer_fn=MF.defer_grad_work) if sys.argv[3] == "explicit" else {}
+sync = ddp.FlatGradAllReduce(list(region.parameters()), buckets=ddp.region_buckets(region), overlap=True, **kw)
+assert sync.defer_fn is MF.defer_grad_work
 sync.broadcast_parameters()
 batch = synth.make_batch((4, 20, 12, 6, 16), rank=0, ragged=True, device=dev)
 lo, hi = ddp.shard_range(4, rank, world)
@@ -1179,13 +1233,13 @@ dist.barrier(); print("rank", rank, "ok")
 """
 
 
-def _run_world2(tmp_path, backend, port, local_ranks, extra_env):
+def _run_world2(tmp_path, backend, port, local_ranks, extra_env, wiring="explicit"):
     import subprocess
     import sys
     script = tmp_path / "w.py"
     script.write_text(_WORLD2_SCRIPT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", **extra_env)
-    procs = [subprocess.Popen([sys.executable, str(script), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), backend],
+    procs = [subprocess.Popen([sys.executable, str(script), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), backend, wiring],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(local_ranks[r])), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
@@ -1201,12 +1255,12 @@ def test_gradient_allreduce_over_rccl_world2(tmp_path):
     _run_world2(tmp_path, "nccl", 29631, [0, 1], {})
 
 
-@pytest.mark.parametrize("mode", ["0", "2"])
-def test_gradient_allreduce_world2_on_one_gpu_gloo(tmp_path, mode):
+@pytest.mark.parametrize("mode,wiring", [("0", "explicit"), ("2", "explicit"), ("2", "default"), ("1", "default")])
+def test_gradient_allreduce_world2_on_one_gpu_gloo(tmp_path, mode, wiring):
     """two ranks on the ONE GPU of the box, `gloo` carrying the exchange: the device side of the N > 1 path (grad hooks ->
     bucket launches queued behind the deferred weight-gradient phase on the side stream -> wait -> copy back) as bench.py
     runs it, against one process on the whole batch."""
-    _run_world2(tmp_path, "gloo", 29633 + int(mode), [0, 0], {"MMB_SIDE_STREAM": mode})
+    _run_world2(tmp_path, "gloo", 29633 + int(mode) + (4 if wiring == "default" else 0), [0, 0], {"MMB_SIDE_STREAM": mode}, wiring)
 
 
 # ------------------------------------------------------------------------------------------- fuzz

@@ -23,10 +23,23 @@ def test_cabi_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/mmbidaf.h but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes binding table out of sync with the header"
-    assert _lib.load().mmb_version() == 100
+    assert _lib.load().mmb_version() == _lib.ABI_VERSION == int(re.search(r"#define MMB_VERSION (\d+)", header).group(1))
     # struct layouts mirror the header (pointer/int counts)
     assert ctypes.sizeof(_lib.LstmFwdDesc) == 8 * 19 + 4 * 4
     assert ctypes.sizeof(_lib.LstmBwdDesc) == 8 * 20 + 4 * 4
+
+
+def test_stale_library_is_refused(tmp_path, monkeypatch):
+    """The library carries the hash of the sources it was compiled from; a binary that does not match the sources beside
+    it (a stale prebuilt .so) must not load."""
+    from mmbidaf_amd import _lib, build
+    assert _lib.build_hash() == build.source_hash()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "source_hash", lambda: "0123456789abcdef")
+    with pytest.raises(RuntimeError, match="stale library"):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load() is not None
 
 
 def test_product_never_imports_the_oracle():
@@ -214,3 +227,21 @@ def test_deferred_work_of_a_dead_backward_pass_is_dropped():
     MF._join_pending.add((0, 7))
     MF._drop_stale_deferred(0)            # called from a forward outside any backward pass
     assert MF._deferred[0] == [] and not MF._join_pending and not ran
+
+
+def test_bench_gpus2_entry_self_launches_over_gloo():
+    """`python bench.py --gpus 2` from a bare shell (no WORLD_SIZE) must start its own torch.distributed.run child, one
+    rank per GPU, relay rank 0's JSON line and exit with the child's code.  Driven here through the
+    CPU rehearsal mode (gloo, no hot-path compute: the hot path has no CPU form)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-cpu", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rehearsal"] is True and out["dist"]["world_size"] == 2 and out["dist"]["backend"] == "gloo"
+    # a failing rank must surface as a non-zero exit code of the parent
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-cpu", "--config", "nope"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0

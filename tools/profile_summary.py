@@ -126,13 +126,9 @@ def pmc(d, cfg="cfg2"):
         old = json.load(open(path)) if os.path.exists(path) else {}
         # the file is stamped with a hash of the kernel sources it was measured on (bench.py quotes it only when that
         # matches the sources it is running): measurements of other sources are dropped
-        import hashlib
-        h = hashlib.sha1()
-        d = os.path.join(root, "mmbidaf_amd", "csrc")
-        for f in sorted(os.listdir(d)):
-            if f.endswith((".hip", ".h")):
-                h.update(open(os.path.join(d, f), "rb").read())
-        stamp = h.hexdigest()[:16]
+        sys.path.insert(0, root)
+        from mmbidaf_amd.build import source_hash      # the hash compiled into the library (mmb_build_hash)
+        stamp = source_hash()
         if old.get("source_hash") != stamp:
             old = {"source_hash": stamp}
         parts = old.setdefault(cfg, {}).setdefault("_parts", {})
