@@ -28,8 +28,8 @@ from mmbidaf_amd.hot_region import HotRegion
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F16_MFMA_PEAK_TF = 2500.0    # dense fp16/bf16 MFMA peak (the fused attention issues 3 fp16 MFMAs per fp32-accurate product)
-ATT_FWD_KERNELS = ["att_rank1", "att_col", "att_combine", "att_row"]
-ATT_BWD_KERNELS = ["att_bwd_pre", "att_bwd_j1", "att_bwd_j2", "att_bwd_jfin", "att_bwd_i"]
+ATT_FWD_KERNELS = ["att_rank1", "att_col", "att_row"]                 # split pass, column pass, row pass (one grouped launch each)
+ATT_BWD_KERNELS = ["att_bwd_pre", "att_bwd_j1", "att_bwd_i"]           # prologue, dq sweep, gradient sweeps (j + i in one launch)
 ATT_KERNELS = ATT_FWD_KERNELS + ATT_BWD_KERNELS
 ATT_GROUPS = ["att_fwd", "att_bwd"]      # one event pair around ALL kernels of a fused forward / backward call
 ALL_KERNELS = ATT_GROUPS + ATT_KERNELS + ["gemm", "lstm_rec_fwd", "lstm_rec_bwd"]
@@ -163,7 +163,7 @@ def cpu_baseline(region, cfg, ragged):
 
 def attention_roofline(a, prof, B, T, Ma, Mi, D, fused):
     """roofline.achieved = algorithmic bytes / kernel time / HBM peak for the fused BiDAF attention, forward
-    and backward of BOTH attentions of a step (nine kernels each); algorithmic bytes fwd 4B(5TD+MD), bwd 4B(6TD+2MD).
+    and backward of BOTH attentions of a step (six grouped launches); algorithmic bytes fwd 4B(5TD+MD), bwd 4B(6TD+2MD).
     Times are HIP events recorded by the library around every launch on the launch stream, over the timed region."""
     if not fused:
         return None       # D > 208 runs the general-width kernels (bidaf_big.hip: batched GEMMs + softmax kernels)
@@ -177,13 +177,13 @@ def attention_roofline(a, prof, B, T, Ma, Mi, D, fused):
     per = None
     if all(k in prof for k in ATT_KERNELS):      # --profile-all: every kernel bracketed on its own as well
         per = {k: (prof[k][0] / steps * 1e3, prof[k][1] / steps, prof[k][2]) for k in ATT_KERNELS}   # us per step, launches per step, symbol
-    # matrix-core work of the fused kernels: S-type and PV-type products at the padded sizes (7 k tiles / 13 feature
-    # tiles), 3 fp16 MFMAs per product, per (16 lane rows x 32 streamed rows): col 81, row 2 x 81 (two waves per SIMD, both
-    # compute S), j1 243, j2 123, i 246 MFMAs of 16x16x32
-    units = lambda M: B * ((M + 15) // 16) * ((T + 31) // 32) * (81 + 243 + 123) + B * ((T + 15) // 16) * ((M + 31) // 32) * (162 + 246)
+    # matrix-core work of the fused kernels: S-type (42) and PV-type (39) products at the padded sizes (7 k tiles / 13
+    # feature tiles, 3 fp16 MFMAs per product), per (16 lane rows x 32 streamed rows): column pass 81, row pass 120,
+    # dq sweep 81, j sweep 246, i sweep 246 MFMAs of 16x16x32 -- no product is computed twice
+    units = lambda M: B * ((M + 15) // 16) * ((T + 31) // 32) * (81 + 81 + 246) + B * ((T + 15) // 16) * ((M + 31) // 32) * (120 + 246)
     flops = sum(units(M) for M in (Ma, Mi)) * 2 * 16 * 16 * 32
-    sym_launches = {"att_prep_kernel": 2, "att_col_kernel": 2, "att_combine_kernel": 2, "att_row8_kernel": 2, "att_bwd_pre_kernel": 2,
-                    "att_bwd_j1_kernel": 2, "att_bwd_j2_kernel": 2, "att_bwd_jfin_kernel": 2, "att_bwd_i_kernel": 2}   # launches per step
+    sym_launches = {"att_prep_kernel": 1, "att_col_kernel": 1, "att_row_kernel": 1, "att_bwd_pre_kernel": 1,
+                    "att_bwd_dq_kernel": 1, "att_bwd_sweep_kernel": 1}   # launches per step: both attentions share every launch
     traffic, traffic_note = None, "no PMC file stamped with these kernel sources"
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
@@ -191,11 +191,12 @@ def attention_roofline(a, prof, B, T, Ma, Mi, D, fused):
             t = json.load(open(tpath))
             if t.get("source_hash") == source_hash() and a.config in t:
                 traffic = sum(t[a.config].get(sym, 0.0) * n for sym, n in sym_launches.items())
-                traffic_note = "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per step over the nine kernels, separate rocprofv3 --pmc passes of this command (tools/run_round_profiles.sh)"
+                traffic_note = "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per step over the six kernels, separate rocprofv3 --pmc passes of this command (tools/run_round_profiles.sh)"
         except Exception:
             pass
-    out = {"bound": "hbm", "kernel": "fused BiDAF attention, forward + backward of both attentions (9 kernels each; one HIP-event "
-                                     "pair around each fused forward / backward call, launch gaps included)",
+    out = {"bound": "hbm", "kernel": "fused BiDAF attention, forward + backward of both attentions (6 grouped launches per step: split, "
+                                     "column, row pass; prologue, dq sweep, gradient sweeps; one HIP-event pair around the grouped "
+                                     "forward / backward call, launch gaps included)",
            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
            "traffic": traffic, "traffic_note": traffic_note,
            "algorithmic_bytes_per_step": int(fwd_b + bwd_b), "us_per_step": round(tot_us, 1),
@@ -211,7 +212,7 @@ def attention_roofline(a, prof, B, T, Ma, Mi, D, fused):
         out["slowest_kernel"] = {"name": per[slow][2], "us_per_step": round(per[slow][0], 1), "launches_per_step": per[slow][1]}
         out["kernel_us_per_launch"] = {per[k][2]: round(per[k][0] / max(per[k][1], 1), 2) for k in ATT_KERNELS}
     else:
-        out["slowest_kernel"] = {"name": "att_bwd_i_kernel", "note": "per-kernel times: bench.py --profile-all, or profiles/r02_kernel_stats.md"}
+        out["slowest_kernel"] = {"name": "att_bwd_sweep_kernel", "note": "per-kernel times: bench.py --profile-all, or profiles/r03_kernel_stats.md"}
     return out
 
 

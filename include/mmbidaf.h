@@ -49,6 +49,7 @@ const char* mmb_build_hash(void);
  * after synchronising the stream.  Disabled (mask 0) by default: no events, no overhead.
  */
 enum {
+    /* attention: split pass, column pass, (unused), row pass; backward prologue, dq sweep, (unused), (unused), gradient sweeps */
     MMB_K_ATT_RANK1 = 0, MMB_K_ATT_COL, MMB_K_ATT_COMBINE, MMB_K_ATT_ROW,
     MMB_K_ATT_BWD_PRE, MMB_K_ATT_BWD_J1, MMB_K_ATT_BWD_J2, MMB_K_ATT_BWD_JFIN, MMB_K_ATT_BWD_I,
     MMB_K_GEMM, MMB_K_LSTM_REC_FWD, MMB_K_LSTM_REC_BWD, MMB_K_SPLIT,
@@ -83,7 +84,7 @@ const char* mmb_kernel_name(int kernel_id);   /* device-side symbol stem, as roc
  *   and may be NULL.  The general-width path takes u8 masks only.
  * D must be a multiple of 4.  D <= MMB_ATT_MAX_D runs the fused kernels; wider D (up to MMB_ATT_GENERAL_MAX_D)
  * materialises the (B,T,M) similarity matrix in `workspace`.  Both paths need mmb_bidaf_fwd_workspace_bytes(B,T,M,D)
- * bytes of scratch (fused: the per-split partial column softmaxes).
+ * bytes of scratch (fused: nothing is kept outside the saved buffer, a token 256 bytes).
  */
 size_t mmb_bidaf_saved_bytes(int B, int T, int M, int D, int has_drop);
 
@@ -101,6 +102,34 @@ int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t* text_mask,
                   float* row_stat, float* col_stat, void* saved, size_t saved_bytes,
                   float* workspace, size_t workspace_bytes,
                   int B, int T, int M, int D, int device, void* stream);
+
+/*
+ * Grouped form: up to 4 attentions in ONE call with ONE launch per stage (the model's text<->audio and text<->image
+ * pair, reference models.py:131-132, which share their text operand).  All attentions of a call have the same B and D
+ * and are all in training mode (text_d / mod_d given) or all in eval mode; attentions whose `text` pointers and T are
+ * equal share one set of text operand planes (made once; it lives in the FIRST such attention's `saved` buffer, so a
+ * backward call must present the same group).  Field meanings as in mmb_bidaf_fwd / mmb_bidaf_bwd; the backward-only
+ * fields are ignored by the forward call, `bias` by the backward call; `workspace` is the forward scratch in a forward
+ * call and the backward scratch in a backward call.
+ */
+typedef struct {
+    const float *text, *mod;
+    const uint8_t *text_mask, *mod_mask;
+    const int32_t *text_len, *mod_len;
+    const float *text_d, *mod_d;
+    const float *w_t, *w_m, *w_tm, *bias;
+    float *out, *bsave, *rterm, *cterm, *row_stat, *col_stat;
+    void* saved;
+    size_t saved_bytes;
+    float* workspace;
+    size_t workspace_bytes;
+    /* backward */
+    const float* d_out;
+    float *d_text, *d_mod, *d_text_d, *d_mod_d, *d_w_t, *d_w_m, *d_w_tm, *d_bias;
+    int32_t T, M;
+} mmb_bidaf_desc;
+int mmb_bidaf_group_fwd(const mmb_bidaf_desc* d, int n, int B, int D, int device, void* stream);
+int mmb_bidaf_group_bwd(const mmb_bidaf_desc* d, int n, int B, int D, int device, void* stream);
 
 /* bytes of scratch mmb_bidaf_bwd needs (contents undefined on entry) */
 size_t mmb_bidaf_bwd_workspace_bytes(int B, int T, int M, int D);

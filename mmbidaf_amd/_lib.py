@@ -44,6 +44,18 @@ class LstmBwdDesc(ctypes.Structure):
     ]
 
 
+class BidafDesc(ctypes.Structure):
+    """mmb_bidaf_desc: one attention of a grouped call"""
+    _fields_ = [(n, c_f) for n in ("text", "mod", "text_mask", "mod_mask", "text_len", "mod_len", "text_d", "mod_d",
+                                   "w_t", "w_m", "w_tm", "bias", "out", "bsave", "rterm", "cterm", "row_stat", "col_stat",
+                                   "saved")] + [("saved_bytes", ctypes.c_size_t), ("workspace", c_f),
+                                                ("workspace_bytes", ctypes.c_size_t)] + \
+               [(n, c_f) for n in ("d_out", "d_text", "d_mod", "d_text_d", "d_mod_d", "d_w_t", "d_w_m", "d_w_tm", "d_bias")] + \
+               [("T", ctypes.c_int32), ("M", ctypes.c_int32)]
+
+
+MAX_ATT_GROUP = 4
+
 DECODER_PTRS = ["W2", "b2", "W4", "b4", "wc1", "bc1", "v1", "bv1", "wc2", "bc2", "v2", "bv2",
                 "Wb1", "bb1", "Wb2", "bb2", "Wb3", "bb3", "Wb4", "bb4", "vb1", "bvb1", "vb2", "bvb2",
                 "W_ih", "W_hh", "b_ih", "b_hh", "W_out", "b_out"]
@@ -68,6 +80,8 @@ SIGNATURES = {
     "mmb_bidaf_fwd": (c_i, [c_f] * 19 + [ctypes.c_size_t, c_f, ctypes.c_size_t] + [c_i] * 5 + [c_f]),
     "mmb_bidaf_bwd_workspace_bytes": (ctypes.c_size_t, [c_i] * 4),
     "mmb_bidaf_bwd": (c_i, [c_f] * 28 + [ctypes.c_size_t] + [c_i] * 5 + [c_f]),
+    "mmb_bidaf_group_fwd": (c_i, [ctypes.POINTER(BidafDesc), c_i, c_i, c_i, c_i, c_f]),
+    "mmb_bidaf_group_bwd": (c_i, [ctypes.POINTER(BidafDesc), c_i, c_i, c_i, c_i, c_f]),
     "mmb_bilstm_layer_fwd": (c_i, [ctypes.POINTER(LstmFwdDesc), c_i, c_i, c_f]),
     "mmb_bilstm_layer_bwd": (c_i, [ctypes.POINTER(LstmBwdDesc), c_i, c_i, c_f]),
     "mmb_bilstm_layer_bwd_phase": (c_i, [ctypes.POINTER(LstmBwdDesc), c_i, c_i, c_i, c_f]),

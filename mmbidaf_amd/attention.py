@@ -42,6 +42,21 @@ class BiDAFAttention(nn.Module):
                                   self.modality_weight, self.text_modality_weight, self.bias,
                                   text_d=text_d, mod_d=mod_d)
 
+    @staticmethod
+    def forward_group(modules, texts, modalities, text_masks, modality_masks):
+        """Several independent BiDAFAttention modules (the model's text<->audio / text<->image pair, reference
+        models.py:131-132) in ONE grouped library call: one launch per stage, text planes shared when the text tensor is."""
+        import torch.nn.modules.module as _M
+        hooked = any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks for m in modules) or \
+            _M._global_forward_hooks or _M._global_forward_pre_hooks or _M._global_backward_hooks
+        if hooked:       # module hooks only fire through Module.__call__: keep nn.Module semantics, one call per module
+            return [m(t, x, tm, mm) for m, t, x, tm, mm in zip(modules, texts, modalities, text_masks, modality_masks)]
+        problems = []
+        for m, text, mod, tm, mm in zip(modules, texts, modalities, text_masks, modality_masks):
+            text_d, mod_d = m._dropped(text, mod)
+            problems.append((text, mod, tm, mm, m.text_weight, m.modality_weight, m.text_modality_weight, m.bias, text_d, mod_d))
+        return MF.bidaf_attention_group(problems)
+
     def get_similarity_matrix(self, text, modality):
         """(B,T,M) trilinear similarity (reference attention.py:56-75).  Kept for API parity; the
         fused forward never materialises it, so this is plain tensor algebra on whatever device

@@ -104,9 +104,9 @@ extern "C" int mmb_profile_read(int kernel_id, double* total_ms, int* launches) 
 
 extern "C" const char* mmb_kernel_name(int kernel_id) {
     static const char* names[MMB_K_COUNT] = {
-        "att_prep_kernel", "att_col_kernel", "att_combine_kernel", "att_row8_kernel",
-        "att_bwd_pre_kernel", "att_bwd_j1_kernel", "att_bwd_j2_kernel", "att_bwd_jfin_kernel", "att_bwd_i_kernel",
-        "gemm_kernel", "lstm_rec_fwd_kernel", "lstm_rec_bwd_kernel", "split_", "att_fwd(prep+col+combine+row8)", "att_bwd(pre+j1+j2+jfin+i)"};
+        "att_prep_kernel", "att_col_kernel", "(unused)", "att_row_kernel",
+        "att_bwd_pre_kernel", "att_bwd_dq_kernel", "(unused)", "(unused)", "att_bwd_sweep_kernel",
+        "gemm_kernel", "lstm_rec_fwd_kernel", "lstm_rec_bwd_kernel", "split_", "att_fwd(prep+col+row)", "att_bwd(pre+dq+sweep)"};
     return (kernel_id >= 0 && kernel_id < MMB_K_COUNT) ? names[kernel_id] : "";
 }
 

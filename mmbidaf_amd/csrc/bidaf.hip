@@ -39,6 +39,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace mmb {
@@ -423,20 +425,108 @@ __device__ __forceinline__ bool mask_live(const uint8_t* mask, const int* len, i
     return len ? (m < len[b]) : (mask[(size_t)b * R + m] != 0);
 }
 
-// ------------------------------------------------------------------------------------------ split passes
-// One wave per row, lane = 4 features (coalesced 16 B per lane).  Up to 4 tensors per launch (blockIdx.y).  Also the rank-1 terms of the similarity: term[b,row] = src[b,row] . w + bias.
+// ------------------------------------------------------------------------------------------ grouped launches
+// One call handles up to MAXG attentions (the model's text<->audio and text<->image pair, models.py:131-132) with ONE
+// launch per stage: the kernels take a table of per-attention pointers and decode (attention, tile, sample) from the block
+// index.  Every attention's block range starts at a multiple of 8, so "blocks of one sample share id % 8" (one XCD's L2
+// serves their panels) holds inside each range.
+constexpr int MAXG = 4;
+struct AttG {
+    const float *text, *mod, *text_d, *mod_d;       // (B,T,D) / (B,M,D); text_d / mod_d = text / mod without dropout
+    const uint8_t *text_mask, *mod_mask;            // (B,T) / (B,M) or null with the lengths
+    const int *text_len, *mod_len;                  // (B) or null
+    const float *w_t, *w_m, *w_tm, *bias;
+    float *out, *bsave, *rterm, *cterm, *row_stat, *col_stat;
+    // operand planes + inverse row scales: text, dropped text, mod, dropped mod, mod_d * w_tm (eval mode only), q
+    char *pT, *pTd, *pM, *pMd, *pMw, *pQ;
+    float *iT, *iTd, *iM, *iMd, *iMw, *iQ;
+    // backward
+    const float* d_out;
+    float *d_text, *d_mod, *d_text_d, *d_mod_d, *d_w_t, *d_w_m, *d_w_tm, *d_bias;
+    char *pDa, *pDb, *pDq;
+    float *iDa, *iDb, *iDq, *delta1, *delta2;
+    int T, M;
+};
+struct GroupArgs {
+    AttG g[MAXG];
+    int n, B, D, dbg;
+};
+struct BlkMap {
+    int begin[MAXG + 1];   // block range of attention k: [begin[k], begin[k+1]), begins are multiples of 8
+};
+
+__device__ __forceinline__ int find_att(const BlkMap& bm, int n, int id, int& local) {
+    int k = 0;
+    for (int i = 1; i < n; ++i)
+        if (id >= bm.begin[i]) k = i;
+    local = id - bm.begin[k];
+    return k;
+}
+// local block id -> (tile, sample); false for the padding blocks of a range
+__device__ __forceinline__ bool decode_local(int id, int tiles, int B, int& tile, int& b) {
+    if (B % 8 == 0) {
+        b = (id & 7) + 8 * ((id >> 3) % (B / 8));
+        tile = (id >> 3) / (B / 8);
+    } else {
+        b = id % B;
+        tile = id / B;
+    }
+    return tile < tiles;
+}
+
+// stage one 32-row panel with all NWV waves of the workgroup (28 LDS-DMA pieces of 1 KiB)
+template <int NWV>
+__device__ __forceinline__ void stage_panel_w(char* panel, const char* planes_b, int p0, int wave, int lane) {
+    const char* src = planes_b + (size_t)(p0 >> 4) * PRB + lane * 16;
+#pragma unroll
+    for (int k = 0; k < (28 + NWV - 1) / NWV; ++k) {
+        const int piece = wave + NWV * k;
+        if (piece < 28)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                             (__attribute__((address_space(3))) void*)(panel + piece * 1024), 16, 0, 0);
+    }
+}
+
+// workgroup-wide maxima of NV_ non-negative per-thread values over NWV waves (red: >= NV_ * NWV floats of LDS)
+template <int NV_, int NWV>
+__device__ __forceinline__ void wg_allmax_w(float (&v)[NV_], float* red, int tid) {
+#pragma unroll
+    for (int k = 0; k < NV_; ++k) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v[k] = fmaxf(v[k], __shfl_xor(v[k], o));
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NV_; ++k) red[(tid >> 6) * NV_ + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV_; ++k) {
+        float m = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) m = fmaxf(m, red[w * NV_ + k]);
+        v[k] = m;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------ split pass (forward)
+// One wave per row, lane = 4 features (coalesced 16 B per lane); blockIdx.y = source.  Writes the operand planes + inverse
+// row scale of src (optionally scaled feature-wise by `mul`) and up to two rank-1 terms term_k[b,row] = src[b,row] . w_k +
+// bias_k (two attentions that share their text read it once: one plane set, one rterm each).
 struct SplitSrc {
     const float* src;     // (B,R,D)
-    char* planes;         // B x planes_sample_bytes(R)
+    char* planes;         // B x planes_sample_bytes(R), or null (terms only)
     float* inv;           // (B, pad32(R)) inverse row scales, 0 for all-zero and padding rows
-    const float* w;       // (D) or null: rank-1 weight of `term`
-    const float* bias;    // (1) or null
-    float* term;          // (B,R) or null
-    const float* mul;     // (D) or null: the planes hold src * mul feature-wise (the w_tm-folded lane-side operands)
+    const float* mul;     // (D) or null
+    const float* w[2];    // (D) or null
+    const float* bias[2]; // (1) or null
+    float* term[2];       // (B,R) or null
     int R;
 };
 struct PrepArgs {
-    SplitSrc t[6];
+    SplitSrc t[12];
     int n, D, B;
 };
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -469,25 +559,34 @@ __device__ __forceinline__ void store_split_row(char* planes_b, float* inv_row, 
     }
     if (c == 0) *inv_row = amax > 0.f ? 1.0f / s : 0.f;
 }
-// One wave per row (fully coalesced 16 B per lane), 4 rows per workgroup; blockIdx.y = tensor
+// fp32 value of features 4c..4c+3 of a planes row: x = (h0 + h1) * inv
+__device__ __forceinline__ f4 planes_row_f32(const char* planes_b, const float* inv_b, int row, int c) {
+    const char* d = planes_b + pl_off_att(row, c >> 1) + (c & 1) * 8;
+    const half4 h0 = *reinterpret_cast<const half4*>(d), h1 = *reinterpret_cast<const half4*>(d + 1024);
+    const float iv = inv_b[row];
+    return f4{((float)h0[0] + (float)h1[0]) * iv, ((float)h0[1] + (float)h1[1]) * iv, ((float)h0[2] + (float)h1[2]) * iv,
+              ((float)h0[3] + (float)h1[3]) * iv};
+}
 __global__ __launch_bounds__(256) void att_prep_kernel(const PrepArgs a) {
-    const SplitSrc s = a.t[blockIdx.y];
+    const SplitSrc& s = a.t[blockIdx.y];
     const int Rp = pad32(s.R);
     const long rowi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rowi >= (long)a.B * Rp) return;
     const int b = rowi / Rp, row = rowi - (long)b * Rp, c = threadIdx.x & 63, d = 4 * c;
     f4 x = f4{0.f, 0.f, 0.f, 0.f};
-    float dot = 0.f;
-    if (row < s.R && d < a.D) {
-        x = *reinterpret_cast<const f4*>(s.src + ((size_t)b * s.R + row) * a.D + d);
-        if (s.w) dot = f4sum(x * *reinterpret_cast<const f4*>(s.w + d));
-        if (s.mul) x = x * *reinterpret_cast<const f4*>(s.mul + d);
+    const bool in = row < s.R && d < a.D;
+    if (in) x = *reinterpret_cast<const f4*>(s.src + ((size_t)b * s.R + row) * a.D + d);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (s.term[k]) {
+            float dot = in ? f4sum(x * *reinterpret_cast<const f4*>(s.w[k] + d)) : 0.f;
+            dot = wave_allsum(dot);
+            if (c == 0 && row < s.R) s.term[k][(size_t)b * s.R + row] = dot + (s.bias[k] ? s.bias[k][0] : 0.f);
+        }
     }
+    if (!s.planes) return;
+    if (in && s.mul) x = x * *reinterpret_cast<const f4*>(s.mul + d);
     const float amax = wave_allmax(f4amax(x));
-    if (s.term) {
-        dot = wave_allsum(dot);
-        if (c == 0 && row < s.R) s.term[(size_t)b * s.R + row] = dot + (s.bias ? s.bias[0] : 0.f);
-    }
     store_split_row(s.planes + (size_t)b * planes_sample_bytes(s.R), s.inv + (size_t)b * Rp + row, row, c, x, amax);
 }
 
@@ -511,140 +610,347 @@ __global__ __launch_bounds__(256) void att_rank1_kernel(const float* __restrict_
     }
 }
 
-// ------------------------------------------------------------------------------------------ forward
-struct AttFwdArgs {
-    const char* side_p;     // planes of the lane-side S operand (dropped copy * w_tm)   + inverse scales (B, pad32(N))
-    const float* side_i;
-    const char* mS;         // planes of the streamed S operand (dropped copy)      + inverse scales (B, pad32(R))
-    const float* iS;
-    const char* mV0;        // planes of the first value tensor (== mS without dropout)
-    const float* iV0;
-    const char* mV1;        // planes of the second value tensor (row pass only)
-    const float* iV1;
-    const uint8_t* m_mask;  // (B,R) or null when m_len is given
-    const int* m_len;       // (B) prefix lengths or null
-    const float* m_term;    // (B,R)
-    const float* n_term;    // (B,N)
-    float* stat;            // (B,N,2) {max,sum}                     (row pass)
-    float* part_o;          // (B,splits,N,D) unnormalised partials  (col pass)
-    float* part_stat;       // (B,splits,N,2)
-    const float* text;      // (B,N,D)                               (row pass epilogue)
-    float* out;             // (B,N,4D)
-    float* bsave;           // (B,N,D)
-    int N, R, D, B, splits, rows_per_split;
-    int nstage;             // LDS stages of the panel loop (1 or 2)
-    int dbg;
-};
+// ------------------------------------------------------------------------------------------ light sweeps
+// Column pass (forward: q = P2^T text) and the dq sweep of the backward (dq = P1^T db): lane side = 64 modality rows of one
+// sample (mod_d * w_tm, split in registers from fp32), streamed side = ALL text rows of the sample -- no split of T over
+// workgroups, hence no partial results in HBM and no combine pass.  8 waves = two per SIMD: waves w and w + 4 own the SAME
+// 16 lane rows and take alternate 32-row panels (group = wave >> 2), so every panel is computed once; the two groups'
+// accumulators meet in LDS at the end (online-softmax merge / plain sum).  An iteration stages the two panels of a 64-row
+// stretch for both groups; two LDS stages when they fit (one tensor streamed), else one.
+// Per-row scalars of the streamed rows are fetched one iteration ahead (one value per thread) and parked in LDS, so LDS
+// use does not grow with the sequence length.
+constexpr int NT8 = 512;
 
-// NV = 1: column pass = att_col_kernel (lane side = modality rows j, streams text rows i), produces the partials of q.
-// NV = 2: row pass = att_row_kernel    (lane side = text rows i, streams modality rows j with values [mod | q]), produces out.
-template <int NV, bool DBG>
-__device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
-    const int dbg = DBG ? a.dbg : 0;   // timing-only ablations are compiled into their own kernel instances
+// KIND 0: column pass.  KIND 1: dq sweep.
+template <int KIND, bool DBG>
+__device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap& bm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dbg = DBG ? a.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
     const int r = lane & 15, g = lane >> 4;
-    const int N = a.N, R = a.R, D = a.D, Rp = pad32(R);
-    int tile, split, b;
-    decode_block((N + 16 * NW - 1) / (16 * NW), a.splits, a.B, tile, split, b);
-    const int n = (tile * NW + wave) * 16 + r;
-    const int rps = a.rows_per_split;
+    int local;
+    const AttG& A = a.g[find_att(bm, a.n, blockIdx.x, local)];
+    const int N = A.M, R = A.T, D = a.D, Rp = pad32(R), Np = pad32(N);
+    int tile, b;
+    if (!decode_local(local, (N + 63) / 64, a.B, tile, b)) return;
+    const int n = (tile * 4 + w4) * 16 + r;
+    const bool wave_on = (tile * 4 + w4) * 16 < N;
 
-    const bool sep_s = a.mS != a.mV0;  // dropped copy differs from the clean value panel
-    // LDS: nstage stages of [V0 | V1 (NV == 2) | S (dropped copy)] panels, then the per-row scalars of the WHOLE split
-    const int npan = NV + (sep_s ? 1 : 0);
-    const int stage_b = npan * PANEL_B;
-    const bool db = a.nstage == 2;     // two stages: the LDS-DMA of panel p+1 is in flight under the MFMAs of panel p
-    float* mterm_all = reinterpret_cast<float*>(smem + a.nstage * stage_b);
-    int* mcode_all = reinterpret_cast<int*>(mterm_all + rps);
-    float* sS_all = mterm_all + 2 * rps;              // inverse row scale of the S operand
-    float* sV0_all = mterm_all + 3 * rps;             // inverse row scale of V0 times c0
-    float* sV1_all = mterm_all + 4 * rps;
-    float* red = mterm_all + 5 * rps;
-
+    // streamed tensors: V (value of the PV product) and S (operand of the similarity)
+    //   column pass: V = text planes, S = dropped text planes (the same panel without dropout)
+    //   dq sweep:    V = db planes,   S = dropped text planes
     const size_t szR = planes_sample_bytes(R);
-    const char* mS_b = a.mS + (size_t)b * szR;
-    const char* mV0_b = a.mV0 + (size_t)b * szR;
-    const char* mV1_b = NV == 2 ? a.mV1 + (size_t)b * szR : nullptr;
+    const char* pV_b = (KIND == 0 ? A.pT : A.pDb) + (size_t)b * szR;
+    const char* pS_b = A.pTd + (size_t)b * szR;
+    const float* iV_b = (KIND == 0 ? A.iT : A.iDb) + (size_t)b * Rp;
+    const float* iS_b = A.iTd + (size_t)b * Rp;
+    const bool sep_s = KIND == 1 || A.pTd != A.pT;
+    const int npan = sep_s ? 2 : 1;
+    const int stage_b = 2 * npan * PANEL_B;               // both groups' panels of one iteration
+    const bool db = !sep_s;                               // two stages fit only with one streamed tensor
+    constexpr int NSC = KIND == 0 ? 4 : 5;
+    float* sc = reinterpret_cast<float*>(smem + (db ? 2 : 1) * stage_b);   // [2 buffers][NSC][64]
+    float* red = sc + 2 * NSC * 64;
 
     side_t side;
     float inv_n;
-    load_side_planes(side, inv_n, a.side_p + (size_t)b * planes_sample_bytes(N), a.side_i + (size_t)b * pad32(N), n, N, g);
-    const float nterm = n < N ? a.n_term[(size_t)b * N + n] : 0.f;
+    load_side_f32(side, inv_n, A.mod_d + (size_t)b * N * D, n, N, D, g, A.w_tm);
+    const bool nin = n < N;
+    const float nterm = nin ? A.cterm[(size_t)b * N + n] : 0.f;
+    const bool mm = nin ? mask_live(A.mod_mask, A.mod_len, b, N, n) : false;
     const tr_off tr = make_tr_off(lane);
 
-    // row pass: the workgroup's 64 text rows, one row per wave-instruction (lane = 16-B chunk), are read ONCE into
-    // registers (16 independent loads in flight), copied out at once as the first quarter of `out` (a verbatim copy of
-    // text, attention.py:52 -- these stores overlap the main loop) and kept for the epilogue's text*a, text*b
-    f4 trow[16];
-    if (NV == 2) {
-        const float* tx = a.text + (size_t)b * N * D;
-        float* oo = a.out + (size_t)b * N * 4 * D;
-        const bool cin = 4 * lane < D;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int gn = tile * NW * 16 + wave + NW * k;
-            trow[k] = (gn < N && cin) ? *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * lane) : f4{0.f, 0.f, 0.f, 0.f};
+    // c: power of two mapping the largest inverse scale of the value rows to 2^14
+    float im[1] = {0.f};
+    for (int i = tid; i < R; i += NT8) im[0] = fmaxf(im[0], iV_b[i]);
+    wg_allmax_w<1, 8>(im, red, tid);
+    const float cV = cmap(im[0]);
+
+    // per-row scalars of streamed row m (fetched by thread (k = tid >> 6, rr = tid & 63) for row 64 it + rr)
+    const int sck = tid >> 6, scr = tid & 63;
+    auto fetch = [&](int m) -> float {
+        const bool in = m < R;
+        const size_t bm_ = (size_t)b * R + m;
+        if (KIND == 0) {
+            switch (sck) {
+                case 0: return in ? A.rterm[bm_] : 0.f;
+                case 1: return (float)mask_code(in, A.text_mask, A.text_len, b, R, m);
+                case 2: return in ? iS_b[m] : 0.f;
+                default: return in ? iV_b[m] * cV : 0.f;
+            }
+        } else {
+            switch (sck) {
+                case 0: return in ? A.rterm[bm_] : 0.f;
+                case 1: return in ? A.row_stat[bm_ * 2] : INFINITY;          // exp(x - inf) = 0 beyond the range
+                case 2: return in ? 1.0f / A.row_stat[bm_ * 2 + 1] : 0.f;
+                case 3: return in ? iS_b[m] : 0.f;
+                default: return in ? iV_b[m] * cV : 0.f;
+            }
         }
+    };
+    float sc_next = 0.f;
+    auto sc_fetch = [&](int it) { if (sck < NSC) sc_next = fetch(64 * it + scr); };
+    auto sc_commit = [&](int buf) { if (sck < NSC) sc[(buf * NSC + sck) * 64 + scr] = sc_next; };
+
+    auto stage = [&](char* base, int it) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int gn = tile * NW * 16 + wave + NW * k;
-            if (gn < N && cin) *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 4 * lane) = trow[k];
+        for (int gq = 0; gq < 2; ++gq) {
+            const int p0 = 64 * it + 32 * gq;
+            if (p0 < Rp) {
+                stage_panel_w<8>(base + gq * npan * PANEL_B, pV_b, p0, wave, lane);
+                if (sep_s) stage_panel_w<8>(base + gq * npan * PANEL_B + PANEL_B, pS_b, p0, wave, lane);
+            }
+        }
+    };
+
+    acc_t O;
+    zero_acc(O);
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int niter = (dbg & 16) ? 0 : (R + 63) / 64;
+    if (niter > 0) {
+        sc_fetch(0);
+        if (db) stage(smem, 0);
+    }
+    for (int it = 0; it < niter; ++it) {
+        char* base;
+        int sb;
+        if (db) {
+            sb = it & 1;
+            base = smem + sb * stage_b;
+            sc_commit(sb);
+            __syncthreads();        // this iteration's panels have landed, the other stage and scalar buffer are free
+            if (it + 1 < niter) {
+                stage(smem + (sb ^ 1) * stage_b, it + 1);
+                sc_fetch(it + 1);
+            }
+        } else {
+            sb = 0;
+            base = smem;
+            __syncthreads();
+            stage(base, it);
+            sc_commit(0);
+            __syncthreads();
+            if (it + 1 < niter) sc_fetch(it + 1);
+        }
+        const int p0 = 64 * it + 32 * grp;
+        if (p0 < R && wave_on) {
+            const char* pV = base + grp * npan * PANEL_B;
+            const char* pS = sep_s ? pV + PANEL_B : pV;
+            const float* s0 = sc + (sb * NSC) * 64 + 32 * grp;     // scalar k of local row ml: s0[k * 64 + ml]
+            f4 v[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+            if (!(dbg & 2)) sprod2(pS, r, g, side, v);
+            f4 w[2];
+            if (KIND == 0) {
+                float bmax = -INFINITY;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ml = mb * 16 + 4 * g + e;
+                        const float code = s0[64 + ml];
+                        const float x = v[mb][e] * (s0[128 + ml] * inv_n) + s0[ml] + nterm;
+                        v[mb][e] = code == 2.f ? x : (code == 1.f ? NEG : -INFINITY);
+                        bmax = fmaxf(bmax, v[mb][e]);
+                    }
+                bmax = kg_allmax(bmax);
+                const float m_new = fmaxf(m_run, bmax);
+                const float alpha = __expf(m_run - m_new);
+                float psum = 0.f;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pv = __expf(v[mb][e] - m_new);
+                        psum += pv;
+                        w[mb][e] = pv * s0[192 + mb * 16 + 4 * g + e];
+                    }
+                l_run = l_run * alpha + psum;
+                if (__any(alpha != 1.0f)) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) O[dt] *= alpha;
+                }
+                m_run = m_new;
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ml = mb * 16 + 4 * g + e;
+                        const float x = mm ? v[mb][e] * (s0[192 + ml] * inv_n) + s0[ml] + nterm : NEG;
+                        const float p = __expf(x - s0[64 + ml]) * s0[128 + ml];
+                        w[mb][e] = p * s0[256 + ml];
+                    }
+            }
+            half8 W0, W1;
+            split_w(w[0], w[1], W0, W1);
+            if (!(dbg & 4)) pvprod(pV, tr, W0, W1, O);
         }
     }
+    __syncthreads();      // all panels are dead
+
+    // ---- merge group 1 into group 0 (lane-private exchange: [w4][dt | stats][lane] 16-B slots)
+    char* xb = smem + (size_t)w4 * (DT + 1) * 1024 + lane * 16;
+    if (grp == 1) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(xb + dt * 1024) = O[dt];
+        *reinterpret_cast<f4*>(xb + DT * 1024) = f4{m_run, l_run, 0.f, 0.f};
+    }
+    __syncthreads();
+    float l = 0.f;
+    if (grp == 0) {
+        const f4 st = *reinterpret_cast<const f4*>(xb + DT * 1024);
+        if (KIND == 0) {
+            const float m = fmaxf(m_run, st.x);
+            const float e0 = m_run == -INFINITY ? 0.f : __expf(m_run - m), e1 = st.x == -INFINITY ? 0.f : __expf(st.x - m);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) O[dt] = O[dt] * e0 + *reinterpret_cast<const f4*>(xb + dt * 1024) * e1;
+            l_run = l_run * e0 + st.y * e1;
+            m_run = m;
+            l = kg_allsum(l_run);
+        } else {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) O[dt] += *reinterpret_cast<const f4*>(xb + dt * 1024);
+        }
+    }
+    __syncthreads();
+    if (dbg & 8) return;
+    // ---- epilogue: group 0 parks the finished tile, then all 8 waves work on whole rows (one row per wave-instruction,
+    // lane = 16-B chunk): the result is only ever an MFMA operand, so it is written as planes with its row scale
+    float* et = reinterpret_cast<float*>(smem);              // [64][LDP]
+    float* est = et + 64 * LDP;                              // [64][2] column statistics {max, sum}
+    if (grp == 0) {
+        const float scale = KIND == 0 ? 1.0f / (l * cV) : 1.0f / cV;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(et + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
+        if (KIND == 0 && g == 0) {
+            est[(w4 * 16 + r) * 2] = m_run;
+            est[(w4 * 16 + r) * 2 + 1] = l;
+        }
+    }
+    __syncthreads();
+    const int row0 = tile * 64;
+    char* dst_p = (KIND == 0 ? A.pQ : A.pDq) + (size_t)b * planes_sample_bytes(N);
+    float* dst_i = (KIND == 0 ? A.iQ : A.iDq) + (size_t)b * Np;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int rr = wave + 8 * k, gn = row0 + rr;
+        if (gn >= Np) continue;                       // (wave-uniform) rows N..Np-1 are written as zeros
+        f4 x = f4{0.f, 0.f, 0.f, 0.f};
+        if (gn < N && 4 * lane < D) x = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * lane);
+        const float amax = wave_allmax(f4amax(x));
+        store_split_row(dst_p, dst_i + gn, gn, lane, x, amax);
+        if (gn < N) {
+            if (KIND == 0) {
+                if (lane == 0) {
+                    A.col_stat[((size_t)b * N + gn) * 2] = est[rr * 2];
+                    A.col_stat[((size_t)b * N + gn) * 2 + 1] = est[rr * 2 + 1];
+                }
+            } else {
+                // delta2_j = q_j . dq_j
+                float dot = 0.f;
+                if (lane < 8 * KT) dot = f4sum(x * planes_row_f32(A.pQ + (size_t)b * planes_sample_bytes(N), A.iQ + (size_t)b * Np, gn, lane));
+                dot = wave_allsum(dot);
+                if (lane == 0) A.delta2[(size_t)b * N + gn] = dot;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ row pass (forward)
+// Lane side = 64 text rows (text_d * w_tm, split in registers from fp32), streams the modality rows with values
+// [mod | q]: a = P1 mod, b = P1 q, out = [text, a, text*a, text*b].  4 waves with one 16-row tile each, at most 256
+// registers and one LDS stage: TWO workgroups share a CU (two waves per SIMD), each hiding the other's staging waits.
+template <bool DBG>
+__global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, const BlkMap bm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dbg = DBG ? a.dbg : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    int local;
+    const AttG& A = a.g[find_att(bm, a.n, blockIdx.x, local)];
+    const int N = A.T, R = A.M, D = a.D, Rp = pad32(R);
+    int tile, b;
+    if (!decode_local(local, (N + 63) / 64, a.B, tile, b)) return;
+    const int n = (tile * NW + wave) * 16 + r;
+    const bool wave_on = (tile * NW + wave) * 16 < N;
+
+    const size_t szR = planes_sample_bytes(R);
+    const char* pV0_b = A.pM + (size_t)b * szR;
+    const char* pV1_b = A.pQ + (size_t)b * szR;
+    const char* pS_b = A.pMd + (size_t)b * szR;
+    const float* iV0_b = A.iM + (size_t)b * Rp;
+    const float* iV1_b = A.iQ + (size_t)b * Rp;
+    const float* iS_b = A.iMd + (size_t)b * Rp;
+    const bool sep_s = A.pMd != A.pM;
+    const int npan = 2 + (sep_s ? 1 : 0);
+    constexpr int NSC = 5;
+    float* sc = reinterpret_cast<float*>(smem + npan * PANEL_B);    // [NSC][32]
+    float* red = sc + NSC * 32;
+
+    side_t side;
+    float inv_n;
+    load_side_f32(side, inv_n, A.text_d + (size_t)b * N * D, n, N, D, g, A.w_tm);
+    const float nterm = n < N ? A.rterm[(size_t)b * N + n] : 0.f;
+    const tr_off tr = make_tr_off(lane);
+
+    // first quarter of `out` = verbatim copy of text (attention.py:52): one row per wave-instruction, 16 rows per wave
+    {
+        const float* tx = A.text + (size_t)b * N * D;
+        float* oo = A.out + (size_t)b * N * 4 * D;
+        const bool cin = 4 * lane < D;
+        f4 t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int gn = tile * 64 + wave + NW * k;
+            t[k] = (gn < N && cin) ? *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * lane) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int gn = tile * 64 + wave + NW * k;
+            if (gn < N && cin) *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 4 * lane) = t[k];
+        }
+    }
+    float im[2] = {0.f, 0.f};
+    for (int i = tid; i < R; i += NTHR) {
+        im[0] = fmaxf(im[0], iV0_b[i]);
+        im[1] = fmaxf(im[1], iV1_b[i]);
+    }
+    wg_allmax_w<2, NW>(im, red, tid);
+    const float c0 = cmap(im[0]), c1 = cmap(im[1]);
+
+    const int sck = tid >> 5, scr = tid & 31;
+    auto fetch = [&](int m) -> float {
+        const bool in = m < R;
+        switch (sck) {
+            case 0: return in ? A.cterm[(size_t)b * R + m] : 0.f;
+            case 1: return (float)mask_code(in, A.mod_mask, A.mod_len, b, R, m);
+            case 2: return in ? iS_b[m] : 0.f;
+            case 3: return in ? iV0_b[m] * c0 : 0.f;
+            default: return in ? iV1_b[m] * c1 : 0.f;
+        }
+    };
+    float sc_next = 0.f;
+    const int row_end = (dbg & 16) ? 0 : R;
+    if (row_end > 0 && sck < NSC) sc_next = fetch(scr);
+
     acc_t O0, O1;
     zero_acc(O0);
     zero_acc(O1);
     float m_run = -INFINITY, l_run = 0.f;
-
-    const int row_begin = split * rps;
-    const int row_end = (dbg & 16) ? row_begin : min(R, row_begin + rps);
-    float im[2] = {0.f, 0.f};
-    for (int i = tid; i < rps; i += NTHR) {
-        const int m = row_begin + i;
-        const bool in = m < min(R, row_begin + rps);
-        mterm_all[i] = in ? a.m_term[(size_t)b * R + m] : 0.f;
-        mcode_all[i] = mask_code(in, a.m_mask, a.m_len, b, R, m);
-        sS_all[i] = in ? a.iS[(size_t)b * Rp + m] : 0.f;
-        const float v0 = in ? a.iV0[(size_t)b * Rp + m] : 0.f;
-        sV0_all[i] = v0;
-        im[0] = fmaxf(im[0], v0);
-        if (NV == 2) {
-            const float v1 = in ? a.iV1[(size_t)b * Rp + m] : 0.f;
-            sV1_all[i] = v1;
-            im[1] = fmaxf(im[1], v1);
-        }
-    }
-    wg_allmax(im, red, tid);
-    const float c0 = cmap(im[0]), c1 = cmap(im[1]);
-    for (int i = tid; i < rps; i += NTHR) {   // each thread rescales the entries it wrote itself
-        sV0_all[i] *= c0;
-        if (NV == 2) sV1_all[i] *= c1;
-    }
-
-    auto stage = [&](char* base, int p0) {
-        if ((dbg & 1) && p0 != row_begin) return;
-        stage_panel(base, mV0_b, p0, tid);
-        if (NV == 2) stage_panel(base + PANEL_B, mV1_b, p0, tid);
-        if (sep_s) stage_panel(base + NV * PANEL_B, mS_b, p0, tid);
-    };
-    int cur = 0;
-    if (db) {
-        if (row_begin < row_end) stage(smem, row_begin);
+    for (int p0 = 0; p0 < row_end; p0 += PR) {
         __syncthreads();
-    }
-    for (int p0 = row_begin; p0 < row_end; p0 += PR) {
-        char* base = smem + (db ? cur * stage_b : 0);
-        if (db) {
-            if (p0 + PR < row_end) stage(smem + (cur ^ 1) * stage_b, p0 + PR);
-        } else {
-            __syncthreads();
-            stage(base, p0);
-            __syncthreads();
-        }
-        const char* pV0 = base;
-        const char* pV1 = base + PANEL_B;                 // only touched when NV == 2
-        const char* pS = sep_s ? base + NV * PANEL_B : pV0;
-        const int i0 = p0 - row_begin;
+        stage_panel_w<NW>(smem, pV0_b, p0, wave, lane);
+        stage_panel_w<NW>(smem + PANEL_B, pV1_b, p0, wave, lane);
+        if (sep_s) stage_panel_w<NW>(smem + 2 * PANEL_B, pS_b, p0, wave, lane);
+        if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+        __syncthreads();
+        if (p0 + PR < row_end && sck < NSC) sc_next = fetch(p0 + PR + scr);
+        if (!wave_on) continue;
+        const char* pV0 = smem;
+        const char* pV1 = smem + PANEL_B;
+        const char* pS = sep_s ? smem + 2 * PANEL_B : pV0;
 
         f4 v[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
         if (!(dbg & 2)) sprod2(pS, r, g, side, v);
@@ -653,10 +959,10 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int ml = i0 + mb * 16 + 4 * g + e;
-                const int code = mcode_all[ml];
-                const float x = v[mb][e] * (sS_all[ml] * inv_n) + mterm_all[ml] + nterm;
-                v[mb][e] = code == 2 ? x : (code == 1 ? NEG : -INFINITY);
+                const int ml = mb * 16 + 4 * g + e;
+                const float code = sc[32 + ml];
+                const float x = v[mb][e] * (sc[64 + ml] * inv_n) + sc[ml] + nterm;
+                v[mb][e] = code == 2.f ? x : (code == 1.f ? NEG : -INFINITY);
                 bmax = fmaxf(bmax, v[mb][e]);
             }
         bmax = kg_allmax(bmax);
@@ -675,7 +981,7 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 O0[dt] *= alpha;
-                if (NV == 2) O1[dt] *= alpha;
+                O1[dt] *= alpha;
             }
         }
         m_run = m_new;
@@ -684,369 +990,83 @@ __device__ __forceinline__ void att_fwd_body(const AttFwdArgs& a, char* smem) {
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * sV0_all[i0 + mb * 16 + 4 * g + e];
+                for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * sc[96 + mb * 16 + 4 * g + e];
             half8 W0, W1;
             split_w(w[0], w[1], W0, W1);
             if (!(dbg & 4)) pvprod(pV0, tr, W0, W1, O0);
         }
-        if (NV == 2) {
+        {
             f4 w[2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * sV1_all[i0 + mb * 16 + 4 * g + e];
+                for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * sc[128 + mb * 16 + 4 * g + e];
             half8 W0, W1;
             split_w(w[0], w[1], W0, W1);
             if (!(dbg & 4)) pvprod(pV1, tr, W0, W1, O1);
         }
-        if (db) {
-            __syncthreads();   // retires the DMA of the next stage and frees this one
-            cur ^= 1;
-        }
     }
 
-    // ---- epilogue.  The accumulators hold 16 rows x 64-B pieces per store instruction; written directly that is 16
-    // partial cache lines per instruction.  Instead each wave parks its tile in LDS (the panels are dead) and the
-    // workgroup writes whole rows: one row per wave-instruction, lane = 16-B chunk.
+    // ---- epilogue: each wave parks its tile in LDS (the panels are dead) and the workgroup writes whole rows
     const float l = kg_allsum(l_run);
-    const bool partial = NV == 1;
     if (n < N && g == 0) {
-        float* st = partial ? a.part_stat + (((size_t)b * a.splits + split) * N + n) * 2 : a.stat + ((size_t)b * N + n) * 2;
+        float* st = A.row_stat + ((size_t)b * N + n) * 2;
         st[0] = m_run;
         st[1] = l;
     }
     if (dbg & 8) return;
-    float* et = reinterpret_cast<float*>(smem);          // [16*NW][LDP]
-    const int row0 = tile * NW * 16;                    // first lane-side row of this workgroup
-    const int c4 = lane;                                // this lane's 16-B chunk of a row
+    float* et = reinterpret_cast<float*>(smem);          // [64][LDP]
+    const int row0 = tile * 64;
+    const int c4 = lane;
+    const float* tx = A.text + (size_t)b * N * D;
+    float* oo = A.out + (size_t)b * N * 4 * D;
+    float* bo = A.bsave + (size_t)b * N * D;
     auto park = [&](const acc_t& O, float scale) {
         __syncthreads();
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-            *reinterpret_cast<f4*>(et + (wave * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(et + (wave * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
         __syncthreads();
     };
-    park(O0, partial ? 1.0f / c0 : 1.0f / (l * c0));
-    if (NV == 1) {
-        float* dst = a.part_o + ((size_t)b * a.splits + split) * N * D;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int rr = wave + NW * k;
-            const int gn = row0 + rr;
-            if (gn < N && 4 * c4 < D) *reinterpret_cast<f4*>(dst + (size_t)gn * D + 4 * c4) = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
-        }
-    } else {
-        float* oo = a.out + (size_t)b * N * 4 * D;
-        float* bo = a.bsave + (size_t)b * N * D;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int rr = wave + NW * k, gn = row0 + rr;
-            if (gn < N && 4 * c4 < D) {
-                const f4 av = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
-                float* o = oo + (size_t)gn * 4 * D + 4 * c4;
-                *reinterpret_cast<f4*>(o + D) = av;
-                *reinterpret_cast<f4*>(o + 2 * D) = trow[k] * av;
-            }
-        }
-        park(O1, 1.0f / (l * c1));
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int rr = wave + NW * k, gn = row0 + rr;
-            if (gn < N && 4 * c4 < D) {
-                const f4 bv = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
-                *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 3 * D + 4 * c4) = trow[k] * bv;
-                *reinterpret_cast<f4*>(bo + (size_t)gn * D + 4 * c4) = bv;
-            }
-        }
-    }
-}
-
-template <bool DBG>
-__global__ __launch_bounds__(NTHR) void att_col_kernel(const AttFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    att_fwd_body<1, DBG>(a, smem);
-}
-template <bool DBG>
-__global__ __launch_bounds__(NTHR) void att_row_kernel(const AttFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    att_fwd_body<2, DBG>(a, smem);
-}
-
-// Row pass with TWO waves per SIMD (8 waves per workgroup): waves w and w+4 own the same 16 text rows and split the
-// two value products between them -- role 0 accumulates a = P1.mod, role 1 accumulates b = P1.q -- so each wave needs
-// one accumulator set (<= 256 registers) and the pair hides each other's LDS / softmax / barrier latencies; both compute
-// S and the online softmax of the panel (42 of the 81 MFMAs a wave issues per panel are redundant: the price).
-template <bool DBG>
-__global__ __launch_bounds__(2 * NTHR) void att_row8_kernel(const AttFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int dbg = DBG ? a.dbg : 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int role = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
-    const int r = lane & 15, g = lane >> 4;
-    const int N = a.N, R = a.R, D = a.D, Rp = pad32(R);
-    int tile, split, b;
-    decode_block((N + 16 * NW - 1) / (16 * NW), 1, a.B, tile, split, b);
-    const int n = (tile * NW + w4) * 16 + r;
-    const int rps = a.rows_per_split;   // = pad32(R): one split
-
-    const bool sep_s = a.mS != a.mV0;
-    const int npan = 2 + (sep_s ? 1 : 0);
-    const int stage_b = npan * PANEL_B;
-    const bool db = a.nstage == 2;
-    float* mterm_all = reinterpret_cast<float*>(smem + a.nstage * stage_b);
-    int* mcode_all = reinterpret_cast<int*>(mterm_all + rps);
-    float* sS_all = mterm_all + 2 * rps;
-    float* sV_all[2] = {mterm_all + 3 * rps, mterm_all + 4 * rps};
-    float* red = mterm_all + 5 * rps;
-
-    const size_t szR = planes_sample_bytes(R);
-    const char* mS_b = a.mS + (size_t)b * szR;
-    const char* mV0_b = a.mV0 + (size_t)b * szR;
-    const char* mV1_b = a.mV1 + (size_t)b * szR;
-
-    side_t side;
-    float inv_n;
-    load_side_planes(side, inv_n, a.side_p + (size_t)b * planes_sample_bytes(N), a.side_i + (size_t)b * pad32(N), n, N, g);
-    const float nterm = n < N ? a.n_term[(size_t)b * N + n] : 0.f;
-    const tr_off tr = make_tr_off(lane);
-
-    // first quarter of `out` = verbatim copy of text (attention.py:52): 8 rows per wave, loads batched, stores at once
-    {
-        const float* tx = a.text + (size_t)b * N * D;
-        float* oo = a.out + (size_t)b * N * 4 * D;
-        const bool cin = 4 * lane < D;
-        f4 t[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int gn = tile * NW * 16 + wave + 8 * k;
-            t[k] = (gn < N && cin) ? *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * lane) : f4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int gn = tile * NW * 16 + wave + 8 * k;
-            if (gn < N && cin) *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 4 * lane) = t[k];
-        }
-    }
-    acc_t O;
-    zero_acc(O);
-    float m_run = -INFINITY, l_run = 0.f;
-
-    const int row_end = (dbg & 16) ? 0 : R;
-    float im[2] = {0.f, 0.f};
-    for (int i = tid; i < rps; i += 2 * NTHR) {
-        const bool in = i < R;
-        mterm_all[i] = in ? a.m_term[(size_t)b * R + i] : 0.f;
-        mcode_all[i] = mask_code(in, a.m_mask, a.m_len, b, R, i);
-        sS_all[i] = in ? a.iS[(size_t)b * Rp + i] : 0.f;
-        const float v0 = in ? a.iV0[(size_t)b * Rp + i] : 0.f, v1 = in ? a.iV1[(size_t)b * Rp + i] : 0.f;
-        sV_all[0][i] = v0;
-        sV_all[1][i] = v1;
-        im[0] = fmaxf(im[0], v0);
-        im[1] = fmaxf(im[1], v1);
-    }
-    {   // workgroup maximum over the 8 waves
-#pragma unroll
-        for (int k = 0; k < 2; ++k) im[k] = wave_allmax(im[k]);
-        __syncthreads();
-        if (lane == 0) { red[wave * 2] = im[0]; red[wave * 2 + 1] = im[1]; }
-        __syncthreads();
-        im[0] = im[1] = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) { im[0] = fmaxf(im[0], red[w * 2]); im[1] = fmaxf(im[1], red[w * 2 + 1]); }
-    }
-    const float cv[2] = {cmap(im[0]), cmap(im[1])};
-    for (int i = tid; i < rps; i += 2 * NTHR) {
-        sV_all[0][i] *= cv[0];
-        sV_all[1][i] *= cv[1];
-    }
-    const float c_mine = role ? cv[1] : cv[0];
-    const float* sV_mine = role ? sV_all[1] : sV_all[0];
-
-    // staging: waves 0-3 bring the mod panel, waves 4-7 the q panel (7 pieces each); a separate S panel: all 8 waves
-    auto stage = [&](char* base, int p0) {
-        if ((dbg & 1) && p0 != 0) return;
-        stage_panel(base + role * PANEL_B, role ? mV1_b : mV0_b, p0, tid & (NTHR - 1));
-        if (sep_s) {
-            const char* src = mS_b + (size_t)(p0 >> 4) * PRB + lane * 16;
-            char* dst = base + 2 * PANEL_B;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int piece = wave + 8 * k;
-                if (piece < PANEL_B / 1024)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
-                                                     (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
-            }
-        }
-    };
-    int cur = 0;
-    if (db) {
-        if (0 < row_end) stage(smem, 0);
-        __syncthreads();
-    }
-    for (int p0 = 0; p0 < row_end; p0 += PR) {
-        char* base = smem + (db ? cur * stage_b : 0);
-        if (db) {
-            if (p0 + PR < row_end) stage(smem + (cur ^ 1) * stage_b, p0 + PR);
-        } else {
-            __syncthreads();
-            stage(base, p0);
-            __syncthreads();
-        }
-        const char* pS = sep_s ? base + 2 * PANEL_B : base;
-        const char* pV = base + role * PANEL_B;
-
-        f4 v[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-        if (!(dbg & 2)) sprod2(pS, r, g, side, v);
-        float bmax = -INFINITY;
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ml = p0 + mb * 16 + 4 * g + e;
-                const int code = mcode_all[ml];
-                const float x = v[mb][e] * (sS_all[ml] * inv_n) + mterm_all[ml] + nterm;
-                v[mb][e] = code == 2 ? x : (code == 1 ? NEG : -INFINITY);
-                bmax = fmaxf(bmax, v[mb][e]);
-            }
-        bmax = kg_allmax(bmax);
-        const float m_new = fmaxf(m_run, bmax);
-        const float alpha = __expf(m_run - m_new);
-        float psum = 0.f;
-        f4 w[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float pv = __expf(v[mb][e] - m_new);
-                psum += pv;
-                w[mb][e] = pv * sV_mine[p0 + mb * 16 + 4 * g + e];
-            }
-        l_run = l_run * alpha + psum;
-        if (__any(alpha != 1.0f)) {
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) O[dt] *= alpha;
-        }
-        m_run = m_new;
-        half8 W0, W1;
-        split_w(w[0], w[1], W0, W1);
-        if (!(dbg & 4)) pvprod(pV, tr, W0, W1, O);
-        if (db) {
-            __syncthreads();
-            cur ^= 1;
-        }
-    }
-
-    // ---- epilogue: every wave parks its tile (role 0: a, role 1: b) in its role's LDS region, then the workgroup writes
-    // whole rows: role 0 the a and text*a quarters, role 1 the text*b quarter and the saved b
-    const float l = kg_allsum(l_run);
-    if (role == 0 && n < N && g == 0) {
-        float* st = a.stat + ((size_t)b * N + n) * 2;
-        st[0] = m_run;
-        st[1] = l;
-    }
-    if (dbg & 8) return;
-    float* et = reinterpret_cast<float*>(smem) + role * (16 * NW * LDP);
-    const int row0 = tile * NW * 16;
-    const int c4 = lane;
-    const float* tx = a.text + (size_t)b * N * D;
     f4 trow[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const int gn = row0 + w4 + NW * k;
+        const int gn = row0 + wave + NW * k;
         trow[k] = (gn < N && 4 * c4 < D) ? *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * c4) : f4{0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();
-    {
-        const float scale = 1.0f / (l * c_mine);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(et + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
-    }
-    __syncthreads();
-    float* oo = a.out + (size_t)b * N * 4 * D;
-    float* bo = a.bsave + (size_t)b * N * D;
+    park(O0, 1.0f / (l * c0));
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const int rr = w4 + NW * k, gn = row0 + rr;
+        const int rr = wave + NW * k, gn = row0 + rr;
         if (gn < N && 4 * c4 < D) {
-            const f4 ov = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
+            const f4 av = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
             float* o = oo + (size_t)gn * 4 * D + 4 * c4;
-            if (role == 0) {
-                *reinterpret_cast<f4*>(o + D) = ov;
-                *reinterpret_cast<f4*>(o + 2 * D) = trow[k] * ov;
-            } else {
-                *reinterpret_cast<f4*>(o + 3 * D) = trow[k] * ov;
-                *reinterpret_cast<f4*>(bo + (size_t)gn * D + 4 * c4) = ov;
-            }
+            *reinterpret_cast<f4*>(o + D) = av;
+            *reinterpret_cast<f4*>(o + 2 * D) = trow[k] * av;
         }
     }
-}
-
-// merge the per-split partial column softmaxes, q = sum_p O_p e^{m_p-m} / sum_p l_p e^{m_p-m}, and write q as planes
-// (it is only ever a streamed / lane-side MFMA operand): one wave per modality row, lane = float4 chunk
-__global__ __launch_bounds__(256) void att_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_stat,
-                                                          char* __restrict__ q_planes, float* __restrict__ q_inv, float* __restrict__ stat,
-                                                          int B, int N, int D, int splits) {
-    const int Np = pad32(N);
-    const long rowi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (rowi >= (long)B * Np) return;
-    const int b = rowi / Np, n = rowi - (long)b * Np, c = threadIdx.x & 63, d = 4 * c;
-    f4 v = f4{0.f, 0.f, 0.f, 0.f};
-    if (n < N) {
-        // four splits per trip: their statistics and partial rows are loaded together (independent of the running values),
-        // lanes beyond D read column 0 and drop it -- no branch around the loads
-        const int dsafe = d < D ? d : 0;
-        float m = -INFINITY, l = 0.f;
-        for (int p0 = 0; p0 < splits; p0 += 4) {
-            float pm[4], pl[4];
-            f4 po[4];
+    park(O1, 1.0f / (l * c1));
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const size_t o = ((size_t)b * splits + min(p0 + k, splits - 1)) * N + n;
-                pm[k] = part_stat[o * 2];
-                pl[k] = part_stat[o * 2 + 1];
-                po[k] = *reinterpret_cast<const f4*>(part_o + o * D + dsafe);
-            }
-            float mn = m;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (p0 + k < splits) mn = fmaxf(mn, pm[k]);
-            const float resc = __expf(m - mn);   // exp(-inf) = 0 on the first trip
-            l *= resc;
-            v = v * resc;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (p0 + k < splits) {
-                    const float sc = __expf(pm[k] - mn);
-                    l += pl[k] * sc;
-                    v += po[k] * sc;
-                }
-            m = mn;
-        }
-        if (d >= D) v = f4{0.f, 0.f, 0.f, 0.f};
-        v = v * (1.0f / l);
-        if (c == 0) {
-            stat[((size_t)b * N + n) * 2] = m;
-            stat[((size_t)b * N + n) * 2 + 1] = l;
+    for (int k = 0; k < 16; ++k) {
+        const int rr = wave + NW * k, gn = row0 + rr;
+        if (gn < N && 4 * c4 < D) {
+            const f4 bv = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
+            *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 3 * D + 4 * c4) = trow[k] * bv;
+            *reinterpret_cast<f4*>(bo + (size_t)gn * D + 4 * c4) = bv;
         }
     }
-    const float amax = wave_allmax(f4amax(v));
-    store_split_row(q_planes + (size_t)b * planes_sample_bytes(N), q_inv + (size_t)b * Np + n, n, c, v, amax);
 }
 
 // ------------------------------------------------------------------------------------------ backward
-// prologue over text rows (one wave per row, lane = float4 chunk: every access a coalesced 16 B per lane):
+// prologue over text rows (one wave per row, lane = float4 chunk: every access a coalesced 16 B per lane); blockIdx.y =
+// attention of the group:
 //   da = g1 + g2*text ; db = g3*text  (written as planes: they are only ever MFMA operands)
 //   delta1 = da.a + db.b ; d_text = g0 + g2*a + g3*b      (a = out[:, D:2D], b = bsave)
-__global__ __launch_bounds__(256) void att_bwd_pre_kernel(const float* __restrict__ d_out, const float* __restrict__ out,
-                                                          const float* __restrict__ text, const float* __restrict__ bsave,
-                                                          char* __restrict__ da_planes, float* __restrict__ da_inv,
-                                                          char* __restrict__ db_planes, float* __restrict__ db_inv,
-                                                          float* __restrict__ delta1, float* __restrict__ d_text,
-                                                          float* __restrict__ d_w_t, float* __restrict__ d_w_m,
-                                                          float* __restrict__ d_w_tm, float* __restrict__ d_bias, int B, int T, int D) {
-    if (blockIdx.x == 0) {  // the parameter gradients are accumulated with atomics by the later kernels
-        for (int i = threadIdx.x; i < D; i += 256) d_w_t[i] = d_w_m[i] = d_w_tm[i] = 0.f;
-        if (threadIdx.x == 0) d_bias[0] = 0.f;
+__global__ __launch_bounds__(256) void att_bwd_pre_kernel(const GroupArgs a) {
+    const AttG& A = a.g[blockIdx.y];
+    const int B = a.B, T = A.T, D = a.D;
+    if (blockIdx.x == 0) {  // the parameter gradients are accumulated with atomics by the sweep kernel
+        for (int i = threadIdx.x; i < D; i += 256) A.d_w_t[i] = A.d_w_m[i] = A.d_w_tm[i] = 0.f;
+        if (threadIdx.x == 0) A.d_bias[0] = 0.f;
     }
     const int Tp = pad32(T);
     const long rowi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1056,602 +1076,475 @@ __global__ __launch_bounds__(256) void att_bwd_pre_kernel(const float* __restric
     float acc = 0.f;
     if (row < T && d < D) {
         const size_t rr = (size_t)b * T + row;
-        const float* g = d_out + rr * 4 * D;
+        const float* g = A.d_out + rr * 4 * D;
         const f4 g0 = *reinterpret_cast<const f4*>(g + d), g1 = *reinterpret_cast<const f4*>(g + D + d);
         const f4 g2 = *reinterpret_cast<const f4*>(g + 2 * D + d), g3 = *reinterpret_cast<const f4*>(g + 3 * D + d);
-        const f4 av = *reinterpret_cast<const f4*>(out + rr * 4 * D + D + d);
-        const f4 t = *reinterpret_cast<const f4*>(text + rr * D + d);
-        const f4 bv = *reinterpret_cast<const f4*>(bsave + rr * D + d);
+        const f4 av = *reinterpret_cast<const f4*>(A.out + rr * 4 * D + D + d);
+        const f4 t = *reinterpret_cast<const f4*>(A.text + rr * D + d);
+        const f4 bv = *reinterpret_cast<const f4*>(A.bsave + rr * D + d);
         xa = g1 + g2 * t;
         xb = g3 * t;
-        *reinterpret_cast<f4*>(d_text + rr * D + d) = g0 + g2 * av + g3 * bv;
+        *reinterpret_cast<f4*>(A.d_text + rr * D + d) = g0 + g2 * av + g3 * bv;
         acc = f4sum(xa * av + xb * bv);
     }
     const float amax_a = wave_allmax(f4amax(xa)), amax_b = wave_allmax(f4amax(xb));
     acc = wave_allsum(acc);
-    if (c == 0 && row < T) delta1[(size_t)b * T + row] = acc;
+    if (c == 0 && row < T) A.delta1[(size_t)b * T + row] = acc;
     const size_t sz = planes_sample_bytes(T);
-    store_split_row(da_planes + (size_t)b * sz, da_inv + (size_t)b * Tp + row, row, c, xa, amax_a);
-    store_split_row(db_planes + (size_t)b * sz, db_inv + (size_t)b * Tp + row, row, c, xb, amax_b);
+    store_split_row(A.pDa + (size_t)b * sz, A.iDa + (size_t)b * Tp + row, row, c, xa, amax_a);
+    store_split_row(A.pDb + (size_t)b * sz, A.iDb + (size_t)b * Tp + row, row, c, xb, amax_b);
 }
 
-struct AttBwdArgs {
-    const float *text, *mod, *text_d, *mod_d;       // (B,T,D) / (B,M,D) fp32 (lane-side loads)
-    const uint8_t *text_mask, *mod_mask;            // (B,T) / (B,M) or null with the lengths
-    const int *text_len, *mod_len;                  // (B) or null
-    const float *w_t, *w_m, *w_tm;
-    const float *rterm, *cterm, *row_stat, *col_stat;
-    // planes + inverse scales (saved by the forward: text, text_d, mod, mod_d, q; workspace: da, db, dq)
-    const char *pT, *pTd, *pM, *pMd, *pQ, *pDa, *pDb, *pTw, *pMw;   // pTw / pMw: text_d * w_tm, mod_d * w_tm (lane-side S operands)
-    const float *iT, *iTd, *iM, *iMd, *iQ, *iDa, *iDb, *iTw, *iMw;
-    char* pDq;
-    float* iDq;
-    const float* delta1;                             // (B,T)
-    float* delta2;                                   // (B,M)
-    float *d_mod, *d_mod_d, *d_text, *d_text_d;      // outputs
-    float *d_w_t, *d_w_m, *d_w_tm, *d_bias;          // outputs, zeroed by the prologue, accumulated with atomics
-    // per-split partial sums of the j-side sweeps, (B,splits,M,D) / (B,splits,M)
-    float *p_dq, *p_dmc, *p_dmd1, *p_dmd2, *p_dc1, *p_dc2;
-    int B, T, M, D, splits, rows_per_split;
-    int fold;                                        // 1: no dropped copies, d_*_d folded into d_*
-    int nstage_j2;                                   // LDS stages of the second j sweep (1 or 2)
-    int jf_rows;                                     // rows per wave of the j-side epilogue (1, 2, 4 or 8)
-    int i_blocks;                                    // workgroups of the i-side pass; ids beyond them run the j-side epilogue
-    int dbg;
+// Gradient sweeps.  With dS = P1 (dP1 - delta1_i) mask_j + P2 (dP2 - delta2_j) mask_i,
+//   dP1_ij = da_i . mod_j + db_i . q_j,   dP2_ij = text_i . dq_j:
+//   j sweep (lane side = 64 modality rows j, streams all text rows i):
+//       dmodc_j = sum_i P1_ij da_i ; dmodd_j = sum_i dS_ij text_d_i ; dc_j = sum_i dS_ij
+//       d_mod_d_j = dc_j w_m + w_tm * dmodd_j ; d_mod_j = dmodc_j (+ d_mod_d_j when folded) ; d_w_m += dc_j mod_d_j
+//   i sweep (lane side = 64 text rows i, streams all modality rows j):
+//       d_text_i += sum_j P2_ij dq_j ; dX_i = sum_j dS_ij mod_d_j ; dr_i = sum_j dS_ij
+//       d_text_d_i = dr_i w_t + w_tm * dX_i ; d_w_t += dr_i text_d_i ; d_w_tm += dX_i * text_d_i ; d_bias += dr_i
+// Both need four S-type products (similarity, the two halves of dP1, dP2) and two PV-type products per (16 lane rows x
+// 32-row panel), i.e. 4 lane-side operands and 2 accumulator sets: 330 registers for one wave.  Here a PAIR of waves
+// (w, w + 4: the two waves of one SIMD) owns the 16 rows and splits the PRODUCTS, not the data:
+//   role 0: similarity + dP2, then the softmax / gradient arithmetic of the tile, then one PV product;
+//   role 1: the two halves of dP1 (sent to role 0 through 2 KiB of LDS), then the other PV product with the weights
+//           role 0 sends back.
+// Each wave carries two lane-side operands and one accumulator set (<= 256 registers: two waves per SIMD), no product
+// is computed twice, and the two roles run the SAME matrix-core instruction stream on different panels.
+// Both sweeps are independent of each other (they need dq from the dq sweep): they share ONE launch, the long j-sweep
+// workgroups first.
+struct SweepMap {
+    BlkMap j, i;
+    int i_begin;        // first block of the i sweep
 };
 
-// Accumulator tiles hold 16 rows x 64-B pieces per store instruction (16 partial cache lines); instead every wave parks
-// its tile in LDS and the workgroup stores its 64 rows whole: one row per wave-instruction, lane = 16-B chunk.
-// et: [64][LDP] floats of LDS that no wave still reads (the panels are dead); dst: row `row0` of a (rows, D) matrix.
-__device__ __forceinline__ void park_store(float* et, const acc_t& O, float scale, float* dst, int nrows, int D, int tid) {
-    const int lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-    __syncthreads();
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(et + (wave * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int rr = wave + NW * k;
-        if (rr < nrows && 4 * lane < D) *reinterpret_cast<f4*>(dst + (size_t)rr * D + 4 * lane) = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * lane);
-    }
+// W0 | W1 of a weight set travel through LDS as 2 x 16 B per lane
+__device__ __forceinline__ void xch_put(char* p, const half8 W0, const half8 W1) {
+    *reinterpret_cast<half8*>(p) = W0;
+    *reinterpret_cast<half8*>(p + 1024) = W1;
 }
-__device__ __forceinline__ void store_acc(float* dst_row, const acc_t& v, float scale, int D, int g) {
+__device__ __forceinline__ void xch_get(const char* p, half8& W0, half8& W1) {
+    W0 = *reinterpret_cast<const half8*>(p);
+    W1 = *reinterpret_cast<const half8*>(p + 1024);
+}
+__device__ __forceinline__ void copy_side(side_t& d, const side_t& s) {
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const int d = 16 * dt + 4 * g;
-        if (d < D) *reinterpret_cast<f4*>(dst_row + d) = v[dt] * scale;
+    for (int kt = 0; kt < KT; ++kt) {
+        d.h[kt][0] = s.h[kt][0];
+        d.h[kt][1] = s.h[kt][1];
     }
 }
 
-// j-side sweep 1 (lane side = modality rows j, streams a slice of the text rows i):
-//   dq_j += sum_i P1_ij db_i ; dmodc_j += sum_i P1_ij da_i ; dS1 = P1 (dP1 - delta1_i) mask_j
-//   dmodd_j += sum_i dS1_ij text_d_i (scaled by w_tm later) ; dc_j += sum_i dS1_ij
-template <bool DBG>
-__global__ __launch_bounds__(NTHR) void att_bwd_j1_kernel(const AttBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+constexpr int XCH_PAIR = 4096;     // per pair: [dp1: 2 x 1 KiB][weights: 2 x 1 KiB]
+
+template <bool DBG, bool SAME>
+__device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, int local, char* smem) {
     const int dbg = DBG ? a.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int role = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
     const int r = lane & 15, g = lane >> 4;
-    const int T = a.T, M = a.M, D = a.D, Tp = pad32(T);
-    int tile, split, b;
-    decode_block((M + 16 * NW - 1) / (16 * NW), a.splits, a.B, tile, split, b);
-    const int n = (tile * NW + wave) * 16 + r;  // modality row j
-    const int rps = a.rows_per_split;
+    const int T = A.T, M = A.M, D = a.D, Tp = pad32(T), Mp = pad32(M);
+    int tile, b;
+    if (!decode_local(local, (M + 63) / 64, a.B, tile, b)) return;
+    const int n = (tile * 4 + w4) * 16 + r;  // modality row j
+    const bool wave_on = (tile * 4 + w4) * 16 < M;
+    const bool nin = n < M;
 
+    constexpr int NPAN = SAME ? 3 : 4;
     char* pTd = smem;
     char* pDa = smem + PANEL_B;
     char* pDb = smem + 2 * PANEL_B;
-    float* rt_all = reinterpret_cast<float*>(smem + 3 * PANEL_B);
-    float* rmax_all = rt_all + rps;
-    float* rinv_all = rt_all + 2 * rps;    // 1/rowsum, 0 beyond the slice
-    float* dl1_all = rt_all + 3 * rps;
-    float* sTd_all = rt_all + 4 * rps;
-    float* sDa_all = rt_all + 5 * rps;
-    float* sDb_all = rt_all + 6 * rps;
-    float* red = rt_all + 7 * rps;
+    char* pT = SAME ? pTd : smem + 3 * PANEL_B;
+    constexpr int NSC = 9;
+    float* sc = reinterpret_cast<float*>(smem + NPAN * PANEL_B);   // [NSC][32]
+    char* xch = reinterpret_cast<char*>(sc + NSC * 32) + w4 * XCH_PAIR + lane * 16;
+    float* red = reinterpret_cast<float*>(smem + NPAN * PANEL_B + NSC * 32 * 4 + 4 * XCH_PAIR);
 
     const size_t szT = planes_sample_bytes(T), szM = planes_sample_bytes(M);
-    side_t sideS, sideM, sideQ;
-    float inS, inM, inQ;
-    load_side_planes(sideS, inS, a.pMw + (size_t)b * szM, a.iMw + (size_t)b * pad32(M), n, M, g);
-    load_side_planes(sideM, inM, a.pM + (size_t)b * szM, a.iM + (size_t)b * pad32(M), n, M, g);
-    load_side_planes(sideQ, inQ, a.pQ + (size_t)b * szM, a.iQ + (size_t)b * pad32(M), n, M, g);
-    const bool nin = n < M;
-    const float cterm = nin ? a.cterm[(size_t)b * M + n] : 0.f;
-    const bool mm = nin ? mask_live(a.mod_mask, a.mod_len, b, M, n) : false;
+    const char* td_b = A.pTd + (size_t)b * szT;
+    const char* t_b = A.pT + (size_t)b * szT;
+    const char* da_b = A.pDa + (size_t)b * szT;
+    const char* db_b = A.pDb + (size_t)b * szT;
+    const float* iTd_b = A.iTd + (size_t)b * Tp;
+    const float* iT_b = A.iT + (size_t)b * Tp;
+    const float* iDa_b = A.iDa + (size_t)b * Tp;
+    const float* iDb_b = A.iDb + (size_t)b * Tp;
+
+    // lane-side operands: role 0 = {mod_d * w_tm (similarity), dq (dP2)}, role 1 = {mod (da.mod), q (db.q)}
+    side_t sa, sb;
+    float ina, inb;
+    if (role == 0) {
+        load_side_f32(sa, ina, A.mod_d + (size_t)b * M * D, n, M, D, g, A.w_tm);
+        load_side_planes(sb, inb, A.pDq + (size_t)b * szM, A.iDq + (size_t)b * Mp, n, M, g);
+    } else {
+        load_side_planes(sa, ina, A.pM + (size_t)b * szM, A.iM + (size_t)b * Mp, n, M, g);
+        load_side_planes(sb, inb, A.pQ + (size_t)b * szM, A.iQ + (size_t)b * Mp, n, M, g);
+    }
+    const float inM = nin ? A.iM[(size_t)b * Mp + n] : 0.f, inQ = nin ? A.iQ[(size_t)b * Mp + n] : 0.f;
+    const float inDq = nin ? A.iDq[(size_t)b * Mp + n] : 0.f;
+    const float cterm = nin ? A.cterm[(size_t)b * M + n] : 0.f;
+    const float cmax = nin ? A.col_stat[((size_t)b * M + n) * 2] : 0.f;
+    const float cinv = nin ? 1.0f / A.col_stat[((size_t)b * M + n) * 2 + 1] : 0.f;
+    const float delta2 = nin ? A.delta2[(size_t)b * M + n] : 0.f;
+    const bool mm = nin ? mask_live(A.mod_mask, A.mod_len, b, M, n) : false;
     const float mmf = mm ? 1.f : 0.f;
     const tr_off tr = make_tr_off(lane);
 
-    const int row_begin = split * rps, row_end = (dbg & 16) ? row_begin : min(T, row_begin + rps);
-    float im[3] = {0.f, 0.f, 0.f};
-    for (int i = tid; i < rps; i += NTHR) {
-        const int t = row_begin + i;
-        const bool in = t < min(T, row_begin + rps);
+    float im[4] = {0.f, 0.f, 0.f, 0.f};   // text_d, text, da, db
+    for (int i = tid; i < T; i += NT8) {
+        im[0] = fmaxf(im[0], iTd_b[i]);
+        im[1] = fmaxf(im[1], iT_b[i]);
+        im[2] = fmaxf(im[2], iDa_b[i]);
+        im[3] = fmaxf(im[3], iDb_b[i]);
+    }
+    wg_allmax_w<4, 8>(im, red, tid);
+    const float cDa = cmap(im[2]);
+    // |dS_ij| <= |dP1| + |delta1| + |dP2| + |delta2| <= 2 D 2^28 (inv_da_i inv_mod_j + inv_db_i inv_q_j + inv_t_i inv_dq_j)
+    const float cS = cmap_bound(im[0], 1.3743895e11f /* 2^37 */ * (im[2] * inM + im[3] * inQ + im[1] * inDq));
+
+    const int sck = tid >> 5, scr = tid & 31;
+    auto fetch = [&](int t) -> float {
+        const bool in = t < T;
         const size_t bt = (size_t)b * T + t;
-        rt_all[i] = in ? a.rterm[bt] : 0.f;
-        rmax_all[i] = in ? a.row_stat[bt * 2] : INFINITY;   // exp(x - inf) = 0 beyond the slice
-        rinv_all[i] = in ? 1.0f / a.row_stat[bt * 2 + 1] : 0.f;
-        dl1_all[i] = in ? a.delta1[bt] : 0.f;
-        const float v0 = in ? a.iTd[(size_t)b * Tp + t] : 0.f, v1 = in ? a.iDa[(size_t)b * Tp + t] : 0.f, v2 = in ? a.iDb[(size_t)b * Tp + t] : 0.f;
-        sTd_all[i] = v0; sDa_all[i] = v1; sDb_all[i] = v2;
-        im[0] = fmaxf(im[0], v0); im[1] = fmaxf(im[1], v1); im[2] = fmaxf(im[2], v2);
-    }
-    wg_allmax(im, red, tid);
-    const float cDa = cmap(im[1]), cDb = cmap(im[2]);
-    // |dS1_ij| <= |dP1_ij| + |delta1_i| <= 2 D 2^28 (inv_da_i inv_mod_j + inv_db_i inv_q_j)   (row maxima < 2^14 inv)
-    const float cS = cmap_bound(im[0], 1.3743895e11f /* 2^37 */ * (im[1] * inM + im[2] * inQ));
-
-    acc_t dq, dmc, dmd;
-    zero_acc(dq);
-    zero_acc(dmc);
-    zero_acc(dmd);
-    float dc = 0.f;
-
-    const char* td_b = a.pTd + (size_t)b * szT;
-    const char* da_b = a.pDa + (size_t)b * szT;
-    const char* db_b = a.pDb + (size_t)b * szT;
-    for (int p0 = row_begin; p0 < row_end; p0 += PR) {
-        __syncthreads();
-        if (!(dbg & 1) || p0 == row_begin) {
-            stage_panel(pTd, td_b, p0, tid);
-            stage_panel(pDa, da_b, p0, tid);
-            stage_panel(pDb, db_b, p0, tid);
+        switch (sck) {
+            case 0: return in ? A.rterm[bt] : 0.f;
+            case 1: return in ? A.row_stat[bt * 2] : INFINITY;      // exp(x - inf) = 0 beyond the range
+            case 2: return in ? 1.0f / A.row_stat[bt * 2 + 1] : 0.f;
+            case 3: return in ? A.delta1[bt] : 0.f;
+            case 4: return (float)mask_code(in, A.text_mask, A.text_len, b, T, t);
+            case 5: return in ? iTd_b[t] : 0.f;
+            case 6: return in ? iT_b[t] : 0.f;
+            case 7: return in ? iDa_b[t] : 0.f;
+            default: return in ? iDb_b[t] : 0.f;
         }
-        __syncthreads();
-        const int i0 = p0 - row_begin;
-        f4 s[2], dpa[2], dpb[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) s[q] = dpa[q] = dpb[q] = f4{0.f, 0.f, 0.f, 0.f};
-        if (!(dbg & 2)) {
-            sprod2<false>(pTd, r, g, sideS, s);
-            sprod2<false>(pDa, r, g, sideM, dpa);
-            sprod2<false>(pDb, r, g, sideQ, dpb);
-        }
-        f4 wq[2], wc[2], wd[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ml = i0 + mb * 16 + 4 * g + e;
-                const float x = mm ? s[mb][e] * (sTd_all[ml] * inS) + rt_all[ml] + cterm : NEG;
-                const float p = __expf(x - rmax_all[ml]) * rinv_all[ml];  // rinv = 0 beyond the slice
-                const float dp = dpa[mb][e] * (sDa_all[ml] * inM) + dpb[mb][e] * (sDb_all[ml] * inQ);
-                const float gd = p * (dp - dl1_all[ml]) * mmf;
-                dc += gd;
-                wq[mb][e] = p * (sDb_all[ml] * cDb);
-                wc[mb][e] = p * (sDa_all[ml] * cDa);
-                wd[mb][e] = gd * (sTd_all[ml] * cS);
-            }
-        half8 W0, W1;
-        split_w(wq[0], wq[1], W0, W1);
-        if (!(dbg & 4)) pvprod<1>(pDb, tr, W0, W1, dq);
-        split_w(wc[0], wc[1], W0, W1);
-        if (!(dbg & 4)) pvprod<1>(pDa, tr, W0, W1, dmc);
-        split_w(wd[0], wd[1], W0, W1);
-        if (!(dbg & 4)) pvprod<1>(pTd, tr, W0, W1, dmd);
-    }
-    dc = kg_allsum(dc);
-    if (dbg & 8) return;
-    {
-        float* et = reinterpret_cast<float*>(smem);
-        const int row0 = tile * NW * 16;
-        const size_t prow0 = ((size_t)b * a.splits + split) * M + row0;
-        park_store(et, dq, 1.0f / cDb, a.p_dq + prow0 * D, M - row0, D, tid);
-        park_store(et, dmc, 1.0f / cDa, a.p_dmc + prow0 * D, M - row0, D, tid);
-        park_store(et, dmd, 1.0f / cS, a.p_dmd1 + prow0 * D, M - row0, D, tid);
-        if (nin && g == 0) a.p_dc1[prow0 + (n - row0)] = dc;
-    }
-}
-
-// j-side sweep 2 (needs the complete dq = sum of the sweep-1 partials):
-//   dS2 = P2 (dP2 - delta2_j) mask_i, dP2_ij = text_i . dq_j ; dmodd_j += sum_i dS2_ij text_d_i ; dc_j += sum_i dS2_ij
-//   split 0 also publishes dq_j (as planes) and delta2_j = q_j . dq_j for the i-side pass
-template <bool DBG>
-__global__ __launch_bounds__(NTHR) void att_bwd_j2_kernel(const AttBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int dbg = DBG ? a.dbg : 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, g = lane >> 4;
-    const int T = a.T, M = a.M, D = a.D, Tp = pad32(T), Mp = pad32(M);
-    int tile, split, b;
-    decode_block((M + 16 * NW - 1) / (16 * NW), a.splits, a.B, tile, split, b);
-    const int n = (tile * NW + wave) * 16 + r;
-    const int rps = a.rows_per_split;
-
-    const bool sep = a.pTd != a.pT;
-    const int stage_b = (sep ? 2 : 1) * PANEL_B;
-    const bool db = a.nstage_j2 == 2;
-    float* rt_all = reinterpret_cast<float*>(smem + a.nstage_j2 * stage_b);
-    int* code_all = reinterpret_cast<int*>(rt_all + rps);   // 0 beyond slice, 1 masked, 2 live
-    float* sT_all = rt_all + 2 * rps;
-    float* sTd_all = rt_all + 3 * rps;
-    float* red = rt_all + 4 * rps;
-
-    const size_t szT = planes_sample_bytes(T), szM = planes_sample_bytes(M);
-    side_t sideS, sideDq;
-    float inS, inDq;
-    load_side_planes(sideS, inS, a.pMw + (size_t)b * szM, a.iMw + (size_t)b * Mp, n, M, g);
-    float delta2;
-    {
-        float x[KT][8];
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[kt][j] = 0.f;
-        for (int p = 0; p < a.splits; ++p) {
-            float t[KT][8];
-            load_row_regs(t, a.p_dq + ((size_t)b * a.splits + p) * M * D, n, M, D, g, nullptr);
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x[kt][j] += t[kt][j];
-        }
-        side_t sq;
-        float inQ;
-        load_side_planes(sq, inQ, a.pQ + (size_t)b * szM, a.iQ + (size_t)b * Mp, n, M, g);
-        delta2 = kg_allsum(side_dot_regs(sq, inQ, x));
-        side_from_regs(x, sideDq, inDq);
-    }
-    const bool nin = n < M;
-    if (split == 0 && n < Mp) {   // rows M..Mp-1 are written as zeros (their loads were guarded)
-        char* dst = a.pDq + (size_t)b * szM;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            char* d = dst + pl_off_att(n, 4 * kt + g);
-            *reinterpret_cast<half8*>(d) = sideDq.h[kt][0];
-            *reinterpret_cast<half8*>(d + 1024) = sideDq.h[kt][1];
-        }
-        if (g == 0) {
-            a.iDq[(size_t)b * Mp + n] = inDq;
-            if (nin) a.delta2[(size_t)b * M + n] = delta2;
-        }
-    }
-    const float cterm = nin ? a.cterm[(size_t)b * M + n] : 0.f;
-    const float cmax = nin ? a.col_stat[((size_t)b * M + n) * 2] : 0.f;
-    const float cinv = nin ? 1.0f / a.col_stat[((size_t)b * M + n) * 2 + 1] : 0.f;
-    const tr_off tr = make_tr_off(lane);
-
-    const int row_begin = split * rps, row_end = (dbg & 16) ? row_begin : min(T, row_begin + rps);
-    float im[2] = {0.f, 0.f};
-    for (int i = tid; i < rps; i += NTHR) {
-        const int t = row_begin + i;
-        const bool in = t < min(T, row_begin + rps);
-        rt_all[i] = in ? a.rterm[(size_t)b * T + t] : 0.f;
-        code_all[i] = mask_code(in, a.text_mask, a.text_len, b, T, t);
-        const float v0 = in ? a.iT[(size_t)b * Tp + t] : 0.f, v1 = in ? a.iTd[(size_t)b * Tp + t] : 0.f;
-        sT_all[i] = v0; sTd_all[i] = v1;
-        im[0] = fmaxf(im[0], v0); im[1] = fmaxf(im[1], v1);
-    }
-    wg_allmax(im, red, tid);
-    // |dS2_ij| <= |dP2_ij| + |delta2_j| <= 2 D 2^28 inv_t_i inv_dq_j
-    const float cS = cmap_bound(im[1], 1.3743895e11f * (im[0] * inDq));
-
-    acc_t dmd;
-    zero_acc(dmd);
-    float dc = 0.f;
-    const char* td_b = a.pTd + (size_t)b * szT;
-    const char* t_b = a.pT + (size_t)b * szT;
-    auto stage = [&](char* base, int p0) {
-        if ((dbg & 1) && p0 != row_begin) return;
-        stage_panel(base, t_b, p0, tid);
-        if (sep) stage_panel(base + PANEL_B, td_b, p0, tid);
     };
-    int cur = 0;
-    if (db) {
-        if (row_begin < row_end) stage(smem, row_begin);
+    float sc_next = 0.f;
+    const int Tloop = (dbg & 16) ? 0 : T;
+    if (Tloop > 0 && sck < NSC) sc_next = fetch(scr);
+
+    acc_t O;        // role 0: dmodd (sum_i dS text_d), role 1: dmodc (sum_i P1 da)
+    zero_acc(O);
+    float dc = 0.f;
+    const char* pan1 = role ? pDa : pTd;
+    const char* pan2 = role ? pDb : pT;
+    const char* panV = role ? pDa : pTd;
+    for (int p0 = 0; p0 < Tloop; p0 += PR) {
         __syncthreads();
-    }
-    for (int p0 = row_begin; p0 < row_end; p0 += PR) {
-        char* base = smem + (db ? cur * stage_b : 0);
-        if (db) {
-            if (p0 + PR < row_end) stage(smem + (cur ^ 1) * stage_b, p0 + PR);
-        } else {
-            __syncthreads();
-            stage(base, p0);
-            __syncthreads();
+        stage_panel_w<8>(pTd, td_b, p0, wave, lane);
+        stage_panel_w<8>(pDa, da_b, p0, wave, lane);
+        stage_panel_w<8>(pDb, db_b, p0, wave, lane);
+        if (!SAME) stage_panel_w<8>(pT, t_b, p0, wave, lane);
+        if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+        __syncthreads();
+        if (p0 + PR < Tloop && sck < NSC) sc_next = fetch(p0 + PR + scr);
+        f4 c1[2], c2[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
+        if (!(dbg & 2) && wave_on) {
+            sprod2(pan1, r, g, sa, c1);
+            sprod2(pan2, r, g, sb, c2);
         }
-        const char* pT = base;
-        const char* pTd = sep ? base + PANEL_B : pT;
-        const int i0 = p0 - row_begin;
-        f4 s[2], dp[2];
+        const float* sg = sc + 4 * g;            // scalar k of the lane's 4 rows of block mb: f4 at sg[k * 32 + mb * 16]
+        if (role == 1) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) s[q] = dp[q] = f4{0.f, 0.f, 0.f, 0.f};
-        if (!(dbg & 2)) {
-            sprod2(pTd, r, g, sideS, s);
-            sprod2(pT, r, g, sideDq, dp);
-        }
-        f4 wd[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ml = i0 + mb * 16 + 4 * g + e;
-                const int code = code_all[ml];
-                const float x = code == 2 ? s[mb][e] * (sTd_all[ml] * inS) + rt_all[ml] + cterm : NEG;
-                const float p = code ? __expf(x - cmax) * cinv : 0.f;
-                const float gd = code == 2 ? p * (dp[mb][e] * (sT_all[ml] * inDq) - delta2) : 0.f;
-                dc += gd;
-                wd[mb][e] = gd * (sTd_all[ml] * cS);
+            for (int mb = 0; mb < 2; ++mb) {
+                const f4 sDa = *reinterpret_cast<const f4*>(sg + 7 * 32 + mb * 16), sDb = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16);
+                *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sDa * ina) + c2[mb] * (sDb * inb);
             }
-        half8 W0, W1;
-        split_w(wd[0], wd[1], W0, W1);
-        if (!(dbg & 4)) pvprod(pTd, tr, W0, W1, dmd);
-        if (db) {
-            __syncthreads();
-            cur ^= 1;
         }
+        __syncthreads();
+        half8 W0, W1;
+        if (role == 0) {
+            f4 wc[2], wd[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const f4 dp1 = *reinterpret_cast<const f4*>(xch + mb * 1024);
+                const f4 s_rt = *reinterpret_cast<const f4*>(sg + mb * 16), s_rmax = *reinterpret_cast<const f4*>(sg + 32 + mb * 16);
+                const f4 s_rinv = *reinterpret_cast<const f4*>(sg + 64 + mb * 16), s_dl1 = *reinterpret_cast<const f4*>(sg + 96 + mb * 16);
+                const f4 s_code = *reinterpret_cast<const f4*>(sg + 128 + mb * 16), s_sTd = *reinterpret_cast<const f4*>(sg + 160 + mb * 16);
+                const f4 s_sT = *reinterpret_cast<const f4*>(sg + 192 + mb * 16), s_sDa = *reinterpret_cast<const f4*>(sg + 224 + mb * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float code = s_code[e];
+                    const float xr = c1[mb][e] * (s_sTd[e] * ina) + s_rt[e] + cterm;
+                    const float P1 = __expf((mm ? xr : NEG) - s_rmax[e]) * s_rinv[e];     // 0 beyond the range (rinv = 0)
+                    const float P2 = code != 0.f ? __expf((code == 2.f ? xr : NEG) - cmax) * cinv : 0.f;
+                    const float g1 = P1 * (dp1[e] - s_dl1[e]) * mmf;
+                    const float g2 = code == 2.f ? P2 * (c2[mb][e] * (s_sT[e] * inb) - delta2) : 0.f;
+                    dc += g1 + g2;
+                    wc[mb][e] = P1 * (s_sDa[e] * cDa);
+                    wd[mb][e] = (g1 + g2) * (s_sTd[e] * cS);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            split_w(wc[0], wc[1], W0, W1);
+            xch_put(xch + 2048, W0, W1);
+            split_w(wd[0], wd[1], W0, W1);
+        }
+        __syncthreads();
+        if (role == 1) xch_get(xch + 2048, W0, W1);
+        if (!(dbg & 4) && wave_on) pvprod(panV, tr, W0, W1, O);
     }
     dc = kg_allsum(dc);
-    if (dbg & 8) return;
-    {
-        float* et = reinterpret_cast<float*>(smem);
-        const int row0 = tile * NW * 16;
-        const size_t prow0 = ((size_t)b * a.splits + split) * M + row0;
-        park_store(et, dmd, 1.0f / cS, a.p_dmd2 + prow0 * D, M - row0, D, tid);
-        if (nin && g == 0) a.p_dc2[prow0 + (n - row0)] = dc;
-    }
-}
-
-// j-side epilogue: one wave per JF_ROWS modality rows, lane = 4 features.  Sums the split partials, writes
-//   d_mod_d_j = dc_j w_m + w_tm * dmodd_j ;  d_mod_j = dmodc_j (+ d_mod_d_j when folded)
-// and accumulates d_w_m += sum_j dc_j mod_d[j,:]: registers over the wave's rows, LDS across the 4 waves, then ONE
-// atomic per feature and workgroup with consecutive lanes on consecutive addresses.
-template <int JF_ROWS>
-__device__ __forceinline__ void att_bwd_jfin_body(const AttBwdArgs& a, int B, int block, float (*wred)[256]) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int chunk = block * 4 + wave;
-    const int M = a.M, D = a.D, S = a.splits;
-    const int rows = B * M;
-    const int d = lane * 4;
-    const bool din = d < D;
-    const f4 wm = din ? *reinterpret_cast<const f4*>(a.w_m + d) : f4{0.f, 0.f, 0.f, 0.f};
-    const f4 wtm = din ? *reinterpret_cast<const f4*>(a.w_tm + d) : f4{0.f, 0.f, 0.f, 0.f};
-    float dc[JF_ROWS];
-    f4 c[JF_ROWS], dd[JF_ROWS];
-    size_t base[JF_ROWS];
-#pragma unroll
-    for (int rr = 0; rr < JF_ROWS; ++rr) {
-        const int row = min(chunk * JF_ROWS + rr, rows - 1);
-        const int b = row / M, n = row % M;
-        base[rr] = (size_t)b * S * M + n;
-        dc[rr] = 0.f;
-        c[rr] = dd[rr] = f4{0.f, 0.f, 0.f, 0.f};
-    }
-    const int dsafe = din ? d : 0;   // lanes beyond D read column 0 and drop it: no branch around the loads, so that all
-                                     // 3 * JF_ROWS vector loads of a split are in flight together
-    for (int p = 0; p < S; ++p) {
-        f4 vc[JF_ROWS], v1[JF_ROWS], v2[JF_ROWS];
-        float s1[JF_ROWS], s2[JF_ROWS];
-#pragma unroll
-        for (int rr = 0; rr < JF_ROWS; ++rr) {
-            const size_t prow = base[rr] + (size_t)p * M;
-            s1[rr] = a.p_dc1[prow];
-            s2[rr] = a.p_dc2[prow];
-            vc[rr] = *reinterpret_cast<const f4*>(a.p_dmc + prow * D + dsafe);
-            v1[rr] = *reinterpret_cast<const f4*>(a.p_dmd1 + prow * D + dsafe);
-            v2[rr] = *reinterpret_cast<const f4*>(a.p_dmd2 + prow * D + dsafe);
-        }
-#pragma unroll
-        for (int rr = 0; rr < JF_ROWS; ++rr) {
-            dc[rr] += s1[rr] + s2[rr];
-            c[rr] += vc[rr];
-            dd[rr] += v1[rr];
-            dd[rr] += v2[rr];
-        }
-    }
-    f4 wacc = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int rr = 0; rr < JF_ROWS; ++rr) {
-        const int row = chunk * JF_ROWS + rr;
-        if (row < rows && din) {
-            const f4 gd = wm * dc[rr] + wtm * dd[rr];
-            if (a.fold) {
-                *reinterpret_cast<f4*>(a.d_mod + (size_t)row * D + d) = c[rr] + gd;
-            } else {
-                *reinterpret_cast<f4*>(a.d_mod + (size_t)row * D + d) = c[rr];
-                *reinterpret_cast<f4*>(a.d_mod_d + (size_t)row * D + d) = gd;
-            }
-            wacc += *reinterpret_cast<const f4*>(a.mod_d + (size_t)row * D + d) * dc[rr];
-        }
-    }
-    *reinterpret_cast<f4*>(&wred[wave][d]) = wacc;
     __syncthreads();
-    const int t = threadIdx.x;
-    if (t < D) atomicAdd(a.d_w_m + t, (wred[0][t] + wred[1][t]) + (wred[2][t] + wred[3][t]));
-}
-__device__ __forceinline__ void att_bwd_jfin_dispatch(const AttBwdArgs& a, int block, float (*wred)[256]) {
-    switch (a.jf_rows) {
-        case 8: att_bwd_jfin_body<8>(a, a.B, block, wred); break;
-        case 4: att_bwd_jfin_body<4>(a, a.B, block, wred); break;
-        case 2: att_bwd_jfin_body<2>(a, a.B, block, wred); break;
-        default: att_bwd_jfin_body<1>(a, a.B, block, wred); break;
+    if (dbg & 8) return;
+    // ---- epilogue: role 0 parks dmodd and dc, role 1 parks dmodc; then whole rows, one per wave-instruction
+    float* eD = reinterpret_cast<float*>(smem);                 // [64][LDP]  sum_i dS text_d
+    float* eC = eD + 64 * LDP;                                  // [64][LDP]  sum_i P1 da
+    float* dcs = eC + 64 * LDP;                                 // [64]
+    float* part = dcs + 64;                                     // [8][256] per-wave partial sums of d_w_m
+    {
+        float* dstt = role ? eC : eD;
+        const float scale = role ? 1.0f / cDa : 1.0f / cS;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(dstt + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
+        if (role == 0 && g == 0) dcs[w4 * 16 + r] = nin ? dc : 0.f;
+    }
+    __syncthreads();
+    const int row0 = tile * 64, d4 = 4 * lane;
+    const bool cin = d4 < D;
+    const f4 wm = cin ? *reinterpret_cast<const f4*>(A.w_m + d4) : f4{0.f, 0.f, 0.f, 0.f};
+    const f4 wtm = cin ? *reinterpret_cast<const f4*>(A.w_tm + d4) : f4{0.f, 0.f, 0.f, 0.f};
+    const bool fold = A.d_mod_d == nullptr;
+    f4 pw = f4{0.f, 0.f, 0.f, 0.f};
+    f4 mdv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int gn = row0 + wave + 8 * k;
+        mdv[k] = (gn < M && cin) ? *reinterpret_cast<const f4*>(A.mod_d + ((size_t)b * M + gn) * D + d4) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int rr = wave + 8 * k, gn = row0 + rr;
+        if (gn < M && cin) {
+            const f4 dd = *reinterpret_cast<const f4*>(eD + rr * LDP + d4);
+            const f4 cc = *reinterpret_cast<const f4*>(eC + rr * LDP + d4);
+            const float dcr = dcs[rr];
+            const f4 gd = wm * dcr + wtm * dd;
+            const size_t o = ((size_t)b * M + gn) * D + d4;
+            if (fold) {
+                *reinterpret_cast<f4*>(A.d_mod + o) = cc + gd;
+            } else {
+                *reinterpret_cast<f4*>(A.d_mod + o) = cc;
+                *reinterpret_cast<f4*>(A.d_mod_d + o) = gd;
+            }
+            pw += mdv[k] * dcr;
+        }
+    }
+    *reinterpret_cast<f4*>(part + wave * 256 + d4) = pw;
+    __syncthreads();
+    if (tid < D) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) acc += part[w * 256 + tid];
+        atomicAdd(A.d_w_m + tid, acc);
     }
 }
-// stand-alone launch of the j-side epilogue (timing tools, MMB_ATT_JFIN_SEPARATE=1); by default its workgroups ride in the
-// launch of att_bwd_i_kernel, which leaves 32 of the 256 CUs idle and does not depend on them
-__global__ __launch_bounds__(256) void att_bwd_jfin_kernel(const AttBwdArgs a) {
-    __shared__ float wred[4][256];
-    att_bwd_jfin_dispatch(a, blockIdx.x, wred);
-}
 
-// i-side pass (lane side = text rows i, streams all modality rows j):
-//   dS = P1 (dP1 - delta1_i) mask_j + P2 (dP2 - delta2_j) mask_i
-//   d_text_i += sum_j P2_ij dq_j ; dX_i = sum_j dS_ij mod_d_j ; dr_i = sum_j dS_ij
-//   d_text_d_i = dr_i w_t + w_tm * dX_i ; d_w_t += dr_i text_d_i ; d_w_tm += dX_i * text_d_i ; d_bias += dr_i
-// SAME = no dropped copies (text_d == text, mod_d == mod): the similarity is then formed as text . (mod * w_tm) -- lane side
-// = the text planes the dP2 product needs anyway, streamed side = the w_tm-folded modality planes -- so the pass carries
-// three lane-side operands (168 registers) instead of four and reads one 11.5-MB plane set less.
 template <bool DBG, bool SAME>
-__global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, int local, char* smem) {
     const int dbg = DBG ? a.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int role = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
     const int r = lane & 15, g = lane >> 4;
-    const int T = a.T, M = a.M, D = a.D, Mp = pad32(M);
-    if ((int)blockIdx.x >= a.i_blocks) {
-        // passenger workgroups: the j-side epilogue (sums of the split partials -> d_mod, d_mod_d, d_w_m).  It depends on the
-        // two j sweeps only, like this pass, whose T/64 * B workgroups (224 at the metric configuration) leave CUs idle.
-        att_bwd_jfin_dispatch(a, blockIdx.x - a.i_blocks, reinterpret_cast<float(*)[256]>(smem));
-        return;
-    }
-    int tile, split, b;
-    decode_block((T + 16 * NW - 1) / (16 * NW), 1, a.B, tile, split, b);
-    const int n = (tile * NW + wave) * 16 + r;  // text row i
+    const int T = A.T, M = A.M, D = a.D, Tp = pad32(T), Mp = pad32(M);
+    int tile, b;
+    if (!decode_local(local, (T + 63) / 64, a.B, tile, b)) return;
+    const int n = (tile * 4 + w4) * 16 + r;  // text row i
+    const bool wave_on = (tile * 4 + w4) * 16 < T;
+    const bool nin = n < T;
 
-    const bool sep = a.pMd != a.pM;
     char* pM = smem;
     char* pQ = smem + PANEL_B;
     char* pDq = smem + 2 * PANEL_B;
-    char* pMd = sep ? smem + 3 * PANEL_B : pM;
-    char* pSp = SAME ? smem + 3 * PANEL_B : pMd;      // streamed S operand: mod * w_tm (SAME) or the dropped copy mod_d
-    float* ct_all = reinterpret_cast<float*>(smem + 4 * PANEL_B);   // per-row scalars of ALL modality rows
-    float* cmax_all = ct_all + Mp;
-    float* cinv_all = ct_all + 2 * Mp;     // 0 beyond M
-    float* dl2_all = ct_all + 3 * Mp;
-    float* mmf_all = ct_all + 4 * Mp;      // modality mask as float, -1 beyond M
-    float* sM_all = ct_all + 5 * Mp;
-    float* sMd_all = ct_all + 6 * Mp;
-    float* sQ_all = ct_all + 7 * Mp;
-    float* sDq_all = ct_all + 8 * Mp;
-    float* sSp_all = ct_all + 9 * Mp;      // inverse row scales of the streamed S operand
-    float* red = ct_all + 10 * Mp;
+    char* pSp = smem + 3 * PANEL_B;          // streamed similarity operand: mod * w_tm (SAME) or the dropped copy mod_d
+    char* pMd = SAME ? pM : pSp;             // value rows of dX = sum_j dS mod_d
+    constexpr int NSC = 10;
+    float* sc = reinterpret_cast<float*>(smem + 4 * PANEL_B);    // [NSC][32]
+    char* xch = reinterpret_cast<char*>(sc + NSC * 32) + w4 * XCH_PAIR + lane * 16;
+    float* red = reinterpret_cast<float*>(smem + 4 * PANEL_B + NSC * 32 * 4 + 4 * XCH_PAIR);
 
     const size_t szT = planes_sample_bytes(T), szM = planes_sample_bytes(M);
-    side_t sideS_, sideDa, sideDb, sideT;
-    float inS_ = 0.f, inDa, inDb, inT;
-    if (!SAME) load_side_planes(sideS_, inS_, a.pTw + (size_t)b * szT, a.iTw + (size_t)b * pad32(T), n, T, g);
-    load_side_planes(sideDa, inDa, a.pDa + (size_t)b * szT, a.iDa + (size_t)b * pad32(T), n, T, g);
-    load_side_planes(sideDb, inDb, a.pDb + (size_t)b * szT, a.iDb + (size_t)b * pad32(T), n, T, g);
-    load_side_planes(sideT, inT, a.pT + (size_t)b * szT, a.iT + (size_t)b * pad32(T), n, T, g);
-    const side_t& sideS = SAME ? sideT : sideS_;
-    const float inS = SAME ? inT : inS_;
-    const bool nin = n < T;
-    const float rterm = nin ? a.rterm[(size_t)b * T + n] : 0.f;
-    const float rmax = nin ? a.row_stat[((size_t)b * T + n) * 2] : 0.f;
-    const float rinv = nin ? 1.0f / a.row_stat[((size_t)b * T + n) * 2 + 1] : 0.f;
-    const float dl1 = nin ? a.delta1[(size_t)b * T + n] : 0.f;
-    const bool tm = nin ? mask_live(a.text_mask, a.text_len, b, T, n) : false;
+    const char* m_b = A.pM + (size_t)b * szM;
+    const char* q_b = A.pQ + (size_t)b * szM;
+    const char* dq_b = A.pDq + (size_t)b * szM;
+    const char* sp_b = (SAME ? A.pMw : A.pMd) + (size_t)b * szM;
+    const float* iM_b = A.iM + (size_t)b * Mp;
+    const float* iMd_b = A.iMd + (size_t)b * Mp;
+    const float* iQ_b = A.iQ + (size_t)b * Mp;
+    const float* iDq_b = A.iDq + (size_t)b * Mp;
+    const float* iSp_b = (SAME ? A.iMw : A.iMd) + (size_t)b * Mp;
+
+    // lane-side operands: role 0 = {similarity operand, text (dP2)}, role 1 = {da, db}.  Without dropped copies the
+    // similarity is formed as text . (mod * w_tm): the text planes serve both products of role 0.
+    side_t sa, sb;
+    float ina, inb;
+    if (role == 0) {
+        load_side_planes(sb, inb, A.pT + (size_t)b * szT, A.iT + (size_t)b * Tp, n, T, g);
+        if (SAME) ina = inb;      // both products of role 0 use the text planes: ONE lane-side operand
+        else load_side_f32(sa, ina, A.text_d + (size_t)b * T * D, n, T, D, g, A.w_tm);
+    } else {
+        load_side_planes(sa, ina, A.pDa + (size_t)b * szT, A.iDa + (size_t)b * Tp, n, T, g);
+        load_side_planes(sb, inb, A.pDb + (size_t)b * szT, A.iDb + (size_t)b * Tp, n, T, g);
+    }
+    const float inDa = nin ? A.iDa[(size_t)b * Tp + n] : 0.f, inDb = nin ? A.iDb[(size_t)b * Tp + n] : 0.f;
+    const float inT = nin ? A.iT[(size_t)b * Tp + n] : 0.f;
+    const float rterm = nin ? A.rterm[(size_t)b * T + n] : 0.f;
+    const float rmax = nin ? A.row_stat[((size_t)b * T + n) * 2] : 0.f;
+    const float rinv = nin ? 1.0f / A.row_stat[((size_t)b * T + n) * 2 + 1] : 0.f;
+    const float dl1 = nin ? A.delta1[(size_t)b * T + n] : 0.f;
+    const bool tm = nin ? mask_live(A.text_mask, A.text_len, b, T, n) : false;
     const float tmf = tm ? 1.f : 0.f;
     const tr_off tr = make_tr_off(lane);
 
     float im[4] = {0.f, 0.f, 0.f, 0.f};   // mod, mod_d, q, dq
-    for (int j = tid; j < Mp; j += NTHR) {
+    for (int j = tid; j < M; j += NT8) {
+        im[0] = fmaxf(im[0], iM_b[j]);
+        im[1] = fmaxf(im[1], iMd_b[j]);
+        im[2] = fmaxf(im[2], iQ_b[j]);
+        im[3] = fmaxf(im[3], iDq_b[j]);
+    }
+    wg_allmax_w<4, 8>(im, red, tid);
+    const float cDq = cmap(im[3]);
+    const float cS = cmap_bound(im[1], 1.3743895e11f /* 2^37 */ * (inDa * im[0] + inDb * im[2] + im[3] * inT));   // the same value in both roles
+
+    const int sck = tid >> 5, scr = tid & 31;
+    auto fetch = [&](int j) -> float {
         const bool in = j < M;
         const size_t bj = (size_t)b * M + j;
-        ct_all[j] = in ? a.cterm[bj] : 0.f;
-        cmax_all[j] = in ? a.col_stat[bj * 2] : 0.f;
-        cinv_all[j] = in ? 1.0f / a.col_stat[bj * 2 + 1] : 0.f;
-        dl2_all[j] = in ? a.delta2[bj] : 0.f;
-        mmf_all[j] = in ? (mask_live(a.mod_mask, a.mod_len, b, M, j) ? 1.f : 0.f) : -1.f;
-        const size_t pj = (size_t)b * Mp + j;
-        const float v0 = in ? a.iM[pj] : 0.f, v1 = in ? a.iMd[pj] : 0.f, v2 = in ? a.iQ[pj] : 0.f, v3 = in ? a.iDq[pj] : 0.f;
-        sM_all[j] = v0; sMd_all[j] = v1; sQ_all[j] = v2; sDq_all[j] = v3;
-        sSp_all[j] = SAME ? (in ? a.iMw[pj] : 0.f) : v1;
-        im[0] = fmaxf(im[0], v0); im[1] = fmaxf(im[1], v1); im[2] = fmaxf(im[2], v2); im[3] = fmaxf(im[3], v3);
-    }
-    wg_allmax(im, red, tid);
-    const float cDq = cmap(im[3]);
-    const float cS = cmap_bound(im[1], 1.3743895e11f * (inDa * im[0] + inDb * im[2] + im[3] * inT));
-
-    acc_t dtx, dX;
-    zero_acc(dtx);
-    zero_acc(dX);
-    float dr = 0.f;
-    const char* m_b = a.pM + (size_t)b * szM;
-    const char* md_b = a.pMd + (size_t)b * szM;
-    const char* q_b = a.pQ + (size_t)b * szM;
-    const char* dq_b = a.pDq + (size_t)b * szM;
-    const char* sp_b = a.pMw + (size_t)b * szM;
+        switch (sck) {
+            case 0: return in ? A.cterm[bj] : 0.f;
+            case 1: return in ? A.col_stat[bj * 2] : 0.f;
+            case 2: return in ? 1.0f / A.col_stat[bj * 2 + 1] : 0.f;
+            case 3: return in ? A.delta2[bj] : 0.f;
+            case 4: return in ? (mask_live(A.mod_mask, A.mod_len, b, M, j) ? 1.f : 0.f) : -1.f;   // modality mask, -1 beyond M
+            case 5: return in ? iSp_b[j] : 0.f;
+            case 6: return in ? iDq_b[j] : 0.f;
+            case 7: return in ? iMd_b[j] : 0.f;
+            case 8: return in ? iM_b[j] : 0.f;
+            default: return in ? iQ_b[j] : 0.f;
+        }
+    };
+    float sc_next = 0.f;
     const int Mloop = (dbg & 16) ? 0 : M;
+    if (Mloop > 0 && sck < NSC) sc_next = fetch(scr);
+
+    acc_t O;        // role 0: sum_j P2 dq, role 1: dX = sum_j dS mod_d
+    zero_acc(O);
+    float dr = 0.f;
+    const char* pan1 = role ? pM : pSp;
+    const char* pan2 = role ? pQ : pDq;
+    const char* panV = role ? pMd : pDq;
     for (int p0 = 0; p0 < Mloop; p0 += PR) {
         __syncthreads();
-        if (!(dbg & 1) || p0 == 0) {
-            stage_panel(pM, m_b, p0, tid);
-            stage_panel(pQ, q_b, p0, tid);
-            stage_panel(pDq, dq_b, p0, tid);
-            if (SAME) stage_panel(pSp, sp_b, p0, tid);
-            else if (sep) stage_panel(pMd, md_b, p0, tid);
+        stage_panel_w<8>(pM, m_b, p0, wave, lane);
+        stage_panel_w<8>(pQ, q_b, p0, wave, lane);
+        stage_panel_w<8>(pDq, dq_b, p0, wave, lane);
+        stage_panel_w<8>(pSp, sp_b, p0, wave, lane);
+        if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+        __syncthreads();
+        if (p0 + PR < Mloop && sck < NSC) sc_next = fetch(p0 + PR + scr);
+        f4 c1[2], c2[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
+        if (!(dbg & 2) && wave_on) {
+            if (SAME && role == 0) {
+                sprod2(pSp, r, g, sb, c1);
+                sprod2(pDq, r, g, sb, c2);
+            } else {
+                sprod2(pan1, r, g, sa, c1);
+                sprod2(pan2, r, g, sb, c2);
+            }
+        }
+        const float* sg = sc + 4 * g;            // scalar k of the lane's 4 rows of block mb: f4 at sg[k * 32 + mb * 16]
+        if (role == 1) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const f4 sM = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16), sQ = *reinterpret_cast<const f4*>(sg + 9 * 32 + mb * 16);
+                *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sM * ina) + c2[mb] * (sQ * inb);
+            }
         }
         __syncthreads();
-        f4 s[2], dpa[2], dpb[2], dp2[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) s[q] = dpa[q] = dpb[q] = dp2[q] = f4{0.f, 0.f, 0.f, 0.f};
-        if (!(dbg & 2)) {
-            sprod2<false>(pSp, r, g, sideS, s);
-            sprod2<false>(pM, r, g, sideDa, dpa);
-            sprod2<false>(pQ, r, g, sideDb, dpb);
-            sprod2<false>(pDq, r, g, sideT, dp2);
-        }
-        f4 wt[2], wx[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ml = p0 + mb * 16 + 4 * g + e;
-                const float mf = mmf_all[ml];
-                const float x = s[mb][e] * (sSp_all[ml] * inS) + rterm + ct_all[ml];
-                const float P1 = mf >= 0.f ? __expf((mf > 0.f ? x : NEG) - rmax) * rinv : 0.f;
-                const float P2 = mf >= 0.f ? __expf((tm ? x : NEG) - cmax_all[ml]) * cinv_all[ml] : 0.f;
-                const float dp1 = dpa[mb][e] * (sM_all[ml] * inDa) + dpb[mb][e] * (sQ_all[ml] * inDb);
-                const float g1 = mf > 0.f ? P1 * (dp1 - dl1) : 0.f;
-                const float g2 = P2 * (dp2[mb][e] * (sDq_all[ml] * inT) - dl2_all[ml]) * tmf;
-                dr += g1 + g2;
-                wt[mb][e] = P2 * (sDq_all[ml] * cDq);
-                wx[mb][e] = (g1 + g2) * (sMd_all[ml] * cS);
-            }
         half8 W0, W1;
-        split_w(wt[0], wt[1], W0, W1);
-        if (!(dbg & 4)) pvprod<1>(pDq, tr, W0, W1, dtx);
-        split_w(wx[0], wx[1], W0, W1);
-        if (!(dbg & 4)) pvprod<1>(pMd, tr, W0, W1, dX);
+        if (role == 0) {
+            f4 wt[2], wx[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const f4 dp1 = *reinterpret_cast<const f4*>(xch + mb * 1024);
+                const f4 s_ct = *reinterpret_cast<const f4*>(sg + mb * 16), s_cmax = *reinterpret_cast<const f4*>(sg + 32 + mb * 16);
+                const f4 s_cinv = *reinterpret_cast<const f4*>(sg + 64 + mb * 16), s_dl2 = *reinterpret_cast<const f4*>(sg + 96 + mb * 16);
+                const f4 s_mf = *reinterpret_cast<const f4*>(sg + 128 + mb * 16), s_sSp = *reinterpret_cast<const f4*>(sg + 160 + mb * 16);
+                const f4 s_sDq = *reinterpret_cast<const f4*>(sg + 192 + mb * 16), s_sMd = *reinterpret_cast<const f4*>(sg + 224 + mb * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float mf = s_mf[e];
+                    const float x = c1[mb][e] * (s_sSp[e] * ina) + rterm + s_ct[e];
+                    const float P1 = mf >= 0.f ? __expf((mf > 0.f ? x : NEG) - rmax) * rinv : 0.f;
+                    const float P2 = mf >= 0.f ? __expf((tm ? x : NEG) - s_cmax[e]) * s_cinv[e] : 0.f;
+                    const float g1 = mf > 0.f ? P1 * (dp1[e] - dl1) : 0.f;
+                    const float g2 = P2 * (c2[mb][e] * (s_sDq[e] * inb) - s_dl2[e]) * tmf;
+                    dr += g1 + g2;
+                    wt[mb][e] = P2 * (s_sDq[e] * cDq);
+                    wx[mb][e] = (g1 + g2) * (s_sMd[e] * cS);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            split_w(wx[0], wx[1], W0, W1);
+            xch_put(xch + 2048, W0, W1);
+            split_w(wt[0], wt[1], W0, W1);
+        }
+        __syncthreads();
+        if (role == 1) xch_get(xch + 2048, W0, W1);
+        if (!(dbg & 4) && wave_on) pvprod(panV, tr, W0, W1, O);
     }
     dr = kg_allsum(dr);
+    __syncthreads();
     if (dbg & 8) return;
-    const float sdtx = 1.0f / cDq, sdX = 1.0f / cS;
-    // ---- epilogue.  The accumulator tiles hold 16 rows x 64-B pieces per instruction; the workgroup parks dX and the
-    // P2.dq sum in LDS (the panels are dead) and then works on whole rows -- one text row per wave-instruction, lane = 16-B
-    // chunk -- so that text_d, the d_text read-modify-write and d_text_d are fully coalesced, and the parameter-gradient
-    // sums over rows (d_w_t, d_w_tm) are plain per-lane accumulations over the wave's 16 rows (no cross-lane reduction).
+    // ---- epilogue.  The accumulator tiles hold 16 rows x 64-B pieces per instruction; role 1 parks dX, role 0 the P2.dq
+    // sum and dr in LDS (the panels are dead) and the workgroup then works on whole rows -- one text row per
+    // wave-instruction, lane = 16-B chunk -- so that text_d, the d_text read-modify-write and d_text_d are fully coalesced,
+    // and the parameter-gradient sums over rows (d_w_t, d_w_tm) are per-lane accumulations over the wave's rows.
     float* eX = reinterpret_cast<float*>(smem);                 // [64][LDP]  dX
-    float* eT = eX + 16 * NW * LDP;                             // [64][LDP]  sum_j P2 dq
-    float* drs = eT + 16 * NW * LDP;                            // [64]       dr
-    float* part = drs + 16 * NW;                                // [NW][2][256] per-wave partial sums of d_w_t, d_w_tm
-    __syncthreads();
+    float* eT = eX + 64 * LDP;                                  // [64][LDP]  sum_j P2 dq
+    float* drs = eT + 64 * LDP;                                 // [64]       dr
+    float* part = drs + 64;                                     // [8][2][256] per-wave partial sums of d_w_t, d_w_tm
+    {
+        float* dstt = role ? eX : eT;
+        const float scale = role ? 1.0f / cS : 1.0f / cDq;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        *reinterpret_cast<f4*>(eX + (wave * 16 + r) * LDP + 16 * dt + 4 * g) = dX[dt] * sdX;
-        *reinterpret_cast<f4*>(eT + (wave * 16 + r) * LDP + 16 * dt + 4 * g) = dtx[dt] * sdtx;
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(dstt + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
+        if (role == 0 && g == 0) drs[w4 * 16 + r] = nin ? dr : 0.f;
     }
-    if (g == 0) drs[wave * 16 + r] = nin ? dr : 0.f;
     __syncthreads();
-    const int row0 = tile * NW * 16, d4 = 4 * lane;
+    const int row0 = tile * 64, d4 = 4 * lane;
     const bool cin = d4 < D;
-    const f4 wt4 = cin ? *reinterpret_cast<const f4*>(a.w_t + d4) : f4{0.f, 0.f, 0.f, 0.f};
-    const f4 wtm = cin ? *reinterpret_cast<const f4*>(a.w_tm + d4) : f4{0.f, 0.f, 0.f, 0.f};
+    const f4 wt4 = cin ? *reinterpret_cast<const f4*>(A.w_t + d4) : f4{0.f, 0.f, 0.f, 0.f};
+    const f4 wtm = cin ? *reinterpret_cast<const f4*>(A.w_tm + d4) : f4{0.f, 0.f, 0.f, 0.f};
+    const bool fold = A.d_text_d == nullptr;
     f4 pt = f4{0.f, 0.f, 0.f, 0.f}, ptm = pt;
-    f4 tdv[16], prev[16];
+    f4 tdv[8], prev[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {   // all loads of the wave's 16 rows in flight together
-        const int gn = row0 + wave + NW * k;
+    for (int k = 0; k < 8; ++k) {   // all loads of the wave's 8 rows in flight together
+        const int gn = row0 + wave + 8 * k;
         const bool ok = gn < T && cin;
         const size_t o = ((size_t)b * T + min(gn, T - 1)) * D + d4;
-        tdv[k] = ok ? *reinterpret_cast<const f4*>(a.text_d + o) : f4{0.f, 0.f, 0.f, 0.f};
-        prev[k] = ok ? *reinterpret_cast<const f4*>(a.d_text + o) : f4{0.f, 0.f, 0.f, 0.f};   // g0 + g2*a + g3*b from the prologue
+        tdv[k] = ok ? *reinterpret_cast<const f4*>(A.text_d + o) : f4{0.f, 0.f, 0.f, 0.f};
+        prev[k] = ok ? *reinterpret_cast<const f4*>(A.d_text + o) : f4{0.f, 0.f, 0.f, 0.f};   // g0 + g2*a + g3*b from the prologue
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int rr = wave + NW * k, gn = row0 + rr;
+    for (int k = 0; k < 8; ++k) {
+        const int rr = wave + 8 * k, gn = row0 + rr;
         if (gn < T && cin) {
             const f4 dXv = *reinterpret_cast<const f4*>(eX + rr * LDP + d4);
             const f4 dtv = *reinterpret_cast<const f4*>(eT + rr * LDP + d4);
             const float drr = drs[rr];
             const f4 gd = wt4 * drr + wtm * dXv;
             const size_t o = ((size_t)b * T + gn) * D + d4;
-            if (a.fold) {
-                *reinterpret_cast<f4*>(a.d_text + o) = prev[k] + dtv + gd;
+            if (fold) {
+                *reinterpret_cast<f4*>(A.d_text + o) = prev[k] + dtv + gd;
             } else {
-                *reinterpret_cast<f4*>(a.d_text + o) = prev[k] + dtv;
-                *reinterpret_cast<f4*>(a.d_text_d + o) = gd;
+                *reinterpret_cast<f4*>(A.d_text + o) = prev[k] + dtv;
+                *reinterpret_cast<f4*>(A.d_text_d + o) = gd;
             }
             pt += tdv[k] * drr;
             ptm += tdv[k] * dXv;
@@ -1661,58 +1554,41 @@ __global__ __launch_bounds__(NTHR) void att_bwd_i_kernel(const AttBwdArgs a) {
     *reinterpret_cast<f4*>(part + (wave * 2 + 1) * 256 + d4) = ptm;
     __syncthreads();
     {
-        const int which = tid >> 7 ? 1 : 0, i = tid & 127;   // 2 x 128 threads x 2 features cover d_w_t | d_w_tm (D <= 208)
+        const int which = tid >> 8, d = tid & 255;   // 2 x 256 threads cover d_w_t | d_w_tm (D <= 208)
+        if (d < D) {
+            float acc = 0.f;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int d = i + 128 * h;
-            if (d < D) {
-                float acc = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) acc += part[(w * 2 + which) * 256 + d];
-                atomicAdd((which ? a.d_w_tm : a.d_w_t) + d, acc);
-            }
+            for (int w = 0; w < 8; ++w) acc += part[(w * 2 + which) * 256 + d];
+            atomicAdd((which ? A.d_w_tm : A.d_w_t) + d, acc);
         }
     }
     if (wave == 0) {
-        const float sb = wave_allsum(drs[lane]);
-        if (lane == 0) atomicAdd(a.d_bias, sb);
+        const float sb_ = wave_allsum(drs[lane]);
+        if (lane == 0) atomicAdd(A.d_bias, sb_);
     }
 }
+
+template <bool DBG, bool SAME>
+__global__ __launch_bounds__(NT8) void att_bwd_sweep_kernel(const GroupArgs a, const SweepMap sm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int local;
+    if ((int)blockIdx.x < sm.i_begin) {
+        const AttG& A = a.g[find_att(sm.j, a.n, blockIdx.x, local)];
+        sweep_j_body<DBG, SAME>(a, A, local, smem);
+    } else {
+        const AttG& A = a.g[find_att(sm.i, a.n, blockIdx.x, local)];
+        sweep_i_body<DBG, SAME>(a, A, local, smem);
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------ host side
-// How many ways to split the streamed side (R rows, PR-row panels) of a sweep whose lane side has N rows per sample:
-// the workgroups (4 waves = 64 lane-side rows each) run in rounds of `slots` (256 CUs x workgroups that fit a CU),
-// so the cost is rounds x (panels per split + fixed per-workgroup work) plus the traffic of the per-split partials.
-static int pick_splits(int B, int N, int R, int slots = 256) {
-    const long tiles = (long)B * ((N + 63) / 64);
-    const int smax = (R + PR - 1) / PR;
-    int best = 1;
-    double best_cost = 1e30;
-    for (int s = 1; s <= smax; ++s) {
-        const long rounds = (tiles * s + slots - 1) / slots;
-        const int panels = ((R + s - 1) / s + PR - 1) / PR;
-        const double cost = (double)rounds * (panels + 1.5) + 0.15 * s;
-        if (cost < best_cost) { best_cost = cost; best = s; }
-    }
-    return best;
-}
-// tuning aid (tools/att_bench.py): MMB_ATT_FSPLIT / MMB_ATT_BSPLIT force the number of splits of the column pass / of
-// the backward j sweeps (read at every call)
-static int forced_splits(const char* name, int R) {
-    const char* e = getenv(name);
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? (v < (R + PR - 1) / PR ? v : (R + PR - 1) / PR) : 0;
-}
-static int rows_per_split(int R, int splits) {
-    int rp = (R + splits - 1) / splits;
-    return (rp + PR - 1) / PR * PR;
-}
-
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
-// saved-for-backward buffer of the fused path: planes + inverse row scales of text, mod, q (and of the dropped copies)
+// saved-for-backward buffer of the fused path: planes + inverse row scales of text, mod, q, of the dropped copies (training
+// mode) or of mod * w_tm (eval mode: the streamed similarity operand of the i sweep)
 struct SavedLayout {
-    size_t pT, pTd, pM, pMd, pQ, pTw, pMw, iT, iTd, iM, iMd, iQ, iTw, iMw, total;
+    size_t pT, pTd, pM, pMd, pMw, pQ, iT, iTd, iM, iMd, iMw, iQ, total;
 };
 static SavedLayout saved_layout(int B, int T, int M, int drop) {
     SavedLayout L{};
@@ -1724,29 +1600,23 @@ static SavedLayout saved_layout(int B, int T, int M, int drop) {
     L.pTd = drop ? take(szT) : L.pT;
     L.pM = take(szM);
     L.pMd = drop ? take(szM) : L.pM;
+    L.pMw = drop ? L.pM : take(szM);
     L.pQ = take(szM);
-    L.pTw = take(szT);
-    L.pMw = take(szM);
     L.iT = take(nT);
     L.iTd = drop ? take(nT) : L.iT;
     L.iM = take(nM);
     L.iMd = drop ? take(nM) : L.iM;
+    L.iMw = drop ? L.iM : take(nM);
     L.iQ = take(nM);
-    L.iTw = take(nT);
-    L.iMw = take(nM);
     L.total = o;
     return L;
 }
 
 struct BwdWs {
-    size_t pDa, pDb, pDq, iDa, iDb, iDq, delta1, delta2, p_dq, p_dmc, p_dmd1, p_dmd2, p_dc1, p_dc2, total;   // bytes
-    int splits;
+    size_t pDa, pDb, pDq, iDa, iDb, iDq, delta1, delta2, total;   // bytes
 };
-static BwdWs bwd_layout(int B, int T, int M, int D) {
+static BwdWs bwd_layout(int B, int T, int M) {
     BwdWs w{};
-    w.splits = pick_splits(B, M, T);
-    if (int f = forced_splits("MMB_ATT_BSPLIT", T)) w.splits = f;
-    const size_t S = w.splits;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += align256(bytes); return at; };
     const size_t szT = planes_sample_bytes(T) * B, szM = planes_sample_bytes(M) * B;
@@ -1758,29 +1628,28 @@ static BwdWs bwd_layout(int B, int T, int M, int D) {
     w.iDq = take((size_t)B * pad32(M) * 4);
     w.delta1 = take((size_t)B * T * 4);
     w.delta2 = take((size_t)B * M * 4);
-    w.p_dq = take(S * B * M * D * 4);
-    w.p_dmc = take(S * B * M * D * 4);
-    w.p_dmd1 = take(S * B * M * D * 4);
-    w.p_dmd2 = take(S * B * M * D * 4);
-    w.p_dc1 = take(S * B * M * 4);
-    w.p_dc2 = take(S * B * M * 4);
     w.total = o;
     return w;
-}
-static int fwd_splits(int B, int T, int M) {
-    if (int f = forced_splits("MMB_ATT_FSPLIT", T)) return f;
-    return pick_splits(B, M, T, 512);   // two workgroups per CU
-}
-static size_t fwd_ws_bytes(int B, int T, int M, int D) {
-    const size_t S = fwd_splits(B, T, M);
-    return align256(S * B * M * D * 4) + align256(S * B * M * 2 * 4);
 }
 
 template <typename K>
 static int allow_lds(K kernel, size_t bytes) {
-    MMB_REQUIRE(bytes <= 160 * 1024, "bidaf: %zu bytes of LDS needed, 160 KiB available (sequence too long for one split)", bytes);
+    MMB_REQUIRE(bytes <= 160 * 1024, "bidaf: %zu bytes of LDS needed, 160 KiB available", bytes);
     MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return MMB_OK;
+}
+
+// blocks of a sweep whose lane side has `rows` rows per sample, padded to a multiple of 8 (XCD-aware decode)
+static int sweep_blocks(int rows, int B) { return (((rows + 63) / 64) * B + 7) / 8 * 8; }
+
+// stand-alone wrappers so that a profile names the forward column pass and the backward dq sweep apart
+template <bool DBG>
+__global__ __launch_bounds__(NT8) void att_col_kernel(const GroupArgs a, const BlkMap bm) {
+    att_jsweep_body<0, DBG>(a, bm);
+}
+template <bool DBG>
+__global__ __launch_bounds__(NT8) void att_bwd_dq_kernel(const GroupArgs a, const BlkMap bm) {
+    att_jsweep_body<1, DBG>(a, bm);
 }
 
 }  // namespace mmb
@@ -1805,9 +1674,243 @@ extern "C" size_t mmb_bidaf_saved_bytes(int B, int T, int M, int D, int has_drop
 extern "C" size_t mmb_bidaf_fwd_workspace_bytes(int B, int T, int M, int D) {
     if (B < 1 || T < 1 || M < 1 || D < 4) return 0;
     if (D > MMB_ATT_MAX_D) return bidaf_big_fwd_ws_floats(B, T, M, D) * sizeof(float);
-    return fwd_ws_bytes(B, T, M, D);
+    return 256;      // the fused path keeps nothing outside the saved buffer
 }
 
+extern "C" size_t mmb_bidaf_bwd_workspace_bytes(int B, int T, int M, int D) {
+    if (B < 1 || T < 1 || M < 1 || D < 4) return 0;
+    if (D > MMB_ATT_MAX_D) return bidaf_big_bwd_ws_floats(B, T, M, D) * sizeof(float);
+    return bwd_layout(B, T, M).total;
+}
+
+// fills the device view of a group from the descriptors (pointers common to forward and backward)
+static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backward, GroupArgs& ga) {
+    MMB_REQUIRE(d && n >= 1 && n <= MAXG, "bidaf group: 1..%d attentions per call", MAXG);
+    memset(&ga, 0, sizeof(ga));
+    ga.n = n; ga.B = B; ga.D = D; ga.dbg = att_dbg();
+    const bool drop = d[0].text_d != nullptr;
+    for (int k = 0; k < n; ++k) {
+        const mmb_bidaf_desc& s = d[k];
+        if (int rc = check_att_dims(B, s.T, s.M, D)) return rc;
+        MMB_REQUIRE(s.text && s.mod && s.w_t && s.w_m && s.w_tm && (backward || s.bias) && s.out && s.bsave && s.rterm && s.cterm && s.row_stat &&
+                        s.col_stat && s.saved, "bidaf group: null pointer in attention %d", k);
+        MMB_REQUIRE((s.text_mask || s.text_len) && (s.mod_mask || s.mod_len), "bidaf: a mask or a length vector is needed for each side");
+        MMB_REQUIRE((s.text_d != nullptr) == drop && (s.mod_d != nullptr) == drop,
+                    "bidaf group: text_d and mod_d must be given for all attentions of a call or for none");
+        MMB_REQUIRE(s.saved_bytes >= mmb_bidaf_saved_bytes(B, s.T, s.M, D, drop), "bidaf: saved buffer too small (%zu < %zu)",
+                    s.saved_bytes, mmb_bidaf_saved_bytes(B, s.T, s.M, D, drop));
+        AttG& g = ga.g[k];
+        g.text = s.text; g.mod = s.mod; g.text_d = drop ? s.text_d : s.text; g.mod_d = drop ? s.mod_d : s.mod;
+        g.text_mask = s.text_len ? nullptr : s.text_mask; g.mod_mask = s.mod_len ? nullptr : s.mod_mask;
+        g.text_len = s.text_len; g.mod_len = s.mod_len;
+        g.w_t = s.w_t; g.w_m = s.w_m; g.w_tm = s.w_tm; g.bias = s.bias;
+        g.out = s.out; g.bsave = s.bsave; g.rterm = s.rterm; g.cterm = s.cterm; g.row_stat = s.row_stat; g.col_stat = s.col_stat;
+        g.T = s.T; g.M = s.M;
+        const SavedLayout L = saved_layout(B, s.T, s.M, drop);
+        char* sv = static_cast<char*>(s.saved);
+        auto fp = [&](size_t off) { return reinterpret_cast<float*>(sv + off); };
+        g.pT = sv + L.pT; g.pTd = sv + L.pTd; g.pM = sv + L.pM; g.pMd = sv + L.pMd; g.pMw = sv + L.pMw; g.pQ = sv + L.pQ;
+        g.iT = fp(L.iT); g.iTd = fp(L.iTd); g.iM = fp(L.iM); g.iMd = fp(L.iMd); g.iMw = fp(L.iMw); g.iQ = fp(L.iQ);
+        // attentions of one call that read the same text tensor share ONE set of text planes (made once by the split pass)
+        for (int j = 0; j < k; ++j)
+            if (d[j].text == s.text && d[j].T == s.T) {
+                g.pT = ga.g[j].pT; g.iT = ga.g[j].iT;
+                if (!drop) { g.pTd = g.pT; g.iTd = g.iT; }
+                break;
+            }
+        if (backward) {
+            MMB_REQUIRE(s.d_out && s.d_text && s.d_mod && s.d_w_t && s.d_w_m && s.d_w_tm && s.d_bias && s.workspace,
+                        "bidaf group bwd: null pointer in attention %d", k);
+            MMB_REQUIRE(drop ? (s.d_text_d && s.d_mod_d) : (!s.d_text_d && !s.d_mod_d),
+                        "bidaf bwd: d_text_d/d_mod_d must be given exactly when text_d/mod_d are");
+            MMB_REQUIRE(s.workspace_bytes >= mmb_bidaf_bwd_workspace_bytes(B, s.T, s.M, D), "bidaf bwd: workspace too small (%zu < %zu)",
+                        s.workspace_bytes, mmb_bidaf_bwd_workspace_bytes(B, s.T, s.M, D));
+            const BwdWs W = bwd_layout(B, s.T, s.M);
+            char* ws = reinterpret_cast<char*>(s.workspace);
+            auto wf = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+            g.d_out = s.d_out; g.d_text = s.d_text; g.d_mod = s.d_mod; g.d_text_d = s.d_text_d; g.d_mod_d = s.d_mod_d;
+            g.d_w_t = s.d_w_t; g.d_w_m = s.d_w_m; g.d_w_tm = s.d_w_tm; g.d_bias = s.d_bias;
+            g.pDa = ws + W.pDa; g.pDb = ws + W.pDb; g.pDq = ws + W.pDq;
+            g.iDa = wf(W.iDa); g.iDb = wf(W.iDb); g.iDq = wf(W.iDq); g.delta1 = wf(W.delta1); g.delta2 = wf(W.delta2);
+        }
+    }
+    return MMB_OK;
+}
+
+static int general_width_fwd(const mmb_bidaf_desc& s, int B, int D, hipStream_t stream) {
+    MMB_REQUIRE(s.text_mask && s.mod_mask, "mmb_bidaf_fwd: the general-width path (D > %d) takes u8 masks", MMB_ATT_MAX_D);
+    MMB_REQUIRE(s.workspace && s.workspace_bytes >= mmb_bidaf_fwd_workspace_bytes(B, s.T, s.M, D),
+                "mmb_bidaf_fwd: needs a workspace of mmb_bidaf_fwd_workspace_bytes() = %zu bytes", mmb_bidaf_fwd_workspace_bytes(B, s.T, s.M, D));
+    const float* text_d = s.text_d ? s.text_d : s.text;
+    const float* mod_d = s.mod_d ? s.mod_d : s.mod;
+    {
+        ProfScope ps_(MMB_K_ATT_RANK1, stream);
+        hipLaunchKernelGGL(att_rank1_kernel, dim3((B * s.T + B * s.M + 3) / 4), dim3(256), 0, stream, text_d, mod_d, s.w_t, s.w_m, s.bias,
+                           s.rterm, s.cterm, B * s.T, B * s.M, D);
+    }
+    MMB_HIP(hipGetLastError());
+    return bidaf_big_fwd(s.text, s.mod, s.text_mask, s.mod_mask, text_d, mod_d, s.w_tm, s.out, static_cast<float*>(s.saved), s.bsave,
+                         s.rterm, s.cterm, s.row_stat, s.col_stat, s.workspace, B, s.T, s.M, D, stream);
+}
+
+extern "C" int mmb_bidaf_group_fwd(const mmb_bidaf_desc* d, int n, int B, int D, int device, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MMB_REQUIRE(d && n >= 1 && n <= MAXG, "mmb_bidaf_group_fwd: 1..%d attentions per call", MAXG);
+    MMB_HIP(hipSetDevice(device));
+    if (D > MMB_ATT_MAX_D) {     // general-size path (bidaf_big.hip), one attention after the other
+        for (int k = 0; k < n; ++k) {
+            if (int rc = check_att_dims(B, d[k].T, d[k].M, D)) return rc;
+            MMB_REQUIRE((d[k].text_d != nullptr) == (d[k].mod_d != nullptr), "mmb_bidaf_fwd: text_d and mod_d must both be given or both be NULL");
+            if (int rc = general_width_fwd(d[k], B, D, stream)) return rc;
+        }
+        return MMB_OK;
+    }
+    GroupArgs ga;
+    if (int rc = fill_group(d, n, B, D, false, ga)) return rc;
+    const bool drop = d[0].text_d != nullptr;
+    ProfScope ps_all_(MMB_K_ATT_FWD, stream);   // the whole fused forward (bench.py's roofline figure)
+
+    // ---- split pass: planes + inverse row scales, rank-1 terms; a text tensor shared by several attentions is read once
+    {
+        PrepArgs p{};
+        p.D = D; p.B = B;
+        int cnt = 0, owner_src[MAXG];
+        long rows = 0;
+        auto add = [&](const float* src, char* planes, float* inv, const float* mul, const float* w, const float* bias, float* term, int R) {
+            SplitSrc& s = p.t[cnt];
+            s.src = src; s.planes = planes; s.inv = inv; s.mul = mul; s.R = R;
+            s.w[0] = w; s.bias[0] = bias; s.term[0] = term;
+            rows = std::max(rows, (long)B * pad32(R));
+            return cnt++;
+        };
+        for (int k = 0; k < n; ++k) {
+            const AttG& g = ga.g[k];
+            int shared = -1;
+            for (int j = 0; j < k; ++j)
+                if (ga.g[j].pT == g.pT) { shared = j; break; }
+            if (!drop) {
+                if (shared < 0) {
+                    owner_src[k] = add(g.text, g.pT, g.iT, nullptr, g.w_t, g.bias, g.rterm, g.T);
+                } else {
+                    SplitSrc& s = p.t[owner_src[shared]];
+                    owner_src[k] = owner_src[shared];
+                    if (!s.term[1]) { s.w[1] = g.w_t; s.bias[1] = g.bias; s.term[1] = g.rterm; }
+                    else owner_src[k] = add(g.text, nullptr, nullptr, nullptr, g.w_t, g.bias, g.rterm, g.T);   // terms only
+                }
+                add(g.mod, g.pM, g.iM, nullptr, g.w_m, nullptr, g.cterm, g.M);
+                add(g.mod, g.pMw, g.iMw, g.w_tm, nullptr, nullptr, nullptr, g.M);
+            } else {
+                if (shared < 0) owner_src[k] = add(g.text, g.pT, g.iT, nullptr, nullptr, nullptr, nullptr, g.T);
+                else owner_src[k] = owner_src[shared];
+                add(g.text_d, g.pTd, g.iTd, nullptr, g.w_t, g.bias, g.rterm, g.T);
+                add(g.mod, g.pM, g.iM, nullptr, nullptr, nullptr, nullptr, g.M);
+                add(g.mod_d, g.pMd, g.iMd, nullptr, g.w_m, nullptr, g.cterm, g.M);
+            }
+        }
+        p.n = cnt;
+        ProfScope ps_(MMB_K_ATT_RANK1, stream);
+        hipLaunchKernelGGL(att_prep_kernel, dim3((unsigned)((rows + 3) / 4), cnt), dim3(256), 0, stream, p);
+        MMB_HIP(hipGetLastError());
+    }
+    // ---- column pass: lane side = modality rows, streams all text rows; writes q as planes + the column statistics
+    {
+        BlkMap bm{};
+        for (int k = 0; k < n; ++k) bm.begin[k + 1] = bm.begin[k] + sweep_blocks(ga.g[k].M, B);
+        for (int k = n; k < MAXG; ++k) bm.begin[k + 1] = bm.begin[n];
+        const size_t lds = (size_t)(drop ? 1 : 2) * 2 * (drop ? 2 : 1) * PANEL_B + (2 * 4 * 64 + 64) * sizeof(float);
+        auto kern = ga.dbg ? att_col_kernel<true> : att_col_kernel<false>;
+        if (int rc = allow_lds(kern, lds)) return rc;
+        ProfScope ps_(MMB_K_ATT_COL, stream);
+        hipLaunchKernelGGL(kern, dim3(bm.begin[n]), dim3(NT8), lds, stream, ga, bm);
+        MMB_HIP(hipGetLastError());
+    }
+    // ---- row pass: lane side = text rows, streams [mod | q]
+    {
+        BlkMap bm{};
+        for (int k = 0; k < n; ++k) bm.begin[k + 1] = bm.begin[k] + sweep_blocks(ga.g[k].T, B);
+        for (int k = n; k < MAXG; ++k) bm.begin[k + 1] = bm.begin[n];
+        size_t lds = (size_t)(drop ? 3 : 2) * PANEL_B + (5 * 32 + 16) * sizeof(float);
+        const size_t epi = (size_t)64 * LDP * sizeof(float);
+        if (lds < epi) lds = epi;
+        auto kern = ga.dbg ? att_row_kernel<true> : att_row_kernel<false>;
+        if (int rc = allow_lds(kern, lds)) return rc;
+        ProfScope ps_(MMB_K_ATT_ROW, stream);
+        hipLaunchKernelGGL(kern, dim3(bm.begin[n]), dim3(NTHR), lds, stream, ga, bm);
+        MMB_HIP(hipGetLastError());
+    }
+    return MMB_OK;
+}
+
+extern "C" int mmb_bidaf_group_bwd(const mmb_bidaf_desc* d, int n, int B, int D, int device, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MMB_REQUIRE(d && n >= 1 && n <= MAXG, "mmb_bidaf_group_bwd: 1..%d attentions per call", MAXG);
+    MMB_HIP(hipSetDevice(device));
+    if (D > MMB_ATT_MAX_D) {
+        for (int k = 0; k < n; ++k) {
+            const mmb_bidaf_desc& s = d[k];
+            if (int rc = check_att_dims(B, s.T, s.M, D)) return rc;
+            MMB_REQUIRE(s.text_mask && s.mod_mask, "mmb_bidaf_bwd: the general-width path (D > %d) takes u8 masks", MMB_ATT_MAX_D);
+            MMB_REQUIRE(s.d_out && s.out && s.text && s.mod && s.w_t && s.w_m && s.w_tm && s.saved && s.bsave && s.rterm && s.cterm && s.row_stat &&
+                            s.col_stat && s.d_text && s.d_mod && s.d_w_t && s.d_w_m && s.d_w_tm && s.d_bias && s.workspace, "mmb_bidaf_bwd: null pointer");
+            MMB_REQUIRE((s.text_d != nullptr) == (s.mod_d != nullptr), "mmb_bidaf_bwd: text_d and mod_d must both be given or both be NULL");
+            MMB_REQUIRE(s.text_d ? (s.d_text_d && s.d_mod_d) : (!s.d_text_d && !s.d_mod_d),
+                        "mmb_bidaf_bwd: d_text_d/d_mod_d must be given exactly when text_d/mod_d are");
+            MMB_REQUIRE(s.workspace_bytes >= mmb_bidaf_bwd_workspace_bytes(B, s.T, s.M, D), "mmb_bidaf_bwd: workspace too small (%zu < %zu)",
+                        s.workspace_bytes, mmb_bidaf_bwd_workspace_bytes(B, s.T, s.M, D));
+            if (int rc = bidaf_big_bwd(s.d_out, s.out, s.text, s.mod, s.text_mask, s.mod_mask, s.text_d, s.mod_d, s.w_t, s.w_m, s.w_tm,
+                                       static_cast<const float*>(s.saved), s.bsave, s.rterm, s.cterm, s.row_stat, s.col_stat, s.d_text, s.d_mod,
+                                       s.d_text_d, s.d_mod_d, s.d_w_t, s.d_w_m, s.d_w_tm, s.d_bias, s.workspace, B, s.T, s.M, D, stream))
+                return rc;
+        }
+        return MMB_OK;
+    }
+    GroupArgs ga;
+    if (int rc = fill_group(d, n, B, D, true, ga)) return rc;
+    const bool drop = d[0].text_d != nullptr;
+    ProfScope ps_all_(MMB_K_ATT_BWD, stream);   // the whole fused backward
+
+    {
+        long rows = 0;
+        for (int k = 0; k < n; ++k) rows = std::max(rows, (long)B * pad32(ga.g[k].T));
+        ProfScope ps_(MMB_K_ATT_BWD_PRE, stream);
+        hipLaunchKernelGGL(att_bwd_pre_kernel, dim3((unsigned)((rows + 3) / 4), n), dim3(256), 0, stream, ga);
+        MMB_HIP(hipGetLastError());
+    }
+    // ---- dq sweep: dq = P1^T db as planes, delta2 = q . dq
+    {
+        BlkMap bm{};
+        for (int k = 0; k < n; ++k) bm.begin[k + 1] = bm.begin[k] + sweep_blocks(ga.g[k].M, B);
+        for (int k = n; k < MAXG; ++k) bm.begin[k + 1] = bm.begin[n];
+        const size_t lds = (size_t)2 * 2 * PANEL_B + (2 * 5 * 64 + 64) * sizeof(float);
+        auto kern = ga.dbg ? att_bwd_dq_kernel<true> : att_bwd_dq_kernel<false>;
+        if (int rc = allow_lds(kern, lds)) return rc;
+        ProfScope ps_(MMB_K_ATT_BWD_J1, stream);
+        hipLaunchKernelGGL(kern, dim3(bm.begin[n]), dim3(NT8), lds, stream, ga, bm);
+        MMB_HIP(hipGetLastError());
+    }
+    // ---- gradient sweeps: the j sweep (d_mod, d_mod_d, d_w_m) and the i sweep (d_text, d_text_d, d_w_t, d_w_tm, d_bias) in one launch
+    {
+        SweepMap sm{};
+        for (int k = 0; k < n; ++k) sm.j.begin[k + 1] = sm.j.begin[k] + sweep_blocks(ga.g[k].M, B);
+        for (int k = n; k < MAXG; ++k) sm.j.begin[k + 1] = sm.j.begin[n];
+        sm.i_begin = sm.j.begin[n];
+        sm.i.begin[0] = sm.i_begin;
+        for (int k = 0; k < n; ++k) sm.i.begin[k + 1] = sm.i.begin[k] + sweep_blocks(ga.g[k].T, B);
+        for (int k = n; k < MAXG; ++k) sm.i.begin[k + 1] = sm.i.begin[n];
+        const size_t loop_b = (size_t)4 * PANEL_B + 10 * 32 * sizeof(float) + 4 * XCH_PAIR + 64 * sizeof(float);
+        const size_t epi = ((size_t)2 * 64 * LDP + 64 + 8 * 2 * 256) * sizeof(float);
+        const size_t lds = loop_b > epi ? loop_b : epi;
+        auto kern = ga.dbg ? (drop ? att_bwd_sweep_kernel<true, false> : att_bwd_sweep_kernel<true, true>)
+                           : (drop ? att_bwd_sweep_kernel<false, false> : att_bwd_sweep_kernel<false, true>);
+        if (int rc = allow_lds(kern, lds)) return rc;
+        ProfScope ps_(MMB_K_ATT_BWD_I, stream);
+        hipLaunchKernelGGL(kern, dim3(sm.i.begin[n]), dim3(NT8), lds, stream, ga, sm);
+        MMB_HIP(hipGetLastError());
+    }
+    return MMB_OK;
+}
+
+// single-attention entry points: a group of one
 extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t* text_mask, const uint8_t* mod_mask,
                              const int32_t* text_len, const int32_t* mod_len,
                              const float* text_d, const float* mod_d, const float* w_t, const float* w_m,
@@ -1815,118 +1918,16 @@ extern "C" int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t*
                              float* cterm, float* row_stat, float* col_stat, void* saved, size_t saved_bytes,
                              float* workspace, size_t workspace_bytes,
                              int B, int T, int M, int D, int device, void* stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (int rc = check_att_dims(B, T, M, D)) return rc;
     MMB_REQUIRE(text && mod && w_t && w_m && w_tm && bias && out && bsave && rterm && cterm && row_stat && col_stat && saved,
                 "mmb_bidaf_fwd: null pointer");
-    MMB_REQUIRE((text_mask || text_len) && (mod_mask || mod_len), "mmb_bidaf_fwd: a mask or a length vector is needed for each side");
-    const bool drop = text_d != nullptr;
-    MMB_REQUIRE(drop == (mod_d != nullptr), "mmb_bidaf_fwd: text_d and mod_d must both be given or both be NULL");
-    MMB_REQUIRE(saved_bytes >= mmb_bidaf_saved_bytes(B, T, M, D, drop), "mmb_bidaf_fwd: saved buffer too small (%zu < %zu)",
-                saved_bytes, mmb_bidaf_saved_bytes(B, T, M, D, drop));
-    MMB_REQUIRE(workspace && workspace_bytes >= mmb_bidaf_fwd_workspace_bytes(B, T, M, D),
-                "mmb_bidaf_fwd: needs a workspace of mmb_bidaf_fwd_workspace_bytes() = %zu bytes", mmb_bidaf_fwd_workspace_bytes(B, T, M, D));
-    MMB_HIP(hipSetDevice(device));
-    if (!text_d) text_d = text;
-    if (!mod_d) mod_d = mod;
-
-    if (D > MMB_ATT_MAX_D) {   // general-size path (bidaf_big.hip): similarity matrix materialised in the workspace
-        MMB_REQUIRE(text_mask && mod_mask, "mmb_bidaf_fwd: the general-width path (D > %d) takes u8 masks", MMB_ATT_MAX_D);
-        {
-            ProfScope ps_(MMB_K_ATT_RANK1, stream);
-            hipLaunchKernelGGL(att_rank1_kernel, dim3((B * T + B * M + 3) / 4), dim3(256), 0, stream, text_d, mod_d, w_t, w_m, bias, rterm, cterm,
-                               B * T, B * M, D);
-        }
-        MMB_HIP(hipGetLastError());
-        return bidaf_big_fwd(text, mod, text_mask, mod_mask, text_d, mod_d, w_tm, out, static_cast<float*>(saved), bsave, rterm, cterm,
-                             row_stat, col_stat, workspace, B, T, M, D, stream);
-    }
-    const SavedLayout L = saved_layout(B, T, M, drop);
-    char* sv = static_cast<char*>(saved);
-    auto fp = [&](size_t off) { return reinterpret_cast<float*>(sv + off); };
-    ProfScope ps_all_(MMB_K_ATT_FWD, stream);   // the whole fused forward (bench.py's roofline figure)
-
-    // ---- split passes: planes + inverse row scales of text / mod (and the dropped copies), rank-1 terms
-    {
-        PrepArgs p{};
-        p.D = D; p.B = B;
-        int k = 0;
-        p.t[k++] = SplitSrc{text_d, sv + L.pTd, fp(L.iTd), w_t, bias, rterm, nullptr, T};
-        p.t[k++] = SplitSrc{mod_d, sv + L.pMd, fp(L.iMd), w_m, nullptr, cterm, nullptr, M};
-        p.t[k++] = SplitSrc{text_d, sv + L.pTw, fp(L.iTw), nullptr, nullptr, nullptr, w_tm, T};   // lane-side S operands: w_tm folded in
-        p.t[k++] = SplitSrc{mod_d, sv + L.pMw, fp(L.iMw), nullptr, nullptr, nullptr, w_tm, M};
-        if (drop) {
-            p.t[k++] = SplitSrc{text, sv + L.pT, fp(L.iT), nullptr, nullptr, nullptr, nullptr, T};
-            p.t[k++] = SplitSrc{mod, sv + L.pM, fp(L.iM), nullptr, nullptr, nullptr, nullptr, M};
-        }
-        p.n = k;
-        const long rows = (long)B * pad32(T > M ? T : M);
-        ProfScope ps_(MMB_K_ATT_RANK1, stream);
-        hipLaunchKernelGGL(att_prep_kernel, dim3((unsigned)((rows + 3) / 4), k), dim3(256), 0, stream, p);
-        MMB_HIP(hipGetLastError());
-    }
-    // ---- column pass: lane side = modality rows, streams text; partials merged (and q split into planes) by the combine
-    const int splits = fwd_splits(B, T, M);
-    float* part_o = workspace;
-    float* part_stat = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align256((size_t)splits * B * M * D * 4));
-    {
-        AttFwdArgs a{};
-        a.side_p = sv + L.pMw; a.side_i = fp(L.iMw);
-        a.mS = sv + L.pTd; a.iS = fp(L.iTd); a.mV0 = sv + L.pT; a.iV0 = fp(L.iT); a.mV1 = nullptr; a.iV1 = nullptr;
-        a.m_mask = text_len ? nullptr : text_mask; a.m_len = text_len; a.m_term = rterm; a.n_term = cterm;
-        a.part_o = part_o; a.part_stat = part_stat;
-        a.N = M; a.R = T; a.D = D; a.B = B; a.splits = splits; a.rows_per_split = rows_per_split(T, splits);
-        a.dbg = att_dbg();
-        const size_t arr = ((size_t)5 * a.rows_per_split + 16) * sizeof(float), stage_b = (size_t)(drop ? 2 : 1) * PANEL_B;
-        a.nstage = (2 * stage_b + arr <= 80 * 1024 && a.rows_per_split > PR) ? 2 : 1;   // keep two workgroups per CU
-        size_t lds = a.nstage * stage_b + arr;
-        if (lds < (size_t)16 * NW * LDP * sizeof(float)) lds = (size_t)16 * NW * LDP * sizeof(float);   // epilogue staging tile
-        auto kern = a.dbg ? att_col_kernel<true> : att_col_kernel<false>;
-        if (int rc = allow_lds(kern, lds)) return rc;
-        {
-            ProfScope ps_(MMB_K_ATT_COL, stream);
-            hipLaunchKernelGGL(kern, dim3(((M + 63) / 64) * splits * B), dim3(NTHR), lds, stream, a);
-        }
-        MMB_HIP(hipGetLastError());
-        const long rows = (long)B * pad32(M);
-        {
-            ProfScope ps_(MMB_K_ATT_COMBINE, stream);
-            hipLaunchKernelGGL(att_combine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, part_o, part_stat, sv + L.pQ,
-                               fp(L.iQ), col_stat, B, M, D, splits);
-        }
-        MMB_HIP(hipGetLastError());
-    }
-    // ---- row pass: lane side = text rows, streams [mod | q]
-    {
-        AttFwdArgs a{};
-        a.side_p = sv + L.pTw; a.side_i = fp(L.iTw);
-        a.mS = sv + L.pMd; a.iS = fp(L.iMd); a.mV0 = sv + L.pM; a.iV0 = fp(L.iM); a.mV1 = sv + L.pQ; a.iV1 = fp(L.iQ);
-        a.m_mask = mod_len ? nullptr : mod_mask; a.m_len = mod_len; a.m_term = cterm; a.n_term = rterm; a.stat = row_stat;
-        a.text = text; a.out = out; a.bsave = bsave;
-        a.N = T; a.R = M; a.D = D; a.B = B; a.splits = 1; a.rows_per_split = rows_per_split(M, 1);
-        a.dbg = att_dbg();
-        const size_t arr = ((size_t)5 * a.rows_per_split + 16) * sizeof(float), stage_b = (size_t)(drop ? 3 : 2) * PANEL_B;
-        a.nstage = (2 * stage_b + arr <= 160 * 1024 && a.rows_per_split > PR) ? 2 : 1;
-        size_t lds = a.nstage * stage_b + arr;
-        const size_t epi = (size_t)16 * NW * LDP * sizeof(float);
-        if (lds < epi) lds = epi;
-        static const bool row8 = [] { const char* e = getenv("MMB_ATT_ROW8"); return !e || atoi(e) != 0; }();
-        if (row8 && lds < 2 * epi) lds = 2 * epi;   // the two roles' epilogue staging tiles
-        auto kern = row8 ? (a.dbg ? att_row8_kernel<true> : att_row8_kernel<false>) : (a.dbg ? att_row_kernel<true> : att_row_kernel<false>);
-        if (int rc = allow_lds(kern, lds)) return rc;
-        {
-            ProfScope ps_(MMB_K_ATT_ROW, stream);
-            hipLaunchKernelGGL(kern, dim3(((T + 63) / 64) * B), dim3(row8 ? 2 * NTHR : NTHR), lds, stream, a);
-        }
-        MMB_HIP(hipGetLastError());
-    }
-    return MMB_OK;
-}
-
-extern "C" size_t mmb_bidaf_bwd_workspace_bytes(int B, int T, int M, int D) {
-    if (B < 1 || T < 1 || M < 1 || D < 4) return 0;
-    if (D > MMB_ATT_MAX_D) return bidaf_big_bwd_ws_floats(B, T, M, D) * sizeof(float);
-    return bwd_layout(B, T, M, D).total;
+    MMB_REQUIRE((text_d != nullptr) == (mod_d != nullptr), "mmb_bidaf_fwd: text_d and mod_d must both be given or both be NULL");
+    mmb_bidaf_desc s{};
+    s.text = text; s.mod = mod; s.text_mask = text_mask; s.mod_mask = mod_mask; s.text_len = text_len; s.mod_len = mod_len;
+    s.text_d = text_d; s.mod_d = mod_d; s.w_t = w_t; s.w_m = w_m; s.w_tm = w_tm; s.bias = bias;
+    s.out = out; s.bsave = bsave; s.rterm = rterm; s.cterm = cterm; s.row_stat = row_stat; s.col_stat = col_stat;
+    s.saved = saved; s.saved_bytes = saved_bytes; s.workspace = workspace; s.workspace_bytes = workspace_bytes;
+    s.T = T; s.M = M;
+    return mmb_bidaf_group_fwd(&s, 1, B, D, device, stream_);
 }
 
 extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* text, const float* mod,
@@ -1937,105 +1938,19 @@ extern "C" int mmb_bidaf_bwd(const float* d_out, const float* out, const float* 
                              float* d_text, float* d_mod, float* d_text_d, float* d_mod_d, float* d_w_t, float* d_w_m,
                              float* d_w_tm, float* d_bias, float* workspace, size_t workspace_bytes, int B, int T, int M,
                              int D, int device, void* stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (int rc = check_att_dims(B, T, M, D)) return rc;
     MMB_REQUIRE(d_out && out && text && mod && w_t && w_m && w_tm && saved && bsave && rterm && cterm &&
                     row_stat && col_stat && d_text && d_mod && d_w_t && d_w_m && d_w_tm && d_bias && workspace,
                 "mmb_bidaf_bwd: null pointer");
-    MMB_REQUIRE((text_mask || text_len) && (mod_mask || mod_len), "mmb_bidaf_bwd: a mask or a length vector is needed for each side");
-    const bool drop_t = text_d != nullptr, drop_m = mod_d != nullptr;
-    MMB_REQUIRE(drop_t == drop_m, "mmb_bidaf_bwd: text_d and mod_d must both be given or both be NULL");
-    MMB_REQUIRE(drop_t ? (d_text_d && d_mod_d) : (!d_text_d && !d_mod_d),
-                "mmb_bidaf_bwd: d_text_d/d_mod_d must be given exactly when text_d/mod_d are");
-    MMB_REQUIRE(workspace_bytes >= mmb_bidaf_bwd_workspace_bytes(B, T, M, D), "mmb_bidaf_bwd: workspace too small (%zu < %zu)",
-                workspace_bytes, mmb_bidaf_bwd_workspace_bytes(B, T, M, D));
-    MMB_HIP(hipSetDevice(device));
-    if (D > MMB_ATT_MAX_D) {
-        MMB_REQUIRE(text_mask && mod_mask, "mmb_bidaf_bwd: the general-width path (D > %d) takes u8 masks", MMB_ATT_MAX_D);
-        return bidaf_big_bwd(d_out, out, text, mod, text_mask, mod_mask, text_d, mod_d, w_t, w_m, w_tm, static_cast<const float*>(saved), bsave,
-                             rterm, cterm, row_stat, col_stat, d_text, d_mod, d_text_d, d_mod_d, d_w_t, d_w_m, d_w_tm, d_bias, workspace,
-                             B, T, M, D, stream);
-    }
-    const SavedLayout S = saved_layout(B, T, M, drop_t);
-    const BwdWs L = bwd_layout(B, T, M, D);
-    ProfScope ps_all_(MMB_K_ATT_BWD, stream);   // the whole fused backward
-    const char* sv = static_cast<const char*>(saved);
-    char* ws = reinterpret_cast<char*>(workspace);
-    auto sf = [&](size_t off) { return reinterpret_cast<const float*>(sv + off); };
-    auto wf = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
-
-    AttBwdArgs a{};
-    a.text = text; a.mod = mod; a.text_d = drop_t ? text_d : text; a.mod_d = drop_m ? mod_d : mod;
-    a.text_mask = text_len ? nullptr : text_mask; a.mod_mask = mod_len ? nullptr : mod_mask;
-    a.text_len = text_len; a.mod_len = mod_len;
-    a.w_t = w_t; a.w_m = w_m; a.w_tm = w_tm;
-    a.rterm = rterm; a.cterm = cterm; a.row_stat = row_stat; a.col_stat = col_stat;
-    a.pT = sv + S.pT; a.pTd = sv + S.pTd; a.pM = sv + S.pM; a.pMd = sv + S.pMd; a.pQ = sv + S.pQ; a.pTw = sv + S.pTw; a.pMw = sv + S.pMw;
-    a.iT = sf(S.iT); a.iTd = sf(S.iTd); a.iM = sf(S.iM); a.iMd = sf(S.iMd); a.iQ = sf(S.iQ); a.iTw = sf(S.iTw); a.iMw = sf(S.iMw);
-    a.pDa = ws + L.pDa; a.pDb = ws + L.pDb; a.pDq = ws + L.pDq;
-    a.iDa = wf(L.iDa); a.iDb = wf(L.iDb); a.iDq = wf(L.iDq);
-    a.delta1 = wf(L.delta1); a.delta2 = wf(L.delta2);
-    a.p_dq = wf(L.p_dq); a.p_dmc = wf(L.p_dmc); a.p_dmd1 = wf(L.p_dmd1);
-    a.p_dmd2 = wf(L.p_dmd2); a.p_dc1 = wf(L.p_dc1); a.p_dc2 = wf(L.p_dc2);
-    a.d_mod = d_mod; a.d_mod_d = d_mod_d; a.d_text = d_text; a.d_text_d = d_text_d;
-    a.d_w_t = d_w_t; a.d_w_m = d_w_m; a.d_w_tm = d_w_tm; a.d_bias = d_bias;
-    a.B = B; a.T = T; a.M = M; a.D = D; a.fold = drop_t ? 0 : 1;
-    a.splits = L.splits;
-    a.rows_per_split = rows_per_split(T, a.splits);
-    a.dbg = att_dbg();
-
-    {
-        const long rows = (long)B * pad32(T);
-        ProfScope ps_(MMB_K_ATT_BWD_PRE, stream);
-        hipLaunchKernelGGL(att_bwd_pre_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, d_out, out, text, bsave,
-                           ws + L.pDa, wf(L.iDa), ws + L.pDb, wf(L.iDb), wf(L.delta1), d_text, d_w_t, d_w_m, d_w_tm, d_bias, B, T, D);
-    }
-    MMB_HIP(hipGetLastError());
-    const int tiles_m = (M + 63) / 64, tiles_t = (T + 63) / 64;
-    {
-        const size_t lds = (size_t)3 * PANEL_B + ((size_t)7 * a.rows_per_split + 16) * sizeof(float);
-        auto kern = a.dbg ? att_bwd_j1_kernel<true> : att_bwd_j1_kernel<false>;
-        if (int rc = allow_lds(kern, lds)) return rc;
-        ProfScope ps_(MMB_K_ATT_BWD_J1, stream);
-        hipLaunchKernelGGL(kern, dim3(tiles_m * a.splits * B), dim3(NTHR), lds, stream, a);
-    }
-    MMB_HIP(hipGetLastError());
-    {
-        const size_t arr = ((size_t)4 * a.rows_per_split + 16) * sizeof(float), stage_b = (size_t)(drop_t ? 2 : 1) * PANEL_B;
-        a.nstage_j2 = (2 * stage_b + arr <= 160 * 1024 && a.rows_per_split > PR) ? 2 : 1;
-        size_t lds = a.nstage_j2 * stage_b + arr;
-        if (lds < (size_t)16 * NW * LDP * sizeof(float)) lds = (size_t)16 * NW * LDP * sizeof(float);   // epilogue staging tile
-        auto kern = a.dbg ? att_bwd_j2_kernel<true> : att_bwd_j2_kernel<false>;
-        if (int rc = allow_lds(kern, lds)) return rc;
-        ProfScope ps_(MMB_K_ATT_BWD_J2, stream);
-        hipLaunchKernelGGL(kern, dim3(tiles_m * a.splits * B), dim3(NTHR), lds, stream, a);
-    }
-    MMB_HIP(hipGetLastError());
-    // j-side epilogue: rows per wave such that there are enough waves to fill the chip and few enough workgroups that the
-    // d_w_m atomics stay cheap.  Its workgroups ride in the i-side launch (same block size, needs only the j sweeps) unless
-    // the timing tools ask for their own launch.
-    const int rows = B * M;
-    a.jf_rows = rows >= 8192 ? 8 : rows >= 4096 ? 4 : rows >= 2048 ? 2 : 1;
-    const int jf_blocks = ((rows + a.jf_rows - 1) / a.jf_rows + 3) / 4;
-    static const bool jf_separate = [] { const char* e = getenv("MMB_ATT_JFIN_SEPARATE"); return e && atoi(e) != 0; }();
-    const bool separate = jf_separate || a.dbg != 0;
-    if (separate) {
-        ProfScope ps_(MMB_K_ATT_BWD_JFIN, stream);
-        hipLaunchKernelGGL(att_bwd_jfin_kernel, dim3(jf_blocks), dim3(256), 0, stream, a);
-        MMB_HIP(hipGetLastError());
-    }
-    {
-        size_t lds = (size_t)4 * PANEL_B + ((size_t)10 * pad32(M) + 16) * sizeof(float);
-        const size_t epi = ((size_t)2 * 16 * NW * LDP + 16 * NW + NW * 2 * 256) * sizeof(float);   // parked dX, P2.dq tiles + dr + partial sums
-        if (lds < epi) lds = epi;
-        const bool same = a.fold && a.pMd == a.pM && a.pTd == a.pT;
-        auto kern = a.dbg ? (same ? att_bwd_i_kernel<true, true> : att_bwd_i_kernel<true, false>)
-                          : (same ? att_bwd_i_kernel<false, true> : att_bwd_i_kernel<false, false>);
-        if (int rc = allow_lds(kern, lds)) return rc;
-        a.i_blocks = tiles_t * B;
-        ProfScope ps_(MMB_K_ATT_BWD_I, stream);
-        hipLaunchKernelGGL(kern, dim3(a.i_blocks + (separate ? 0 : jf_blocks)), dim3(NTHR), lds, stream, a);
-    }
-    MMB_HIP(hipGetLastError());
-    return MMB_OK;
+    MMB_REQUIRE((text_d != nullptr) == (mod_d != nullptr), "mmb_bidaf_bwd: text_d and mod_d must both be given or both be NULL");
+    mmb_bidaf_desc s{};
+    s.text = text; s.mod = mod; s.text_mask = text_mask; s.mod_mask = mod_mask; s.text_len = text_len; s.mod_len = mod_len;
+    s.text_d = text_d; s.mod_d = mod_d; s.w_t = w_t; s.w_m = w_m; s.w_tm = w_tm; s.bias = nullptr;
+    s.out = const_cast<float*>(out); s.bsave = const_cast<float*>(bsave); s.rterm = const_cast<float*>(rterm);
+    s.cterm = const_cast<float*>(cterm); s.row_stat = const_cast<float*>(row_stat); s.col_stat = const_cast<float*>(col_stat);
+    s.saved = const_cast<void*>(saved); s.saved_bytes = mmb_bidaf_saved_bytes(B, T, M, D, text_d != nullptr);
+    s.workspace = workspace; s.workspace_bytes = workspace_bytes;
+    s.d_out = d_out; s.d_text = d_text; s.d_mod = d_mod; s.d_text_d = d_text_d; s.d_mod_d = d_mod_d;
+    s.d_w_t = d_w_t; s.d_w_m = d_w_m; s.d_w_tm = d_w_tm; s.d_bias = d_bias;
+    s.T = T; s.M = M;
+    return mmb_bidaf_group_bwd(&s, 1, B, D, device, stream_);
 }

@@ -281,93 +281,135 @@ class PrefixMask:
         return self._tensor
 
 
-class _BiDAFAttentionFn(torch.autograd.Function):
-    """out = BiDAFAttention(text, mod)  -- reference layers/attention.py:37-75 (A1-A5, A-bwd)."""
+_ATT_ARGS = 10     # per attention: text, mod, text_d, mod_d, w_t, w_m, w_tm, bias, text_mask, mod_mask
+
+
+class _BiDAFAttentionGroupFn(torch.autograd.Function):
+    """out_k = BiDAFAttention_k(text_k, mod_k) for up to 4 attentions in ONE grouped library call (one launch per stage for
+    the whole group; attentions that share their text tensor share its operand planes) -- reference
+    layers/attention.py:37-75 (A1-A5, A-bwd); the model's pair is models.py:131-132."""
 
     @staticmethod
-    def forward(ctx, text, mod, text_d, mod_d, w_t, w_m, w_tm, bias, text_mask, mod_mask):
+    def forward(ctx, *flat):
         lib = _lib.load()
-        _require_gpu(text, mod, w_t, w_m, w_tm, bias)
-        B, T, D = text.shape
-        M = mod.shape[1]
-        if D % 4 != 0 or D > _lib.ATT_GENERAL_MAX_D:
-            raise RuntimeError(f"mmbidaf_amd: attention width D=2H={D} must be a multiple of 4 and <= {_lib.ATT_GENERAL_MAX_D}")
-        text, mod = _f32c(text), _f32c(mod)
-        has_drop = text_d is not None
-        if has_drop:
-            text_d, mod_d = _f32c(text_d), _f32c(mod_d)
-        w_t_, w_m_, w_tm_, bias_ = (_f32c(w_t.reshape(-1)), _f32c(w_m.reshape(-1)),
-                                    _f32c(w_tm.reshape(-1)), _f32c(bias.reshape(-1)))
-        fused = D <= _lib.ATT_MAX_D
+        n = len(flat) // _ATT_ARGS
+        assert len(flat) == n * _ATT_ARGS and 1 <= n <= _lib.MAX_ATT_GROUP
+        descs = (_lib.BidafDesc * n)()
+        saved, outs, meta, keep = [], [], [], []
+        B = D = dev = None
+        for k in range(n):
+            text, mod, text_d, mod_d, w_t, w_m, w_tm, bias, text_mask, mod_mask = flat[k * _ATT_ARGS:(k + 1) * _ATT_ARGS]
+            _require_gpu(text, mod, w_t, w_m, w_tm, bias)
+            if k == 0:
+                B, _, D = text.shape
+                dev = text.device
+                if D % 4 != 0 or D > _lib.ATT_GENERAL_MAX_D:
+                    raise RuntimeError(f"mmbidaf_amd: attention width D=2H={D} must be a multiple of 4 and <= {_lib.ATT_GENERAL_MAX_D}")
+            T, M = text.shape[1], mod.shape[1]
+            if text.shape != (B, T, D) or mod.shape != (B, M, D):
+                raise RuntimeError("mmbidaf_amd: the attentions of a grouped call must agree in batch size and width")
+            text, mod = _f32c(text), _f32c(mod)
+            has_drop = text_d is not None
+            if has_drop:
+                text_d, mod_d = _f32c(text_d), _f32c(mod_d)
+            w_t_, w_m_, w_tm_, bias_ = (_f32c(w_t.reshape(-1)), _f32c(w_m.reshape(-1)), _f32c(w_tm.reshape(-1)), _f32c(bias.reshape(-1)))
+            fused = D <= _lib.ATT_MAX_D
 
-        def mask_args(mask, n):
-            """(u8 mask or None, int32 lengths or None): prefix masks travel as lengths on the fused path"""
-            if isinstance(mask, PrefixMask):
-                if fused:
-                    return None, mask.lengths_dev
-                mask = mask.tensor()
-            _require_gpu(mask)
-            return _mask_u8(mask, B, n), None
-        tmask, tlen = mask_args(text_mask, T)
-        mmask, mlen = mask_args(mod_mask, M)
-        dev = text.device
-        out = torch.empty(B, T, 4 * D, device=dev, dtype=torch.float32)
-        bsave = torch.empty(B, T, D, device=dev, dtype=torch.float32)
-        rterm = torch.empty(B, T, device=dev, dtype=torch.float32)
-        cterm = torch.empty(B, M, device=dev, dtype=torch.float32)
-        row_stat = torch.empty(B, T, 2, device=dev, dtype=torch.float32)
-        col_stat = torch.empty(B, M, 2, device=dev, dtype=torch.float32)
-        saved_bytes = lib.mmb_bidaf_saved_bytes(B, T, M, D, int(has_drop))
-        saved = torch.empty(saved_bytes, device=dev, dtype=torch.uint8)      # operand planes + row scales (or q, general path)
-        ws_bytes = lib.mmb_bidaf_fwd_workspace_bytes(B, T, M, D)
-        ws = torch.empty(max(ws_bytes, 4) // 4, device=dev, dtype=torch.float32)
-        rc = lib.mmb_bidaf_fwd(_ptr(text), _ptr(mod), _ptr(tmask), _ptr(mmask), _ptr(tlen), _ptr(mlen),
-                               _ptr(text_d) if has_drop else None, _ptr(mod_d) if has_drop else None,
-                               _ptr(w_t_), _ptr(w_m_), _ptr(w_tm_), _ptr(bias_),
-                               _ptr(out), _ptr(bsave), _ptr(rterm), _ptr(cterm), _ptr(row_stat), _ptr(col_stat),
-                               _ptr(saved), saved_bytes, _ptr(ws), ws_bytes, B, T, M, D, dev.index, _stream())
-        _lib.check(rc, "mmb_bidaf_fwd")
-        ctx.has_drop = has_drop
-        ctx.shapes = (w_t.shape, w_m.shape, w_tm.shape, bias.shape)
-        ctx.save_for_backward(text, mod, text_d if has_drop else None, mod_d if has_drop else None,
-                              w_t_, w_m_, w_tm_, tmask, mmask, tlen, mlen, out, saved, bsave, rterm, cterm, row_stat, col_stat)
-        return out
+            def mask_args(mask, cnt):
+                """(u8 mask or None, int32 lengths or None): prefix masks travel as lengths on the fused path"""
+                if isinstance(mask, PrefixMask):
+                    if fused:
+                        return None, mask.lengths_dev
+                    mask = mask.tensor()
+                _require_gpu(mask)
+                return _mask_u8(mask, B, cnt), None
+            tmask, tlen = mask_args(text_mask, T)
+            mmask, mlen = mask_args(mod_mask, M)
+            out = torch.empty(B, T, 4 * D, device=dev, dtype=torch.float32)
+            bsave = torch.empty(B, T, D, device=dev, dtype=torch.float32)
+            rterm = torch.empty(B, T, device=dev, dtype=torch.float32)
+            cterm = torch.empty(B, M, device=dev, dtype=torch.float32)
+            row_stat = torch.empty(B, T, 2, device=dev, dtype=torch.float32)
+            col_stat = torch.empty(B, M, 2, device=dev, dtype=torch.float32)
+            saved_bytes = lib.mmb_bidaf_saved_bytes(B, T, M, D, int(has_drop))
+            sv = torch.empty(saved_bytes, device=dev, dtype=torch.uint8)      # operand planes + row scales (or q, general path)
+            ws_bytes = lib.mmb_bidaf_fwd_workspace_bytes(B, T, M, D)
+            ws = torch.empty(max(ws_bytes, 4) // 4, device=dev, dtype=torch.float32)
+            d = descs[k]
+            d.text, d.mod, d.text_mask, d.mod_mask, d.text_len, d.mod_len = _ptr(text), _ptr(mod), _ptr(tmask), _ptr(mmask), _ptr(tlen), _ptr(mlen)
+            d.text_d, d.mod_d = (_ptr(text_d), _ptr(mod_d)) if has_drop else (None, None)
+            d.w_t, d.w_m, d.w_tm, d.bias = _ptr(w_t_), _ptr(w_m_), _ptr(w_tm_), _ptr(bias_)
+            d.out, d.bsave, d.rterm, d.cterm, d.row_stat, d.col_stat = _ptr(out), _ptr(bsave), _ptr(rterm), _ptr(cterm), _ptr(row_stat), _ptr(col_stat)
+            d.saved, d.saved_bytes, d.workspace, d.workspace_bytes = _ptr(sv), saved_bytes, _ptr(ws), ws_bytes
+            d.T, d.M = T, M
+            keep += [ws, bias_]
+            meta.append((has_drop, (w_t.shape, w_m.shape, w_tm.shape, bias.shape)))
+            saved += [text, mod, text_d if has_drop else None, mod_d if has_drop else None, w_t_, w_m_, w_tm_, tmask, mmask, tlen, mlen,
+                      out, sv, bsave, rterm, cterm, row_stat, col_stat]
+            outs.append(out)
+        _lib.check(lib.mmb_bidaf_group_fwd(descs, n, B, D, dev.index, _stream()), "mmb_bidaf_group_fwd")
+        ctx.n, ctx.meta = n, meta
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, d_out):
+    def backward(ctx, *d_outs):
         lib = _lib.load()
-        (text, mod, text_d, mod_d, w_t, w_m, w_tm, tmask, mmask, tlen, mlen, out, saved, bsave, rterm, cterm,
-         row_stat, col_stat) = ctx.saved_tensors
-        B, T, D = text.shape
-        M = mod.shape[1]
-        dev = text.device
-        d_out = _f32c(d_out)
-        d_text = torch.empty_like(text)
-        d_mod = torch.empty_like(mod)
-        d_text_d = torch.empty_like(text) if ctx.has_drop else None
-        d_mod_d = torch.empty_like(mod) if ctx.has_drop else None
-        d_w = torch.empty(3 * D + 4, device=dev, dtype=torch.float32)
-        d_w_t, d_w_m, d_w_tm, d_bias = d_w[0:D], d_w[D:2 * D], d_w[2 * D:3 * D], d_w[3 * D:3 * D + 1]
-        ws_bytes = lib.mmb_bidaf_bwd_workspace_bytes(B, T, M, D)
-        ws = torch.empty(ws_bytes // 4, device=dev, dtype=torch.float32)
-        rc = lib.mmb_bidaf_bwd(_ptr(d_out), _ptr(out), _ptr(text), _ptr(mod), _ptr(tmask), _ptr(mmask), _ptr(tlen), _ptr(mlen),
-                               _ptr(text_d), _ptr(mod_d), _ptr(w_t), _ptr(w_m), _ptr(w_tm),
-                               _ptr(saved), _ptr(bsave), _ptr(rterm), _ptr(cterm), _ptr(row_stat), _ptr(col_stat),
-                               _ptr(d_text), _ptr(d_mod), _ptr(d_text_d), _ptr(d_mod_d),
-                               _ptr(d_w_t), _ptr(d_w_m), _ptr(d_w_tm), _ptr(d_bias),
-                               _ptr(ws), ws_bytes, B, T, M, D, dev.index, _stream())
-        _lib.check(rc, "mmb_bidaf_bwd")
-        s_t, s_m, s_tm, s_b = ctx.shapes
-        return (d_text, d_mod, d_text_d, d_mod_d, d_w_t.reshape(s_t), d_w_m.reshape(s_m), d_w_tm.reshape(s_tm),
-                d_bias.reshape(s_b), None, None)
+        n = ctx.n
+        sv_all = ctx.saved_tensors
+        descs = (_lib.BidafDesc * n)()
+        results, keep = [], []
+        B = D = dev = None
+        for k in range(n):
+            (text, mod, text_d, mod_d, w_t, w_m, w_tm, tmask, mmask, tlen, mlen, out, saved, bsave, rterm, cterm,
+             row_stat, col_stat) = sv_all[k * 18:(k + 1) * 18]
+            has_drop, (s_t, s_m, s_tm, s_b) = ctx.meta[k]
+            B, T, D = text.shape
+            M = mod.shape[1]
+            dev = text.device
+            d_out = torch.zeros_like(out) if d_outs[k] is None else _f32c(d_outs[k])
+            d_text = torch.empty_like(text)
+            d_mod = torch.empty_like(mod)
+            d_text_d = torch.empty_like(text) if has_drop else None
+            d_mod_d = torch.empty_like(mod) if has_drop else None
+            d_w = torch.empty(3 * D + 4, device=dev, dtype=torch.float32)
+            d_w_t, d_w_m, d_w_tm, d_bias = d_w[0:D], d_w[D:2 * D], d_w[2 * D:3 * D], d_w[3 * D:3 * D + 1]
+            ws_bytes = lib.mmb_bidaf_bwd_workspace_bytes(B, T, M, D)
+            ws = torch.empty(ws_bytes // 4, device=dev, dtype=torch.float32)
+            d = descs[k]
+            d.text, d.mod, d.text_mask, d.mod_mask, d.text_len, d.mod_len = _ptr(text), _ptr(mod), _ptr(tmask), _ptr(mmask), _ptr(tlen), _ptr(mlen)
+            d.text_d, d.mod_d = _ptr(text_d), _ptr(mod_d)
+            d.w_t, d.w_m, d.w_tm, d.bias = _ptr(w_t), _ptr(w_m), _ptr(w_tm), None
+            d.out, d.bsave, d.rterm, d.cterm, d.row_stat, d.col_stat = _ptr(out), _ptr(bsave), _ptr(rterm), _ptr(cterm), _ptr(row_stat), _ptr(col_stat)
+            d.saved, d.saved_bytes, d.workspace, d.workspace_bytes = _ptr(saved), saved.numel(), _ptr(ws), ws_bytes
+            d.d_out, d.d_text, d.d_mod, d.d_text_d, d.d_mod_d = _ptr(d_out), _ptr(d_text), _ptr(d_mod), _ptr(d_text_d), _ptr(d_mod_d)
+            d.d_w_t, d.d_w_m, d.d_w_tm, d.d_bias = _ptr(d_w_t), _ptr(d_w_m), _ptr(d_w_tm), _ptr(d_bias)
+            d.T, d.M = T, M
+            keep += [d_out, ws, d_w]
+            results += [d_text, d_mod, d_text_d, d_mod_d, d_w_t.reshape(s_t), d_w_m.reshape(s_m), d_w_tm.reshape(s_tm),
+                        d_bias.reshape(s_b), None, None]
+        _lib.check(lib.mmb_bidaf_group_bwd(descs, n, B, D, dev.index, _stream()), "mmb_bidaf_group_bwd")
+        return tuple(results)
+
+
+def bidaf_attention_group(problems):
+    """problems: list of dicts / tuples (text, mod, text_mask, mod_mask, w_t, w_m, w_tm, bias[, text_d, mod_d]); returns the list
+    of outputs (B,T,4D).  One grouped library call: one launch per stage for all attentions, shared text planes."""
+    flat = []
+    for p in problems:
+        text, mod, text_mask, mod_mask, w_t, w_m, w_tm, bias = p[:8]
+        text_d, mod_d = (p[8], p[9]) if len(p) > 8 else (None, None)
+        if (text_d is None) != (mod_d is None):
+            raise ValueError("text_d and mod_d must be given together")
+        flat += [text, mod, text_d, mod_d, w_t, w_m, w_tm, bias, text_mask, mod_mask]
+    return list(_BiDAFAttentionGroupFn.apply(*flat))
 
 
 def bidaf_attention(text, mod, text_mask, mod_mask, w_t, w_m, w_tm, bias, text_d=None, mod_d=None):
     """Fused BiDAF attention.  text_d / mod_d: dropped copies seen only by the similarity (Q6).
     text_mask / mod_mask: (B,T) / (B,M) 0/1 tensors, or PrefixMask objects (lengths only)."""
-    if (text_d is None) != (mod_d is None):
-        raise ValueError("text_d and mod_d must be given together")
-    return _BiDAFAttentionFn.apply(text, mod, text_d, mod_d, w_t, w_m, w_tm, bias, text_mask, mod_mask)
+    return bidaf_attention_group([(text, mod, text_mask, mod_mask, w_t, w_m, w_tm, bias, text_d, mod_d)])[0]
 
 
 # --------------------------------------------------------------------------------------- LSTM

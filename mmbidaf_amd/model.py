@@ -12,11 +12,7 @@ import torch.nn as nn
 
 from .attention import BiDAFAttention, MultimodalAttentionDecoder
 from .encoding import Embedding, ImageEmbedding, RNNEncoder, encode_group, to_device_cached
-import os
-
-from .functional import PrefixMask, side_stream
-
-MF_TWO_STREAM_ATTENTION = os.environ.get("MMB_ATT_TWO_STREAMS", "0") == "1"
+from .functional import PrefixMask
 
 
 class MMBiDAF(nn.Module):
@@ -60,18 +56,11 @@ class MMBiDAF(nn.Module):
             lens_dev = to_device_cached("len_i32", lengths, dev, lambda: torch.tensor(list(lengths), dtype=torch.int32))
             return PrefixMask(lengths, x.size(1), lens_dev)
         text_mask, audio_mask, image_mask = mask(text_emb, text_lengths), mask(audio_emb, audio_lengths), mask(image_emb, image_lengths)
-        if dev.type == "cuda" and MF_TWO_STREAM_ATTENTION:
-            # the two attentions are independent (models.py:131-132): text<->image runs on the side stream beside
-            # text<->audio (autograd runs each backward on its forward's stream and orders the streams itself)
-            main, side = torch.cuda.current_stream(dev), side_stream(dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                att_image = self.bidaf_att_image(text_enc, image_enc, text_mask, image_mask)
-            att_audio = self.bidaf_att_audio(text_enc, audio_enc, text_mask, audio_mask)
-            main.wait_stream(side)
-            for t in (text_enc, image_enc):
-                t.record_stream(side)
-            att_image.record_stream(main)
+        if dev.type == "cuda":
+            # the two attentions are independent and share the text operand (models.py:131-132): ONE grouped call
+            att_audio, att_image = BiDAFAttention.forward_group(
+                [self.bidaf_att_audio, self.bidaf_att_image], [text_enc, text_enc], [audio_enc, image_enc],
+                [text_mask, text_mask], [audio_mask, image_mask])
         else:
             att_audio = self.bidaf_att_audio(text_enc, audio_enc, text_mask, audio_mask)
             att_image = self.bidaf_att_image(text_enc, image_enc, text_mask, image_mask)

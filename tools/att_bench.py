@@ -2,9 +2,9 @@
 """Per-kernel times of the fused BiDAF attention (forward + backward) on the cfg2 shapes, with the library's
 timing-only ablations (mmb_set_att_debug; results of ablated runs are wrong by design):
 
-    python tools/att_bench.py [--iters 20] [--masks 0,1,2,4,8,16] [--B 32 --T 400 --D 200]
+    python tools/att_bench.py [--iters 20] [--masks 0,2,4,8,16] [--B 32 --T 400 --D 200 --Ms 256,64]
 
-GPU box only.  Rows: kernel; columns: ablation mask.  us per launch, audio (M=256) and image (M=64) separately."""
+GPU box only.  Rows: kernel; columns: ablation mask.  us per grouped launch (all attentions of --Ms in one call, shared text)."""
 import argparse
 import os
 import sys
@@ -14,70 +14,74 @@ import torch
 
 from mmbidaf_amd import _lib, functional as MF
 
-KERNELS = ["att_rank1", "att_col", "att_combine", "att_row", "att_bwd_pre", "att_bwd_j1", "att_bwd_j2", "att_bwd_jfin", "att_bwd_i"]
+KERNELS = ["att_rank1", "att_col", "att_row", "att_bwd_pre", "att_bwd_j1", "att_bwd_i"]   # split, column, row; prologue, dq sweep, gradient sweeps
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--masks", default="0,1,2,4,6,8,16")
+    ap.add_argument("--masks", default="0,2,4,6,8,16")
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--T", type=int, default=400)
     ap.add_argument("--D", type=int, default=200)
-    ap.add_argument("--Ms", default="256,64")
+    ap.add_argument("--Ms", default="256,64", help="modality lengths of the attentions of ONE grouped call (shared text)")
     ap.add_argument("--drop", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
     g = torch.Generator().manual_seed(1)
-    for M in [int(m) for m in a.Ms.split(",")]:
-        B, T, D = a.B, a.T, a.D
-        text = torch.randn(B, T, D, generator=g).to(dev).requires_grad_(True)
+    B, T, D = a.B, a.T, a.D
+    Ms = [int(m) for m in a.Ms.split(",")]
+    text = torch.randn(B, T, D, generator=g).to(dev).requires_grad_(True)
+    tl = torch.full((B,), T, dtype=torch.int32, device=dev)
+    tm = MF.PrefixMask([T] * B, T, tl)
+    probs, leaves, cots = [], [text], []
+    for M in Ms:
         mod = torch.randn(B, M, D, generator=g).to(dev).requires_grad_(True)
         ps = [(torch.randn(D, 1, generator=g) * 0.1).to(dev).requires_grad_(True), (torch.randn(D, 1, generator=g) * 0.1).to(dev).requires_grad_(True),
               (torch.randn(1, 1, D, generator=g) * 0.1).to(dev).requires_grad_(True), torch.zeros(1, device=dev, requires_grad=True)]
-        tl = torch.full((B,), T, dtype=torch.int32, device=dev)
         ml = torch.full((B,), M, dtype=torch.int32, device=dev)
-        tm, mm = MF.PrefixMask([T] * B, T, tl), MF.PrefixMask([M] * B, M, ml)
-        cot = torch.randn(B, T, 4 * D, generator=g).to(dev)
-        kw = {}
+        mm = MF.PrefixMask([M] * B, M, ml)
+        drops = (None, None)
         if a.drop:
-            kw = dict(text_d=text * (torch.rand(B, T, D, device=dev) > 0.2).float() / 0.8, mod_d=mod * (torch.rand(B, M, D, device=dev) > 0.2).float() / 0.8)
+            drops = (text * (torch.rand(B, T, D, device=dev) > 0.2).float() / 0.8, mod * (torch.rand(B, M, D, device=dev) > 0.2).float() / 0.8)
+        probs.append((text, mod, tm, mm, *ps, *drops))
+        leaves += [mod] + ps
+        cots.append(torch.randn(B, T, 4 * D, generator=g).to(dev))
 
-        def step():
-            for t in [text, mod] + ps:
-                t.grad = None
-            out = MF.bidaf_attention(text, mod, tm, mm, *ps, **kw)
-            out.backward(cot)
-        table = {}
-        for mask in [int(x) for x in a.masks.split(",")]:
-            lib.mmb_set_att_debug(mask)
-            for _ in range(3):
-                step()
-            torch.cuda.synchronize()
-            _lib.profile_enable(KERNELS)
-            for _ in range(a.iters):
-                step()
-            torch.cuda.synchronize()
-            _lib.profile_enable([])
-            table[mask] = {k: _lib.profile_read(k) for k in KERNELS}
-        lib.mmb_set_att_debug(0)
-        print(f"\nB={B} T={T} M={M} D={D} drop={a.drop}: us per launch by ablation mask "
-              f"(1 first panel only staged, 2 no S products, 4 no PV products, 8 no epilogue, 16 no panel loop)")
-        print(f"{'kernel':14s}" + "".join(f"{m:>9d}" for m in table))
-        tot = {m: 0.0 for m in table}
-        for k in KERNELS:
-            row = f"{k:14s}"
-            for m in table:
-                ms, n, _ = table[m][k]
-                us = ms / max(n, 1) * 1e3
-                tot[m] += us
-                row += f"{us:9.1f}"
-            print(row)
-        print(f"{'total':14s}" + "".join(f"{tot[m]:9.1f}" for m in table))
-        fb = MF.attention_bytes(B, T, M, D) if hasattr(MF, "attention_bytes") else None
-        alg = 4 * B * (5 * T * D + M * D) + 4 * B * (6 * T * D + 2 * M * D)
-        print(f"algorithmic bytes fwd+bwd {alg / 1e6:.1f} MB -> {alg / (tot[0] * 1e-6) / 1e9:.0f} GB/s = {alg / (tot[0] * 1e-6) / 8e12 * 100:.1f} % of 8 TB/s")
+    def step():
+        for t in leaves:
+            t.grad = None
+        outs = MF.bidaf_attention_group(probs)
+        torch.autograd.backward(outs, cots)
+    table = {}
+    for mask in [int(x) for x in a.masks.split(",")]:
+        lib.mmb_set_att_debug(mask)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        _lib.profile_enable(KERNELS)
+        for _ in range(a.iters):
+            step()
+        torch.cuda.synchronize()
+        _lib.profile_enable([])
+        table[mask] = {k: _lib.profile_read(k) for k in KERNELS}
+    lib.mmb_set_att_debug(0)
+    print(f"\nB={B} T={T} Ms={Ms} D={D} drop={a.drop}: us per grouped launch by ablation mask "
+          f"(2 no S products, 4 no PV products, 8 no epilogue, 16 no panel loop)")
+    print(f"{'kernel':14s}" + "".join(f"{m:>9d}" for m in table))
+    tot = {m: 0.0 for m in table}
+    for k in KERNELS:
+        row = f"{k:14s}"
+        for m in table:
+            ms, n, _ = table[m][k]
+            us = ms / max(n, 1) * 1e3
+            tot[m] += us
+            row += f"{us:9.1f}"
+        print(row)
+    print(f"{'total':14s}" + "".join(f"{tot[m]:9.1f}" for m in table))
+    alg = sum(4 * B * (5 * T * D + M * D) + 4 * B * (6 * T * D + 2 * M * D) for M in Ms)
+    print(f"algorithmic bytes fwd+bwd {alg / 1e6:.1f} MB -> {alg / (tot[0] * 1e-6) / 1e9:.0f} GB/s = {alg / (tot[0] * 1e-6) / 8e12 * 100:.1f} % of 8 TB/s")
 
 
 if __name__ == "__main__":
