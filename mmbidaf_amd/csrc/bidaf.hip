@@ -1137,6 +1137,10 @@ __device__ __forceinline__ void copy_side(side_t& d, const side_t& s) {
 
 constexpr int XCH_PAIR = 4096;     // per pair: [dp1: 2 x 1 KiB][weights: 2 x 1 KiB]
 
+// workgroup barrier that orders LDS traffic only: the LDS-DMA of the next panel stays in flight across it (a __syncthreads
+// would wait for vmcnt(0), i.e. for the prefetch it is meant to overlap)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool DBG, bool SAME>
 __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, int local, char* smem) {
     const int dbg = DBG ? a.dbg : 0;
@@ -1170,26 +1174,13 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     const float* iDa_b = A.iDa + (size_t)b * Tp;
     const float* iDb_b = A.iDb + (size_t)b * Tp;
 
-    // lane-side operands: role 0 = {mod_d * w_tm (similarity), dq (dP2)}, role 1 = {mod (da.mod), q (db.q)}
-    side_t sa, sb;
-    float ina, inb;
-    if (role == 0) {
-        load_side_f32(sa, ina, A.mod_d + (size_t)b * M * D, n, M, D, g, A.w_tm);
-        load_side_planes(sb, inb, A.pDq + (size_t)b * szM, A.iDq + (size_t)b * Mp, n, M, g);
-    } else {
-        load_side_planes(sa, ina, A.pM + (size_t)b * szM, A.iM + (size_t)b * Mp, n, M, g);
-        load_side_planes(sb, inb, A.pQ + (size_t)b * szM, A.iQ + (size_t)b * Mp, n, M, g);
+    const int Tloop = (dbg & 16) ? 0 : T;
+    if (Tloop > 0) {       // first panel in flight under the operand loads below
+        stage_panel_w<8>(pTd, td_b, 0, wave, lane);
+        stage_panel_w<8>(pDa, da_b, 0, wave, lane);
+        stage_panel_w<8>(pDb, db_b, 0, wave, lane);
+        if (!SAME) stage_panel_w<8>(pT, t_b, 0, wave, lane);
     }
-    const float inM = nin ? A.iM[(size_t)b * Mp + n] : 0.f, inQ = nin ? A.iQ[(size_t)b * Mp + n] : 0.f;
-    const float inDq = nin ? A.iDq[(size_t)b * Mp + n] : 0.f;
-    const float cterm = nin ? A.cterm[(size_t)b * M + n] : 0.f;
-    const float cmax = nin ? A.col_stat[((size_t)b * M + n) * 2] : 0.f;
-    const float cinv = nin ? 1.0f / A.col_stat[((size_t)b * M + n) * 2 + 1] : 0.f;
-    const float delta2 = nin ? A.delta2[(size_t)b * M + n] : 0.f;
-    const bool mm = nin ? mask_live(A.mod_mask, A.mod_len, b, M, n) : false;
-    const float mmf = mm ? 1.f : 0.f;
-    const tr_off tr = make_tr_off(lane);
-
     float im[4] = {0.f, 0.f, 0.f, 0.f};   // text_d, text, da, db
     for (int i = tid; i < T; i += NT8) {
         im[0] = fmaxf(im[0], iTd_b[i]);
@@ -1199,9 +1190,8 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     }
     wg_allmax_w<4, 8>(im, red, tid);
     const float cDa = cmap(im[2]);
-    // |dS_ij| <= |dP1| + |delta1| + |dP2| + |delta2| <= 2 D 2^28 (inv_da_i inv_mod_j + inv_db_i inv_q_j + inv_t_i inv_dq_j)
-    const float cS = cmap_bound(im[0], 1.3743895e11f /* 2^37 */ * (im[2] * inM + im[3] * inQ + im[1] * inDq));
 
+    // per-row scalars of streamed text row t, fetched one panel ahead by thread (k = tid >> 5, rr = tid & 31)
     const int sck = tid >> 5, scr = tid & 31;
     auto fetch = [&](int t) -> float {
         const bool in = t < T;
@@ -1218,43 +1208,47 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
             default: return in ? iDb_b[t] : 0.f;
         }
     };
-    float sc_next = 0.f;
-    const int Tloop = (dbg & 16) ? 0 : T;
-    if (Tloop > 0 && sck < NSC) sc_next = fetch(scr);
+    const float* sg = sc + 4 * g;            // scalar k of the lane's 4 rows of block mb: f4 at sg[k * 32 + mb * 16]
+    const tr_off tr = make_tr_off(lane);
+    float* eD = reinterpret_cast<float*>(smem);                 // epilogue: [64][LDP]  sum_i dS text_d
+    float* eC = eD + 64 * LDP;                                  //           [64][LDP]  sum_i P1 da
+    float* dcs = eC + 64 * LDP;                                 //           [64]       dc
 
-    acc_t O;        // role 0: dmodd (sum_i dS text_d), role 1: dmodc (sum_i P1 da)
-    zero_acc(O);
-    float dc = 0.f;
-    const char* pan1 = role ? pDa : pTd;
-    const char* pan2 = role ? pDb : pT;
-    const char* panV = role ? pDa : pTd;
-    for (int p0 = 0; p0 < Tloop; p0 += PR) {
-        __syncthreads();
-        stage_panel_w<8>(pTd, td_b, p0, wave, lane);
-        stage_panel_w<8>(pDa, da_b, p0, wave, lane);
-        stage_panel_w<8>(pDb, db_b, p0, wave, lane);
-        if (!SAME) stage_panel_w<8>(pT, t_b, p0, wave, lane);
-        if (sck < NSC) sc[sck * 32 + scr] = sc_next;
-        __syncthreads();
-        if (p0 + PR < Tloop && sck < NSC) sc_next = fetch(p0 + PR + scr);
-        f4 c1[2], c2[2];
+    // Each role runs its OWN copy of the panel loop (same barrier sequence): the register allocator then sees role 0's
+    // operands + arithmetic and role 1's operands apart instead of their union.
+    //   staging: db (and the clean text with dropped copies) is read by the S-type products only and re-filled by the role-1
+    //   waves while role 0 does the tile's arithmetic; text_d and da by all waves after the PV products
+    if (role == 0) {
+        side_t sS, sDq;      // mod_d * w_tm (similarity), dq (dP2)
+        float inS, inDq;
+        load_side_f32(sS, inS, A.mod_d + (size_t)b * M * D, n, M, D, g, A.w_tm);
+        load_side_planes(sDq, inDq, A.pDq + (size_t)b * szM, A.iDq + (size_t)b * Mp, n, M, g);
+        const float inM = nin ? A.iM[(size_t)b * Mp + n] : 0.f, inQ = nin ? A.iQ[(size_t)b * Mp + n] : 0.f;
+        const float cterm = nin ? A.cterm[(size_t)b * M + n] : 0.f;
+        const float cmax = nin ? A.col_stat[((size_t)b * M + n) * 2] : 0.f;
+        const float cinv = nin ? 1.0f / A.col_stat[((size_t)b * M + n) * 2 + 1] : 0.f;
+        const float delta2 = nin ? A.delta2[(size_t)b * M + n] : 0.f;
+        const bool mm = nin ? mask_live(A.mod_mask, A.mod_len, b, M, n) : false;
+        const float mmf = mm ? 1.f : 0.f;
+        // |dS_ij| <= |dP1| + |delta1| + |dP2| + |delta2| <= 2 D 2^28 (inv_da_i inv_mod_j + inv_db_i inv_q_j + inv_t_i inv_dq_j)
+        const float cS = cmap_bound(im[0], 1.3743895e11f /* 2^37 */ * (im[2] * inM + im[3] * inQ + im[1] * inDq));
+        float sc_next = 0.f;
+        if (Tloop > 0 && sck < NSC) sc_next = fetch(scr);
+        acc_t O;        // dmodd = sum_i dS text_d
+        zero_acc(O);
+        float dc = 0.f;
+        for (int p0 = 0; p0 < Tloop; p0 += PR) {
+            if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+            __syncthreads();          // this panel's DMA has landed (vmcnt(0)), its scalars are visible
+            if (p0 + PR < Tloop && sck < NSC) sc_next = fetch(p0 + PR + scr);
+            f4 c1[2], c2[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
-        if (!(dbg & 2) && wave_on) {
-            sprod2(pan1, r, g, sa, c1);
-            sprod2(pan2, r, g, sb, c2);
-        }
-        const float* sg = sc + 4 * g;            // scalar k of the lane's 4 rows of block mb: f4 at sg[k * 32 + mb * 16]
-        if (role == 1) {
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const f4 sDa = *reinterpret_cast<const f4*>(sg + 7 * 32 + mb * 16), sDb = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16);
-                *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sDa * ina) + c2[mb] * (sDb * inb);
+            for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
+            if (!(dbg & 2) && wave_on) {
+                sprod2(pTd, r, g, sS, c1);
+                sprod2(pT, r, g, sDq, c2);
             }
-        }
-        __syncthreads();
-        half8 W0, W1;
-        if (role == 0) {
+            lds_barrier();            // role 1's dP1 is in LDS
             f4 wc[2], wd[2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -1266,41 +1260,85 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float code = s_code[e];
-                    const float xr = c1[mb][e] * (s_sTd[e] * ina) + s_rt[e] + cterm;
+                    const float xr = c1[mb][e] * (s_sTd[e] * inS) + s_rt[e] + cterm;
                     const float P1 = __expf((mm ? xr : NEG) - s_rmax[e]) * s_rinv[e];     // 0 beyond the range (rinv = 0)
                     const float P2 = code != 0.f ? __expf((code == 2.f ? xr : NEG) - cmax) * cinv : 0.f;
                     const float g1 = P1 * (dp1[e] - s_dl1[e]) * mmf;
-                    const float g2 = code == 2.f ? P2 * (c2[mb][e] * (s_sT[e] * inb) - delta2) : 0.f;
+                    const float g2 = code == 2.f ? P2 * (c2[mb][e] * (s_sT[e] * inDq) - delta2) : 0.f;
                     dc += g1 + g2;
                     wc[mb][e] = P1 * (s_sDa[e] * cDa);
                     wd[mb][e] = (g1 + g2) * (s_sTd[e] * cS);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            half8 W0, W1;
             split_w(wc[0], wc[1], W0, W1);
             xch_put(xch + 2048, W0, W1);
             split_w(wd[0], wd[1], W0, W1);
+            lds_barrier();            // role 1 has its weights
+            if (!(dbg & 4) && wave_on) pvprod(pTd, tr, W0, W1, O);
+            lds_barrier();            // all panels are free
+            if (p0 + PR < Tloop) {
+                stage_panel_w<8>(pTd, td_b, p0 + PR, wave, lane);
+                stage_panel_w<8>(pDa, da_b, p0 + PR, wave, lane);
+            }
+        }
+        dc = kg_allsum(dc);
+        __syncthreads();
+        if (dbg & 8) return;
+        const float scale = 1.0f / cS;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(eD + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
+        if (g == 0) dcs[w4 * 16 + r] = nin ? dc : 0.f;
+    } else {
+        side_t sM, sQ;       // mod (da . mod), q (db . q)
+        float inM, inQ;
+        load_side_planes(sM, inM, A.pM + (size_t)b * szM, A.iM + (size_t)b * Mp, n, M, g);
+        load_side_planes(sQ, inQ, A.pQ + (size_t)b * szM, A.iQ + (size_t)b * Mp, n, M, g);
+        float sc_next = 0.f;
+        if (Tloop > 0 && sck < NSC) sc_next = fetch(scr);
+        acc_t O;        // dmodc = sum_i P1 da
+        zero_acc(O);
+        for (int p0 = 0; p0 < Tloop; p0 += PR) {
+            if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+            __syncthreads();
+            if (p0 + PR < Tloop && sck < NSC) sc_next = fetch(p0 + PR + scr);
+            f4 c1[2], c2[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
+            if (!(dbg & 2) && wave_on) {
+                sprod2(pDa, r, g, sM, c1);
+                sprod2(pDb, r, g, sQ, c2);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const f4 sDa = *reinterpret_cast<const f4*>(sg + 7 * 32 + mb * 16), sDb = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16);
+                *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sDa * inM) + c2[mb] * (sDb * inQ);
+            }
+            lds_barrier();
+            if (p0 + PR < Tloop) {    // db (and text) are dead: re-fill them under role 0's arithmetic
+                stage_panel_w<4>(pDb, db_b, p0 + PR, w4, lane);
+                if (!SAME) stage_panel_w<4>(pT, t_b, p0 + PR, w4, lane);
+            }
+            lds_barrier();
+            half8 W0, W1;
+            xch_get(xch + 2048, W0, W1);
+            if (!(dbg & 4) && wave_on) pvprod(pDa, tr, W0, W1, O);
+            lds_barrier();
+            if (p0 + PR < Tloop) {
+                stage_panel_w<8>(pTd, td_b, p0 + PR, wave, lane);
+                stage_panel_w<8>(pDa, da_b, p0 + PR, wave, lane);
+            }
         }
         __syncthreads();
-        if (role == 1) xch_get(xch + 2048, W0, W1);
-        if (!(dbg & 4) && wave_on) pvprod(panV, tr, W0, W1, O);
-    }
-    dc = kg_allsum(dc);
-    __syncthreads();
-    if (dbg & 8) return;
-    // ---- epilogue: role 0 parks dmodd and dc, role 1 parks dmodc; then whole rows, one per wave-instruction
-    float* eD = reinterpret_cast<float*>(smem);                 // [64][LDP]  sum_i dS text_d
-    float* eC = eD + 64 * LDP;                                  // [64][LDP]  sum_i P1 da
-    float* dcs = eC + 64 * LDP;                                 // [64]
-    float* part = dcs + 64;                                     // [8][256] per-wave partial sums of d_w_m
-    {
-        float* dstt = role ? eC : eD;
-        const float scale = role ? 1.0f / cDa : 1.0f / cS;
+        if (dbg & 8) return;
+        const float scale = 1.0f / cDa;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(dstt + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
-        if (role == 0 && g == 0) dcs[w4 * 16 + r] = nin ? dc : 0.f;
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(eC + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
     }
     __syncthreads();
+    // ---- epilogue: whole rows, one per wave-instruction (role 0 parked dmodd and dc, role 1 dmodc)
+    float* part = dcs + 64;                                     // [8][256] per-wave partial sums of d_w_m
     const int row0 = tile * 64, d4 = 4 * lane;
     const bool cin = d4 < D;
     const f4 wm = cin ? *reinterpret_cast<const f4*>(A.w_m + d4) : f4{0.f, 0.f, 0.f, 0.f};
@@ -1333,7 +1371,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     }
     *reinterpret_cast<f4*>(part + wave * 256 + d4) = pw;
     __syncthreads();
-    if (tid < D) {
+    if (tid < D && !(dbg & 32)) {
         float acc = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) acc += part[w * 256 + tid];
@@ -1375,28 +1413,13 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     const float* iDq_b = A.iDq + (size_t)b * Mp;
     const float* iSp_b = (SAME ? A.iMw : A.iMd) + (size_t)b * Mp;
 
-    // lane-side operands: role 0 = {similarity operand, text (dP2)}, role 1 = {da, db}.  Without dropped copies the
-    // similarity is formed as text . (mod * w_tm): the text planes serve both products of role 0.
-    side_t sa, sb;
-    float ina, inb;
-    if (role == 0) {
-        load_side_planes(sb, inb, A.pT + (size_t)b * szT, A.iT + (size_t)b * Tp, n, T, g);
-        if (SAME) ina = inb;      // both products of role 0 use the text planes: ONE lane-side operand
-        else load_side_f32(sa, ina, A.text_d + (size_t)b * T * D, n, T, D, g, A.w_tm);
-    } else {
-        load_side_planes(sa, ina, A.pDa + (size_t)b * szT, A.iDa + (size_t)b * Tp, n, T, g);
-        load_side_planes(sb, inb, A.pDb + (size_t)b * szT, A.iDb + (size_t)b * Tp, n, T, g);
+    const int Mloop = (dbg & 16) ? 0 : M;
+    if (Mloop > 0) {       // first panel in flight under the operand loads below
+        stage_panel_w<8>(pM, m_b, 0, wave, lane);
+        stage_panel_w<8>(pQ, q_b, 0, wave, lane);
+        stage_panel_w<8>(pDq, dq_b, 0, wave, lane);
+        stage_panel_w<8>(pSp, sp_b, 0, wave, lane);
     }
-    const float inDa = nin ? A.iDa[(size_t)b * Tp + n] : 0.f, inDb = nin ? A.iDb[(size_t)b * Tp + n] : 0.f;
-    const float inT = nin ? A.iT[(size_t)b * Tp + n] : 0.f;
-    const float rterm = nin ? A.rterm[(size_t)b * T + n] : 0.f;
-    const float rmax = nin ? A.row_stat[((size_t)b * T + n) * 2] : 0.f;
-    const float rinv = nin ? 1.0f / A.row_stat[((size_t)b * T + n) * 2 + 1] : 0.f;
-    const float dl1 = nin ? A.delta1[(size_t)b * T + n] : 0.f;
-    const bool tm = nin ? mask_live(A.text_mask, A.text_len, b, T, n) : false;
-    const float tmf = tm ? 1.f : 0.f;
-    const tr_off tr = make_tr_off(lane);
-
     float im[4] = {0.f, 0.f, 0.f, 0.f};   // mod, mod_d, q, dq
     for (int j = tid; j < M; j += NT8) {
         im[0] = fmaxf(im[0], iM_b[j]);
@@ -1406,6 +1429,8 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     }
     wg_allmax_w<4, 8>(im, red, tid);
     const float cDq = cmap(im[3]);
+    const float inDa = nin ? A.iDa[(size_t)b * Tp + n] : 0.f, inDb = nin ? A.iDb[(size_t)b * Tp + n] : 0.f;
+    const float inT = nin ? A.iT[(size_t)b * Tp + n] : 0.f;
     const float cS = cmap_bound(im[1], 1.3743895e11f /* 2^37 */ * (inDa * im[0] + inDb * im[2] + im[3] * inT));   // the same value in both roles
 
     const int sck = tid >> 5, scr = tid & 31;
@@ -1425,48 +1450,45 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
             default: return in ? iQ_b[j] : 0.f;
         }
     };
-    float sc_next = 0.f;
-    const int Mloop = (dbg & 16) ? 0 : M;
-    if (Mloop > 0 && sck < NSC) sc_next = fetch(scr);
+    const float* sg = sc + 4 * g;            // scalar k of the lane's 4 rows of block mb: f4 at sg[k * 32 + mb * 16]
+    const tr_off tr = make_tr_off(lane);
+    float* eX = reinterpret_cast<float*>(smem);                 // epilogue: [64][LDP]  dX
+    float* eT = eX + 64 * LDP;                                  //           [64][LDP]  sum_j P2 dq
+    float* drs = eT + 64 * LDP;                                 //           [64]       dr
 
-    acc_t O;        // role 0: sum_j P2 dq, role 1: dX = sum_j dS mod_d
-    zero_acc(O);
-    float dr = 0.f;
-    const char* pan1 = role ? pM : pSp;
-    const char* pan2 = role ? pQ : pDq;
-    const char* panV = role ? pMd : pDq;
-    for (int p0 = 0; p0 < Mloop; p0 += PR) {
-        __syncthreads();
-        stage_panel_w<8>(pM, m_b, p0, wave, lane);
-        stage_panel_w<8>(pQ, q_b, p0, wave, lane);
-        stage_panel_w<8>(pDq, dq_b, p0, wave, lane);
-        stage_panel_w<8>(pSp, sp_b, p0, wave, lane);
-        if (sck < NSC) sc[sck * 32 + scr] = sc_next;
-        __syncthreads();
-        if (p0 + PR < Mloop && sck < NSC) sc_next = fetch(p0 + PR + scr);
-        f4 c1[2], c2[2];
+    // role-specialised copies of the panel loop, as in the j sweep.  Staging: the panels only the S-type products read -- q and
+    // the similarity operand mod * w_tm (eval mode) / q and mod (training mode, where the dropped copy is also the value tensor
+    // of dX) -- are re-filled by the role-1 waves under role 0's arithmetic, the other two by all waves after the PV products
+    if (role == 0) {
+        side_t sT, sS;       // text (dP2; without dropped copies also the similarity, formed as text . (mod * w_tm)); text_d * w_tm
+        float inS = inT;
+        float inT_;
+        load_side_planes(sT, inT_, A.pT + (size_t)b * szT, A.iT + (size_t)b * Tp, n, T, g);
+        if (!SAME) load_side_f32(sS, inS, A.text_d + (size_t)b * T * D, n, T, D, g, A.w_tm);
+        const float rterm = nin ? A.rterm[(size_t)b * T + n] : 0.f;
+        const float rmax = nin ? A.row_stat[((size_t)b * T + n) * 2] : 0.f;
+        const float rinv = nin ? 1.0f / A.row_stat[((size_t)b * T + n) * 2 + 1] : 0.f;
+        const float dl1 = nin ? A.delta1[(size_t)b * T + n] : 0.f;
+        const bool tm = nin ? mask_live(A.text_mask, A.text_len, b, T, n) : false;
+        const float tmf = tm ? 1.f : 0.f;
+        float sc_next = 0.f;
+        if (Mloop > 0 && sck < NSC) sc_next = fetch(scr);
+        acc_t O;        // sum_j P2 dq
+        zero_acc(O);
+        float dr = 0.f;
+        for (int p0 = 0; p0 < Mloop; p0 += PR) {
+            if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+            __syncthreads();          // this panel's DMA has landed (vmcnt(0)), its scalars are visible
+            if (p0 + PR < Mloop && sck < NSC) sc_next = fetch(p0 + PR + scr);
+            f4 c1[2], c2[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
-        if (!(dbg & 2) && wave_on) {
-            if (SAME && role == 0) {
-                sprod2(pSp, r, g, sb, c1);
-                sprod2(pDq, r, g, sb, c2);
-            } else {
-                sprod2(pan1, r, g, sa, c1);
-                sprod2(pan2, r, g, sb, c2);
+            for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
+            if (!(dbg & 2) && wave_on) {
+                if (SAME) sprod2(pSp, r, g, sT, c1);
+                else sprod2(pSp, r, g, sS, c1);
+                sprod2(pDq, r, g, sT, c2);
             }
-        }
-        const float* sg = sc + 4 * g;            // scalar k of the lane's 4 rows of block mb: f4 at sg[k * 32 + mb * 16]
-        if (role == 1) {
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const f4 sM = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16), sQ = *reinterpret_cast<const f4*>(sg + 9 * 32 + mb * 16);
-                *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sM * ina) + c2[mb] * (sQ * inb);
-            }
-        }
-        __syncthreads();
-        half8 W0, W1;
-        if (role == 0) {
+            lds_barrier();            // role 1's dP1 is in LDS
             f4 wt[2], wx[2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -1478,44 +1500,88 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float mf = s_mf[e];
-                    const float x = c1[mb][e] * (s_sSp[e] * ina) + rterm + s_ct[e];
+                    const float x = c1[mb][e] * (s_sSp[e] * inS) + rterm + s_ct[e];
                     const float P1 = mf >= 0.f ? __expf((mf > 0.f ? x : NEG) - rmax) * rinv : 0.f;
                     const float P2 = mf >= 0.f ? __expf((tm ? x : NEG) - s_cmax[e]) * s_cinv[e] : 0.f;
                     const float g1 = mf > 0.f ? P1 * (dp1[e] - dl1) : 0.f;
-                    const float g2 = P2 * (c2[mb][e] * (s_sDq[e] * inb) - s_dl2[e]) * tmf;
+                    const float g2 = P2 * (c2[mb][e] * (s_sDq[e] * inT) - s_dl2[e]) * tmf;
                     dr += g1 + g2;
                     wt[mb][e] = P2 * (s_sDq[e] * cDq);
                     wx[mb][e] = (g1 + g2) * (s_sMd[e] * cS);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            half8 W0, W1;
             split_w(wx[0], wx[1], W0, W1);
             xch_put(xch + 2048, W0, W1);
             split_w(wt[0], wt[1], W0, W1);
+            lds_barrier();            // role 1 has its weights
+            if (!(dbg & 4) && wave_on) pvprod(pDq, tr, W0, W1, O);
+            lds_barrier();            // all panels are free
+            if (p0 + PR < Mloop) {
+                stage_panel_w<8>(pDq, dq_b, p0 + PR, wave, lane);
+                stage_panel_w<8>(SAME ? pM : pSp, SAME ? m_b : sp_b, p0 + PR, wave, lane);
+            }
+        }
+        dr = kg_allsum(dr);
+        __syncthreads();
+        if (dbg & 8) return;
+        const float scale = 1.0f / cDq;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(eT + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
+        if (g == 0) drs[w4 * 16 + r] = nin ? dr : 0.f;
+    } else {
+        side_t sDa, sDb;
+        float iDa_, iDb_;
+        load_side_planes(sDa, iDa_, A.pDa + (size_t)b * szT, A.iDa + (size_t)b * Tp, n, T, g);
+        load_side_planes(sDb, iDb_, A.pDb + (size_t)b * szT, A.iDb + (size_t)b * Tp, n, T, g);
+        float sc_next = 0.f;
+        if (Mloop > 0 && sck < NSC) sc_next = fetch(scr);
+        acc_t O;        // dX = sum_j dS mod_d
+        zero_acc(O);
+        for (int p0 = 0; p0 < Mloop; p0 += PR) {
+            if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+            __syncthreads();
+            if (p0 + PR < Mloop && sck < NSC) sc_next = fetch(p0 + PR + scr);
+            f4 c1[2], c2[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
+            if (!(dbg & 2) && wave_on) {
+                sprod2(pM, r, g, sDa, c1);
+                sprod2(pQ, r, g, sDb, c2);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const f4 sM = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16), sQ = *reinterpret_cast<const f4*>(sg + 9 * 32 + mb * 16);
+                *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sM * inDa) + c2[mb] * (sQ * inDb);
+            }
+            lds_barrier();
+            if (p0 + PR < Mloop) {    // the S-only panels are dead: re-fill them under role 0's arithmetic
+                stage_panel_w<4>(pQ, q_b, p0 + PR, w4, lane);
+                stage_panel_w<4>(SAME ? pSp : pM, SAME ? sp_b : m_b, p0 + PR, w4, lane);
+            }
+            lds_barrier();
+            half8 W0, W1;
+            xch_get(xch + 2048, W0, W1);
+            if (!(dbg & 4) && wave_on) pvprod(pMd, tr, W0, W1, O);
+            lds_barrier();
+            if (p0 + PR < Mloop) {
+                stage_panel_w<8>(pDq, dq_b, p0 + PR, wave, lane);
+                stage_panel_w<8>(SAME ? pM : pSp, SAME ? m_b : sp_b, p0 + PR, wave, lane);
+            }
         }
         __syncthreads();
-        if (role == 1) xch_get(xch + 2048, W0, W1);
-        if (!(dbg & 4) && wave_on) pvprod(panV, tr, W0, W1, O);
+        if (dbg & 8) return;
+        const float scale = 1.0f / cS;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(eX + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
     }
-    dr = kg_allsum(dr);
     __syncthreads();
-    if (dbg & 8) return;
-    // ---- epilogue.  The accumulator tiles hold 16 rows x 64-B pieces per instruction; role 1 parks dX, role 0 the P2.dq
-    // sum and dr in LDS (the panels are dead) and the workgroup then works on whole rows -- one text row per
+    // ---- epilogue.  The accumulator tiles hold 16 rows x 64-B pieces per instruction; role 1 parked dX, role 0 the P2.dq
+    // sum and dr in LDS (the panels are dead) and the workgroup now works on whole rows -- one text row per
     // wave-instruction, lane = 16-B chunk -- so that text_d, the d_text read-modify-write and d_text_d are fully coalesced,
     // and the parameter-gradient sums over rows (d_w_t, d_w_tm) are per-lane accumulations over the wave's rows.
-    float* eX = reinterpret_cast<float*>(smem);                 // [64][LDP]  dX
-    float* eT = eX + 64 * LDP;                                  // [64][LDP]  sum_j P2 dq
-    float* drs = eT + 64 * LDP;                                 // [64]       dr
     float* part = drs + 64;                                     // [8][2][256] per-wave partial sums of d_w_t, d_w_tm
-    {
-        float* dstt = role ? eX : eT;
-        const float scale = role ? 1.0f / cS : 1.0f / cDq;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(dstt + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
-        if (role == 0 && g == 0) drs[w4 * 16 + r] = nin ? dr : 0.f;
-    }
-    __syncthreads();
     const int row0 = tile * 64, d4 = 4 * lane;
     const bool cin = d4 < D;
     const f4 wt4 = cin ? *reinterpret_cast<const f4*>(A.w_t + d4) : f4{0.f, 0.f, 0.f, 0.f};
@@ -1555,14 +1621,14 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     __syncthreads();
     {
         const int which = tid >> 8, d = tid & 255;   // 2 x 256 threads cover d_w_t | d_w_tm (D <= 208)
-        if (d < D) {
+        if (d < D && !(dbg & 32)) {
             float acc = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) acc += part[(w * 2 + which) * 256 + d];
             atomicAdd((which ? A.d_w_tm : A.d_w_t) + d, acc);
         }
     }
-    if (wave == 0) {
+    if (wave == 0 && !(dbg & 32)) {
         const float sb_ = wave_allsum(drs[lane]);
         if (lane == 0) atomicAdd(A.d_bias, sb_);
     }
