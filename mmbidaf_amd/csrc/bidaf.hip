@@ -209,6 +209,22 @@ __device__ __forceinline__ void load_side_planes(side_t& sd, float& inv_n, const
     }
     inv_n = n < N ? inv_b[n] : 0.f;
 }
+// lane-side operand src * w (feature-wise) from an operand already in registers: reconstructed, scaled, split again
+__device__ __forceinline__ void side_times_w(const side_t& src, float in_src, const float* w, int D, int g, side_t& dst, float& in_dst) {
+    float x[KT][8];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int d = 32 * kt + 8 * g + 4 * h;
+            const f4 wv = d < D ? *reinterpret_cast<const f4*>(w + d) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[kt][4 * h + j] = ((float)src.h[kt][0][4 * h + j] + (float)src.h[kt][1][4 * h + j]) * wv[j];
+        }
+    float inv;
+    side_from_regs(x, dst, inv);
+    in_dst = inv * in_src;
+}
 // value of the lane's features of a planes row, reconstructed to fp32 (x = (h0 + h1) * inv)
 __device__ __forceinline__ float side_dot_regs(const side_t& sd, float inv_n, const float (&x)[KT][8]) {
     float acc = 0.f;
@@ -437,9 +453,9 @@ struct AttG {
     const int *text_len, *mod_len;                  // (B) or null
     const float *w_t, *w_m, *w_tm, *bias;
     float *out, *bsave, *rterm, *cterm, *row_stat, *col_stat;
-    // operand planes + inverse row scales: text, dropped text, mod, dropped mod, mod_d * w_tm (eval mode only), q
-    char *pT, *pTd, *pM, *pMd, *pMw, *pQ;
-    float *iT, *iTd, *iM, *iMd, *iMw, *iQ;
+    // operand planes + inverse row scales: text, dropped text, mod, dropped mod, q
+    char *pT, *pTd, *pM, *pMd, *pQ;
+    float *iT, *iTd, *iM, *iMd, *iQ;
     // backward
     const float* d_out;
     float *d_text, *d_mod, *d_text_d, *d_mod_d, *d_w_t, *d_w_m, *d_w_tm, *d_bias;
@@ -1141,6 +1157,25 @@ constexpr int XCH_PAIR = 4096;     // per pair: [dp1: 2 x 1 KiB][weights: 2 x 1 
 // would wait for vmcnt(0), i.e. for the prefetch it is meant to overlap)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Panel ring of the gradient sweeps: NS = 5 LDS slots of one 28-KiB panel each for the NT = 3 (eval mode) or 4 (training
+// mode) tensors a sweep streams.  Piece q = (panel index) * NT + x lives in slot q % NS; tensor order x: first the tensors
+// only the S-type products read (their slots come free in the MIDDLE of an iteration), then the value tensors of the PV
+// products (free at its end).  With NT = 3 all of panel p + 1 is issued in the middle of iteration p -- two pieces into the
+// spare slots, the third into the slot the S-only tensor of panel p has just vacated -- so the LDS-DMA runs under the tile
+// arithmetic and the PV products, and the one full wait per iteration (top of the loop) finds its data landed.
+constexpr int RING_NS = 5;
+__device__ __forceinline__ char* ring_slot(char* smem, int piece) {
+    // opaque to the optimiser: seen as a function of the loop counter, the slot address is strength-reduced into one
+    // induction variable PER fragment read (52 VGPRs in a PV product, all spilled) instead of one base + immediate offsets
+    int off = (piece % RING_NS) * PANEL_B;
+    asm volatile("" : "+s"(off));
+    return smem + off;
+}
+constexpr int SWEEP_SC_OFF = RING_NS * PANEL_B;          // per-row scalars [10][32] floats
+constexpr int SWEEP_XCH_OFF = SWEEP_SC_OFF + 10 * 32 * 4;
+constexpr int SWEEP_RED_OFF = SWEEP_XCH_OFF + 4 * XCH_PAIR;
+constexpr int SWEEP_LOOP_LDS = SWEEP_RED_OFF + 64 * 4;
+
 template <bool DBG, bool SAME>
 __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, int local, char* smem) {
     const int dbg = DBG ? a.dbg : 0;
@@ -1154,32 +1189,31 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     const bool wave_on = (tile * 4 + w4) * 16 < M;
     const bool nin = n < M;
 
-    constexpr int NPAN = SAME ? 3 : 4;
-    char* pTd = smem;
-    char* pDa = smem + PANEL_B;
-    char* pDb = smem + 2 * PANEL_B;
-    char* pT = SAME ? pTd : smem + 3 * PANEL_B;
+    // streamed tensors in ring order: db, [text], text_d, da   (text only with dropped copies)
+    constexpr int NT = SAME ? 3 : 4;
+    constexpr int X_DB = 0, X_T = 1, X_TD = SAME ? 1 : 2, X_DA = SAME ? 2 : 3;
     constexpr int NSC = 9;
-    float* sc = reinterpret_cast<float*>(smem + NPAN * PANEL_B);   // [NSC][32]
-    char* xch = reinterpret_cast<char*>(sc + NSC * 32) + w4 * XCH_PAIR + lane * 16;
-    float* red = reinterpret_cast<float*>(smem + NPAN * PANEL_B + NSC * 32 * 4 + 4 * XCH_PAIR);
+    float* sc = reinterpret_cast<float*>(smem + SWEEP_SC_OFF);   // [NSC][32]
+    char* xch = smem + SWEEP_XCH_OFF + w4 * XCH_PAIR + lane * 16;
+    float* red = reinterpret_cast<float*>(smem + SWEEP_RED_OFF);
 
     const size_t szT = planes_sample_bytes(T), szM = planes_sample_bytes(M);
-    const char* td_b = A.pTd + (size_t)b * szT;
-    const char* t_b = A.pT + (size_t)b * szT;
-    const char* da_b = A.pDa + (size_t)b * szT;
-    const char* db_b = A.pDb + (size_t)b * szT;
+    const char* src[4];
+    src[X_DB] = A.pDb + (size_t)b * szT;
+    src[X_TD] = A.pTd + (size_t)b * szT;
+    src[X_DA] = A.pDa + (size_t)b * szT;
+    if (!SAME) src[X_T] = A.pT + (size_t)b * szT;
     const float* iTd_b = A.iTd + (size_t)b * Tp;
     const float* iT_b = A.iT + (size_t)b * Tp;
     const float* iDa_b = A.iDa + (size_t)b * Tp;
     const float* iDb_b = A.iDb + (size_t)b * Tp;
 
-    const int Tloop = (dbg & 16) ? 0 : T;
-    if (Tloop > 0) {       // first panel in flight under the operand loads below
-        stage_panel_w<8>(pTd, td_b, 0, wave, lane);
-        stage_panel_w<8>(pDa, da_b, 0, wave, lane);
-        stage_panel_w<8>(pDb, db_b, 0, wave, lane);
-        if (!SAME) stage_panel_w<8>(pT, t_b, 0, wave, lane);
+    const int np = (dbg & 16) ? 0 : (T + PR - 1) / PR;       // panels
+    auto issue8 = [&](int pi, int x) { stage_panel_w<8>(ring_slot(smem, pi * NT + x), src[x], pi * PR, wave, lane); };
+    auto issue4 = [&](int pi, int x) { stage_panel_w<4>(ring_slot(smem, pi * NT + x), src[x], pi * PR, w4, lane); };
+    if (np > 0) {          // first panel in flight under the operand loads below
+#pragma unroll
+        for (int x = 0; x < NT; ++x) issue8(0, x);
     }
     float im[4] = {0.f, 0.f, 0.f, 0.f};   // text_d, text, da, db
     for (int i = tid; i < T; i += NT8) {
@@ -1214,10 +1248,24 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     float* eC = eD + 64 * LDP;                                  //           [64][LDP]  sum_i P1 da
     float* dcs = eC + 64 * LDP;                                 //           [64]       dc
 
+    // top of iteration pi, behind the full barrier: the value tensors of panel pi - 1 are free
+    auto issue_top = [&](int pi) {
+        if (NT == 4 && pi > 0) issue8(pi, 3);                   // training mode: the 4th tensor of THIS panel, just in time
+    };
+    // The whole next panel is issued by the role-1 waves right after the S-type products (they idle while role 0 does the
+    // tile's arithmetic): two pieces into the spare slots, the last into the slot the S-only tensor of this panel has just
+    // vacated.  vmcnt counts in issue order, so a wave with DMA in flight would stall at its next scratch reload: role 0
+    // never issues DMA inside the loop, and role 1 issues it BEHIND the reloads of its S-type products.
+    auto issue_mid = [&](int pi) {
+        if (pi + 1 < np) {
+            issue4(pi + 1, 0);
+            issue4(pi + 1, 1);
+            issue4(pi + 1, 2);
+        }
+    };
+
     // Each role runs its OWN copy of the panel loop (same barrier sequence): the register allocator then sees role 0's
     // operands + arithmetic and role 1's operands apart instead of their union.
-    //   staging: db (and the clean text with dropped copies) is read by the S-type products only and re-filled by the role-1
-    //   waves while role 0 does the tile's arithmetic; text_d and da by all waves after the PV products
     if (role == 0) {
         side_t sS, sDq;      // mod_d * w_tm (similarity), dq (dP2)
         float inS, inDq;
@@ -1233,14 +1281,19 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         // |dS_ij| <= |dP1| + |delta1| + |dP2| + |delta2| <= 2 D 2^28 (inv_da_i inv_mod_j + inv_db_i inv_q_j + inv_t_i inv_dq_j)
         const float cS = cmap_bound(im[0], 1.3743895e11f /* 2^37 */ * (im[2] * inM + im[3] * inQ + im[1] * inDq));
         float sc_next = 0.f;
-        if (Tloop > 0 && sck < NSC) sc_next = fetch(scr);
+        if (np > 0 && sck < NSC) sc_next = fetch(scr);
         acc_t O;        // dmodd = sum_i dS text_d
         zero_acc(O);
         float dc = 0.f;
-        for (int p0 = 0; p0 < Tloop; p0 += PR) {
+#pragma unroll 1
+        for (int pi = 0; pi < np; ++pi) {
             if (sck < NSC) sc[sck * 32 + scr] = sc_next;
             __syncthreads();          // this panel's DMA has landed (vmcnt(0)), its scalars are visible
-            if (p0 + PR < Tloop && sck < NSC) sc_next = fetch(p0 + PR + scr);
+            issue_top(pi);
+            if (NT == 4 && pi > 0) __syncthreads();
+            if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            const char* pTd = ring_slot(smem, pi * NT + X_TD);
+            const char* pT = ring_slot(smem, pi * NT + X_T);
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
@@ -1277,11 +1330,6 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
             split_w(wd[0], wd[1], W0, W1);
             lds_barrier();            // role 1 has its weights
             if (!(dbg & 4) && wave_on) pvprod(pTd, tr, W0, W1, O);
-            lds_barrier();            // all panels are free
-            if (p0 + PR < Tloop) {
-                stage_panel_w<8>(pTd, td_b, p0 + PR, wave, lane);
-                stage_panel_w<8>(pDa, da_b, p0 + PR, wave, lane);
-            }
         }
         dc = kg_allsum(dc);
         __syncthreads();
@@ -1296,19 +1344,24 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         load_side_planes(sM, inM, A.pM + (size_t)b * szM, A.iM + (size_t)b * Mp, n, M, g);
         load_side_planes(sQ, inQ, A.pQ + (size_t)b * szM, A.iQ + (size_t)b * Mp, n, M, g);
         float sc_next = 0.f;
-        if (Tloop > 0 && sck < NSC) sc_next = fetch(scr);
+        if (np > 0 && sck < NSC) sc_next = fetch(scr);
         acc_t O;        // dmodc = sum_i P1 da
         zero_acc(O);
-        for (int p0 = 0; p0 < Tloop; p0 += PR) {
+#pragma unroll 1
+        for (int pi = 0; pi < np; ++pi) {
             if (sck < NSC) sc[sck * 32 + scr] = sc_next;
             __syncthreads();
-            if (p0 + PR < Tloop && sck < NSC) sc_next = fetch(p0 + PR + scr);
+            issue_top(pi);
+            if (NT == 4 && pi > 0) __syncthreads();
+            if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            const char* pDa = ring_slot(smem, pi * NT + X_DA);
+            const char* pDb = ring_slot(smem, pi * NT + X_DB);
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
             if (!(dbg & 2) && wave_on) {
-                sprod2(pDa, r, g, sM, c1);
                 sprod2(pDb, r, g, sQ, c2);
+                sprod2(pDa, r, g, sM, c1);
             }
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -1316,19 +1369,11 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
                 *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sDa * inM) + c2[mb] * (sDb * inQ);
             }
             lds_barrier();
-            if (p0 + PR < Tloop) {    // db (and text) are dead: re-fill them under role 0's arithmetic
-                stage_panel_w<4>(pDb, db_b, p0 + PR, w4, lane);
-                if (!SAME) stage_panel_w<4>(pT, t_b, p0 + PR, w4, lane);
-            }
+            issue_mid(pi);            // the S-only panels are dead: re-fill their slots under role 0's arithmetic
             lds_barrier();
             half8 W0, W1;
             xch_get(xch + 2048, W0, W1);
             if (!(dbg & 4) && wave_on) pvprod(pDa, tr, W0, W1, O);
-            lds_barrier();
-            if (p0 + PR < Tloop) {
-                stage_panel_w<8>(pTd, td_b, p0 + PR, wave, lane);
-                stage_panel_w<8>(pDa, da_b, p0 + PR, wave, lane);
-            }
         }
         __syncthreads();
         if (dbg & 8) return;
@@ -1392,33 +1437,32 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     const bool wave_on = (tile * 4 + w4) * 16 < T;
     const bool nin = n < T;
 
-    char* pM = smem;
-    char* pQ = smem + PANEL_B;
-    char* pDq = smem + 2 * PANEL_B;
-    char* pSp = smem + 3 * PANEL_B;          // streamed similarity operand: mod * w_tm (SAME) or the dropped copy mod_d
-    char* pMd = SAME ? pM : pSp;             // value rows of dX = sum_j dS mod_d
+    // streamed tensors in ring order: q, mod, [mod_d], dq.  Without dropped copies the similarity is formed as
+    // (text * w_tm) . mod, so the mod panel serves the similarity, da . mod and the value rows of dX.
+    constexpr int NT = SAME ? 3 : 4;
+    constexpr int X_Q = 0, X_M = 1, X_MD = SAME ? 1 : 2, X_DQ = SAME ? 2 : 3;
     constexpr int NSC = 10;
-    float* sc = reinterpret_cast<float*>(smem + 4 * PANEL_B);    // [NSC][32]
-    char* xch = reinterpret_cast<char*>(sc + NSC * 32) + w4 * XCH_PAIR + lane * 16;
-    float* red = reinterpret_cast<float*>(smem + 4 * PANEL_B + NSC * 32 * 4 + 4 * XCH_PAIR);
+    float* sc = reinterpret_cast<float*>(smem + SWEEP_SC_OFF);    // [NSC][32]
+    char* xch = smem + SWEEP_XCH_OFF + w4 * XCH_PAIR + lane * 16;
+    float* red = reinterpret_cast<float*>(smem + SWEEP_RED_OFF);
 
     const size_t szT = planes_sample_bytes(T), szM = planes_sample_bytes(M);
-    const char* m_b = A.pM + (size_t)b * szM;
-    const char* q_b = A.pQ + (size_t)b * szM;
-    const char* dq_b = A.pDq + (size_t)b * szM;
-    const char* sp_b = (SAME ? A.pMw : A.pMd) + (size_t)b * szM;
+    const char* src[4];
+    src[X_Q] = A.pQ + (size_t)b * szM;
+    src[X_M] = A.pM + (size_t)b * szM;
+    src[X_DQ] = A.pDq + (size_t)b * szM;
+    if (!SAME) src[X_MD] = A.pMd + (size_t)b * szM;
     const float* iM_b = A.iM + (size_t)b * Mp;
     const float* iMd_b = A.iMd + (size_t)b * Mp;
     const float* iQ_b = A.iQ + (size_t)b * Mp;
     const float* iDq_b = A.iDq + (size_t)b * Mp;
-    const float* iSp_b = (SAME ? A.iMw : A.iMd) + (size_t)b * Mp;
 
-    const int Mloop = (dbg & 16) ? 0 : M;
-    if (Mloop > 0) {       // first panel in flight under the operand loads below
-        stage_panel_w<8>(pM, m_b, 0, wave, lane);
-        stage_panel_w<8>(pQ, q_b, 0, wave, lane);
-        stage_panel_w<8>(pDq, dq_b, 0, wave, lane);
-        stage_panel_w<8>(pSp, sp_b, 0, wave, lane);
+    const int np = (dbg & 16) ? 0 : (M + PR - 1) / PR;
+    auto issue8 = [&](int pi, int x) { stage_panel_w<8>(ring_slot(smem, pi * NT + x), src[x], pi * PR, wave, lane); };
+    auto issue4 = [&](int pi, int x) { stage_panel_w<4>(ring_slot(smem, pi * NT + x), src[x], pi * PR, w4, lane); };
+    if (np > 0) {
+#pragma unroll
+        for (int x = 0; x < NT; ++x) issue8(0, x);
     }
     float im[4] = {0.f, 0.f, 0.f, 0.f};   // mod, mod_d, q, dq
     for (int j = tid; j < M; j += NT8) {
@@ -1443,7 +1487,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
             case 2: return in ? 1.0f / A.col_stat[bj * 2 + 1] : 0.f;
             case 3: return in ? A.delta2[bj] : 0.f;
             case 4: return in ? (mask_live(A.mod_mask, A.mod_len, b, M, j) ? 1.f : 0.f) : -1.f;   // modality mask, -1 beyond M
-            case 5: return in ? iSp_b[j] : 0.f;
+            case 5: return in ? iMd_b[j] : 0.f;      // streamed similarity operand (= mod without dropped copies)
             case 6: return in ? iDq_b[j] : 0.f;
             case 7: return in ? iMd_b[j] : 0.f;
             case 8: return in ? iM_b[j] : 0.f;
@@ -1456,15 +1500,27 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     float* eT = eX + 64 * LDP;                                  //           [64][LDP]  sum_j P2 dq
     float* drs = eT + 64 * LDP;                                 //           [64]       dr
 
-    // role-specialised copies of the panel loop, as in the j sweep.  Staging: the panels only the S-type products read -- q and
-    // the similarity operand mod * w_tm (eval mode) / q and mod (training mode, where the dropped copy is also the value tensor
-    // of dX) -- are re-filled by the role-1 waves under role 0's arithmetic, the other two by all waves after the PV products
+    auto issue_top = [&](int pi) {
+        if (NT == 4 && pi > 0) issue8(pi, 3);                   // training mode: the 4th tensor of THIS panel, just in time
+    };
+    // The whole next panel is issued by the role-1 waves right after the S-type products (they idle while role 0 does the
+    // tile's arithmetic): two pieces into the spare slots, the last into the slot the S-only tensor of this panel has just
+    // vacated.  vmcnt counts in issue order, so a wave with DMA in flight would stall at its next scratch reload: role 0
+    // never issues DMA inside the loop, and role 1 issues it BEHIND the reloads of its S-type products.
+    auto issue_mid = [&](int pi) {
+        if (pi + 1 < np) {
+            issue4(pi + 1, 0);
+            issue4(pi + 1, 1);
+            issue4(pi + 1, 2);
+        }
+    };
+
     if (role == 0) {
-        side_t sT, sS;       // text (dP2; without dropped copies also the similarity, formed as text . (mod * w_tm)); text_d * w_tm
-        float inS = inT;
-        float inT_;
+        side_t sT, sS;       // text (dP2); text_d * w_tm (similarity)
+        float inS, inT_;
         load_side_planes(sT, inT_, A.pT + (size_t)b * szT, A.iT + (size_t)b * Tp, n, T, g);
-        if (!SAME) load_side_f32(sS, inS, A.text_d + (size_t)b * T * D, n, T, D, g, A.w_tm);
+        if (SAME) side_times_w(sT, inT_, A.w_tm, D, g, sS, inS);
+        else load_side_f32(sS, inS, A.text_d + (size_t)b * T * D, n, T, D, g, A.w_tm);
         const float rterm = nin ? A.rterm[(size_t)b * T + n] : 0.f;
         const float rmax = nin ? A.row_stat[((size_t)b * T + n) * 2] : 0.f;
         const float rinv = nin ? 1.0f / A.row_stat[((size_t)b * T + n) * 2 + 1] : 0.f;
@@ -1472,20 +1528,24 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         const bool tm = nin ? mask_live(A.text_mask, A.text_len, b, T, n) : false;
         const float tmf = tm ? 1.f : 0.f;
         float sc_next = 0.f;
-        if (Mloop > 0 && sck < NSC) sc_next = fetch(scr);
+        if (np > 0 && sck < NSC) sc_next = fetch(scr);
         acc_t O;        // sum_j P2 dq
         zero_acc(O);
         float dr = 0.f;
-        for (int p0 = 0; p0 < Mloop; p0 += PR) {
+#pragma unroll 1
+        for (int pi = 0; pi < np; ++pi) {
             if (sck < NSC) sc[sck * 32 + scr] = sc_next;
             __syncthreads();          // this panel's DMA has landed (vmcnt(0)), its scalars are visible
-            if (p0 + PR < Mloop && sck < NSC) sc_next = fetch(p0 + PR + scr);
+            issue_top(pi);
+            if (NT == 4 && pi > 0) __syncthreads();
+            if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            const char* pMd = ring_slot(smem, pi * NT + X_MD);
+            const char* pDq = ring_slot(smem, pi * NT + X_DQ);
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
             if (!(dbg & 2) && wave_on) {
-                if (SAME) sprod2(pSp, r, g, sT, c1);
-                else sprod2(pSp, r, g, sS, c1);
+                sprod2(pMd, r, g, sS, c1);
                 sprod2(pDq, r, g, sT, c2);
             }
             lds_barrier();            // role 1's dP1 is in LDS
@@ -1517,11 +1577,6 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
             split_w(wt[0], wt[1], W0, W1);
             lds_barrier();            // role 1 has its weights
             if (!(dbg & 4) && wave_on) pvprod(pDq, tr, W0, W1, O);
-            lds_barrier();            // all panels are free
-            if (p0 + PR < Mloop) {
-                stage_panel_w<8>(pDq, dq_b, p0 + PR, wave, lane);
-                stage_panel_w<8>(SAME ? pM : pSp, SAME ? m_b : sp_b, p0 + PR, wave, lane);
-            }
         }
         dr = kg_allsum(dr);
         __syncthreads();
@@ -1536,19 +1591,25 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         load_side_planes(sDa, iDa_, A.pDa + (size_t)b * szT, A.iDa + (size_t)b * Tp, n, T, g);
         load_side_planes(sDb, iDb_, A.pDb + (size_t)b * szT, A.iDb + (size_t)b * Tp, n, T, g);
         float sc_next = 0.f;
-        if (Mloop > 0 && sck < NSC) sc_next = fetch(scr);
+        if (np > 0 && sck < NSC) sc_next = fetch(scr);
         acc_t O;        // dX = sum_j dS mod_d
         zero_acc(O);
-        for (int p0 = 0; p0 < Mloop; p0 += PR) {
+#pragma unroll 1
+        for (int pi = 0; pi < np; ++pi) {
             if (sck < NSC) sc[sck * 32 + scr] = sc_next;
             __syncthreads();
-            if (p0 + PR < Mloop && sck < NSC) sc_next = fetch(p0 + PR + scr);
+            issue_top(pi);
+            if (NT == 4 && pi > 0) __syncthreads();
+            if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            const char* pM = ring_slot(smem, pi * NT + X_M);
+            const char* pQ = ring_slot(smem, pi * NT + X_Q);
+            const char* pMd = ring_slot(smem, pi * NT + X_MD);
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
             if (!(dbg & 2) && wave_on) {
-                sprod2(pM, r, g, sDa, c1);
                 sprod2(pQ, r, g, sDb, c2);
+                sprod2(pM, r, g, sDa, c1);
             }
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -1556,19 +1617,11 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
                 *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sM * inDa) + c2[mb] * (sQ * inDb);
             }
             lds_barrier();
-            if (p0 + PR < Mloop) {    // the S-only panels are dead: re-fill them under role 0's arithmetic
-                stage_panel_w<4>(pQ, q_b, p0 + PR, w4, lane);
-                stage_panel_w<4>(SAME ? pSp : pM, SAME ? sp_b : m_b, p0 + PR, w4, lane);
-            }
+            issue_mid(pi);            // the S-only panels are dead: re-fill their slots under role 0's arithmetic
             lds_barrier();
             half8 W0, W1;
             xch_get(xch + 2048, W0, W1);
             if (!(dbg & 4) && wave_on) pvprod(pMd, tr, W0, W1, O);
-            lds_barrier();
-            if (p0 + PR < Mloop) {
-                stage_panel_w<8>(pDq, dq_b, p0 + PR, wave, lane);
-                stage_panel_w<8>(SAME ? pM : pSp, SAME ? m_b : sp_b, p0 + PR, wave, lane);
-            }
         }
         __syncthreads();
         if (dbg & 8) return;
@@ -1651,10 +1704,9 @@ __global__ __launch_bounds__(NT8) void att_bwd_sweep_kernel(const GroupArgs a, c
 // ------------------------------------------------------------------------------------------ host side
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
-// saved-for-backward buffer of the fused path: planes + inverse row scales of text, mod, q, of the dropped copies (training
-// mode) or of mod * w_tm (eval mode: the streamed similarity operand of the i sweep)
+// saved-for-backward buffer of the fused path: planes + inverse row scales of text, mod, q and of the dropped copies (training mode)
 struct SavedLayout {
-    size_t pT, pTd, pM, pMd, pMw, pQ, iT, iTd, iM, iMd, iMw, iQ, total;
+    size_t pT, pTd, pM, pMd, pQ, iT, iTd, iM, iMd, iQ, total;
 };
 static SavedLayout saved_layout(int B, int T, int M, int drop) {
     SavedLayout L{};
@@ -1666,13 +1718,11 @@ static SavedLayout saved_layout(int B, int T, int M, int drop) {
     L.pTd = drop ? take(szT) : L.pT;
     L.pM = take(szM);
     L.pMd = drop ? take(szM) : L.pM;
-    L.pMw = drop ? L.pM : take(szM);
     L.pQ = take(szM);
     L.iT = take(nT);
     L.iTd = drop ? take(nT) : L.iT;
     L.iM = take(nM);
     L.iMd = drop ? take(nM) : L.iM;
-    L.iMw = drop ? L.iM : take(nM);
     L.iQ = take(nM);
     L.total = o;
     return L;
@@ -1775,8 +1825,8 @@ static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backwar
         const SavedLayout L = saved_layout(B, s.T, s.M, drop);
         char* sv = static_cast<char*>(s.saved);
         auto fp = [&](size_t off) { return reinterpret_cast<float*>(sv + off); };
-        g.pT = sv + L.pT; g.pTd = sv + L.pTd; g.pM = sv + L.pM; g.pMd = sv + L.pMd; g.pMw = sv + L.pMw; g.pQ = sv + L.pQ;
-        g.iT = fp(L.iT); g.iTd = fp(L.iTd); g.iM = fp(L.iM); g.iMd = fp(L.iMd); g.iMw = fp(L.iMw); g.iQ = fp(L.iQ);
+        g.pT = sv + L.pT; g.pTd = sv + L.pTd; g.pM = sv + L.pM; g.pMd = sv + L.pMd; g.pQ = sv + L.pQ;
+        g.iT = fp(L.iT); g.iTd = fp(L.iTd); g.iM = fp(L.iM); g.iMd = fp(L.iMd); g.iQ = fp(L.iQ);
         // attentions of one call that read the same text tensor share ONE set of text planes (made once by the split pass)
         for (int j = 0; j < k; ++j)
             if (d[j].text == s.text && d[j].T == s.T) {
@@ -1864,7 +1914,6 @@ extern "C" int mmb_bidaf_group_fwd(const mmb_bidaf_desc* d, int n, int B, int D,
                     else owner_src[k] = add(g.text, nullptr, nullptr, nullptr, g.w_t, g.bias, g.rterm, g.T);   // terms only
                 }
                 add(g.mod, g.pM, g.iM, nullptr, g.w_m, nullptr, g.cterm, g.M);
-                add(g.mod, g.pMw, g.iMw, g.w_tm, nullptr, nullptr, nullptr, g.M);
             } else {
                 if (shared < 0) owner_src[k] = add(g.text, g.pT, g.iT, nullptr, nullptr, nullptr, nullptr, g.T);
                 else owner_src[k] = owner_src[shared];
@@ -1963,7 +2012,7 @@ extern "C" int mmb_bidaf_group_bwd(const mmb_bidaf_desc* d, int n, int B, int D,
         sm.i.begin[0] = sm.i_begin;
         for (int k = 0; k < n; ++k) sm.i.begin[k + 1] = sm.i.begin[k] + sweep_blocks(ga.g[k].T, B);
         for (int k = n; k < MAXG; ++k) sm.i.begin[k + 1] = sm.i.begin[n];
-        const size_t loop_b = (size_t)4 * PANEL_B + 10 * 32 * sizeof(float) + 4 * XCH_PAIR + 64 * sizeof(float);
+        const size_t loop_b = SWEEP_LOOP_LDS;
         const size_t epi = ((size_t)2 * 64 * LDP + 64 + 8 * 2 * 256) * sizeof(float);
         const size_t lds = loop_b > epi ? loop_b : epi;
         auto kern = ga.dbg ? (drop ? att_bwd_sweep_kernel<true, false> : att_bwd_sweep_kernel<true, true>)
