@@ -360,6 +360,104 @@ __device__ __forceinline__ void pvprod(const char* panel, const tr_off& tr, cons
     }
 }
 
+// ---- hand-pipelined forms of the two products.  hipcc, once the kernel is near its register budget, schedules the fragment
+// reads of sprod2 / pvprod right in front of the MFMAs that consume them (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, 54 waits
+// per 84 MFMAs): every MFMA then pays the LDS latency.  Here the reads are asm statements the compiler cannot move -- the
+// fragments of step k+1 are issued BEFORE the MFMAs of step k -- and each step waits with a counted lgkmcnt for exactly the
+// reads it consumes (a wait statement names its fragments "+v", so no consumer is scheduled above it).  The compiler does
+// not count these reads: its own LDS traffic in flight only makes a counted wait stricter (LDS returns in order), never
+// weaker.  tools/asm_load_audit.py checks the built code object's assembly for a compiler access (copy, spill) to a fragment
+// register between its read and its wait.
+__device__ __forceinline__ unsigned lds_addr32(const char* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(p);
+}
+template <int OFF>
+__device__ __forceinline__ half8 ds_rd128(unsigned a) {
+    half8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
+    return r;
+}
+template <int OFF>
+__device__ __forceinline__ v4s ds_rd_tr64(unsigned a) {
+    v4s r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait4(half8& a, half8& b, half8& c, half8& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait4s(v4s& a, v4s& b, v4s& c, v4s& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+
+template <int KT_>
+struct SStep {
+    static __device__ __forceinline__ void run(unsigned a, const side_t& side, f4 (&c)[2], half8 (&cur)[4]) {
+        half8 nxt[4];
+        if constexpr (KT_ + 1 < KT) {
+            nxt[0] = ds_rd128<(0 * KT + KT_ + 1) * PCH>(a);
+            nxt[1] = ds_rd128<(0 * KT + KT_ + 1) * PCH + 1024>(a);
+            nxt[2] = ds_rd128<(1 * KT + KT_ + 1) * PCH>(a);
+            nxt[3] = ds_rd128<(1 * KT + KT_ + 1) * PCH + 1024>(a);
+            lgkm_wait4<4>(cur[0], cur[1], cur[2], cur[3]);
+        } else {
+            lgkm_wait4<0>(cur[0], cur[1], cur[2], cur[3]);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(cur[2 * mb], side.h[KT_][1], c[mb]);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(cur[2 * mb + 1], side.h[KT_][0], c[mb]);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(cur[2 * mb], side.h[KT_][0], c[mb]);
+        if constexpr (KT_ + 1 < KT) SStep<KT_ + 1>::run(a, side, c, nxt);
+    }
+};
+// S-type product, reads one k tile ahead
+__device__ __forceinline__ void sprod2p(const char* panel, int r, int g, const side_t& side, f4 (&c)[2]) {
+    const unsigned a = lds_addr32(panel + r * 64 + ((g ^ att_swz(r)) << 4));
+    half8 cur[4];
+    cur[0] = ds_rd128<0>(a);
+    cur[1] = ds_rd128<1024>(a);
+    cur[2] = ds_rd128<KT * PCH>(a);
+    cur[3] = ds_rd128<KT * PCH + 1024>(a);
+    SStep<0>::run(a, side, c, cur);
+}
+
+template <int DT_>
+struct PStep {
+    // fragment set of feature tile dt: chunk (dt >> 1) of row blocks 0 / 1, planes 0 / 1, at the lane's offset tr.o[dt & 1]
+    static __device__ __forceinline__ void load(unsigned a0, unsigned a1, v4s (&x)[4]) {
+        const unsigned a = (DT_ & 1) ? a1 : a0;
+        x[0] = ds_rd_tr64<(DT_ >> 1) * PCH>(a);
+        x[1] = ds_rd_tr64<(DT_ >> 1) * PCH + KT * PCH>(a);
+        x[2] = ds_rd_tr64<(DT_ >> 1) * PCH + 1024>(a);
+        x[3] = ds_rd_tr64<(DT_ >> 1) * PCH + KT * PCH + 1024>(a);
+    }
+    static __device__ __forceinline__ void run(unsigned a0, unsigned a1, const half8 W0, const half8 W1, acc_t& O, v4s (&cur)[4]) {
+        v4s nxt[4];
+        if constexpr (DT_ + 1 < DT) {
+            PStep<DT_ + 1>::load(a0, a1, nxt);
+            lgkm_wait4s<4>(cur[0], cur[1], cur[2], cur[3]);
+        } else {
+            lgkm_wait4s<0>(cur[0], cur[1], cur[2], cur[3]);
+        }
+        const half8 A0 = cat44(cur[0], cur[1]), A1 = cat44(cur[2], cur[3]);
+        O[DT_] = mfma_h(A0, W1, O[DT_]);
+        O[DT_] = mfma_h(A1, W0, O[DT_]);
+        O[DT_] = mfma_h(A0, W0, O[DT_]);
+        if constexpr (DT_ + 1 < DT) PStep<DT_ + 1>::run(a0, a1, W0, W1, O, nxt);
+    }
+};
+// PV-type product, transpose reads one feature tile ahead
+__device__ __forceinline__ void pvprodp(const char* panel, const tr_off& tr, const half8 W0, const half8 W1, acc_t& O) {
+    const unsigned a0 = lds_addr32(panel + tr.o[0]), a1 = lds_addr32(panel + tr.o[1]);
+    v4s cur[4];
+    PStep<0>::load(a0, a1, cur);
+    PStep<0>::run(a0, a1, W0, W1, O, cur);
+}
+
 // two-term split of the 8 accumulator values a lane holds for the panel (w0: block 0, w1: block 1), truncating
 // conversions (v_cvt_pkrtz_f16_f32: 6 VALU per pair); |w| <= ~2^14 by construction
 __device__ __forceinline__ void split_w(const f4 w0, const f4 w1, half8& H0, half8& H1) {
@@ -756,7 +854,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
             const char* pS = sep_s ? pV + PANEL_B : pV;
             const float* s0 = sc + (sb * NSC) * 64 + 32 * grp;     // scalar k of local row ml: s0[k * 64 + ml]
             f4 v[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-            if (!(dbg & 2)) sprod2(pS, r, g, side, v);
+            if (!(dbg & 2)) sprod2p(pS, r, g, side, v);
             f4 w[2];
             if (KIND == 0) {
                 float bmax = -INFINITY;
@@ -801,7 +899,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
             }
             half8 W0, W1;
             split_w(w[0], w[1], W0, W1);
-            if (!(dbg & 4)) pvprod(pV, tr, W0, W1, O);
+            if (!(dbg & 4)) pvprodp(pV, tr, W0, W1, O);
         }
     }
     __syncthreads();      // all panels are dead
@@ -969,7 +1067,7 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
         const char* pS = sep_s ? smem + 2 * PANEL_B : pV0;
 
         f4 v[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-        if (!(dbg & 2)) sprod2(pS, r, g, side, v);
+        if (!(dbg & 2)) sprod2p(pS, r, g, side, v);
         float bmax = -INFINITY;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -1009,7 +1107,7 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
                 for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * sc[96 + mb * 16 + 4 * g + e];
             half8 W0, W1;
             split_w(w[0], w[1], W0, W1);
-            if (!(dbg & 4)) pvprod(pV0, tr, W0, W1, O0);
+            if (!(dbg & 4)) pvprodp(pV0, tr, W0, W1, O0);
         }
         {
             f4 w[2];
@@ -1019,7 +1117,7 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
                 for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * sc[128 + mb * 16 + 4 * g + e];
             half8 W0, W1;
             split_w(w[0], w[1], W0, W1);
-            if (!(dbg & 4)) pvprod(pV1, tr, W0, W1, O1);
+            if (!(dbg & 4)) pvprodp(pV1, tr, W0, W1, O1);
         }
     }
 
@@ -1298,8 +1396,8 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
             if (!(dbg & 2) && wave_on) {
-                sprod2(pTd, r, g, sS, c1);
-                sprod2(pT, r, g, sDq, c2);
+                sprod2p(pTd, r, g, sS, c1);
+                sprod2p(pT, r, g, sDq, c2);
             }
             lds_barrier();            // role 1's dP1 is in LDS
             f4 wc[2], wd[2];
@@ -1329,7 +1427,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
             xch_put(xch + 2048, W0, W1);
             split_w(wd[0], wd[1], W0, W1);
             lds_barrier();            // role 1 has its weights
-            if (!(dbg & 4) && wave_on) pvprod(pTd, tr, W0, W1, O);
+            if (!(dbg & 4) && wave_on) pvprodp(pTd, tr, W0, W1, O);
         }
         dc = kg_allsum(dc);
         __syncthreads();
@@ -1360,8 +1458,8 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
             if (!(dbg & 2) && wave_on) {
-                sprod2(pDb, r, g, sQ, c2);
-                sprod2(pDa, r, g, sM, c1);
+                sprod2p(pDb, r, g, sQ, c2);
+                sprod2p(pDa, r, g, sM, c1);
             }
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -1373,7 +1471,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
             lds_barrier();
             half8 W0, W1;
             xch_get(xch + 2048, W0, W1);
-            if (!(dbg & 4) && wave_on) pvprod(pDa, tr, W0, W1, O);
+            if (!(dbg & 4) && wave_on) pvprodp(pDa, tr, W0, W1, O);
         }
         __syncthreads();
         if (dbg & 8) return;
@@ -1460,18 +1558,19 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     const int np = (dbg & 16) ? 0 : (M + PR - 1) / PR;
     auto issue8 = [&](int pi, int x) { stage_panel_w<8>(ring_slot(smem, pi * NT + x), src[x], pi * PR, wave, lane); };
     auto issue4 = [&](int pi, int x) { stage_panel_w<4>(ring_slot(smem, pi * NT + x), src[x], pi * PR, w4, lane); };
-    if (np > 0) {
+    if (np > 0 || !(dbg & 64)) {
 #pragma unroll
         for (int x = 0; x < NT; ++x) issue8(0, x);
     }
     float im[4] = {0.f, 0.f, 0.f, 0.f};   // mod, mod_d, q, dq
+    if (!(dbg & 128))
     for (int j = tid; j < M; j += NT8) {
         im[0] = fmaxf(im[0], iM_b[j]);
         im[1] = fmaxf(im[1], iMd_b[j]);
         im[2] = fmaxf(im[2], iQ_b[j]);
         im[3] = fmaxf(im[3], iDq_b[j]);
     }
-    wg_allmax_w<4, 8>(im, red, tid);
+    if (!(dbg & 128)) wg_allmax_w<4, 8>(im, red, tid);
     const float cDq = cmap(im[3]);
     const float inDa = nin ? A.iDa[(size_t)b * Tp + n] : 0.f, inDb = nin ? A.iDb[(size_t)b * Tp + n] : 0.f;
     const float inT = nin ? A.iT[(size_t)b * Tp + n] : 0.f;
@@ -1518,9 +1617,11 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     if (role == 0) {
         side_t sT, sS;       // text (dP2); text_d * w_tm (similarity)
         float inS, inT_;
+        if (!(dbg & 256)) {
         load_side_planes(sT, inT_, A.pT + (size_t)b * szT, A.iT + (size_t)b * Tp, n, T, g);
         if (SAME) side_times_w(sT, inT_, A.w_tm, D, g, sS, inS);
         else load_side_f32(sS, inS, A.text_d + (size_t)b * T * D, n, T, D, g, A.w_tm);
+        }
         const float rterm = nin ? A.rterm[(size_t)b * T + n] : 0.f;
         const float rmax = nin ? A.row_stat[((size_t)b * T + n) * 2] : 0.f;
         const float rinv = nin ? 1.0f / A.row_stat[((size_t)b * T + n) * 2 + 1] : 0.f;
@@ -1545,8 +1646,8 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
             if (!(dbg & 2) && wave_on) {
-                sprod2(pMd, r, g, sS, c1);
-                sprod2(pDq, r, g, sT, c2);
+                sprod2p(pMd, r, g, sS, c1);
+                sprod2p(pDq, r, g, sT, c2);
             }
             lds_barrier();            // role 1's dP1 is in LDS
             f4 wt[2], wx[2];
@@ -1576,7 +1677,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
             xch_put(xch + 2048, W0, W1);
             split_w(wt[0], wt[1], W0, W1);
             lds_barrier();            // role 1 has its weights
-            if (!(dbg & 4) && wave_on) pvprod(pDq, tr, W0, W1, O);
+            if (!(dbg & 4) && wave_on) pvprodp(pDq, tr, W0, W1, O);
         }
         dr = kg_allsum(dr);
         __syncthreads();
@@ -1588,8 +1689,10 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     } else {
         side_t sDa, sDb;
         float iDa_, iDb_;
+        if (!(dbg & 256)) {
         load_side_planes(sDa, iDa_, A.pDa + (size_t)b * szT, A.iDa + (size_t)b * Tp, n, T, g);
         load_side_planes(sDb, iDb_, A.pDb + (size_t)b * szT, A.iDb + (size_t)b * Tp, n, T, g);
+        }
         float sc_next = 0.f;
         if (np > 0 && sck < NSC) sc_next = fetch(scr);
         acc_t O;        // dX = sum_j dS mod_d
@@ -1608,8 +1711,8 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
             if (!(dbg & 2) && wave_on) {
-                sprod2(pQ, r, g, sDb, c2);
-                sprod2(pM, r, g, sDa, c1);
+                sprod2p(pQ, r, g, sDb, c2);
+                sprod2p(pM, r, g, sDa, c1);
             }
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -1621,7 +1724,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
             lds_barrier();
             half8 W0, W1;
             xch_get(xch + 2048, W0, W1);
-            if (!(dbg & 4) && wave_on) pvprod(pMd, tr, W0, W1, O);
+            if (!(dbg & 4) && wave_on) pvprodp(pMd, tr, W0, W1, O);
         }
         __syncthreads();
         if (dbg & 8) return;
@@ -1691,6 +1794,9 @@ template <bool DBG, bool SAME>
 __global__ __launch_bounds__(NT8) void att_bwd_sweep_kernel(const GroupArgs a, const SweepMap sm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int local;
+    if (DBG && (a.dbg & 512)) return;                                  // timing only: launch floor
+    if (DBG && (a.dbg & 1024) && (int)blockIdx.x < sm.i_begin) return;  // timing only: i sweep alone
+    if (DBG && (a.dbg & 2048) && (int)blockIdx.x >= sm.i_begin) return; // timing only: j sweep alone
     if ((int)blockIdx.x < sm.i_begin) {
         const AttG& A = a.g[find_att(sm.j, a.n, blockIdx.x, local)];
         sweep_j_body<DBG, SAME>(a, A, local, smem);

@@ -81,7 +81,8 @@ def main():
         print(row)
     print(f"{'total':14s}" + "".join(f"{tot[m]:9.1f}" for m in table))
     alg = sum(4 * B * (5 * T * D + M * D) + 4 * B * (6 * T * D + 2 * M * D) for M in Ms)
-    print(f"algorithmic bytes fwd+bwd {alg / 1e6:.1f} MB -> {alg / (tot[0] * 1e-6) / 1e9:.0f} GB/s = {alg / (tot[0] * 1e-6) / 8e12 * 100:.1f} % of 8 TB/s")
+    if 0 in tot:
+        print(f"algorithmic bytes fwd+bwd {alg / 1e6:.1f} MB -> {alg / (tot[0] * 1e-6) / 1e9:.0f} GB/s = {alg / (tot[0] * 1e-6) / 8e12 * 100:.1f} % of 8 TB/s")
 
 
 if __name__ == "__main__":
