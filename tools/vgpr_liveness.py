@@ -13,12 +13,14 @@ start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and want in l 
 
 
 def regs(tok):
+    """VGPRs v0.. as 0.., AGPRs a0.. as 256.. (one unified file on gfx950)"""
     out = []
-    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+    for m in re.finditer(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b", tok):
         if m.group(1):
-            out += list(range(int(m.group(1)), int(m.group(2)) + 1))
+            base = 256 if m.group(1) == "a" else 0
+            out += [base + k for k in range(int(m.group(2)), int(m.group(3)) + 1)]
         else:
-            out.append(int(m.group(3)))
+            out.append((256 if m.group(4) == "a" else 0) + int(m.group(5)))
     return out
 
 
