@@ -477,19 +477,6 @@ __device__ __forceinline__ void split_w(const f4 w0, const f4 w1, half8& H0, hal
     H1 = __builtin_bit_cast(half8, ll);
 }
 
-// two-term split of the 4 values a lane holds for ONE 16-row block: dwords [2 mb, 2 mb + 1] of the (W0, W1) pair of split_w
-__device__ __forceinline__ void split_w_half(const f4 w, int mb, u4v& hh, u4v& ll) {
-    auto pk = [](float a, float b, unsigned& h, unsigned& l) {
-        const auto h2 = __builtin_amdgcn_cvt_pkrtz(a, b);
-        const auto l2 = __builtin_amdgcn_cvt_pkrtz(a - (float)h2[0], b - (float)h2[1]);
-        h = __builtin_bit_cast(unsigned, h2);
-        l = __builtin_bit_cast(unsigned, l2);
-    };
-    unsigned h, l;
-    pk(w.x, w.y, h, l); hh[2 * mb] = h; ll[2 * mb] = l;
-    pk(w.z, w.w, h, l); hh[2 * mb + 1] = h; ll[2 * mb + 1] = l;
-}
-
 // workgroup-wide maximum of up to 4 non-negative per-thread values (red: >= 4 * NW floats of LDS); all threads get it
 template <int NV_>
 __device__ __forceinline__ void wg_allmax(float (&v)[NV_], float* red, int tid) {
@@ -603,7 +590,8 @@ __device__ __forceinline__ bool decode_local(int id, int tiles, int B, int& tile
 
 // stage one 32-row panel with all NWV waves of the workgroup (28 LDS-DMA pieces of 1 KiB)
 template <int NWV>
-__device__ __forceinline__ void stage_panel_w(char* panel, const char* planes_b, int p0, int wave, int lane) {
+__device__ __forceinline__ void stage_panel_w(char* panel, const char* planes_b, int p0, int wave_, int lane) {
+    const int wave = __builtin_amdgcn_readfirstlane(wave_);     // provably wave-uniform: the piece guards become scalar branches
     const char* src = planes_b + (size_t)(p0 >> 4) * PRB + lane * 16;
 #pragma unroll
     for (int k = 0; k < (28 + NWV - 1) / NWV; ++k) {
@@ -1231,13 +1219,21 @@ __global__ __launch_bounds__(256) void att_bwd_pre_kernel(const GroupArgs a) {
 //       d_text_i += sum_j P2_ij dq_j ; dX_i = sum_j dS_ij mod_d_j ; dr_i = sum_j dS_ij
 //       d_text_d_i = dr_i w_t + w_tm * dX_i ; d_w_t += dr_i text_d_i ; d_w_tm += dX_i * text_d_i ; d_bias += dr_i
 // Both need four S-type products (similarity, the two halves of dP1, dP2) and two PV-type products per (16 lane rows x
-// 32-row panel): 4 lane-side operands (224 registers) and 2 accumulator sets (104) -- 64 % of a SIMD's register file for ONE
-// 16-row tile, however it is cut.  Splitting the tile's work over two waves of a SIMD (tried first: product-wise roles,
-// operands exchanged through LDS) leaves each wave 256 registers for 164 of state plus its own fragments, addresses and
-// arithmetic: hipcc spilled ~400 registers per wave (0.5 GB of scratch traffic per launch, reloads in front of the MFMAs).
-// So: ONE wave per SIMD with the whole tile state in its 512 registers, and the latency hiding done by hand instead of by a
-// second wave -- fragment reads one step ahead of the MFMAs (sprod2p / pvprodp) and the next panel's LDS-DMA in flight during
-// the whole iteration (panel ring below).
+// 32-row panel), i.e. 4 lane-side operands and 2 accumulator sets: 330 registers for one wave.  Here a PAIR of waves
+// (w, w + 4: the two waves of one SIMD) owns the 16 rows and splits the PRODUCTS, not the data:
+//   role 0: similarity + dP2, then the softmax / gradient arithmetic of the tile, then one PV product;
+//   role 1: the two halves of dP1 (sent to role 0 through 2 KiB of LDS), then the other PV product with the weights
+//           role 0 sends back.
+// Each wave carries two lane-side operands and one accumulator set (<= 256 registers: two waves per SIMD, which is what a
+// single wave lacks here -- its instruction stream of one panel is ~8000 issue cycles for 3900 cycles of MFMA, and two waves
+// of a SIMD issue alternately), no product is computed twice, and the two roles run the SAME matrix-core instruction stream
+// on different panels.  Two things this form depends on (both measured):
+//   * the accumulators are updated UNCONDITIONALLY.  A branch around the products (e.g. skipping waves whose rows lie beyond
+//     the sequence) makes the accumulator a phi of "updated" and "not updated": hipcc then copies all 52 registers every
+//     iteration and, at 256 registers, spills ~400 per wave (0.5 GB of scratch traffic per launch).  Rows beyond the
+//     sequence simply compute on zero operands.
+//   * each role runs its own copy of the panel loop, so that the allocator sees role 0's operands + arithmetic and role 1's
+//     operands apart instead of their union.
 // Both sweeps are independent of each other (they need dq from the dq sweep): they share ONE launch, the long j-sweep
 // workgroups first.
 struct SweepMap {
@@ -1245,38 +1241,59 @@ struct SweepMap {
     int i_begin;        // first block of the i sweep
 };
 
+// W0 | W1 of a weight set travel through LDS as 2 x 16 B per lane
+__device__ __forceinline__ void xch_put(char* p, const half8 W0, const half8 W1) {
+    *reinterpret_cast<half8*>(p) = W0;
+    *reinterpret_cast<half8*>(p + 1024) = W1;
+}
+__device__ __forceinline__ void xch_get(const char* p, half8& W0, half8& W1) {
+    W0 = *reinterpret_cast<const half8*>(p);
+    W1 = *reinterpret_cast<const half8*>(p + 1024);
+}
+__device__ __forceinline__ void copy_side(side_t& d, const side_t& s) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        d.h[kt][0] = s.h[kt][0];
+        d.h[kt][1] = s.h[kt][1];
+    }
+}
+
+constexpr int XCH_PAIR = 4096;     // per pair: [dp1: 2 x 1 KiB][weights: 2 x 1 KiB]
+
 // workgroup barrier that orders LDS traffic only: the LDS-DMA of the next panel stays in flight across it (a __syncthreads
 // would wait for vmcnt(0), i.e. for the prefetch it is meant to overlap)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Panel ring: NS = 5 LDS slots of one 28-KiB panel each for the NT = 3 (eval mode) or 4 (training mode) tensors a sweep
-// streams.  Piece q = (panel index) * NT + x lives in slot q % NS; tensor order x: first the tensors only the S-type products
-// read (their slots come free in the MIDDLE of an iteration), then the value tensors of the PV products (free at its end).
-// With NT = 3, two pieces of panel p + 1 are issued at the top of iteration p into the spare slots and the third, behind the
-// S-type products, into the slot the S-only tensor of panel p has just vacated: the LDS-DMA runs under the products, and the
-// one full wait per iteration (top of the loop) finds its data landed.
+// Panel ring of the gradient sweeps: NS = 5 LDS slots of one 28-KiB panel each for the NT = 3 (eval mode) or 4 (training
+// mode) tensors a sweep streams.  Piece q = (panel index) * NT + x lives in slot q % NS; tensor order x: first the tensors
+// only the S-type products read (their slots come free in the MIDDLE of an iteration), then the value tensors of the PV
+// products (free at its end).  With NT = 3 all of panel p + 1 is issued in the middle of iteration p -- two pieces into the
+// spare slots, the third into the slot the S-only tensor of panel p has just vacated -- so the LDS-DMA runs under the tile
+// arithmetic and the PV products, and the one full wait per iteration (top of the loop) finds its data landed.
 constexpr int RING_NS = 5;
 __device__ __forceinline__ char* ring_slot(char* smem, int piece) {
     // opaque to the optimiser: seen as a function of the loop counter, the slot address is strength-reduced into one
-    // induction variable PER fragment read (52 VGPRs in a PV product) instead of one base + immediate offsets
+    // induction variable PER fragment read (52 VGPRs in a PV product, all spilled) instead of one base + immediate offsets
     int off = (piece % RING_NS) * PANEL_B;
     asm volatile("" : "+s"(off));
     return smem + off;
 }
 constexpr int SWEEP_SC_OFF = RING_NS * PANEL_B;          // per-row scalars [10][32] floats
-constexpr int SWEEP_RED_OFF = SWEEP_SC_OFF + 10 * 32 * 4;
+constexpr int SWEEP_XCH_OFF = SWEEP_SC_OFF + 10 * 32 * 4;
+constexpr int SWEEP_RED_OFF = SWEEP_XCH_OFF + 4 * XCH_PAIR;
 constexpr int SWEEP_LOOP_LDS = SWEEP_RED_OFF + 64 * 4;
 
 template <bool DBG, bool SAME>
 __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, int local, char* smem) {
     const int dbg = DBG ? a.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int role = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
     const int r = lane & 15, g = lane >> 4;
     const int T = A.T, M = A.M, D = a.D, Tp = pad32(T), Mp = pad32(M);
     int tile, b;
     if (!decode_local(local, (M + 63) / 64, a.B, tile, b)) return;
-    const int n = (tile * NW + wave) * 16 + r;  // modality row j
-    const bool wave_on = (tile * NW + wave) * 16 < M;
+    const int n = (tile * 4 + w4) * 16 + r;  // modality row j
+    const bool wave_on = (tile * 4 + w4) * 16 < M;
     const bool nin = n < M;
 
     // streamed tensors in ring order: db, [text], text_d, da   (text only with dropped copies)
@@ -1284,6 +1301,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     constexpr int X_DB = 0, X_T = 1, X_TD = SAME ? 1 : 2, X_DA = SAME ? 2 : 3;
     constexpr int NSC = 9;
     float* sc = reinterpret_cast<float*>(smem + SWEEP_SC_OFF);   // [NSC][32]
+    char* xch = smem + SWEEP_XCH_OFF + w4 * XCH_PAIR + lane * 16;
     float* red = reinterpret_cast<float*>(smem + SWEEP_RED_OFF);
 
     const size_t szT = planes_sample_bytes(T), szM = planes_sample_bytes(M);
@@ -1298,26 +1316,30 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     const float* iDb_b = A.iDb + (size_t)b * Tp;
 
     const int np = (dbg & 16) ? 0 : (T + PR - 1) / PR;       // panels
-    auto issue = [&](int pi, int x) { stage_panel_w<NW>(ring_slot(smem, pi * NT + x), src[x], pi * PR, wave, lane); };
+    auto issue8 = [&](int pi, int x) { stage_panel_w<8>(ring_slot(smem, pi * NT + x), src[x], pi * PR, wave, lane); };
+    auto issue4 = [&](int pi, int x) { stage_panel_w<4>(ring_slot(smem, pi * NT + x), src[x], pi * PR, w4, lane); };
     if (np > 0) {          // first panel in flight under the operand loads below
 #pragma unroll
-        for (int x = 0; x < NT; ++x) issue(0, x);
+        for (int x = 0; x < NT; ++x) issue8(0, x);
     }
-    float im[4] = {0.f, 0.f, 0.f, 0.f};   // text_d, text, da, db
-    for (int i = tid; i < T; i += NTHR) {
-        im[0] = fmaxf(im[0], iTd_b[i]);
-        im[1] = fmaxf(im[1], iT_b[i]);
-        im[2] = fmaxf(im[2], iDa_b[i]);
-        im[3] = fmaxf(im[3], iDb_b[i]);
-    }
-    wg_allmax_w<4, NW>(im, red, tid);
-    const float cDa = cmap(im[2]);
-
-    // per-row scalars of streamed text row t: value k of row rr of the next panel is fetched by thread 32 k + rr
-    auto fetch = [&](int k, int t) -> float {
+    // maxima of the streamed rows' inverse scales (text_d, text, da, db): a pass over T floats each, reduced over the
+    // workgroup -- run by both roles AFTER their operand loads are in flight
+    float im[4] = {0.f, 0.f, 0.f, 0.f};
+    auto maxima = [&]() {
+        for (int i = tid; i < T; i += NT8) {
+            im[0] = fmaxf(im[0], iTd_b[i]);
+            im[1] = fmaxf(im[1], iT_b[i]);
+            im[2] = fmaxf(im[2], iDa_b[i]);
+            im[3] = fmaxf(im[3], iDb_b[i]);
+        }
+        wg_allmax_w<4, 8>(im, red, tid);
+    };
+    // per-row scalars of streamed text row t, fetched one panel ahead by thread (k = tid >> 5, rr = tid & 31)
+    const int sck = tid >> 5, scr = tid & 31;
+    auto fetch = [&](int t) -> float {
         const bool in = t < T;
         const size_t bt = (size_t)b * T + t;
-        switch (k) {
+        switch (sck) {
             case 0: return in ? A.rterm[bt] : 0.f;
             case 1: return in ? A.row_stat[bt * 2] : INFINITY;      // exp(x - inf) = 0 beyond the range
             case 2: return in ? 1.0f / A.row_stat[bt * 2 + 1] : 0.f;
@@ -1329,139 +1351,167 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
             default: return in ? iDb_b[t] : 0.f;
         }
     };
-    const int sck = tid >> 5, scr = tid & 31;     // sck 0..7; value 8 by the threads of sck == 0 in a second fetch
-    float sc_a = 0.f, sc_b = 0.f;
-    auto sc_fetch = [&](int pi) {
-        sc_a = fetch(sck, pi * PR + scr);
-        if (sck == 0) sc_b = fetch(8, pi * PR + scr);
-    };
-    auto sc_commit = [&]() {
-        sc[sck * 32 + scr] = sc_a;
-        if (sck == 0) sc[8 * 32 + scr] = sc_b;
-    };
     const float* sg = sc + 4 * g;            // scalar k of the lane's 4 rows of block mb: f4 at sg[k * 32 + mb * 16]
     const tr_off tr = make_tr_off(lane);
+    float* eD = reinterpret_cast<float*>(smem);                 // epilogue: [64][LDP]  sum_i dS text_d
+    float* eC = eD + 64 * LDP;                                  //           [64][LDP]  sum_i P1 da
+    float* dcs = eC + 64 * LDP;                                 //           [64]       dc
 
-    // lane-side operands: mod_d * w_tm (similarity), dq (dP2), mod (da . mod), q (db . q)
-    side_t sS, sDq, sM, sQ;
-    float inS, inDq, inM, inQ;
-    load_side_f32(sS, inS, A.mod_d + (size_t)b * M * D, n, M, D, g, A.w_tm);
-    load_side_planes(sDq, inDq, A.pDq + (size_t)b * szM, A.iDq + (size_t)b * Mp, n, M, g);
-    load_side_planes(sM, inM, A.pM + (size_t)b * szM, A.iM + (size_t)b * Mp, n, M, g);
-    load_side_planes(sQ, inQ, A.pQ + (size_t)b * szM, A.iQ + (size_t)b * Mp, n, M, g);
-    const float cterm = nin ? A.cterm[(size_t)b * M + n] : 0.f;
-    const float cmax = nin ? A.col_stat[((size_t)b * M + n) * 2] : 0.f;
-    const float cinv = nin ? 1.0f / A.col_stat[((size_t)b * M + n) * 2 + 1] : 0.f;
-    const float delta2 = nin ? A.delta2[(size_t)b * M + n] : 0.f;
-    const bool mm = nin ? mask_live(A.mod_mask, A.mod_len, b, M, n) : false;
-    const float mmf = mm ? 1.f : 0.f;
-    // |dS_ij| <= |dP1| + |delta1| + |dP2| + |delta2| <= 2 D 2^28 (inv_da_i inv_mod_j + inv_db_i inv_q_j + inv_t_i inv_dq_j)
-    const float cS = cmap_bound(im[0], 1.3743895e11f /* 2^37 */ * (im[2] * inM + im[3] * inQ + im[1] * inDq));
-    if (np > 0) sc_fetch(0);
-
-    acc_t Od, Oc;        // dmodd = sum_i dS text_d ; dmodc = sum_i P1 da
-    zero_acc(Od);
-    zero_acc(Oc);
-    float dc = 0.f;
-#pragma unroll 1
-    for (int pi = 0; pi < np; ++pi) {
-        sc_commit();
-        __syncthreads();          // this panel's DMA has landed (vmcnt(0)), its scalars are visible, the previous panel is free
-        if (NT == 4 && pi > 0) {  // training mode: the 4th tensor of THIS panel, just in time
-            issue(pi, 3);
-            __syncthreads();
-        }
+    // top of iteration pi, behind the full barrier: the value tensors of panel pi - 1 are free
+    auto issue_top = [&](int pi) {
+        if (NT == 4 && pi > 0) issue8(pi, 3);                   // training mode: the 4th tensor of THIS panel, just in time
+    };
+    // The whole next panel is issued by the role-1 waves right after the S-type products (they idle while role 0 does the
+    // tile's arithmetic): two pieces into the spare slots, the last into the slot the S-only tensor of this panel has just
+    // vacated.  vmcnt counts in issue order, so a wave with DMA in flight would stall at its next scratch reload: role 0
+    // never issues DMA inside the loop, and role 1 issues it BEHIND the reloads of its S-type products.
+    auto issue_mid = [&](int pi) {
         if (pi + 1 < np) {
-            issue(pi + 1, 0);
-            if (NT == 3) issue(pi + 1, 1);
-            sc_fetch(pi + 1);
+            issue4(pi + 1, 0);
+            issue4(pi + 1, 1);
+            issue4(pi + 1, 2);
         }
-        const char* pDb = ring_slot(smem, pi * NT + X_DB);
-        const char* pT = ring_slot(smem, pi * NT + X_T);
-        const char* pTd = ring_slot(smem, pi * NT + X_TD);
-        const char* pDa = ring_slot(smem, pi * NT + X_DA);
-        f4 cb[2], c2[2], ca[2], c1[2];
+    };
+
+    // Each role runs its OWN copy of the panel loop (same barrier sequence): the register allocator then sees role 0's
+    // operands + arithmetic and role 1's operands apart instead of their union.
+    if (role == 0) {
+        side_t sS, sDq;      // mod_d * w_tm (similarity), dq (dP2)
+        float inS, inDq;
+        load_side_f32(sS, inS, A.mod_d + (size_t)b * M * D, n, M, D, g, A.w_tm);
+        load_side_planes(sDq, inDq, A.pDq + (size_t)b * szM, A.iDq + (size_t)b * Mp, n, M, g);
+        const float inM = nin ? A.iM[(size_t)b * Mp + n] : 0.f, inQ = nin ? A.iQ[(size_t)b * Mp + n] : 0.f;
+        const float cterm = nin ? A.cterm[(size_t)b * M + n] : 0.f;
+        const float cmax = nin ? A.col_stat[((size_t)b * M + n) * 2] : 0.f;
+        const float cinv = nin ? 1.0f / A.col_stat[((size_t)b * M + n) * 2 + 1] : 0.f;
+        const float delta2 = nin ? A.delta2[(size_t)b * M + n] : 0.f;
+        const bool mm = nin ? mask_live(A.mod_mask, A.mod_len, b, M, n) : false;
+        const float mmf = mm ? 1.f : 0.f;
+        float sc_next = 0.f;
+        if (np > 0 && sck < NSC) sc_next = fetch(scr);
+        maxima();             // every load of the prologue is in flight by now: ONE round trip to memory, not one per stage
+        const float cDa = cmap(im[2]);
+        // |dS_ij| <= |dP1| + |delta1| + |dP2| + |delta2| <= 2 D 2^28 (inv_da_i inv_mod_j + inv_db_i inv_q_j + inv_t_i inv_dq_j)
+        const float cS = cmap_bound(im[0], 1.3743895e11f /* 2^37 */ * (im[2] * inM + im[3] * inQ + im[1] * inDq));
+        acc_t O;        // dmodd = sum_i dS text_d
+        zero_acc(O);
+        float dc = 0.f;
+#pragma unroll 1
+        for (int pi = 0; pi < np; ++pi) {
+            if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+            __syncthreads();          // this panel's DMA has landed (vmcnt(0)), its scalars are visible
+            issue_top(pi);
+            if (NT == 4 && pi > 0) __syncthreads();
+            if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            const char* pTd = ring_slot(smem, pi * NT + X_TD);
+            const char* pT = ring_slot(smem, pi * NT + X_T);
+            f4 c1[2], c2[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) cb[q] = c2[q] = ca[q] = c1[q] = f4{0.f, 0.f, 0.f, 0.f};
-        if (!(dbg & 2)) {
-            sprod2p(pDb, r, g, sQ, cb);            // the S-only tensors first: their slots are re-filled below
-            if (!SAME) sprod2p(pT, r, g, sDq, c2);
-        }
-        lds_barrier();
-        if (pi + 1 < np) {        // db (and the clean text) are dead in every wave: the rest of the next panel into their slots
-            if (NT == 3) issue(pi + 1, 2);
-            else { issue(pi + 1, 1); issue(pi + 1, 2); }
-        }
-        if (!(dbg & 2)) {
-            if (SAME) sprod2p(pTd, r, g, sDq, c2);
-            sprod2p(pDa, r, g, sM, ca);
-            sprod2p(pTd, r, g, sS, c1);
-        }
-        u4v c_hi, c_lo, d_hi, d_lo;          // (W0, W1) of the two weight sets, packed block by block
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            const f4 s_rt = *reinterpret_cast<const f4*>(sg + mb * 16), s_rmax = *reinterpret_cast<const f4*>(sg + 32 + mb * 16);
-            const f4 s_rinv = *reinterpret_cast<const f4*>(sg + 64 + mb * 16), s_dl1 = *reinterpret_cast<const f4*>(sg + 96 + mb * 16);
-            const f4 s_code = *reinterpret_cast<const f4*>(sg + 128 + mb * 16), s_sTd = *reinterpret_cast<const f4*>(sg + 160 + mb * 16);
-            const f4 s_sT = *reinterpret_cast<const f4*>(sg + 192 + mb * 16), s_sDa = *reinterpret_cast<const f4*>(sg + 224 + mb * 16);
-            const f4 s_sDb = *reinterpret_cast<const f4*>(sg + 256 + mb * 16);
-            f4 wc, wd;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float code = s_code[e];
-                const float dp1 = ca[mb][e] * (s_sDa[e] * inM) + cb[mb][e] * (s_sDb[e] * inQ);
-                const float xr = c1[mb][e] * (s_sTd[e] * inS) + s_rt[e] + cterm;
-                const float P1 = __expf((mm ? xr : NEG) - s_rmax[e]) * s_rinv[e];     // 0 beyond the range (rinv = 0)
-                const float P2 = code != 0.f ? __expf((code == 2.f ? xr : NEG) - cmax) * cinv : 0.f;
-                const float g1 = P1 * (dp1 - s_dl1[e]) * mmf;
-                const float g2 = code == 2.f ? P2 * (c2[mb][e] * (s_sT[e] * inDq) - delta2) : 0.f;
-                dc += g1 + g2;
-                wc[e] = P1 * (s_sDa[e] * cDa);
-                wd[e] = (g1 + g2) * (s_sTd[e] * cS);
+            for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
+            if (!(dbg & 2)) {
+                sprod2p(pTd, r, g, sS, c1);
+                sprod2p(pT, r, g, sDq, c2);
             }
-            split_w_half(wc, mb, c_hi, c_lo);
-            split_w_half(wd, mb, d_hi, d_lo);
-            __builtin_amdgcn_sched_barrier(0);      // block by block: keeps the 9 scalar vectors of one block alive, not 18
-        }
-        if (!(dbg & 4)) {
-            pvprodp(pDa, tr, __builtin_bit_cast(half8, c_hi), __builtin_bit_cast(half8, c_lo), Oc);
-            __builtin_amdgcn_sched_barrier(0);
-            pvprodp(pTd, tr, __builtin_bit_cast(half8, d_hi), __builtin_bit_cast(half8, d_lo), Od);
-        }
-    }
-    dc = kg_allsum(dc);
-    __syncthreads();
-    if (dbg & 8) return;
-    // ---- epilogue: every wave parks its two tiles and dc, then whole rows, one per wave-instruction
-    float* eD = reinterpret_cast<float*>(smem);                 // [64][LDP]  sum_i dS text_d
-    float* eC = eD + 64 * LDP;                                  // [64][LDP]  sum_i P1 da
-    float* dcs = eC + 64 * LDP;                                 // [64]       dc
-    float* part = dcs + 64;                                     // [NW][256] per-wave partial sums of d_w_m
-    {
-        const float sd = 1.0f / cS, sc_ = 1.0f / cDa;
+            lds_barrier();            // role 1's dP1 is in LDS
+            f4 wc[2], wd[2];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            *reinterpret_cast<f4*>(eD + (wave * 16 + r) * LDP + 16 * dt + 4 * g) = Od[dt] * sd;
-            *reinterpret_cast<f4*>(eC + (wave * 16 + r) * LDP + 16 * dt + 4 * g) = Oc[dt] * sc_;
+            for (int mb = 0; mb < 2; ++mb) {
+                const f4 dp1 = *reinterpret_cast<const f4*>(xch + mb * 1024);
+                const f4 s_rt = *reinterpret_cast<const f4*>(sg + mb * 16), s_rmax = *reinterpret_cast<const f4*>(sg + 32 + mb * 16);
+                const f4 s_rinv = *reinterpret_cast<const f4*>(sg + 64 + mb * 16), s_dl1 = *reinterpret_cast<const f4*>(sg + 96 + mb * 16);
+                const f4 s_code = *reinterpret_cast<const f4*>(sg + 128 + mb * 16), s_sTd = *reinterpret_cast<const f4*>(sg + 160 + mb * 16);
+                const f4 s_sT = *reinterpret_cast<const f4*>(sg + 192 + mb * 16), s_sDa = *reinterpret_cast<const f4*>(sg + 224 + mb * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float code = s_code[e];
+                    const float xr = c1[mb][e] * (s_sTd[e] * inS) + s_rt[e] + cterm;
+                    const float P1 = __expf((mm ? xr : NEG) - s_rmax[e]) * s_rinv[e];     // 0 beyond the range (rinv = 0)
+                    const float P2 = code != 0.f ? __expf((code == 2.f ? xr : NEG) - cmax) * cinv : 0.f;
+                    const float g1 = P1 * (dp1[e] - s_dl1[e]) * mmf;
+                    const float g2 = code == 2.f ? P2 * (c2[mb][e] * (s_sT[e] * inDq) - delta2) : 0.f;
+                    dc += g1 + g2;
+                    wc[mb][e] = P1 * (s_sDa[e] * cDa);
+                    wd[mb][e] = (g1 + g2) * (s_sTd[e] * cS);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            half8 W0, W1;
+            split_w(wc[0], wc[1], W0, W1);
+            xch_put(xch + 2048, W0, W1);
+            split_w(wd[0], wd[1], W0, W1);
+            lds_barrier();            // role 1 has its weights
+            if (!(dbg & 4)) pvprodp(pTd, tr, W0, W1, O);
         }
-        if (g == 0) dcs[wave * 16 + r] = nin ? dc : 0.f;
+        dc = kg_allsum(dc);
+        __syncthreads();
+        if (dbg & 8) return;
+        const float scale = 1.0f / cS;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(eD + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
+        if (g == 0) dcs[w4 * 16 + r] = nin ? dc : 0.f;
+    } else {
+        side_t sM, sQ;       // mod (da . mod), q (db . q)
+        float inM, inQ;
+        load_side_planes(sM, inM, A.pM + (size_t)b * szM, A.iM + (size_t)b * Mp, n, M, g);
+        load_side_planes(sQ, inQ, A.pQ + (size_t)b * szM, A.iQ + (size_t)b * Mp, n, M, g);
+        float sc_next = 0.f;
+        if (np > 0 && sck < NSC) sc_next = fetch(scr);
+        maxima();
+        const float cDa = cmap(im[2]);
+        acc_t O;        // dmodc = sum_i P1 da
+        zero_acc(O);
+#pragma unroll 1
+        for (int pi = 0; pi < np; ++pi) {
+            if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+            __syncthreads();
+            issue_top(pi);
+            if (NT == 4 && pi > 0) __syncthreads();
+            if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            const char* pDa = ring_slot(smem, pi * NT + X_DA);
+            const char* pDb = ring_slot(smem, pi * NT + X_DB);
+            f4 c1[2], c2[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
+            if (!(dbg & 2)) {
+                sprod2p(pDb, r, g, sQ, c2);
+                sprod2p(pDa, r, g, sM, c1);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const f4 sDa = *reinterpret_cast<const f4*>(sg + 7 * 32 + mb * 16), sDb = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16);
+                *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sDa * inM) + c2[mb] * (sDb * inQ);
+            }
+            lds_barrier();
+            issue_mid(pi);            // the S-only panels are dead: re-fill their slots under role 0's arithmetic
+            lds_barrier();
+            half8 W0, W1;
+            xch_get(xch + 2048, W0, W1);
+            if (!(dbg & 4)) pvprodp(pDa, tr, W0, W1, O);
+        }
+        __syncthreads();
+        if (dbg & 8) return;
+        const float scale = 1.0f / cDa;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(eC + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
     }
     __syncthreads();
+    // ---- epilogue: whole rows, one per wave-instruction (role 0 parked dmodd and dc, role 1 dmodc)
+    float* part = dcs + 64;                                     // [8][256] per-wave partial sums of d_w_m
     const int row0 = tile * 64, d4 = 4 * lane;
     const bool cin = d4 < D;
     const f4 wm = cin ? *reinterpret_cast<const f4*>(A.w_m + d4) : f4{0.f, 0.f, 0.f, 0.f};
     const f4 wtm = cin ? *reinterpret_cast<const f4*>(A.w_tm + d4) : f4{0.f, 0.f, 0.f, 0.f};
     const bool fold = A.d_mod_d == nullptr;
     f4 pw = f4{0.f, 0.f, 0.f, 0.f};
-    f4 mdv[16];
+    f4 mdv[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int gn = row0 + wave + NW * k;
+    for (int k = 0; k < 8; ++k) {
+        const int gn = row0 + wave + 8 * k;
         mdv[k] = (gn < M && cin) ? *reinterpret_cast<const f4*>(A.mod_d + ((size_t)b * M + gn) * D + d4) : f4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int rr = wave + NW * k, gn = row0 + rr;
+    for (int k = 0; k < 8; ++k) {
+        const int rr = wave + 8 * k, gn = row0 + rr;
         if (gn < M && cin) {
             const f4 dd = *reinterpret_cast<const f4*>(eD + rr * LDP + d4);
             const f4 cc = *reinterpret_cast<const f4*>(eC + rr * LDP + d4);
@@ -1482,7 +1532,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     if (tid < D && !(dbg & 32)) {
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) acc += part[w * 256 + tid];
+        for (int w = 0; w < 8; ++w) acc += part[w * 256 + tid];
         atomicAdd(A.d_w_m + tid, acc);
     }
 }
@@ -1491,12 +1541,13 @@ template <bool DBG, bool SAME>
 __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, int local, char* smem) {
     const int dbg = DBG ? a.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int role = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
     const int r = lane & 15, g = lane >> 4;
     const int T = A.T, M = A.M, D = a.D, Tp = pad32(T), Mp = pad32(M);
     int tile, b;
     if (!decode_local(local, (T + 63) / 64, a.B, tile, b)) return;
-    const int n = (tile * NW + wave) * 16 + r;  // text row i
-    const bool wave_on = (tile * NW + wave) * 16 < T;
+    const int n = (tile * 4 + w4) * 16 + r;  // text row i
+    const bool wave_on = (tile * 4 + w4) * 16 < T;
     const bool nin = n < T;
 
     // streamed tensors in ring order: q, mod, [mod_d], dq.  Without dropped copies the similarity is formed as
@@ -1505,6 +1556,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     constexpr int X_Q = 0, X_M = 1, X_MD = SAME ? 1 : 2, X_DQ = SAME ? 2 : 3;
     constexpr int NSC = 10;
     float* sc = reinterpret_cast<float*>(smem + SWEEP_SC_OFF);    // [NSC][32]
+    char* xch = smem + SWEEP_XCH_OFF + w4 * XCH_PAIR + lane * 16;
     float* red = reinterpret_cast<float*>(smem + SWEEP_RED_OFF);
 
     const size_t szT = planes_sample_bytes(T), szM = planes_sample_bytes(M);
@@ -1519,175 +1571,213 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     const float* iDq_b = A.iDq + (size_t)b * Mp;
 
     const int np = (dbg & 16) ? 0 : (M + PR - 1) / PR;
-    auto issue = [&](int pi, int x) { stage_panel_w<NW>(ring_slot(smem, pi * NT + x), src[x], pi * PR, wave, lane); };
-    if (np > 0) {
+    auto issue8 = [&](int pi, int x) { stage_panel_w<8>(ring_slot(smem, pi * NT + x), src[x], pi * PR, wave, lane); };
+    auto issue4 = [&](int pi, int x) { stage_panel_w<4>(ring_slot(smem, pi * NT + x), src[x], pi * PR, w4, lane); };
+    if (np > 0 || !(dbg & 64)) {
 #pragma unroll
-        for (int x = 0; x < NT; ++x) issue(0, x);
+        for (int x = 0; x < NT; ++x) issue8(0, x);
     }
-    float im[4] = {0.f, 0.f, 0.f, 0.f};   // mod, mod_d, q, dq
-    for (int j = tid; j < M; j += NTHR) {
-        im[0] = fmaxf(im[0], iM_b[j]);
-        im[1] = fmaxf(im[1], iMd_b[j]);
-        im[2] = fmaxf(im[2], iQ_b[j]);
-        im[3] = fmaxf(im[3], iDq_b[j]);
-    }
-    wg_allmax_w<4, NW>(im, red, tid);
-    const float cDq = cmap(im[3]);
+    // maxima of the streamed rows' inverse scales (mod, mod_d, q, dq), run by both roles after their operand loads
+    float im[4] = {0.f, 0.f, 0.f, 0.f};
+    float cDq = 1.f, cS = 1.f;
+    const float inDa = nin ? A.iDa[(size_t)b * Tp + n] : 0.f, inDb = nin ? A.iDb[(size_t)b * Tp + n] : 0.f;
+    const float inT = nin ? A.iT[(size_t)b * Tp + n] : 0.f;
+    auto maxima = [&]() {
+        if (!(dbg & 128)) {
+            for (int j = tid; j < M; j += NT8) {
+                im[0] = fmaxf(im[0], iM_b[j]);
+                im[1] = fmaxf(im[1], iMd_b[j]);
+                im[2] = fmaxf(im[2], iQ_b[j]);
+                im[3] = fmaxf(im[3], iDq_b[j]);
+            }
+            wg_allmax_w<4, 8>(im, red, tid);
+        }
+        cDq = cmap(im[3]);
+        cS = cmap_bound(im[1], 1.3743895e11f /* 2^37 */ * (inDa * im[0] + inDb * im[2] + im[3] * inT));   // the same value in both roles
+    };
 
-    auto fetch = [&](int k, int j) -> float {
+    const int sck = tid >> 5, scr = tid & 31;
+    auto fetch = [&](int j) -> float {
         const bool in = j < M;
         const size_t bj = (size_t)b * M + j;
-        switch (k) {
+        switch (sck) {
             case 0: return in ? A.cterm[bj] : 0.f;
             case 1: return in ? A.col_stat[bj * 2] : 0.f;
             case 2: return in ? 1.0f / A.col_stat[bj * 2 + 1] : 0.f;
             case 3: return in ? A.delta2[bj] : 0.f;
             case 4: return in ? (mask_live(A.mod_mask, A.mod_len, b, M, j) ? 1.f : 0.f) : -1.f;   // modality mask, -1 beyond M
-            case 5: return in ? iMd_b[j] : 0.f;      // streamed similarity operand and value rows of dX (= mod without dropped copies)
+            case 5: return in ? iMd_b[j] : 0.f;      // streamed similarity operand (= mod without dropped copies)
             case 6: return in ? iDq_b[j] : 0.f;
-            case 7: return in ? iM_b[j] : 0.f;
+            case 7: return in ? iMd_b[j] : 0.f;
+            case 8: return in ? iM_b[j] : 0.f;
             default: return in ? iQ_b[j] : 0.f;
         }
     };
-    const int sck = tid >> 5, scr = tid & 31;
-    float sc_a = 0.f, sc_b = 0.f;
-    auto sc_fetch = [&](int pi) {
-        sc_a = fetch(sck, pi * PR + scr);
-        if (sck == 0) sc_b = fetch(8, pi * PR + scr);
-    };
-    auto sc_commit = [&]() {
-        sc[sck * 32 + scr] = sc_a;
-        if (sck == 0) sc[8 * 32 + scr] = sc_b;
-    };
     const float* sg = sc + 4 * g;            // scalar k of the lane's 4 rows of block mb: f4 at sg[k * 32 + mb * 16]
     const tr_off tr = make_tr_off(lane);
+    float* eX = reinterpret_cast<float*>(smem);                 // epilogue: [64][LDP]  dX
+    float* eT = eX + 64 * LDP;                                  //           [64][LDP]  sum_j P2 dq
+    float* drs = eT + 64 * LDP;                                 //           [64]       dr
 
-    // lane-side operands: text (dP2), text_d * w_tm (similarity), da, db
-    side_t sT, sS, sDa, sDb;
-    float inT, inS, inDa, inDb;
-    load_side_planes(sT, inT, A.pT + (size_t)b * szT, A.iT + (size_t)b * Tp, n, T, g);
-    if (SAME) side_times_w(sT, inT, A.w_tm, D, g, sS, inS);
-    else load_side_f32(sS, inS, A.text_d + (size_t)b * T * D, n, T, D, g, A.w_tm);
-    load_side_planes(sDa, inDa, A.pDa + (size_t)b * szT, A.iDa + (size_t)b * Tp, n, T, g);
-    load_side_planes(sDb, inDb, A.pDb + (size_t)b * szT, A.iDb + (size_t)b * Tp, n, T, g);
-    const float cS = cmap_bound(im[1], 1.3743895e11f /* 2^37 */ * (inDa * im[0] + inDb * im[2] + im[3] * inT));
-    const float rterm = nin ? A.rterm[(size_t)b * T + n] : 0.f;
-    const float rmax = nin ? A.row_stat[((size_t)b * T + n) * 2] : 0.f;
-    const float rinv = nin ? 1.0f / A.row_stat[((size_t)b * T + n) * 2 + 1] : 0.f;
-    const float dl1 = nin ? A.delta1[(size_t)b * T + n] : 0.f;
-    const bool tm = nin ? mask_live(A.text_mask, A.text_len, b, T, n) : false;
-    const float tmf = tm ? 1.f : 0.f;
-    if (np > 0) sc_fetch(0);
+    auto issue_top = [&](int pi) {
+        if (NT == 4 && pi > 0) issue8(pi, 3);                   // training mode: the 4th tensor of THIS panel, just in time
+    };
+    // The whole next panel is issued by the role-1 waves right after the S-type products (they idle while role 0 does the
+    // tile's arithmetic): two pieces into the spare slots, the last into the slot the S-only tensor of this panel has just
+    // vacated.  vmcnt counts in issue order, so a wave with DMA in flight would stall at its next scratch reload: role 0
+    // never issues DMA inside the loop, and role 1 issues it BEHIND the reloads of its S-type products.
+    auto issue_mid = [&](int pi) {
+        if (pi + 1 < np) {
+            issue4(pi + 1, 0);
+            issue4(pi + 1, 1);
+            issue4(pi + 1, 2);
+        }
+    };
 
-    acc_t Ot, Ox;        // sum_j P2 dq ; dX = sum_j dS mod_d
-    zero_acc(Ot);
-    zero_acc(Ox);
-    float dr = 0.f;
+    if (role == 0) {
+        side_t sT, sS;       // text (dP2); text_d * w_tm (similarity)
+        float inS, inT_;
+        if (!(dbg & 256)) {
+        load_side_planes(sT, inT_, A.pT + (size_t)b * szT, A.iT + (size_t)b * Tp, n, T, g);
+        if (SAME) side_times_w(sT, inT_, A.w_tm, D, g, sS, inS);
+        else load_side_f32(sS, inS, A.text_d + (size_t)b * T * D, n, T, D, g, A.w_tm);
+        }
+        const float rterm = nin ? A.rterm[(size_t)b * T + n] : 0.f;
+        const float rmax = nin ? A.row_stat[((size_t)b * T + n) * 2] : 0.f;
+        const float rinv = nin ? 1.0f / A.row_stat[((size_t)b * T + n) * 2 + 1] : 0.f;
+        const float dl1 = nin ? A.delta1[(size_t)b * T + n] : 0.f;
+        const bool tm = nin ? mask_live(A.text_mask, A.text_len, b, T, n) : false;
+        const float tmf = tm ? 1.f : 0.f;
+        float sc_next = 0.f;
+        if (np > 0 && sck < NSC) sc_next = fetch(scr);
+        maxima();             // every load of the prologue is in flight by now
+        acc_t O;        // sum_j P2 dq
+        zero_acc(O);
+        float dr = 0.f;
 #pragma unroll 1
-    for (int pi = 0; pi < np; ++pi) {
-        sc_commit();
-        __syncthreads();          // this panel's DMA has landed (vmcnt(0)), its scalars are visible, the previous panel is free
-        if (NT == 4 && pi > 0) {
-            issue(pi, 3);
-            __syncthreads();
-        }
-        if (pi + 1 < np) {
-            issue(pi + 1, 0);
-            if (NT == 3) issue(pi + 1, 1);
-            sc_fetch(pi + 1);
-        }
-        const char* pQ = ring_slot(smem, pi * NT + X_Q);
-        const char* pM = ring_slot(smem, pi * NT + X_M);
-        const char* pMd = ring_slot(smem, pi * NT + X_MD);
-        const char* pDq = ring_slot(smem, pi * NT + X_DQ);
-        f4 cb[2], ca[2], c1[2], c2[2];
+        for (int pi = 0; pi < np; ++pi) {
+            if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+            __syncthreads();          // this panel's DMA has landed (vmcnt(0)), its scalars are visible
+            issue_top(pi);
+            if (NT == 4 && pi > 0) __syncthreads();
+            if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            const char* pMd = ring_slot(smem, pi * NT + X_MD);
+            const char* pDq = ring_slot(smem, pi * NT + X_DQ);
+            f4 c1[2], c2[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) cb[q] = ca[q] = c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
-        if (!(dbg & 2)) {
-            sprod2p(pQ, r, g, sDb, cb);            // the S-only tensors first: their slots are re-filled below
-            if (!SAME) sprod2p(pM, r, g, sDa, ca);
-        }
-        lds_barrier();
-        if (pi + 1 < np) {
-            if (NT == 3) issue(pi + 1, 2);
-            else { issue(pi + 1, 1); issue(pi + 1, 2); }
-        }
-        if (!(dbg & 2)) {
-            if (SAME) sprod2p(pM, r, g, sDa, ca);
-            sprod2p(pMd, r, g, sS, c1);
-            sprod2p(pDq, r, g, sT, c2);
-        }
-        u4v t_hi, t_lo, x_hi, x_lo;          // (W0, W1) of the two weight sets, packed block by block
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            const f4 s_ct = *reinterpret_cast<const f4*>(sg + mb * 16), s_cmax = *reinterpret_cast<const f4*>(sg + 32 + mb * 16);
-            const f4 s_cinv = *reinterpret_cast<const f4*>(sg + 64 + mb * 16), s_dl2 = *reinterpret_cast<const f4*>(sg + 96 + mb * 16);
-            const f4 s_mf = *reinterpret_cast<const f4*>(sg + 128 + mb * 16), s_sMd = *reinterpret_cast<const f4*>(sg + 160 + mb * 16);
-            const f4 s_sDq = *reinterpret_cast<const f4*>(sg + 192 + mb * 16), s_sM = *reinterpret_cast<const f4*>(sg + 224 + mb * 16);
-            const f4 s_sQ = *reinterpret_cast<const f4*>(sg + 256 + mb * 16);
-            f4 wt, wx;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float mf = s_mf[e];
-                const float dp1 = ca[mb][e] * (s_sM[e] * inDa) + cb[mb][e] * (s_sQ[e] * inDb);
-                const float x = c1[mb][e] * (s_sMd[e] * inS) + rterm + s_ct[e];
-                const float P1 = mf >= 0.f ? __expf((mf > 0.f ? x : NEG) - rmax) * rinv : 0.f;
-                const float P2 = mf >= 0.f ? __expf((tm ? x : NEG) - s_cmax[e]) * s_cinv[e] : 0.f;
-                const float g1 = mf > 0.f ? P1 * (dp1 - dl1) : 0.f;
-                const float g2 = P2 * (c2[mb][e] * (s_sDq[e] * inT) - s_dl2[e]) * tmf;
-                dr += g1 + g2;
-                wt[e] = P2 * (s_sDq[e] * cDq);
-                wx[e] = (g1 + g2) * (s_sMd[e] * cS);
+            for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
+            if (!(dbg & 2)) {
+                sprod2p(pMd, r, g, sS, c1);
+                sprod2p(pDq, r, g, sT, c2);
             }
-            split_w_half(wt, mb, t_hi, t_lo);
-            split_w_half(wx, mb, x_hi, x_lo);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!(dbg & 4)) {
-            pvprodp(pDq, tr, __builtin_bit_cast(half8, t_hi), __builtin_bit_cast(half8, t_lo), Ot);
-            __builtin_amdgcn_sched_barrier(0);
-            pvprodp(pMd, tr, __builtin_bit_cast(half8, x_hi), __builtin_bit_cast(half8, x_lo), Ox);
-        }
-    }
-    dr = kg_allsum(dr);
-    __syncthreads();
-    if (dbg & 8) return;
-    // ---- epilogue.  The accumulator tiles hold 16 rows x 64-B pieces per instruction; every wave parks dX, the P2.dq sum and
-    // dr in LDS (the panels are dead) and the workgroup then works on whole rows -- one text row per wave-instruction, lane =
-    // 16-B chunk -- so that text_d, the d_text read-modify-write and d_text_d are fully coalesced, and the parameter-gradient
-    // sums over rows (d_w_t, d_w_tm) are per-lane accumulations over the wave's rows.
-    float* eX = reinterpret_cast<float*>(smem);                 // [64][LDP]  dX
-    float* eT = eX + 64 * LDP;                                  // [64][LDP]  sum_j P2 dq
-    float* drs = eT + 64 * LDP;                                 // [64]       dr
-    float* part = drs + 64;                                     // [NW][2][256] per-wave partial sums of d_w_t, d_w_tm
-    {
-        const float sx = 1.0f / cS, st = 1.0f / cDq;
+            lds_barrier();            // role 1's dP1 is in LDS
+            f4 wt[2], wx[2];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            *reinterpret_cast<f4*>(eX + (wave * 16 + r) * LDP + 16 * dt + 4 * g) = Ox[dt] * sx;
-            *reinterpret_cast<f4*>(eT + (wave * 16 + r) * LDP + 16 * dt + 4 * g) = Ot[dt] * st;
+            for (int mb = 0; mb < 2; ++mb) {
+                const f4 dp1 = *reinterpret_cast<const f4*>(xch + mb * 1024);
+                const f4 s_ct = *reinterpret_cast<const f4*>(sg + mb * 16), s_cmax = *reinterpret_cast<const f4*>(sg + 32 + mb * 16);
+                const f4 s_cinv = *reinterpret_cast<const f4*>(sg + 64 + mb * 16), s_dl2 = *reinterpret_cast<const f4*>(sg + 96 + mb * 16);
+                const f4 s_mf = *reinterpret_cast<const f4*>(sg + 128 + mb * 16), s_sSp = *reinterpret_cast<const f4*>(sg + 160 + mb * 16);
+                const f4 s_sDq = *reinterpret_cast<const f4*>(sg + 192 + mb * 16), s_sMd = *reinterpret_cast<const f4*>(sg + 224 + mb * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float mf = s_mf[e];
+                    const float x = c1[mb][e] * (s_sSp[e] * inS) + rterm + s_ct[e];
+                    const float P1 = mf >= 0.f ? __expf((mf > 0.f ? x : NEG) - rmax) * rinv : 0.f;
+                    const float P2 = mf >= 0.f ? __expf((tm ? x : NEG) - s_cmax[e]) * s_cinv[e] : 0.f;
+                    const float g1 = mf > 0.f ? P1 * (dp1[e] - dl1) : 0.f;
+                    const float g2 = P2 * (c2[mb][e] * (s_sDq[e] * inT) - s_dl2[e]) * tmf;
+                    dr += g1 + g2;
+                    wt[mb][e] = P2 * (s_sDq[e] * cDq);
+                    wx[mb][e] = (g1 + g2) * (s_sMd[e] * cS);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            half8 W0, W1;
+            split_w(wx[0], wx[1], W0, W1);
+            xch_put(xch + 2048, W0, W1);
+            split_w(wt[0], wt[1], W0, W1);
+            lds_barrier();            // role 1 has its weights
+            if (!(dbg & 4)) pvprodp(pDq, tr, W0, W1, O);
         }
-        if (g == 0) drs[wave * 16 + r] = nin ? dr : 0.f;
+        dr = kg_allsum(dr);
+        __syncthreads();
+        if (dbg & 8) return;
+        const float scale = 1.0f / cDq;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(eT + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
+        if (g == 0) drs[w4 * 16 + r] = nin ? dr : 0.f;
+    } else {
+        side_t sDa, sDb;
+        float iDa_, iDb_;
+        if (!(dbg & 256)) {
+        load_side_planes(sDa, iDa_, A.pDa + (size_t)b * szT, A.iDa + (size_t)b * Tp, n, T, g);
+        load_side_planes(sDb, iDb_, A.pDb + (size_t)b * szT, A.iDb + (size_t)b * Tp, n, T, g);
+        }
+        float sc_next = 0.f;
+        if (np > 0 && sck < NSC) sc_next = fetch(scr);
+        maxima();
+        acc_t O;        // dX = sum_j dS mod_d
+        zero_acc(O);
+#pragma unroll 1
+        for (int pi = 0; pi < np; ++pi) {
+            if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+            __syncthreads();
+            issue_top(pi);
+            if (NT == 4 && pi > 0) __syncthreads();
+            if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            const char* pM = ring_slot(smem, pi * NT + X_M);
+            const char* pQ = ring_slot(smem, pi * NT + X_Q);
+            const char* pMd = ring_slot(smem, pi * NT + X_MD);
+            f4 c1[2], c2[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
+            if (!(dbg & 2)) {
+                sprod2p(pQ, r, g, sDb, c2);
+                sprod2p(pM, r, g, sDa, c1);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const f4 sM = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16), sQ = *reinterpret_cast<const f4*>(sg + 9 * 32 + mb * 16);
+                *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sM * inDa) + c2[mb] * (sQ * inDb);
+            }
+            lds_barrier();
+            issue_mid(pi);            // the S-only panels are dead: re-fill their slots under role 0's arithmetic
+            lds_barrier();
+            half8 W0, W1;
+            xch_get(xch + 2048, W0, W1);
+            if (!(dbg & 4)) pvprodp(pMd, tr, W0, W1, O);
+        }
+        __syncthreads();
+        if (dbg & 8) return;
+        const float scale = 1.0f / cS;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(eX + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
     }
     __syncthreads();
+    // ---- epilogue.  The accumulator tiles hold 16 rows x 64-B pieces per instruction; role 1 parked dX, role 0 the P2.dq
+    // sum and dr in LDS (the panels are dead) and the workgroup now works on whole rows -- one text row per
+    // wave-instruction, lane = 16-B chunk -- so that text_d, the d_text read-modify-write and d_text_d are fully coalesced,
+    // and the parameter-gradient sums over rows (d_w_t, d_w_tm) are per-lane accumulations over the wave's rows.
+    float* part = drs + 64;                                     // [8][2][256] per-wave partial sums of d_w_t, d_w_tm
     const int row0 = tile * 64, d4 = 4 * lane;
     const bool cin = d4 < D;
     const f4 wt4 = cin ? *reinterpret_cast<const f4*>(A.w_t + d4) : f4{0.f, 0.f, 0.f, 0.f};
     const f4 wtm = cin ? *reinterpret_cast<const f4*>(A.w_tm + d4) : f4{0.f, 0.f, 0.f, 0.f};
     const bool fold = A.d_text_d == nullptr;
     f4 pt = f4{0.f, 0.f, 0.f, 0.f}, ptm = pt;
-    f4 tdv[16], prev[16];
+    f4 tdv[8], prev[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {   // all loads of the wave's 16 rows in flight together
-        const int gn = row0 + wave + NW * k;
+    for (int k = 0; k < 8; ++k) {   // all loads of the wave's 8 rows in flight together
+        const int gn = row0 + wave + 8 * k;
         const bool ok = gn < T && cin;
         const size_t o = ((size_t)b * T + min(gn, T - 1)) * D + d4;
         tdv[k] = ok ? *reinterpret_cast<const f4*>(A.text_d + o) : f4{0.f, 0.f, 0.f, 0.f};
         prev[k] = ok ? *reinterpret_cast<const f4*>(A.d_text + o) : f4{0.f, 0.f, 0.f, 0.f};   // g0 + g2*a + g3*b from the prologue
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int rr = wave + NW * k, gn = row0 + rr;
+    for (int k = 0; k < 8; ++k) {
+        const int rr = wave + 8 * k, gn = row0 + rr;
         if (gn < T && cin) {
             const f4 dXv = *reinterpret_cast<const f4*>(eX + rr * LDP + d4);
             const f4 dtv = *reinterpret_cast<const f4*>(eT + rr * LDP + d4);
@@ -1708,16 +1798,12 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     *reinterpret_cast<f4*>(part + (wave * 2 + 1) * 256 + d4) = ptm;
     __syncthreads();
     {
-        const int d = tid;   // 256 threads cover d_w_t and d_w_tm (D <= 208)
+        const int which = tid >> 8, d = tid & 255;   // 2 x 256 threads cover d_w_t | d_w_tm (D <= 208)
         if (d < D && !(dbg & 32)) {
-            float at = 0.f, atm = 0.f;
+            float acc = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                at += part[(w * 2 + 0) * 256 + d];
-                atm += part[(w * 2 + 1) * 256 + d];
-            }
-            atomicAdd(A.d_w_t + d, at);
-            atomicAdd(A.d_w_tm + d, atm);
+            for (int w = 0; w < 8; ++w) acc += part[(w * 2 + which) * 256 + d];
+            atomicAdd((which ? A.d_w_tm : A.d_w_t) + d, acc);
         }
     }
     if (wave == 0 && !(dbg & 32)) {
@@ -1727,7 +1813,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
 }
 
 template <bool DBG, bool SAME>
-__global__ __launch_bounds__(NTHR) void att_bwd_sweep_kernel(const GroupArgs a, const SweepMap sm) {
+__global__ __launch_bounds__(NT8) void att_bwd_sweep_kernel(const GroupArgs a, const SweepMap sm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int local;
     if (DBG && (a.dbg & 512)) return;                                  // timing only: launch floor
@@ -1741,6 +1827,7 @@ __global__ __launch_bounds__(NTHR) void att_bwd_sweep_kernel(const GroupArgs a, 
         sweep_i_body<DBG, SAME>(a, A, local, smem);
     }
 }
+
 
 // ------------------------------------------------------------------------------------------ host side
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -2054,13 +2141,13 @@ extern "C" int mmb_bidaf_group_bwd(const mmb_bidaf_desc* d, int n, int B, int D,
         for (int k = 0; k < n; ++k) sm.i.begin[k + 1] = sm.i.begin[k] + sweep_blocks(ga.g[k].T, B);
         for (int k = n; k < MAXG; ++k) sm.i.begin[k + 1] = sm.i.begin[n];
         const size_t loop_b = SWEEP_LOOP_LDS;
-        const size_t epi = ((size_t)2 * 64 * LDP + 64 + NW * 2 * 256) * sizeof(float);
+        const size_t epi = ((size_t)2 * 64 * LDP + 64 + 8 * 2 * 256) * sizeof(float);
         const size_t lds = loop_b > epi ? loop_b : epi;
         auto kern = ga.dbg ? (drop ? att_bwd_sweep_kernel<true, false> : att_bwd_sweep_kernel<true, true>)
                            : (drop ? att_bwd_sweep_kernel<false, false> : att_bwd_sweep_kernel<false, true>);
         if (int rc = allow_lds(kern, lds)) return rc;
         ProfScope ps_(MMB_K_ATT_BWD_I, stream);
-        hipLaunchKernelGGL(kern, dim3(sm.i.begin[n]), dim3(NTHR), lds, stream, ga, sm);
+        hipLaunchKernelGGL(kern, dim3(sm.i.begin[n]), dim3(NT8), lds, stream, ga, sm);
         MMB_HIP(hipGetLastError());
     }
     return MMB_OK;

@@ -212,7 +212,7 @@ def test_attention_wide_dynamic_range_vs_float64():
     (DESIGN 4.1): rows more than ~2^10 below the largest value row of their sample lose relative (not absolute) precision.
     Inputs here: per-row scales e^-8 .. e^3 on both sides and heavy-tailed entries inside rows; reference = the oracle in
     float64.  Asserted: every output / gradient to 1e-4 of ITS OWN tensor scale (the bound of every other test), and --
-    the documented limit -- small-magnitude text rows of `out` to 2e-3 of their own row scale."""
+    row by row -- the attended context and text*b of every live text row to 1e-4 of that ROW's own scale (measured 2e-6 .. 7e-6)."""
     from mmbidaf_amd import functional as MF
     d = dev()
     g = torch.Generator().manual_seed(77)
@@ -241,8 +241,8 @@ def test_attention_wide_dynamic_range_vs_float64():
         row_scale = ref[:, :, lo:hi].abs().amax(-1).clamp_min(1e-30)
         rel = ((got[:, :, lo:hi] - ref[:, :, lo:hi]).abs().amax(-1) / row_scale)
         rel = rel[tm]        # live text rows
-        record_parity(f"row-relative error of {nm} (wide range)", rel.max().item(), 2e-3, 1.0)
-        assert rel.max().item() <= 2e-3, f"{nm}: row-relative error {rel.max().item():.2e}"
+        record_parity(f"row-relative error of {nm} (wide range)", rel.max().item(), 1e-4, 1.0)
+        assert rel.max().item() <= 1e-4, f"{nm}: row-relative error {rel.max().item():.2e}"
 
 
 def test_attention_full_size_properties():
