@@ -56,8 +56,11 @@ def parse():
                     help="arithmetic of the LSTM layers' matrix-core products: f32 = fp32-accurate split (default; the metric "
                          "configuration), bf16 = bf16 operands, one product (default for cfg5, which BASELINE.json names as bf16)")
     ap.add_argument("--graph", action="store_true",
-                    help="capture one fwd+bwd step of the region into a hipGraph after warm-up and replay it (the C-ABI calls only "
-                         "enqueue on the given stream): the host then issues ONE launch per step (N=1, fixed lengths only)")
+                    help="insist on the hipGraph form of the step (the default whenever the lengths are fixed): one fwd+bwd step of the "
+                         "region is captured after warm-up and replayed -- the C-ABI calls only enqueue on the given stream -- so the host "
+                         "issues ONE launch per step; for N > 1 the flat gradient all-reduce follows each replay")
+    ap.add_argument("--eager", action="store_true",
+                    help="issue every step from Python (autograd + ~60 launches per step; needs a host that keeps up with a 2.6-ms step)")
     ap.add_argument("--profile-all", action="store_true", help="time every kernel class (perturbs the step time a little)")
     ap.add_argument("--drop-prob", type=float, default=0.0,
                     help="train the region with this dropout probability (the reference trains at 0.2, train.py:210): dropped "
@@ -161,13 +164,13 @@ def cpu_baseline(region, cfg, ragged):
                       f"{threads} threads on {cpu}; the reference's own Python does not travel to this box"}
 
 
-def attention_roofline(a, prof, B, T, Ma, Mi, D, fused):
+def attention_roofline(a, prof, B, T, Ma, Mi, D, fused, steps=None):
     """roofline.achieved = algorithmic bytes / kernel time / HBM peak for the fused BiDAF attention, forward
     and backward of BOTH attentions of a step (six grouped launches); algorithmic bytes fwd 4B(5TD+MD), bwd 4B(6TD+2MD).
     Times are HIP events recorded by the library around every launch on the launch stream, over the timed region."""
     if not fused:
         return None       # D > 208 runs the general-width kernels (bidaf_big.hip: batched GEMMs + softmax kernels)
-    steps = max(a.steps, 1)
+    steps = max(steps or a.steps, 1)
     fwd_us = prof["att_fwd"][0] / steps * 1e3
     bwd_us = prof["att_bwd"][0] / steps * 1e3
     fwd_b = sum(synth.attention_algorithmic_bytes(B, T, M, D) for M in (Ma, Mi))
@@ -244,7 +247,14 @@ def main():
     from mmbidaf_amd import functional as MF
     dtype = a.dtype or ("bf16" if a.config == "cfg5" else "f32")
     MF.set_precision("bf16" if dtype == "bf16" else "fp32")
-    sync = ddp.FlatGradAllReduce(params, buckets=ddp.region_buckets(region), overlap=True, defer_fn=MF.defer_grad_work)
+    # hipGraph replay is the default form of the step (fixed lengths: the synthetic workload); --fresh-lengths (new lengths
+    # every step), --profile-all (an event pair around every kernel) and --eager issue the step from Python
+    want_graph = not a.eager and not a.fresh_lengths and not a.profile_all
+    if a.graph and not want_graph:
+        raise SystemExit("--graph: fixed lengths, no --profile-all / --eager")
+    # eager: buckets launched from grad hooks so that the exchange overlaps the rest of the backward pass; graph: the
+    # collectives stay outside the captured step and follow each replay
+    sync = ddp.FlatGradAllReduce(params, buckets=ddp.region_buckets(region), overlap=not want_graph, defer_fn=MF.defer_grad_work)
     sync.broadcast_parameters()
     batch = synth.make_batch(a.config, rank=rank, ragged=a.ragged, device=dev, batch=B)
     xs = [batch[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]  # they come from trainable embeddings
@@ -270,37 +280,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    graph, graph_note = None, None
+    eager_step = step
+    if want_graph:
+        # whole-step capture (PyTorch's "whole network" recipe): grads are allocated inside the graph's private pool, the
+        # synthetic batch and the parameters are static tensors.  Capture is set-up work, outside the warm-up and timed steps.
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            for p in params:
+                p.grad = None
+            for x in xs:
+                x.grad = None
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+                synth.region_loss(outs, batch).backward()
+            graph = g_
+
+            def step():
+                graph.replay()
+                sync()
+        except Exception as e:      # noqa: BLE001  (a capture failure must not cost the run: fall back to eager, say so)
+            if a.graph:
+                raise
+            graph, graph_note, step = None, f"hipGraph capture failed ({type(e).__name__}: {e}); eager steps", eager_step
+            torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
-    graph = None
-    if a.graph:
-        if world > 1 or a.fresh_lengths:
-            raise SystemExit("--graph: single GPU, fixed lengths")
-        # whole-step capture (PyTorch's "whole network" recipe): grads are allocated inside the graph's private pool, the
-        # synthetic batch and the parameters are static tensors
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        for p in params:
-            p.grad = None
-        for x in xs:
-            x.grad = None
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
-            synth.region_loss(outs, batch).backward()
-        eager_step = step
-        step = graph.replay
-        for _ in range(2):
-            step()
     # default: two event pairs per attention call (36 events per step around every kernel cost 4 % of the step)
     timed = ALL_KERNELS if a.profile_all else ATT_GROUPS
     if graph is not None:
-        timed = []          # the event pairs of the timing hook cannot be recorded inside a replayed graph
+        timed = []          # the event pairs of the timing hook cannot be recorded inside a replayed graph: see below
     fence()
     _lib.profile_enable(timed)
     t0 = time.perf_counter()
@@ -309,6 +325,25 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     _lib.profile_enable([])
+    prof_steps = a.steps
+    if graph is not None:
+        # attention kernel times for the roofline figure: HIP events cannot bracket kernels inside a replayed graph, so the same
+        # step is issued eagerly a few times right after the timed region, with the library's event pairs around the grouped
+        # attention calls (same process, same tensors, same kernels)
+        prof_steps = min(max(a.steps, 5), 20)
+        timed = ATT_GROUPS
+        for p in params:
+            p.grad = None
+        for x in xs:
+            x.grad = None
+        for _ in range(2):
+            eager_step()
+        fence()
+        _lib.profile_enable(timed)
+        for _ in range(prof_steps):
+            eager_step()
+        fence()
+        _lib.profile_enable([])
     devices = [f"cuda:{local}"]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -341,10 +376,16 @@ def main():
                                    f"fwd+bwd"
                                    f"{' + bucketed gradient all-reduce (sum)' if world > 1 else ''}",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
-            "roofline": attention_roofline(a, prof, B, T, Ma, Mi, D, fused=D <= _lib.ATT_MAX_D) if timed else None,
+            "roofline": attention_roofline(a, prof, B, T, Ma, Mi, D, fused=D <= _lib.ATT_MAX_D, steps=prof_steps) if timed else None,
         }
         if graph is not None:
-            out["config"]["launch"] = "hipGraph replay of one captured fwd+bwd step"
+            out["config"]["launch"] = ("hipGraph replay of one captured fwd+bwd step (all launches of the step on the GPU's queues, one graph "
+                                       "launch per step from the host)" + ("; flat gradient all-reduce after each replay" if world > 1 else ""))
+            if out["roofline"] is not None:
+                out["roofline"]["timing_note"] = (f"kernel times: HIP events around the grouped attention calls over {prof_steps} EAGER steps of the same "
+                                                  "workload issued right after the timed region (events cannot bracket kernels inside a replayed graph)")
+        else:
+            out["config"]["launch"] = "eager: every step issued from Python" + (f" ({graph_note})" if graph_note else "")
         if world > 1:
             out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": devices,
                            "grad_buckets": len(sync.buckets), "grad_elems": sync.numel}
