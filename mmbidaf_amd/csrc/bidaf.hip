@@ -768,19 +768,28 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
     float* sc = reinterpret_cast<float*>(smem + (db ? 2 : 1) * stage_b);   // [2 buffers][NSC][64]
     float* red = sc + 2 * NSC * 64;
 
-    side_t side;
-    float inv_n;
-    load_side_f32(side, inv_n, A.mod_d + (size_t)b * N * D, n, N, D, g, A.w_tm);
+    const int niter = (dbg & 16) ? 0 : (R + 63) / 64;
+    auto stage = [&](char* base, int it) {
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+            const int p0 = 64 * it + 32 * gq;
+            if (p0 < Rp) {
+                stage_panel_w<8>(base + gq * npan * PANEL_B, pV_b, p0, wave, lane);
+                if (sep_s) stage_panel_w<8>(base + gq * npan * PANEL_B + PANEL_B, pS_b, p0, wave, lane);
+            }
+        }
+    };
+    // prologue: the first panels, the lane-side rows, the maxima pass and the first scalars are all requested before anything
+    // waits -- one round trip to memory, not one per stage
+    if (niter > 0 && db) stage(smem, 0);
+    float xrow[KT][8];
+    load_row_regs(xrow, A.mod_d + (size_t)b * N * D, n, N, D, g, A.w_tm);
     const bool nin = n < N;
     const float nterm = nin ? A.cterm[(size_t)b * N + n] : 0.f;
     const bool mm = nin ? mask_live(A.mod_mask, A.mod_len, b, N, n) : false;
     const tr_off tr = make_tr_off(lane);
-
-    // c: power of two mapping the largest inverse scale of the value rows to 2^14
     float im[1] = {0.f};
     for (int i = tid; i < R; i += NT8) im[0] = fmaxf(im[0], iV_b[i]);
-    wg_allmax_w<1, 8>(im, red, tid);
-    const float cV = cmap(im[0]);
 
     // per-row scalars of streamed row m (fetched by thread (k = tid >> 6, rr = tid & 63) for row 64 it + rr)
     const int sck = tid >> 6, scr = tid & 63;
@@ -792,7 +801,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
                 case 0: return in ? A.rterm[bm_] : 0.f;
                 case 1: return (float)mask_code(in, A.text_mask, A.text_len, b, R, m);
                 case 2: return in ? iS_b[m] : 0.f;
-                default: return in ? iV_b[m] * cV : 0.f;
+                default: return in ? iV_b[m] : 0.f;
             }
         } else {
             switch (sck) {
@@ -800,7 +809,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
                 case 1: return in ? A.row_stat[bm_ * 2] : INFINITY;          // exp(x - inf) = 0 beyond the range
                 case 2: return in ? 1.0f / A.row_stat[bm_ * 2 + 1] : 0.f;
                 case 3: return in ? iS_b[m] : 0.f;
-                default: return in ? iV_b[m] * cV : 0.f;
+                default: return in ? iV_b[m] : 0.f;
             }
         }
     };
@@ -808,26 +817,18 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
     auto sc_fetch = [&](int it) { if (sck < NSC) sc_next = fetch(64 * it + scr); };
     auto sc_commit = [&](int buf) { if (sck < NSC) sc[(buf * NSC + sck) * 64 + scr] = sc_next; };
 
-    auto stage = [&](char* base, int it) {
-#pragma unroll
-        for (int gq = 0; gq < 2; ++gq) {
-            const int p0 = 64 * it + 32 * gq;
-            if (p0 < Rp) {
-                stage_panel_w<8>(base + gq * npan * PANEL_B, pV_b, p0, wave, lane);
-                if (sep_s) stage_panel_w<8>(base + gq * npan * PANEL_B + PANEL_B, pS_b, p0, wave, lane);
-            }
-        }
-    };
+    if (niter > 0) sc_fetch(0);
+    side_t side;
+    float inv_n;
+    side_from_regs(xrow, side, inv_n);
+    // c: power of two mapping the largest inverse scale of the value rows to 2^14
+    wg_allmax_w<1, 8>(im, red, tid);
+    const float cV = cmap(im[0]);
 
     acc_t O;
     zero_acc(O);
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int niter = (dbg & 16) ? 0 : (R + 63) / 64;
-    if (niter > 0) {
-        sc_fetch(0);
-        if (db) stage(smem, 0);
-    }
     for (int it = 0; it < niter; ++it) {
         char* base;
         int sb;
@@ -879,7 +880,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
                     for (int e = 0; e < 4; ++e) {
                         const float pv = __expf(v[mb][e] - m_new);
                         psum += pv;
-                        w[mb][e] = pv * s0[192 + mb * 16 + 4 * g + e];
+                        w[mb][e] = pv * (s0[192 + mb * 16 + 4 * g + e] * cV);
                     }
                 l_run = l_run * alpha + psum;
                 if (__any(alpha != 1.0f)) {
@@ -895,7 +896,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
                         const int ml = mb * 16 + 4 * g + e;
                         const float x = mm ? v[mb][e] * (s0[192 + ml] * inv_n) + s0[ml] + nterm : NEG;
                         const float p = __expf(x - s0[64 + ml]) * s0[128 + ml];
-                        w[mb][e] = p * s0[256 + ml];
+                        w[mb][e] = p * (s0[256 + ml] * cV);
                     }
             }
             half8 W0, W1;
@@ -948,6 +949,16 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
     const int row0 = tile * 64;
     char* dst_p = (KIND == 0 ? A.pQ : A.pDq) + (size_t)b * planes_sample_bytes(N);
     float* dst_i = (KIND == 0 ? A.iQ : A.iDq) + (size_t)b * Np;
+    f4 qrow[8];
+    if (KIND == 1) {         // delta2_j = q_j . dq_j: the q rows of the wave's 8 rows, all loads in flight together
+        const char* q_p = A.pQ + (size_t)b * planes_sample_bytes(N);
+        const float* q_i = A.iQ + (size_t)b * Np;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int gn = min(row0 + wave + 8 * k, Np - 1);
+            qrow[k] = lane < 8 * KT ? planes_row_f32(q_p, q_i, gn, lane) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int rr = wave + 8 * k, gn = row0 + rr;
@@ -963,15 +974,13 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
                     A.col_stat[((size_t)b * N + gn) * 2 + 1] = est[rr * 2 + 1];
                 }
             } else {
-                // delta2_j = q_j . dq_j
-                float dot = 0.f;
-                if (lane < 8 * KT) dot = f4sum(x * planes_row_f32(A.pQ + (size_t)b * planes_sample_bytes(N), A.iQ + (size_t)b * Np, gn, lane));
-                dot = wave_allsum(dot);
+                const float dot = wave_allsum(f4sum(x * qrow[k]));
                 if (lane == 0) A.delta2[(size_t)b * N + gn] = dot;
             }
         }
     }
 }
+
 
 // ------------------------------------------------------------------------------------------ row pass (forward)
 // Lane side = 64 text rows (text_d * w_tm, split in registers from fp32), streams the modality rows with values
@@ -1004,12 +1013,37 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
     float* sc = reinterpret_cast<float*>(smem + npan * PANEL_B);    // [NSC][32]
     float* red = sc + NSC * 32;
 
-    side_t side;
-    float inv_n;
-    load_side_f32(side, inv_n, A.text_d + (size_t)b * N * D, n, N, D, g, A.w_tm);
+    // prologue: the first panel, the lane-side rows, the text rows of the verbatim copy, the maxima pass and the first scalars are
+    // all requested before anything waits
+    const int row_end = (dbg & 16) ? 0 : R;
+    auto stage = [&](int p0) {
+        stage_panel_w<NW>(smem, pV0_b, p0, wave, lane);
+        stage_panel_w<NW>(smem + PANEL_B, pV1_b, p0, wave, lane);
+        if (sep_s) stage_panel_w<NW>(smem + 2 * PANEL_B, pS_b, p0, wave, lane);
+    };
+    if (row_end > 0) stage(0);
+    float xrow[KT][8];
+    load_row_regs(xrow, A.text_d + (size_t)b * N * D, n, N, D, g, A.w_tm);
     const float nterm = n < N ? A.rterm[(size_t)b * N + n] : 0.f;
     const tr_off tr = make_tr_off(lane);
-
+    const int sck = tid >> 5, scr = tid & 31;
+    auto fetch = [&](int m) -> float {
+        const bool in = m < R;
+        switch (sck) {
+            case 0: return in ? A.cterm[(size_t)b * R + m] : 0.f;
+            case 1: return (float)mask_code(in, A.mod_mask, A.mod_len, b, R, m);
+            case 2: return in ? iS_b[m] : 0.f;
+            case 3: return in ? iV0_b[m] : 0.f;
+            default: return in ? iV1_b[m] : 0.f;
+        }
+    };
+    float sc_next = 0.f;
+    if (row_end > 0 && sck < NSC) sc_next = fetch(scr);
+    float im[2] = {0.f, 0.f};
+    for (int i = tid; i < R; i += NTHR) {
+        im[0] = fmaxf(im[0], iV0_b[i]);
+        im[1] = fmaxf(im[1], iV1_b[i]);
+    }
     // first quarter of `out` = verbatim copy of text (attention.py:52): one row per wave-instruction, 16 rows per wave
     {
         const float* tx = A.text + (size_t)b * N * D;
@@ -1027,38 +1061,21 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
             if (gn < N && cin) *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 4 * lane) = t[k];
         }
     }
-    float im[2] = {0.f, 0.f};
-    for (int i = tid; i < R; i += NTHR) {
-        im[0] = fmaxf(im[0], iV0_b[i]);
-        im[1] = fmaxf(im[1], iV1_b[i]);
-    }
+    side_t side;
+    float inv_n;
+    side_from_regs(xrow, side, inv_n);
     wg_allmax_w<2, NW>(im, red, tid);
     const float c0 = cmap(im[0]), c1 = cmap(im[1]);
-
-    const int sck = tid >> 5, scr = tid & 31;
-    auto fetch = [&](int m) -> float {
-        const bool in = m < R;
-        switch (sck) {
-            case 0: return in ? A.cterm[(size_t)b * R + m] : 0.f;
-            case 1: return (float)mask_code(in, A.mod_mask, A.mod_len, b, R, m);
-            case 2: return in ? iS_b[m] : 0.f;
-            case 3: return in ? iV0_b[m] * c0 : 0.f;
-            default: return in ? iV1_b[m] * c1 : 0.f;
-        }
-    };
-    float sc_next = 0.f;
-    const int row_end = (dbg & 16) ? 0 : R;
-    if (row_end > 0 && sck < NSC) sc_next = fetch(scr);
 
     acc_t O0, O1;
     zero_acc(O0);
     zero_acc(O1);
     float m_run = -INFINITY, l_run = 0.f;
     for (int p0 = 0; p0 < row_end; p0 += PR) {
-        __syncthreads();
-        stage_panel_w<NW>(smem, pV0_b, p0, wave, lane);
-        stage_panel_w<NW>(smem + PANEL_B, pV1_b, p0, wave, lane);
-        if (sep_s) stage_panel_w<NW>(smem + 2 * PANEL_B, pS_b, p0, wave, lane);
+        if (p0 > 0) {
+            __syncthreads();
+            stage(p0);
+        }
         if (sck < NSC) sc[sck * 32 + scr] = sc_next;
         __syncthreads();
         if (p0 + PR < row_end && sck < NSC) sc_next = fetch(p0 + PR + scr);
@@ -1105,7 +1122,7 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * sc[96 + mb * 16 + 4 * g + e];
+                for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * (sc[96 + mb * 16 + 4 * g + e] * c0);
             half8 W0, W1;
             split_w(w[0], w[1], W0, W1);
             if (!(dbg & 4)) pvprodp(pV0, tr, W0, W1, O0);
@@ -1115,7 +1132,7 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * sc[128 + mb * 16 + 4 * g + e];
+                for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * (sc[128 + mb * 16 + 4 * g + e] * c1);
             half8 W0, W1;
             split_w(w[0], w[1], W0, W1);
             if (!(dbg & 4)) pvprodp(pV1, tr, W0, W1, O1);

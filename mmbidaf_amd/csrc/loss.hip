@@ -15,6 +15,8 @@ struct WSumArgs {
     long n[MMB_WSUM_MAX];
     int blk_begin[MMB_WSUM_MAX + 1];
     int k;
+    int reps;          // chunks of WS_PER_BLOCK elements per workgroup (keeps the grid near one workgroup per CU x 2: the
+                       // ticket atomics and fences of the forward are per workgroup)
 };
 constexpr int WS_PER_BLOCK = 256 * 4 * 8;   // elements one workgroup covers
 __device__ __forceinline__ float f4sum(const f4 v) { return (v.x + v.y) + (v.z + v.w); }
@@ -25,20 +27,23 @@ __global__ __launch_bounds__(256) void wsum_fwd_kernel(const WSumArgs a, float* 
     int k = 0;
     for (int i = 1; i < a.k; ++i)
         if ((int)blockIdx.x >= a.blk_begin[i]) k = i;
-    const long base = (long)(blockIdx.x - a.blk_begin[k]) * WS_PER_BLOCK;
     const float* x = a.x[k];
     const float* w = a.w[k];
     const long n = a.n[k];
     float acc = 0.f;
+    for (int rep = 0; rep < a.reps; ++rep) {
+        const long base = ((long)(blockIdx.x - a.blk_begin[k]) * a.reps + rep) * WS_PER_BLOCK;
+        if (base >= n) break;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const long i = base + ((long)it * 256 + threadIdx.x) * 4;
-        if (i + 3 < n) {
-            const f4 v = *reinterpret_cast<const f4*>(x + i);
-            if (w) acc += f4sum(v * *reinterpret_cast<const f4*>(w + i));
-            else acc += f4sum(v);
-        } else {
-            for (long j = i; j < n; ++j) acc += x[j] * (w ? w[j] : 1.0f);
+        for (int it = 0; it < 8; ++it) {
+            const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+            if (i + 3 < n) {
+                const f4 v = *reinterpret_cast<const f4*>(x + i);
+                if (w) acc += f4sum(v * *reinterpret_cast<const f4*>(w + i));
+                else acc += f4sum(v);
+            } else {
+                for (long j = i; j < n; ++j) acc += x[j] * (w ? w[j] : 1.0f);
+            }
         }
     }
 #pragma unroll
@@ -71,20 +76,23 @@ __global__ __launch_bounds__(256) void wsum_bwd_kernel(const WSumArgs a, const f
     int k = 0;
     for (int i = 1; i < a.k; ++i)
         if ((int)blockIdx.x >= a.blk_begin[i]) k = i;
-    const long base = (long)(blockIdx.x - a.blk_begin[k]) * WS_PER_BLOCK;
     const float g = g_ptr[0];
     const float* w = a.w[k];
     float* dx = a.dx[k];
     const long n = a.n[k];
+    for (int rep = 0; rep < a.reps; ++rep) {
+        const long base = ((long)(blockIdx.x - a.blk_begin[k]) * a.reps + rep) * WS_PER_BLOCK;
+        if (base >= n) break;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const long i = base + ((long)it * 256 + threadIdx.x) * 4;
-        if (i + 3 < n) {
-            f4 v = f4{g, g, g, g};
-            if (w) v = *reinterpret_cast<const f4*>(w + i) * g;
-            *reinterpret_cast<f4*>(dx + i) = v;
-        } else {
-            for (long j = i; j < n; ++j) dx[j] = g * (w ? w[j] : 1.0f);
+        for (int it = 0; it < 8; ++it) {
+            const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+            if (i + 3 < n) {
+                f4 v = f4{g, g, g, g};
+                if (w) v = *reinterpret_cast<const f4*>(w + i) * g;
+                *reinterpret_cast<f4*>(dx + i) = v;
+            } else {
+                for (long j = i; j < n; ++j) dx[j] = g * (w ? w[j] : 1.0f);
+            }
         }
     }
 }
@@ -92,6 +100,11 @@ __global__ __launch_bounds__(256) void wsum_bwd_kernel(const WSumArgs a, const f
 static int fill_args(WSumArgs& a, const float* const* x, const float* const* w, float* const* dx, const long* n, int k) {
     MMB_REQUIRE(k >= 1 && k <= MMB_WSUM_MAX && n, "mmb_weighted_sums: 1..%d tensors", MMB_WSUM_MAX);
     a.k = k;
+    long chunks = 0;
+    for (int i = 0; i < k; ++i) chunks += (n[i] + WS_PER_BLOCK - 1) / WS_PER_BLOCK;
+    a.reps = (int)((chunks + 511) / 512);
+    if (a.reps < 1) a.reps = 1;
+    const long per_block = (long)WS_PER_BLOCK * a.reps;
     int blk = 0;
     for (int i = 0; i < k; ++i) {
         MMB_REQUIRE(n[i] >= 0 && (!x || x[i]) && (!dx || dx[i]), "mmb_weighted_sums: null tensor %d", i);
@@ -102,7 +115,7 @@ static int fill_args(WSumArgs& a, const float* const* x, const float* const* w, 
         a.dx[i] = dx ? dx[i] : nullptr;
         a.n[i] = n[i];
         a.blk_begin[i] = blk;
-        blk += (int)((n[i] + WS_PER_BLOCK - 1) / WS_PER_BLOCK);
+        blk += (int)((n[i] + per_block - 1) / per_block);
     }
     a.blk_begin[k] = blk;
     return MMB_OK;
