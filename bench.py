@@ -192,7 +192,8 @@ def attention_roofline(a, prof, B, T, Ma, Mi, D, fused, steps=None):
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath))
-            if t.get("source_hash") == source_hash() and a.config in t:
+            # (the PMC passes run the full-length, dropout-free workload of the configuration: other variants quote no traffic)
+            if t.get("source_hash") == source_hash() and a.config in t and not a.ragged and not a.fresh_lengths and a.drop_prob == 0.0 and not a.batch:
                 traffic = sum(t[a.config].get(sym, 0.0) * n for sym, n in sym_launches.items())
                 traffic_note = "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per step over the six kernels, separate rocprofv3 --pmc passes of this command (tools/run_round_profiles.sh)"
         except Exception:

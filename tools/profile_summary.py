@@ -141,4 +141,4 @@ def pmc(d, cfg="cfg2"):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "timeline": timeline}[sys.argv[1]](sys.argv[2])
+    {"stats": stats, "pmc": pmc, "timeline": timeline}[sys.argv[1]](*sys.argv[2:])      # pmc DIR [config name]
