@@ -170,8 +170,17 @@ __device__ __forceinline__ void side_from_regs(float (&x)[KT][8], side_t& sd, fl
 #pragma unroll
         for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(x[kt][j]));
     amax = kg_allmax(amax);
+    // NaN / infinity among the wave's 16 rows (x - x is NaN exactly there): poison the scale, so that the products come out NaN
+    // as in the reference instead of the clamped finite values the split would carry (wave-wide: a non-finite row of a sample
+    // spreads over the whole sample through the column softmax anyway)
+    bool badl = false;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) badl = badl || !((x[kt][j] - x[kt][j]) == 0.f);
+    const bool bad = __any(badl);
     const float s = a_pow2_scale(amax);
-    inv_n = amax > 0.f ? 1.0f / s : 0.f;
+    inv_n = bad ? __builtin_nanf("") : (amax > 0.f ? 1.0f / s : 0.f);
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
@@ -657,6 +666,10 @@ __device__ __forceinline__ float wave_allsum(float v) {
 }
 // lane c (< 8 KT) holds features 4c..4c+3 of `row`; amax = the row's max |x| (wave-uniform)
 __device__ __forceinline__ void store_split_row(char* planes_b, float* inv_row, int row, int c, f4 x, float amax) {
+    // a NaN / infinity anywhere in the row (x - x != 0 exactly for those) poisons the row's inverse scale: every product the
+    // row takes part in then comes out NaN, as in the reference, instead of the clamped finite value the split would carry
+    const f4 z = x - x;
+    const bool bad = __any(!(z.x == 0.f && z.y == 0.f && z.z == 0.f && z.w == 0.f));
     const float s = a_pow2_scale(amax);
     if (c < 8 * KT) {
         x = x * s;
@@ -672,7 +685,7 @@ __device__ __forceinline__ void store_split_row(char* planes_b, float* inv_row, 
         *reinterpret_cast<half4*>(d) = h0;
         *reinterpret_cast<half4*>(d + 1024) = h1;
     }
-    if (c == 0) *inv_row = amax > 0.f ? 1.0f / s : 0.f;
+    if (c == 0) *inv_row = bad ? __builtin_nanf("") : (amax > 0.f ? 1.0f / s : 0.f);
 }
 // fp32 value of features 4c..4c+3 of a planes row: x = (h0 + h1) * inv
 __device__ __forceinline__ f4 planes_row_f32(const char* planes_b, const float* inv_b, int row, int c) {

@@ -245,6 +245,29 @@ def test_attention_wide_dynamic_range_vs_float64():
         assert rel.max().item() <= 1e-4, f"{nm}: row-relative error {rel.max().item():.2e}"
 
 
+def test_attention_propagates_non_finite_inputs():
+    """the two-term split clamps its operands, which would turn a NaN / infinity in `text` or `modality` into a
+    finite value inside the attention where the reference propagates NaN.  A non-finite element now poisons its row's scale:
+    the outputs that depend on that row are NaN as in the reference (oracle), the verbatim copy of text aside."""
+    from mmbidaf_amd import functional as MF
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    B, T, M, D = 2, 40, 24, 200
+    ps = [torch.randn(D, 1, generator=g) * 0.1, torch.randn(D, 1, generator=g) * 0.1, torch.randn(1, 1, D, generator=g) * 0.1, torch.zeros(1)]
+    tm, mm = torch.ones(B, T, dtype=torch.bool), torch.ones(B, M, dtype=torch.bool)
+    for which, val in (("text", float("nan")), ("mod", float("inf"))):
+        text, mod = torch.randn(B, T, D, generator=g), torch.randn(B, M, D, generator=g)
+        (text if which == "text" else mod)[0, 5, 17] = val
+        out = MF.bidaf_attention(text.to(d), mod.to(d), tm.to(d), mm.to(d), *[p_.to(d) for p_ in ps]).cpu()
+        ref = O.bidaf_attention(text, mod, tm, mm, *ps)
+        # sample 1 is untouched and finite on both sides; in sample 0 the attended quarters agree in WHERE they are non-finite
+        assert torch.isfinite(out[1]).all() and torch.isfinite(ref[1]).all()
+        close(out[1], ref[1], f"clean sample beside a non-finite one ({which})")
+        bad_got, bad_ref = ~torch.isfinite(out[0, :, D:]), ~torch.isfinite(ref[0, :, D:])
+        assert bad_ref.any() and bad_got.any(), "the reference propagates the non-finite value; so must the kernels"
+        assert (bad_got | ~bad_ref).all(), f"{which}: finite values where the reference has NaN"
+
+
 def test_attention_full_size_properties():
     """cfg2 size (B=32, T=400, M=256, D=200): size-independent properties instead of the oracle."""
     B, T, M, D = 32, 400, 256, 200
