@@ -33,6 +33,7 @@ ATT_BWD_KERNELS = ["att_bwd_pre", "att_bwd_j1", "att_bwd_i"]           # prologu
 ATT_KERNELS = ATT_FWD_KERNELS + ATT_BWD_KERNELS
 ATT_GROUPS = ["att_fwd", "att_bwd"]      # one event pair around ALL kernels of a fused forward / backward call
 ALL_KERNELS = ATT_GROUPS + ATT_KERNELS + ["gemm", "lstm_rec_fwd", "lstm_rec_bwd"]
+LSTM_GEMM_GROUPS = ["gemm", "lstm_rec_fwd", "lstm_rec_bwd"]   # general-width path: plane GEMMs + the per-step fused kernels (whole time loops)
 
 
 def source_hash():
@@ -162,6 +163,32 @@ def cpu_baseline(region, cfg, ragged):
             "sample": f"{n} fwd+bwd steps of the same workload at the full batch {B_s} after 1 warm-up ({dt:.1f} s), "
                       f"oracle HotRegionCPU = torch {torch.__version__} CPU packed nn.LSTM + bmm/softmax attention, "
                       f"{threads} threads on {cpu}; the reference's own Python does not travel to this box"}
+
+
+def lstm_gemm_roofline(prof, B, T, Ma, Mi, H, steps, dtype):
+    """Configuration 5 (H = 512: BASELINE.json names "MFMA LSTM gate GEMMs"): the binding roofline is the matrix pipe.  FLOPs of
+    every gate GEMM of a step -- hoisted input projections, the recurrent products inside the per-step fused kernels, input and
+    weight gradients -- over the time of the kernels that run them (plane GEMMs + the fused-step time loops, HIP events on the
+    launch stream; the time loops include their launch-to-launch gaps, which is what bounds them)."""
+    steps = max(steps, 1)
+    flops = 0.0
+    #            rows            I      layers/dirs
+    for rows, I in ((B * T, H), (B * Ma, H), (B * Mi, H),            # input encoders (L = 1)
+                    (B * T, 8 * H), (B * T, 2 * H),                  # modelling encoder text<->audio, layers 0 and 1
+                    (B * T, 8 * H), (B * T, 2 * H)):                 # modelling encoder text<->image
+        per_dir_fwd = 2.0 * rows * (I + H) * 4 * H                   # x.W_ih^T and h.W_hh^T
+        flops += 2 * per_dir_fwd * 3                                 # two directions; backward = 2 x forward (d_x / dh and the weight gradients)
+    us = {k: prof[k][0] / steps * 1e3 for k in LSTM_GEMM_GROUPS}
+    tot = sum(us.values())
+    peak = F16_MFMA_PEAK_TF
+    ach = flops / (tot * 1e-6) / 1e12 if tot else 0.0
+    return {"bound": "mfma", "kernel": "LSTM gate GEMMs at H = 512: hoisted projections and gradient GEMMs (operand-plane GEMM kernels) + the "
+                                       "recurrent products inside the per-step fused kernels (one launch per time step; their launch gaps are "
+                                       "inside the bracket)",
+            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "flops_per_step": flops, "us_per_step": {k: round(v, 1) for k, v in us.items()},
+            "arithmetic": "one v_mfma_f32_16x16x32_bf16 per product (bf16 operands)" if dtype == "bf16" else
+                          "three v_mfma_f32_16x16x32_f16 per product (fp32-accurate two-term split): the figure counts the fp32-equivalent FLOPs once"}
 
 
 def attention_roofline(a, prof, B, T, Ma, Mi, D, fused, steps=None):
@@ -315,7 +342,8 @@ def main():
     for _ in range(a.warmup):
         step()
     # default: two event pairs per attention call (36 events per step around every kernel cost 4 % of the step)
-    timed = ALL_KERNELS if a.profile_all else ATT_GROUPS
+    fused_att = D <= _lib.ATT_MAX_D
+    timed = ALL_KERNELS if a.profile_all else (ATT_GROUPS if fused_att else LSTM_GEMM_GROUPS)
     if graph is not None:
         timed = []          # the event pairs of the timing hook cannot be recorded inside a replayed graph: see below
     fence()
@@ -332,7 +360,7 @@ def main():
         # step is issued eagerly a few times right after the timed region, with the library's event pairs around the grouped
         # attention calls (same process, same tensors, same kernels)
         prof_steps = min(max(a.steps, 5), 20)
-        timed = ATT_GROUPS
+        timed = ATT_GROUPS if fused_att else LSTM_GEMM_GROUPS
         for p in params:
             p.grad = None
         for x in xs:
@@ -377,13 +405,14 @@ def main():
                                    f"fwd+bwd"
                                    f"{' + bucketed gradient all-reduce (sum)' if world > 1 else ''}",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
-            "roofline": attention_roofline(a, prof, B, T, Ma, Mi, D, fused=D <= _lib.ATT_MAX_D, steps=prof_steps) if timed else None,
+            "roofline": (attention_roofline(a, prof, B, T, Ma, Mi, D, fused=True, steps=prof_steps) if fused_att else
+                         lstm_gemm_roofline(prof, B, T, Ma, Mi, H, prof_steps, dtype)) if timed else None,
         }
         if graph is not None:
             out["config"]["launch"] = ("hipGraph replay of one captured fwd+bwd step (all launches of the step on the GPU's queues, one graph "
                                        "launch per step from the host)" + ("; flat gradient all-reduce after each replay" if world > 1 else ""))
             if out["roofline"] is not None:
-                out["roofline"]["timing_note"] = (f"kernel times: HIP events around the grouped attention calls over {prof_steps} EAGER steps of the same "
+                out["roofline"]["timing_note"] = (f"kernel times: HIP events around the {'grouped attention calls' if fused_att else 'GEMM launches and the recurrence time loops'} over {prof_steps} EAGER steps of the same "
                                                   "workload issued right after the timed region (events cannot bracket kernels inside a replayed graph)")
         else:
             out["config"]["launch"] = "eager: every step issued from Python" + (f" ({graph_note})" if graph_note else "")
