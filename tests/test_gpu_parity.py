@@ -245,6 +245,58 @@ def test_attention_wide_dynamic_range_vs_float64():
         assert rel.max().item() <= 1e-4, f"{nm}: row-relative error {rel.max().item():.2e}"
 
 
+def test_attention_grouped_call_matches_single_calls_and_the_oracle():
+    """mmb_bidaf_group_fwd / _bwd (one launch per stage for up to 4 attentions): a group of FOUR attentions -- two sharing
+    one text tensor (shared operand planes, like models.py:131-132), one with its own text of the same length, one with a
+    DIFFERENT text length -- against the oracle and, bit for bit in the forward, against four single calls."""
+    from mmbidaf_amd import functional as MF
+    d = dev()
+    g = torch.Generator().manual_seed(41)
+    B, D = 3, 200
+    Ts, Ms = [70, 70, 70, 33], [40, 9, 64, 129]
+    text_shared = torch.randn(B, 70, D, generator=g)
+    texts = [text_shared, text_shared, torch.randn(B, 70, D, generator=g), torch.randn(B, 33, D, generator=g)]
+    mods = [torch.randn(B, m, D, generator=g) for m in Ms]
+    tlens = [[70, 41, 70], [70, 41, 70], [13, 70, 55], [33, 33, 7]]
+    mlens = [[40, 40, 3], [9, 1, 5], [64, 20, 64], [129, 77, 100]]
+    params = [[torch.randn(D, 1, generator=g) * 0.1, torch.randn(D, 1, generator=g) * 0.1, torch.randn(1, 1, D, generator=g) * 0.1,
+               torch.randn(1, generator=g) * 0.1] for _ in range(4)]
+    cots = [torch.randn(B, t, 4 * D, generator=g) for t in Ts]
+    mask = lambda n, lens: torch.arange(n).unsqueeze(0) < torch.tensor(lens).unsqueeze(1)
+
+    def leaves():
+        ts = text_shared.clone().to(d).requires_grad_(True)
+        tx = [ts, ts, texts[2].clone().to(d).requires_grad_(True), texts[3].clone().to(d).requires_grad_(True)]
+        md = [m.clone().to(d).requires_grad_(True) for m in mods]
+        ps = [[p_.clone().to(d).requires_grad_(True) for p_ in pk] for pk in params]
+        return tx, md, ps
+    tx, md, ps = leaves()
+    probs = [(tx[k], md[k], mask(Ts[k], tlens[k]).to(d), mask(Ms[k], mlens[k]).to(d), *ps[k]) for k in range(4)]
+    outs = MF.bidaf_attention_group(probs)
+    torch.autograd.backward(outs, [c.to(d) for c in cots])
+    tx1, md1, ps1 = leaves()
+    outs1 = [MF.bidaf_attention(tx1[k], md1[k], mask(Ts[k], tlens[k]).to(d), mask(Ms[k], mlens[k]).to(d), *ps1[k]) for k in range(4)]
+    torch.autograd.backward(outs1, [c.to(d) for c in cots])
+    for k in range(4):
+        assert torch.equal(outs[k], outs1[k]), f"grouped forward {k} differs from the single call"
+    # oracle
+    rt = text_shared.clone().requires_grad_(True)
+    rtx = [rt, rt, texts[2].clone().requires_grad_(True), texts[3].clone().requires_grad_(True)]
+    rmd = [m.clone().requires_grad_(True) for m in mods]
+    rps = [[p_.clone().requires_grad_(True) for p_ in pk] for pk in params]
+    routs = [O.bidaf_attention(rtx[k], rmd[k], mask(Ts[k], tlens[k]), mask(Ms[k], mlens[k]), *rps[k]) for k in range(4)]
+    torch.autograd.backward(routs, cots)
+    for k in range(4):
+        close(outs[k], routs[k].detach(), f"group out {k}")
+        close(md[k].grad, rmd[k].grad, f"group d_mod {k}")
+        close(md1[k].grad, rmd[k].grad, f"single d_mod {k}")
+        for n, a, b in zip(("w_t", "w_m", "w_tm"), ps[k], rps[k]):
+            close(a.grad, b.grad, f"group d_{n} {k}")
+    for k in (0, 2, 3):      # tx[0] is tx[1]: its gradient is the sum over both attentions
+        close(tx[k].grad, rtx[k].grad, f"group d_text {k}")
+        close(tx1[k].grad, rtx[k].grad, f"single d_text {k}")
+
+
 def test_attention_propagates_non_finite_inputs():
     """the two-term split clamps its operands, which would turn a NaN / infinity in `text` or `modality` into a
     finite value inside the attention where the reference propagates NaN.  A non-finite element now poisons its row's scale:
