@@ -342,6 +342,13 @@ int mmb_set_gemm_mode(int mode);
 int mmb_set_precision(int mode);
 int mmb_get_precision(void);
 
+/* Hidden sizes above MMB_LSTM_MAX_H whose layer call fits the chip with one workgroup per CU run their whole time loop as
+ * ONE persistent launch (csrc/lstm_fs.hip: the workgroups of a chain meet at a counter after every step; every spin is
+ * bounded).  A launch whose bounded spin gave up -- its workgroups were not resident together -- leaves invalid results,
+ * sets a host-visible word, and the NEXT LSTM call of the process returns MMB_ERR_HIP.  This reads that word: 0 on a
+ * healthy process.  MMB_LSTM_FS_PERSIST=0 in the environment selects the launch-per-step kernels. */
+int mmb_lstm_persist_timeouts(void);
+
 int mmb_gemm_f32(const float* A, const float* Bm, float* C, const float* bias,
                  int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb, int accumulate,
                  int device, void* stream);

@@ -89,6 +89,7 @@ SIGNATURES = {
     "mmb_set_gemm_mode": (c_i, [c_i]),
     "mmb_set_precision": (c_i, [c_i]),
     "mmb_get_precision": (c_i, []),
+    "mmb_lstm_persist_timeouts": (c_i, []),
     "mmb_bilstm_ws_bytes": (ctypes.c_size_t, [c_i] * 5),
     "mmb_gemm_nt_planes": (c_i, [c_f] * 4 + [c_i] * 3 + [c_f, ctypes.c_size_t, c_i, c_f]),
     "mmb_weighted_sums_ws_bytes": (ctypes.c_size_t, [ctypes.POINTER(ctypes.c_long), c_i]),

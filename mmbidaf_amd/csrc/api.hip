@@ -150,3 +150,4 @@ extern "C" int mmb_set_precision(int mode) {
     return MMB_OK;
 }
 extern "C" int mmb_get_precision(void) { return mmb::precision_mode(); }
+extern "C" int mmb_lstm_persist_timeouts(void) { return mmb::lstm_fs_timeouts(); }

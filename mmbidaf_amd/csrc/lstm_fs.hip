@@ -424,6 +424,446 @@ __global__ __launch_bounds__(512) void lstm_fs_bwd_kernel(const FsBwdArgs args, 
     }
 }
 
+// ------------------------------------------------------------------------------------------ persistent form
+// The whole time loop of a layer call in ONE launch: every workgroup keeps its W_hh fragments in registers for all T steps
+// and the workgroups of one (encoder, direction) chain meet after every step at a counter in global memory.  Used when the
+// grid fits the chip with one workgroup per CU (cfg5: 2 x 3 chains x 32 workgroups = 192 of 256 CUs); everything else
+// takes the launch-per-step kernels above.  What it removes per step: the kernel boundary, the W_hh fragment reads
+// (half of a step's operand bytes), the dependent len -> gx / c_prev / dc loads (gx is prefetched one step ahead, c and
+// dc never leave their thread's registers) and the store drain at kernel end.
+//
+// Hand-off of the recurrent operand between the workgroups of a chain (cdna_hip_programming.md Guideline 16, the
+// sc1-load form of MI355X_MICROARCH.md "Valid forms", third table row, matched in every cell):
+//   * payload: each workgroup stages its slice of the next step's operand in LDS and writes it with 16-B `sc1`
+//     (write-through) buffer stores, every 128-B line whole by one store instruction of one wave (the exchange layout is
+//     slice-major: a workgroup's bytes are contiguous);
+//   * every storing wave then runs `s_waitcnt vmcnt(0)`, the workgroup meets at a barrier, ONE lane adds 1 to the chain's
+//     counter (agent-scope atomic; hipMalloc memory, zeroed by a memset node before every launch);
+//   * consumer: ONE lane polls the counter with a relaxed agent-scope (`global_load_dword sc1`) load until all workgroups
+//     of the chain have arrived s times, a workgroup barrier follows, then EVERY load of the handed-off bytes is a
+//     `buffer_load_dwordx4 ... sc1` to registers (no plain load ever touches those bytes: no stale L1 line can be hit).
+//   The BPTT's running maximum (an agent-scope atomicMax by every wave, before that wave's drain) is read back the same way.
+// Nothing depends on workgroup placement or dispatch order; the XCD-pinning of fs_decode is speed only.  All workgroups of
+// a chain must be resident together: the host launches this form only when grid <= number of CUs, and every spin is
+// bounded (FS_SPIN_TICKS of the 100 MHz wall clock): a workgroup that gives up sets the time-out word (host-visible,
+// checked by the next library call: MMB_ERR_HIP), poisons nothing and leaves -- its chain's other workgroups then time
+// out as well, so the grid always drains.
+constexpr unsigned long long FS_SPIN_TICKS = 300000000ull;   // 3 s
+constexpr int FS_PART_BYTES = 8 * 64 * 17 * 16;             // forward partial tiles
+constexpr int FS_CNT_STRIDE = 32;                           // unsigneds between two chains' counters (128 B)
+
+__device__ __forceinline__ void fs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// thread 0 polls, everybody learns the outcome behind the barrier that the hand-off needs anyway
+__device__ __forceinline__ bool fs_chain_wait(unsigned* cnt, unsigned target, unsigned* tmo, volatile int* lflag) {
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        const unsigned long long t0 = wall_clock64();
+        for (unsigned spins = 1; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins & 255u) == 0 && wall_clock64() - t0 > FS_SPIN_TICKS) {
+                __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ok = 0;
+                break;
+            }
+        }
+        *lflag = ok;
+    }
+    fs_lds_barrier();
+    return *lflag != 0;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fs_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// forward: workgroup = 16 units x 4 gates x 64 samples as in lstm_fs_fwd_kernel; wave w keeps the W_hh fragments of k
+// tiles w and w + 8 (H <= 512) in registers.  Exchange layout of h (per direction, step parity, plane):
+// [sample block][slice of 16 units][sample 64][unit 16] halfs -- the 2 KB a workgroup writes per plane are contiguous.
+template <int NPL>
+__global__ __launch_bounds__(512) void lstm_fs_fwd_persist_kernel(const FsFwdArgs args, unsigned* __restrict__ cnt_base,
+                                                                   unsigned* __restrict__ tmo) {
+    constexpr int NQ = 2, KT = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int chain, sl;
+    if (!fs_decode(2 * args.n, chain, sl)) return;
+    const int slice = sl % args.nslices, sblk = sl / args.nslices;
+    const FsFwdProb& P = args.p[chain >> 1];
+    const int dir = chain & 1;
+    const int H = P.H, T = P.T, nkt = args.nkt;
+    const int nsbp = (P.B + 63) >> 6;
+    if (sblk >= nsbp) return;                       // (not one of the chain's arrivals)
+    const unsigned nwg = (unsigned)(args.nslices * nsbp);
+    unsigned* cnt = cnt_base + chain * FS_CNT_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    f4* part = reinterpret_cast<f4*>(smem);                                   // [wave][sample 64][17] quads
+    char* stage = smem + FS_PART_BYTES;                                       // [plane][sample 64][unit 16] halfs
+    volatile int* lflag = reinterpret_cast<volatile int*>(smem + FS_PART_BYTES + 4096);
+    for (int i = tid; i < 1024; i += 512) reinterpret_cast<unsigned*>(stage)[i] = 0u;   // padding units stay 0 for good
+
+    // W_hh fragments of this wave's k tiles: loop-invariant
+    u4 a[KT][4][NPL];
+    {
+        const char* A = P.wp[dir] + fs_off(64 * slice + r, g, nkt, NPL);
+        const size_t rbA = (size_t)nkt * NPL * 1024;
+#pragma unroll
+        for (int q = 0; q < KT; ++q) {
+            const int kt = wave + 8 * q;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    a[q][i][pl] = kt < nkt ? *reinterpret_cast<const u4*>(A + i * rbA + (size_t)kt * NPL * 1024 + pl * 1024) : u4{0u, 0u, 0u, 0u};
+        }
+    }
+    // this thread's two (unit, sample) pairs: the same ones at every step, so c stays in a register
+    int e_len[NQ], e_u[NQ], e_b[NQ];
+    f4 e_winv[NQ], gx_nx[NQ];
+    float c_st[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int pair = tid + 512 * q;
+        e_u[q] = 16 * slice + (pair & 15);
+        e_b[q] = 64 * sblk + (pair >> 4);
+        e_len[q] = (e_u[q] < H && e_b[q] < P.B) ? min(max(P.len[e_b[q]], 0), T) : 0;
+        e_winv[q] = f4{1.f, 1.f, 1.f, 1.f};
+        if (NPL == 2 && e_len[q] > 0) e_winv[q] = *reinterpret_cast<const f4*>(P.winv[dir] + 4 * e_u[q]) * (1.0f / FS_HSCALE);
+        c_st[q] = 0.f;
+        gx_nx[q] = f4{0.f, 0.f, 0.f, 0.f};
+        if (0 < e_len[q]) {
+            const size_t row = (size_t)e_b[q] * T + (dir ? e_len[q] - 1 : 0);
+            gx_nx[q] = *reinterpret_cast<const f4*>(P.gx + (row * 2 + dir) * 4 * H + (size_t)e_u[q] * 4);
+        }
+    }
+    const unsigned pstride = (unsigned)nsbp * 2 * nkt * 2048;                 // bytes of one plane of the exchange buffer
+    const unsigned my_slab = (unsigned)(sblk * 2 * nkt + slice) * 2048;       // this workgroup's 2 KB in a plane
+    // operand fragment of k tile `wave` (+ 8 q: 16 slices further), lane (sample r, octet g): 16 B of slice 2 kt + (g >> 1)
+    const unsigned hoff = ((unsigned)(sblk * 2 * nkt + 2 * wave + (g >> 1)) * 64 + r) * 32 + (g & 1) * 16;
+    fs_lds_barrier();                                                         // the zeroed stage
+
+    for (int s = 0; s < T; ++s) {
+        if (s > 0 && !fs_chain_wait(cnt, (unsigned)s * nwg, tmo, lflag)) return;
+        f4 gx_cur[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) gx_cur[q] = gx_nx[q];
+        // next step's input projection, requested a step ahead (HBM latency).  vmcnt retires in order, so the request sits
+        // where nothing younger is waited for soon: behind the matrix products in the waves that do not publish h, behind
+        // the arrival in those that do (their drain would wait for it)
+        auto prefetch_gx = [&]() {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (s + 1 < e_len[q]) {
+                    const size_t row = (size_t)e_b[q] * T + (dir ? e_len[q] - 2 - s : s + 1);
+                    gx_nx[q] = *reinterpret_cast<const f4*>(P.gx + (row * 2 + dir) * 4 * H + (size_t)e_u[q] * 4);
+                }
+        };
+        const bool storing = tid < 128 * NPL;      // whole waves: 2 per plane
+        f4 c[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {   // h_{-1} = 0
+            const __amdgpu_buffer_rsrc_t hb = fs_rsrc(P.hp[dir][(s + 1) & 1], pstride * NPL);
+            // (a k tile beyond nkt: zero W_hh fragments, and an offset beyond num_records, where a buffer load returns 0
+            //  without touching memory: no branch, all loads of the step in flight together)
+            constexpr int QB = NPL == 2 ? 1 : KT;        // k tiles per batch of loads (registers: two planes -> one at a time)
+#pragma unroll
+            for (int q0 = 0; q0 < KT; q0 += QB) {
+                u4 b[QB][4][NPL];
+#pragma unroll
+                for (int q = 0; q < QB; ++q) {
+                    const unsigned o = hoff + (wave + 8 * (q0 + q) < nkt ? (unsigned)(q0 + q) * (16 * 64 * 32) : 0xF0000000u);
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) b[q][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(hb, o + j * 512, pl * pstride, 16);   // sc1
+                }
+#pragma unroll
+                for (int q = 0; q < QB; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) c[i][j] = fs_prod<NPL>(a[q0 + q][i], b[q][j], c[i][j]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[(wave * 64 + 16 * j + r) * 17 + 4 * i + g] = c[i][j];
+        if (!storing) prefetch_gx();
+        fs_lds_barrier();
+        f4 o_g[NQ];
+        float o_c[NQ], o_h[NQ];
+        bool e_on[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int pair = tid + 512 * q, ul = pair & 15, bl = pair >> 4;
+            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 8; ++w) acc += part[(w * 64 + bl) * 17 + ul];
+            e_on[q] = s < e_len[q];
+            if (!e_on[q]) continue;
+            const f4 pre = acc * e_winv[q] + gx_cur[q];
+            const float gi = sigmoidf_(pre.x), gf = sigmoidf_(pre.y), gg = tanhf_(pre.z), go = sigmoidf_(pre.w);
+            const float cc = fmaf(gf, c_st[q], gi * gg);
+            const float h = go * tanhf_(cc);
+            c_st[q] = cc;
+            o_g[q] = f4{gi, gf, gg, go};
+            o_c[q] = cc;
+            o_h[q] = h;
+            char* d = stage + bl * 32 + ul * 2;
+            if (NPL == 2) {
+                const float hv = h * FS_HSCALE;
+                const _Float16 h0 = (_Float16)hv;
+                *reinterpret_cast<_Float16*>(d) = h0;
+                *reinterpret_cast<_Float16*>(d + 2048) = (_Float16)(hv - (float)h0);
+            } else {
+                *reinterpret_cast<__bf16*>(d) = (__bf16)h;
+            }
+        }
+        fs_lds_barrier();
+        auto store_outputs = [&]() {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (!e_on[q]) continue;
+                const int u = e_u[q], b = e_b[q];
+                const size_t row = (size_t)b * T + (dir ? e_len[q] - 1 - s : s);
+                *reinterpret_cast<f4*>(P.gates + (row * 2 + dir) * 4 * H + (size_t)u * 4) = o_g[q];
+                P.cs[row * 2 * H + dir * H + u] = o_c[q];
+                P.y[row * 2 * H + dir * H + u] = o_h[q];
+                if (s == e_len[q] - 1) {
+                    const size_t st = ((size_t)dir * P.B + b) * H + u;
+                    P.h_n[P.hn_pos ? ((size_t)P.hn_pos[b] * 2 + dir) * H + u : st] = o_h[q];
+                    P.c_n[st] = o_c[q];
+                }
+            }
+        };
+        if (storing) {
+            const int pl = tid >> 7, i = tid & 127;
+            const u4 v = *reinterpret_cast<const u4*>(stage + pl * 2048 + i * 16);
+            const __amdgpu_buffer_rsrc_t hn = fs_rsrc(P.hp[dir][s & 1], pstride * NPL);
+            __builtin_amdgcn_raw_buffer_store_b128(v, hn, pl * pstride + my_slab + i * 16, 0, 16);   // sc1: write-through
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            store_outputs();
+        }
+        fs_lds_barrier();
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (storing) {
+            store_outputs();
+            prefetch_gx();
+        }
+    }
+}
+
+// BPTT: workgroup = 16 MU units x 16 NT samples (MU NT = 4: 1024 (unit, sample) pairs, two per thread); K = 4H split over
+// the 8 waves, wave w keeps the W_hh^T fragments of k tiles w, w + 8, ... (up to 8: H <= 512) in registers for all T steps.
+// Fewer samples per workgroup = fewer bytes of the previous step's d_a to pull per workgroup and step (every workgroup
+// needs ALL 4H gate gradients of its samples: 16 NT x 4H halfs per plane), at MU x the W_hh^T registers.
+// Exchange layout of d_a (per direction, step parity, plane): [sample block][k tile][sample 16 NT][32 k] halfs; the 2 MU k
+// tiles a workgroup owns are contiguous (8 KB per plane), a 128-B line holds two samples of one k tile.
+// The running cell-state gradient dc and c_t stay in their thread's registers; d_y / gates / c_prev of the next step are
+// requested behind the arrival.  Scale of the fp16 planes as in fs_da_scale, with the step maximum read back by an
+// agent-scope atomic load behind the chain barrier.
+template <int NPL, int MU, int NT>
+__global__ __launch_bounds__(512) void lstm_fs_bwd_persist_kernel(const FsBwdArgs args, unsigned* __restrict__ cnt_base,
+                                                                   unsigned* __restrict__ tmo) {
+    constexpr int UW = 16 * MU, SWB = 16 * NT, KTW = 8, ROWS = 512 / UW, KB = 4;   // KB: k tiles per batch of operand loads
+    constexpr int PARTF_BYTES = 8 * SWB * (UW + 1) * 4, STAGE_PL = 2 * MU * SWB * 64;   // = 8 KB per plane
+    static_assert(MU * NT == 4 && KTW % KB == 0, "1024 pairs per workgroup");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int chain, sl;
+    if (!fs_decode(2 * args.n, chain, sl)) return;
+    const int slice = sl % args.nslices, sblk = sl / args.nslices;
+    const FsBwdProb& P = args.p[chain >> 1];
+    const int dir = chain & 1;
+    const int H = P.H, T = P.T, nkt = args.nkt4;
+    const int nsbp = (P.B + SWB - 1) / SWB;
+    if (sblk >= nsbp) return;
+    const unsigned nwg = (unsigned)(args.nslices * nsbp);
+    unsigned* cnt = cnt_base + chain * FS_CNT_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    float* partf = reinterpret_cast<float*>(smem);                            // [wave][sample SWB][UW + 1]
+    char* stage = smem + PARTF_BYTES;                                         // [plane][k tile 2 MU][sample SWB][32 k] halfs
+    volatile int* lflag = reinterpret_cast<volatile int*>(smem + PARTF_BYTES + NPL * STAGE_PL);
+    for (int i = tid; i < NPL * STAGE_PL / 4; i += 512) reinterpret_cast<unsigned*>(stage)[i] = 0u;
+
+    u4 a[KTW][MU][NPL];
+    {
+        const char* A = P.wtp[dir] + fs_off(UW * slice + r, g, nkt, NPL);
+        const size_t rb = (size_t)nkt * NPL * 1024;
+#pragma unroll
+        for (int q = 0; q < KTW; ++q) {
+            const int kt = wave + 8 * q;
+#pragma unroll
+            for (int i = 0; i < MU; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    a[q][i][pl] = kt < nkt ? *reinterpret_cast<const u4*>(A + i * rb + (size_t)kt * NPL * 1024 + pl * 1024) : u4{0u, 0u, 0u, 0u};
+        }
+    }
+    // this thread's two (unit, sample) pairs
+    const int ul = tid & (UW - 1), u = UW * slice + ul;
+    int e_len[2], e_b[2];
+    float dcs[2], c_t[2], n_dy[2], n_cp[2];
+    f4 n_g4[2];
+    const float wtinv = (NPL == 2 && u < H) ? P.wtinv[dir][u] : 1.0f;
+    // operands of step s for pair k: d_y (+ d_hn at the sample's first BPTT step), gates, c of the step before
+    auto request = [&](int k, int s) {
+        n_dy[k] = 0.f; n_cp[k] = 0.f; n_g4[k] = f4{0.f, 0.f, 0.f, 0.f};
+        const int len = e_len[k], b = e_b[k];
+        if (s < len) {
+            const int t = dir ? s : len - 1 - s;
+            const size_t row = (size_t)b * T + t;
+            n_dy[k] = P.d_y[row * 2 * H + dir * H + u];
+            if (s == 0 && P.d_hn) n_dy[k] += P.d_hn[P.hn_pos ? ((size_t)P.hn_pos[b] * 2 + dir) * H + u : ((size_t)dir * P.B + b) * H + u];
+            n_g4[k] = *reinterpret_cast<const f4*>(P.gates + (row * 2 + dir) * 4 * H + (size_t)u * 4);
+            const bool has_prev = dir ? (t + 1 < len) : (t > 0);
+            if (has_prev) n_cp[k] = P.cs[((size_t)b * T + (dir ? t + 1 : t - 1)) * 2 * H + dir * H + u];
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        e_b[k] = SWB * sblk + tid / UW + ROWS * k;
+        e_len[k] = (e_b[k] < P.B && u < H) ? min(max(P.len[e_b[k]], 0), T) : 0;
+        dcs[k] = 0.f;
+        c_t[k] = 0.f;
+        if (0 < e_len[k]) c_t[k] = P.cs[((size_t)e_b[k] * T + (dir ? 0 : e_len[k] - 1)) * 2 * H + dir * H + u];
+        request(k, 0);
+    }
+    const unsigned pstride = (unsigned)nsbp * nkt * SWB * 64;                 // bytes of one plane of the exchange buffer
+    const unsigned my_slab = ((unsigned)sblk * nkt + 2 * MU * slice) * SWB * 64;
+    const unsigned aoff = (((unsigned)sblk * nkt + wave) * SWB + r) * 64 + g * 16;   // fragment of k tile `wave`, lane (sample r, octet g)
+    float sc_prev = 1.0f;
+    const float bnd_y = NPL == 2 ? P.bound[0] : 0.f, bnd_h = NPL == 2 ? P.bound[1] : 0.f;   // written by the launches before this one
+    fs_lds_barrier();
+
+    for (int s = 0; s < T; ++s) {
+        if (s > 0 && !fs_chain_wait(cnt, (unsigned)s * nwg, tmo, lflag)) return;
+        float e_dy[2], e_cp[2];
+        f4 e_g4[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { e_dy[k] = n_dy[k]; e_cp[k] = n_cp[k]; e_g4[k] = n_g4[k]; }
+        float inv_prev = 1.0f, sc = 1.0f;
+        if (NPL == 2) {
+            const float y = bnd_y;
+            float ref = y + bnd_h;
+            if (s > 0) ref = fmaxf(__uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned*>(P.amax[dir] + (s - 1)), __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT)), y);
+            sc = fs_pow2_scale(ref, 5);
+            inv_prev = s > 0 ? 1.0f / sc_prev : 0.f;
+            sc_prev = sc;
+        }
+        f4 c[MU][NT];
+#pragma unroll
+        for (int i = 0; i < MU; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) c[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            const __amdgpu_buffer_rsrc_t ab = fs_rsrc(P.ap[dir][(s + 1) & 1], pstride * NPL);
+#pragma unroll
+            for (int q0 = 0; q0 < KTW; q0 += KB) {
+                u4 b[KB][NT][NPL];
+#pragma unroll
+                for (int q = 0; q < KB; ++q) {
+                    const unsigned o = aoff + (wave + 8 * (q0 + q) < nkt ? (unsigned)(q0 + q) * (8 * SWB * 64) : 0xF0000000u);
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) b[q][j][pl] = __builtin_amdgcn_raw_buffer_load_b128(ab, o + j * 1024, pl * pstride, 16);   // sc1
+                }
+#pragma unroll
+                for (int q = 0; q < KB; ++q)
+#pragma unroll
+                    for (int i = 0; i < MU; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) c[i][j] = fs_prod<NPL>(a[q0 + q][i], b[q][j], c[i][j]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MU; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) partf[(wave * SWB + 16 * j + r) * (UW + 1) + 16 * i + 4 * g + e] = c[i][j][e];
+        fs_lds_barrier();
+        float lmax = 0.f;
+        f4 o_da[2];
+        bool e_on[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int bl = tid / UW + ROWS * k;
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) acc += partf[(w * SWB + bl) * (UW + 1) + ul];
+            e_on[k] = s < e_len[k];
+            if (!e_on[k]) continue;
+            const float dh = (NPL == 2 ? acc * wtinv * inv_prev : acc) + e_dy[k];
+            const f4 g4 = e_g4[k];
+            const float c_prev = e_cp[k];
+            const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
+            const float tc = tanhf_(c_t[k]);
+            const float dc_t = fmaf(dh * go, 1.0f - tc * tc, dcs[k]);
+            const float da0 = dc_t * gg * gi * (1.0f - gi), da1 = dc_t * c_prev * gf * (1.0f - gf);
+            const float da2 = dc_t * gi * (1.0f - gg * gg), da3 = dh * tc * go * (1.0f - go);
+            o_da[k] = f4{da0, da1, da2, da3};
+            dcs[k] = dc_t * gf;
+            c_t[k] = c_prev;           // the next BPTT step's c_t
+            char* d = stage + ((ul >> 3) * SWB + bl) * 64 + (ul & 7) * 8;
+            if (NPL == 2) {
+                lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(da0), fabsf(da1)), fmaxf(fabsf(da2), fabsf(da3))));
+                const float v[4] = {da0 * sc, da1 * sc, da2 * sc, da3 * sc};
+                half4 h0, h1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x = fminf(fmaxf(v[q], -60000.0f), 60000.0f);
+                    const _Float16 hh = (_Float16)x;
+                    h0[q] = hh;
+                    h1[q] = (_Float16)(x - (float)hh);
+                }
+                *reinterpret_cast<half4*>(d) = h0;
+                *reinterpret_cast<half4*>(d + STAGE_PL) = h1;
+            } else {
+                const bf4 h0 = {(__bf16)da0, (__bf16)da1, (__bf16)da2, (__bf16)da3};
+                *reinterpret_cast<bf4*>(d) = h0;
+            }
+        }
+        if (NPL == 2) {   // before this wave's drain below: the maximum is read back by every workgroup of the chain next step
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+            if (lane == 0 && lmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(&P.amax[dir][s]), __float_as_uint(lmax));
+        }
+        fs_lds_barrier();
+        {
+            const __amdgpu_buffer_rsrc_t an = fs_rsrc(P.ap[dir][s & 1], pstride * NPL);
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                const u4 v = *reinterpret_cast<const u4*>(stage + pl * STAGE_PL + tid * 16);
+                // (the last slice may own k tiles beyond nkt: padding units, nothing to publish -- and no room for it)
+                if (2 * MU * slice + tid / (4 * SWB) < nkt)
+                    __builtin_amdgcn_raw_buffer_store_b128(v, an, pl * pstride + my_slab + tid * 16, 0, 16);   // sc1: write-through
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        fs_lds_barrier();
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (e_on[k]) {
+                const size_t row = (size_t)e_b[k] * T + (dir ? s : e_len[k] - 1 - s);
+                float* da = P.d_a + row * 8 * H + (size_t)dir * 4 * H + u;
+                da[0] = o_da[k].x;
+                da[(size_t)H] = o_da[k].y;
+                da[(size_t)2 * H] = o_da[k].z;
+                da[(size_t)3 * H] = o_da[k].w;
+            }
+            request(k, s + 1);
+        }
+    }
+}
+
 // out[0] = max(out[0], max |p[i]|)  (out pre-zeroed)
 __global__ __launch_bounds__(256) void lstm_fs_absmax_kernel(const float* __restrict__ p, long n, float* out) {
     float m = 0.f;
@@ -438,7 +878,8 @@ __global__ __launch_bounds__(256) void lstm_fs_absmax_kernel(const float* __rest
 static size_t fs_rup(size_t x) { return (x + 255) / 256 * 256; }
 static int fs_pad(int x, int a) { return (x + a - 1) / a * a; }
 
-struct FsFwdWs { size_t wp[2], winv[2], hp[2][2], total, zero_from; int nkt; };
+constexpr size_t FS_SYNC_BYTES = 2 * MMB_MAX_GROUP * FS_CNT_STRIDE * 4;   // one counter per chain, 128 B apart (problem 0's block is used)
+struct FsFwdWs { size_t wp[2], winv[2], sync, hp[2][2], total, zero_from; int nkt; };
 static FsFwdWs fs_fwd_layout(int B, int H) {
     FsFwdWs w{};
     w.nkt = fs_pad(H, 32) / 32;
@@ -447,12 +888,13 @@ static FsFwdWs fs_fwd_layout(int B, int H) {
     for (int d = 0; d < 2; ++d) { w.wp[d] = o; o += fs_rup(fs_planes_bytes(rows_p, w.nkt, 2)); }
     for (int d = 0; d < 2; ++d) { w.winv[d] = o; o += fs_rup((size_t)rows_p * 4); }
     w.zero_from = o;
+    w.sync = o; o += FS_SYNC_BYTES;
     for (int d = 0; d < 2; ++d)
         for (int q = 0; q < 2; ++q) { w.hp[d][q] = o; o += fs_rup(fs_planes_bytes(Bp, w.nkt, 2)); }
     w.total = o;
     return w;
 }
-struct FsBwdWs { size_t wtp[2], wtinv[2], bound, amax[2], dc, ap[2][2], total, zero_from; int nkt4; };
+struct FsBwdWs { size_t wtp[2], wtinv[2], sync, bound, amax[2], dc, ap[2][2], total, zero_from; int nkt4; };
 static FsBwdWs fs_bwd_layout(int B, int T, int H) {
     FsBwdWs w{};
     w.nkt4 = fs_pad(4 * H, 32) / 32;
@@ -461,6 +903,7 @@ static FsBwdWs fs_bwd_layout(int B, int T, int H) {
     for (int d = 0; d < 2; ++d) { w.wtp[d] = o; o += fs_rup(fs_planes_bytes(rows_p, w.nkt4, 2)); }
     for (int d = 0; d < 2; ++d) { w.wtinv[d] = o; o += fs_rup((size_t)rows_p * 4); }
     w.zero_from = o;
+    w.sync = o; o += FS_SYNC_BYTES;
     w.bound = o; o += 256;
     for (int d = 0; d < 2; ++d) { w.amax[d] = o; o += fs_rup((size_t)(T + 1) * 4); }
     w.dc = o; o += fs_rup((size_t)2 * B * H * 4);
@@ -471,6 +914,44 @@ static FsBwdWs fs_bwd_layout(int B, int T, int H) {
 }
 size_t lstm_fs_fwd_ws_bytes(int B, int H) { return fs_fwd_layout(B, H).total; }
 size_t lstm_fs_bwd_ws_bytes(int B, int T, int H) { return fs_bwd_layout(B, T, H).total; }
+
+// ---- persistent form: eligibility and the time-out word
+static int fs_persist_mode() {   // MMB_LSTM_FS_PERSIST=0: launch-per-step kernels only
+    static const int v = [] { const char* e = getenv("MMB_LSTM_FS_PERSIST"); return e ? atoi(e) : 1; }();
+    return v;
+}
+static int fs_num_cus() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int v = cus[dev & 63].load();
+    if (v == 0) {
+        hipDeviceProp_t pr;
+        v = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : -1;
+        cus[dev & 63].store(v);
+    }
+    return v;
+}
+// host-pinned, device-visible word a workgroup sets when a bounded spin gives up (never on a healthy run)
+static unsigned* fs_timeout_word() {
+    static unsigned* w = [] {
+        unsigned* p = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&p), 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return (unsigned*)nullptr;
+        *p = 0u;
+        void* dp = nullptr;      // (unified addressing: the same address; asked for rather than assumed)
+        if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || dp != static_cast<void*>(p)) return (unsigned*)nullptr;
+        return p;
+    }();
+    return w;
+}
+static int fs_check_timeout() {
+    unsigned* w = fs_timeout_word();
+    if (w && *reinterpret_cast<volatile unsigned*>(w) != 0u)
+        return fail(MMB_ERR_HIP, "lstm_fs: a persistent recurrence launch timed out at its per-step barrier (workgroups of a chain were not "
+                                 "resident together); its results are invalid.  MMB_LSTM_FS_PERSIST=0 selects the launch-per-step kernels");
+    return MMB_OK;
+}
+int lstm_fs_timeouts() { unsigned* w = fs_timeout_word(); return w ? (int)*reinterpret_cast<volatile unsigned*>(w) : -1; }
 
 // prep (W_hh planes, zeroed recurrent operand) + the time loop; lstm_big.hip does the packed-sequence post-processing
 int lstm_fs_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* ws, hipStream_t stream) {
@@ -501,6 +982,30 @@ int lstm_fs_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* ws, hipStream_t 
     }
     MMB_HIP(hipGetLastError());
     a.nslices = (H + 15) / 16;
+    if (fs_persist_mode() && a.nkt <= 16) {
+        // one launch for the whole time loop when every workgroup gets a CU of its own
+        const int nsb64 = (maxB + 63) / 64, slots_p = (2 * n + 7) & ~7;
+        const long grid_p = (long)slots_p * a.nslices * nsb64;
+        unsigned* tmo = fs_timeout_word();
+        if (tmo && grid_p <= fs_num_cus()) {
+            if (int rc = fs_check_timeout()) return rc;
+            a.nsb = nsb64;
+            constexpr int lds_p = FS_PART_BYTES + 4096 + 16;
+            auto kp = npl == 2 ? lstm_fs_fwd_persist_kernel<2> : lstm_fs_fwd_persist_kernel<1>;
+            static PerDeviceOnce attr_p[2];
+            if (attr_p[npl - 1].pending()) {
+                MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
+                attr_p[npl - 1].mark();
+            }
+            unsigned* cnt = reinterpret_cast<unsigned*>(ws[0] + fs_fwd_layout(d[0].B, H).sync);
+            {
+                ProfScope ps_(MMB_K_LSTM_REC_FWD, stream);
+                hipLaunchKernelGGL(kp, dim3((unsigned)grid_p), dim3(512), lds_p, stream, a, cnt, tmo);
+            }
+            MMB_HIP(hipGetLastError());
+            return MMB_OK;
+        }
+    }
     // 64 samples per workgroup; 32 (MMB_LSTM_FS_NS=2: twice the workgroups, each reading the W_hh slice again) measured
     // slower at cfg5 (50.8 vs 49.3 ms/step)
     static const int ns_env = [] { const char* e = getenv("MMB_LSTM_FS_NS"); return e ? atoi(e) : 0; }();
@@ -562,6 +1067,38 @@ int lstm_fs_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* ws, hipStream_t 
         maxB = max(maxB, p.B);
     }
     MMB_HIP(hipGetLastError());
+    if (fs_persist_mode() && a.nkt4 <= 64) {
+        // one launch for the whole time loop when every workgroup gets a CU of its own: 32 units x 32 samples per workgroup,
+        // 64 x 16 with one-plane (bf16) operands (MMB_LSTM_FS_PERSIST_MU=2 / 4 forces one)
+        static const int pmu_env = [] { const char* e = getenv("MMB_LSTM_FS_PERSIST_MU"); return e ? atoi(e) : 0; }();
+        const int pmu = pmu_env == 2 || pmu_env == 4 ? pmu_env : (npl == 1 ? 4 : 2);
+        const int pnt = 4 / pmu;
+        if (npl == 2 && pmu == 4) return fail(MMB_ERR_ARG, "MMB_LSTM_FS_PERSIST_MU=4 needs the bf16 mode (registers)");
+        const int slots_p = (2 * n + 7) & ~7;
+        const int psl = (H + 16 * pmu - 1) / (16 * pmu), psb = (maxB + 16 * pnt - 1) / (16 * pnt);
+        const long grid_p = (long)slots_p * psl * psb;
+        unsigned* tmo = fs_timeout_word();
+        if (tmo && grid_p <= fs_num_cus()) {
+            if (int rc = fs_check_timeout()) return rc;
+            a.nslices = psl;
+            a.nsb = psb;
+            const int lds_p = 8 * 16 * pnt * (16 * pmu + 1) * 4 + npl * 8192 + 16;
+            auto kp = npl == 2 ? lstm_fs_bwd_persist_kernel<2, 2, 2> : (pmu == 4 ? lstm_fs_bwd_persist_kernel<1, 4, 1> : lstm_fs_bwd_persist_kernel<1, 2, 2>);
+            static PerDeviceOnce attr_p[3];
+            const int ai = npl == 2 ? 0 : (pmu == 4 ? 1 : 2);
+            if (attr_p[ai].pending()) {
+                MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 32 * 65 * 4 + 2 * 8192 + 16));
+                attr_p[ai].mark();
+            }
+            unsigned* cnt = reinterpret_cast<unsigned*>(ws[0] + fs_bwd_layout(d[0].B, d[0].T, H).sync);
+            {
+                ProfScope ps_(MMB_K_LSTM_REC_BWD, stream);
+                hipLaunchKernelGGL(kp, dim3((unsigned)grid_p), dim3(512), lds_p, stream, a, cnt, tmo);
+            }
+            MMB_HIP(hipGetLastError());
+            return MMB_OK;
+        }
+    }
     a.nsb = (maxB + 63) / 64;
     // 32 units per workgroup unless that leaves fewer than ~192 workgroups (the XCDs the chains are pinned to hold 32 CUs each)
     static const int mu_env = [] { const char* e = getenv("MMB_LSTM_FS_MU"); return e ? atoi(e) : 0; }();

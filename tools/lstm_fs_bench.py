@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Time the general-size (H > 128) recurrence alone on the cfg5 encoder stage (3 encoders x 2 directions x B samples,
+H = 512): the persistent launch (default) or the launch-per-step kernels (MMB_LSTM_FS_PERSIST=0), through the library's
+event hook.    python tools/lstm_fs_bench.py [--B 64] [--H 512] [--Ts 400,256,64] [--bf16] [--iters 3]"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from mmbidaf_amd import _lib, functional as MF
+from mmbidaf_amd.encoding import RNNEncoder, encode_group
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--B", type=int, default=64)
+ap.add_argument("--H", type=int, default=512)
+ap.add_argument("--I", type=int, default=512)
+ap.add_argument("--Ts", default="400,256,64")
+ap.add_argument("--bf16", action="store_true")
+ap.add_argument("--iters", type=int, default=3)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+MF.set_precision("bf16" if a.bf16 else "fp32")
+Ts = [int(t) for t in a.Ts.split(",")]
+encs = [RNNEncoder(a.I, a.H, 1).to(dev) for _ in Ts]
+xs = [torch.randn(a.B, T, a.I, device=dev, requires_grad=True) for T in Ts]
+lens = [[T] * a.B for T in Ts]
+def run():
+    outs = encode_group(encs, xs, lens)
+    sum(o[0].sum() for o in outs).backward()
+t0 = time.time()
+run()
+torch.cuda.synchronize()
+print(f"first call {time.time() - t0:.2f} s; time-outs {_lib.load().mmb_lstm_persist_timeouts()}", flush=True)
+run()
+torch.cuda.synchronize()
+_lib.profile_enable(["lstm_rec_fwd", "lstm_rec_bwd"])
+for _ in range(a.iters): run()
+torch.cuda.synchronize()
+mode = "persistent" if os.environ.get("MMB_LSTM_FS_PERSIST", "1") != "0" else "per-step launches"
+for k in ("lstm_rec_fwd", "lstm_rec_bwd"):
+    ms, n, _ = _lib.profile_read(k)
+    print(f"{mode} {'bf16' if a.bf16 else 'fp32-accurate'} B={a.B} H={a.H}: {k}: {ms / a.iters:.3f} ms per layer call = {ms / a.iters * 1e3 / max(Ts):.2f} us/step (T={max(Ts)})")
+print("time-outs", _lib.load().mmb_lstm_persist_timeouts())
