@@ -167,9 +167,10 @@ def cpu_baseline(region, cfg, ragged):
 
 def lstm_gemm_roofline(prof, B, T, Ma, Mi, H, steps, dtype):
     """Configuration 5 (H = 512: BASELINE.json names "MFMA LSTM gate GEMMs"): the binding roofline is the matrix pipe.  FLOPs of
-    every gate GEMM of a step -- hoisted input projections, the recurrent products inside the per-step fused kernels, input and
-    weight gradients -- over the time of the kernels that run them (plane GEMMs + the fused-step time loops, HIP events on the
-    launch stream; the time loops include their launch-to-launch gaps, which is what bounds them)."""
+    every gate GEMM of a step -- hoisted input projections, the recurrent products inside the recurrence kernels, input and
+    weight gradients -- over the time of the kernels that run them (plane GEMMs + the recurrence launches, HIP events on the
+    launch stream; a recurrence launch is one persistent kernel per layer call whose steps are bound by the per-step chain
+    barrier, or, where that form does not apply, one launch per time step with its gaps inside the bracket)."""
     steps = max(steps, 1)
     flops = 0.0
     #            rows            I      layers/dirs
@@ -183,8 +184,8 @@ def lstm_gemm_roofline(prof, B, T, Ma, Mi, H, steps, dtype):
     peak = F16_MFMA_PEAK_TF
     ach = flops / (tot * 1e-6) / 1e12 if tot else 0.0
     return {"bound": "mfma", "kernel": "LSTM gate GEMMs at H = 512: hoisted projections and gradient GEMMs (operand-plane GEMM kernels) + the "
-                                       "recurrent products inside the per-step fused kernels (one launch per time step; their launch gaps are "
-                                       "inside the bracket)",
+                                       "recurrent products inside the recurrence kernels (one persistent launch per layer call, W_hh fragments in "
+                                       "registers, a counter barrier per chain and time step; the barrier waits are inside the bracket)",
             "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
             "flops_per_step": flops, "us_per_step": {k: round(v, 1) for k, v in us.items()},
             "arithmetic": "one v_mfma_f32_16x16x32_bf16 per product (bf16 operands)" if dtype == "bf16" else

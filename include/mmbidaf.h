@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMB_VERSION 300            /* round 3 ABI: grouped attention entry points, build hash */
+#define MMB_VERSION 301            /* round 3 ABI: grouped attention entry points, build hash, persistent-recurrence status word */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
 #define MMB_ATT_MAX_D 208          /* attention feature width D = 2H of the fused (register-resident) kernels */
 #define MMB_ATT_GENERAL_MAX_D 4096 /* wider D (up to this) runs the general path: similarity matrix in a workspace */

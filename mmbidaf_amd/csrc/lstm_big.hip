@@ -343,11 +343,13 @@ static int big_fwd_post(const mmb_lstm_fwd_desc* d, int n, hipStream_t stream) {
     MMB_HIP(hipGetLastError());
     return MMB_OK;
 }
-static int big_bwd_post(const mmb_lstm_bwd_desc* d, int n, hipStream_t stream) {
+// have_db: the recurrence launch already accumulated d_b (persistent form)
+static int big_bwd_post(const mmb_lstm_bwd_desc* d, int n, hipStream_t stream, bool have_db = false) {
     const int H = d[0].H;
     for (int i = 0; i < n; ++i) {
         const mmb_lstm_bwd_desc& p = d[i];
         hipLaunchKernelGGL(lstm_big_zero_tail_kernel, dim3(64, p.B), dim3(256), 0, stream, p.d_a, p.lengths, p.B, p.T, 8 * H);
+        if (have_db) continue;
         MMB_HIP(hipMemsetAsync(p.d_b, 0, sizeof(float) * 8 * H, stream));
         hipLaunchKernelGGL(lstm_big_colsum_kernel, dim3((8 * H + 255) / 256, 64), dim3(256), 0, stream, p.d_a, p.d_b, (long)p.B * p.T, 8 * H);
     }
@@ -406,8 +408,10 @@ int lstm_big_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* big_ws, hipStre
             MMB_REQUIRE(d[i].H == d[0].H, "grouped general-size LSTM problems must share H");
             fs_ws[i] = big_ws[i] + big_bwd_own(d[i].B, d[0].H);
         }
-        if (int rc = lstm_fs_bwd(d, n, fs_ws, stream)) return rc;
-        return big_bwd_post(d, n, stream);
+        for (int i = 0; i < n; ++i) MMB_HIP(hipMemsetAsync(d[i].d_b, 0, sizeof(float) * 8 * d[0].H, stream));   // (the persistent form adds into it)
+        bool have_db = false;
+        if (int rc = lstm_fs_bwd(d, n, fs_ws, stream, &have_db)) return rc;
+        return big_bwd_post(d, n, stream, have_db);
     }
     BigBwdArgs a{};
     a.n = n;

@@ -1,7 +1,8 @@
 // Fused-step LSTM recurrence for hidden sizes above the register-resident limit (H > MMB_LSTM_MAX_H, e.g. BASELINE
 // cfg5's H = 512): ONE kernel per time step -- recurrent product on the 16-bit matrix cores + the whole cell update --
 // instead of lstm_big.hip's exact-f32 skinny GEMM + cell kernel (two launches, ~26 us per step pair at cfg5).
-// The stream order is still the only barrier between steps: no cooperative launch, no spin wait, nothing that can hang.
+// In this (launch-per-step) form the stream order is the only barrier between steps; the persistent form further down
+// replaces it by a bounded-spin counter barrier per chain.
 //
 //   forward step s   pre (B x 4H) = h_{s-1} (B x H) . W_hh^T,  then gates, c, h  (reference: nn.LSTM as called at
 //                    layers/encoding.py:79-81,96 on a packed batch; same semantics and saved tensors as lstm.hip)
@@ -27,10 +28,11 @@
 // are dealt so that all slices of one (encoder, direction) chain run on ONE XCD: its W_hh planes (1-4 MB) and recurrent
 // operand stay in that XCD's L2.  NPL = 2: fp16 two-term planes (fp32-accurate); NPL = 1: one bf16 plane (mmb_set_precision).
 //
-// STATUS: the default for H > MMB_LSTM_MAX_H (MMB_LSTM_FS=0: lstm_big.hip's two launches per step).  cfg5 (B=64, H=512):
-// ~86 ms per region step fp32-accurate (two launches: 92.2), 49.2 ms with bf16 operands (65.3); forward step ~9 us, BPTT
-// step ~14 us, of which ~5 us are the launch-to-launch floor of a dependent chain; what remains beyond that is the
-// persistent form (W_hh resident, per-step barrier across the workgroups of a chain).
+// STATUS: the default for H > MMB_LSTM_MAX_H (MMB_LSTM_FS=0: lstm_big.hip's two launches per step).  Launch-per-step form,
+// cfg5 (B=64, H=512): ~86 ms per region step fp32-accurate, 49 ms with bf16 operands; forward step ~9 us, BPTT step ~14 us
+// plus ~1.8 us of kernel boundary each.  PERSISTENT form (below; 128 < H <= 512 and grid <= CUs, the default when it
+// applies): one launch per layer call, W_hh fragments in registers, per-step chain barrier: 5.3 / 4.3 us per step bf16
+// (7.0 / 9.9 fp32-accurate), cfg5 31.0 / 58.9 ms per region step.
 #include "common.h"
 
 namespace mmb {
@@ -136,7 +138,7 @@ struct FsFwdProb {
     char* hp[2][2];         // h planes [direction][step parity], rows = samples padded to 64, zero at entry
     int B, T, H;
 };
-struct FsFwdArgs { FsFwdProb p[MMB_MAX_GROUP]; int n, nkt, nslices, nsb; };
+struct FsFwdArgs { FsFwdProb p[MMB_MAX_GROUP]; int n, nkt, nslices, nsb, dbg; };   // dbg: timing-only ablations of the persistent form (MMB_LSTM_FS_DBG)
 
 // One workgroup = 16 units x 4 gates (64 plane rows) x 64 samples; its 8 waves SPLIT K (wave w takes k tiles w, w+8, ...)
 // and each computes all 4 x 4 tiles of the workgroup tile on its K part, so every operand fragment is read exactly once per
@@ -258,6 +260,7 @@ struct FsBwdProb {
     const float* d_y; const float* d_hn; const float* gates; const float* cs;
     const int* hn_pos; const int* len;
     float* d_a;             // (B,T,2,4H) torch gate order
+    float* d_b;             // (2,4H) bias gradient, zero at entry: accumulated by the persistent form only (null: not wanted)
     float* dc;              // (2,B,H) running cell-state gradient
     const char* wtp[2];     // W_hh planes (mode 1) per direction
     const float* wtinv[2];
@@ -266,7 +269,7 @@ struct FsBwdProb {
     const float* bound;     // [2]: max |d_y|, max |d_hn| over the whole problem
     int B, T, H;
 };
-struct FsBwdArgs { FsBwdProb p[MMB_MAX_GROUP]; int n, nkt4, nslices, nsb; };
+struct FsBwdArgs { FsBwdProb p[MMB_MAX_GROUP]; int n, nkt4, nslices, nsb, dbg; };
 
 // scale of the d_a planes WRITTEN at step s (and read at step s+1): every lane derives the same power of two (fp16 planes)
 __device__ __forceinline__ float fs_da_scale(const FsBwdProb& P, int dir, int s) {
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(512) void lstm_fs_fwd_persist_kernel(const FsFwdArg
     fs_lds_barrier();                                                         // the zeroed stage
 
     for (int s = 0; s < T; ++s) {
-        if (s > 0 && !fs_chain_wait(cnt, (unsigned)s * nwg, tmo, lflag)) return;
+        if (s > 0 && !fs_chain_wait(cnt, (args.dbg & 1) ? 0u : (unsigned)s * nwg, tmo, lflag)) return;
         f4 gx_cur[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) gx_cur[q] = gx_nx[q];
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(512) void lstm_fs_fwd_persist_kernel(const FsFwdArg
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) c[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-        if (s > 0) {   // h_{-1} = 0
+        if (s > 0 && !(args.dbg & 2)) {   // h_{-1} = 0
             const __amdgpu_buffer_rsrc_t hb = fs_rsrc(P.hp[dir][(s + 1) & 1], pstride * NPL);
             // (a k tile beyond nkt: zero W_hh fragments, and an offset beyond num_records, where a buffer load returns 0
             //  without touching memory: no branch, all loads of the step in flight together)
@@ -601,7 +604,8 @@ __global__ __launch_bounds__(512) void lstm_fs_fwd_persist_kernel(const FsFwdArg
             const int pair = tid + 512 * q, ul = pair & 15, bl = pair >> 4;
             f4 acc = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int w = 0; w < 8; ++w) acc += part[(w * 64 + bl) * 17 + ul];
+            for (int w = 0; w < 8; ++w)
+                if (w == 0 || !(args.dbg & 8)) acc += part[(w * 64 + bl) * 17 + ul];
             e_on[q] = s < e_len[q];
             if (!e_on[q]) continue;
             const f4 pre = acc * e_winv[q] + gx_cur[q];
@@ -644,7 +648,7 @@ __global__ __launch_bounds__(512) void lstm_fs_fwd_persist_kernel(const FsFwdArg
             const u4 v = *reinterpret_cast<const u4*>(stage + pl * 2048 + i * 16);
             const __amdgpu_buffer_rsrc_t hn = fs_rsrc(P.hp[dir][s & 1], pstride * NPL);
             __builtin_amdgcn_raw_buffer_store_b128(v, hn, pl * pstride + my_slab + i * 16, 0, 16);   // sc1: write-through
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(args.dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             store_outputs();
         }
@@ -736,12 +740,13 @@ __global__ __launch_bounds__(512) void lstm_fs_bwd_persist_kernel(const FsBwdArg
     const unsigned pstride = (unsigned)nsbp * nkt * SWB * 64;                 // bytes of one plane of the exchange buffer
     const unsigned my_slab = ((unsigned)sblk * nkt + 2 * MU * slice) * SWB * 64;
     const unsigned aoff = (((unsigned)sblk * nkt + wave) * SWB + r) * 64 + g * 16;   // fragment of k tile `wave`, lane (sample r, octet g)
+    f4 db_acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};   // bias gradient: this thread's pairs summed over the steps
     float sc_prev = 1.0f;
     const float bnd_y = NPL == 2 ? P.bound[0] : 0.f, bnd_h = NPL == 2 ? P.bound[1] : 0.f;   // written by the launches before this one
     fs_lds_barrier();
 
     for (int s = 0; s < T; ++s) {
-        if (s > 0 && !fs_chain_wait(cnt, (unsigned)s * nwg, tmo, lflag)) return;
+        if (s > 0 && !fs_chain_wait(cnt, (args.dbg & 1) ? 0u : (unsigned)s * nwg, tmo, lflag)) return;
         float e_dy[2], e_cp[2];
         f4 e_g4[2];
 #pragma unroll
@@ -761,7 +766,7 @@ __global__ __launch_bounds__(512) void lstm_fs_bwd_persist_kernel(const FsBwdArg
         for (int i = 0; i < MU; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) c[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-        if (s > 0) {
+        if (s > 0 && !(args.dbg & 2)) {
             const __amdgpu_buffer_rsrc_t ab = fs_rsrc(P.ap[dir][(s + 1) & 1], pstride * NPL);
 #pragma unroll
             for (int q0 = 0; q0 < KTW; q0 += KB) {
@@ -809,6 +814,7 @@ __global__ __launch_bounds__(512) void lstm_fs_bwd_persist_kernel(const FsBwdArg
             const float da0 = dc_t * gg * gi * (1.0f - gi), da1 = dc_t * c_prev * gf * (1.0f - gf);
             const float da2 = dc_t * gi * (1.0f - gg * gg), da3 = dh * tc * go * (1.0f - go);
             o_da[k] = f4{da0, da1, da2, da3};
+            db_acc[k] += o_da[k];
             dcs[k] = dc_t * gf;
             c_t[k] = c_prev;           // the next BPTT step's c_t
             char* d = stage + ((ul >> 3) * SWB + bl) * 64 + (ul & 7) * 8;
@@ -845,7 +851,7 @@ __global__ __launch_bounds__(512) void lstm_fs_bwd_persist_kernel(const FsBwdArg
                 if (2 * MU * slice + tid / (4 * SWB) < nkt)
                     __builtin_amdgcn_raw_buffer_store_b128(v, an, pl * pstride + my_slab + tid * 16, 0, 16);   // sc1: write-through
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(args.dbg & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         fs_lds_barrier();
         if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -860,6 +866,19 @@ __global__ __launch_bounds__(512) void lstm_fs_bwd_persist_kernel(const FsBwdArg
                 da[(size_t)3 * H] = o_da[k].w;
             }
             request(k, s + 1);
+        }
+    }
+    if (P.d_b) {   // d_b (2,4H) += the workgroup's samples summed (LDS), one atomic per (unit, gate) and workgroup
+        f4* dbs = reinterpret_cast<f4*>(smem);           // [sample SWB][unit UW] quads: 16 KB of the partial-tile region
+        fs_lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) dbs[(tid / UW + ROWS * k) * UW + ul] = db_acc[k];
+        fs_lds_barrier();
+        if (tid < UW && u < H) {
+            f4 sum = f4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < SWB; ++b) sum += dbs[b * UW + tid];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(P.d_b + (size_t)dir * 4 * H + (size_t)e * H + u, sum[e]);
         }
     }
 }
@@ -918,6 +937,10 @@ size_t lstm_fs_bwd_ws_bytes(int B, int T, int H) { return fs_bwd_layout(B, T, H)
 // ---- persistent form: eligibility and the time-out word
 static int fs_persist_mode() {   // MMB_LSTM_FS_PERSIST=0: launch-per-step kernels only
     static const int v = [] { const char* e = getenv("MMB_LSTM_FS_PERSIST"); return e ? atoi(e) : 1; }();
+    return v;
+}
+static int fs_dbg() {            // timing-only ablations (results wrong): 1 no chain wait, 2 no operand loads, 4 no publish drain, 8 one partial tile
+    static const int v = [] { const char* e = getenv("MMB_LSTM_FS_DBG"); return e ? atoi(e) : 0; }();
     return v;
 }
 static int fs_num_cus() {
@@ -990,6 +1013,7 @@ int lstm_fs_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* ws, hipStream_t 
         if (tmo && grid_p <= fs_num_cus()) {
             if (int rc = fs_check_timeout()) return rc;
             a.nsb = nsb64;
+            a.dbg = fs_dbg();
             constexpr int lds_p = FS_PART_BYTES + 4096 + 16;
             auto kp = npl == 2 ? lstm_fs_fwd_persist_kernel<2> : lstm_fs_fwd_persist_kernel<1>;
             static PerDeviceOnce attr_p[2];
@@ -1032,7 +1056,9 @@ int lstm_fs_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* ws, hipStream_t 
     return MMB_OK;
 }
 
-int lstm_fs_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* ws, hipStream_t stream) {
+// *db_done: set when the launch also produced d_b (which must then be ZERO at entry); otherwise d_b is untouched
+int lstm_fs_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* ws, hipStream_t stream, bool* db_done) {
+    if (db_done) *db_done = false;
     FsBwdArgs a{};
     a.n = n;
     const int npl = precision_mode() == 1 ? 1 : 2;
@@ -1082,6 +1108,9 @@ int lstm_fs_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* ws, hipStream_t 
             if (int rc = fs_check_timeout()) return rc;
             a.nslices = psl;
             a.nsb = psb;
+            a.dbg = fs_dbg();
+            for (int i = 0; i < n; ++i) a.p[i].d_b = db_done ? d[i].d_b : nullptr;
+            if (db_done) *db_done = true;
             const int lds_p = 8 * 16 * pnt * (16 * pmu + 1) * 4 + npl * 8192 + 16;
             auto kp = npl == 2 ? lstm_fs_bwd_persist_kernel<2, 2, 2> : (pmu == 4 ? lstm_fs_bwd_persist_kernel<1, 4, 1> : lstm_fs_bwd_persist_kernel<1, 2, 2>);
             static PerDeviceOnce attr_p[3];

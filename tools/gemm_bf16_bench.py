@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""The operand-plane GEMM in the bf16 mode (one bf16 plane, one product) on cfg5's projection shapes, kernel-only time from
+the library's event hook, next to torch's bf16 matmul (hipBLASLt) as a yardstick.  MMB_PLANES_DBG (timing-only ablations:
+2 no MFMA, 8 no DMA after the prologue, 16 MFMA only) and MMB_PLANES_TUNE=<cfg><split> apply.  GPU box only."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from mmbidaf_amd import functional as MF, _lib
+
+dev = torch.device("cuda:0")
+MF.set_precision("bf16")
+SHAPES = [("gx modL0", 25600, 4096, 4096), ("gx modL1", 25600, 4096, 1024), ("gx enc", 25600, 4096, 512), ("dW L0", 4096, 5120, 25600)]
+for name, M, N, K in SHAPES:
+    a = torch.randn(M, K, device=dev)
+    b = torch.randn(N, K, device=dev) * 0.05
+    for _ in range(2):
+        MF.gemm_nt_planes(a, b)
+    torch.cuda.synchronize()
+    _lib.profile_enable(["gemm", "split"])
+    for _ in range(5):
+        MF.gemm_nt_planes(a, b)
+    torch.cuda.synchronize()
+    _lib.profile_enable([])
+    gms, gn, _ = _lib.profile_read("gemm")
+    sms, sn, _ = _lib.profile_read("split")
+    fl = 2.0 * M * N * K
+    t = gms / gn * 1e-3
+    ab, bb = a.bfloat16(), b.bfloat16()
+    for _ in range(2):
+        ab @ bb.t()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ab @ bb.t()
+    e1.record()
+    torch.cuda.synchronize()
+    tt = e0.elapsed_time(e1) / 5 * 1e-3
+    print(f"{name:9s} {M:6d}x{N:5d}x{K:6d}  planes bf16 {t*1e6:8.1f} us {fl/t/1e12:7.1f} TF (+ splits {sms/5*1e3:7.1f} us) | torch bf16 {tt*1e6:8.1f} us {fl/tt/1e12:7.1f} TF", flush=True)
