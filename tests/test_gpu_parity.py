@@ -4,6 +4,7 @@ Run on the MI355X box:  python -m pytest tests -m gpu -x -q
 Tolerance (north_star): max-abs <= 1e-4 in fp32, scaled by max|ref| when that exceeds 1 (sums over
 B*T terms such as weight gradients grow with the problem size)."""
 import os
+import sys
 
 import pytest
 import torch
@@ -545,6 +546,48 @@ def test_rnn_encoder_general_hidden_size_vs_oracle():
         close(xgi.grad, dxr, "d_x")
         for n, p in e_.named_parameters():
             close(p.grad, P[n[4:]].grad, "grad " + n)
+
+
+def test_general_hidden_size_persistent_recurrence_is_what_runs_and_never_times_out():
+    """128 < H <= 512 with a grid that fits the chip runs the PERSISTENT recurrence (lstm_fs.hip: one launch per layer call,
+    bounded-spin chain barrier per step).  The library's per-kernel event hook sees ONE forward and ONE backward recurrence
+    bracket per layer call whatever the form, so the form is told apart by the kernel's own status word and by the launch
+    count rocprof reports (profiles/r03_cfg5_kernel_stats.md); here: the status word stays 0 over a full-length (T = 400)
+    two-layer encoder at H = 512, B = 64 -- 2 x 1600 chain barriers of 32 / 16 workgroups each -- and the result has the packed-
+    sequence properties (zeros behind each length, batch independence)."""
+    from mmbidaf_amd.encoding import RNNEncoder
+    from mmbidaf_amd import _lib
+    lib = _lib.load()
+    assert lib.mmb_lstm_persist_timeouts() == 0
+    torch.manual_seed(17)
+    e = RNNEncoder(64, 512, 2).to(dev())
+    g = torch.Generator().manual_seed(18)
+    x = (torch.randn(64, 400, 64, generator=g) * 0.5).to(dev()).requires_grad_(True)
+    lens = [400] + [int(v) for v in torch.randint(1, 401, (63,), generator=g)]
+    y, h = e(x, lens)
+    (y.square().sum() + h.sum()).backward()
+    torch.cuda.synchronize()
+    assert lib.mmb_lstm_persist_timeouts() == 0, "a chain barrier of the persistent recurrence timed out"
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+    for b in (1, 7, 63):
+        assert (y[b, lens[b]:] == 0).all() and (x.grad[b, lens[b]:] == 0).all()
+    x2 = x.detach()[:3].clone().requires_grad_(True)
+    y2, h2 = e(x2, lens[:3])
+    (y2.square().sum() + h2.sum()).backward()
+    close(y2, y[:3].detach().cpu(), "y of a 3-sample batch vs the same samples inside B=64")
+    close(x2.grad, x.grad[:3].cpu(), "d_x of a 3-sample batch vs the same samples inside B=64")
+    assert lib.mmb_lstm_persist_timeouts() == 0
+
+
+def test_general_hidden_size_launch_per_step_form_still_matches_the_oracle():
+    """MMB_LSTM_FS_PERSIST=0 (read once per process, hence a child process): the launch-per-step kernels that grids larger
+    than the chip fall back to run the same oracle comparison."""
+    import subprocess
+    env = dict(os.environ, MMB_LSTM_FS_PERSIST="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k",
+                        "test_rnn_encoder_general_hidden_size_vs_oracle or test_hot_region_cfg5_hidden512_vs_oracle",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_lstm_time_reversal_property_full_size():
