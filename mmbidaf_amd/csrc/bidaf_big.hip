@@ -42,25 +42,57 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// column softmax over i (text axis) with the text mask: P2[b,i,j], col_stat[b,j] = {max, sum}.  One thread per column.
+// column softmax over i (text axis) with the text mask: P2[b,i,j], col_stat[b,j] = {max, sum}.  Workgroup = 64 columns x
+// 4 waves that take every 4th row (256-B coalesced rows, four independent loads in flight per thread); each thread keeps
+// an online (max, sum), the four partial pairs meet in LDS, a second pass writes P2.
 __global__ __launch_bounds__(256) void big_colsoft_kernel(const float* __restrict__ S, const float* __restrict__ rterm,
                                                           const float* __restrict__ cterm, const uint8_t* __restrict__ tmask,
                                                           float* __restrict__ P2, float* __restrict__ col_stat, int T, int M) {
-    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= M) return;
-    const float* Sb = S + (size_t)b * T * M + j;
+    __shared__ float pm[4][64], ps[4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const bool on = j < M;
+    const float* Sb = S + (size_t)b * T * M + (on ? j : 0);
     const float* r = rterm + (size_t)b * T;
     const uint8_t* mk = tmask + (size_t)b * T;
-    const float c = cterm[(size_t)b * M + j];
-    float mx = -INFINITY;
-    for (int i = 0; i < T; ++i) mx = fmaxf(mx, mk[i] ? Sb[(size_t)i * M] + r[i] + c : BIG_NEG);
-    float sum = 0.f;
-    for (int i = 0; i < T; ++i) sum += expf((mk[i] ? Sb[(size_t)i * M] + r[i] + c : BIG_NEG) - mx);
+    const float c = on ? cterm[(size_t)b * M + j] : 0.f;
+    float mx = -INFINITY, sum = 0.f;
+    for (int i0 = w; i0 < T; i0 += 16) {
+        float x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + 4 * q;
+            x[q] = i < T ? (mk[i] ? Sb[(size_t)i * M] + r[i] + c : BIG_NEG) : -INFINITY;
+        }
+        const float m4 = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+        if (m4 > mx) { sum *= expf(mx - m4); mx = m4; }     // (mx = -inf at first: expf(-inf) = 0, sum is 0 anyway)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sum += expf(x[q] - mx);    // rows beyond T: expf(-inf) = 0
+    }
+    pm[w][lane] = mx; ps[w][lane] = sum;
+    __syncthreads();
+    mx = fmaxf(fmaxf(pm[0][lane], pm[1][lane]), fmaxf(pm[2][lane], pm[3][lane]));
+    sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sum += ps[q][lane] * expf(pm[q][lane] - mx);   // a wave without rows: 0 * expf(-inf) = 0
+    if (!on) return;
     const float inv = 1.0f / sum;
     float* Pb = P2 + (size_t)b * T * M + j;
-    for (int i = 0; i < T; ++i) Pb[(size_t)i * M] = expf((mk[i] ? Sb[(size_t)i * M] + r[i] + c : BIG_NEG) - mx) * inv;
-    col_stat[((size_t)b * M + j) * 2] = mx;
-    col_stat[((size_t)b * M + j) * 2 + 1] = sum;
+    for (int i0 = w; i0 < T; i0 += 16) {
+        float x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + 4 * q;
+            x[q] = i < T ? (mk[i] ? Sb[(size_t)i * M] + r[i] + c : BIG_NEG) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (i0 + 4 * q < T) Pb[(size_t)(i0 + 4 * q) * M] = expf(x[q] - mx) * inv;
+    }
+    if (w == 0) {
+        col_stat[((size_t)b * M + j) * 2] = mx;
+        col_stat[((size_t)b * M + j) * 2 + 1] = sum;
+    }
 }
 
 // row softmax over j (modality axis) with the modality mask, IN PLACE over S: P1[b,i,j], row_stat[b,i] = {max, sum}.
@@ -152,15 +184,29 @@ __global__ __launch_bounds__(256) void big_rowdot_kernel(const float* __restrict
     if (lane == 0) dst[row] = acc;
 }
 
-// coldot[b,j] = sum_i X[b,i,j] * (Y ? Y[b,i,j] : 1)       (one thread per column)
+// coldot[b,j] = sum_i X[b,i,j] * (Y ? Y[b,i,j] : 1)       (workgroup = 64 columns x 4 waves that take every 4th row)
 __global__ __launch_bounds__(256) void big_coldot_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                          float* __restrict__ dst, int T, int M) {
-    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= M) return;
-    const size_t base = (size_t)b * T * M + j;
+    __shared__ float pa[4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const bool on = j < M;
+    const size_t base = (size_t)b * T * M + (on ? j : 0);
     float acc = 0.f;
-    for (int i = 0; i < T; ++i) acc += X[base + (size_t)i * M] * (Y ? Y[base + (size_t)i * M] : 1.0f);
-    dst[(size_t)b * M + j] = acc;
+    for (int i0 = w; i0 < T; i0 += 16) {
+        float x[4], y[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + 4 * q;
+            x[q] = i < T ? X[base + (size_t)i * M] : 0.f;
+            y[q] = (Y && i < T) ? Y[base + (size_t)i * M] : 1.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = fmaf(x[q], y[q], acc);
+    }
+    pa[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && on) dst[(size_t)b * M + j] = (pa[0][lane] + pa[1][lane]) + (pa[2][lane] + pa[3][lane]);
 }
 
 // dS = mmask_j * P1 * (dP1 - rowdot_i) + tmask_i * P2 * (dP2 - coldot_j), written over dP1
@@ -201,6 +247,7 @@ __global__ __launch_bounds__(256) void big_colreduce_kernel(const float* __restr
     const long chunk = (rows + gridDim.y - 1) / gridDim.y;
     const long r0 = (long)blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
     float acc = 0.f;
+#pragma unroll 4
     for (long r = r0; r < r1; ++r) acc += X[(size_t)r * D + d] * (Y ? Y[(size_t)r * D + d] : 1.0f) * (s ? s[r] : 1.0f);
     atomicAdd(&out[d], acc);
 }
@@ -276,7 +323,7 @@ int bidaf_big_fwd(const float* text, const float* mod, const uint8_t* text_mask,
     if (int rc = big_similarity(text_d, mod_d, w_tm, tw, S, B, T, M, D, stream)) return rc;
     {
         ProfScope ps_(MMB_K_ATT_COL, stream);
-        hipLaunchKernelGGL(big_colsoft_kernel, dim3((M + 255) / 256, B), dim3(256), 0, stream, S, rterm, cterm, text_mask, P2, col_stat, T, M);
+        hipLaunchKernelGGL(big_colsoft_kernel, dim3((M + 63) / 64, B), dim3(256), 0, stream, S, rterm, cterm, text_mask, P2, col_stat, T, M);
         MMB_HIP(hipGetLastError());
     }
     {
@@ -323,12 +370,12 @@ int bidaf_big_bwd(const float* d_out, const float* out, const float* text, const
     if (int rc = bgemm(P2, dq, d_text, T, D, M, M, D, D, 0, 0, 1, B, sTM, sMD, sTD, stream)) return rc;
     // softmax backward of both axes -> dS (over dP1)
     hipLaunchKernelGGL(big_rowdot_kernel, dim3((BT + 3) / 4), dim3(256), 0, stream, P1, dP1, rowv, BT, M);
-    hipLaunchKernelGGL(big_coldot_kernel, dim3((M + 255) / 256, B), dim3(256), 0, stream, P2, dP2, colv, T, M);
+    hipLaunchKernelGGL(big_coldot_kernel, dim3((M + 63) / 64, B), dim3(256), 0, stream, P2, dP2, colv, T, M);
     MMB_HIP(hipGetLastError());
     BIG_EW(big_ds_kernel, total, P1, P2, dP1, dP2, rowv, colv, text_mask, mod_mask, total, T, M);
     float* dS = dP1;
     hipLaunchKernelGGL(big_rowdot_kernel, dim3((BT + 3) / 4), dim3(256), 0, stream, dS, static_cast<const float*>(nullptr), dr, BT, M);
-    hipLaunchKernelGGL(big_coldot_kernel, dim3((M + 255) / 256, B), dim3(256), 0, stream, dS, static_cast<const float*>(nullptr), dc, T, M);
+    hipLaunchKernelGGL(big_coldot_kernel, dim3((M + 63) / 64, B), dim3(256), 0, stream, dS, static_cast<const float*>(nullptr), dc, T, M);
     MMB_HIP(hipGetLastError());
     // G = dS . mod_d (T x D), Hm = dS^T . text_d (M x D): the bilinear term without w_tm
     if (int rc = bgemm(dS, md, G, T, D, M, M, D, D, 0, 0, 0, B, sTM, sMD, sTD, stream)) return rc;
@@ -341,9 +388,9 @@ int bidaf_big_bwd(const float* d_out, const float* out, const float* text, const
     MMB_HIP(hipMemsetAsync(d_w_m, 0, sizeof(float) * D, stream));
     MMB_HIP(hipMemsetAsync(d_w_tm, 0, sizeof(float) * D, stream));
     const float* none = nullptr;
-    hipLaunchKernelGGL(big_colreduce_kernel, dim3((D + 255) / 256, 64), dim3(256), 0, stream, td, G, none, d_w_tm, BT, D);
-    hipLaunchKernelGGL(big_colreduce_kernel, dim3((D + 255) / 256, 64), dim3(256), 0, stream, td, none, static_cast<const float*>(dr), d_w_t, BT, D);
-    hipLaunchKernelGGL(big_colreduce_kernel, dim3((D + 255) / 256, 64), dim3(256), 0, stream, md, none, static_cast<const float*>(dc), d_w_m, BM, D);
+    hipLaunchKernelGGL(big_colreduce_kernel, dim3((D + 255) / 256, 256), dim3(256), 0, stream, td, G, none, d_w_tm, BT, D);
+    hipLaunchKernelGGL(big_colreduce_kernel, dim3((D + 255) / 256, 256), dim3(256), 0, stream, td, none, static_cast<const float*>(dr), d_w_t, BT, D);
+    hipLaunchKernelGGL(big_colreduce_kernel, dim3((D + 255) / 256, 256), dim3(256), 0, stream, md, none, static_cast<const float*>(dc), d_w_m, BM, D);
     hipLaunchKernelGGL(big_total_kernel, dim3(1), dim3(256), 0, stream, dr, d_bias, BT);
     MMB_HIP(hipGetLastError());
     return MMB_OK;
