@@ -525,8 +525,13 @@ void set_gemm_mode(int mode) { g_gemm_mode = (mode == 0 || mode == 2 || mode == 
 int gemm_launch(const GemmArgs& g, hipStream_t stream) {
     if (g.M <= 0 || g.N <= 0) return MMB_OK;
     int mode = gemm_mode();
-    if (g.batch > 1) mode = 0;   // batched products (general-size attention) always take the exact-f32 kernels
-    if (mode == 1)  // auto: the split-bf16 kernel wins on wide, deep products (tools/gemm_bench.py), both are fp32-accurate
+    if (g.batch > 1) {
+        // batched products: the pointer-table form (per-step recurrent products of lstm_big.hip) stays on the exact-f32 kernels;
+        // strided batches (general-width attention: 64 products of 400 x 256 x 1024 at cfg5) take the three-term bf16 kernel
+        // when deep enough for it to win (39 -> ~150 TFLOP/s there), MMB_GEMM_BATCH_BF16=0 keeps them on the f32 kernels
+        static const bool bb = [] { const char* e = getenv("MMB_GEMM_BATCH_BF16"); return !(e && atoi(e) == 0); }();
+        mode = (bb && mode != 0 && !g.use_ptrs && g.K >= 64 && (long)g.M * g.N >= 4096) ? 3 : 0;
+    } else if (mode == 1)  // auto: the split-bf16 kernel wins on wide, deep products (tools/gemm_bench.py), both are fp32-accurate
         mode = (!g.ta && g.N >= 400 && g.K >= 200) ? 3 : 0;   // transposed-A (weight-gradient) shapes: the f32 kernel is faster
     if (mode != 0 && gemm_bf16_eligible(g)) return gemm_bf16_launch(g, mode, stream);
     if (g.nseg > 0 && !fast_ok(g)) return fail(MMB_ERR_ARG, "gemm: segmented B needs the aligned fast path");

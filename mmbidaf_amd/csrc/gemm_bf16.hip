@@ -48,6 +48,11 @@ __device__ __forceinline__ void split_store(char* const (&img)[3], int off, cons
 //                           B is (N,K) [TB=1, K contiguous] or (K,N) [TB=0, N contiguous].
 template <int WAVES, int MT, int NT, bool TA, bool TB, int NS>
 __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_kernel(const GemmArgs g, const int kchunk) {
+    // batched mode (g.batch > 1, strided operands): blockIdx.z = product, no K split
+    const int bz = g.batch > 1 ? blockIdx.z : 0, kz = g.batch > 1 ? 0 : blockIdx.z;
+    const float* gA = g.A + (size_t)bz * g.sA;
+    const float* gB = g.B + (size_t)bz * g.sB;
+    float* gC = g.C + (size_t)bz * g.sC;
     constexpr int BM = WAVES * MT * 16, BN = NT * 16, NTHR = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* imgA[3];
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_kernel(const GemmArgs g,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kg = lane >> 4;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kb = blockIdx.z * kchunk;
+    const int kb = kz * kchunk;
     const int ke = min(g.K, kb + kchunk);
 
     // ---- prefetch registers: "units" of 8 k-values per tile row (K-contiguous) or 8k x 4m patches (M/N-contiguous)
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_kernel(const GemmArgs g,
             if (A_UNITS % NTHR == 0 || c < A_UNITS) {
                 if constexpr (!TA) {
                     const int row = c >> 2, oct = c & 3;
-                    const float* src = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + k0 + 8 * oct;
+                    const float* src = gA + (size_t)min(m0 + row, g.M - 1) * g.lda + k0 + 8 * oct;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         f4 t = f4{0.f, 0.f, 0.f, 0.f};
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_kernel(const GemmArgs g,
                     }
                 } else {
                     const int m4 = c % (BM / 4), oct = c / (BM / 4);
-                    const float* src = g.A + (size_t)(k0 + 8 * oct) * g.lda + min(m0 + 4 * m4, g.M - 4);
+                    const float* src = gA + (size_t)(k0 + 8 * oct) * g.lda + min(m0 + 4 * m4, g.M - 4);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         f4 t = f4{0.f, 0.f, 0.f, 0.f};
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_kernel(const GemmArgs g,
                         const int H = g.gate_H, blk = gn / (4 * H), rem = gn % (4 * H);
                         srow = blk * 4 * H + (rem & 3) * H + (rem >> 2);
                     }
-                    const float* src = g.B + (size_t)srow * g.ldb + k0 + 8 * oct;
+                    const float* src = gB + (size_t)srow * g.ldb + k0 + 8 * oct;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         f4 t = f4{0.f, 0.f, 0.f, 0.f};
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_kernel(const GemmArgs g,
                 } else {
                     const int n4 = c % (BN / 4), oct = c / (BN / 4);
                     int col = min(n0 + 4 * n4, g.N - 4), ld = g.ldb, shift = g.shiftB;
-                    const float* base = g.B;
+                    const float* base = gB;
                     if (g.nseg > 0) {  // virtual concatenation [x | y_fwd | y_rev]: pick this patch's segment
                         int sg = 0;
                         while (sg < g.nseg - 1 && col >= g.seg_cols[sg]) col -= g.seg_cols[sg++];
@@ -229,13 +234,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_kernel(const GemmArgs g,
     }
 
     // ---- epilogue: lane (r,kg) holds C[m = 4kg+e][n = r] of each 16x16 tile
-    const bool atomic = gridDim.z > 1;
+    const bool atomic = g.batch <= 1 && gridDim.z > 1;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + j * 16 + r;
         if (n >= g.N) continue;
         float bv = 0.f;
-        if (blockIdx.z == 0 && (g.bias || g.bias2)) {
+        if (kz == 0 && (g.bias || g.bias2)) {
             int srow = n;
             if (g.gate_H > 0) {
                 const int H = g.gate_H, blk = n / (4 * H), rem = n % (4 * H);
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_kernel(const GemmArgs g,
             for (int e = 0; e < 4; ++e) {
                 const int m = m0 + (wave * MT + i) * 16 + 4 * kg + e;
                 if (m >= g.M) continue;
-                float* dst = g.C + (size_t)m * g.ldc + n;
+                float* dst = gC + (size_t)m * g.ldc + n;
                 const float v = acc[i][j][e] + bv;
                 if (atomic)
                     atomicAdd(dst, v);
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_kernel(const GemmArgs g,
 template <int WAVES, int MT, int NT, int NS>
 static int launch_bf16(const GemmArgs& g, int splitk, hipStream_t stream) {
     constexpr int BM = WAVES * MT * 16, BN = NT * 16;
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, splitk);
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch > 1 ? g.batch : splitk);
     int kchunk = (g.K + splitk - 1) / splitk;
     kchunk = (kchunk + KT - 1) / KT * KT;
     const size_t lds = (size_t)NS * (BM + BN) * ROWB;
@@ -297,6 +302,7 @@ static int launch_bf16(const GemmArgs& g, int splitk, hipStream_t stream) {
 }
 
 bool gemm_bf16_eligible(const GemmArgs& g) {
+    if (g.batch > 1 && (g.use_ptrs || g.nseg > 0 || g.sA % 4 || g.sB % 4 || g.batch > 65535)) return false;   // batched: strided operands only
     const bool al = (reinterpret_cast<uintptr_t>(g.A) % 16 == 0) && (g.nseg > 0 || reinterpret_cast<uintptr_t>(g.B) % 16 == 0);
     if (!gemm_segments_ok(g)) return false;
     if (!al || g.lda % 4 || (g.nseg == 0 && g.ldb % 4) || g.K % 4) return false;
@@ -306,14 +312,16 @@ bool gemm_bf16_eligible(const GemmArgs& g) {
 }
 
 int gemm_bf16_launch(const GemmArgs& g, int ns, hipStream_t stream) {
-    const bool narrow = g.N <= 112;
+    // column tile: 112 for narrow outputs and where it wastes less padding than 208 (N = 256: 336 instead of 416 columns)
+    const bool narrow = g.N <= 112 || ((g.N + 111) / 112) * 112 < ((g.N + 207) / 208) * 208;
     const int bn = narrow ? 112 : 208;
-    const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + bn - 1) / bn);
+    const long nb = g.batch > 1 ? g.batch : 1;
+    const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + bn - 1) / bn) * nb;
     const bool small = tiles128 < 320 && g.K < 4096;  // too few 128-row tiles (and no split-K) to fill 256 CUs twice
     const int bm = small ? 64 : 128;
-    const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
+    const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * nb;
     int splitk = 1;
-    if (tiles < 192 && g.K >= 512) {
+    if (g.batch <= 1 && tiles < 192 && g.K >= 512) {
         long s = (512 + tiles - 1) / tiles;
         const long smax = g.K / 256;
         if (s > smax) s = smax;
