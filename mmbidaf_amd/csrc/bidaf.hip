@@ -149,15 +149,6 @@ __device__ __forceinline__ float r_allsum(float v) {  // over the 16 lanes of a 
     v += __shfl_xor(v, 8);
     return v;
 }
-__device__ __forceinline__ float half_allsum(float v) {  // over the 32 lanes of a half wave
-    v += __shfl_xor(v, 16);
-    return r_allsum(v);
-}
-__device__ __forceinline__ float half_allmax(float v) {
-#pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
 __device__ __forceinline__ float f4sum(const f4 v) { return (v.x + v.y) + (v.z + v.w); }
 __device__ __forceinline__ float f4amax(const f4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 
@@ -234,86 +225,10 @@ __device__ __forceinline__ void side_times_w(const side_t& src, float in_src, co
     side_from_regs(x, dst, inv);
     in_dst = inv * in_src;
 }
-// value of the lane's features of a planes row, reconstructed to fp32 (x = (h0 + h1) * inv)
-__device__ __forceinline__ float side_dot_regs(const side_t& sd, float inv_n, const float (&x)[KT][8]) {
-    float acc = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += ((float)sd.h[kt][0][j] + (float)sd.h[kt][1][j]) * x[kt][j];
-    return acc * inv_n;
-}
-
-// ---- stage the 32-row panel starting at row p0 (a multiple of 32) of one sample's planes: 28 contiguous KiB,
-// 7 LDS-DMA wave-instructions per wave, LDS image lane-linear = the global image
-__device__ __forceinline__ void stage_panel(char* panel, const char* planes_b, int p0, int tid) {
-    const char* src = planes_b + (size_t)(p0 >> 4) * PRB + (tid & 63) * 16;
-    const int wave = tid >> 6;
-#pragma unroll
-    for (int k = 0; k < PANEL_B / 1024 / NW; ++k) {
-        const int piece = wave + NW * k;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
-                                         (__attribute__((address_space(3))) void*)(panel + piece * 1024), 16, 0, 0);
-    }
-}
 
 __device__ __forceinline__ f4 mfma_h(const half8 a, const half8 b, const f4 c) {
     // v_mfma_f32_16x16x32_f16: A[row l&15][k = 8(l>>4)+j], B[k][col l&15], C[row 4(l>>4)+e][col l&15]
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
-// S-type product of the panel's two 16-row blocks against the lane-side registers: c[mb][e] = row 16 mb + 4g + e.
-// Software-pipelined by hand: the 4 b128 reads of k tile kt+1 are issued before the 6 MFMAs of k tile kt and interleaved
-// with them (at one wave per SIMD hipcc otherwise waits out every LDS latency in front of the MFMAs that need it).
-template <bool PIPE = true>
-__device__ __forceinline__ void sprod2(const char* panel, int r, int g, const side_t& side, f4 (&c)[2]) {
-    const char* p = panel + r * 64 + ((g ^ att_swz(r)) << 4);
-    if (!PIPE) {   // register-starved kernels (3-4 lane-side operands): plain order, the compiler schedules
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            half8 a0[2], a1[2];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                a0[mb] = *reinterpret_cast<const half8*>(p + (mb * KT + kt) * PCH);
-                a1[mb] = *reinterpret_cast<const half8*>(p + (mb * KT + kt) * PCH + 1024);
-            }
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(a0[mb], side.h[kt][1], c[mb]);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(a1[mb], side.h[kt][0], c[mb]);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(a0[mb], side.h[kt][0], c[mb]);
-        }
-        return;
-    }
-    half8 fr[2][4];   // [buffer][mb * 2 + plane]
-    auto ld = [&](int kt, half8 (&x)[4]) {
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            x[2 * mb] = *reinterpret_cast<const half8*>(p + (mb * KT + kt) * PCH);
-            x[2 * mb + 1] = *reinterpret_cast<const half8*>(p + (mb * KT + kt) * PCH + 1024);
-        }
-    };
-    ld(0, fr[0]);
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        const half8(&x)[4] = fr[kt & 1];
-        if (kt + 1 < KT) ld(kt + 1, fr[(kt + 1) & 1]);
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(x[2 * mb], side.h[kt][1], c[mb]);
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(x[2 * mb + 1], side.h[kt][0], c[mb]);
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(x[2 * mb], side.h[kt][0], c[mb]);
-        if (kt + 1 < KT) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        }
-    }
 }
 
 // per-lane byte offsets of the transpose reads: lane 4q+p of a 16-lane group supplies row 4g+q, features 4p..4p+3 of the
@@ -329,49 +244,17 @@ __device__ __forceinline__ tr_off make_tr_off(int lane) {
     for (int hlf = 0; hlf < 2; ++hlf) t.o[hlf] = row * 64 + (((2 * hlf + (p >> 1)) ^ att_swz(row)) << 4) + (p & 1) * 8;
     return t;
 }
-__device__ __forceinline__ v4s tr16(const char* lds_addr) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(lds_addr));
-}
 __device__ __forceinline__ half8 cat44(const v4s lo, const v4s hi) {
     const s8v t = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(half8, t);
 }
 
-// PV-type: O[dt] += V^T[16 dt ..][32 rows] . W   with W already split into (W0, W1) (k = 8g+j <-> row as above).
-// The 4 transpose reads of feature tile dt+PVD run ahead of the 3 MFMAs of tile dt (ring of PVD+1 fragment sets).
-template <int PVD = 3>
-__device__ __forceinline__ void pvprod(const char* panel, const tr_off& tr, const half8 W0, const half8 W1, acc_t& O) {
-    v4s fr[PVD + 1][4];
-    auto ld = [&](int dt, v4s (&x)[4]) {
-        const char* base = panel + (dt >> 1) * PCH + tr.o[dt & 1];
-        x[0] = tr16(base);
-        x[1] = tr16(base + KT * PCH);
-        x[2] = tr16(base + 1024);
-        x[3] = tr16(base + KT * PCH + 1024);
-    };
-#pragma unroll
-    for (int d = 0; d < PVD; ++d) ld(d, fr[d]);
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        if (dt + PVD < DT) ld(dt + PVD, fr[(dt + PVD) % (PVD + 1)]);
-        const v4s(&x)[4] = fr[dt % (PVD + 1)];
-        const half8 A0 = cat44(x[0], x[1]), A1 = cat44(x[2], x[3]);
-        O[dt] = mfma_h(A0, W1, O[dt]);
-        O[dt] = mfma_h(A1, W0, O[dt]);
-        O[dt] = mfma_h(A0, W0, O[dt]);
-        if (dt + PVD < DT) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-    }
-}
-
-// ---- hand-pipelined forms of the two products.  hipcc, once the kernel is near its register budget, schedules the fragment
-// reads of sprod2 / pvprod right in front of the MFMAs that consume them (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, 54 waits
-// per 84 MFMAs): every MFMA then pays the LDS latency.  Here the reads are asm statements the compiler cannot move -- the
+// ---- the two products, hand-pipelined.
+//   S-type : c[mb][e] (row 16 mb + 4g + e of the panel's two 16-row blocks) += panel rows . lane-side registers
+//   PV-type: O[dt] += V^T[16 dt ..][32 rows] . W   with W already split into (W0, W1) (k = 8g+j <-> row as in tr_off)
+// Written as plain C++ (fragment reads through pointers, round 2), hipcc, once the kernel is near its register budget,
+// schedules every fragment read right in front of the MFMAs that consume it (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, 54
+// waits per 84 MFMAs): every MFMA then pays the LDS latency.  Here the reads are asm statements the compiler cannot move -- the
 // fragments of step k+1 are issued BEFORE the MFMAs of step k -- and each step waits with a counted lgkmcnt for exactly the
 // reads it consumes (a wait statement names its fragments "+v", so no consumer is scheduled above it).  The compiler does
 // not count these reads: its own LDS traffic in flight only makes a counted wait stricter (LDS returns in order), never
@@ -486,28 +369,6 @@ __device__ __forceinline__ void split_w(const f4 w0, const f4 w1, half8& H0, hal
     H1 = __builtin_bit_cast(half8, ll);
 }
 
-// workgroup-wide maximum of up to 4 non-negative per-thread values (red: >= 4 * NW floats of LDS); all threads get it
-template <int NV_>
-__device__ __forceinline__ void wg_allmax(float (&v)[NV_], float* red, int tid) {
-#pragma unroll
-    for (int k = 0; k < NV_; ++k) {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v[k] = fmaxf(v[k], __shfl_xor(v[k], o));
-    }
-    __syncthreads();
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < NV_; ++k) red[(tid >> 6) * 4 + k] = v[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NV_; ++k) {
-        float m = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) m = fmaxf(m, red[w * 4 + k]);
-        v[k] = m;
-    }
-}
 // power of two c with c * imax = 2^14 (imax = largest inverse scale, itself a power of two); 1 when there is none
 __device__ __forceinline__ float cmap(float imax) { return imax > 0.f ? WMAX / imax : 1.0f; }
 // power of two c <= 2^14 / (imax * bound): maps the largest possible |W inv_V| of a softmax-gradient operand to <= 2^14
@@ -516,25 +377,6 @@ __device__ __forceinline__ float cmap_bound(float imax, float bound) {
     if (!(den > 0.f) || !(den < 1e37f)) return 1.0f;
     const float c = WMAX / den;
     return (c > 1e-30f && c < 1e30f) ? pow2_floor(c) : 1.0f;
-}
-
-// block index -> (lane-side tile, split, sample).  Blocks are dealt round-robin over the 8 XCDs (id % 8 labels the
-// XCD group), so all blocks of one sample are given ids with equal id % 8: the panels they all stream then stay in
-// that XCD's L2.  Purely a speed choice; any mapping is correct.
-__device__ __forceinline__ void decode_block(int tiles, int splits, int B, int& tile, int& split, int& b) {
-    const int id = blockIdx.x;
-    int slot;
-    if (B % 8 == 0) {
-        const int xcd = id & 7;
-        slot = id >> 3;
-        b = xcd + 8 * (slot % (B / 8));
-        slot /= (B / 8);
-    } else {
-        b = id % B;
-        slot = id / B;
-    }
-    tile = slot % tiles;
-    split = slot / tiles;
 }
 
 // mask code of streamed row m: 0 = beyond the range, 1 = masked, 2 = live.  Prefix masks come from the lengths
@@ -1279,13 +1121,6 @@ __device__ __forceinline__ void xch_put(char* p, const half8 W0, const half8 W1)
 __device__ __forceinline__ void xch_get(const char* p, half8& W0, half8& W1) {
     W0 = *reinterpret_cast<const half8*>(p);
     W1 = *reinterpret_cast<const half8*>(p + 1024);
-}
-__device__ __forceinline__ void copy_side(side_t& d, const side_t& s) {
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        d.h[kt][0] = s.h[kt][0];
-        d.h[kt][1] = s.h[kt][1];
-    }
 }
 
 constexpr int XCH_PAIR = 4096;     // per pair: [dp1: 2 x 1 KiB][weights: 2 x 1 KiB]
