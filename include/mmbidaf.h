@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMB_VERSION 301            /* round 3 ABI: grouped attention entry points, build hash, persistent-recurrence status word */
+#define MMB_VERSION 302            /* round 3 ABI: grouped attention entry points, build hash, persistent-recurrence status word, hidden-state op */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
 #define MMB_ATT_MAX_D 208          /* attention feature width D = 2H of the fused (register-resident) kernels */
 #define MMB_ATT_GENERAL_MAX_D 4096 /* wider D (up to this) runs the general path: similarity matrix in a workspace */
@@ -243,6 +243,10 @@ int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* descs, int n, int phase,
  * counterpart (single stream, train.py:136-152). */
 int mmb_stream_create_cu_mask(int device, const uint32_t* mask, int n_words, void** stream_out);
 int mmb_stream_destroy(int device, void* stream);
+/* One idle wave that holds `stream` for `microseconds` (<= 1000): placed in front of side-stream work meant to run beside a
+ * recurrence that is launched on another stream at the same point of the dependency graph, so that the recurrence's
+ * workgroups are dispatched first also when both branches of a replayed hipGraph start together (see csrc/api.hip). */
+int mmb_stream_delay(int device, void* stream, int microseconds);
 
 /* loss = sum_k <x_k, w_k> over up to MMB_WSUM_MAX tensors of n[k] floats (w_k null: plain sum of x_k) into out[0], and its
  * gradient dx_k = g[0] * w_k (g a device scalar).  This is the synthetic objective of the throughput measurement (SURVEY.md
@@ -330,6 +334,16 @@ int mmb_highway_gate_bwd(const float* d_y, const float* x, float* gt, float* d_x
  *   0           exact-f32 MFMA (v_mfma_f32_16x16x4_f32).
  */
 int mmb_set_gemm_mode(int mode);
+
+/* Final hidden states of the modelling encoders and the decoder's initial hidden state, one launch each way (reference
+ * layers/encoding.py:101-103: h_n concatenated over the layers, rows in length-sorted order; models.py:143: decoder_hidden =
+ * sum over both encoders' layers and directions).
+ *   fwd: h[e*L + k] (B,2,H) = state of layer k of encoder e  ->  hid[e] (B,2L,H),  dec (B,H)
+ *   bwd: g_hid[e] (B,2L,H) or NULL, g_dec (B,H) or NULL  ->  d_h[e*L + k] (B,2,H) = g_hid[e][:, 2k:2k+2, :] + g_dec[:, None, :]
+ * n_enc * L <= 16. */
+int mmb_hidden_states_fwd(const float* const* h, int n_enc, int L, float* const* hid, float* dec, int B, int H, int device, void* stream);
+int mmb_hidden_states_bwd(const float* const* g_hid, const float* g_dec, float* const* d_h, int n_enc, int L, int B, int H,
+                          int device, void* stream);
 
 /* Arithmetic of every matrix-core product of the LSTM layers (input projection, recurrent product of the general-size
  * path, input and weight gradients):

@@ -141,6 +141,26 @@ extern "C" int mmb_stream_destroy(int device, void* stream) {
     return MMB_OK;
 }
 
+// One wave that holds its stream for `microseconds` of the 100 MHz wall clock and does nothing else.  The host side puts it
+// at the head of side-stream work that is meant to run BESIDE a recurrence launched on the main stream at the same point of
+// the dependency graph: enqueue order decides which kernel's workgroups are dispatched first when both are issued from the
+// host one after the other, but inside a replayed hipGraph the two branches start together, and a GEMM that wins the race
+// fills every CU -- the recurrence (2 B workgroups that need a CU each for their whole run) then starts late: 257 -> 326-364 us
+// per backward recurrence measured at cfg2.  The delay lets the recurrence's workgroups take their CUs first.
+namespace mmb {
+__global__ __launch_bounds__(64) void delay_kernel(const long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace mmb
+extern "C" int mmb_stream_delay(int device, void* stream, int microseconds) {
+    MMB_REQUIRE(microseconds >= 0 && microseconds <= 1000, "mmb_stream_delay: 0 <= microseconds <= 1000");
+    MMB_HIP(hipSetDevice(device));
+    if (microseconds > 0) hipLaunchKernelGGL(mmb::delay_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), (long long)microseconds * 100);
+    MMB_HIP(hipGetLastError());
+    return MMB_OK;
+}
+
 // Arithmetic of the LSTM layers' matrix-core products: 0 = fp32-accurate (two-term fp16 split, three products; default),
 // 1 = plain bf16 operands with fp32 accumulation (one product) -- the "bf16, MFMA LSTM gate GEMMs" form BASELINE.json's
 // H = 512 configuration names.  Process-wide; takes effect at the next call (operand planes are made per call).

@@ -794,3 +794,79 @@ extern "C" int mmb_decoder_step_bwd(const mmb_decoder_params* w, const float* en
     MMB_HIP(hipGetLastError());
     return MMB_OK;
 }
+
+// ------------------------------------------------------------------------------------------ final hidden states -> decoder h0
+// The reference concatenates the per-layer final hidden states of each modelling encoder (layers/encoding.py:101-103, rows in
+// length-sorted order) and sums BOTH encoders' states over layers and directions into the decoder's initial hidden state
+// (models.py:143).  In stock PyTorch that is 2 cat + 2 sum + 1 add kernels forward and 4 strided copies + the gradient adds
+// backward; here one launch each way.
+namespace mmb {
+constexpr int HID_MAX_PARTS = 16;
+struct HidArgs {
+    const float* h[HID_MAX_PARTS];     // fwd: per-layer states (B,2,H);        bwd: unused
+    float* hid[HID_MAX_PARTS];         // fwd: hid[e] (B,2L,H);                 bwd: d_h[e*L+k] (B,2,H)
+    const float* g_hid[HID_MAX_PARTS]; // bwd: cotangent of hid[e] or null
+    float* dec;                        // fwd: (B,H)
+    const float* g_dec;                // bwd: (B,H) or null
+    int n_enc, L, B, H;
+};
+// one thread per (sample b, feature h): loops over encoders, layers, directions
+__global__ __launch_bounds__(256) void hidden_states_fwd_kernel(const HidArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.B * a.H) return;
+    const int b = i / a.H, h = i - b * a.H;
+    float sum = 0.f;
+    for (int e = 0; e < a.n_enc; ++e)
+        for (int k = 0; k < a.L; ++k)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const float v = a.h[e * a.L + k][((size_t)b * 2 + d) * a.H + h];
+                a.hid[e][((size_t)b * 2 * a.L + 2 * k + d) * a.H + h] = v;
+                sum += v;
+            }
+    a.dec[i] = sum;
+}
+__global__ __launch_bounds__(256) void hidden_states_bwd_kernel(const HidArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.B * a.H) return;
+    const int b = i / a.H, h = i - b * a.H;
+    const float gd = a.g_dec ? a.g_dec[i] : 0.f;
+    for (int e = 0; e < a.n_enc; ++e)
+        for (int k = 0; k < a.L; ++k)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const float g = a.g_hid[e] ? a.g_hid[e][((size_t)b * 2 * a.L + 2 * k + d) * a.H + h] : 0.f;
+                a.hid[e * a.L + k][((size_t)b * 2 + d) * a.H + h] = g + gd;
+            }
+}
+}  // namespace mmb
+
+extern "C" int mmb_hidden_states_fwd(const float* const* h, int n_enc, int L, float* const* hid, float* dec, int B, int H,
+                                     int device, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MMB_REQUIRE(h && hid && dec && n_enc >= 1 && L >= 1 && n_enc * L <= mmb::HID_MAX_PARTS && B >= 1 && H >= 1,
+                "mmb_hidden_states_fwd: bad argument (n_enc * L <= %d)", mmb::HID_MAX_PARTS);
+    MMB_HIP(hipSetDevice(device));
+    mmb::HidArgs a{};
+    for (int p = 0; p < n_enc * L; ++p) { MMB_REQUIRE(h[p], "mmb_hidden_states_fwd: null state %d", p); a.h[p] = h[p]; }
+    for (int e = 0; e < n_enc; ++e) { MMB_REQUIRE(hid[e], "mmb_hidden_states_fwd: null output %d", e); a.hid[e] = hid[e]; }
+    a.dec = dec; a.n_enc = n_enc; a.L = L; a.B = B; a.H = H;
+    hipLaunchKernelGGL(mmb::hidden_states_fwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream, a);
+    MMB_HIP(hipGetLastError());
+    return MMB_OK;
+}
+
+extern "C" int mmb_hidden_states_bwd(const float* const* g_hid, const float* g_dec, float* const* d_h, int n_enc, int L, int B, int H,
+                                     int device, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    MMB_REQUIRE(g_hid && d_h && n_enc >= 1 && L >= 1 && n_enc * L <= mmb::HID_MAX_PARTS && B >= 1 && H >= 1,
+                "mmb_hidden_states_bwd: bad argument (n_enc * L <= %d)", mmb::HID_MAX_PARTS);
+    MMB_HIP(hipSetDevice(device));
+    mmb::HidArgs a{};
+    for (int e = 0; e < n_enc; ++e) a.g_hid[e] = g_hid[e];
+    for (int p = 0; p < n_enc * L; ++p) { MMB_REQUIRE(d_h[p], "mmb_hidden_states_bwd: null output %d", p); a.hid[p] = d_h[p]; }
+    a.g_dec = g_dec; a.n_enc = n_enc; a.L = L; a.B = B; a.H = H;
+    hipLaunchKernelGGL(mmb::hidden_states_bwd_kernel, dim3((B * H + 255) / 256), dim3(256), 0, stream, a);
+    MMB_HIP(hipGetLastError());
+    return MMB_OK;
+}

@@ -94,10 +94,11 @@ def lstm_direction_params(rnn, layer):
     return fwd, rev
 
 
-def encode_group(encoders, xs, lengths_list):
+def encode_group(encoders, xs, lengths_list, cat_hidden=True):
     """Run several independent RNNEncoders with the same depth and hidden size as ONE grouped
     launch per layer (models.py:97,102,113 and models.py:134-135 are independent of each other).
-    Returns [(y, h_n_sorted)] exactly as each encoder's forward would."""
+    Returns [(y, h_n_sorted)] exactly as each encoder's forward would; cat_hidden=False: h_n stays the list over layers of
+    (B,2,H) tensors (for mmbidaf_amd.functional.hidden_states, which concatenates and sums them in one launch)."""
     n = len(encoders)
     L = encoders[0].rnn.num_layers
     assert all(e.rnn.num_layers == L and e.rnn.hidden_size == encoders[0].rnn.hidden_size for e in encoders)
@@ -131,7 +132,7 @@ def encode_group(encoders, xs, lengths_list):
     results = []
     for e, y, hs, lengths in zip(encoders, inputs, h_all, lengths_list):
         y = F.dropout(y, e.drop_prob, e.training)                  # encoding.py:104, also for 1-layer encoders
-        h_n = hs[0] if len(hs) == 1 else torch.cat(hs, dim=1)      # (B,2L,H): [l0_fwd, l0_bwd, l1_fwd, l1_bwd] (Q4),
+        h_n = hs if not cat_hidden else hs[0] if len(hs) == 1 else torch.cat(hs, dim=1)   # (B,2L,H): [l0_fwd, l0_bwd, l1_fwd, l1_bwd] (Q4),
         results.append((y, h_n))                                   # rows already in length-sorted order (Q3)
     return results
 

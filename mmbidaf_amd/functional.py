@@ -30,7 +30,9 @@ def _stream():
 #      side work of the layer below the attention lands beside the attention backward -- two full-chip kernels time-slice);
 #   2  (default) phase 2 is DEFERRED until the next LSTM layer's backward call, whose first kernel is a recurrence; whatever
 #      is still deferred when autograd finishes (the input encoders' phase 2) runs on the caller's stream.  cfg2: 3.26 ->
-#      3.12 ms/step (profiles/r02_side_stream.md).
+#      3.12 ms/step (profiles/r02_side_stream.md).  Tried in round 3 and dropped: that last phase 2 on a THIRD stream behind an
+#      event recorded between the two halves of its layer's phase 1 (inside a replayed hipGraph the deferred work of the
+#      earlier layers then ran after everything else: 2.53 -> 2.81 ms/step), and the same on the side stream (no gain).
 # MMB_SIDE_CU_MASK=half|lo:hi restricts the side stream to a set of CUs (mmb_stream_create_cu_mask).  Measured: ANY stream
 # made by hipExtStreamCreateWithCUMask -- even with all 256 bits set -- runs the step at 5.0-5.3 ms, so it is not used.
 _side_streams = {}
@@ -73,6 +75,19 @@ def side_stream(device):
     return s
 
 
+_SIDE_DELAY_US = int(os.environ.get("MMB_SIDE_DELAY_US", "12"))
+
+
+def _side_head_start(dev_index, side):
+    """Side-stream work ordered behind an event recorded just BEFORE a recurrence launch is meant to run beside that
+    recurrence, on the CUs it leaves free.  Issued from the host it reaches the GPU after the recurrence; as parallel branches
+    of a replayed hipGraph the two start together, and a GEMM that wins the race takes every CU while the recurrence's
+    workgroups wait (257 -> 326-364 us per backward recurrence, profiles/r03_side_dispatch_order.md).  A few microseconds
+    of an idle wave at the head of the side work let the recurrence's workgroups be dispatched first."""
+    if _SIDE_DELAY_US > 0:
+        _lib.check(_lib.load().mmb_stream_delay(dev_index, side.cuda_stream, _SIDE_DELAY_US), "mmb_stream_delay")
+
+
 def flush_deferred(device, to_side=True, after=None):
     """Enqueue the deferred weight-gradient work of `device`: on the side stream, ordered behind everything the current
     stream holds so far -- or behind the event `after` only -- (to_side=True), or on the current stream itself."""
@@ -86,6 +101,7 @@ def flush_deferred(device, to_side=True, after=None):
         side = side_stream(key)
         if after is not None:
             side.wait_event(after)
+            _side_head_start(key, side)
         else:
             side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -219,6 +235,7 @@ def _prepare_enqueue(dev, todo, current, after):
         return
     side = side_stream(dev)
     side.wait_event(after)
+    _side_head_start(dev.index, side)
     with torch.cuda.stream(side):
         for rec in todo:
             n = len(rec.probs)
@@ -609,6 +626,52 @@ def bilstm_layer(problems):
         flat += [p[0]] + list(p[2]) + list(p[3])
     outs = _BiLSTMLayerFn.apply(lengths, hn_pos, *flat)
     return [(outs[2 * i], outs[2 * i + 1]) for i in range(len(problems))]
+
+
+class _HiddenStatesFn(torch.autograd.Function):
+    """(hid_0 .. hid_{n-1}, dec) from the per-layer final hidden states of n encoders with L layers each (reference
+    layers/encoding.py:101-103 and models.py:143): hid_e = cat over layers (B,2L,H), dec = sum over everything (B,H).
+    One library launch each way instead of 2 cat + 2 sum + 1 add (forward) and 4 strided copies + gradient adds (backward)."""
+
+    @staticmethod
+    def forward(ctx, n_enc, L, *hs):
+        lib = _lib.load()
+        assert len(hs) == n_enc * L
+        _require_gpu(*hs)
+        hs = [_f32c(h) for h in hs]
+        B, two, H = hs[0].shape
+        assert two == 2 and all(h.shape == (B, 2, H) for h in hs)
+        dev = hs[0].device
+        hids = [torch.empty(B, 2 * L, H, device=dev, dtype=torch.float32) for _ in range(n_enc)]
+        dec = torch.empty(B, H, device=dev, dtype=torch.float32)
+        hp = (ctypes.c_void_p * len(hs))(*[h.data_ptr() for h in hs])
+        op = (ctypes.c_void_p * n_enc)(*[t.data_ptr() for t in hids])
+        _lib.check(lib.mmb_hidden_states_fwd(hp, n_enc, L, op, _ptr(dec), B, H, dev.index, _stream()), "mmb_hidden_states_fwd")
+        ctx.dims = (n_enc, L, B, H, dev)
+        ctx.set_materialize_grads(False)
+        return (*hids, dec)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        n_enc, L, B, H, dev = ctx.dims
+        g_hid = [None if g is None else _f32c(g) for g in grads[:n_enc]]
+        g_dec = None if grads[n_enc] is None else _f32c(grads[n_enc])
+        d_h = [torch.empty(B, 2, H, device=dev, dtype=torch.float32) for _ in range(n_enc * L)]
+        gp = (ctypes.c_void_p * n_enc)(*[None if g is None else g.data_ptr() for g in g_hid])
+        dp = (ctypes.c_void_p * len(d_h))(*[t.data_ptr() for t in d_h])
+        _lib.check(lib.mmb_hidden_states_bwd(gp, _ptr(g_dec), dp, n_enc, L, B, H, dev.index, _stream()), "mmb_hidden_states_bwd")
+        return (None, None, *d_h)
+
+
+def hidden_states(per_layer):
+    """per_layer: list over encoders of the list over layers of h_n (B,2,H) (rows in the reference's length-sorted order).
+    Returns ([hid_e (B,2L,H)], dec (B,H)): the encoders' concatenated final states and their sum over encoders, layers and
+    directions -- the decoder's initial hidden state (models.py:143)."""
+    n_enc, L = len(per_layer), len(per_layer[0])
+    assert all(len(p) == L for p in per_layer)
+    outs = _HiddenStatesFn.apply(n_enc, L, *[h for p in per_layer for h in p])
+    return list(outs[:n_enc]), outs[n_enc]
 
 
 def set_precision(mode):

@@ -27,5 +27,6 @@ class HotRegion(nn.Module):
 
     def forward(self, x_text, x_aud, x_img, text_len, aud_len, img_len):
         """-> (mod_text_audio (B,T,2H), hidden_a (B,4,H), mod_text_image, hidden_i, decoder_hidden (B,1,H))"""
-        mod_a, hid_a, mod_i, hid_i, _ = self.hot_path(x_text, x_aud, x_img, text_len, aud_len, img_len)
-        return mod_a, hid_a, mod_i, hid_i, (hid_a.sum(1) + hid_i.sum(1)).unsqueeze(1)
+        mod_a, hid_a, mod_i, hid_i, _, dec_hidden = self.hot_path(x_text, x_aud, x_img, text_len, aud_len, img_len,
+                                                                   with_decoder_hidden=True)
+        return mod_a, hid_a, mod_i, hid_i, dec_hidden

@@ -7,12 +7,17 @@ co-scheduled in grouped launches.  Everything else is the surrounding graph in s
 PyTorch-ROCm; the decoder loss is gathered on the device instead of the reference's
 per-sample `int(tensor)` host syncs (same values).
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from .attention import BiDAFAttention, MultimodalAttentionDecoder
 from .encoding import Embedding, ImageEmbedding, RNNEncoder, encode_group, to_device_cached
+from . import functional as MF
 from .functional import PrefixMask
+
+_FUSED_HIDDEN = os.environ.get("MMB_FUSED_HIDDEN", "1") != "0"     # 0: torch.cat / sum / add as in the reference (ablation)
 
 
 class MMBiDAF(nn.Module):
@@ -40,9 +45,10 @@ class MMBiDAF(nn.Module):
         lens = torch.as_tensor(X_len, dtype=torch.long)
         return torch.arange(X.size(1)).unsqueeze(0) < lens.unsqueeze(1)
 
-    def hot_path(self, text_emb, audio_emb, image_emb, text_lengths, audio_lengths, image_lengths):
+    def hot_path(self, text_emb, audio_emb, image_emb, text_lengths, audio_lengths, image_lengths, with_decoder_hidden=False):
         """models.py:97,102,113,116-118,131-135: returns the two modality-aware encodings and
-        their (length-sorted) final hidden states."""
+        their (length-sorted) final hidden states (+ the text mask); with_decoder_hidden=True appends the decoder's initial
+        hidden state (B,1,H) = sum of both encoders' final states over layers and directions (models.py:143)."""
         (text_enc, _), (audio_enc, _), (image_enc, _) = encode_group(
             [self.text_enc, self.audio_enc, self.image_enc], [text_emb, audio_emb, image_emb],
             [text_lengths, audio_lengths, image_lengths])
@@ -64,8 +70,18 @@ class MMBiDAF(nn.Module):
         else:
             att_audio = self.bidaf_att_audio(text_enc, audio_enc, text_mask, audio_mask)
             att_image = self.bidaf_att_image(text_enc, image_enc, text_mask, image_mask)
-        (mod_a, hid_a), (mod_i, hid_i) = encode_group([self.mod_t_a, self.mod_t_i], [att_audio, att_image],
-                                                      [text_lengths, text_lengths])
+        if dev.type == "cuda" and _FUSED_HIDDEN:
+            # per-layer final states -> (B,2L,H) per encoder and the decoder's initial hidden state (models.py:143) in ONE launch
+            (mod_a, hs_a), (mod_i, hs_i) = encode_group([self.mod_t_a, self.mod_t_i], [att_audio, att_image],
+                                                        [text_lengths, text_lengths], cat_hidden=False)
+            (hid_a, hid_i), dec_hidden = MF.hidden_states([hs_a, hs_i])
+            dec_hidden = dec_hidden.unsqueeze(1)
+        else:
+            (mod_a, hid_a), (mod_i, hid_i) = encode_group([self.mod_t_a, self.mod_t_i], [att_audio, att_image],
+                                                          [text_lengths, text_lengths])
+            dec_hidden = (hid_a.sum(1) + hid_i.sum(1)).unsqueeze(1)
+        if with_decoder_hidden:
+            return mod_a, hid_a, mod_i, hid_i, text_mask, dec_hidden
         return mod_a, hid_a, mod_i, hid_i, text_mask
 
     def forward(self, embedded_text, original_text_lengths, embedded_audio, original_audio_lengths,
@@ -78,13 +94,15 @@ class MMBiDAF(nn.Module):
         image_feat = self.image_keyframes_emb(frames).reshape(B, transformed_images.size(1), -1)
         image_emb = self.i_emb(image_feat)
 
-        mod_a, hid_a, mod_i, hid_i, text_mask = self.hot_path(
-            text_emb, audio_emb, image_emb, original_text_lengths, original_audio_lengths, original_image_lengths)
+        mod_a, hid_a, mod_i, hid_i, text_mask, dec_hidden = self.hot_path(
+            text_emb, audio_emb, image_emb, original_text_lengths, original_audio_lengths, original_image_lengths,
+            with_decoder_hidden=True)
 
         return self.decode(embedded_text, text_emb.size(1), mod_a, hid_a, mod_i, hid_i, text_mask,
-                           batch_target_indices, max_dec_len)
+                           batch_target_indices, max_dec_len, decoder_hidden=dec_hidden)
 
-    def decode(self, embedded_text, T, mod_a, hid_a, mod_i, hid_i, text_mask, batch_target_indices, max_dec_len):
+    def decode(self, embedded_text, T, mod_a, hid_a, mod_i, hid_i, text_mask, batch_target_indices, max_dec_len,
+               decoder_hidden=None):
         """Pointer decoder loop with coverage (reference models.py:120-206): teacher forcing when training, greedy
         otherwise.  On the GPU every decode step is ONE fused kernel (mmbidaf_amd/decoder.py) and
         the per-sample loss terms are gathered on the device (same values as the reference's per-sample Python
@@ -96,7 +114,8 @@ class MMBiDAF(nn.Module):
         pad = torch.zeros(B, self.max_transcript_length - text_mask.size(1), dtype=text_mask.dtype, device=dev)
         decoder_mask = torch.cat((text_mask, pad), dim=1)
         # the reference sums the (length-sorted) hidden states over layers and directions, models.py:143
-        decoder_hidden = (hid_a.sum(1) + hid_i.sum(1)).unsqueeze(1)
+        if decoder_hidden is None:
+            decoder_hidden = (hid_a.sum(1) + hid_i.sum(1)).unsqueeze(1)
         eps = 1e-12
         rows = torch.arange(B, device=dev)
         targets = batch_target_indices.to(dev).reshape(B, -1).long()

@@ -548,6 +548,33 @@ def test_rnn_encoder_general_hidden_size_vs_oracle():
             close(p.grad, P[n[4:]].grad, "grad " + n)
 
 
+def test_hidden_states_op_matches_cat_and_sum():
+    """mmb_hidden_states_fwd/bwd (layers/encoding.py:101-103 cat over layers; models.py:143 sum into the decoder's h0): values,
+    and gradients with every cotangent present and with some of them absent."""
+    from mmbidaf_amd import functional as MF
+    g = torch.Generator().manual_seed(77)
+    B, H, L = 5, 36, 3
+    hs = [[torch.randn(B, 2, H, generator=g) for _ in range(L)] for _ in range(2)]
+    for use in ((True, True, True), (True, False, True), (False, False, True), (False, True, False)):
+        leaves = [[h.clone().to(dev()).requires_grad_(True) for h in e] for e in hs]
+        ref = [[h.clone().requires_grad_(True) for h in e] for e in hs]
+        (hid_a, hid_i), dec = MF.hidden_states(leaves)
+        r_a, r_i = torch.cat(ref[0], dim=1), torch.cat(ref[1], dim=1)
+        r_dec = r_a.sum(1) + r_i.sum(1)
+        close(hid_a, r_a.detach(), "hid_a")
+        close(hid_i, r_i.detach(), "hid_i")
+        close(dec, r_dec.detach(), "dec_hidden")
+        cots = [torch.randn(B, 2 * L, H, generator=g), torch.randn(B, 2 * L, H, generator=g), torch.randn(B, H, generator=g)]
+        outs, routs = [hid_a, hid_i, dec], [r_a, r_i, r_dec]
+        sel = [k for k in range(3) if use[k]]
+        torch.autograd.backward([outs[k] for k in sel], [cots[k].to(dev()) for k in sel])
+        torch.autograd.backward([routs[k] for k in sel], [cots[k] for k in sel])
+        for e in range(2):
+            for k in range(L):
+                rg = ref[e][k].grad if ref[e][k].grad is not None else torch.zeros(B, 2, H)   # (no cotangent reaches it)
+                close(leaves[e][k].grad, rg, f"d_h[{e}][{k}] with cotangents {use}")
+
+
 def test_general_hidden_size_persistent_recurrence_is_what_runs_and_never_times_out():
     """128 < H <= 512 with a grid that fits the chip runs the PERSISTENT recurrence (lstm_fs.hip: one launch per layer call,
     bounded-spin chain barrier per step).  The library's per-kernel event hook sees ONE forward and ONE backward recurrence

@@ -44,6 +44,7 @@ def stats(d):
 def timeline(d, which=-2):
     """One step of the kernel trace as a timeline (start offset, duration, queue) + how much of it ran two-deep.
     A step ends with the last `lstm_unpack_dw_kernel` before the first forward recurrence that follows a backward one."""
+    which = int(which)      # (index of the step in the trace; a replayed-graph step sits in the middle of a bench.py run)
     rows = []
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         rows += list(csv.DictReader(open(f)))
