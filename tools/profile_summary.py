@@ -51,9 +51,9 @@ def timeline(d, which=-2):
     ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?")) for r in rows))
     cuts, seen_bwd = [0], False
     for i, e in enumerate(ev):
-        if e[2].startswith("lstm_rec_bwd"):
+        if e[2].startswith(("lstm_rec_bwd", "lstm_fs_bwd")):
             seen_bwd = True
-        if e[2].startswith("lstm_rec_fwd") and seen_bwd:
+        if e[2].startswith(("lstm_rec_fwd", "lstm_fs_fwd")) and seen_bwd:
             # the previous step ends with the last weight-gradient unpack kernel before this recurrence
             j = i
             while j > 0 and not ev[j - 1][2].startswith("lstm_unpack_dw"):
