@@ -606,6 +606,30 @@ def test_general_hidden_size_persistent_recurrence_is_what_runs_and_never_times_
     assert lib.mmb_lstm_persist_timeouts() == 0
 
 
+@pytest.mark.parametrize("B,H,T", [(70, 256, 9), (33, 192, 14), (130, 136, 6)])
+def test_persistent_recurrence_with_several_sample_blocks_vs_oracle(B, H, T):
+    """Batches above one sample block of the persistent recurrence (64 samples forward, 32 / 16 backward): the exchange
+    buffers, arrival counts and fragment offsets of sample blocks > 0, ragged lengths, B not a multiple of the block."""
+    from mmbidaf_amd.encoding import RNNEncoder
+    from mmbidaf_amd import _lib
+    g = torch.Generator().manual_seed(1000 + B)
+    torch.manual_seed(B)
+    e = RNNEncoder(20, H, 1).to(dev())
+    x = torch.randn(B, T, 20, generator=g) * 0.5
+    l = [T] + [int(v) for v in torch.randint(1, T + 1, (B - 1,), generator=g)]
+    xd = x.to(dev()).requires_grad_(True)
+    y, h = e(xd, l)
+    cy, ch = torch.randn(*y.shape, generator=g), torch.randn(*h.shape, generator=g)
+    ((y * cy.to(dev())).sum() + (h * ch.to(dev())).sum()).backward()
+    yr, hr, dxr, P = _oracle_encoder(e, x, l, cy, ch)
+    close(y, yr, "y")
+    close(h, hr, "h_n")
+    close(xd.grad, dxr, "d_x")
+    for n, p in e.named_parameters():
+        close(p.grad, P[n[4:]].grad, "grad " + n)
+    assert _lib.load().mmb_lstm_persist_timeouts() == 0
+
+
 def test_general_hidden_size_launch_per_step_form_still_matches_the_oracle():
     """MMB_LSTM_FS_PERSIST=0 (read once per process, hence a child process): the launch-per-step kernels that grids larger
     than the chip fall back to run the same oracle comparison."""
