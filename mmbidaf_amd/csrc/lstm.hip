@@ -501,8 +501,16 @@ static int gx_planes_group(const mmb_lstm_fwd_desc* d, const int* idx, int m, hi
         g.C = p.gx; g.ldc = 8 * H; g.bias = bias; g.M = (int)BT; g.N = 8 * H; g.K = L.Ip;
         g.np = np; g.a_inv = xinv; g.b_inv = winv;
     }
-    if (int rc = planes_split_rows_group(sx, m, stream)) return rc;
-    if (int rc = planes_split_rows_group(sw, m, stream)) return rc;
+    if (2 * m <= MMB_MAX_GROUP) {
+        // activations and weights have the same padded width, hence the same split variant: ONE launch for all 2 m passes (the
+        // weight passes' few row blocks ride along; as a launch of their own they cost 5-10 us on the critical path each)
+        SplitRowsArgs all[MMB_MAX_GROUP];
+        for (int k = 0; k < m; ++k) { all[k] = sx[k]; all[m + k] = sw[k]; }
+        if (int rc = planes_split_rows_group(all, 2 * m, stream)) return rc;
+    } else {
+        if (int rc = planes_split_rows_group(sx, m, stream)) return rc;
+        if (int rc = planes_split_rows_group(sw, m, stream)) return rc;
+    }
     return planes_gemm_group(gs, m, stream);
 }
 
