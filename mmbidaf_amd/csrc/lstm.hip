@@ -389,9 +389,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // d_w_cat (8H, I+2H) -> d_w_ih (2,4H,I), d_w_hh (2,4H,H): rows [dir*4H..), columns [0,I) | [I + dir*H, +H);
 // with db_part, also d_b (2,4H) = sum over the B samples of the recurrence's per-sample partials
-__global__ __launch_bounds__(256) void lstm_unpack_dw_kernel(const float* __restrict__ cat, float* __restrict__ d_w_ih,
-                                                             float* __restrict__ d_w_hh, int H, int I,
-                                                             const float* __restrict__ db_part, float* __restrict__ d_b, int B) {
+struct UnpackProb { const float* cat; float* d_w_ih; float* d_w_hh; const float* db_part; float* d_b; int I, B; };
+struct UnpackArgs { UnpackProb p[MMB_MAX_GROUP]; int H; };
+// (grid.y = problem of a grouped layer call: one launch for all of them)
+__global__ __launch_bounds__(256) void lstm_unpack_dw_kernel(const UnpackArgs args) {
+    const UnpackProb& P = args.p[blockIdx.y];
+    const float* __restrict__ cat = P.cat;
+    float* __restrict__ d_w_ih = P.d_w_ih;
+    float* __restrict__ d_w_hh = P.d_w_hh;
+    const float* __restrict__ db_part = P.db_part;
+    float* __restrict__ d_b = P.d_b;
+    const int H = args.H, I = P.I, B = P.B;
     const int ldc = I + 2 * H;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (db_part && idx < 8 * H) {
@@ -685,13 +693,16 @@ static int grads_planes_group(const mmb_lstm_bwd_desc* d, const int* idx, int m,
         for (int k = 0; k < m; ++k) gw[k].prezeroed = ksplit[k] ? 1 : 0;
         if (int rc = planes_gemm_group(gw, m, stream)) return rc;
         ProfScope ps_(MMB_K_GEMM, stream);
+        UnpackArgs ua{};
+        ua.H = d[idx[0]].H;
+        int max_total = 0;
         for (int k = 0; k < m; ++k) {
             const mmb_lstm_bwd_desc& p = d[idx[k]];
-            const int H = p.H, I = p.I;
-            const int total = 8 * H * (I + 2 * H);
-            hipLaunchKernelGGL(lstm_unpack_dw_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.d_w_cat, p.d_w_ih, p.d_w_hh, H, I,
-                               db_partials ? reinterpret_cast<const float*>(ws[k] + L[k].dbp) : static_cast<const float*>(nullptr), p.d_b, p.B);
+            ua.p[k] = UnpackProb{p.d_w_cat, p.d_w_ih, p.d_w_hh,
+                                 db_partials ? reinterpret_cast<const float*>(ws[k] + L[k].dbp) : static_cast<const float*>(nullptr), p.d_b, p.I, p.B};
+            max_total = max(max_total, 8 * p.H * (p.I + 2 * p.H));
         }
+        hipLaunchKernelGGL(lstm_unpack_dw_kernel, dim3((max_total + 255) / 256, m), dim3(256), 0, stream, ua);
         MMB_HIP(hipGetLastError());
     }
     if (phase & 1) {
@@ -887,8 +898,10 @@ extern "C" int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* d, int n, int
                 if (rc) return rc;
                 const int total = 8 * H * (p.I + 2 * H);
                 ProfScope ps_(MMB_K_GEMM, stream);
-                hipLaunchKernelGGL(lstm_unpack_dw_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.d_w_cat, p.d_w_ih,
-                                   p.d_w_hh, H, p.I, static_cast<const float*>(nullptr), p.d_b, p.B);
+                UnpackArgs ua{};
+                ua.H = H;
+                ua.p[0] = UnpackProb{p.d_w_cat, p.d_w_ih, p.d_w_hh, static_cast<const float*>(nullptr), p.d_b, p.I, p.B};
+                hipLaunchKernelGGL(lstm_unpack_dw_kernel, dim3((total + 255) / 256, 1), dim3(256), 0, stream, ua);
                 MMB_HIP(hipGetLastError());
                 fused = true;
             }
