@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMB_VERSION 302            /* round 3 ABI: grouped attention entry points, build hash, persistent-recurrence status word, hidden-state op */
+#define MMB_VERSION 303            /* round 3 ABI: grouped attention entry points, build hash, persistent-recurrence status word, hidden-state op */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
 #define MMB_ATT_MAX_D 208          /* attention feature width D = 2H of the fused (register-resident) kernels */
 #define MMB_ATT_GENERAL_MAX_D 4096 /* wider D (up to this) runs the general path: similarity matrix in a workspace */
@@ -180,14 +180,17 @@ typedef struct {
     float* cs;                 /* (B,T,2,H)   cell state after each step                         */
     void* ws;                  /* scratch of mmb_bilstm_ws_bytes(B,T,I,H,0) bytes (operand planes) or NULL          */
     const int32_t* hn_pos;     /* (B) or NULL                                                                        */
-    float* x_absmax;           /* (2) must be 0 on entry; receives [max |x|, max |W_ih|] (saved: the backward's     */
-                               /* transposed fp16 planes are scaled by them); may be NULL when ws is NULL            */
+    float* x_absmax;           /* (mmb_bilstm_absmax_floats(B,T,H)) receives the per-row-block maxima of |x| and of the */
+                               /* stacked |W_ih| (plain stores: no initialisation needed; saved: the backward's      */
+                               /* transposed fp16 planes are scaled by their maximum); may be NULL when ws is NULL   */
     int32_t B, T, I, H;
 } mmb_lstm_fwd_desc;
 
 /* bytes of the optional operand-plane scratch of one problem (backward != 0: for mmb_bilstm_layer_bwd).  With it (and
  * I, H multiples of 4) the layer's GEMMs run on the 16-bit matrix cores from error-compensated splits (fp32-level accuracy);
  * without it they run on the exact-f32 MFMA kernels. */
+/* floats of desc.x_absmax: ceil(B*T/16) + ceil(8H/16) */
+size_t mmb_bilstm_absmax_floats(int B, int T, int H);
 size_t mmb_bilstm_ws_bytes(int B, int T, int I, int H, int backward);
 
 int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* descs, int n, int device, void* stream);
@@ -214,7 +217,7 @@ typedef struct {
                                /* d_w_hh with ONE GEMM against [x | y_fwd(t-1) | y_rev(t+1)]     */
     void* ws;                  /* scratch of mmb_bilstm_ws_bytes(B,T,I,H,1) bytes or NULL        */
     const int32_t* hn_pos;     /* (B) or NULL: layout of d_hn, as in the forward desc             */
-    const float* x_absmax;     /* (2) as left by the forward call                                 */
+    const float* x_absmax;     /* as left by the forward call                                     */
     int32_t B, T, I, H;
 } mmb_lstm_bwd_desc;
 

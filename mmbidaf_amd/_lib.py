@@ -16,7 +16,7 @@ ATT_GENERAL_MAX_D = 4096     # general path (similarity matrix in a workspace)
 LSTM_MAX_H = 128            # register-resident recurrence (one launch per layer)
 LSTM_GENERAL_MAX_H = 1024   # general recurrence (one launch per time step)
 
-ABI_VERSION = 302           # MMB_VERSION the signatures below were written for (include/mmbidaf.h)
+ABI_VERSION = 303           # MMB_VERSION the signatures below were written for (include/mmbidaf.h)
 
 c_f = ctypes.c_void_p  # device pointers travel as raw addresses
 c_i = ctypes.c_int
@@ -94,6 +94,7 @@ SIGNATURES = {
     "mmb_hidden_states_fwd": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_i, ctypes.POINTER(ctypes.c_void_p), c_f, c_i, c_i, c_i, c_f]),
     "mmb_hidden_states_bwd": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_i, c_i, c_f]),
     "mmb_bilstm_ws_bytes": (ctypes.c_size_t, [c_i] * 5),
+    "mmb_bilstm_absmax_floats": (ctypes.c_size_t, [c_i] * 3),
     "mmb_gemm_nt_planes": (c_i, [c_f] * 4 + [c_i] * 3 + [c_f, ctypes.c_size_t, c_i, c_f]),
     "mmb_weighted_sums_ws_bytes": (ctypes.c_size_t, [ctypes.POINTER(ctypes.c_long), c_i]),
     "mmb_weighted_sums_fwd": (c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_long), c_i,

@@ -131,7 +131,8 @@ struct SplitRowsArgs {
     float* bias_out;
     int np;
     float* inv_out;      // np == 2: (R) 1/s of every plane row
-    float* absmax_out;   // np == 2, optional: max |x| over the whole matrix is atomically max-ed into this (pre-zeroed) float
+    float* absmax_out;   // np == 2, optional: max |x| over the whole matrix is atomically max-ed into this (pre-zeroed) float,
+    int absmax_partials; // or (absmax_partials != 0) absmax_out[row block] = that block's max |x|: ceil(R / 16) plain stores, no zeroing needed
     // np == 2, optional: ONE power-of-two scale for the whole tensor from an upper bound of max |x| = the maximum of the
     // tensor_absmax_n floats at tensor_absmax (partials written by the producer) instead of one scale per row: such planes
     // can also be read k-major (transpose reads) by a GEMM that contracts over the ROWS (PlanesGemmArgs::ta)

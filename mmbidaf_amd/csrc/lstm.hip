@@ -495,13 +495,14 @@ static int gx_planes_group(const mmb_lstm_fwd_desc* d, const int* idx, int m, hi
         x = SplitRowsArgs{};
         x.src1 = p.x; x.src2 = p.x; x.R1 = (int)BT; x.R = (int)BT; x.C = p.I; x.ld = p.I; x.Cp = L.Ip; x.gate_H = 0;
         x.planes = xP;
-        x.np = np; x.inv_out = xinv; x.absmax_out = p.x_absmax;   // max |x| is saved for the backward's transposed planes
+        const int nbx = (int)((BT + 15) / 16);    // x_absmax = [per-row-block maxima of x | of the stacked W_ih]: plain stores, no zeroing
+        x.np = np; x.inv_out = xinv; x.absmax_out = p.x_absmax; x.absmax_partials = 1;   // saved for the backward's transposed planes
         SplitRowsArgs& w = sw[k];
         w = SplitRowsArgs{};
         w.src1 = p.w_ih[0]; w.src2 = p.w_ih[1]; w.R1 = 4 * H; w.R = 8 * H; w.C = p.I; w.ld = p.I; w.Cp = L.Ip; w.gate_H = H;
         w.planes = wP;
         w.b1a = p.b_ih[0]; w.b2a = p.b_hh[0]; w.b1b = p.b_ih[1]; w.b2b = p.b_hh[1]; w.bias_out = bias;
-        w.np = np; w.inv_out = winv; w.absmax_out = p.x_absmax ? p.x_absmax + 1 : nullptr;   // max |W_ih| for the backward's W^T planes
+        w.np = np; w.inv_out = winv; w.absmax_out = p.x_absmax ? p.x_absmax + nbx : nullptr; w.absmax_partials = 1;   // max |W_ih| for the backward's W^T planes
         PlanesGemmArgs& g = gs[k];
         g = PlanesGemmArgs{};
         g.A = xP;
@@ -595,7 +596,7 @@ static int grads_planes_group(const mmb_lstm_bwd_desc* d, const int* idx, int m,
             t.seg_ptr[2] = p.y + H; t.seg_ld[2] = 2 * H; t.seg_cols[2] = H; t.seg_shift[2] = +1;
             t.R = p.B * p.T; t.period = p.T; t.Rp = L[k].BTp; t.Ctot = I + 2 * H; t.planes = reinterpret_cast<bf16_t*>(ws[k] + L[k].xcT);
             t.np = np; t.inv_out = reinterpret_cast<float*>(ws[k] + L[k].xcTinv);
-            t.seg_absmax[0] = p.x_absmax; t.seg_absmax_n[0] = 1;       // max |x|, recorded by the forward's split pass
+            t.seg_absmax[0] = p.x_absmax; t.seg_absmax_n[0] = (int)(((long)p.B * p.T + 15) / 16);   // max |x| per row block, recorded by the forward's split pass
             t.seg_bound[1] = 1.0f; t.seg_bound[2] = 1.0f;               // |h| = |o * tanh(c)| < 1
             if (ksplit[k]) { t.zero_ptr = p.d_w_cat; t.zero_n = (long)8 * H * (I + 2 * H); }
         }
@@ -617,7 +618,7 @@ static int grads_planes_group(const mmb_lstm_bwd_desc* d, const int* idx, int m,
             t.nseg = 1; t.seg_ptr[0] = p.w_ih[0]; t.seg_ld[0] = I; t.seg_cols[0] = I; t.seg_shift[0] = 0;
             t.stack_ptr = p.w_ih[1]; t.stack_R1 = 4 * H;
             t.R = 8 * H; t.period = 1; t.Rp = L[k].K8; t.Ctot = I; t.planes = reinterpret_cast<bf16_t*>(ws[k] + L[k].wT);
-            t.np = np; t.seg_absmax[0] = p.x_absmax ? p.x_absmax + 1 : nullptr; t.seg_absmax_n[0] = 1;
+            t.np = np; t.seg_absmax[0] = p.x_absmax ? p.x_absmax + ((long)p.B * p.T + 15) / 16 : nullptr; t.seg_absmax_n[0] = (8 * H + 15) / 16;
             t.inv_out = reinterpret_cast<float*>(ws[k] + L[k].wTinv);
         }
         return planes_split_transpose_group(tw, ndx, stream);
@@ -739,6 +740,11 @@ static int grads_planes_group(const mmb_lstm_bwd_desc* d, const int* idx, int m,
 }  // namespace mmb
 
 using namespace mmb;
+
+extern "C" size_t mmb_bilstm_absmax_floats(int B, int T, int H) {
+    if (B < 1 || T < 1 || H < 1) return 0;
+    return (size_t)(((long)B * T + 15) / 16 + (8 * H + 15) / 16);
+}
 
 extern "C" size_t mmb_bilstm_ws_bytes(int B, int T, int I, int H, int backward) {
     if (B < 1 || T < 1 || I < 1 || H < 1 || I % 4 || H % 4) return 0;

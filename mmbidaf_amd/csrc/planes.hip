@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsGroup G)
 // inverse to inv_out, the block maximum to absmax_out); pass 2 re-reads the block (L2-resident: 16 rows) and writes the
 // two fp16 planes of the scaled values.
 __global__ __launch_bounds__(256) void split_rows16_kernel(const SplitRowsGroup G) {
-    __shared__ float sc[16];
+    __shared__ float sc[16], bmx[16];
     const SplitRowsArgs& a = G.a[blockIdx.y];
     const int nkt = a.Cp / 32;
     const int rb = blockIdx.x, t = threadIdx.x;
@@ -165,10 +165,17 @@ __global__ __launch_bounds__(256) void split_rows16_kernel(const SplitRowsGroup 
             const float s = pow2_scale(amax);
             sc[rl] = s;
             if (dr < a.R) a.inv_out[dr] = 1.0f / s;
-            if (a.absmax_out && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.absmax_out), __float_as_uint(amax));
+            if (a.absmax_out && !a.absmax_partials && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.absmax_out), __float_as_uint(amax));
+            if (a.absmax_out && a.absmax_partials) bmx[rl] = dr < a.R ? amax : 0.f;
         }
     }
     __syncthreads();
+    if (a.absmax_out && a.absmax_partials && t == 0 && rb * 16 < a.R) {
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m = fmaxf(m, bmx[i]);
+        a.absmax_out[rb] = m;
+    }
     const int lane = t & 63, wave = t >> 6;
     const int rl = lane >> 2, dr = rb * 16 + rl;
     const float* base = nullptr;
@@ -237,8 +244,14 @@ __global__ __launch_bounds__(256) void split_rows16_reg_kernel(const SplitRowsGr
     const float s = pow2_scale(rmax);
     if (wave == 0 && (lane & 3) == 0 && dr < a.R) {
         a.inv_out[dr] = 1.0f / s;
-        if (a.absmax_out && rmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.absmax_out), __float_as_uint(rmax));
+        if (a.absmax_out && !a.absmax_partials && rmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.absmax_out), __float_as_uint(rmax));
         if (a.bias_out) a.bias_out[dr] = second ? a.b1b[lr] + a.b2b[lr] : a.b1a[lr] + a.b2a[lr];
+    }
+    if (a.absmax_out && a.absmax_partials && wave == 0 && rb * 16 < a.R) {   // the block's maximum: over the 16 rows (lanes 4 rl)
+        float bm = dr < a.R ? rmax : 0.f;
+#pragma unroll
+        for (int o = 4; o <= 32; o <<= 1) bm = fmaxf(bm, __shfl_xor(bm, o));
+        if (lane == 0) a.absmax_out[rb] = bm;
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {

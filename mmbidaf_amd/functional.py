@@ -464,7 +464,13 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         dev = flat[0].device
         ctx.set_materialize_grads(False)     # an unused output (h_n of the input encoders) arrives as None, not as a zero fill
         _drop_stale_deferred(dev.index)
-        x_absmax = torch.zeros(n, 2, device=dev, dtype=torch.float32)    # [max |x|, max |W_ih|] per problem, filled by the library
+        # per problem: the row-block maxima of |x| and |W_ih| the library's split pass records for the backward's planes
+        # (plain stores: nothing to zero -- a fill kernel per layer call on the critical path before)
+        am_n = [int(lib.mmb_bilstm_absmax_floats(flat[i * _PER_PROBLEM].shape[0], flat[i * _PER_PROBLEM].shape[1],
+                                                 flat[i * _PER_PROBLEM + 2].shape[1])) for i in range(n)]
+        am_flat = torch.empty(sum(am_n), device=dev, dtype=torch.float32)
+        am_off = [sum(am_n[:i]) for i in range(n)]
+        x_absmax = [am_flat[am_off[i]:am_off[i] + am_n[i]] for i in range(n)]
         for i in range(n):
             x, *ws_ = flat[i * _PER_PROBLEM:(i + 1) * _PER_PROBLEM]
             _require_gpu(x, *ws_)
