@@ -110,8 +110,16 @@ def flush_deferred(device, to_side=True, after=None):
                 for t in tensors:
                     t.record_stream(side)
     else:
+        # operands prepared on the side stream: a weight-gradient phase waits for the event behind ITS preparation (long
+        # past) rather than for everything the side stream still holds (the previous layer's weight-gradient GEMM, which would
+        # put ~20 us of idle main stream in front of the last phase of the pass); anything else waits for the side stream
         if key in _side_streams:
-            main.wait_stream(_side_streams[key])     # operands prepared on the side stream
+            if all(hasattr(fn, "prepared") for fn, _ in todo):
+                for fn, _ in todo:
+                    if fn.prepared is not None:
+                        main.wait_event(fn.prepared)
+            else:
+                main.wait_stream(_side_streams[key])
         for fn, _ in todo:
             fn(main)
 
@@ -601,6 +609,7 @@ class _BiLSTMLayerFn(torch.autograd.Function):
                     _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 2 | flags, dev.index, stream.cuda_stream), "mmb_bilstm_layer_bwd_phase(2)")
                     with torch.cuda.stream(stream):
                         d_b_dup.copy_(d_b_flat)
+                phase2.prepared = prep.event if (flags and prep is not None) else None
                 _deferred.setdefault(dev.index, []).append((phase2, touched + [d_b_dup]))
             else:
                 side = side_stream(dev)
