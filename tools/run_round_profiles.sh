@@ -12,6 +12,8 @@ rm -rf $R/gpurun_out/prof_stats
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats -o trace --output-format csv -- $B > $R/gpurun_out/${TAG}_rocprof_bench.json 2> $R/gpurun_out/${TAG}_rocprof.err
 python3 $R/tools/profile_summary.py stats $R/gpurun_out/prof_stats > $R/gpurun_out/${TAG}_kernel_stats.md
 python3 $R/tools/profile_summary.py timeline $R/gpurun_out/prof_stats > $R/gpurun_out/${TAG}_timeline.md
+# (the default picks one of the eagerly issued, instrumented steps at the end of the run; step 6 is a REPLAYED graph step)
+python3 $R/tools/profile_summary.py timeline $R/gpurun_out/prof_stats 6 > $R/gpurun_out/${TAG}_timeline_graph.md
 rm -rf $R/gpurun_out/prof_stats
 echo "stats done"
 for C in FETCH_SIZE WRITE_SIZE; do
