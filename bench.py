@@ -283,7 +283,10 @@ def main():
         raise SystemExit("--graph: fixed lengths, no --profile-all / --eager")
     # eager: buckets launched from grad hooks so that the exchange overlaps the rest of the backward pass; graph: the
     # collectives stay outside the captured step and follow each replay
-    sync = ddp.FlatGradAllReduce(params, buckets=ddp.region_buckets(region), overlap=not want_graph, defer_fn=MF.defer_grad_work)
+    # (graph replay: nothing to overlap with -- ONE bucket, i.e. one packing kernel, one all-reduce of the whole 9.7 MB flat
+    #  gradient and one copy back per step instead of one of each per bucket, all issued from the host behind the replay)
+    sync = ddp.FlatGradAllReduce(params, buckets=None if want_graph else ddp.region_buckets(region), overlap=not want_graph,
+                                 defer_fn=MF.defer_grad_work)
     sync.broadcast_parameters()
     batch = synth.make_batch(a.config, rank=rank, ragged=a.ragged, device=dev, batch=B)
     xs = [batch[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]  # they come from trainable embeddings
