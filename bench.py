@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--fresh-lengths", action="store_true",
                     help="new ragged lengths every step (the host-derived masks / sort orders miss the device cache, as in real training)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs the default single-GPU run appends (cfg4, cfg5 bf16, ragged, training mode, eager with fresh lengths)")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"],
                     help="arithmetic of the LSTM layers' matrix-core products: f32 = fp32-accurate split (default; the metric "
                          "configuration), bf16 = bf16 operands, one product (default for cfg5, which BASELINE.json names as bf16)")
@@ -248,21 +250,21 @@ def attention_roofline(a, prof, B, T, Ma, Mi, D, fused, steps=None):
     return out
 
 
-def main():
-    a = parse()
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(a))      # before anything touches the GPU
-    if a.rehearse_cpu:
-        return rehearse_cpu(a)
-    rank, world, local = ddp.init_from_env()
-    if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the hot path"
-    local = local % torch.cuda.device_count()   # (rehearsals with more ranks than GPUs share a device)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    _lib.load()
+class Leg:
+    """What one measured leg needs from the command line (the headline leg takes it from the flags, the secondary legs are
+    fixed variants of the same workload family)."""
 
+    def __init__(self, config="cfg2", steps=50, warmup=10, batch=None, ragged=False, fresh_lengths=False, eager=False, graph=False,
+                 profile_all=False, drop_prob=0.0, dtype=None):
+        self.config, self.steps, self.warmup, self.batch = config, steps, warmup, batch
+        self.ragged, self.fresh_lengths, self.eager, self.graph = ragged, fresh_lengths, eager, graph
+        self.profile_all, self.drop_prob, self.dtype = profile_all, drop_prob, dtype
+
+
+def run_leg(a, rank, world, local, dev):
+    """Build the region and the synthetic batch of leg `a`, warm up, time EXACTLY a.steps steps between barriers +
+    synchronisations, and return the JSON fields of the leg (rank 0) -- plus the region, for the CPU baseline."""
+    from mmbidaf_amd import functional as MF
     B, T, Ma, Mi, H = synth.CONFIGS[a.config]
     if a.batch:
         B = a.batch
@@ -271,9 +273,6 @@ def main():
     region = HotRegion(H, drop_prob=a.drop_prob).to(dev)
     region.train(a.drop_prob > 0.0)      # drop_prob 0: train and eval mode are the same graph
     params = list(region.parameters())
-    # gradient exchange: SUM over ranks (the reference's loss is a sum over samples), bucketed in backward order and
-    # launched from grad hooks so that it overlaps the rest of the backward pass
-    from mmbidaf_amd import functional as MF
     dtype = a.dtype or ("bf16" if a.config == "cfg5" else "f32")
     MF.set_precision("bf16" if dtype == "bf16" else "fp32")
     # hipGraph replay is the default form of the step (fixed lengths: the synthetic workload); --fresh-lengths (new lengths
@@ -281,10 +280,10 @@ def main():
     want_graph = not a.eager and not a.fresh_lengths and not a.profile_all
     if a.graph and not want_graph:
         raise SystemExit("--graph: fixed lengths, no --profile-all / --eager")
-    # eager: buckets launched from grad hooks so that the exchange overlaps the rest of the backward pass; graph: the
-    # collectives stay outside the captured step and follow each replay
-    # (graph replay: nothing to overlap with -- ONE bucket, i.e. one packing kernel, one all-reduce of the whole 9.7 MB flat
-    #  gradient and one copy back per step instead of one of each per bucket, all issued from the host behind the replay)
+    # gradient exchange: SUM over ranks (the reference's loss is a sum over samples).  eager: buckets launched from grad hooks
+    # so that the exchange overlaps the rest of the backward pass; graph: the collectives stay outside the captured step and
+    # follow each replay (nothing to overlap with -- ONE bucket, i.e. one packing kernel, one all-reduce of the whole 9.7 MB
+    # flat gradient and one copy back per step, all issued from the host behind the replay)
     sync = ddp.FlatGradAllReduce(params, buckets=None if want_graph else ddp.region_buckets(region), overlap=not want_graph,
                                  defer_fn=MF.defer_grad_work)
     sync.broadcast_parameters()
@@ -358,6 +357,12 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     _lib.profile_enable([])
+    # a persistent recurrence launch (H > 128) that timed out at its per-step barrier leaves invalid results; inside a replayed
+    # graph nothing but this look at the status word can notice
+    timeouts = _lib.persist_timeouts()
+    if timeouts > 0:
+        raise _lib.PersistentRecurrenceTimeout(f"bench.py {a.config}: {timeouts} workgroup(s) of a persistent recurrence launch timed out "
+                                               "inside the timed region: the step times are INVALID")
     prof_steps = a.steps
     if graph is not None:
         # attention kernel times for the roofline figure: HIP events cannot bracket kernels inside a replayed graph, so the same
@@ -386,14 +391,12 @@ def main():
         dist.all_gather_object(gathered, f"rank{rank}:cuda:{local}:{torch.cuda.get_device_name(local)}")
         devices = gathered
     prof = {k: _lib.profile_read(k) for k in timed}
-
+    out = None
     if rank == 0:
         out = {
-            "metric": "samples/sec fwd+bwd, synthetic T_text=400 H=100, at 1/2/4/8 MI355X",
             "value": round(world * B * a.steps / dt, 2), "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "build_hash": source_hash(),
+            "dtype": dtype,
             "arithmetic": ("fp32 in, fp32 out, fp32 accumulation throughout; recurrences on fp32 VALU; every dense contraction (attention "
                            "similarity / context products, LSTM projection and gradient GEMMs) on fp16 MFMA from an error-compensated split of "
                            "the fp32 operands (two fp16 terms of the power-of-two-scaled rows, 3 cross products: max error ~1e-6 of the "
@@ -401,16 +404,19 @@ def main():
                           ("fp32 in, fp32 out, fp32 accumulation and cell update; every matrix-core product of the LSTM layers (input "
                            "projection, recurrent product, input / weight gradients) on v_mfma_f32_16x16x32_bf16 from bf16-rounded operands "
                            "(mmb_set_precision(1); tolerance 3e-2 of the tensor scale vs the fp32 oracle, tests/test_gpu_parity.py); the "
-                           "attention keeps its fp32-accurate arithmetic"),
+                           + ("attention (D <= 208: fused kernels) keeps its fp32-accurate arithmetic" if fused_att else
+                              "general-width attention (D = %d > 208) runs its batched similarity / context products on the two-term bf16 "
+                              "split in this mode (about 2^-16 relative per product, inside the same 3e-2 bound)" % D)),
             "config": {"workload": f"{a.config}: hot-path region (3 BiLSTM enc -> 2 BiDAF att -> 2 two-layer BiLSTM) "
                                    f"B={B}/GPU T_text={T} T_aud={Ma} T_img={Mi} H={H}, "
-                                   f"{'ragged U{n/2..n}' if a.ragged else 'full'} lengths, "
+                                   f"{'NEW ragged lengths U{n/2..n} every step' if a.fresh_lengths else 'ragged U{n/2..n}' if a.ragged else 'full'} lengths, "
                                    f"{'training mode drop_prob=%g (dropped similarity copies, inter-layer + output dropout), ' % a.drop_prob if a.drop_prob > 0 else ''}"
                                    f"fwd+bwd"
                                    f"{' + bucketed gradient all-reduce (sum)' if world > 1 else ''}",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": (attention_roofline(a, prof, B, T, Ma, Mi, D, fused=True, steps=prof_steps) if fused_att else
                          lstm_gemm_roofline(prof, B, T, Ma, Mi, H, prof_steps, dtype)) if timed else None,
+            "lstm_persist_timeouts": timeouts,
         }
         if graph is not None:
             out["config"]["launch"] = ("hipGraph replay of one captured fwd+bwd step (all launches of the step on the GPU's queues, one graph "
@@ -426,9 +432,97 @@ def main():
         if a.profile_all:
             out["kernel_ms_per_step"] = {k: round(v[0] / a.steps, 4) for k, v in prof.items()}
             out["kernel_launches_per_step"] = {k: v[1] / a.steps for k, v in prof.items()}
+    sync.remove_hooks()
+    return out, region
+
+
+# Secondary legs of the default single-GPU run: the other BASELINE.json configurations and the variants of
+# the headline workload a drop-in caller actually runs, each a short measurement of its own AFTER the headline leg (whose
+# fields they never touch).  (name, Leg)
+SECONDARY = [
+    ("cfg4_long_sequences", Leg(config="cfg4", steps=5, warmup=2)),
+    ("cfg5_h512_bf16", Leg(config="cfg5", steps=3, warmup=2)),
+    ("cfg2_ragged", Leg(config="cfg2", steps=20, warmup=5, ragged=True)),
+    ("cfg2_training_drop0.2", Leg(config="cfg2", steps=20, warmup=5, drop_prob=0.2)),
+    ("cfg2_eager_fresh_lengths", Leg(config="cfg2", steps=20, warmup=5, fresh_lengths=True)),
+]
+SECONDARY_BUDGET_S = 45.0
+
+
+def run_secondary(rank, world, local, dev):
+    import gc
+    res, t_start = {}, time.perf_counter()
+    for name, leg in SECONDARY:
+        used = time.perf_counter() - t_start
+        if used > SECONDARY_BUDGET_S:
+            res[name] = {"skipped": f"time budget of {SECONDARY_BUDGET_S:.0f} s for the secondary legs spent ({used:.0f} s)"}
+            continue
+        try:
+            gc.collect()
+            torch.cuda.empty_cache()
+            out, region = run_leg(leg, rank, world, local, dev)
+            del region
+            r = out.get("roofline") or {}
+            res[name] = {"workload": out["config"]["workload"], "launch": out["config"]["launch"], "dtype": out["dtype"],
+                         "steps": out["steps"], "warmup": out["warmup"], "ms_per_step": out["ms_per_step"], "value": out["value"],
+                         "unit": out["unit"],
+                         "roofline": {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "us_per_step")} if r else None}
+        except Exception as e:      # noqa: BLE001  (a secondary leg never costs the headline line)
+            res[name] = {"skipped": f"{type(e).__name__}: {e}"[:300]}
+            try:
+                torch.cuda.synchronize()
+            except Exception:       # noqa: BLE001
+                pass
+    from mmbidaf_amd import functional as MF
+    MF.set_precision("fp32")
+    res["wall_s"] = round(time.perf_counter() - t_start, 1)
+    return res
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))      # before anything touches the GPU
+    if a.rehearse_cpu:
+        return rehearse_cpu(a)
+    rank, world, local = ddp.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the hot path"
+    local = local % torch.cuda.device_count()   # (rehearsals with more ranks than GPUs share a device)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    _lib.load()
+
+    try:
+        out, region = run_leg(a, rank, world, local, dev)
+    except _lib.PersistentRecurrenceTimeout as e:
+        # the persistent H > 128 recurrence gave up at a chain barrier (its workgroups were not resident together): nothing timed is
+        # valid.  One GPU: measure again in a FRESH child process on the launch-per-step kernels (never by re-exec'ing this
+        # process, which has touched the GPU) and exit with its code; several ranks: fail loudly, the launcher tears the job down.
+        print(f"bench.py: {e}", file=sys.stderr, flush=True)
+        if world > 1 or os.environ.get("MMB_LSTM_FS_PERSIST") == "0":
+            sys.exit(3)
+        import subprocess
+        env = dict(os.environ, MMB_LSTM_FS_PERSIST="0")
+        print("bench.py: repeating the run in a child process with MMB_LSTM_FS_PERSIST=0 (launch-per-step recurrence)", file=sys.stderr, flush=True)
+        sys.exit(subprocess.call([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+
+    if rank == 0:
+        line = {"metric": "samples/sec fwd+bwd, synthetic T_text=400 H=100, at 1/2/4/8 MI355X"}
+        line.update({k: out[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step")})
+        line.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": out["dtype"], "data": "synthetic",
+                     "build_hash": source_hash()})
+        line.update({k: v for k, v in out.items() if k not in line})
+        if os.environ.get("MMB_LSTM_FS_PERSIST") == "0":
+            line["config"]["recurrence"] = "launch-per-step kernels (MMB_LSTM_FS_PERSIST=0)"
+        default_run = (world == 1 and a.config == "cfg2" and not (a.batch or a.ragged or a.fresh_lengths or a.eager or a.profile_all
+                                                                    or a.drop_prob > 0.0 or a.dtype))
+        if default_run and not a.no_secondary:
+            line["secondary"] = run_secondary(rank, world, local, dev)
         if world == 1 and not a.no_cpu_baseline and a.drop_prob == 0.0:     # (the CPU port is timed on the dropout-free graph)
-            out["cpu_baseline"] = cpu_baseline(region, a.config, a.ragged)
-        print(json.dumps(out), flush=True)
+            line["cpu_baseline"] = cpu_baseline(region, a.config, a.ragged)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

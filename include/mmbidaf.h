@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMB_VERSION 303            /* round 3 ABI: grouped attention entry points, build hash, persistent-recurrence status word, hidden-state op */
+#define MMB_VERSION 400            /* round 4 ABI: + persistent-recurrence reset / enable */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
 #define MMB_ATT_MAX_D 208          /* attention feature width D = 2H of the fused (register-resident) kernels */
 #define MMB_ATT_GENERAL_MAX_D 4096 /* wider D (up to this) runs the general path: similarity matrix in a workspace */
@@ -365,6 +365,13 @@ int mmb_get_precision(void);
  * sets a host-visible word, and the NEXT LSTM call of the process returns MMB_ERR_HIP.  This reads that word: 0 on a
  * healthy process.  MMB_LSTM_FS_PERSIST=0 in the environment selects the launch-per-step kernels. */
 int mmb_lstm_persist_timeouts(void);
+/* The word is sticky for the life of the process (every later LSTM call fails until it is cleared).  A caller that has
+ * handled the time-out -- discarded the step's results and switched the process to the launch-per-step kernels with
+ * mmb_lstm_persist_enable(0) -- clears it here (after synchronising the device).  Returns the value it held. */
+int mmb_lstm_persist_reset(void);
+/* 0: launch-per-step kernels from the next call on; 1: the persistent form where it applies (the default; the environment
+ * variable MMB_LSTM_FS_PERSIST=0 sets 0 at start-up).  Returns the previous setting. */
+int mmb_lstm_persist_enable(int on);
 
 int mmb_gemm_f32(const float* A, const float* Bm, float* C, const float* bias,
                  int M, int N, int K, int lda, int ldb, int ldc, int ta, int tb, int accumulate,

@@ -16,7 +16,7 @@ ATT_GENERAL_MAX_D = 4096     # general path (similarity matrix in a workspace)
 LSTM_MAX_H = 128            # register-resident recurrence (one launch per layer)
 LSTM_GENERAL_MAX_H = 1024   # general recurrence (one launch per time step)
 
-ABI_VERSION = 303           # MMB_VERSION the signatures below were written for (include/mmbidaf.h)
+ABI_VERSION = 400           # MMB_VERSION the signatures below were written for (include/mmbidaf.h)
 
 c_f = ctypes.c_void_p  # device pointers travel as raw addresses
 c_i = ctypes.c_int
@@ -90,6 +90,8 @@ SIGNATURES = {
     "mmb_set_precision": (c_i, [c_i]),
     "mmb_get_precision": (c_i, []),
     "mmb_lstm_persist_timeouts": (c_i, []),
+    "mmb_lstm_persist_reset": (c_i, []),
+    "mmb_lstm_persist_enable": (c_i, [c_i]),
     "mmb_stream_delay": (c_i, [c_i, c_f, c_i]),
     "mmb_hidden_states_fwd": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_i, ctypes.POINTER(ctypes.c_void_p), c_f, c_i, c_i, c_i, c_f]),
     "mmb_hidden_states_bwd": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_i, c_i, c_f]),
@@ -174,3 +176,34 @@ def profile_read(name):
     kid = KERNEL_IDS[name]
     check(load().mmb_profile_read(kid, ctypes.byref(ms), ctypes.byref(n)), "mmb_profile_read")
     return ms.value, n.value, load().mmb_kernel_name(kid).decode()
+
+
+class PersistentRecurrenceTimeout(RuntimeError):
+    """A persistent recurrence launch (H > 128, csrc/lstm_fs.hip) gave up at its per-step barrier: the results of the step
+    that contained it are invalid."""
+
+
+def persist_timeouts():
+    """Value of the persistent recurrence's host-visible time-out word: 0 on a healthy process.  Meaningful for the work the
+    device has finished: read it behind a synchronisation point (end of a step / of a timed region)."""
+    return int(load().mmb_lstm_persist_timeouts())
+
+
+def persist_check(where):
+    """Raise PersistentRecurrenceTimeout when a persistent recurrence launch timed out (inside a replayed graph no
+    library call runs between launches, so the word has to be looked at by whoever consumes the step's results: bench.py
+    after its timed region, ddp.FlatGradAllReduce at its sync point, MMBiDAF / HotRegion users through this call)."""
+    n = persist_timeouts()
+    if n > 0:
+        raise PersistentRecurrenceTimeout(
+            f"{where}: a persistent LSTM recurrence launch timed out at its per-step barrier ({n} workgroup(s) gave up): "
+            "the results of that step are INVALID.  Discard them, call mmbidaf_amd._lib.persist_fallback() (or start the "
+            "process with MMB_LSTM_FS_PERSIST=0) and repeat the step.")
+
+
+def persist_fallback():
+    """Switch this process to the launch-per-step recurrence kernels and clear the (sticky) time-out word.  The caller has
+    synchronised the device and discarded the failed step."""
+    lib = load()
+    lib.mmb_lstm_persist_enable(0)
+    return int(lib.mmb_lstm_persist_reset())

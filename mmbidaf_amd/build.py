@@ -22,11 +22,23 @@ def _headers():
     return hs
 
 
-def _newer(path, deps):
-    if not os.path.exists(path):
-        return True
-    t = os.path.getmtime(path)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _obj_key(src, hdrs, cmd_flags):
+    """Content key of one object: sha1 over the source, every header and the compiler + flags it is built with.  Kept next
+    to the object (<obj>.key); an object is reused only while its key matches (modification times say nothing
+    after an rsync / checkout that preserves or rewinds them, and a changed FLAGS / HIPCC must rebuild everything)."""
+    h = hashlib.sha1()
+    for f in [src] + sorted(hdrs):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    h.update("\0".join(cmd_flags).encode())
+    return h.hexdigest()
+
+
+def _obj_current(obj, key):
+    try:
+        return os.path.exists(obj) and open(obj + ".key").read().strip() == key
+    except OSError:
+        return False
 
 
 def source_hash():
@@ -66,18 +78,27 @@ def build_library(force=False, verbose=False, jobs=None):
     todo = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s + ".o")
-        # api.hip carries the hash of ALL sources (mmb_build_hash): recompiled whenever any of them changed
-        if force or _newer(obj, [src] + hdrs) or (s == "api.hip" and _built_hash() != stamp):
-            extra = [f'-DMMB_BUILD_HASH="{stamp}"'] if s == "api.hip" else []
-            todo.append([hipcc] + FLAGS + extra + ["-c", src, "-o", obj])
+        # api.hip carries the hash of ALL sources (mmb_build_hash): its flags, hence its key, change whenever any of them does
+        extra = [f'-DMMB_BUILD_HASH="{stamp}"'] if s == "api.hip" else []
+        key = _obj_key(src, hdrs, [hipcc] + FLAGS + extra)
+        if force or not _obj_current(obj, key):
+            todo.append(([hipcc] + FLAGS + extra + ["-c", src, "-o", obj], obj, key))
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=CSRC)
+
+    def compile_one(item):
+        cmd, obj, key = item
+        if os.path.exists(obj + ".key"):
+            os.remove(obj + ".key")
+        run(cmd)
+        with open(obj + ".key", "w") as f:
+            f.write(key + "\n")
     jobs = jobs or min(6, os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
-        list(ex.map(run, todo))
+        list(ex.map(compile_one, todo))
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(OBJ, s + ".o") for s in SOURCES] + ["-o", LIB])
     with open(HASH_FILE, "w") as f:
         f.write(stamp + "\n")

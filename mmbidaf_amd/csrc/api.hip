@@ -171,3 +171,5 @@ extern "C" int mmb_set_precision(int mode) {
 }
 extern "C" int mmb_get_precision(void) { return mmb::precision_mode(); }
 extern "C" int mmb_lstm_persist_timeouts(void) { return mmb::lstm_fs_timeouts(); }
+extern "C" int mmb_lstm_persist_reset(void) { return mmb::lstm_fs_reset_timeouts(); }
+extern "C" int mmb_lstm_persist_enable(int on) { return mmb::lstm_fs_set_persist(on); }

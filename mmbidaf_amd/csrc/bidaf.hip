@@ -491,8 +491,9 @@ struct SplitSrc {
     float* term[2];       // (B,R) or null
     int R;
 };
+constexpr int PREP_MAX_SRC = 16;   // training mode: up to 4 sources per attention (text, text_d, mod, mod_d) x 4 attentions
 struct PrepArgs {
-    SplitSrc t[12];
+    SplitSrc t[PREP_MAX_SRC];
     int n, D, B;
 };
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -1884,8 +1885,10 @@ extern "C" int mmb_bidaf_group_fwd(const mmb_bidaf_desc* d, int n, int B, int D,
         PrepArgs p{};
         p.D = D; p.B = B;
         int cnt = 0, owner_src[MAXG];
+        bool overflow = false;
         long rows = 0;
         auto add = [&](const float* src, char* planes, float* inv, const float* mul, const float* w, const float* bias, float* term, int R) {
+            if (cnt >= PREP_MAX_SRC) { overflow = true; return PREP_MAX_SRC - 1; }   // (cannot happen with n <= MAXG: refused below all the same)
             SplitSrc& s = p.t[cnt];
             s.src = src; s.planes = planes; s.inv = inv; s.mul = mul; s.R = R;
             s.w[0] = w; s.bias[0] = bias; s.term[0] = term;
@@ -1915,6 +1918,8 @@ extern "C" int mmb_bidaf_group_fwd(const mmb_bidaf_desc* d, int n, int B, int D,
                 add(g.mod_d, g.pMd, g.iMd, nullptr, g.w_m, nullptr, g.cterm, g.M);
             }
         }
+        static_assert(PREP_MAX_SRC >= 4 * MAXG, "split pass: one slot per (attention, source)");
+        MMB_REQUIRE(!overflow && cnt >= 1 && cnt <= PREP_MAX_SRC, "bidaf group: %d split sources for %d attentions (capacity %d)", cnt, n, PREP_MAX_SRC);
         p.n = cnt;
         ProfScope ps_(MMB_K_ATT_RANK1, stream);
         hipLaunchKernelGGL(att_prep_kernel, dim3((unsigned)((rows + 3) / 4), cnt), dim3(256), 0, stream, p);

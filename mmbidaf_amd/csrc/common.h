@@ -205,6 +205,8 @@ size_t lstm_fs_bwd_ws_bytes(int B, int T, int H);
 int lstm_fs_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* ws, hipStream_t stream);
 int lstm_fs_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* ws, hipStream_t stream, bool* db_done);
 int lstm_fs_timeouts();   // persistent recurrence: value of the time-out word (0 on a healthy process; -1: no pinned memory)
+int lstm_fs_reset_timeouts();     // clears the word, returns what it held
+int lstm_fs_set_persist(int on);  // 0: launch-per-step kernels only; returns the previous setting
 int lstm_big_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* big_ws, hipStream_t stream);
 int lstm_big_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* big_ws, hipStream_t stream);
 

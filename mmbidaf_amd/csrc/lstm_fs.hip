@@ -935,10 +935,12 @@ size_t lstm_fs_fwd_ws_bytes(int B, int H) { return fs_fwd_layout(B, H).total; }
 size_t lstm_fs_bwd_ws_bytes(int B, int T, int H) { return fs_bwd_layout(B, T, H).total; }
 
 // ---- persistent form: eligibility and the time-out word
-static int fs_persist_mode() {   // MMB_LSTM_FS_PERSIST=0: launch-per-step kernels only
-    static const int v = [] { const char* e = getenv("MMB_LSTM_FS_PERSIST"); return e ? atoi(e) : 1; }();
+static std::atomic<int>& fs_persist_flag() {   // MMB_LSTM_FS_PERSIST=0 / mmb_lstm_persist_enable(0): launch-per-step kernels only
+    static std::atomic<int> v{[] { const char* e = getenv("MMB_LSTM_FS_PERSIST"); return e ? atoi(e) : 1; }()};
     return v;
 }
+static int fs_persist_mode() { return fs_persist_flag().load(std::memory_order_relaxed); }
+int lstm_fs_set_persist(int on) { return fs_persist_flag().exchange(on ? 1 : 0); }
 static int fs_dbg() {            // timing-only ablations (results wrong): 1 no chain wait, 2 no operand loads, 4 no publish drain, 8 one partial tile
     static const int v = [] { const char* e = getenv("MMB_LSTM_FS_DBG"); return e ? atoi(e) : 0; }();
     return v;
@@ -975,6 +977,13 @@ static int fs_check_timeout() {
     return MMB_OK;
 }
 int lstm_fs_timeouts() { unsigned* w = fs_timeout_word(); return w ? (int)*reinterpret_cast<volatile unsigned*>(w) : -1; }
+int lstm_fs_reset_timeouts() {
+    unsigned* w = fs_timeout_word();
+    if (!w) return -1;
+    const int v = (int)*reinterpret_cast<volatile unsigned*>(w);
+    *reinterpret_cast<volatile unsigned*>(w) = 0u;
+    return v;
+}
 
 // prep (W_hh planes, zeroed recurrent operand) + the time loop; lstm_big.hip does the packed-sequence post-processing
 int lstm_fs_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* ws, hipStream_t stream) {

@@ -168,7 +168,12 @@ class FlatGradAllReduce:
                 p.copy_(chunk.view_as(p))
 
     def __call__(self):
-        """Call after backward: grad <- sum (or mean) over ranks, in place."""
+        """Call after backward: grad <- sum (or mean) over ranks, in place.
+        Also the place where a time-out of a persistent recurrence launch of an EARLIER step surfaces: the
+        gradients it would exchange are invalid, and inside a replayed graph no library call runs that could notice."""
+        if self.flat.is_cuda:
+            from . import _lib
+            _lib.persist_check("FlatGradAllReduce")
         if self.world == 1:
             return
         for bi in range(len(self.buckets)):

@@ -476,7 +476,9 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         # (plain stores: nothing to zero -- a fill kernel per layer call on the critical path before)
         am_n = [int(lib.mmb_bilstm_absmax_floats(flat[i * _PER_PROBLEM].shape[0], flat[i * _PER_PROBLEM].shape[1],
                                                  flat[i * _PER_PROBLEM + 2].shape[1])) for i in range(n)]
-        am_flat = torch.empty(sum(am_n), device=dev, dtype=torch.float32)
+        # (bf16 mode: the one-plane split pass records no maxima -- zeros, so that a backward pass run after a switch back to
+        #  fp32 finds a defined (degenerate) bound instead of uninitialised memory)
+        am_flat = (torch.zeros if get_precision() == "bf16" else torch.empty)(sum(am_n), device=dev, dtype=torch.float32)
         am_off = [sum(am_n[:i]) for i in range(n)]
         x_absmax = [am_flat[am_off[i]:am_off[i] + am_n[i]] for i in range(n)]
         for i in range(n):

@@ -270,28 +270,36 @@ def get_mask(max_len, lengths):
     return torch.arange(max_len)[None, :] < torch.as_tensor(lengths, dtype=torch.long)[:, None]
 
 
-def hot_region(x_text, x_aud, x_img, text_len, aud_len, img_len, P):
-    """models.py:97,102,113,116-118,131-135,143 on post-embedding features, drop_prob = 0.
+def hot_region(x_text, x_aud, x_img, text_len, aud_len, img_len, P, masks=None):
+    """models.py:97,102,113,116-118,131-135,143 on post-embedding features; drop_prob = 0 unless `masks` is given.
+    masks (training mode, every entry a multiplicative keep/(1-p) mask of its tensor's shape): 'out_text', 'out_aud',
+    'out_img' (RNNEncoder output dropout, encoding.py:104), 'att_a_text', 'att_a_mod', 'att_i_text', 'att_i_mod' (the dropped
+    copies only the similarity sees, attention.py:66-67), 'inter_a', 'inter_i' (nn.LSTM inter-layer dropout of the two-layer
+    modelling encoders, encoding.py:81), 'out_a', 'out_i' (their output dropout).
     P: dict of parameter dicts: 'text_enc','audio_enc','image_enc','mod_t_a','mod_t_i' (LSTM
     params by torch name) and 'bidaf_att_audio','bidaf_att_image' (text_weight, modality_weight,
     text_modality_weight, bias).  Returns dict of every intermediate the goldens capture."""
     out = {}
-    te, _ = rnn_encoder(x_text, text_len, P["text_enc"], 1)
-    ae, _ = rnn_encoder(x_aud, aud_len, P["audio_enc"], 1)
-    ie, _ = rnn_encoder(x_img, img_len, P["image_enc"], 1)
+    M = masks or {}
+    te, _ = rnn_encoder(x_text, text_len, P["text_enc"], 1, out_mask=M.get("out_text"))
+    ae, _ = rnn_encoder(x_aud, aud_len, P["audio_enc"], 1, out_mask=M.get("out_aud"))
+    ie, _ = rnn_encoder(x_img, img_len, P["image_enc"], 1, out_mask=M.get("out_img"))
     tm = get_mask(x_text.size(1), text_len)
     am = get_mask(x_aud.size(1), aud_len)
     im = get_mask(x_img.size(1), img_len)
 
-    def att(name, mod, mask):
+    def att(name, mod, mask, mt, mm):
         p = P[name]
+        kw = dict(text_d=te * mt, mod_d=mod * mm) if mt is not None else {}
         return bidaf_attention(te, mod, tm, mask, p["text_weight"], p["modality_weight"],
-                               p["text_modality_weight"], p["bias"])
+                               p["text_modality_weight"], p["bias"], **kw)
 
-    ta = att("bidaf_att_audio", ae, am)
-    ti = att("bidaf_att_image", ie, im)
-    ya, ha = rnn_encoder(ta, text_len, P["mod_t_a"], 2)
-    yi, hi = rnn_encoder(ti, text_len, P["mod_t_i"], 2)
+    ta = att("bidaf_att_audio", ae, am, M.get("att_a_text"), M.get("att_a_mod"))
+    ti = att("bidaf_att_image", ie, im, M.get("att_i_text"), M.get("att_i_mod"))
+    ya, ha = rnn_encoder(ta, text_len, P["mod_t_a"], 2, out_mask=M.get("out_a"),
+                         dropout_masks=[M["inter_a"]] if "inter_a" in M else None)
+    yi, hi = rnn_encoder(ti, text_len, P["mod_t_i"], 2, out_mask=M.get("out_i"),
+                         dropout_masks=[M["inter_i"]] if "inter_i" in M else None)
     out.update(text_enc=te, audio_enc=ae, image_enc=ie, att_audio=ta, att_image=ti,
                mod_t_a=ya, mod_t_a_h=ha, mod_t_i=yi, mod_t_i_h=hi,
                decoder_hidden=(ha.sum(1) + hi.sum(1)).unsqueeze(1))

@@ -187,7 +187,7 @@ def test_attention_vs_oracle(B, T, M, D, use_drop):
 
 
 @pytest.mark.parametrize("B,T,M,D,use_drop", [(2, 37, 29, 212, False), (3, 50, 70, 256, True), (2, 9, 300, 512, False),
-                                              (1, 70, 5, 1024, True)])
+                                              (1, 70, 5, 1024, True), (2, 400, 256, 1024, False)])
 def test_attention_general_width_vs_oracle(B, T, M, D, use_drop):
     """D above the fused kernels' 208 runs the general path (similarity matrix in a workspace, batched f32 GEMMs);
     ragged masks, with and without the dropped copies, up to cfg5's D = 1024."""
@@ -606,7 +606,7 @@ def test_general_hidden_size_persistent_recurrence_is_what_runs_and_never_times_
     assert lib.mmb_lstm_persist_timeouts() == 0
 
 
-@pytest.mark.parametrize("B,H,T", [(70, 256, 9), (33, 192, 14), (130, 136, 6)])
+@pytest.mark.parametrize("B,H,T", [(70, 256, 9), (33, 192, 14), (130, 136, 6), (70, 256, 260), (40, 512, 256)])
 def test_persistent_recurrence_with_several_sample_blocks_vs_oracle(B, H, T):
     """Batches above one sample block of the persistent recurrence (64 samples forward, 32 / 16 backward): the exchange
     buffers, arrival counts and fragment offsets of sample blocks > 0, ragged lengths, B not a multiple of the block."""
@@ -1539,3 +1539,223 @@ def test_rnn_encoder_fuzz_random_shapes():
         close(xd.grad, dxr, "d_x " + tag)
         for n, p in e.named_parameters():
             close(p.grad, P[n[4:]].grad, "grad " + n + " " + tag)
+
+
+# ------------------------------------------------------------------------------------------- round 4 additions
+@pytest.mark.parametrize("shared_text", [True, False])
+def test_attention_group_of_four_in_training_mode_vs_oracle(shared_text):
+    """A group of FOUR attentions WITH dropped copies (the split pass then has 13 sources with a shared text and
+    16 with private ones -- past the 12-entry table it used to write into): outputs and every gradient against the oracle."""
+    from mmbidaf_amd import functional as MF
+    d = dev()
+    g = torch.Generator().manual_seed(404 + int(shared_text))
+    B, D, T = 2, 200, 45
+    Ms = [33, 9, 64, 70]
+    t_shared = torch.randn(B, T, D, generator=g)
+    texts = [t_shared if shared_text else torch.randn(B, T, D, generator=g) for _ in range(4)]
+    mods = [torch.randn(B, m, D, generator=g) for m in Ms]
+    keep = lambda *sh: (torch.rand(*sh, generator=g) > 0.2).float() / 0.8
+    mt = [keep(B, T, D) for _ in range(4)]
+    mm = [keep(B, m, D) for m in Ms]
+    tl, mls = [T, 31], [[m, max(1, m // 3)] for m in Ms]
+    mask = lambda n, lens: torch.arange(n).unsqueeze(0) < torch.tensor(lens).unsqueeze(1)
+    params = [[torch.randn(D, 1, generator=g) * 0.1, torch.randn(D, 1, generator=g) * 0.1, torch.randn(1, 1, D, generator=g) * 0.1,
+               torch.randn(1, generator=g) * 0.1] for _ in range(4)]
+    cots = [torch.randn(B, T, 4 * D, generator=g) for _ in range(4)]
+
+    def leaves(to):
+        uniq = {}
+        tx = []
+        for t in texts:
+            if id(t) not in uniq:
+                uniq[id(t)] = t.clone().to(to).requires_grad_(True)
+            tx.append(uniq[id(t)])
+        return tx, [m.clone().to(to).requires_grad_(True) for m in mods], [[p_.clone().to(to).requires_grad_(True) for p_ in pk] for pk in params]
+    tx, md, ps = leaves(d)
+    probs = [(tx[k], md[k], mask(T, tl).to(d), mask(Ms[k], mls[k]).to(d), *ps[k], tx[k] * mt[k].to(d), md[k] * mm[k].to(d)) for k in range(4)]
+    outs = MF.bidaf_attention_group(probs)
+    torch.autograd.backward(outs, [c.to(d) for c in cots])
+    rtx, rmd, rps = leaves("cpu")
+    routs = [O.bidaf_attention(rtx[k], rmd[k], mask(T, tl), mask(Ms[k], mls[k]), *rps[k], text_d=rtx[k] * mt[k], mod_d=rmd[k] * mm[k]) for k in range(4)]
+    torch.autograd.backward(routs, cots)
+    for k in range(4):
+        close(outs[k], routs[k].detach(), f"group-of-4 training out {k}")
+        close(md[k].grad, rmd[k].grad, f"group-of-4 training d_mod {k}")
+        for n, a, b in zip(("w_t", "w_m", "w_tm"), ps[k], rps[k]):
+            close(a.grad, b.grad, f"group-of-4 training d_{n} {k}")
+    for k in ([0] if shared_text else range(4)):
+        close(tx[k].grad, rtx[k].grad, f"group-of-4 training d_text {k}")
+
+
+def _region_P(region):
+    P = {}
+    for k, v in region.state_dict().items():
+        mod, rest = k.split(".", 1)
+        P.setdefault(mod, {})[rest[4:] if rest.startswith("rnn.") else rest] = v.detach().cpu().clone().requires_grad_(True)
+    return P
+
+
+_MASK_ORDER = ("out_text", "out_aud", "out_img", "att_a_text", "att_a_mod", "att_i_text", "att_i_mod", "inter_a", "inter_i", "out_a", "out_i")
+
+
+def _region_mask_shapes(B, T, Ma, Mi, H):
+    """shapes of the 11 dropout draws of one training-mode region step, in call order (encode_group: output dropout of the three
+    input encoders; forward_group: dropped copies of (text, audio), (text, image); encode_group: inter-layer dropout of the
+    two modelling encoders, then their output dropout)"""
+    D = 2 * H
+    return [(B, T, D), (B, Ma, D), (B, Mi, D), (B, T, D), (B, Ma, D), (B, T, D), (B, Mi, D), (B, T, D), (B, T, D), (B, T, D), (B, T, D)]
+
+
+def _check_region_against_masked_oracle(region, batch, outs, xs, masks, tag, tol=TOL):
+    P = _region_P(region)
+    xr = [batch[k].clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+    r = O.hot_region(*xr, batch["text_len"], batch["aud_len"], batch["img_len"], P, masks=masks)
+    routs = (r["mod_t_a"], r["mod_t_a_h"], r["mod_t_i"], r["mod_t_i_h"], r["decoder_hidden"])
+    for n, a, b in zip(("mod_a", "hid_a", "mod_i", "hid_i", "dec_hidden"), outs, routs):
+        close(a, b.detach(), f"{n} ({tag})", tol=tol, absolute=True)
+    from mmbidaf_amd import synth
+    synth.region_loss(routs, batch).backward()
+    for n, a, b in zip(("d_x_text", "d_x_aud", "d_x_img"), xs, xr):
+        close(a.grad, b.grad, f"{n} ({tag})", tol=tol, absolute=True)
+    for n, p in region.named_parameters():
+        mod, rest = n.split(".", 1)
+        if rest == "bias":
+            continue         # attention bias: analytically zero gradient (Q5)
+        close(p.grad, P[mod][rest[4:] if rest.startswith("rnn.") else rest].grad, f"grad {n} ({tag})", tol=tol)
+
+
+def test_hot_region_training_mode_cfg2_lengths_vs_oracle_with_replayed_masks():
+    """The region as the reference trains it (drop_prob 0.2, train.py:210) at cfg2's sequence lengths (B = 4, T = 400 / 256 / 64,
+    ragged): the grouped two-attention call with dropped copies (the 4-tensor gradient sweeps), inter-layer and output dropout.
+    torch's device generator is replayed to recover the eleven masks, which the oracle then applies: every output, input
+    gradient and parameter gradient must AGREE, not just be finite."""
+    import torch.nn.functional as F
+    from mmbidaf_amd import synth
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    shape = (4, 400, 256, 64, 100)
+    torch.manual_seed(224)
+    region = HotRegion(100, drop_prob=0.2).to(d).train()
+    batch = synth.make_batch(shape, ragged=True)
+    gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    xs = [gpu[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+    torch.manual_seed(4242)
+    outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+    synth.region_loss(outs, gpu).backward()
+    torch.manual_seed(4242)      # same generator state -> the same eleven masks, in call order
+    masks = {k: F.dropout(torch.ones(*sh, device=d), 0.2, True).cpu() for k, sh in zip(_MASK_ORDER, _region_mask_shapes(*shape))}
+    assert 0.1 < (masks["att_a_text"] == 0).float().mean() < 0.3 and not torch.equal(masks["att_a_text"], masks["att_i_text"])
+    _check_region_against_masked_oracle(region, batch, outs, xs, masks, "training mode, cfg2 lengths")
+
+
+def test_region_graph_replay_with_dropout_draws_fresh_masks_every_replay(monkeypatch):
+    """hipGraph replay in training mode: torch's graph-safe generator advances its offset per replay, so two replays of ONE
+    captured step must use DIFFERENT dropout masks, and each replay must match the oracle under the masks it used.  The masks
+    are made observable by routing F.dropout through `x * F.dropout(ones)` (the same generator calls, the same values): the
+    mask tensors live in the graph's pool and hold the masks of the latest replay."""
+    import torch.nn.functional as F
+    from mmbidaf_amd import synth
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    shape = (3, 40, 24, 8, 100)
+    torch.manual_seed(224)
+    region = HotRegion(100, drop_prob=0.2).to(d).train()
+    batch = synth.make_batch(shape, ragged=True)
+    gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    xs = [gpu[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+    params = list(region.parameters())
+    seen = []
+    orig = F.dropout
+
+    def spy(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return x
+        m = orig(torch.ones_like(x), p, True)
+        seen.append(m)
+        return x * m
+    monkeypatch.setattr(F, "dropout", spy)
+
+    def step():
+        outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+        synth.region_loss(outs, gpu).backward()
+        return outs
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            for t in params + xs:
+                t.grad = None
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for t in params + xs:
+        t.grad = None
+    seen.clear()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = step()
+    assert len(seen) == 11, f"{len(seen)} dropout draws in one training-mode step, expected 11"
+    kept = []
+    for rep in range(2):
+        g.replay()
+        torch.cuda.synchronize()
+        masks = {k: m.detach().cpu().clone() for k, m in zip(_MASK_ORDER, seen)}
+        kept.append(masks)
+        _check_region_against_masked_oracle(region, batch, [o.detach().clone() for o in outs], xs, masks, f"graph replay {rep} with dropout")
+    assert not torch.equal(kept[0]["att_a_text"], kept[1]["att_a_text"]), "two replays of the captured step used the same dropout masks"
+    assert not torch.equal(kept[0]["out_a"], kept[1]["out_a"])
+
+
+def test_five_consecutive_steps_with_new_lengths_every_step_vs_oracle():
+    """What train.py does (train.py:126-146: every batch brings its own `original_*_lengths`): five consecutive fwd+bwd steps of
+    ONE region object, each with different ragged lengths -- the host-derived index tensors, cached descriptors and workspaces
+    of a step must never leak into the next -- every step against the oracle."""
+    from mmbidaf_amd import synth
+    from mmbidaf_amd.hot_region import HotRegion
+    import random
+    d = dev()
+    shape = (5, 60, 37, 12, 100)
+    B, T, Ma, Mi, H = shape
+    torch.manual_seed(224)
+    region = HotRegion(H).to(d)
+    ref = None
+    rng = random.Random(5)
+    for it in range(5):
+        batch = synth.make_batch(shape, rank=it, ragged=True)
+        batch["text_len"] = [T if it % 2 == 0 else T - 7] + [rng.randint(1, T) for _ in range(B - 1)]
+        batch["aud_len"] = [rng.randint(1, Ma) for _ in range(B)]
+        batch["img_len"] = [rng.randint(1, Mi) for _ in range(B)]
+        gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        xs = [gpu[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+        for p in region.parameters():
+            p.grad = None
+        outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+        synth.region_loss(outs, gpu).backward()
+        if ref is None:
+            ref = O.HotRegionCPU(region.state_dict(), H)
+        ref.zero_grad(set_to_none=True)
+        xr = [batch[k].clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+        routs = ref(*xr, batch["text_len"], batch["aud_len"], batch["img_len"])
+        synth.region_loss(routs, batch).backward()
+        for n, a, b in zip(("mod_a", "hid_a", "mod_i", "hid_i", "dec_hidden"), outs, routs):
+            close(a, b, f"{n} (step {it}, new lengths)", absolute=True)
+        for n, a, b in zip(("d_x_text", "d_x_aud", "d_x_img"), xs, xr):
+            close(a.grad, b.grad, f"{n} (step {it}, new lengths)", absolute=True)
+        rg = ref.named_grads()
+        for n, p in region.named_parameters():
+            if not n.endswith(".bias"):
+                close(p.grad, rg[n], f"grad {n} (step {it}, new lengths)")
+
+
+def test_persist_timeout_status_word_is_checked_and_can_be_cleared():
+    """the persistent recurrence's time-out word must be looked at by whoever consumes a step; _lib.persist_check
+    raises on a non-zero word, persist_fallback() switches to the launch-per-step kernels and clears it."""
+    from mmbidaf_amd import _lib
+    lib = _lib.load()
+    torch.cuda.synchronize()
+    assert _lib.persist_timeouts() == 0
+    _lib.persist_check("test")          # healthy: no exception
+    prev = lib.mmb_lstm_persist_enable(1)
+    assert prev in (0, 1)
+    assert lib.mmb_lstm_persist_reset() == 0
+    lib.mmb_lstm_persist_enable(prev)
