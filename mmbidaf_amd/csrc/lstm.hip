@@ -96,7 +96,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float c = 0.f, h = 0.f;
     const bool is_tanh = kq == 2;
     const bool b0 = kq & 1, b1 = kq & 2;
-    const float act_in = is_tanh ? -2.0f : -1.0f, act_mul = is_tanh ? 2.0f : 1.0f, act_sub = is_tanh ? 1.0f : 0.0f;
+    // The serial tail of a step (reduce -> activation -> cell -> h) is what a time step costs beyond its FMAs, so every
+    // operation that can be taken off that dependency chain is (round 4):
+    //  * sigma(x) = 1 / (1 + 2^(-x log2 e)): the factor -log2 e (-2 log2 e for the tanh gate, tanh x = 2 sigma(2x) - 1) is ONE
+    //    constant, one multiply in front of v_exp_f32 instead of two;
+    //  * gx enters as the INITIAL value of the lane's own gate accumulator (the transposing reduction sums a_g over the quad,
+    //    so a value added to a_g in exactly one lane -- lane g -- is added once): no add behind the reduction, and the wait
+    //    for the streamed gx moves to the start of the step, where it has long arrived;
+    //  * the cell update works on the raw sigmoids s_i, s_f, s_g (s_g = sigma(2 pre_g)):  c' = s_f c - s_i + 2 s_i s_g, with
+    //    A = s_f c - s_i and B = s_i s_g independent of each other; the activation tanh = 2 s_g - 1 that the backward pass
+    //    needs is formed beside the chain, for the store only;
+    //  * h = s_o tanh(c') = s_o - 2 s_o r with r = 1 / (1 + 2^(2 c' log2 e)):  one fma behind the reciprocal.
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float act_in2 = is_tanh ? -2.0f * LOG2E : -LOG2E;
+    const float act_mul = is_tanh ? 2.0f : 1.0f, act_sub = is_tanh ? 1.0f : 0.0f;
     int cur = 0;
 
     // one time step, given the input-projection value gx of (t, dir, u, kq)
@@ -108,7 +121,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int q = 0; q < KQP / 4; ++q) hv[q] = *reinterpret_cast<const f4*>(hq + 4 * q);
         __builtin_amdgcn_sched_group_barrier(0x100, KQP / 4, 0);  // the whole DS-read burst first
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float a0 = kq == 0 ? gx : 0.f, a1 = kq == 1 ? gx : 0.f, a2 = kq == 2 ? gx : 0.f, a3 = kq == 3 ? gx : 0.f;
 #pragma unroll
         for (int k4 = 0; k4 < KQP; k4 += 4) {
 #pragma unroll
@@ -127,19 +140,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float rA = keepA + quad_xor1(sendA);
         const float rB = keepB + quad_xor1(sendB);
         const float keep = b1 ? rB : rA, send = b1 ? rA : rB;
-        const float pre = keep + quad_xor2(send) + gx;
-        // activation of my gate: sigmoid for i,f,o; tanh(x) = 2 sigmoid(2x) - 1 for g
-        const float sg = fast_rcp(1.0f + __expf(act_in * pre));
-        const float act = fmaf(act_mul, sg, -act_sub);
-        const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act);
-        const float gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
-        c = fmaf(gf, c, gi * gg);
-        h = go * tanhf_(c);
+        const float pre = keep + quad_xor2(send);
+        // raw sigmoid of my gate (of 2 pre for the g gate)
+        const float sg = fast_rcp(1.0f + __builtin_amdgcn_exp2f(act_in2 * pre));
+        const float si = quad_bcast<0>(sg), sf = quad_bcast<1>(sg), s2 = quad_bcast<2>(sg), so = quad_bcast<3>(sg);
+        const float A = fmaf(sf, c, -si);
+        const float Bp = si * s2;
+        c = fmaf(2.0f, Bp, A);
+        const float r = fast_rcp(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * c));
+        h = fmaf(r, -2.0f * so, so);
+        hw0[(cur ^ 1) * hstride] = h;
+        __builtin_amdgcn_sched_barrier(0);      // the LDS hand-off first: the streamed stores below are nobody's dependency
         if (!(DBG & 1)) {
-            gates_b[g_off] = act;
+            gates_b[g_off] = fmaf(act_mul, sg, -act_sub);      // the activation itself (tanh for the g gate): off the chain
             st_base[st_off] = (kq & 1) ? c : h;
         }
-        hw0[(cur ^ 1) * hstride] = h;
         g_off += g_step;
         st_off += s_step;
         cur ^= 1;
@@ -279,13 +294,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // one BPTT step given the saved gates (i,f,g,o) of step t, c of the step the forward recurrence ran before it, d_y[t]
     auto step = [&](const f4 g4, const float c_prev, const float dyv) {
+        // Everything that does not depend on dh -- tanh(c_t) with its two transcendentals, the gate selects, the activation
+        // derivative -- is computed BEFORE the matvec (round 4): behind the `if (!first)` block the compiler put it on the
+        // dependency chain reduce -> ... -> d_a -> LDS, where it cost ~60 cycles of every step.
+        const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
+        constexpr float LOG2E = 1.4426950408889634f;
+        const float tc = fmaf(fast_rcp(1.0f + __builtin_amdgcn_exp2f((-2.0f * LOG2E) * c_t)), 2.0f, -1.0f);   // tanh(c_t)
+        const float go_dtc = go * (1.0f - tc * tc);
+        // my gate's pre-activation gradient (kq = i,f,g,o):
+        //   i: dc_t*g*i(1-i)   f: dc_t*c_prev*f(1-f)   g: dc_t*i*(1-g^2)   o: dh_t*tanh(c)*o(1-o)
+        const float m1 = k2 ? (k1 ? 1.0f : gi) : (k1 ? c_prev : gg);
+        const float gv = k2 ? (k1 ? go : gg) : (k1 ? gf : gi);
+        const float dact = is_g ? 1.0f - gg * gg : gv * (1.0f - gv);
+        const float m1d = m1 * dact;
+        const float dh_dy = dh + dyv;          // first step: dh = d_hn; later steps: overwritten below
+        float dh_t = dh_dy;
         if (!first) {  // block-uniform
             const float* dq = &dabuf[cur][ks][0];
             f4 dv[KQP / 4];
 #pragma unroll
             for (int q = 0; q < KQP / 4; ++q) dv[q] = *reinterpret_cast<const f4*>(dq + 4 * q);
             __builtin_amdgcn_sched_group_barrier(0x100, KQP / 4, 0);  // the whole DS-read burst first
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            // d_y[t] rides in the accumulators: sum o of the row belongs to unit 4 ug + o, whose d_y the lanes ks = 4 o .. 4 o + 3
+            // hold; lane 4 o alone starts its partial sum a_o from it, so no add is left behind the reduction
+            float a0 = ks == 0 ? dyv : 0.f, a1 = ks == 4 ? dyv : 0.f, a2 = ks == 8 ? dyv : 0.f, a3 = ks == 12 ? dyv : 0.f;
 #pragma unroll
             for (int k4 = 0; k4 < KQP; k4 += 4) {
 #pragma unroll
@@ -302,24 +334,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             a1 = row16_allsum(a1);
             a2 = row16_allsum(a2);
             a3 = row16_allsum(a3);
-            dh = o2 ? (o1 ? a3 : a2) : (o1 ? a1 : a0);
+            dh_t = o2 ? (o1 ? a3 : a2) : (o1 ? a1 : a0);
         }
         first = false;
-        const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
-        const float tc = tanhf_(c_t);
-        const float dh_t = dh + dyv;
-        const float dc_t = fmaf(dh_t * go, 1.0f - tc * tc, dc);
-        // my gate's pre-activation gradient (kq = i,f,g,o):
-        //   i: dc_t*g*i(1-i)   f: dc_t*c_prev*f(1-f)   g: dc_t*i*(1-g^2)   o: dh_t*tanh(c)*o(1-o)
+        const float dc_t = fmaf(dh_t, go_dtc, dc);
         const float m0 = is_o ? dh_t * tc : dc_t;
-        const float m1 = k2 ? (k1 ? 1.0f : gi) : (k1 ? c_prev : gg);
-        const float gv = k2 ? (k1 ? go : gg) : (k1 ? gf : gi);
-        const float dact = is_g ? 1.0f - gg * gg : gv * (1.0f - gv);
-        const float da = m0 * m1 * dact;
+        const float da = m0 * m1d;
         dc = dc_t * gf;
         c_t = c_prev;
         if (valid) {  // loop-invariant predicate (only false for padded units when H % 4 != 0)
             daw0[(cur ^ 1) * dstride] = da;
+            __builtin_amdgcn_sched_barrier(0);  // the LDS hand-off first
             da_b[da_off] = da;
         }
         da_off += g_step;
