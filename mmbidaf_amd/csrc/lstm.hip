@@ -20,12 +20,60 @@
 // h_n is the state after the sample's own last step.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace mmb {
 
 constexpr int PF = 4;  // software prefetch distance (time steps) for the streamed per-step operands; vmcnt retires in
                        // issue order, so a prefetched load also waits for the older per-step stores: keep it deep
+
+// ---- prefetch ring of the recurrences' streamed operands (PF steps deep), and what it takes to keep hipcc from draining it.
+// Round 3's form -- `x = ring[j]; ring[j] = load(s + j + PF); step(x)` in a loop unrolled by PF -- issued every refill while the
+// slot's old value was still live, so each refill landed in a fresh register, the loop's back-edge copied the PF fresh
+// registers into place, and that copy waited for ALL of them: s_waitcnt vmcnt(1) once per PF steps, i.e. for a load not two
+// steps old -- a memory round trip exposed on the critical path of a 0.5-us step.  Now
+//  * a slot's old value is CONSUMED (copied / folded into the step's seed) before its refill is issued, with a scheduling
+//    barrier between the two, so the refill can live in the slot's own register and the back-edge needs no copies;
+//  * the first PF steps are peeled in the source: the loop header then merges two predecessors with the SAME operations in
+//    flight behind every slot, and the compiler's counted wait stays vmcnt(PF * ops - 1) instead of the loop-entry state's
+//    vmcnt(PF - 1) (which waits for everything but the last step's operations).
+// The forward kernel's one-register slots come out that way.  The BPTT kernel's slots are six registers each (a dwordx4 and two
+// dwords) and hipcc rotates them through the unrolled body whatever the source does, so its ring does not go through the
+// register allocator at all: the slots are the FIXED registers v232..v255, loaded and read only by asm statements that name
+// them (and list them as clobbers), with hand-counted waits -- vmcnt retires in issue order, so the count of a wait = the
+// vector-memory operations issued after the awaited load: 3 (3 - j) ring loads + 4 j in the first four steps, 4 * 4 - 3 = 13
+// afterwards (three refills + the d_a store per step; "memory" clobbers keep the compiler's store in program order).  The
+// kernel needs ~200 registers and hipcc hands them out from v0 upwards; tests/test_host_cpu.py::test_bptt_ring_registers_are_
+// reserved checks the built kernel's assembly for any other instruction touching v232..v255.  (Slots as "+v" asm operands were
+// tried first: hipcc copies them between registers across the back-edge, reading a slot whose load is still in flight.)
+#define MMB_RING_SLOT(NAME, R0, R1, R2, R3, RC, RY)                                                                                \
+    struct NAME {                                                                                                                   \
+        static __device__ __forceinline__ void load(const float* pg, const float* pc, const float* py) {                           \
+            asm volatile("global_load_dwordx4 v[" #R0 ":" #R3 "], %0, off\n\t"                                                      \
+                         "global_load_dword v" #RC ", %1, off\n\t"                                                                  \
+                         "global_load_dword v" #RY ", %2, off"                                                                      \
+                         :                                                                                                          \
+                         : "v"(pg), "v"(pc), "v"(py)                                                                                \
+                         : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3, "v" #RC, "v" #RY);                                       \
+        }                                                                                                                           \
+        template <int N>                                                                                                            \
+        static __device__ __forceinline__ void take(float& g0, float& g1, float& g2, float& g3, float& c, float& y) {               \
+            asm volatile("s_waitcnt vmcnt(%6)\n\t"                                                                                  \
+                         "v_mov_b32 %0, v" #R0 "\n\tv_mov_b32 %1, v" #R1 "\n\tv_mov_b32 %2, v" #R2 "\n\tv_mov_b32 %3, v" #R3 "\n\t" \
+                         "v_mov_b32 %4, v" #RC "\n\tv_mov_b32 %5, v" #RY                                                           \
+                         : "=v"(g0), "=v"(g1), "=v"(g2), "=v"(g3), "=v"(c), "=v"(y)                                               \
+                         : "n"(N)                                                                                                   \
+                         : "memory");                                                                                               \
+        }                                                                                                                           \
+    };
+namespace ring {
+MMB_RING_SLOT(S0, 232, 233, 234, 235, 236, 237)
+MMB_RING_SLOT(S1, 238, 239, 240, 241, 242, 243)
+MMB_RING_SLOT(S2, 244, 245, 246, 247, 248, 249)
+MMB_RING_SLOT(S3, 250, 251, 252, 253, 254, 255)
+}  // namespace ring
 
 struct RecFwdProb {
     const float* gx;       // (B,T,2,H,4)
@@ -63,17 +111,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the same values to the same addresses, so the step loop needs no "live" predicate at all
     const int u = min(tid >> 2, H - 1);
 
-    // ---- W_hh slice into registers
+    // ---- W_hh slice into registers.  Accumulator j of lane kq belongs to gate (kq + j) & 3 (ROTATED order, see the reduction in
+    // step()), and every weight already carries the factor its gate's sigmoid needs in front of v_exp_f32 (-log2 e; -2 log2 e
+    // for the g gate, tanh x = 2 sigma(2x) - 1): the matvec delivers the exponent itself, no multiply behind the reduction.
+    constexpr float LOG2E = 1.4426950408889634f;
     float w[4][KQ];
     {
         const float* W = P.w_hh[dir];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int j = 0; j < 4; ++j) {
+            const int g = (kq + j) & 3;
+            const float gs = g == 2 ? -2.0f * LOG2E : -LOG2E;
 #pragma unroll
             for (int kk = 0; kk < KQ; ++kk) {
                 const int k = kq * KQ + kk;
-                w[g][kk] = k < H ? W[(size_t)(g * H + u) * H + k] : 0.f;
+                // (clamped address + select, not a guarded load: hipcc gives every guarded load a branch of its own, and with
+                //  the multiply behind it a full s_waitcnt vmcnt(0) per weight -- 100 serial round trips per launch)
+                const float v = W[(size_t)(g * H + u) * H + min(k, H - 1)];
+                w[j][kk] = k < H ? v * gs : 0.f;
             }
+        }
     }
     for (int i = tid; i < 2 * 4 * KQP; i += blockDim.x) (&hbuf[0][0][0])[i] = 0.f;
 
@@ -93,27 +150,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* hw0 = &hbuf[0][u / KQ][u % KQ];                  // h_t slot of this unit (buffer 0)
     const int hstride = 4 * KQP;
 
-    float c = 0.f, h = 0.f;
+    float c2 = 0.f, c = 0.f, h = 0.f;     // c2 = 2 log2(e) c: the cell state as the exponent of its own tanh
     const bool is_tanh = kq == 2;
-    const bool b0 = kq & 1, b1 = kq & 2;
     // The serial tail of a step (reduce -> activation -> cell -> h) is what a time step costs beyond its FMAs, so every
     // operation that can be taken off that dependency chain is (round 4):
-    //  * sigma(x) = 1 / (1 + 2^(-x log2 e)): the factor -log2 e (-2 log2 e for the tanh gate, tanh x = 2 sigma(2x) - 1) is ONE
-    //    constant, one multiply in front of v_exp_f32 instead of two;
-    //  * gx enters as the INITIAL value of the lane's own gate accumulator (the transposing reduction sums a_g over the quad,
-    //    so a value added to a_g in exactly one lane -- lane g -- is added once): no add behind the reduction, and the wait
-    //    for the streamed gx moves to the start of the step, where it has long arrived;
-    //  * the cell update works on the raw sigmoids s_i, s_f, s_g (s_g = sigma(2 pre_g)):  c' = s_f c - s_i + 2 s_i s_g, with
-    //    A = s_f c - s_i and B = s_i s_g independent of each other; the activation tanh = 2 s_g - 1 that the backward pass
-    //    needs is formed beside the chain, for the store only;
-    //  * h = s_o tanh(c') = s_o - 2 s_o r with r = 1 / (1 + 2^(2 c' log2 e)):  one fma behind the reciprocal.
-    constexpr float LOG2E = 1.4426950408889634f;
+    //  * sigma(x) = 1 / (1 + 2^(-x log2 e)): the factor sits in the weights and in the seed (above), v_exp_f32 follows the
+    //    reduction directly;
+    //  * gx enters as the INITIAL value of the lane's own gate accumulator: no add behind the reduction, and the wait for the
+    //    streamed gx moves to the start of the step, where it has long arrived;
+    //  * rotated gate order: lane kq keeps gate (kq + j) & 3 in accumulator j, so the partial sum lane g needs from lane
+    //    g + k (mod 4) is accumulator 4 - k of THAT lane -- the same register index in every lane -- and the transposing quad
+    //    reduction is three chained v_add_f32_dpp (quad rotations by 1, 2, 3) with no select in front of any of them;
+    //  * the cell update works on the raw sigmoids s_i, s_f, s_g (s_g = sigma(2 pre_g)) and on the scaled state c2 = K c,
+    //    K = 2 log2 e:  c2' = s_f c2 + s_i K (2 s_g - 1), three operations behind the reciprocal, and v_exp_f32 takes c2'
+    //    as it stands; the activation tanh = 2 s_g - 1 and the cell state c = c2 / K that the backward pass needs are formed
+    //    beside the chain, for the stores only;
+    //  * h = s_o tanh(c') = s_o - 2 s_o r with r = 1 / (1 + 2^(c2')):  one fma behind the reciprocal.
+    constexpr float KC = 2.0f * LOG2E;
     const float act_in2 = is_tanh ? -2.0f * LOG2E : -LOG2E;
     const float act_mul = is_tanh ? 2.0f : 1.0f, act_sub = is_tanh ? 1.0f : 0.0f;
     int cur = 0;
 
-    // one time step, given the input-projection value gx of (t, dir, u, kq)
-    auto step = [&](const float gx) {
+    // one time step, given the (scaled) input-projection value of (t, dir, u, kq): seed = gx * act_in2
+    auto step = [&](const float seed) {
         // matvec: my quarter of h against my 4 gate rows.  All LDS reads are issued first, into distinct
         // registers (otherwise hipcc recycles 4 VGPRs and exposes the LDS latency several times per step)
         const float* hq = &hbuf[cur][kq][0];
@@ -121,7 +180,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int q = 0; q < KQP / 4; ++q) hv[q] = *reinterpret_cast<const f4*>(hq + 4 * q);
         __builtin_amdgcn_sched_group_barrier(0x100, KQP / 4, 0);  // the whole DS-read burst first
-        float a0 = kq == 0 ? gx : 0.f, a1 = kq == 1 ? gx : 0.f, a2 = kq == 2 ? gx : 0.f, a3 = kq == 3 ? gx : 0.f;
+        float a0 = seed, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int k4 = 0; k4 < KQP; k4 += 4) {
 #pragma unroll
@@ -134,23 +193,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-        // transposing quad reduction: lane kq ends with the full sum of gate kq
-        const float keepA = b0 ? a1 : a0, sendA = b0 ? a0 : a1;
-        const float keepB = b0 ? a3 : a2, sendB = b0 ? a2 : a3;
-        const float rA = keepA + quad_xor1(sendA);
-        const float rB = keepB + quad_xor1(sendB);
-        const float keep = b1 ? rB : rA, send = b1 ? rA : rB;
-        const float pre = keep + quad_xor2(send);
+        // transposing quad reduction: lane kq ends with the full (scaled) pre-activation of gate kq
+        float pre = a0 + quad_perm<0x39>(a3);      // from lane kq + 1: its accumulator 3
+        pre += quad_perm<0x4E>(a2);                // from lane kq + 2: its accumulator 2
+        pre += quad_perm<0x93>(a1);                // from lane kq + 3: its accumulator 1
         // raw sigmoid of my gate (of 2 pre for the g gate)
-        const float sg = fast_rcp(1.0f + __builtin_amdgcn_exp2f(act_in2 * pre));
-        const float si = quad_bcast<0>(sg), sf = quad_bcast<1>(sg), s2 = quad_bcast<2>(sg), so = quad_bcast<3>(sg);
-        const float A = fmaf(sf, c, -si);
-        const float Bp = si * s2;
-        c = fmaf(2.0f, Bp, A);
-        const float r = fast_rcp(1.0f + __builtin_amdgcn_exp2f((2.0f * LOG2E) * c));
+        const float sg = fast_rcp(1.0f + __builtin_amdgcn_exp2f(pre));
+        // c2' = s_f c2 + s_i G with G = K (2 s_g - 1) formed in every lane from its own sigmoid (lane 2's is the one that counts)
+        // beside the broadcasts: three levels behind the reciprocal -- {s_i, G} -> s_i G -> fma
+        const float G = fmaf(2.0f * KC, sg, -KC);
+        const float si = quad_bcast<0>(sg), sf = quad_bcast<1>(sg), so = quad_bcast<3>(sg);
+        c2 = fmaf(sf, c2, si * quad_bcast<2>(G));
+        const float r = fast_rcp(1.0f + __builtin_amdgcn_exp2f(c2));
         h = fmaf(r, -2.0f * so, so);
         hw0[(cur ^ 1) * hstride] = h;
         __builtin_amdgcn_sched_barrier(0);      // the LDS hand-off first: the streamed stores below are nobody's dependency
+        c = c2 * (1.0f / KC);
         if (!(DBG & 1)) {
             gates_b[g_off] = fmaf(act_mul, sg, -act_sub);      // the activation itself (tanh for the g gate): off the chain
             st_base[st_off] = (kq & 1) ? c : h;
@@ -161,26 +219,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();
     };
 
-    // prefetch ring: gxr[j] holds gx of step (s + j); refills are unconditional loads from a clamped step index,
-    // so the main loop body is straight-line code and the compiler keeps counted vmcnt waits
+    // prefetch ring: gxr[j] holds gx of step (s + j); refills are unconditional loads from a clamped step index, so the
+    // main loop body is straight-line code and the compiler keeps counted vmcnt waits (see the note on the ring above)
     const int gx_base = dir * 4 * H + u * 4 + kq;
     auto gx_at = [&](int sidx) { return (DBG & 2) ? 0.01f * sidx : gx_b[(t0 + sgn * min(sidx, len - 1)) * 8 * H + gx_base]; };
     float gxr[PFD];
     __syncthreads();
     int s = 0;
+    auto block = [&](int s0) {     // PFD steps s0 .. s0 + PFD - 1, each refilling its slot for step + PFD
+#pragma unroll
+        for (int j = 0; j < PFD; ++j) {
+            const float seed = gxr[j] * act_in2;
+            __builtin_amdgcn_sched_barrier(0);
+            gxr[j] = gx_at(s0 + j + PFD);
+            __builtin_amdgcn_sched_barrier(0);
+            step(seed);
+        }
+    };
     if (len >= PFD) {
 #pragma unroll
         for (int j = 0; j < PFD; ++j) gxr[j] = gx_at(j);
-        for (; s + PFD <= len; s += PFD) {
-#pragma unroll
-            for (int j = 0; j < PFD; ++j) {
-                const float gx = gxr[j];
-                gxr[j] = gx_at(s + j + PFD);
-                step(gx);
-            }
-        }
+        block(0);                                        // peeled: see the note on the ring
+        for (s = PFD; s + PFD <= len; s += PFD) block(s);
     }
-    for (; s < len; ++s) step(gx_at(s));  // tail (< PF steps): synchronous loads
+    for (; s < len; ++s) step(gx_at(s) * act_in2);  // tail (< PF steps): synchronous loads
 
     if (tid < 4 * H) {
         if (kq == 0) P.h_n[(P.hn_pos ? ((size_t)P.hn_pos[b] * 2 + dir) : ((size_t)dir * P.B + b)) * H + u] = h;
@@ -222,6 +284,12 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
     return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+// value of lane (i + 16 - N) % 16 of the row (DPP row_ror:N, rotate right: data moves to higher lanes), i.e. of the lane
+// 16 - N further on
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float row16_allsum(float v) {
     v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
     v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
@@ -230,7 +298,8 @@ __device__ __forceinline__ float row16_allsum(float v) {
     return v;
 }
 
-template <int KQ>
+// ALLV: H % 4 == 0, every unit of every 4-unit group exists (no predicate around the per-step stores)
+template <int KQ, bool ALLV = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_rec_bwd_kernel(const RecBwdArgs args) {
     constexpr int KQP = (KQ + 3) & ~3;
     __shared__ __attribute__((aligned(16))) float dabuf[2][16][KQP];
@@ -252,7 +321,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bool valid = u_raw < H;                 // H % 4 != 0: the last group has units beyond H
     const int u = min(u_raw, H - 1);
 
-    // ---- W_hh slice: wT[o][kk] = W_hh[(g*H + q*KQ + kk)][4*ug + o],  g = ks>>2, q = ks&3
+    // ---- W_hh slice: wT[j][kk] = W_hh[(g*H + q*KQ + kk)][4*ug + o],  g = ks>>2, q = ks&3, in ROTATED output order
+    // o = (ks>>2 + j) & 3: the lane's own unit (output ks>>2) is accumulator 0, and the partial sum the lane needs from the
+    // lane 4 k further on in the row is accumulator 4 - k of that lane (see the reduction in step())
     float wT[4][KQ];
     {
         const float* W = P.w_hh[dir];
@@ -261,9 +332,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int kk = 0; kk < KQ; ++kk) {
             const int k = q * KQ + kk;
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                const int uo = 4 * ug + o;
-                wT[o][kk] = (k < H && uo < H) ? W[(size_t)(g * H + k) * H + uo] : 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const int uo = 4 * ug + ((g + j) & 3);
+                wT[j][kk] = (k < H && uo < H) ? W[(size_t)(g * H + k) * H + uo] : 0.f;
             }
         }
     }
@@ -288,16 +359,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float db_acc = 0.f, da_max = 0.f;
     int cur = 0;
     bool first = true;
-    const bool o1 = (ks >> 2) & 1, o2 = (ks >> 2) & 2;   // which of the 4 sums is my unit's
     const bool k1 = kq & 1, k2 = kq & 2;                 // my gate, as select flags (no divergent branches in the loop)
     const bool is_g = kq == 2, is_o = kq == 3;
 
     // one BPTT step given the saved gates (i,f,g,o) of step t, c of the step the forward recurrence ran before it, d_y[t]
-    auto step = [&](const f4 g4, const float c_prev, const float dyv) {
+    // `refill` is called once every value of the ring slot has been consumed (see the note on the ring): the step's uses of
+    // (g4, c_prev, dyv) all sit in front of it, the two values needed to the end of the step are copied out.
+    auto step = [&](const f4 g4, const float c_prev_in, const float dyv, auto&& refill) {
         // Everything that does not depend on dh -- tanh(c_t) with its two transcendentals, the gate selects, the activation
         // derivative -- is computed BEFORE the matvec (round 4): behind the `if (!first)` block the compiler put it on the
         // dependency chain reduce -> ... -> d_a -> LDS, where it cost ~60 cycles of every step.
-        const float gi = g4.x, gf = g4.y, gg = g4.z, go = g4.w;
+        const float gi = g4.x, gg = g4.z, go = g4.w;
+        float gf, c_prev;      // needed to the end of the step: real copies, so that the slot's own registers are dead at the refill
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(gf), "=&v"(c_prev) : "v"(g4.y), "v"(c_prev_in));
         constexpr float LOG2E = 1.4426950408889634f;
         const float tc = fmaf(fast_rcp(1.0f + __builtin_amdgcn_exp2f((-2.0f * LOG2E) * c_t)), 2.0f, -1.0f);   // tanh(c_t)
         const float go_dtc = go * (1.0f - tc * tc);
@@ -308,16 +382,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float dact = is_g ? 1.0f - gg * gg : gv * (1.0f - gv);
         const float m1d = m1 * dact;
         const float dh_dy = dh + dyv;          // first step: dh = d_hn; later steps: overwritten below
+        const float a0_seed = kq == 0 ? dyv : 0.f;
         float dh_t = dh_dy;
+        __builtin_amdgcn_sched_barrier(0);
+        refill();
+        __builtin_amdgcn_sched_barrier(0);
         if (!first) {  // block-uniform
             const float* dq = &dabuf[cur][ks][0];
             f4 dv[KQP / 4];
 #pragma unroll
             for (int q = 0; q < KQP / 4; ++q) dv[q] = *reinterpret_cast<const f4*>(dq + 4 * q);
             __builtin_amdgcn_sched_group_barrier(0x100, KQP / 4, 0);  // the whole DS-read burst first
-            // d_y[t] rides in the accumulators: sum o of the row belongs to unit 4 ug + o, whose d_y the lanes ks = 4 o .. 4 o + 3
-            // hold; lane 4 o alone starts its partial sum a_o from it, so no add is left behind the reduction
-            float a0 = ks == 0 ? dyv : 0.f, a1 = ks == 4 ? dyv : 0.f, a2 = ks == 8 ? dyv : 0.f, a3 = ks == 12 ? dyv : 0.f;
+            // d_y[t] rides in the accumulators: accumulator 0 is the lane's own unit, whose d_y the four lanes of its quad hold;
+            // the first of them alone starts its partial sum from it, so no add is left behind the reduction
+            float a0 = a0_seed, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
             for (int k4 = 0; k4 < KQP; k4 += 4) {
 #pragma unroll
@@ -330,11 +408,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
             }
-            a0 = row16_allsum(a0);
-            a1 = row16_allsum(a1);
-            a2 = row16_allsum(a2);
-            a3 = row16_allsum(a3);
-            dh_t = o2 ? (o1 ? a3 : a2) : (o1 ? a1 : a0);
+            // transposing reduction over the row's 16 lanes (5 DPP adds where the plain all-reduce of 4 sums took 16 + selects):
+            // across the quads first -- lane (quad q, r) collects, for ITS unit, the partial sums of the lanes (q', r): from the
+            // lane 4 k further on (row rotation) accumulator 4 - k -- then over the 4 lanes of the quad
+            float dsum = a0 + row_ror<12>(a3);
+            dsum += row_ror<8>(a2);
+            dsum += row_ror<4>(a1);
+            dsum += quad_xor1(dsum);
+            dsum += quad_xor2(dsum);
+            dh_t = dsum;
         }
         first = false;
         const float dc_t = fmaf(dh_t, go_dtc, dc);
@@ -342,7 +424,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float da = m0 * m1d;
         dc = dc_t * gf;
         c_t = c_prev;
-        if (valid) {  // loop-invariant predicate (only false for padded units when H % 4 != 0)
+        if (ALLV || valid) {  // loop-invariant predicate (only false for padded units when H % 4 != 0)
             daw0[(cur ^ 1) * dstride] = da;
             __builtin_amdgcn_sched_barrier(0);  // the LDS hand-off first
             da_b[da_off] = da;
@@ -359,32 +441,68 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto ld_g = [&](int sidx) { return *reinterpret_cast<const f4*>(gates_b + row_of(sidx) * 8 * H); };
     auto ld_dy = [&](int sidx) { return dy_b[row_of(sidx) * 2 * H]; };
     // c of the step the forward recurrence processed before step sidx = the NEXT BPTT step; zero at the sequence start
-    auto ld_cp = [&](int sidx) { const float v = cs_b[row_of(sidx + 1) * 2 * H]; return sidx + 1 < len ? v : 0.f; };
+    auto ld_cp_raw = [&](int sidx) { return cs_b[row_of(sidx + 1) * 2 * H]; };      // (the select is applied when the value is used)
+    auto ld_cp = [&](int sidx) { const float v = ld_cp_raw(sidx); return sidx + 1 < len ? v : 0.f; };
 
-    f4 gr[PF];
-    float cpr[PF], dyr[PF];
     __syncthreads();
     int s = 0;
-    if (len >= PF) {
-#pragma unroll
-        for (int j = 0; j < PF; ++j) {
-            gr[j] = ld_g(j);
-            cpr[j] = ld_cp(j);
-            dyr[j] = ld_dy(j);
+    if constexpr (ALLV) {
+        static_assert(PF == 4, "the BPTT ring is written out for four slots");
+        // fixed-register ring (see the note on the ring at the top of the file)
+        auto issue = [&](auto slot, int sidx) {
+            decltype(slot)::load(gates_b + (size_t)(row_of(sidx) * 8 * H), cs_b + (size_t)(row_of(sidx + 1) * 2 * H), dy_b + (size_t)(row_of(sidx) * 2 * H));
+        };
+        auto rstep = [&](auto slot, auto cnt, int sidx) {
+            float g0, g1, g2, g3, cp, dyv;
+            decltype(slot)::template take<decltype(cnt)::value>(g0, g1, g2, g3, cp, dyv);
+            step(f4{g0, g1, g2, g3}, sidx + 1 < len ? cp : 0.f, dyv, [&]() { issue(slot, sidx + 4); });
+        };
+        using C9 = std::integral_constant<int, 9>;
+        using C10 = std::integral_constant<int, 10>;
+        using C11 = std::integral_constant<int, 11>;
+        using C12 = std::integral_constant<int, 12>;
+        using C13 = std::integral_constant<int, 13>;
+        if (len >= 4) {
+            issue(ring::S0{}, 0);
+            issue(ring::S1{}, 1);
+            issue(ring::S2{}, 2);
+            issue(ring::S3{}, 3);
+            // first four steps: fewer operations in flight behind the awaited loads
+            rstep(ring::S0{}, C9{}, 0);
+            rstep(ring::S1{}, C10{}, 1);
+            rstep(ring::S2{}, C11{}, 2);
+            rstep(ring::S3{}, C12{}, 3);
+            for (s = 4; s + 4 <= len; s += 4) {
+                rstep(ring::S0{}, C13{}, s);
+                rstep(ring::S1{}, C13{}, s + 1);
+                rstep(ring::S2{}, C13{}, s + 2);
+                rstep(ring::S3{}, C13{}, s + 3);
+            }
         }
-        for (; s + PF <= len; s += PF) {
+    } else {
+        // H % 4 != 0: the per-step store sits behind an exec-mask branch -- no static operation count; compiler-managed ring
+        f4 gr[PF];
+        float cpr[PF], dyr[PF];
+        if (len >= PF) {
 #pragma unroll
             for (int j = 0; j < PF; ++j) {
-                const f4 g4 = gr[j];
-                const float cp = cpr[j], dyv = dyr[j];
-                gr[j] = ld_g(s + j + PF);
-                cpr[j] = ld_cp(s + j + PF);
-                dyr[j] = ld_dy(s + j + PF);
-                step(g4, cp, dyv);
+                gr[j] = ld_g(j);
+                cpr[j] = ld_cp_raw(j);
+                dyr[j] = ld_dy(j);
+            }
+            for (; s + PF <= len; s += PF) {
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    step(gr[j], s + j + 1 < len ? cpr[j] : 0.f, dyr[j], [&]() {
+                        gr[j] = ld_g(s + j + PF);
+                        cpr[j] = ld_cp_raw(s + j + PF);
+                        dyr[j] = ld_dy(s + j + PF);
+                    });
+                }
             }
         }
     }
-    for (; s < len; ++s) step(ld_g(s), ld_cp(s), ld_dy(s));  // tail (< PF steps): synchronous loads
+    for (; s < len; ++s) step(ld_g(s), ld_cp(s), ld_dy(s), []() {});  // tail (< PF steps): synchronous loads
 
     if (real && valid) {
         if (P.db_part) P.db_part[((size_t)dir * P.B + b) * 4 * H + kq * H + u] = db_acc;
@@ -897,7 +1015,8 @@ extern "C" int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* d, int n, int
     switch (kq_for(H)) {
         case 8: rc = launch_rec(lstm_rec_bwd_kernel<8>, ra, wg, H, stream, MMB_K_LSTM_REC_BWD); break;
         case 16: rc = launch_rec(lstm_rec_bwd_kernel<16>, ra, wg, H, stream, MMB_K_LSTM_REC_BWD); break;
-        case 25: rc = launch_rec(lstm_rec_bwd_kernel<25>, ra, wg, H, stream, MMB_K_LSTM_REC_BWD); break;
+        case 25: rc = H % 4 == 0 ? launch_rec(lstm_rec_bwd_kernel<25, true>, ra, wg, H, stream, MMB_K_LSTM_REC_BWD)
+                                 : launch_rec(lstm_rec_bwd_kernel<25>, ra, wg, H, stream, MMB_K_LSTM_REC_BWD); break;
         default: rc = launch_rec(lstm_rec_bwd_kernel<32>, ra, wg, H, stream, MMB_K_LSTM_REC_BWD); break;
     }
     if (rc) return rc;

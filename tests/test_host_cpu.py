@@ -245,3 +245,36 @@ def test_bench_gpus2_entry_self_launches_over_gloo():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-cpu", "--config", "nope"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+def test_bptt_ring_registers_are_reserved(tmp_path):
+    """The BPTT recurrence keeps its prefetch ring in the FIXED registers v232..v255, touched only by asm statements that name
+    them (csrc/lstm.hip, note on the ring): hipcc must not have allocated any of them for a value of its own, or a refill landing
+    late would overwrite it.  Checked on the assembly hipcc produces for gfx950 (no GPU needed): inside the H = 100 kernel every
+    instruction that mentions v232..v255 is one of the ring's own loads or copies, the steady-state wait is the hand-counted
+    vmcnt(13), and nothing is spilled."""
+    import re
+    import subprocess
+    from mmbidaf_amd import build as B
+    src = os.path.join(B.CSRC, "lstm.hip")
+    out = tmp_path / "lstm.s"
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-I", B.CSRC, src, "-o", str(out)],
+                   check=True, capture_output=True, timeout=900)
+    text = out.read_text()
+    name = "_ZN3mmb19lstm_rec_bwd_kernelILi25ELb1EEEvNS_10RecBwdArgsE"
+    start = text.index(f"\n{name}:")
+    body = text[start:text.index("s_endpgm", start)]
+    ring = re.compile(r"\bv(23[2-9]|24[0-9]|25[0-5])\b|v\[(23[2-9]|24[0-9]|25[0-5]):")
+    ok_load = re.compile(r"^\s*global_load_dword(x4)?\s+v(\[\d+:\d+\]|\d+),\s+v\[\d+:\d+\],\s+off\s*$")
+    ok_copy = re.compile(r"^\s*v_mov_b32\s+v\d+,\s+v(23[2-9]|24[0-9]|25[0-5])\s*$")
+    hits = [l for l in body.splitlines() if ring.search(l)]
+    assert len(hits) >= 8 * 6 + 8 * 3, f"only {len(hits)} ring instructions found: is the fixed-register ring still what is built?"
+    bad = [l for l in hits if not (ok_load.match(l) or ok_copy.match(l))]
+    assert not bad, "instructions outside the ring touch v232..v255:\n" + "\n".join(bad[:10])
+    dests = [l for l in hits if ok_copy.match(l)]
+    assert all(int(re.match(r"^\s*v_mov_b32\s+v(\d+),", l).group(1)) < 232 for l in dests)
+    assert body.count("s_waitcnt vmcnt(13)") >= 4
+    meta = text[text.index(f".name:           {name}"):]
+    meta = meta[:meta.index(".wavefront_size")]
+    assert re.search(r"\.vgpr_spill_count:\s+0\b", meta) and re.search(r"\.private_segment_fixed_size:\s+0\b", meta), meta
