@@ -49,10 +49,24 @@ class MMBiDAF(nn.Module):
         """models.py:97,102,113,116-118,131-135: returns the two modality-aware encodings and
         their (length-sorted) final hidden states (+ the text mask); with_decoder_hidden=True appends the decoder's initial
         hidden state (B,1,H) = sum of both encoders' final states over layers and directions (models.py:143)."""
+        dev = text_emb.device
+        if dev.type == "cuda":
+            # the whole region as ONE autograd node with a lean host side (mmbidaf_amd/region_fn.py): same library calls, same
+            # results; taken for the reference's exact module structure, anything else runs module by module below
+            from . import region_fn
+            lens3 = (text_lengths, audio_lengths, image_lengths)
+            if region_fn.eligible(self, (text_emb, audio_emb, image_emb), lens3):
+                outs = region_fn.region_forward(self, text_emb, audio_emb, image_emb, *lens3)
+                if outs is not None:
+                    mod_a, hid_a, mod_i, hid_i, dec = outs
+                    meta = region_fn._meta(dev, lens3)
+                    text_mask = PrefixMask(text_lengths, text_emb.size(1), meta[:len(text_lengths)])
+                    if with_decoder_hidden:
+                        return mod_a, hid_a, mod_i, hid_i, text_mask, dec.unsqueeze(1)
+                    return mod_a, hid_a, mod_i, hid_i, text_mask
         (text_enc, _), (audio_enc, _), (image_enc, _) = encode_group(
             [self.text_enc, self.audio_enc, self.image_enc], [text_emb, audio_emb, image_emb],
             [text_lengths, audio_lengths, image_lengths])
-        dev = text_emb.device
         # the reference builds bool prefix masks on the host and copies them every forward (models.py:116-118,126-128);
         # here a prefix mask travels as its int32 length vector (already on the device for the encoders) and the
         # attention kernels derive mask[b, i] = i < len[b] themselves (SURVEY 8(f) row N4)

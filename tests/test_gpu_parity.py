@@ -1769,3 +1769,50 @@ def test_persist_timeout_status_word_is_checked_and_can_be_cleared():
     assert prev in (0, 1)
     assert lib.mmb_lstm_persist_reset() == 0
     lib.mmb_lstm_persist_enable(prev)
+
+
+@pytest.mark.parametrize("drop_prob", [0.0, 0.25])
+def test_single_node_region_equals_the_modular_path_bit_for_bit(monkeypatch, drop_prob):
+    """mmbidaf_amd/region_fn.py issues the same library calls as the module-by-module path from ONE autograd node with a lean
+    host side.  Same inputs, same generator state: every output, input gradient and parameter gradient
+    must be IDENTICAL (attention parameter gradients are sums of atomics: 1e-6), in eval mode and in training mode with
+    dropout -- and the node must actually be what ran."""
+    from mmbidaf_amd import synth, region_fn
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    shape = (5, 70, 41, 9, 100)
+    torch.manual_seed(224)
+    region = HotRegion(100, drop_prob=drop_prob).to(d)
+    region.train(drop_prob > 0)
+    batch = synth.make_batch(shape, ragged=True)
+    gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    calls = []
+    orig = region_fn._RegionFn.apply
+    monkeypatch.setattr(region_fn._RegionFn, "apply", staticmethod(lambda *a: (calls.append(1), orig(*a))[1]))
+
+    def run(enabled):
+        monkeypatch.setattr(region_fn, "_ENABLED", enabled)
+        for p in region.parameters():
+            p.grad = None
+        xs = [gpu[k].detach().clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+        torch.manual_seed(777)
+        outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+        synth.region_loss(outs, gpu).backward()
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in outs], [x.grad.clone() for x in xs], {n: p.grad.clone() for n, p in region.named_parameters()}
+    o1, g1, p1 = run(True)
+    assert len(calls) == 1, "the single-node path was not taken"
+    o0, g0, p0 = run(False)
+    assert len(calls) == 1
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)
+    for n in p1:
+        if "bidaf_att" in n:
+            close(p1[n], p0[n].cpu(), "single-node grad " + n, tol=1e-6)
+        else:
+            assert torch.equal(p1[n], p0[n]), n
+    # b_ih / b_hh gradients are equal but distinct storage (ADVICE r01)
+    ptrs = [p.grad.data_ptr() for p in region.parameters()]
+    assert len(set(ptrs)) == len(ptrs)
