@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMB_VERSION 400            /* round 4 ABI: + persistent-recurrence reset / enable */
+#define MMB_VERSION 401            /* round 4 ABI: + persistent-recurrence reset / enable, mmb_stream_occupy */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
 #define MMB_ATT_MAX_D 208          /* attention feature width D = 2H of the fused (register-resident) kernels */
 #define MMB_ATT_GENERAL_MAX_D 4096 /* wider D (up to this) runs the general path: similarity matrix in a workspace */
@@ -250,6 +250,12 @@ int mmb_stream_destroy(int device, void* stream);
  * recurrence that is launched on another stream at the same point of the dependency graph, so that the recurrence's
  * workgroups are dispatched first also when both branches of a replayed hipGraph start together (see csrc/api.hip). */
 int mmb_stream_delay(int device, void* stream, int microseconds);
+/* Test / rehearsal aid: `workgroups` one-wave workgroups that each hold `lds_bytes` of LDS for `microseconds` on `stream` and do
+ * nothing else -- a stand-in for a long-lived kernel of another stream (e.g. an RCCL collective) sharing the chip with the
+ * persistent recurrence, whose workgroups must be resident together (tests: the recurrence finishes, with correct results and
+ * a zero time-out word, once the tenant has gone; a tenant that outlasts the bounded spin makes the NEXT call fail). */
+int mmb_stream_occupy(int device, void* stream, int microseconds, int workgroups, int lds_bytes);
+
 
 /* loss = sum_k <x_k, w_k> over up to MMB_WSUM_MAX tensors of n[k] floats (w_k null: plain sum of x_k) into out[0], and its
  * gradient dx_k = g[0] * w_k (g a device scalar).  This is the synthetic objective of the throughput measurement (SURVEY.md

@@ -16,7 +16,7 @@ ATT_GENERAL_MAX_D = 4096     # general path (similarity matrix in a workspace)
 LSTM_MAX_H = 128            # register-resident recurrence (one launch per layer)
 LSTM_GENERAL_MAX_H = 1024   # general recurrence (one launch per time step)
 
-ABI_VERSION = 400           # MMB_VERSION the signatures below were written for (include/mmbidaf.h)
+ABI_VERSION = 401           # MMB_VERSION the signatures below were written for (include/mmbidaf.h)
 
 c_f = ctypes.c_void_p  # device pointers travel as raw addresses
 c_i = ctypes.c_int
@@ -93,6 +93,7 @@ SIGNATURES = {
     "mmb_lstm_persist_reset": (c_i, []),
     "mmb_lstm_persist_enable": (c_i, [c_i]),
     "mmb_stream_delay": (c_i, [c_i, c_f, c_i]),
+    "mmb_stream_occupy": (c_i, [c_i, c_f, c_i, c_i, c_i]),
     "mmb_hidden_states_fwd": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_i, ctypes.POINTER(ctypes.c_void_p), c_f, c_i, c_i, c_i, c_f]),
     "mmb_hidden_states_bwd": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_i, c_i, c_f]),
     "mmb_bilstm_ws_bytes": (ctypes.c_size_t, [c_i] * 5),

@@ -153,6 +153,32 @@ __global__ __launch_bounds__(64) void delay_kernel(const long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 }  // namespace mmb
+// A stand-in TENANT for liveness rehearsals of the persistent recurrence: `workgroups` workgroups of one
+// wave, each holding `lds_bytes` of LDS for `microseconds` of the 100 MHz wall clock.  With lds_bytes near the CU's 160 KiB a
+// tenant workgroup keeps every other workgroup off its CU for that long -- what a long-lived kernel of another stream (an RCCL
+// collective under overlap=True) does to a launch that needs all its workgroups resident together.
+namespace mmb {
+__global__ __launch_bounds__(64) void occupy_kernel(const long long ticks) {
+    extern __shared__ char occupy_lds[];
+    if (threadIdx.x == 0) occupy_lds[0] = 1;      // (the allocation must be real)
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace mmb
+extern "C" int mmb_stream_occupy(int device, void* stream, int microseconds, int workgroups, int lds_bytes) {
+    MMB_REQUIRE(microseconds >= 0 && microseconds <= 5000000 && workgroups >= 1 && workgroups <= 4096 && lds_bytes >= 0 && lds_bytes <= 160 * 1024,
+                "mmb_stream_occupy: 0 <= microseconds <= 5e6, 1 <= workgroups <= 4096, 0 <= lds_bytes <= 160 KiB");
+    MMB_HIP(hipSetDevice(device));
+    static mmb::PerDeviceOnce attr;
+    if (attr.pending()) {
+        MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mmb::occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr.mark();
+    }
+    hipLaunchKernelGGL(mmb::occupy_kernel, dim3(workgroups), dim3(64), (size_t)lds_bytes, static_cast<hipStream_t>(stream), (long long)microseconds * 100);
+    MMB_HIP(hipGetLastError());
+    return MMB_OK;
+}
+
 extern "C" int mmb_stream_delay(int device, void* stream, int microseconds) {
     MMB_REQUIRE(microseconds >= 0 && microseconds <= 1000, "mmb_stream_delay: 0 <= microseconds <= 1000");
     MMB_HIP(hipSetDevice(device));

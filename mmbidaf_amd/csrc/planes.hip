@@ -264,39 +264,46 @@ __global__ __launch_bounds__(256) void split_rows16_reg_kernel(const SplitRowsGr
 }
 
 // Planes of the TRANSPOSE of a virtual (R x sum cols) matrix: plane row = source column (global, over the concatenated
-// segments), K = source row.  32 source rows x 64 columns per workgroup through LDS; each wave writes whole chunks.
+// segments), K = source row.  A workgroup takes ST_KT consecutive K tiles (32 source rows each) x 64 columns through LDS, every
+// load of all of them requested before the first wait (round 4: one K tile per workgroup -- 8 KB per workgroup behind two
+// barriers -- ran at 0.45 TB/s on the 680-MB pass of the H = 512 configuration); each wave writes whole chunks.
+constexpr int ST_KT = 4;
 __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTGroup G) {
-    __shared__ float tile[32][65];
+    __shared__ float tile[ST_KT][32][65];
     __shared__ float segs[3];
     const SplitTArgs& a = G.a[blockIdx.z];
-    const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 64;
+    const int kbase = blockIdx.x * 32 * ST_KT, c0 = blockIdx.y * 64;
     const int t = threadIdx.x;
     if (a.zero_ptr) {   // (every workgroup of the pass's grid slice takes part, also those beyond its own extent)
         const long total = (long)gridDim.x * gridDim.y * 256;
         for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + t; i < a.zero_n; i += total) a.zero_ptr[i] = 0.f;
     }
-    if (k0 >= a.Rp || c0 >= (a.Ctot + 15) / 16 * 16) return;
-    // load 32 source rows x 64 columns (two float4 per thread), per-chunk segment lookup, shifted rows, zero outside
-    f4 vload[2];
+    if (kbase >= a.Rp || c0 >= (a.Ctot + 15) / 16 * 16) return;
+    // load ST_KT x (32 source rows x 64 columns) (two float4 per thread and K tile), per-chunk segment lookup, shifted rows,
+    // zero outside
+    const int lcol = c0 + (t & 15) * 4;
+    int lc = lcol, lsg = 0;
+    while (lsg < a.nseg - 1 && lc >= a.seg_cols[lsg]) lc -= a.seg_cols[lsg++];
+    const int lsh = a.seg_shift[lsg];
+    const float* lseg = a.seg_ptr[lsg];
+    const size_t lld = a.seg_ld[lsg];
+    f4 vload[ST_KT][2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int kk = (t >> 4) + 16 * h, col = c0 + (t & 15) * 4;
-        f4 v = f4{0.f, 0.f, 0.f, 0.f};
-        if (col < a.Ctot && k0 + kk < a.R) {
-            int c = col, sg = 0;
-            while (sg < a.nseg - 1 && c >= a.seg_cols[sg]) c -= a.seg_cols[sg++];
-            const int sh = a.seg_shift[sg];
-            const int gk = k0 + kk;
-            const int tt = gk % a.period + sh;
-            if (tt >= 0 && tt < a.period) {
-                const int sr = gk + sh;
-                const float* base = (a.stack_ptr && sr >= a.stack_R1) ? a.stack_ptr + (size_t)(sr - a.stack_R1) * a.seg_ld[sg]
-                                                                      : a.seg_ptr[sg] + (size_t)sr * a.seg_ld[sg];
-                v = *reinterpret_cast<const f4*>(base + c);
+    for (int kt = 0; kt < ST_KT; ++kt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int gk = kbase + 32 * kt + (t >> 4) + 16 * h;
+            f4 v = f4{0.f, 0.f, 0.f, 0.f};
+            if (lcol < a.Ctot && gk < a.R) {
+                const int tt = gk % a.period + lsh;
+                if (tt >= 0 && tt < a.period) {
+                    const int sr = gk + lsh;
+                    const float* base = (a.stack_ptr && sr >= a.stack_R1) ? a.stack_ptr + (size_t)(sr - a.stack_R1) * lld : lseg + (size_t)sr * lld;
+                    v = *reinterpret_cast<const f4*>(base + lc);
+                }
             }
+            vload[kt][h] = v;
         }
-        vload[h] = v;
-    }
     if (a.np == 2 && t < 64) {   // per-segment power-of-two scale from the producers' bound on max |x| (one wave, parallel scan)
         for (int g = 0; g < 3; ++g) {
             float amax = a.seg_bound[g];
@@ -310,31 +317,41 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTGroup 
         }
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int kk = (t >> 4) + 16 * h;
-        float* d = &tile[kk][(t & 15) * 4];
-        d[0] = vload[h].x; d[1] = vload[h].y; d[2] = vload[h].z; d[3] = vload[h].w;
-    }
+    for (int kt = 0; kt < ST_KT; ++kt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kk = (t >> 4) + 16 * h;
+            float* d = &tile[kt][kk][(t & 15) * 4];
+            d[0] = vload[kt][h].x; d[1] = vload[kt][h].y; d[2] = vload[kt][h].z; d[3] = vload[kt][h].w;
+        }
     __syncthreads();
     // each thread: one plane row (source column), one k-octet; a wave = one chunk per plane (columns past Ctot are zeros)
     const int oc = t & 3, cl = t >> 2;
     const int col = c0 + cl;
     if (col >= (a.Ctot + 15) / 16 * 16) return;
-    float x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = tile[8 * oc + j][cl];
+    float sc = 1.f;
     if (a.np == 2) {
         int c = col, sg = 0;
         while (sg < a.nseg - 1 && c >= a.seg_cols[sg]) c -= a.seg_cols[sg++];
-        const float sc = segs[sg];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] *= sc;
-        store_planes16(a.planes, pl_off(col, (k0 >> 3) + oc, a.Rp / 32, 2), x);
+        sc = segs[sg];
         if (blockIdx.x == 0 && oc == 0 && col < a.Ctot) a.inv_out[col] = 1.0f / sc;
-    } else if (a.np == 1) {
-        store_planes1(a.planes, pl_off(col, (k0 >> 3) + oc, a.Rp / 32, 1), x);
-    } else {
-        store_planes(a.planes, pl_off(col, (k0 >> 3) + oc, a.Rp / 32), x);
+    }
+#pragma unroll
+    for (int kt = 0; kt < ST_KT; ++kt) {
+        const int k0 = kbase + 32 * kt;
+        if (k0 >= a.Rp) break;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = tile[kt][8 * oc + j][cl];
+        if (a.np == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] *= sc;
+            store_planes16(a.planes, pl_off(col, (k0 >> 3) + oc, a.Rp / 32, 2), x);
+        } else if (a.np == 1) {
+            store_planes1(a.planes, pl_off(col, (k0 >> 3) + oc, a.Rp / 32, 1), x);
+        } else {
+            store_planes(a.planes, pl_off(col, (k0 >> 3) + oc, a.Rp / 32), x);
+        }
     }
 }
 
@@ -669,7 +686,7 @@ int planes_split_transpose_group(const SplitTArgs* as, int n, hipStream_t stream
     unsigned gx = 1, gy = 1;
     for (int i = 0; i < n; ++i) {
         G.a[i] = as[i];
-        gx = std::max(gx, (unsigned)((as[i].Rp + 31) / 32));
+        gx = std::max(gx, (unsigned)((as[i].Rp + 32 * ST_KT - 1) / (32 * ST_KT)));
         gy = std::max(gy, (unsigned)((as[i].Ctot + 63) / 64));
     }
     ProfScope ps_(MMB_K_SPLIT, stream);

@@ -1822,3 +1822,58 @@ def test_single_node_region_equals_the_modular_path_bit_for_bit(monkeypatch, dro
     # b_ih / b_hh gradients are equal but distinct storage
     ptrs = [p.grad.data_ptr() for p in region.parameters()]
     assert len(set(ptrs)) == len(ptrs)
+
+
+_TENANT_SCRIPT = """
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from mmbidaf_amd import _lib
+from mmbidaf_amd.encoding import RNNEncoder
+lib = _lib.load()
+dev = torch.device("cuda:0")
+torch.manual_seed(17)
+e = RNNEncoder(64, 512, 2).to(dev)
+g = torch.Generator().manual_seed(18)
+x = (torch.randn(64, 120, 64, generator=g) * 0.5).to(dev)
+lens = [120] + [int(v) for v in torch.randint(1, 121, (63,), generator=g)]
+def run(tenant_us):
+    xx = x.clone().requires_grad_(True)
+    for p in e.parameters():
+        p.grad = None
+    side = torch.cuda.Stream()
+    if tenant_us:
+        # a tenant that takes whole CUs (150 KiB of LDS per one-wave workgroup, one per CU) on another stream, started first
+        _lib.check(lib.mmb_stream_occupy(0, side.cuda_stream, tenant_us, 256, 150 * 1024), "occupy")
+    y, h = e(xx, lens)
+    (y.square().sum() + h.sum()).backward()
+    torch.cuda.synchronize()
+    return y.detach().clone(), xx.grad.clone(), [p.grad.clone() for p in e.parameters()]
+ref = run(0)
+assert _lib.persist_timeouts() == 0
+got = run(int(sys.argv[2]))
+n = _lib.persist_timeouts()
+if n:
+    print("TIMEOUT", n)
+    sys.exit(3)          # the consumer of the step must not use its results
+for a, b in zip([ref[0], ref[1]] + ref[2], [got[0], got[1]] + got[2]):
+    assert torch.allclose(a, b, atol=1e-5 * max(1.0, a.abs().max().item())), (a - b).abs().max()
+print("OK")
+"""
+
+
+def test_persistent_recurrence_survives_a_concurrent_tenant_and_reports_a_timeout(tmp_path):
+    """VERDICT r03 item 6 / ADVICE r03: the persistent H = 512 recurrence needs the workgroups of a chain resident together.  A
+    stand-in tenant (mmb_stream_occupy: 256 workgroups that each take a whole CU's LDS) is started on another stream just
+    before a two-layer H = 512 encoder step:
+      * a tenant that leaves after 20 ms only delays the step: same results as without it, time-out word 0;
+      * (not run by default -- it costs the 3-s bounded spin) a tenant that outlasts the spin must surface as a non-zero
+        time-out word, which the child turns into a non-zero exit code."""
+    import subprocess
+    script = tmp_path / "tenant.py"
+    script.write_text(_TENANT_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, str(script), root, "20000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    if os.environ.get("MMB_TEST_TENANT_TIMEOUT") == "1":
+        r = subprocess.run([sys.executable, str(script), root, "4000000"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 3 and "TIMEOUT" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
