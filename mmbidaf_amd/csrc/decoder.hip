@@ -279,6 +279,10 @@ static size_t dec_lds_floats(int T, int H, int E, int L) {
 }
 
 // forward, part 1: workgroup (sample, modality, T chunk) streams its rows of the projection / memory once
+// (NQ = float4 columns per lane: 1 for 2H <= 256, 2 up to 512, 4 up to 1024 -- a kernel per width, so that the H = 100 model
+//  does not pay the registers and scratch of the widest instance: one kernel dispatching at run time was compiled at 256
+//  registers with 584 B/lane of scratch for EVERY width)
+template <int NQ>
 __global__ __launch_bounds__(DEC_NT) void decoder_att_fwd_kernel(const DecFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const mmb_decoder_params& w = a.w;
@@ -294,9 +298,9 @@ __global__ __launch_bounds__(DEC_NT) void decoder_att_fwd_kernel(const DecFwdArg
     const int t_lo = c * a.chunk, t_hi = min(T, t_lo + a.chunk);
     const size_t mo = (size_t)b * T * H2;
     if (a.dbg & 1) return;
-    dec_attention((m ? a.proj_i : a.proj_a) + mo, (m ? a.enc_i : a.enc_a) + mo, hm, a.cov + (size_t)b * T, m ? w.wc2 : w.wc1,
-                  m ? w.bc2 : w.bc1, m ? w.v2 : w.v1, (m ? w.bv2 : w.bv1)[0], H2, t_lo, t_hi, a.e_raw + ((size_t)b * 2 + m) * T,
-                  a.part + (((size_t)b * 2 + m) * a.nch + c) * (H2 + 2), wred);
+    dec_attention_t<NQ>((m ? a.proj_i : a.proj_a) + mo, (m ? a.enc_i : a.enc_a) + mo, hm, a.cov + (size_t)b * T, m ? w.wc2 : w.wc1,
+                        m ? w.bc2 : w.bc1, m ? w.v2 : w.v1, (m ? w.bv2 : w.bv1)[0], H2, t_lo, t_hi, a.e_raw + ((size_t)b * 2 + m) * T,
+                        a.part + (((size_t)b * 2 + m) * a.nch + c) * (H2 + 2), wred);
 }
 
 // forward, part 2: one workgroup per sample combines the partials and does the rest of the step
@@ -414,7 +418,9 @@ __device__ void dec_attention_bwd_t(const float* __restrict__ P, const float* __
         dcx[q] = live[q] ? ld4(dctx + dcl[q]) : f4{0.f, 0.f, 0.f, 0.f};
     }
     float a_bv = 0.f;
-    constexpr int RB = 4;   // memory rows per wave iteration: all loads (incl. the old gradients) issued up front, branch-free
+    // memory rows per wave iteration: all loads (incl. the old gradients) issued up front, branch-free; fewer rows for the wide
+    // instances (4 rows x 4 column groups x 4 tensors of float4 would be 256 registers by itself)
+    constexpr int RB = NQ == 1 ? 4 : NQ == 2 ? 2 : 1;
     for (int t0 = t_lo + wave * RB; t0 < t_hi; t0 += DEC_NW * RB) {
         float part[RB], ct[RB];
         f4 tz[RB][NQ], gp[RB][NQ], ge[RB][NQ];
@@ -616,6 +622,7 @@ __global__ __launch_bounds__(DEC_NT) void decoder_step_bwd_kernel(const DecBwdAr
 }
 
 // backward, part 2: workgroup (sample, modality, T chunk): d_proj / d_enc rows, per-chunk partial sums, d_cov terms
+template <int NQ>
 __global__ __launch_bounds__(DEC_NT) void decoder_att_bwd_kernel(const DecBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const mmb_decoder_params& w = a.w;
@@ -634,11 +641,11 @@ __global__ __launch_bounds__(DEC_NT) void decoder_att_bwd_kernel(const DecBwdArg
     __syncthreads();
     const int t_lo = c * a.chunk, t_hi = min(T, t_lo + a.chunk);
     const size_t mo = (size_t)b * T * H2;
-    dec_attention_bwd((m ? a.proj_i : a.proj_a) + mo, (m ? a.enc_i : a.enc_a) + mo, hm, a.cov + (size_t)b * T, m ? w.wc2 : w.wc1,
-                      m ? w.bc2 : w.bc1, m ? w.v2 : w.v1, a.saved + (size_t)b * a.saved_stride + m * T, bs + 2 * H2,
-                      bs[2 * H2 + T + 2 + m], dctx, bs[2 * H2 + T + m], H2, t_lo, t_hi, (m ? a.d_proj_i : a.d_proj_a) + mo,
-                      (m ? a.d_enc_i : a.d_enc_a) + mo, a.dcovm + ((size_t)b * 2 + m) * T,
-                      a.bpart + (((size_t)b * 2 + m) * a.nch + c) * (3 * H2 + 4), wred, scratch);
+    dec_attention_bwd_t<NQ>((m ? a.proj_i : a.proj_a) + mo, (m ? a.enc_i : a.enc_a) + mo, hm, a.cov + (size_t)b * T, m ? w.wc2 : w.wc1,
+                            m ? w.bc2 : w.bc1, m ? w.v2 : w.v1, a.saved + (size_t)b * a.saved_stride + m * T, bs + 2 * H2,
+                            bs[2 * H2 + T + 2 + m], dctx, bs[2 * H2 + T + m], H2, t_lo, t_hi, (m ? a.d_proj_i : a.d_proj_a) + mo,
+                            (m ? a.d_enc_i : a.d_enc_a) + mo, a.dcovm + ((size_t)b * 2 + m) * T,
+                            a.bpart + (((size_t)b * 2 + m) * a.nch + c) * (3 * H2 + 4), wred, scratch);
 }
 
 // backward, part 3: per sample, fold the chunk partials: delta_ha / delta_hi, the small vector gradients, d_cov, d_h
@@ -742,10 +749,14 @@ extern "C" int mmb_decoder_step_fwd(const mmb_decoder_params* w, const float* en
     static PerDeviceOnce attr;
     if (attr.pending()) {
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_step_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_att_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_att_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_att_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_att_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr.mark();
     }
-    hipLaunchKernelGGL(decoder_att_fwd_kernel, dim3(B, 2 * a.nch), dim3(DEC_NT), lds_att, stream, a);
+    MMB_REQUIRE(H2 <= 1024, "mmb_decoder_step_fwd: hidden size %d too large (2H <= 1024)", H);
+    auto att_k = H2 <= 256 ? decoder_att_fwd_kernel<1> : H2 <= 512 ? decoder_att_fwd_kernel<2> : decoder_att_fwd_kernel<4>;
+    hipLaunchKernelGGL(att_k, dim3(B, 2 * a.nch), dim3(DEC_NT), lds_att, stream, a);
     hipLaunchKernelGGL(decoder_step_fwd_kernel, dim3(B), dim3(DEC_NT), lds, stream, a);
     MMB_HIP(hipGetLastError());
     return MMB_OK;
@@ -785,11 +796,15 @@ extern "C" int mmb_decoder_step_bwd(const mmb_decoder_params* w, const float* en
     static PerDeviceOnce attr;
     if (attr.pending()) {
         MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_step_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_att_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_att_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_att_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MMB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_att_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr.mark();
     }
+    MMB_REQUIRE(H2 <= 1024, "mmb_decoder_step_bwd: hidden size %d too large (2H <= 1024)", H);
+    auto att_k = H2 <= 256 ? decoder_att_bwd_kernel<1> : H2 <= 512 ? decoder_att_bwd_kernel<2> : decoder_att_bwd_kernel<4>;
     hipLaunchKernelGGL(decoder_step_bwd_kernel, dim3(B), dim3(DEC_NT), lds, stream, a);
-    hipLaunchKernelGGL(decoder_att_bwd_kernel, dim3(B, 2 * a.nch), dim3(DEC_NT), lds_att, stream, a);
+    hipLaunchKernelGGL(att_k, dim3(B, 2 * a.nch), dim3(DEC_NT), lds_att, stream, a);
     hipLaunchKernelGGL(decoder_fin_bwd_kernel, dim3(B), dim3(DEC_NT), lds_fin, stream, a);
     MMB_HIP(hipGetLastError());
     return MMB_OK;

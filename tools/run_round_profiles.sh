@@ -7,7 +7,7 @@ TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
-B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary"
 rm -rf $R/gpurun_out/prof_stats
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats -o trace --output-format csv -- $B > $R/gpurun_out/${TAG}_rocprof_bench.json 2> $R/gpurun_out/${TAG}_rocprof.err
 python3 $R/tools/profile_summary.py stats $R/gpurun_out/prof_stats > $R/gpurun_out/${TAG}_kernel_stats.md
