@@ -1043,6 +1043,12 @@ def _region_batch_independence(shape, sub, ragged=True, tol=2e-5):
         raise AssertionError(str(e) + " || repeat: " + "; ".join(rep)) from e
 
 
+def test_hot_region_cfg4_full_size_vs_oracle():
+    """BASELINE.json config 4 at FULL size (B=32, T=1600/1024/256, H=100, ragged): every output and gradient against the oracle
+    (full-size cfg4 was covered by properties only) -- the CPU side takes about a minute."""
+    _region_vs_oracle((32, 1600, 1024, 256, 100), ragged=True)
+
+
 def test_hot_region_cfg4_full_size_properties():
     """config 4 at FULL size (B=32, T=1600, M=1024/256): finite, exact zeros in the padding, batch independence."""
     _region_batch_independence((32, 1600, 1024, 256, 100), sub=2)
@@ -1058,6 +1064,12 @@ def test_hot_region_cfg5_hidden512_full_lengths_vs_oracle():
     """config 5's hidden size at its FULL sequence lengths (T=400/256/64) on a batch of 2: the fused-step recurrence carries
     its operands between 400 steps as fp16 planes with a running scale -- what a T=48 case does not stress."""
     _region_vs_oracle((2, 400, 256, 64, 512), ragged=True, lengths=([400, 317], [256, 130], [64, 9]))
+
+
+def test_hot_region_cfg5_full_size_vs_oracle():
+    """BASELINE.json config 5 at FULL size (B=64, T=400/256/64, H=512, ragged; fp32-accurate arithmetic): every output and gradient
+    against the oracle -- all sample blocks of the persistent recurrence, the general-width attention at D = 1024."""
+    _region_vs_oracle((64, 400, 256, 64, 512), ragged=True)
 
 
 def test_hot_region_cfg5_full_size_properties():
