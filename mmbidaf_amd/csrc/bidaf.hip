@@ -439,6 +439,15 @@ __device__ __forceinline__ bool decode_local(int id, int tiles, int B, int& tile
     return tile < tiles;
 }
 
+// Workgroup barrier behind which every LDS-DMA piece issued so far by ANY wave of the workgroup has landed: each wave drains its
+// own vector-memory counter, then the barrier.  __syncthreads() is NOT that (found in round 4): hipcc lowers its workgroup-scope
+// fence to `s_waitcnt lgkmcnt(0)` alone -- vmcnt is only part of it in threadgroup-split mode -- and the panel reads behind it are
+// asm statements its own waitcnt insertion does not see.  Rounds 2-3 relied on __syncthreads() here: a wave that happened to hold
+// no compiler-visible load (no per-row scalar to fetch, no scratch reload) went through the barrier with its pieces still in
+// flight, and the panel was read before it had landed -- rarely enough to pass every test at the cfg2 lengths, about once in
+// seven steps at cfg4's 50 panels per workgroup (2-6e-4 errors in d_mod of a few 64-row tiles, tools/diag_determinism.py).
+__device__ __forceinline__ void dma_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // stage one 32-row panel with all NWV waves of the workgroup (28 LDS-DMA pieces of 1 KiB)
 template <int NWV>
 __device__ __forceinline__ void stage_panel_w(char* panel, const char* planes_b, int p0, int wave_, int lane) {
@@ -710,7 +719,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
             sb = it & 1;
             base = smem + sb * stage_b;
             sc_commit(sb);
-            __syncthreads();        // this iteration's panels have landed, the other stage and scalar buffer are free
+            dma_sync();             // this iteration's panels have landed, the other stage and scalar buffer are free
             if (it + 1 < niter) {
                 stage(smem + (sb ^ 1) * stage_b, it + 1);
                 sc_fetch(it + 1);
@@ -721,7 +730,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
             __syncthreads();
             stage(base, it);
             sc_commit(0);
-            __syncthreads();
+            dma_sync();
             if (it + 1 < niter) sc_fetch(it + 1);
         }
         const int p0 = 64 * it + 32 * grp;
@@ -951,7 +960,7 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
             stage(p0);
         }
         if (sck < NSC) sc[sck * 32 + scr] = sc_next;
-        __syncthreads();
+        dma_sync();               // the panel staged above (or by the prologue) has landed
         if (p0 + PR < row_end && sck < NSC) sc_next = fetch(p0 + PR + scr);
         if (!wave_on) continue;
         const char* pV0 = smem;
@@ -1144,8 +1153,7 @@ __device__ __forceinline__ void xch_get(const char* p, half8& W0, half8& W1) {
 
 constexpr int XCH_PAIR = 4096;     // per pair: [dp1: 2 x 1 KiB][weights: 2 x 1 KiB]
 
-// workgroup barrier that orders LDS traffic only: the LDS-DMA of the next panel stays in flight across it (a __syncthreads
-// would wait for vmcnt(0), i.e. for the prefetch it is meant to overlap)
+// workgroup barrier that orders LDS traffic only: the LDS-DMA of the next panel stays in flight across it
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Panel ring of the gradient sweeps: NS = 5 LDS slots of one 28-KiB panel each for the NT = 3 (eval mode) or 4 (training
@@ -1283,9 +1291,9 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll 1
         for (int pi = 0; pi < np; ++pi) {
             if (sck < NSC) sc[sck * 32 + scr] = sc_next;
-            __syncthreads();          // this panel's DMA has landed (vmcnt(0)), its scalars are visible
+            dma_sync();               // this panel's DMA has landed, its scalars are visible
             issue_top(pi);
-            if (NT == 4 && pi > 0) __syncthreads();
+            if (NT == 4 && pi > 0) dma_sync();
             if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
             const char* pTd = ring_slot(smem, pi * NT + X_TD);
             const char* pT = ring_slot(smem, pi * NT + X_T);
@@ -1347,9 +1355,9 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll 1
         for (int pi = 0; pi < np; ++pi) {
             if (sck < NSC) sc[sck * 32 + scr] = sc_next;
-            __syncthreads();
+            dma_sync();
             issue_top(pi);
-            if (NT == 4 && pi > 0) __syncthreads();
+            if (NT == 4 && pi > 0) dma_sync();
             if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
             const char* pDa = ring_slot(smem, pi * NT + X_DA);
             const char* pDb = ring_slot(smem, pi * NT + X_DB);
@@ -1541,9 +1549,9 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll 1
         for (int pi = 0; pi < np; ++pi) {
             if (sck < NSC) sc[sck * 32 + scr] = sc_next;
-            __syncthreads();          // this panel's DMA has landed (vmcnt(0)), its scalars are visible
+            dma_sync();               // this panel's DMA has landed, its scalars are visible
             issue_top(pi);
-            if (NT == 4 && pi > 0) __syncthreads();
+            if (NT == 4 && pi > 0) dma_sync();
             if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
             const char* pMd = ring_slot(smem, pi * NT + X_MD);
             const char* pDq = ring_slot(smem, pi * NT + X_DQ);
@@ -1606,9 +1614,9 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll 1
         for (int pi = 0; pi < np; ++pi) {
             if (sck < NSC) sc[sck * 32 + scr] = sc_next;
-            __syncthreads();
+            dma_sync();
             issue_top(pi);
-            if (NT == 4 && pi > 0) __syncthreads();
+            if (NT == 4 && pi > 0) dma_sync();
             if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
             const char* pM = ring_slot(smem, pi * NT + X_M);
             const char* pQ = ring_slot(smem, pi * NT + X_Q);
