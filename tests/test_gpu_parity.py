@@ -1889,3 +1889,33 @@ def test_persistent_recurrence_survives_a_concurrent_tenant_and_reports_a_timeou
     if os.environ.get("MMB_TEST_TENANT_TIMEOUT") == "1":
         r = subprocess.run([sys.executable, str(script), root, "4000000"], capture_output=True, text=True, timeout=600)
         assert r.returncode == 3 and "TIMEOUT" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_region_step_repeats_bit_for_bit_at_cfg4_size():
+    """Run-to-run determinism at BASELINE.json config 4's full size: the same fwd+bwd step twelve times; every output and every
+    input gradient must repeat BIT FOR BIT (parameter gradients are sums of float atomics: 1e-5 of scale).  This is the check that
+    exposed the LDS-DMA landing race of rounds 2-3 (a panel read before its DMA had landed, about one cfg4 step in seven:
+    csrc/bidaf.hip, dma_sync) -- a result that is merely close to the oracle can still hide one."""
+    from mmbidaf_amd import synth
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    torch.manual_seed(224)
+    region = HotRegion(100).to(d)
+    batch = synth.make_batch("cfg4", ragged=True, device=d)
+    first = None
+    for it in range(12):
+        for p in region.parameters():
+            p.grad = None
+        xs = [batch[k].detach().clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+        outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+        synth.region_loss(outs, batch).backward()
+        torch.cuda.synchronize()
+        cur = [o.detach().clone() for o in outs] + [x.grad for x in xs]
+        grads = {n: p.grad.clone() for n, p in region.named_parameters()}
+        if first is None:
+            first, first_g = cur, grads
+            continue
+        for k, (a, b) in enumerate(zip(cur, first)):
+            assert torch.equal(a, b), f"run {it}: tensor {k} differs from the first run by {(a - b).abs().max().item():.3e}"
+        for n in grads:
+            close(grads[n], first_g[n].cpu(), f"repeat grad {n}", tol=1e-5)
