@@ -71,8 +71,6 @@ class _Plan:
             scr.add(tag + ".gx", B * Tn * 8 * H * f)
             scr.add(tag + ".cn", 2 * B * H * f)
             scr.add(tag + ".ws", lib.mmb_bilstm_ws_bytes(B, Tn, I, H, 0))
-            if drop:
-                keep.add(tag + ".yd", B * Tn * D * f)       # y after its dropout (output dropout; inter-layer for layer 0 of the modelling encoders)
         self.att = [("aa", Ma), ("ai", Mi)]
         self.att_saved, self.att_ws_b = {}, {}
         for tag, M in self.att:
@@ -86,9 +84,6 @@ class _Plan:
             keep.add(tag + ".saved", self.att_saved[tag])
             scr.add(tag + ".ws", max(int(lib.mmb_bidaf_fwd_workspace_bytes(B, T, M, D)), 256))
             self.att_ws_b[tag] = int(lib.mmb_bidaf_bwd_workspace_bytes(B, T, M, D))
-            if drop:
-                keep.add(tag + ".text_d", B * T * D * f)
-                keep.add(tag + ".mod_d", B * M * D * f)
         keep.add("hid_a", B * 4 * H * f)
         keep.add("hid_i", B * 4 * H * f)
         keep.add("dec", B * H * f)
@@ -110,8 +105,35 @@ class _Plan:
                 bw.add(tag + ".d_text_d", B * T * D * f)
                 bw.add(tag + ".d_mod_d", B * M * D * f)
         self.bw = bw
-        # parameter gradients: one flat fp32 buffer in the order of `param_list`, bias twins in a second one
-        self.ctypes_cache = {}
+        # training mode: the eleven dropout masks of a step are ONE F.dropout draw over a flat vector of ones, cut in this order
+        # (the call order of the modular path: encoders' output dropout, dropped copies of (text, audio) and (text, image),
+        # inter-layer dropout of the two modelling encoders, their output dropout)
+        self.mask_layout = mask_layout(B, T, Ma, Mi, H)
+        self.mask_total = self.mask_layout[-1][2] + (self.mask_layout[-1][3] + 3) // 4 * 4
+
+
+MASK_NAMES = ("out_et", "out_ea", "out_ei", "aa_t", "aa_m", "ai_t", "ai_m", "inter_a", "inter_i", "out_a", "out_i")
+
+
+def mask_layout(B, T, Ma, Mi, H):
+    """[(name, shape, offset, numel)] of the eleven dropout masks inside the flat draw of a training-mode step."""
+    D = 2 * H
+    shapes = [(B, T, D), (B, Ma, D), (B, Mi, D), (B, T, D), (B, Ma, D), (B, T, D), (B, Mi, D), (B, T, D), (B, T, D), (B, T, D), (B, T, D)]
+    out, o = [], 0
+    for name, sh in zip(MASK_NAMES, shapes):
+        n = sh[0] * sh[1] * sh[2]
+        out.append((name, sh, o, n))
+        o += (n + 3) // 4 * 4
+    return out
+
+
+def draw_masks(B, T, Ma, Mi, H, p, dev):
+    """The masks a training-mode step of these sizes draws from torch's generator in its current state: {name: (shape) tensor of
+    0 / 1/(1-p)}.  Tests replay a step's masks with it (same generator state -> same masks) and hand them to the oracle."""
+    lay = mask_layout(B, T, Ma, Mi, H)
+    total = lay[-1][2] + (lay[-1][3] + 3) // 4 * 4
+    flat = F.dropout(_ones_flat(total, dev), p, True)
+    return {name: flat[o:o + n].view(sh) for name, sh, o, n in lay}, flat
 
 
 _plans = {}
@@ -235,7 +257,8 @@ def eligible(R, xs, lens3):
 
 
 def _drop_conf(R):
-    """(training-mode dropout active?, p of the encoders' output dropout, p of the attentions, p of the inter-layer dropout)"""
+    """None: no dropout (eval mode or drop_prob 0); a float: the one dropout probability of a training-mode step; False: per-site
+    probabilities differ (modular path)"""
     tr = R.text_enc.training
     p_enc = [R.text_enc.drop_prob, R.audio_enc.drop_prob, R.image_enc.drop_prob]
     p_att = [R.bidaf_att_audio.drop_prob, R.bidaf_att_image.drop_prob]
@@ -244,23 +267,22 @@ def _drop_conf(R):
     ps = p_enc + p_att + p_mod + p_inter
     if not tr or all(p == 0.0 for p in ps):
         return None
-    if any(p <= 0.0 or p >= 1.0 for p in ps):
-        return False            # mixed zero / non-zero probabilities: modular path
-    return dict(enc=p_enc, att=p_att, mod=p_mod, inter=p_inter)
+    if any(p != ps[0] for p in ps) or not (0.0 < ps[0] < 1.0):
+        return False            # different probabilities per site (the reference passes ONE drop_prob everywhere): modular path
+    return ps[0]
 
 
 _ones = {}
 
 
-def _mask(shape, p, dev):
-    """The multiplicative mask F.dropout(x, p, True) applies, drawn by the very same call (same generator consumption)."""
-    key = (dev.index, shape)
+def _ones_flat(total, dev):
+    key = (dev.index, total)
     o = _ones.get(key)
     if o is None:
-        if len(_ones) > 64:
+        if len(_ones) > 8:
             _ones.clear()
-        o = _ones[key] = torch.ones(shape, device=dev, dtype=torch.float32)
-    return F.dropout(o, p, True)
+        o = _ones[key] = torch.ones(total, device=dev, dtype=torch.float32)
+    return o
 
 
 class _Ctx:
@@ -311,30 +333,29 @@ class _RegionFn(torch.autograd.Function):
                 d.B, d.T, d.I, d.H = B, Tn[tag], In[tag], H
             _lib.check(lib.mmb_bilstm_layer_fwd(descs, n, di, stream), "mmb_bilstm_layer_fwd")
 
-        masks = {}
-
-        def dropped(tag, src_name, dst_name, shape, p):
-            """keep[dst] = keep[src] * mask; returns the pointer of the dropped copy"""
-            m = _mask(shape, p, dev)
-            masks[tag] = m
-            torch.mul(view(ko[src_name], shape), m, out=view(ko[dst_name], shape))
-            return kb + ko[dst_name]
+        masks, held = {}, []
+        if drop:
+            # ONE generator call for the step's eleven masks (a flat vector of ones through F.dropout, cut by plan.mask_layout),
+            # and one multi-tensor launch per stage to apply them -- 5 launches where eleven F.dropout calls and eleven products
+            # took 22 (training mode at the metric configuration: 0.29 ms behind eval mode, most of it these kernels)
+            flat = F.dropout(_ones_flat(plan.mask_total, dev), drop, True)
+            masks = {name: flat[o:o + n].view(sh) for name, sh, o, n in plan.mask_layout}
 
         # ---- input encoders (models.py:97,102,113) + their output dropout (encoding.py:104)
         lstm_fwd(("et", "ea", "ei"), [xs["et"].data_ptr(), xs["ea"].data_ptr(), xs["ei"].data_ptr()])
         enc_out = {t: kb + ko[t + ".y"] for t in ("et", "ea", "ei")}
-        if drop:
-            for t, p in zip(("et", "ea", "ei"), drop["enc"]):
-                enc_out[t] = dropped("out_" + t, t + ".y", t + ".yd", (B, Tn[t], D), p)
-        # ---- the two attentions (models.py:131-132), one grouped call, shared text planes
         att_in = {"aa": "ea", "ai": "ei"}
-        if drop:      # dropped copies seen by the similarity only (attention.py:66-67), drawn in forward_group's order
-            for (tag, M), p in zip(plan.att, drop["att"]):
-                e = att_in[tag]
-                src_t = "et.yd"
-                src_m = e + ".yd"
-                dropped(tag + "_t", src_t, tag + ".text_d", (B, T, D), p)
-                dropped(tag + "_m", src_m, tag + ".mod_d", (B, M, D), p)
+        att_d = {}
+        if drop:
+            ys = [view(ko[t + ".y"], (B, Tn[t], D)) for t in ("et", "ea", "ei")]
+            yd = torch._foreach_mul(ys, [masks["out_et"], masks["out_ea"], masks["out_ei"]])
+            held += yd
+            enc_out = {"et": yd[0].data_ptr(), "ea": yd[1].data_ptr(), "ei": yd[2].data_ptr()}
+            # dropped copies seen by the similarity only (attention.py:66-67)
+            dd = torch._foreach_mul([yd[0], yd[1], yd[0], yd[2]], [masks["aa_t"], masks["aa_m"], masks["ai_t"], masks["ai_m"]])
+            held += dd
+            att_d = {"aa": (dd[0].data_ptr(), dd[1].data_ptr()), "ai": (dd[2].data_ptr(), dd[3].data_ptr())}
+        # ---- the two attentions (models.py:131-132), one grouped call, shared text planes
         descs = (_lib.BidafDesc * 2)()
         for d, (tag, M) in zip(descs, plan.att):
             q = _P_ATT[tag]
@@ -343,7 +364,7 @@ class _RegionFn(torch.autograd.Function):
             d.text_mask = d.mod_mask = None
             d.text_len, d.mod_len = len_ptr["et"], len_ptr[e]
             if drop:
-                d.text_d, d.mod_d = kb + ko[tag + ".text_d"], kb + ko[tag + ".mod_d"]
+                d.text_d, d.mod_d = att_d[tag]
             else:
                 d.text_d = d.mod_d = None
             d.w_t, d.w_m, d.w_tm, d.bias = pp[q], pp[q + 1], pp[q + 2], pp[q + 3]
@@ -357,14 +378,13 @@ class _RegionFn(torch.autograd.Function):
         lstm_fwd(("a0", "i0"), [kb + ko["aa.out"], kb + ko["ai.out"]])
         l1_in = {"a1": kb + ko["a0.y"], "i1": kb + ko["i0.y"]}
         if drop:
-            l1_in["a1"] = dropped("inter_a", "a0.y", "a0.yd", (B, T, D), drop["inter"][0])
-            l1_in["i1"] = dropped("inter_i", "i0.y", "i0.yd", (B, T, D), drop["inter"][1])
+            y0d = torch._foreach_mul([view(ko["a0.y"], (B, T, D)), view(ko["i0.y"], (B, T, D))], [masks["inter_a"], masks["inter_i"]])
+            held += y0d
+            l1_in = {"a1": y0d[0].data_ptr(), "i1": y0d[1].data_ptr()}
         lstm_fwd(("a1", "i1"), [l1_in["a1"], l1_in["i1"]])
-        out_name = {"a1": "a1.y", "i1": "i1.y"}
+        mod_out = [view(ko["a1.y"], (B, T, D)), view(ko["i1.y"], (B, T, D))]
         if drop:
-            dropped("out_a", "a1.y", "a1.yd", (B, T, D), drop["mod"][0])
-            dropped("out_i", "i1.y", "i1.yd", (B, T, D), drop["mod"][1])
-            out_name = {"a1": "a1.yd", "i1": "i1.yd"}
+            mod_out = torch._foreach_mul(mod_out, [masks["out_a"], masks["out_i"]])
         # ---- final hidden states (encoding.py:101-103) and the decoder's initial hidden state (models.py:143)
         hp = (ctypes.c_void_p * 4)(kb + ko["a0.hn"], kb + ko["a1.hn"], kb + ko["i0.hn"], kb + ko["i1.hn"])
         op = (ctypes.c_void_p * 2)(kb + ko["hid_a"], kb + ko["hid_i"])
@@ -372,12 +392,12 @@ class _RegionFn(torch.autograd.Function):
 
         c = _Ctx()
         c.plan, c.meta, c.drop, c.masks, c.keep, c.xs, c.enc_out, c.l1_in = plan, meta, drop, masks, keep, xs, enc_out, l1_in
+        c.att_d, c.held = att_d, held
         c.need_dx = [bool(ctx.needs_input_grad[1 + i]) for i in range(3)]
         ctx.c = c
         ctx.save_for_backward(*params)
         ctx.set_materialize_grads(False)
-        return (view(ko[out_name["a1"]], (B, T, D)), view(ko["hid_a"], (B, 4, H)), view(ko[out_name["i1"]], (B, T, D)),
-                view(ko["hid_i"], (B, 4, H)), view(ko["dec"], (B, H)))
+        return (mod_out[0], view(ko["hid_a"], (B, 4, H)), mod_out[1], view(ko["hid_i"], (B, 4, H)), view(ko["dec"], (B, H)))
 
     @staticmethod
     def backward(ctx, g_mod_a, g_hid_a, g_mod_i, g_hid_i, g_dec):
@@ -469,8 +489,12 @@ class _RegionFn(torch.autograd.Function):
             _lib.check(lib.mmb_hidden_states_bwd(gp, None if gd is None else gd.data_ptr(), dp, 2, 2, B, H, di, ms), "mmb_hidden_states_bwd")
 
         # ---- modelling encoders, layer 1 (first recurrence of the pass: every layer's operand planes are prepared beside it)
-        pa, ta = cot("a1", g_mod_a, (B, T, D), "out_a")
-        pi, ti = cot("i1", g_mod_i, (B, T, D), "out_i")
+        if drop and g_mod_a is not None and g_mod_i is not None:
+            gy = torch._foreach_mul([g_mod_a.contiguous(), g_mod_i.contiguous()], [masks["out_a"], masks["out_i"]])
+            pa, pi, ta, ti = gy[0].data_ptr(), gy[1].data_ptr(), gy[0], gy[1]
+        else:
+            pa, ta = cot("a1", g_mod_a, (B, T, D), "out_a")
+            pi, ti = cot("i1", g_mod_i, (B, T, D), "out_i")
         hold += [ta, ti]
         L1 = lstm_descs(("a1", "i1"), (pa, pi), (dh["a1"], dh["i1"]), (True, True))
         L0 = lstm_descs(("a0", "i0"), (bb + bo["a1.d_x"], bb + bo["i1.d_x"]), (dh["a0"], dh["i0"]), (True, True))
@@ -498,9 +522,7 @@ class _RegionFn(torch.autograd.Function):
             f0 = 0
         # inter-layer dropout backward, then layer 0
         if drop:
-            for t1, mk in (("a1", "inter_a"), ("i1", "inter_i")):
-                dx = bview(bo[t1 + ".d_x"], (B, T, D))
-                dx.mul_(masks[mk])
+            torch._foreach_mul_([bview(bo["a1.d_x"], (B, T, D)), bview(bo["i1.d_x"], (B, T, D))], [masks["inter_a"], masks["inter_i"]])
         if two:
             main.wait_event(prepared)
             before = torch.cuda.Event()
@@ -522,7 +544,7 @@ class _RegionFn(torch.autograd.Function):
             d.text_mask = d.mod_mask = None
             d.text_len, d.mod_len = len_ptr["et"], len_ptr[e]
             if drop:
-                d.text_d, d.mod_d = kb + ko[tag + ".text_d"], kb + ko[tag + ".mod_d"]
+                d.text_d, d.mod_d = c.att_d[tag]
                 d.d_text_d, d.d_mod_d = bb + bo[tag + ".d_text_d"], bb + bo[tag + ".d_mod_d"]
             else:
                 d.text_d = d.mod_d = d.d_text_d = d.d_mod_d = None
@@ -542,12 +564,11 @@ class _RegionFn(torch.autograd.Function):
         d_text.add_(bview(bo["ai.d_text"], (B, T, D)))
         d_aud, d_img = bview(bo["aa.d_mod"], (B, Ma, D)), bview(bo["ai.d_mod"], (B, Mi, D))
         if drop:
+            # (d_text takes a term from each attention: two launches, a tensor must not appear twice in one multi-tensor update)
             for tag, M, dm in (("aa", Ma, d_aud), ("ai", Mi, d_img)):
-                d_text.addcmul_(bview(bo[tag + ".d_text_d"], (B, T, D)), masks[tag + "_t"])
-                dm.addcmul_(bview(bo[tag + ".d_mod_d"], (B, M, D)), masks[tag + "_m"])
-            d_text.mul_(masks["out_et"])
-            d_aud.mul_(masks["out_ea"])
-            d_img.mul_(masks["out_ei"])
+                torch._foreach_addcmul_([d_text, dm], [bview(bo[tag + ".d_text_d"], (B, T, D)), bview(bo[tag + ".d_mod_d"], (B, M, D))],
+                                        [masks[tag + "_t"], masks[tag + "_m"]])
+            torch._foreach_mul_([d_text, d_aud, d_img], [masks["out_et"], masks["out_ea"], masks["out_ei"]])
         EN = lstm_descs(enc_tags, (d_text.data_ptr(), d_aud.data_ptr(), d_img.data_ptr()), (None, None, None), c.need_dx)
         if two:
             before = torch.cuda.Event()

@@ -1628,6 +1628,18 @@ def _region_mask_shapes(B, T, Ma, Mi, H):
     return [(B, T, D), (B, Ma, D), (B, Mi, D), (B, T, D), (B, Ma, D), (B, T, D), (B, Mi, D), (B, T, D), (B, T, D), (B, T, D), (B, T, D)]
 
 
+def _replay_region_masks(shape, p, d, single_node=True):
+    """The eleven masks a training-mode region step draws from torch's device generator in its CURRENT state, keyed as the oracle
+    wants them.  The single-node path (mmbidaf_amd/region_fn.py, what HotRegion / MMBiDAF run) makes ONE F.dropout draw over a flat
+    vector of ones and cuts it (region_fn.draw_masks); the modular path calls F.dropout eleven times in the reference's order."""
+    import torch.nn.functional as F
+    from mmbidaf_amd import region_fn
+    if single_node:
+        named, _ = region_fn.draw_masks(*shape, p, d)
+        return {k: named[n].cpu() for k, n in zip(_MASK_ORDER, region_fn.MASK_NAMES)}
+    return {k: F.dropout(torch.ones(*sh, device=d), p, True).cpu() for k, sh in zip(_MASK_ORDER, _region_mask_shapes(*shape))}
+
+
 def _check_region_against_masked_oracle(region, batch, outs, xs, masks, tag, tol=TOL):
     P = _region_P(region)
     xr = [batch[k].clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
@@ -1664,8 +1676,8 @@ def test_hot_region_training_mode_cfg2_lengths_vs_oracle_with_replayed_masks():
     torch.manual_seed(4242)
     outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
     synth.region_loss(outs, gpu).backward()
-    torch.manual_seed(4242)      # same generator state -> the same eleven masks, in call order
-    masks = {k: F.dropout(torch.ones(*sh, device=d), 0.2, True).cpu() for k, sh in zip(_MASK_ORDER, _region_mask_shapes(*shape))}
+    torch.manual_seed(4242)      # same generator state -> the same eleven masks
+    masks = _replay_region_masks(shape, 0.2, d)
     assert 0.1 < (masks["att_a_text"] == 0).float().mean() < 0.3 and not torch.equal(masks["att_a_text"], masks["att_i_text"])
     _check_region_against_masked_oracle(region, batch, outs, xs, masks, "training mode, cfg2 lengths")
 
@@ -1674,7 +1686,7 @@ def test_region_graph_replay_with_dropout_draws_fresh_masks_every_replay(monkeyp
     """hipGraph replay in training mode: torch's graph-safe generator advances its offset per replay, so two replays of ONE
     captured step must use DIFFERENT dropout masks, and each replay must match the oracle under the masks it used.  The masks
     are made observable by routing F.dropout through `x * F.dropout(ones)` (the same generator calls, the same values): the
-    mask tensors live in the graph's pool and hold the masks of the latest replay."""
+    (flat) mask tensor lives in the graph's pool and holds the masks of the latest replay."""
     import torch.nn.functional as F
     from mmbidaf_amd import synth
     from mmbidaf_amd.hot_region import HotRegion
@@ -1716,12 +1728,15 @@ def test_region_graph_replay_with_dropout_draws_fresh_masks_every_replay(monkeyp
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         outs = step()
-    assert len(seen) == 11, f"{len(seen)} dropout draws in one training-mode step, expected 11"
+    from mmbidaf_amd import region_fn
+    assert len(seen) == 1, f"{len(seen)} dropout draws in one training-mode step of the single-node path, expected ONE flat draw"
+    lay = region_fn.mask_layout(*shape)
     kept = []
     for rep in range(2):
         g.replay()
         torch.cuda.synchronize()
-        masks = {k: m.detach().cpu().clone() for k, m in zip(_MASK_ORDER, seen)}
+        flat = seen[0].detach()
+        masks = {k: flat[o:o + n].view(sh).cpu().clone() for k, (_, sh, o, n) in zip(_MASK_ORDER, lay)}
         kept.append(masks)
         _check_region_against_masked_oracle(region, batch, [o.detach().clone() for o in outs], xs, masks, f"graph replay {rep} with dropout")
     assert not torch.equal(kept[0]["att_a_text"], kept[1]["att_a_text"]), "two replays of the captured step used the same dropout masks"
@@ -1787,8 +1802,8 @@ def test_persist_timeout_status_word_is_checked_and_can_be_cleared():
 def test_single_node_region_equals_the_modular_path_bit_for_bit(monkeypatch, drop_prob):
     """mmbidaf_amd/region_fn.py issues the same library calls as the module-by-module path from ONE autograd node with a lean
     host side.  Same inputs, same generator state: every output, input gradient and parameter gradient
-    must be IDENTICAL in eval mode (attention parameter gradients are sums of atomics: 1e-6) and equal to rounding in training
-    mode with dropout (identical outputs: the same masks) -- and the node must actually be what ran."""
+    must be IDENTICAL in eval mode (attention parameter gradients are sums of atomics: 1e-6); in training mode with dropout both
+    paths are checked against the oracle under the masks each drew -- and the node must actually be what ran."""
     from mmbidaf_amd import synth, region_fn
     from mmbidaf_amd.hot_region import HotRegion
     d = dev()
@@ -1812,22 +1827,32 @@ def test_single_node_region_equals_the_modular_path_bit_for_bit(monkeypatch, dro
         synth.region_loss(outs, gpu).backward()
         torch.cuda.synchronize()
         return [o.detach().clone() for o in outs], [x.grad.clone() for x in xs], {n: p.grad.clone() for n, p in region.named_parameters()}
+    if drop_prob > 0.0:
+        # training mode: the two paths draw their masks differently (one flat draw / eleven calls), so each is checked against the
+        # oracle under the masks IT drew from the same generator state
+        for enabled in (True, False):
+            monkeypatch.setattr(region_fn, "_ENABLED", enabled)
+            for p in region.parameters():
+                p.grad = None
+            xs = [gpu[k].detach().clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+            torch.manual_seed(777)
+            outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+            synth.region_loss(outs, gpu).backward()
+            torch.manual_seed(777)
+            masks = _replay_region_masks(shape, drop_prob, d, single_node=enabled)
+            _check_region_against_masked_oracle(region, batch, outs, xs, masks, "single node" if enabled else "modular")
+        assert len(calls) == 1, "the single-node path was not taken exactly once"
+        return
     o1, g1, p1 = run(True)
     assert len(calls) == 1, "the single-node path was not taken"
     o0, g0, p0 = run(False)
     assert len(calls) == 1
     for a, b in zip(o1, o0):
         assert torch.equal(a, b)
-    # eval mode: identical.  Training mode: the cotangent of an encoder output is the sum of up to four terms (two attentions,
-    # their dropped copies) which autograd and the node add in different orders -- last-bit differences, 1e-6 of the scale
-    exact = drop_prob == 0.0
-    for k, (a, b) in enumerate(zip(g1, g0)):
-        if exact:
-            assert torch.equal(a, b)
-        else:
-            close(a, b.cpu(), f"single-node d_x {k}", tol=2e-6)
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)
     for n in p1:
-        if "bidaf_att" in n or not exact:
+        if "bidaf_att" in n:
             close(p1[n], p0[n].cpu(), "single-node grad " + n, tol=2e-6)
         else:
             assert torch.equal(p1[n], p0[n]), n
