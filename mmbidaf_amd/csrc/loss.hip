@@ -104,9 +104,8 @@ static int fill_args(WSumArgs& a, const float* const* x, const float* const* w, 
     a.k = k;
     long chunks = 0;
     for (int i = 0; i < k; ++i) chunks += (n[i] + WS_PER_BLOCK - 1) / WS_PER_BLOCK;
-    // (round 4: 2048 instead of 512 workgroups at most -- the forward read its 41 MB at 1.7 TB/s with ~1.6 workgroups per CU;
-    //  a ticket atomic per workgroup is ~10 ns and they do not arrive together)
-    static const int max_wg = [] { const char* e = getenv("MMB_WSUM_MAX_WG"); return e ? atoi(e) : 2048; }();
+    // (MMB_WSUM_MAX_WG: 2048 workgroups measured no different from 512 at the cfg2 objective, round 4)
+    static const int max_wg = [] { const char* e = getenv("MMB_WSUM_MAX_WG"); return e ? atoi(e) : 512; }();
     a.reps = (int)((chunks + max_wg - 1) / max_wg);
     if (a.reps < 1) a.reps = 1;
     const long per_block = (long)WS_PER_BLOCK * a.reps;
