@@ -22,6 +22,7 @@ this node is taken only for the exact module structure of the reference's region
 import ctypes
 import os
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -51,7 +52,15 @@ class _Layout:
 
 
 class _Plan:
-    """Everything about a step that depends on the sizes only: arena layouts and workspace sizes (library queries made once)."""
+    """Everything about a step that depends on the sizes only: arena layouts, workspace sizes (library queries made once), the
+    descriptor recipes and the layout of the flat parameter-gradient buffer."""
+
+    def grad_templates(self, dev):
+        """tensors with the shapes of the gradient views, in flat-buffer order (only their shapes are read)"""
+        t = self._gt.get(dev.index)
+        if t is None:
+            t = self._gt[dev.index] = [torch.empty(sh, device="meta", dtype=torch.float32) for sh in self.grad_layout[2]]
+        return t
 
     def __init__(self, B, T, Ma, Mi, H, drop):
         lib = _lib.load()
@@ -108,6 +117,9 @@ class _Plan:
         # training mode: the eleven dropout masks of a step are ONE F.dropout draw over a flat vector of ones, cut in this order
         # (the call order of the modular path: encoders' output dropout, dropped copies of (text, audio) and (text, image),
         # inter-layer dropout of the two modelling encoders, their output dropout)
+        self.tm = _build_templates(self)
+        self.grad_layout = _grad_layout(self)
+        self._gt = {}
         self.mask_layout = mask_layout(B, T, Ma, Mi, H)
         self.mask_total = self.mask_layout[-1][2] + (self.mask_layout[-1][3] + 3) // 4 * 4
 
@@ -285,6 +297,231 @@ def _ones_flat(total, dev):
     return o
 
 
+class _Tmpl:
+    """A ctypes descriptor array filled by ONE vectorised assignment per call.  Every 8-byte word of the array is either a
+    constant (sizes), `base[sel] + offset` (an address inside one of the step's arenas / the metadata vector), a parameter's
+    address, or a per-call value; the plan builds the recipe once, a step evaluates it with three numpy operations instead of
+    ~25 Python attribute assignments per descriptor (the module-by-module path's descriptor fills were 0.3 ms of a step)."""
+    BASES = {"const": 0, "keep": 1, "scr": 2, "meta": 3, "bw": 4}
+
+    def __init__(self, struct, n):
+        self.struct, self.n = struct, n
+        self.nbytes = ctypes.sizeof(struct) * n
+        self.words_per = ctypes.sizeof(struct) // 8
+        self.raw = np.zeros(self.nbytes, dtype=np.uint8)
+        self.sel = np.zeros(self.nbytes // 8, dtype=np.int64)
+        self.off = np.zeros(self.nbytes // 8, dtype=np.uint64)
+        self.pw, self.pq = [], []            # word index <- parameter index
+        self.dyn = {}                        # name -> word index
+        self._frozen = False
+
+    def _word(self, i, field, k=0):
+        f = getattr(self.struct, field)
+        return (i * ctypes.sizeof(self.struct) + f.offset) // 8 + k
+
+    def ptr(self, i, field, base, offset, k=0):
+        w = self._word(i, field, k)
+        self.sel[w], self.off[w] = self.BASES[base], offset
+
+    def param(self, i, field, q, k=0):
+        self.pw.append(self._word(i, field, k))
+        self.pq.append(q)
+
+    def dynamic(self, i, field, name, k=0):
+        self.dyn[name] = self._word(i, field, k)
+
+    def ints(self, i, **kw):
+        view = self.raw.view(np.int32)
+        for field, v in kw.items():
+            f = getattr(self.struct, field)
+            view[(i * ctypes.sizeof(self.struct) + f.offset) // 4] = v
+
+    def sizes(self, i, **kw):               # size_t fields
+        view = self.raw.view(np.uint64)
+        for field, v in kw.items():
+            view[self._word(i, field)] = v
+
+    def freeze(self):
+        self.pw = np.asarray(self.pw, dtype=np.int64)
+        self.pq = np.asarray(self.pq, dtype=np.int64)
+        self.addr = np.nonzero(self.sel)[0]
+        self.addr_sel = self.sel[self.addr]
+        self.addr_off = self.off[self.addr]
+        self.words = self.raw.view(np.uint64)
+        self._frozen = True
+        return self
+
+    def build(self, bases, pp, **dyn):
+        """-> (ctypes array, the numpy buffer it lives in: keep it referenced for the duration of the call)"""
+        w = self.words.copy()
+        w[self.addr] = bases[self.addr_sel] + self.addr_off
+        if self.pw.size:
+            w[self.pw] = pp[self.pq]
+        for name, v in dyn.items():
+            w[self.dyn[name]] = v or 0
+        return (self.struct * self.n).from_buffer(w), w
+
+    def rows(self, built_words, idx):
+        """a descriptor array of the rows `idx` of an already built one"""
+        wp = self.words_per
+        w = np.concatenate([built_words[i * wp:(i + 1) * wp] for i in idx])
+        return (self.struct * len(idx)).from_buffer(w), w
+
+
+def _build_templates(plan):
+    """The descriptor recipes of one step (see _Tmpl): three forward LSTM calls, the attention group forward / backward, the backward
+    LSTM groups."""
+    B, T, Ma, Mi, H = plan.dims
+    D = 2 * H
+    ko, so, bo = plan.keep.off, plan.scr.off, plan.bw.off
+    Tn = {"et": T, "ea": Ma, "ei": Mi, "a0": T, "a1": T, "i0": T, "i1": T}
+    In = {"et": H, "ea": H, "ei": H, "a0": 8 * H, "a1": 2 * H, "i0": 8 * H, "i1": 2 * H}
+    len_off = {"et": 0, "ea": 4 * B, "ei": 8 * B, "a0": 0, "a1": 0, "i0": 0, "i1": 0}
+    pos_off = {"et": 12 * B, "ea": 16 * B, "ei": 20 * B, "a0": 12 * B, "a1": 12 * B, "i0": 12 * B, "i1": 12 * B}
+    lidx = {t: i for i, t in enumerate(("et", "ea", "ei", "a0", "i0", "a1", "i1"))}
+    F_, Bk = _lib.LstmFwdDesc, _lib.LstmBwdDesc
+    tm = {}
+
+    def fwd(tags, x_src):
+        t = _Tmpl(F_, len(tags))
+        for i, tag in enumerate(tags):
+            q = _P_LSTM[tag]
+            src = x_src[i]
+            if src[0] == "dyn":
+                t.dynamic(i, "x", src[1])
+            else:
+                t.ptr(i, "x", src[0], src[1])
+            t.ptr(i, "lengths", "meta", len_off[tag])
+            t.ptr(i, "hn_pos", "meta", pos_off[tag])
+            for dir_ in (0, 1):
+                for j, fld in enumerate(("w_ih", "w_hh", "b_ih", "b_hh")):
+                    t.param(i, fld, q + 4 * dir_ + j, k=dir_)
+            for fld, base, name in (("y", "keep", ".y"), ("h_n", "keep", ".hn"), ("gates", "keep", ".gates"), ("cs", "keep", ".cs"),
+                                    ("x_absmax", "keep", ".absmax"), ("c_n", "scr", ".cn"), ("gx", "scr", ".gx"), ("ws", "scr", ".ws")):
+                t.ptr(i, fld, base, (ko if base == "keep" else so)[tag + name])
+            t.ints(i, B=B, T=Tn[tag], I=In[tag], H=H)
+        return t.freeze()
+
+    tm["f_enc"] = fwd(("et", "ea", "ei"), [("dyn", "x0"), ("dyn", "x1"), ("dyn", "x2")])
+    tm["f_l0"] = fwd(("a0", "i0"), [("keep", ko["aa.out"]), ("keep", ko["ai.out"])])
+    tm["f_l1"] = fwd(("a1", "i1"), [("dyn", "x0"), ("dyn", "x1")])
+
+    def att(backward):
+        t = _Tmpl(_lib.BidafDesc, 2)
+        for i, (tag, M) in enumerate(plan.att):
+            q = _P_ATT[tag]
+            for fld in ("text", "mod", "text_d", "mod_d"):
+                t.dynamic(i, fld, f"{fld}{i}")
+            t.ptr(i, "text_len", "meta", 0)
+            t.ptr(i, "mod_len", "meta", len_off["ea" if tag == "aa" else "ei"])
+            t.param(i, "w_t", q)
+            t.param(i, "w_m", q + 1)
+            t.param(i, "w_tm", q + 2)
+            if not backward:
+                t.param(i, "bias", q + 3)
+            for fld, name in (("out", ".out"), ("bsave", ".bsave"), ("rterm", ".rterm"), ("cterm", ".cterm"), ("row_stat", ".rstat"),
+                              ("col_stat", ".cstat"), ("saved", ".saved")):
+                t.ptr(i, fld, "keep", ko[tag + name])
+            t.sizes(i, saved_bytes=plan.att_saved[tag])
+            if backward:
+                t.ptr(i, "workspace", "bw", bo[tag + ".ws"])
+                t.sizes(i, workspace_bytes=plan.att_ws_b[tag])
+                t.ptr(i, "d_out", "bw", bo[("a0" if tag == "aa" else "i0") + ".d_x"])
+                t.ptr(i, "d_text", "bw", bo[tag + ".d_text"])
+                t.ptr(i, "d_mod", "bw", bo[tag + ".d_mod"])
+                if plan.drop:
+                    t.ptr(i, "d_text_d", "bw", bo[tag + ".d_text_d"])
+                    t.ptr(i, "d_mod_d", "bw", bo[tag + ".d_mod_d"])
+                for j, fld in enumerate(("d_w_t", "d_w_m", "d_w_tm", "d_bias")):
+                    t.dynamic(i, fld, f"{fld}{i}")
+            else:
+                t.ptr(i, "workspace", "scr", so[tag + ".ws"])
+                t.sizes(i, workspace_bytes=256)
+            t.ints(i, T=T, M=M)
+        return t.freeze()
+
+    tm["f_att"], tm["b_att"] = att(False), att(True)
+
+    def bwd(tags, x_src, dy_src):
+        t = _Tmpl(Bk, len(tags))
+        for i, tag in enumerate(tags):
+            q = _P_LSTM[tag]
+            for fld, src in (("x", x_src[i]), ("d_y", dy_src[i])):
+                if src[0] == "dyn":
+                    t.dynamic(i, fld, src[1])
+                else:
+                    t.ptr(i, fld, src[0], src[1])
+            t.dynamic(i, "d_hn", f"d_hn{i}")
+            t.dynamic(i, "d_x", f"d_x{i}")
+            t.dynamic(i, "d_w_ih", f"d_w_ih{i}")
+            t.dynamic(i, "d_w_hh", f"d_w_hh{i}")
+            t.dynamic(i, "d_b", f"d_b{i}")
+            t.ptr(i, "y", "keep", ko[tag + ".y"])
+            t.ptr(i, "lengths", "meta", len_off[tag])
+            t.ptr(i, "hn_pos", "meta", pos_off[tag])
+            t.param(i, "w_ih", q, k=0)
+            t.param(i, "w_ih", q + 4, k=1)
+            t.param(i, "w_hh", q + 1, k=0)
+            t.param(i, "w_hh", q + 5, k=1)
+            t.ptr(i, "gates", "keep", ko[tag + ".gates"])
+            t.ptr(i, "cs", "keep", ko[tag + ".cs"])
+            t.ptr(i, "x_absmax", "keep", ko[tag + ".absmax"])
+            t.ptr(i, "d_a", "bw", bo[tag + ".d_a"])
+            t.ptr(i, "d_w_cat", "bw", bo[tag + ".d_w_cat"])
+            t.ptr(i, "ws", "bw", bo[tag + ".ws"])
+            t.ints(i, B=B, T=Tn[tag], I=In[tag], H=H)
+        return t.freeze()
+
+    tm["b_l1"] = bwd(("a1", "i1"), [("dyn", "x0"), ("dyn", "x1")], [("dyn", "dy0"), ("dyn", "dy1")])
+    tm["b_l0"] = bwd(("a0", "i0"), [("keep", ko["aa.out"]), ("keep", ko["ai.out"])], [("bw", bo["a1.d_x"]), ("bw", bo["i1.d_x"])])
+    tm["b_en"] = bwd(("et", "ea", "ei"), [("dyn", "x0"), ("dyn", "x1"), ("dyn", "x2")],
+                     [("bw", bo["aa.d_text"]), ("bw", bo["aa.d_mod"]), ("bw", bo["ai.d_mod"])])
+    plan.lidx, plan.Tn, plan.In = lidx, Tn, In
+    return tm
+
+
+# flat layout of the parameter gradients: what the kernels write -- per LSTM problem d_w_ih (2,4H,I) and d_w_hh (2,4H,H), the
+# bias gradients (2 copies: b_ih / b_hh twins) x 7 problems x (2,4H), the two attentions' (3D + 4) -- and the views handed back
+def _grad_layout(plan):
+    B, T, Ma, Mi, H = plan.dims
+    D = 2 * H
+    order = ("et", "ea", "ei", "a0", "i0", "a1", "i1")
+    off, o = {}, 0
+    shapes, slot = [], {}              # views in flat order; slot[param index] = position in that list
+    for t in order:
+        I = plan.In[t]
+        q = _P_LSTM[t]
+        off[t + ".wih"] = o
+        for dir_ in (0, 1):
+            slot[q + 4 * dir_] = len(shapes)
+            shapes.append((4 * H, I))
+        o += 2 * 4 * H * I
+        off[t + ".whh"] = o
+        for dir_ in (0, 1):
+            slot[q + 4 * dir_ + 1] = len(shapes)
+            shapes.append((4 * H, H))
+        o += 2 * 4 * H * H
+    for copy in (0, 1):
+        for t in order:
+            q = _P_LSTM[t]
+            off[f"{t}.b{copy}"] = o
+            for dir_ in (0, 1):
+                slot[q + 4 * dir_ + 2 + copy] = len(shapes)
+                shapes.append((4 * H,))
+            o += 2 * 4 * H
+    for k, (tag, q) in enumerate(_P_ATT.items()):
+        off[tag] = o
+        for j, sh in enumerate(((D, 1), (D, 1), (1, 1, D), (1,))):
+            slot[q + j] = len(shapes)
+            shapes.append(sh)
+        o += 3 * D + 1
+        pad = (-o) % 4
+        if pad:                         # keep every block 16-byte aligned: a dummy view swallows the padding
+            shapes.append((pad,))
+            o += pad
+    return off, o, shapes, [slot[i] for i in range(64)]
+
+
 class _Ctx:
     """What forward hands to backward besides tensors."""
 
@@ -294,22 +531,19 @@ class _RegionFn(torch.autograd.Function):
     def forward(ctx, st, x_text, x_aud, x_img, *params):
         lib = _lib.load()
         plan, meta, drop = st.plan, st.meta, st.drop
+        tm = plan.tm
         B, T, Ma, Mi, H = plan.dims
         D = 2 * H
         dev = x_text.device
         di = dev.index
         stream = torch.cuda.current_stream(dev).cuda_stream
-        xs = {"et": x_text.contiguous(), "ea": x_aud.contiguous(), "ei": x_img.contiguous()}
+        xs = (x_text.contiguous(), x_aud.contiguous(), x_img.contiguous())
         keep = torch.empty(plan.keep.size, device=dev, dtype=torch.uint8)
         scr = torch.empty(plan.scr.size, device=dev, dtype=torch.uint8)
         kb, sb = keep.data_ptr(), scr.data_ptr()
-        ko, so = plan.keep.off, plan.scr.off
-        mp = meta.data_ptr()
-        len_ptr = {"et": mp, "ea": mp + 4 * B, "ei": mp + 8 * B, "a0": mp, "a1": mp, "i0": mp, "i1": mp}
-        pos_ptr = {"et": mp + 12 * B, "ea": mp + 16 * B, "ei": mp + 20 * B, "a0": mp + 12 * B, "a1": mp + 12 * B, "i0": mp + 12 * B, "i1": mp + 12 * B}
-        Tn = {"et": T, "ea": Ma, "ei": Mi, "a0": T, "a1": T, "i0": T, "i1": T}
-        In = {"et": H, "ea": H, "ei": H, "a0": 8 * H, "a1": 2 * H, "i0": 8 * H, "i1": 2 * H}
-        pp = [p.data_ptr() for p in params]
+        ko = plan.keep.off
+        bases = np.array([0, kb, sb, meta.data_ptr(), 0], dtype=np.uint64)
+        pp = np.fromiter((p.data_ptr() for p in params), dtype=np.uint64, count=64)
 
         def view(off, shape):
             n = 1
@@ -317,78 +551,52 @@ class _RegionFn(torch.autograd.Function):
                 n *= s_
             return keep[off:off + 4 * n].view(torch.float32).view(shape)
 
-        def lstm_fwd(tags, x_ptrs):
-            n = len(tags)
-            descs = (_lib.LstmFwdDesc * n)()
-            for d, tag, xp in zip(descs, tags, x_ptrs):
-                q = _P_LSTM[tag]
-                d.x, d.lengths = xp, len_ptr[tag]
-                d.w_ih[0], d.w_hh[0], d.b_ih[0], d.b_hh[0] = pp[q], pp[q + 1], pp[q + 2], pp[q + 3]
-                d.w_ih[1], d.w_hh[1], d.b_ih[1], d.b_hh[1] = pp[q + 4], pp[q + 5], pp[q + 6], pp[q + 7]
-                d.y, d.h_n, d.c_n = kb + ko[tag + ".y"], kb + ko[tag + ".hn"], sb + so[tag + ".cn"]
-                d.gx, d.gates, d.cs = sb + so[tag + ".gx"], kb + ko[tag + ".gates"], kb + ko[tag + ".cs"]
-                d.ws = sb + so[tag + ".ws"]
-                d.hn_pos = pos_ptr[tag]
-                d.x_absmax = kb + ko[tag + ".absmax"]
-                d.B, d.T, d.I, d.H = B, Tn[tag], In[tag], H
-            _lib.check(lib.mmb_bilstm_layer_fwd(descs, n, di, stream), "mmb_bilstm_layer_fwd")
-
         masks, held = {}, []
         if drop:
             # ONE generator call for the step's eleven masks (a flat vector of ones through F.dropout, cut by plan.mask_layout),
             # and one multi-tensor launch per stage to apply them -- 5 launches where eleven F.dropout calls and eleven products
-            # took 22 (training mode at the metric configuration: 0.29 ms behind eval mode, most of it these kernels)
+            # took 22
             flat = F.dropout(_ones_flat(plan.mask_total, dev), drop, True)
             masks = {name: flat[o:o + n].view(sh) for name, sh, o, n in plan.mask_layout}
 
         # ---- input encoders (models.py:97,102,113) + their output dropout (encoding.py:104)
-        lstm_fwd(("et", "ea", "ei"), [xs["et"].data_ptr(), xs["ea"].data_ptr(), xs["ei"].data_ptr()])
-        enc_out = {t: kb + ko[t + ".y"] for t in ("et", "ea", "ei")}
-        att_in = {"aa": "ea", "ai": "ei"}
-        att_d = {}
+        d_, w_ = tm["f_enc"].build(bases, pp, x0=xs[0].data_ptr(), x1=xs[1].data_ptr(), x2=xs[2].data_ptr())
+        _lib.check(lib.mmb_bilstm_layer_fwd(d_, 3, di, stream), "mmb_bilstm_layer_fwd")
+        enc_out = (kb + ko["et.y"], kb + ko["ea.y"], kb + ko["ei.y"])
+        att_d = (None, None, None, None)
         if drop:
-            ys = [view(ko[t + ".y"], (B, Tn[t], D)) for t in ("et", "ea", "ei")]
+            ys = [view(ko["et.y"], (B, T, D)), view(ko["ea.y"], (B, Ma, D)), view(ko["ei.y"], (B, Mi, D))]
             yd = torch._foreach_mul(ys, [masks["out_et"], masks["out_ea"], masks["out_ei"]])
             held += yd
-            enc_out = {"et": yd[0].data_ptr(), "ea": yd[1].data_ptr(), "ei": yd[2].data_ptr()}
+            enc_out = (yd[0].data_ptr(), yd[1].data_ptr(), yd[2].data_ptr())
             # dropped copies seen by the similarity only (attention.py:66-67)
             dd = torch._foreach_mul([yd[0], yd[1], yd[0], yd[2]], [masks["aa_t"], masks["aa_m"], masks["ai_t"], masks["ai_m"]])
             held += dd
-            att_d = {"aa": (dd[0].data_ptr(), dd[1].data_ptr()), "ai": (dd[2].data_ptr(), dd[3].data_ptr())}
+            att_d = (dd[0].data_ptr(), dd[1].data_ptr(), dd[2].data_ptr(), dd[3].data_ptr())
         # ---- the two attentions (models.py:131-132), one grouped call, shared text planes
-        descs = (_lib.BidafDesc * 2)()
-        for d, (tag, M) in zip(descs, plan.att):
-            q = _P_ATT[tag]
-            e = att_in[tag]
-            d.text, d.mod = enc_out["et"], enc_out[e]
-            d.text_mask = d.mod_mask = None
-            d.text_len, d.mod_len = len_ptr["et"], len_ptr[e]
-            if drop:
-                d.text_d, d.mod_d = att_d[tag]
-            else:
-                d.text_d = d.mod_d = None
-            d.w_t, d.w_m, d.w_tm, d.bias = pp[q], pp[q + 1], pp[q + 2], pp[q + 3]
-            d.out, d.bsave = kb + ko[tag + ".out"], kb + ko[tag + ".bsave"]
-            d.rterm, d.cterm, d.row_stat, d.col_stat = kb + ko[tag + ".rterm"], kb + ko[tag + ".cterm"], kb + ko[tag + ".rstat"], kb + ko[tag + ".cstat"]
-            d.saved, d.saved_bytes = kb + ko[tag + ".saved"], plan.att_saved[tag]
-            d.workspace, d.workspace_bytes = sb + so[tag + ".ws"], 256
-            d.T, d.M = T, M
-        _lib.check(lib.mmb_bidaf_group_fwd(descs, 2, B, D, di, stream), "mmb_bidaf_group_fwd")
+        d_, w_ = tm["f_att"].build(bases, pp, text0=enc_out[0], mod0=enc_out[1], text1=enc_out[0], mod1=enc_out[2],
+                                   text_d0=att_d[0], mod_d0=att_d[1], text_d1=att_d[2], mod_d1=att_d[3])
+        _lib.check(lib.mmb_bidaf_group_fwd(d_, 2, B, D, di, stream), "mmb_bidaf_group_fwd")
         # ---- modelling encoders (models.py:134-135): layer 0, inter-layer dropout (encoding.py:81), layer 1, output dropout
-        lstm_fwd(("a0", "i0"), [kb + ko["aa.out"], kb + ko["ai.out"]])
-        l1_in = {"a1": kb + ko["a0.y"], "i1": kb + ko["i0.y"]}
+        d_, w_ = tm["f_l0"].build(bases, pp)
+        _lib.check(lib.mmb_bilstm_layer_fwd(d_, 2, di, stream), "mmb_bilstm_layer_fwd")
+        l1_in = (kb + ko["a0.y"], kb + ko["i0.y"])
         if drop:
             y0d = torch._foreach_mul([view(ko["a0.y"], (B, T, D)), view(ko["i0.y"], (B, T, D))], [masks["inter_a"], masks["inter_i"]])
             held += y0d
-            l1_in = {"a1": y0d[0].data_ptr(), "i1": y0d[1].data_ptr()}
-        lstm_fwd(("a1", "i1"), [l1_in["a1"], l1_in["i1"]])
+            l1_in = (y0d[0].data_ptr(), y0d[1].data_ptr())
+        d_, w_ = tm["f_l1"].build(bases, pp, x0=l1_in[0], x1=l1_in[1])
+        _lib.check(lib.mmb_bilstm_layer_fwd(d_, 2, di, stream), "mmb_bilstm_layer_fwd")
         mod_out = [view(ko["a1.y"], (B, T, D)), view(ko["i1.y"], (B, T, D))]
         if drop:
             mod_out = torch._foreach_mul(mod_out, [masks["out_a"], masks["out_i"]])
         # ---- final hidden states (encoding.py:101-103) and the decoder's initial hidden state (models.py:143)
+        hid_a = torch.empty(B, 4, H, device=dev, dtype=torch.float32)
+        hid_i = torch.empty(B, 4, H, device=dev, dtype=torch.float32)
+        dec = torch.empty(B, H, device=dev, dtype=torch.float32)
         hp = (ctypes.c_void_p * 4)(kb + ko["a0.hn"], kb + ko["a1.hn"], kb + ko["i0.hn"], kb + ko["i1.hn"])
-        op = (ctypes.c_void_p * 2)(kb + ko["hid_a"], kb + ko["hid_i"])
-        _lib.check(lib.mmb_hidden_states_fwd(hp, 2, 2, op, kb + ko["dec"], B, H, di, stream), "mmb_hidden_states_fwd")
+        op = (ctypes.c_void_p * 2)(hid_a.data_ptr(), hid_i.data_ptr())
+        _lib.check(lib.mmb_hidden_states_fwd(hp, 2, 2, op, dec.data_ptr(), B, H, di, stream), "mmb_hidden_states_fwd")
 
         c = _Ctx()
         c.plan, c.meta, c.drop, c.masks, c.keep, c.xs, c.enc_out, c.l1_in = plan, meta, drop, masks, keep, xs, enc_out, l1_in
@@ -397,7 +605,7 @@ class _RegionFn(torch.autograd.Function):
         ctx.c = c
         ctx.save_for_backward(*params)
         ctx.set_materialize_grads(False)
-        return (mod_out[0], view(ko["hid_a"], (B, 4, H)), mod_out[1], view(ko["hid_i"], (B, 4, H)), view(ko["dec"], (B, H)))
+        return (mod_out[0], hid_a, mod_out[1], hid_i, dec)
 
     @staticmethod
     def backward(ctx, g_mod_a, g_hid_a, g_mod_i, g_hid_i, g_dec):
@@ -405,6 +613,7 @@ class _RegionFn(torch.autograd.Function):
         c = ctx.c
         params = ctx.saved_tensors
         plan, meta, drop, masks, keep = c.plan, c.meta, c.drop, c.masks, c.keep
+        tm = plan.tm
         B, T, Ma, Mi, H = plan.dims
         D = 2 * H
         dev = keep.device
@@ -413,24 +622,19 @@ class _RegionFn(torch.autograd.Function):
         side = MF.side_stream(dev) if MF._USE_SIDE else main
         ms, ss = main.cuda_stream, side.cuda_stream
         kb = keep.data_ptr()
-        ko = plan.keep.off
         bw = torch.empty(plan.bw.size, device=dev, dtype=torch.uint8)
         bb, bo = bw.data_ptr(), plan.bw.off
-        mp = meta.data_ptr()
-        len_ptr = {"et": mp, "ea": mp + 4 * B, "ei": mp + 8 * B, "a0": mp, "a1": mp, "i0": mp, "i1": mp}
-        pos_ptr = {"et": mp + 12 * B, "ea": mp + 16 * B, "ei": mp + 20 * B, "a0": mp + 12 * B, "a1": mp + 12 * B, "i0": mp + 12 * B, "i1": mp + 12 * B}
-        Tn = {"et": T, "ea": Ma, "ei": Mi, "a0": T, "a1": T, "i0": T, "i1": T}
-        In = {"et": H, "ea": H, "ei": H, "a0": 8 * H, "a1": 2 * H, "i0": 8 * H, "i1": 2 * H}
-        pp = [p.data_ptr() for p in params]
-        # parameter gradients: fresh tensors shaped like the parameters (AccumulateGrad keeps what it is handed); the two bias
-        # vectors of a direction have the same gradient but must not share storage: d_b and its twin
-        g_wih = {t: torch.empty(2, 4 * H, In[t], device=dev, dtype=torch.float32) for t in _P_LSTM}
-        g_whh = {t: torch.empty(2, 4 * H, H, device=dev, dtype=torch.float32) for t in _P_LSTM}
-        g_b = torch.empty(2, 7, 2, 4 * H, device=dev, dtype=torch.float32)         # [copy][problem][direction][4H]
-        g_att = torch.empty(2, 3 * D + 4, device=dev, dtype=torch.float32)
-        lidx = {t: i for i, t in enumerate(("et", "ea", "ei", "a0", "i0", "a1", "i1"))}
-        x_ptr = {"et": c.xs["et"].data_ptr(), "ea": c.xs["ea"].data_ptr(), "ei": c.xs["ei"].data_ptr(),
-                 "a0": kb + ko["aa.out"], "i0": kb + ko["ai.out"], "a1": c.l1_in["a1"], "i1": c.l1_in["i1"]}
+        bases = np.array([0, kb, 0, meta.data_ptr(), bb], dtype=np.uint64)
+        pp = np.fromiter((p.data_ptr() for p in params), dtype=np.uint64, count=64)
+        # parameter gradients: one flat buffer laid out as the kernels write it (AccumulateGrad keeps the views it is handed; the two
+        # bias vectors of a direction have the same gradient but must not share storage, ADVICE r01: the second copy is its twin)
+        goff, gtot, gshapes, gslot = plan.grad_layout
+        gflat = torch.empty(gtot, device=dev, dtype=torch.float32)
+        gp = gflat.data_ptr()
+        lidx, order = plan.lidx, ("et", "ea", "ei", "a0", "i0", "a1", "i1")
+
+        def gaddr(name):
+            return gp + 4 * goff[name]
 
         def bview(off, shape):
             n = 1
@@ -451,32 +655,24 @@ class _RegionFn(torch.autograd.Function):
                 return o.data_ptr(), o
             return g.data_ptr(), g
 
-        def lstm_descs(tags, d_y_ptrs, d_hn_ptrs, need_dx):
-            n = len(tags)
-            descs = (_lib.LstmBwdDesc * n)()
-            for d, tag, dy, dhn, ndx in zip(descs, tags, d_y_ptrs, d_hn_ptrs, need_dx):
-                q = _P_LSTM[tag]
-                d.d_y, d.d_hn, d.x, d.y, d.lengths = dy, dhn, x_ptr[tag], kb + ko[tag + ".y"], len_ptr[tag]
-                d.w_ih[0], d.w_ih[1], d.w_hh[0], d.w_hh[1] = pp[q], pp[q + 4], pp[q + 1], pp[q + 5]
-                d.gates, d.cs = kb + ko[tag + ".gates"], kb + ko[tag + ".cs"]
-                d.d_x = bb + bo[tag + ".d_x"] if ndx else None
-                d.d_w_ih, d.d_w_hh = g_wih[tag].data_ptr(), g_whh[tag].data_ptr()
-                d.d_b = g_b.data_ptr() + 4 * (lidx[tag] * 8 * H)
-                d.d_a, d.d_w_cat, d.ws = bb + bo[tag + ".d_a"], bb + bo[tag + ".d_w_cat"], bb + bo[tag + ".ws"]
-                d.hn_pos = pos_ptr[tag]
-                d.x_absmax = kb + ko[tag + ".absmax"]
-                d.B, d.T, d.I, d.H = B, Tn[tag], In[tag], H
-            return descs, n
+        def phase(dn, n, bits, stream_ptr, what):
+            _lib.check(lib.mmb_bilstm_layer_bwd_phase(dn, n, bits, di, stream_ptr), what)
 
-        def phase(dn, bits, stream_ptr, what):
-            _lib.check(lib.mmb_bilstm_layer_bwd_phase(dn[0], dn[1], bits, di, stream_ptr), what)
+        def lstm_dyn(tags, need_dx):
+            kw = {}
+            for i, (t, nd) in enumerate(zip(tags, need_dx)):
+                kw[f"d_x{i}"] = bb + bo[t + ".d_x"] if nd else 0
+                kw[f"d_w_ih{i}"] = gaddr(t + ".wih")
+                kw[f"d_w_hh{i}"] = gaddr(t + ".whh")
+                kw[f"d_b{i}"] = gaddr(t + ".b0")
+            return kw
 
         two = side is not main
-        hold = []       # cotangent tensors that must outlive the enqueued kernels' host-side descriptors
+        hold = []       # cotangent tensors / descriptor buffers that must outlive the host-side calls
 
         # ---- hidden states backward: per-layer d_h (B,2,H) in hn_pos order
         if g_hid_a is None and g_hid_i is None and g_dec is None:
-            dh = {t: None for t in ("a0", "a1", "i0", "i1")}
+            dh = {t: 0 for t in ("a0", "a1", "i0", "i1")}
         else:
             gh = [None if g is None else g.contiguous() for g in (g_hid_a, g_hid_i)]
             gd = None if g_dec is None else g_dec.contiguous()
@@ -484,9 +680,9 @@ class _RegionFn(torch.autograd.Function):
             base = bb + bo["d_h"]
             step_b = B * 2 * H * 4
             dh = {"a0": base, "a1": base + step_b, "i0": base + 2 * step_b, "i1": base + 3 * step_b}
-            gp = (ctypes.c_void_p * 2)(*[None if g is None else g.data_ptr() for g in gh])
+            gpp = (ctypes.c_void_p * 2)(*[None if g is None else g.data_ptr() for g in gh])
             dp = (ctypes.c_void_p * 4)(dh["a0"], dh["a1"], dh["i0"], dh["i1"])
-            _lib.check(lib.mmb_hidden_states_bwd(gp, None if gd is None else gd.data_ptr(), dp, 2, 2, B, H, di, ms), "mmb_hidden_states_bwd")
+            _lib.check(lib.mmb_hidden_states_bwd(gpp, None if gd is None else gd.data_ptr(), dp, 2, 2, B, H, di, ms), "mmb_hidden_states_bwd")
 
         # ---- modelling encoders, layer 1 (first recurrence of the pass: every layer's operand planes are prepared beside it)
         if drop and g_mod_a is not None and g_mod_i is not None:
@@ -496,29 +692,34 @@ class _RegionFn(torch.autograd.Function):
             pa, ta = cot("a1", g_mod_a, (B, T, D), "out_a")
             pi, ti = cot("i1", g_mod_i, (B, T, D), "out_i")
         hold += [ta, ti]
-        L1 = lstm_descs(("a1", "i1"), (pa, pi), (dh["a1"], dh["i1"]), (True, True))
-        L0 = lstm_descs(("a0", "i0"), (bb + bo["a1.d_x"], bb + bo["i1.d_x"]), (dh["a0"], dh["i0"]), (True, True))
-        enc_tags = ("et", "ea", "ei")
-        EN_prep = lstm_descs(enc_tags, (None, None, None), (None, None, None), c.need_dx)     # (PREPARE reads x, y, w_ih, x_absmax, ws, d_w_cat only)
+        L1, w1 = tm["b_l1"].build(bases, pp, x0=c.l1_in[0], x1=c.l1_in[1], dy0=pa, dy1=pi, d_hn0=dh["a1"], d_hn1=dh["i1"],
+                                  **lstm_dyn(("a1", "i1"), (True, True)))
+        L0, w0 = tm["b_l0"].build(bases, pp, d_hn0=dh["a0"], d_hn1=dh["i0"], **lstm_dyn(("a0", "i0"), (True, True)))
+        EN, we = tm["b_en"].build(bases, pp, x0=c.xs[0].data_ptr(), x1=c.xs[1].data_ptr(), x2=c.xs[2].data_ptr(),
+                                  d_hn0=0, d_hn1=0, d_hn2=0, **lstm_dyn(("et", "ea", "ei"), c.need_dx))
+        hold += [w1, w0, we]
         if two:
             before = torch.cuda.Event()
             before.record(main)
-            phase(L1, 1 | HAVE_XC, ms, "bwd phase 1 (modelling layer 1)")
+            phase(L1, 2, 1 | HAVE_XC, ms, "bwd phase 1 (modelling layer 1)")
             side.wait_event(before)
             MF._side_head_start(di, side)
-            for dn in (EN_prep, L0, L1):
-                phase(dn, PREPARE | HAVE_WT, ss, "bwd prepare x planes")
-            for dn, ndx in ((L0, (True, True)), (EN_prep, c.need_dx)):
-                idx = [i for i, v in enumerate(ndx) if v]
-                if idx:
-                    sub = (_lib.LstmBwdDesc * len(idx))(*[dn[0][i] for i in idx])
-                    phase((sub, len(idx)), PREPARE | HAVE_XC, ss, "bwd prepare w planes")
+            # (PREPARE reads x, y, w_ih, x_absmax, ws, d_w_cat and the sizes only: the encoders' descriptors serve as they are)
+            phase(EN, 3, PREPARE | HAVE_WT, ss, "bwd prepare x planes")
+            phase(L0, 2, PREPARE | HAVE_WT, ss, "bwd prepare x planes")
+            phase(L1, 2, PREPARE | HAVE_WT, ss, "bwd prepare x planes")
+            phase(L0, 2, PREPARE | HAVE_XC, ss, "bwd prepare w planes")
+            idx = [i for i, v in enumerate(c.need_dx) if v]
+            if idx:
+                sub, wsub = (EN, we) if len(idx) == 3 else tm["b_en"].rows(we, idx)
+                hold.append(wsub)
+                phase(sub, len(idx), PREPARE | HAVE_XC, ss, "bwd prepare w planes")
             prepared = torch.cuda.Event()
             prepared.record(side)
             f0 = HAVE_XC | HAVE_WT
         else:
-            phase(L1, 1, ms, "bwd phase 1 (modelling layer 1)")
-            phase(L1, 2, ms, "bwd phase 2 (modelling layer 1)")
+            phase(L1, 2, 1, ms, "bwd phase 1 (modelling layer 1)")
+            phase(L1, 2, 2, ms, "bwd phase 2 (modelling layer 1)")
             f0 = 0
         # inter-layer dropout backward, then layer 0
         if drop:
@@ -527,78 +728,50 @@ class _RegionFn(torch.autograd.Function):
             main.wait_event(prepared)
             before = torch.cuda.Event()
             before.record(main)
-            phase(L0, 1 | f0, ms, "bwd phase 1 (modelling layer 0)")
+            phase(L0, 2, 1 | f0, ms, "bwd phase 1 (modelling layer 0)")
             side.wait_event(before)
             MF._side_head_start(di, side)
-            phase(L1, 2 | HAVE_XC, ss, "bwd phase 2 (modelling layer 1)")
+            phase(L1, 2, 2 | HAVE_XC, ss, "bwd phase 2 (modelling layer 1)")
         else:
-            phase(L0, 1, ms, "bwd phase 1 (modelling layer 0)")
-            phase(L0, 2, ms, "bwd phase 2 (modelling layer 0)")
+            phase(L0, 2, 1, ms, "bwd phase 1 (modelling layer 0)")
+            phase(L0, 2, 2, ms, "bwd phase 2 (modelling layer 0)")
         # ---- attentions backward (full-chip kernels: nothing beside them)
-        descs = (_lib.BidafDesc * 2)()
-        att_in = {"aa": "ea", "ai": "ei"}
-        for k, (d, (tag, M)) in enumerate(zip(descs, plan.att)):
-            q = _P_ATT[tag]
-            e = att_in[tag]
-            d.text, d.mod = c.enc_out["et"], c.enc_out[e]
-            d.text_mask = d.mod_mask = None
-            d.text_len, d.mod_len = len_ptr["et"], len_ptr[e]
-            if drop:
-                d.text_d, d.mod_d = c.att_d[tag]
-                d.d_text_d, d.d_mod_d = bb + bo[tag + ".d_text_d"], bb + bo[tag + ".d_mod_d"]
-            else:
-                d.text_d = d.mod_d = d.d_text_d = d.d_mod_d = None
-            d.w_t, d.w_m, d.w_tm, d.bias = pp[q], pp[q + 1], pp[q + 2], None
-            d.out, d.bsave = kb + ko[tag + ".out"], kb + ko[tag + ".bsave"]
-            d.rterm, d.cterm, d.row_stat, d.col_stat = kb + ko[tag + ".rterm"], kb + ko[tag + ".cterm"], kb + ko[tag + ".rstat"], kb + ko[tag + ".cstat"]
-            d.saved, d.saved_bytes = kb + ko[tag + ".saved"], plan.att_saved[tag]
-            d.workspace, d.workspace_bytes = bb + bo[tag + ".ws"], plan.att_ws_b[tag]
-            d.d_out = bb + bo[("a0" if tag == "aa" else "i0") + ".d_x"]
-            d.d_text, d.d_mod = bb + bo[tag + ".d_text"], bb + bo[tag + ".d_mod"]
-            gp_ = g_att.data_ptr() + 4 * k * (3 * D + 4)
-            d.d_w_t, d.d_w_m, d.d_w_tm, d.d_bias = gp_, gp_ + 4 * D, gp_ + 8 * D, gp_ + 12 * D
-            d.T, d.M = T, M
-        _lib.check(lib.mmb_bidaf_group_bwd(descs, 2, B, D, di, ms), "mmb_bidaf_group_bwd")
+        adyn = {}
+        for k, tag in enumerate(("aa", "ai")):
+            g0 = gaddr(tag)
+            adyn.update({f"d_w_t{k}": g0, f"d_w_m{k}": g0 + 4 * D, f"d_w_tm{k}": g0 + 8 * D, f"d_bias{k}": g0 + 12 * D})
+        AT, wa = tm["b_att"].build(bases, pp, text0=c.enc_out[0], mod0=c.enc_out[1], text1=c.enc_out[0], mod1=c.enc_out[2],
+                                   text_d0=c.att_d[0], mod_d0=c.att_d[1], text_d1=c.att_d[2], mod_d1=c.att_d[3], **adyn)
+        _lib.check(lib.mmb_bidaf_group_bwd(AT, 2, B, D, di, ms), "mmb_bidaf_group_bwd")
         # cotangents of the input encoders' outputs: text gets both attentions' (+ the dropped copies' through their masks)
         d_text = bview(bo["aa.d_text"], (B, T, D))
         d_text.add_(bview(bo["ai.d_text"], (B, T, D)))
-        d_aud, d_img = bview(bo["aa.d_mod"], (B, Ma, D)), bview(bo["ai.d_mod"], (B, Mi, D))
         if drop:
+            d_aud, d_img = bview(bo["aa.d_mod"], (B, Ma, D)), bview(bo["ai.d_mod"], (B, Mi, D))
             # (d_text takes a term from each attention: two launches, a tensor must not appear twice in one multi-tensor update)
             for tag, M, dm in (("aa", Ma, d_aud), ("ai", Mi, d_img)):
                 torch._foreach_addcmul_([d_text, dm], [bview(bo[tag + ".d_text_d"], (B, T, D)), bview(bo[tag + ".d_mod_d"], (B, M, D))],
                                         [masks[tag + "_t"], masks[tag + "_m"]])
             torch._foreach_mul_([d_text, d_aud, d_img], [masks["out_et"], masks["out_ea"], masks["out_ei"]])
-        EN = lstm_descs(enc_tags, (d_text.data_ptr(), d_aud.data_ptr(), d_img.data_ptr()), (None, None, None), c.need_dx)
         if two:
             before = torch.cuda.Event()
             before.record(main)
-            phase(EN, 1 | f0, ms, "bwd phase 1 (input encoders)")
+            phase(EN, 3, 1 | f0, ms, "bwd phase 1 (input encoders)")
             side.wait_event(before)
             MF._side_head_start(di, side)
-            phase(L0, 2 | f0, ss, "bwd phase 2 (modelling layer 0)")
-            phase(EN, 2 | f0, ms, "bwd phase 2 (input encoders)")
+            phase(L0, 2, 2 | f0, ss, "bwd phase 2 (modelling layer 0)")
+            phase(EN, 3, 2 | f0, ms, "bwd phase 2 (input encoders)")
             main.wait_stream(side)
         else:
-            phase(EN, 1, ms, "bwd phase 1 (input encoders)")
-            phase(EN, 2, ms, "bwd phase 2 (input encoders)")
-        g_b[1].copy_(g_b[0])
-        # ---- hand the gradients back in param_list order
-        grads = [None] * 64
-        brow = g_b.view(28, 4 * H).unbind(0)          # [copy * 14 + problem * 2 + direction]
-        for t, q in _P_LSTM.items():
-            i = lidx[t]
-            grads[q], grads[q + 4] = g_wih[t].unbind(0)
-            grads[q + 1], grads[q + 5] = g_whh[t].unbind(0)
-            grads[q + 2], grads[q + 6] = brow[2 * i], brow[2 * i + 1]
-            grads[q + 3], grads[q + 7] = brow[14 + 2 * i], brow[14 + 2 * i + 1]
-        for k, (tag, q) in enumerate(_P_ATT.items()):
-            row = g_att[k]
-            grads[q] = row[0:D].view(params[q].shape)
-            grads[q + 1] = row[D:2 * D].view(params[q + 1].shape)
-            grads[q + 2] = row[2 * D:3 * D].view(params[q + 2].shape)
-            grads[q + 3] = row[3 * D:3 * D + 1].view(params[q + 3].shape)
-        dxs = [bview(bo[t + ".d_x"], (B, Tn[t], H)) if nd else None for t, nd in zip(enc_tags, c.need_dx)]
+            phase(EN, 3, 1, ms, "bwd phase 1 (input encoders)")
+            phase(EN, 3, 2, ms, "bwd phase 2 (input encoders)")
+        # the b_hh twins of the bias gradients
+        nb = 7 * 2 * 4 * H
+        gflat[goff["et.b1"]:goff["et.b1"] + nb].copy_(gflat[goff["et.b0"]:goff["et.b0"] + nb])
+        # ---- hand the gradients back in param_list order: ONE call cuts the flat buffer into the views
+        views = torch._C._nn.unflatten_dense_tensors(gflat, plan.grad_templates(dev))
+        grads = [views[j] for j in gslot]
+        dxs = [bview(bo[t + ".d_x"], (B, plan.Tn[t], H)) if nd else None for t, nd in zip(("et", "ea", "ei"), c.need_dx)]
         ctx.c = None
         return (None, *dxs, *grads)
 
