@@ -141,7 +141,7 @@ def mask_layout(B, T, Ma, Mi, H):
 
 def draw_masks(B, T, Ma, Mi, H, p, dev):
     """The masks a training-mode step of these sizes draws from torch's generator in its current state: {name: (shape) tensor of
-    0 / 1/(1-p)}.  Tests replay a step's masks with it (same generator state -> same masks) and hand them to the oracle."""
+    0 / 1/(1-p)}.  Tests replay a step's masks with it (same generator state -> same masks) for their CPU comparison."""
     lay = mask_layout(B, T, Ma, Mi, H)
     total = lay[-1][2] + (lay[-1][3] + 3) // 4 * 4
     flat = F.dropout(_ones_flat(total, dev), p, True)
