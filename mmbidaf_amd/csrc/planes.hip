@@ -265,9 +265,10 @@ __global__ __launch_bounds__(256) void split_rows16_reg_kernel(const SplitRowsGr
 
 // Planes of the TRANSPOSE of a virtual (R x sum cols) matrix: plane row = source column (global, over the concatenated
 // segments), K = source row.  A workgroup takes ST_KT consecutive K tiles (32 source rows each) x 64 columns through LDS, every
-// load of all of them requested before the first wait (round 4: one K tile per workgroup -- 8 KB per workgroup behind two
-// barriers -- ran at 0.45 TB/s on the 680-MB pass of the H = 512 configuration); each wave writes whole chunks.
-constexpr int ST_KT = 4;
+// load of all of them requested before the first wait; each wave writes whole chunks.  (Round 4 measured ST_KT = 4: no change at
+// the H = 100 sizes, 20 % SLOWER on the 680-MB pass of the H = 512 configuration -- 33 KB of LDS per workgroup cost more in
+// resident workgroups than the deeper load queue gained -- so one K tile per workgroup stays.)
+constexpr int ST_KT = 1;
 __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTGroup G) {
     __shared__ float tile[ST_KT][32][65];
     __shared__ float segs[3];
