@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMB_VERSION 401            /* round 4 ABI: + persistent-recurrence reset / enable, mmb_stream_occupy */
+#define MMB_VERSION 402            /* round 4 ABI: + persistent-recurrence reset / enable, mmb_stream_occupy, attention phase stamps */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
 #define MMB_ATT_MAX_D 208          /* attention feature width D = 2H of the fused (register-resident) kernels */
 #define MMB_ATT_GENERAL_MAX_D 4096 /* wider D (up to this) runs the general path: similarity matrix in a workspace */
@@ -90,8 +90,13 @@ size_t mmb_bidaf_saved_bytes(int B, int T, int M, int D, int has_drop);
 
 /* Timing-only ablations of the fused attention kernels for tools/att_bench.py (results are then WRONG; 0 = off, the
  * default; also env MMB_ATT_DBG at first use): 1 = stage only the first panel, 2 = no S-type products, 4 = no PV-type
- * products, 8 = no epilogue stores, 16 = no panel loop. */
+ * products, 8 = no epilogue stores, 16 = no panel loop; 4096 = nothing ablated, phase time stamps (below). */
 void mmb_set_att_debug(int mask);
+/* Device buffer for the phase time stamps of the fused attention kernels (debug mask 4096, tools/att_phases.py): u64
+ * [kernel: 0 column, 1 row, 2 dq, 3 gradient sweeps][block < 2048][24]: slots 0-4 100-MHz s_memrealtime ticks written by thread 0 of
+ * each workgroup at entry / loop start / loop end / epilogue start / end, slots 8-15 (wave 0) and 16-23 (wave 4) shader-clock stamps inside one loop
+ * iteration.  Returns the bytes the buffer must hold; NULL = off. */
+size_t mmb_set_att_timestamps(void* device_buf);
 size_t mmb_bidaf_fwd_workspace_bytes(int B, int T, int M, int D);
 
 int mmb_bidaf_fwd(const float* text, const float* mod, const uint8_t* text_mask, const uint8_t* mod_mask,

@@ -16,7 +16,7 @@ ATT_GENERAL_MAX_D = 4096     # general path (similarity matrix in a workspace)
 LSTM_MAX_H = 128            # register-resident recurrence (one launch per layer)
 LSTM_GENERAL_MAX_H = 1024   # general recurrence (one launch per time step)
 
-ABI_VERSION = 401           # MMB_VERSION the signatures below were written for (include/mmbidaf.h)
+ABI_VERSION = 402           # MMB_VERSION the signatures below were written for (include/mmbidaf.h)
 
 c_f = ctypes.c_void_p  # device pointers travel as raw addresses
 c_i = ctypes.c_int
@@ -76,6 +76,7 @@ SIGNATURES = {
     "mmb_kernel_name": (ctypes.c_char_p, [c_i]),
     "mmb_bidaf_saved_bytes": (ctypes.c_size_t, [c_i] * 5),
     "mmb_set_att_debug": (None, [c_i]),
+    "mmb_set_att_timestamps": (ctypes.c_size_t, [c_f]),
     "mmb_bidaf_fwd_workspace_bytes": (ctypes.c_size_t, [c_i] * 4),
     "mmb_bidaf_fwd": (c_i, [c_f] * 19 + [ctypes.c_size_t, c_f, ctypes.c_size_t] + [c_i] * 5 + [c_f]),
     "mmb_bidaf_bwd_workspace_bytes": (ctypes.c_size_t, [c_i] * 4),

@@ -60,7 +60,11 @@ constexpr float WMAX = 16384.0f;   // 2^14: where the largest split operand is m
 // timing-only ablations (mmb_set_att_debug / MMB_ATT_DBG; never set by the product path; results are then WRONG):
 // 1 = stage only the first panel, 2 = no S-type products, 4 = no PV-type products, 8 = no epilogue stores,
 // 16 = no panel loop at all (prologue + epilogue only)
+// 4096 = phase time stamps (DBG kernels, nothing ablated): thread 0 of every workgroup writes s_memrealtime (100 MHz) at
+// its phase boundaries into the buffer given to mmb_set_att_timestamps: [kernel 0..3][block][8] u64 (tools/att_phases.py)
 static int g_att_dbg = -1;
+static unsigned long long* g_att_ts = nullptr;
+constexpr int TS_BLOCKS = 2048, TS_SLOTS = 24;
 static int att_dbg() {
     if (g_att_dbg < 0) {
         const char* e = getenv("MMB_ATT_DBG");
@@ -284,17 +288,24 @@ __device__ __forceinline__ void lgkm_wait4s(v4s& a, v4s& b, v4s& c, v4s& d) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
 
+// no-op hook of the products below
+struct NoHook {
+    __device__ __forceinline__ void operator()(int) const {}
+};
 template <int KT_>
 struct SStep {
-    static __device__ __forceinline__ void run(unsigned a, const side_t& side, f4 (&c)[2], half8 (&cur)[4]) {
+    template <class H>
+    static __device__ __forceinline__ void run(unsigned a, const side_t& side, f4 (&c)[2], half8 (&cur)[4], const H& hook) {
         half8 nxt[4];
         if constexpr (KT_ + 1 < KT) {
             nxt[0] = ds_rd128<(0 * KT + KT_ + 1) * PCH>(a);
             nxt[1] = ds_rd128<(0 * KT + KT_ + 1) * PCH + 1024>(a);
             nxt[2] = ds_rd128<(1 * KT + KT_ + 1) * PCH>(a);
             nxt[3] = ds_rd128<(1 * KT + KT_ + 1) * PCH + 1024>(a);
+            hook(KT_);
             lgkm_wait4<4>(cur[0], cur[1], cur[2], cur[3]);
         } else {
+            hook(KT_);
             lgkm_wait4<0>(cur[0], cur[1], cur[2], cur[3]);
         }
 #pragma unroll
@@ -303,18 +314,21 @@ struct SStep {
         for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(cur[2 * mb + 1], side.h[KT_][0], c[mb]);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) c[mb] = mfma_h(cur[2 * mb], side.h[KT_][0], c[mb]);
-        if constexpr (KT_ + 1 < KT) SStep<KT_ + 1>::run(a, side, c, nxt);
+        if constexpr (KT_ + 1 < KT) SStep<KT_ + 1>::run(a, side, c, nxt, hook);
     }
 };
-// S-type product, reads one k tile ahead
-__device__ __forceinline__ void sprod2p(const char* panel, int r, int g, const side_t& side, f4 (&c)[2]) {
+// S-type product, reads one k tile ahead.  hook(kt), kt = 0..KT-1, runs once per k-tile step between the reads of the next step
+// and this step's wait: the place for ONE LDS-DMA piece per step (a burst of a wave's 7-21 pieces at a barrier costs it 100-185
+// issue cycles per piece with all eight waves queueing at the CU's one address path: spread over the steps they hide under the MFMAs)
+template <class H = NoHook>
+__device__ __forceinline__ void sprod2p(const char* panel, int r, int g, const side_t& side, f4 (&c)[2], const H& hook = H()) {
     const unsigned a = lds_addr32(panel + r * 64 + ((g ^ att_swz(r)) << 4));
     half8 cur[4];
     cur[0] = ds_rd128<0>(a);
     cur[1] = ds_rd128<1024>(a);
     cur[2] = ds_rd128<KT * PCH>(a);
     cur[3] = ds_rd128<KT * PCH + 1024>(a);
-    SStep<0>::run(a, side, c, cur);
+    SStep<0>::run(a, side, c, cur, hook);
 }
 
 template <int DT_>
@@ -327,27 +341,41 @@ struct PStep {
         x[2] = ds_rd_tr64<(DT_ >> 1) * PCH + 1024>(a);
         x[3] = ds_rd_tr64<(DT_ >> 1) * PCH + KT * PCH + 1024>(a);
     }
-    static __device__ __forceinline__ void run(unsigned a0, unsigned a1, const half8 W0, const half8 W1, acc_t& O, v4s (&cur)[4]) {
-        v4s nxt[4];
-        if constexpr (DT_ + 1 < DT) {
-            PStep<DT_ + 1>::load(a0, a1, nxt);
-            lgkm_wait4s<4>(cur[0], cur[1], cur[2], cur[3]);
-        } else {
-            lgkm_wait4s<0>(cur[0], cur[1], cur[2], cur[3]);
-        }
+};
+// step DT_ of the PV product with the transpose reads ND steps ahead: fr is a ring of ND + 1 fragment sets.  One step ahead
+// (rounds 2-3) left 48 cycles of MFMA between a read's issue and its wait, less than the LDS latency beside seven other reading
+// waves: every step stalled (33 cycles per MFMA measured with in-kernel stamps, tools/att_phases.py, against 16).
+template <int DT_, int ND>
+struct PRun {
+    template <class H>
+    static __device__ __forceinline__ void run(unsigned a0, unsigned a1, const half8 W0, const half8 W1, acc_t& O, v4s (&fr)[ND + 1][4],
+                                               const H& hook) {
+        if constexpr (DT_ + ND < DT) PStep<DT_ + ND>::load(a0, a1, fr[(DT_ + ND) % (ND + 1)]);
+        hook(DT_);
+        constexpr int left = (DT - 1 - DT_) < ND ? (DT - 1 - DT_) : ND;      // later steps whose reads are in flight
+        v4s(&cur)[4] = fr[DT_ % (ND + 1)];
+        lgkm_wait4s<4 * left>(cur[0], cur[1], cur[2], cur[3]);
         const half8 A0 = cat44(cur[0], cur[1]), A1 = cat44(cur[2], cur[3]);
         O[DT_] = mfma_h(A0, W1, O[DT_]);
         O[DT_] = mfma_h(A1, W0, O[DT_]);
         O[DT_] = mfma_h(A0, W0, O[DT_]);
-        if constexpr (DT_ + 1 < DT) PStep<DT_ + 1>::run(a0, a1, W0, W1, O, nxt);
+        if constexpr (DT_ + 1 < DT) PRun<DT_ + 1, ND>::run(a0, a1, W0, W1, O, fr, hook);
     }
 };
-// PV-type product, transpose reads one feature tile ahead
-__device__ __forceinline__ void pvprodp(const char* panel, const tr_off& tr, const half8 W0, const half8 W1, acc_t& O) {
+template <int N, int ND>
+struct PPre {
+    static __device__ __forceinline__ void run(unsigned a0, unsigned a1, v4s (&fr)[ND + 1][4]) {
+        PStep<N>::load(a0, a1, fr[N]);
+        if constexpr (N + 1 < ND) PPre<N + 1, ND>::run(a0, a1, fr);
+    }
+};
+// PV-type product, transpose reads ND feature tiles ahead; hook(dt), dt = 0..DT-1, as in sprod2p
+template <int ND = 2, class H = NoHook>
+__device__ __forceinline__ void pvprodp(const char* panel, const tr_off& tr, const half8 W0, const half8 W1, acc_t& O, const H& hook = H()) {
     const unsigned a0 = lds_addr32(panel + tr.o[0]), a1 = lds_addr32(panel + tr.o[1]);
-    v4s cur[4];
-    PStep<0>::load(a0, a1, cur);
-    PStep<0>::run(a0, a1, W0, W1, O, cur);
+    v4s fr[ND + 1][4];
+    PPre<0, ND>::run(a0, a1, fr);
+    PRun<0, ND>::run(a0, a1, W0, W1, O, fr, hook);
 }
 
 // two-term split of the 8 accumulator values a lane holds for the panel (w0: block 0, w1: block 1), truncating
@@ -415,7 +443,40 @@ struct AttG {
 struct GroupArgs {
     AttG g[MAXG];
     int n, B, D, dbg;
+    unsigned long long* ts;
 };
+// DBG template value of the kernels: 0 = product, 1 = timing-only ablations (a.dbg), 2 = time stamps, nothing ablated
+template <int DBG>
+__device__ __forceinline__ void ts_mark(const GroupArgs& a, int kern, int k) {
+    if (DBG == 2 && a.ts && threadIdx.x == 0 && blockIdx.x < TS_BLOCKS)
+        a.ts[((size_t)kern * TS_BLOCKS + blockIdx.x) * TS_SLOTS + k] = __builtin_amdgcn_s_memrealtime();
+}
+// shader-clock stamps (s_memtime) of wave 0 inside ONE iteration of the panel loop (slots 8..15): kept in registers and written
+// at the end of the kernel -- a global store per stamp sat in front of the loop's vmcnt(0) waits and was itself what they timed
+struct TsRec {
+    unsigned long long c[8];
+};
+template <int DBG>
+__device__ __forceinline__ void ts_cyc(TsRec& rec, int k, bool on) {
+    if constexpr (DBG == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t = __builtin_readcyclecounter();
+        if (on) rec.c[k - 8] = t;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int DBG>
+__device__ __forceinline__ void ts_flush(const GroupArgs& a, int kern, const TsRec& rec) {
+    if constexpr (DBG == 2) {
+        // thread 0 (wave 0) -> slots 8..15; thread 256 (wave 4: role 1 of the gradient sweeps, group 1 elsewhere) -> 16..23
+        if (a.ts && (threadIdx.x == 0 || threadIdx.x == 256) && blockIdx.x < TS_BLOCKS) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                a.ts[((size_t)kern * TS_BLOCKS + blockIdx.x) * TS_SLOTS + (threadIdx.x == 0 ? 8 : 16) + k] = rec.c[k];
+        }
+    }
+}
+
 struct BlkMap {
     int begin[MAXG + 1];   // block range of attention k: [begin[k], begin[k+1]), begins are multiples of 8
 };
@@ -437,6 +498,19 @@ __device__ __forceinline__ bool decode_local(int id, int tiles, int B, int& tile
         tile = id / B;
     }
     return tile < tiles;
+}
+
+// The same, sample-major: the `tiles` workgroups of a sample get consecutive turns (ids 8 apart: a chunk of 8 samples, one per XCD,
+// takes 8 * tiles consecutive ids), so that they are dispatched together and stream the sample's panels at the same time -- the
+// first to ask for a panel brings it into the XCD's L2, the others hit.  For launches with more workgroups than the chip holds
+// at once (the i sweep: 448 after the j sweep's 160): tile-major, tiles of one sample started 32 ids = tens of microseconds
+// apart and each re-read its panels from memory (round 4: 276 MB fetched by the gradient sweeps where 90 MB are distinct).
+__device__ __forceinline__ bool decode_local_sm(int id, int tiles, int B, int& tile, int& b) {
+    if (B % 8 != 0) return decode_local(id, tiles, B, tile, b);
+    const int chunk = id / (8 * tiles), rem = id - chunk * 8 * tiles;
+    tile = rem >> 3;
+    b = chunk * 8 + (rem & 7);
+    return chunk < B / 8;
 }
 
 // Workgroup barrier behind which every LDS-DMA piece issued so far by ANY wave of the workgroup has landed: each wave drains its
@@ -620,10 +694,10 @@ __global__ __launch_bounds__(256) void att_rank1_kernel(const float* __restrict_
 constexpr int NT8 = 512;
 
 // KIND 0: column pass.  KIND 1: dq sweep.
-template <int KIND, bool DBG>
+template <int KIND, int DBG>
 __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap& bm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int dbg = DBG ? a.dbg : 0;
+    const int dbg = DBG == 1 ? a.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
     const int r = lane & 15, g = lane >> 4;
@@ -634,6 +708,9 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
     if (!decode_local(local, (N + 63) / 64, a.B, tile, b)) return;
     const int n = (tile * 4 + w4) * 16 + r;
     const bool wave_on = (tile * 4 + w4) * 16 < N;
+    constexpr int TSK = KIND == 0 ? 0 : 2;
+    ts_mark<DBG>(a, TSK, 0);
+    TsRec tsr{};
 
     // streamed tensors: V (value of the PV product) and S (operand of the similarity)
     //   column pass: V = text planes, S = dropped text planes (the same panel without dropout)
@@ -662,9 +739,31 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
             }
         }
     };
+    // two streamed tensors (one stage of 4 panels): the S-only panels and the value panels of an iteration are issued apart
+    auto stage_one = [&](int it, bool s_side) {
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+            const int p0 = 64 * it + 32 * gq;
+            if (p0 < Rp) stage_panel_w<8>(smem + gq * 2 * PANEL_B + (s_side ? PANEL_B : 0), s_side ? pS_b : pV_b, p0, wave, lane);
+        }
+    };
+    // piece k (0..6) of this wave's share of the two panels (one per group, rows 64 it_ + 32 gq) of ONE streamed tensor: the
+    // 56 pieces of the pair are dealt round-robin to the 8 waves; issued one per k-tile / feature-tile step of the products
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    auto piece2 = [&](const char* srcb, char* dst0, int dstride, int it_, int k) {
+        const int idx = wv + 8 * k;
+        const int pn = idx >= 28 ? 1 : 0, pc = idx - 28 * pn;
+        const int p0 = 64 * it_ + 32 * pn;
+        if (p0 < Rp)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcb + (size_t)(p0 >> 4) * PRB + pc * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst0 + pn * dstride + pc * 1024), 16, 0, 0);
+    };
     // prologue: the first panels, the lane-side rows, the maxima pass and the first scalars are all requested before anything
     // waits -- one round trip to memory, not one per stage
-    if (niter > 0 && db) stage(smem, 0);
+    if (niter > 0) {
+        if (db) stage(smem, 0);
+        else stage_one(0, true);
+    }
     float xrow[KT][8];
     load_row_regs(xrow, A.mod_d + (size_t)b * N * D, n, N, D, g, A.w_tm);
     const bool nin = n < N;
@@ -707,6 +806,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
     // c: power of two mapping the largest inverse scale of the value rows to 2^14
     wg_allmax_w<1, 8>(im, red, tid);
     const float cV = cmap(im[0]);
+    ts_mark<DBG>(a, TSK, 1);
 
     acc_t O;
     zero_acc(O);
@@ -715,42 +815,58 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
     for (int it = 0; it < niter; ++it) {
         char* base;
         int sb;
-        if (db) {
-            sb = it & 1;
-            base = smem + sb * stage_b;
-            sc_commit(sb);
-            dma_sync();             // this iteration's panels have landed, the other stage and scalar buffer are free
-            if (it + 1 < niter) {
-                stage(smem + (sb ^ 1) * stage_b, it + 1);
-                sc_fetch(it + 1);
-            }
-        } else {
-            sb = 0;
-            base = smem;
-            __syncthreads();
-            stage(base, it);
-            sc_commit(0);
-            dma_sync();
-            if (it + 1 < niter) sc_fetch(it + 1);
-        }
+        const bool tsi = it == 2;
+        ts_cyc<DBG>(tsr, 8, tsi);
+        // Staging (round 4).  One streamed tensor (db): two stages, the whole next stage is issued during this iteration.  Two
+        // tensors: one stage, two barriers per iteration -- the value panels of iteration it are issued behind its top barrier
+        // (every wave is through the PV product of it - 1) and land under the S-type product and the tile arithmetic; the S-only
+        // panels of it + 1 behind the middle barrier (every wave is through its S-type product) and land under the PV product.
+        // (Rounds 2-3 issued and awaited the one stage at the top: the full LDS-DMA latency every iteration, 5 800 of 8 800
+        // clocks.)  In both forms a wave issues its 7 pieces ONE PER STEP of the product that follows the barrier, not as a burst.
+        const bool more = it + 1 < niter;
+        sb = it & 1;
+        base = db ? smem + sb * stage_b : smem;
+        sc_commit(sb);
+        dma_sync();                 // db: this iteration's stage has landed, the other is free; else: the S-only panels have landed
+        if (more) sc_fetch(it + 1);
+        char* const hs_dst = db ? smem + (sb ^ 1) * stage_b : smem;
+        const int hs_stride = db ? PANEL_B : 2 * PANEL_B, hs_it = db ? it + 1 : it;
+        const bool hs_on = db ? more : true;
+        auto hookS = [&](int k) { if (hs_on) piece2(pV_b, hs_dst, hs_stride, hs_it, k); };
+        auto hookP = [&](int k) { if (!db && more && k < 7) piece2(pS_b, smem + PANEL_B, 2 * PANEL_B, it + 1, k); };
         const int p0 = 64 * it + 32 * grp;
-        if (p0 < R && wave_on) {
-            const char* pV = base + grp * npan * PANEL_B;
-            const char* pS = sep_s ? pV + PANEL_B : pV;
+        ts_cyc<DBG>(tsr, 9, tsi);
+        const bool act = p0 < R && wave_on;
+        const char* pV = base + grp * npan * PANEL_B;
+        const char* pS = sep_s ? pV + PANEL_B : pV;
+        f4 w[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+        if (act) {
             const float* s0 = sc + (sb * NSC) * 64 + 32 * grp;     // scalar k of local row ml: s0[k * 64 + ml]
             f4 v[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-            if (!(dbg & 2)) sprod2p(pS, r, g, side, v);
-            f4 w[2];
+            if (!(dbg & 2)) sprod2p(pS, r, g, side, v, hookS);
+            ts_cyc<DBG>(tsr, 10, tsi);
+            // the per-row scalars of the lane's 2 x 4 rows as whole 16-B reads, all requested before the arithmetic (written with
+            // one scalar read per use, hipcc made each row a branch around its own reads: 16 dependent LDS round trips per panel)
+            const float* sl = s0 + 4 * g;
+            f4 q0[2], q1[2], q2[2], q3[2], q4[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                q0[mb] = *reinterpret_cast<const f4*>(sl + mb * 16);
+                q1[mb] = *reinterpret_cast<const f4*>(sl + 64 + mb * 16);
+                q2[mb] = *reinterpret_cast<const f4*>(sl + 128 + mb * 16);
+                q3[mb] = *reinterpret_cast<const f4*>(sl + 192 + mb * 16);
+                if (KIND == 1) q4[mb] = *reinterpret_cast<const f4*>(sl + 256 + mb * 16);
+            }
             if (KIND == 0) {
                 float bmax = -INFINITY;
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int ml = mb * 16 + 4 * g + e;
-                        const float code = s0[64 + ml];
-                        const float x = v[mb][e] * (s0[128 + ml] * inv_n) + s0[ml] + nterm;
-                        v[mb][e] = code == 2.f ? x : (code == 1.f ? NEG : -INFINITY);
+                        const float code = q1[mb][e];
+                        const float x = v[mb][e] * (q2[mb][e] * inv_n) + q0[mb][e] + nterm;
+                        const float off = code == 1.f ? NEG : -INFINITY;
+                        v[mb][e] = code == 2.f ? x : off;
                         bmax = fmaxf(bmax, v[mb][e]);
                     }
                 bmax = kg_allmax(bmax);
@@ -763,7 +879,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
                     for (int e = 0; e < 4; ++e) {
                         const float pv = __expf(v[mb][e] - m_new);
                         psum += pv;
-                        w[mb][e] = pv * (s0[192 + mb * 16 + 4 * g + e] * cV);
+                        w[mb][e] = pv * (q3[mb][e] * cV);
                     }
                 l_run = l_run * alpha + psum;
                 if (__any(alpha != 1.0f)) {
@@ -776,18 +892,33 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int ml = mb * 16 + 4 * g + e;
-                        const float x = mm ? v[mb][e] * (s0[192 + ml] * inv_n) + s0[ml] + nterm : NEG;
-                        const float p = __expf(x - s0[64 + ml]) * s0[128 + ml];
-                        w[mb][e] = p * (s0[256 + ml] * cV);
+                        const float xs = v[mb][e] * (q3[mb][e] * inv_n) + q0[mb][e] + nterm;
+                        const float x = mm ? xs : NEG;
+                        const float p = __expf(x - q1[mb][e]) * q2[mb][e];
+                        w[mb][e] = p * (q4[mb][e] * cV);
                     }
             }
+        }
+        if (!act || (dbg & 2)) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) hookS(k);
+        }
+        ts_cyc<DBG>(tsr, 11, tsi);
+        if (!db) dma_sync();        // the value panels have landed; the S-only panels are dead
+        if (act) {
             half8 W0, W1;
             split_w(w[0], w[1], W0, W1);
-            if (!(dbg & 4)) pvprodp(pV, tr, W0, W1, O);
+            ts_cyc<DBG>(tsr, 12, tsi);
+            if (!(dbg & 4)) pvprodp<2>(pV, tr, W0, W1, O, hookP);
+            ts_cyc<DBG>(tsr, 13, tsi);
+        }
+        if (!act || (dbg & 4)) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) hookP(k);
         }
     }
     __syncthreads();      // all panels are dead
+    ts_mark<DBG>(a, TSK, 2);
 
     // ---- merge group 1 into group 0 (lane-private exchange: [w4][dt | stats][lane] 16-B slots)
     char* xb = smem + (size_t)w4 * (DT + 1) * 1024 + lane * 16;
@@ -829,6 +960,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
         }
     }
     __syncthreads();
+    ts_mark<DBG>(a, TSK, 3);
     const int row0 = tile * 64;
     char* dst_p = (KIND == 0 ? A.pQ : A.pDq) + (size_t)b * planes_sample_bytes(N);
     float* dst_i = (KIND == 0 ? A.iQ : A.iDq) + (size_t)b * Np;
@@ -862,6 +994,8 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
             }
         }
     }
+    ts_mark<DBG>(a, TSK, 4);
+    ts_flush<DBG>(a, TSK, tsr);
 }
 
 
@@ -869,10 +1003,10 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
 // Lane side = 64 text rows (text_d * w_tm, split in registers from fp32), streams the modality rows with values
 // [mod | q]: a = P1 mod, b = P1 q, out = [text, a, text*a, text*b].  4 waves with one 16-row tile each, at most 256
 // registers and one LDS stage: TWO workgroups share a CU (two waves per SIMD), each hiding the other's staging waits.
-template <bool DBG>
+template <int DBG>
 __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, const BlkMap bm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int dbg = DBG ? a.dbg : 0;
+    const int dbg = DBG == 1 ? a.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     int local;
@@ -882,6 +1016,8 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
     if (!decode_local(local, (N + 63) / 64, a.B, tile, b)) return;
     const int n = (tile * NW + wave) * 16 + r;
     const bool wave_on = (tile * NW + wave) * 16 < N;
+    ts_mark<DBG>(a, 1, 0);
+    TsRec tsr{};
 
     const size_t szR = planes_sample_bytes(R);
     const char* pV0_b = A.pM + (size_t)b * szR;
@@ -949,12 +1085,15 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
     side_from_regs(xrow, side, inv_n);
     wg_allmax_w<2, NW>(im, red, tid);
     const float c0 = cmap(im[0]), c1 = cmap(im[1]);
+    ts_mark<DBG>(a, 1, 1);
 
     acc_t O0, O1;
     zero_acc(O0);
     zero_acc(O1);
     float m_run = -INFINITY, l_run = 0.f;
     for (int p0 = 0; p0 < row_end; p0 += PR) {
+        const bool tsi = p0 == PR;
+        ts_cyc<DBG>(tsr, 8, tsi);
         if (p0 > 0) {
             __syncthreads();
             stage(p0);
@@ -962,6 +1101,7 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
         if (sck < NSC) sc[sck * 32 + scr] = sc_next;
         dma_sync();               // the panel staged above (or by the prologue) has landed
         if (p0 + PR < row_end && sck < NSC) sc_next = fetch(p0 + PR + scr);
+        ts_cyc<DBG>(tsr, 9, tsi);
         if (!wave_on) continue;
         const char* pV0 = smem;
         const char* pV1 = smem + PANEL_B;
@@ -969,15 +1109,27 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
 
         f4 v[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
         if (!(dbg & 2)) sprod2p(pS, r, g, side, v);
+        ts_cyc<DBG>(tsr, 10, tsi);
+        // per-row scalars of the lane's 2 x 4 rows as whole 16-B reads, requested before the arithmetic (see the column pass)
+        const float* sl = sc + 4 * g;
+        f4 q0[2], q1[2], q2[2], q3[2], q4[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            q0[mb] = *reinterpret_cast<const f4*>(sl + mb * 16);
+            q1[mb] = *reinterpret_cast<const f4*>(sl + 32 + mb * 16);
+            q2[mb] = *reinterpret_cast<const f4*>(sl + 64 + mb * 16);
+            q3[mb] = *reinterpret_cast<const f4*>(sl + 96 + mb * 16);
+            q4[mb] = *reinterpret_cast<const f4*>(sl + 128 + mb * 16);
+        }
         float bmax = -INFINITY;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int ml = mb * 16 + 4 * g + e;
-                const float code = sc[32 + ml];
-                const float x = v[mb][e] * (sc[64 + ml] * inv_n) + sc[ml] + nterm;
-                v[mb][e] = code == 2.f ? x : (code == 1.f ? NEG : -INFINITY);
+                const float code = q1[mb][e];
+                const float x = v[mb][e] * (q2[mb][e] * inv_n) + q0[mb][e] + nterm;
+                const float off = code == 1.f ? NEG : -INFINITY;
+                v[mb][e] = code == 2.f ? x : off;
                 bmax = fmaxf(bmax, v[mb][e]);
             }
         bmax = kg_allmax(bmax);
@@ -1000,29 +1152,34 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
             }
         }
         m_run = m_new;
+        ts_cyc<DBG>(tsr, 11, tsi);
         {
             f4 w[2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * (sc[96 + mb * 16 + 4 * g + e] * c0);
+                for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * (q3[mb][e] * c0);
             half8 W0, W1;
             split_w(w[0], w[1], W0, W1);
+            ts_cyc<DBG>(tsr, 12, tsi);
             if (!(dbg & 4)) pvprodp(pV0, tr, W0, W1, O0);
+            ts_cyc<DBG>(tsr, 13, tsi);
         }
         {
             f4 w[2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * (sc[128 + mb * 16 + 4 * g + e] * c1);
+                for (int e = 0; e < 4; ++e) w[mb][e] = v[mb][e] * (q4[mb][e] * c1);
             half8 W0, W1;
             split_w(w[0], w[1], W0, W1);
             if (!(dbg & 4)) pvprodp(pV1, tr, W0, W1, O1);
+            ts_cyc<DBG>(tsr, 14, tsi);
         }
     }
 
     // ---- epilogue: each wave parks its tile in LDS (the panels are dead) and the workgroup writes whole rows
+    ts_mark<DBG>(a, 1, 2);
     const float l = kg_allsum(l_run);
     if (n < N && g == 0) {
         float* st = A.row_stat + ((size_t)b * N + n) * 2;
@@ -1069,6 +1226,8 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
             *reinterpret_cast<f4*>(bo + (size_t)gn * D + 4 * c4) = bv;
         }
     }
+    ts_mark<DBG>(a, 1, 3);
+    ts_flush<DBG>(a, 1, tsr);
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -1175,9 +1334,9 @@ constexpr int SWEEP_XCH_OFF = SWEEP_SC_OFF + 10 * 32 * 4;
 constexpr int SWEEP_RED_OFF = SWEEP_XCH_OFF + 4 * XCH_PAIR;
 constexpr int SWEEP_LOOP_LDS = SWEEP_RED_OFF + 64 * 4;
 
-template <bool DBG, bool SAME>
+template <int DBG, bool SAME>
 __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, int local, char* smem) {
-    const int dbg = DBG ? a.dbg : 0;
+    const int dbg = DBG == 1 ? a.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int role = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
     const int r = lane & 15, g = lane >> 4;
@@ -1187,6 +1346,8 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     const int n = (tile * 4 + w4) * 16 + r;  // modality row j
     const bool wave_on = (tile * 4 + w4) * 16 < M;
     const bool nin = n < M;
+    ts_mark<DBG>(a, 3, 0);
+    TsRec tsr{};
 
     // streamed tensors in ring order: db, [text], text_d, da   (text only with dropped copies)
     constexpr int NT = SAME ? 3 : 4;
@@ -1209,7 +1370,6 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
 
     const int np = (dbg & 16) ? 0 : (T + PR - 1) / PR;       // panels
     auto issue8 = [&](int pi, int x) { stage_panel_w<8>(ring_slot(smem, pi * NT + x), src[x], pi * PR, wave, lane); };
-    auto issue4 = [&](int pi, int x) { stage_panel_w<4>(ring_slot(smem, pi * NT + x), src[x], pi * PR, w4, lane); };
     if (np > 0) {          // first panel in flight under the operand loads below
 #pragma unroll
         for (int x = 0; x < NT; ++x) issue8(0, x);
@@ -1253,16 +1413,21 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     auto issue_top = [&](int pi) {
         if (NT == 4 && pi > 0) issue8(pi, 3);                   // training mode: the 4th tensor of THIS panel, just in time
     };
-    // The whole next panel is issued by the role-1 waves right after the S-type products (they idle while role 0 does the
-    // tile's arithmetic): two pieces into the spare slots, the last into the slot the S-only tensor of this panel has just
-    // vacated.  vmcnt counts in issue order, so a wave with DMA in flight would stall at its next scratch reload: role 0
-    // never issues DMA inside the loop, and role 1 issues it BEHIND the reloads of its S-type products.
-    auto issue_mid = [&](int pi) {
-        if (pi + 1 < np) {
-            issue4(pi + 1, 0);
-            issue4(pi + 1, 1);
-            issue4(pi + 1, 2);
-        }
+    // The next panel is issued by the role-1 waves ONE PIECE PER STEP of their products (round 4; as three bursts of 7 pieces per
+    // wave behind the S-type products, rounds 2-3, the issue alone took the wave 1 300-2 000 clocks at 100-185 per piece, and
+    // the panel landed 2 000+ clocks after the top barrier of the next iteration was reached).  Slots (ring of 5): tensor 0 of
+    // panel p + 1 goes where a value tensor of panel p - 1 was -- free from the top barrier of iteration p on, as is tensor 1's
+    // slot with 3 tensors per panel; the last S-only slot of panel p comes free at the middle barrier.  So: first S-type
+    // product <- tensor 0, second <- tensor 1 (NT = 3), PV product <- the rest.  vmcnt counts in issue order, so a wave with
+    // DMA in flight would stall at its next scratch reload: role 0 never issues DMA inside the loop.
+    const int w4u = __builtin_amdgcn_readfirstlane(w4);
+    const bool nodma = DBG == 2 && (a.dbg & 1);        // timing only (with the time stamps): no LDS-DMA inside the loop
+    auto piece1 = [&](int pn, int x, int k) {          // piece w4 + 4 k (k = 0..6) of tensor x of panel pn
+        if (nodma) return;
+        const int piece = w4u + 4 * k;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src[x] + (size_t)((pn * PR) >> 4) * PRB + lane * 16 + piece * 1024),
+            (__attribute__((address_space(3))) void*)(ring_slot(smem, pn * NT + x) + piece * 1024), 16, 0, 0);
     };
 
     // Each role runs its OWN copy of the panel loop (same barrier sequence): the register allocator then sees role 0's
@@ -1288,13 +1453,17 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         acc_t O;        // dmodd = sum_i dS text_d
         zero_acc(O);
         float dc = 0.f;
+        ts_mark<DBG>(a, 3, 1);
 #pragma unroll 1
         for (int pi = 0; pi < np; ++pi) {
+            const bool tsi = pi == 1;
+            ts_cyc<DBG>(tsr, 8, tsi);
             if (sck < NSC) sc[sck * 32 + scr] = sc_next;
             dma_sync();               // this panel's DMA has landed, its scalars are visible
             issue_top(pi);
             if (NT == 4 && pi > 0) dma_sync();
             if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            ts_cyc<DBG>(tsr, 9, tsi);
             const char* pTd = ring_slot(smem, pi * NT + X_TD);
             const char* pT = ring_slot(smem, pi * NT + X_T);
             f4 c1[2], c2[2];
@@ -1304,7 +1473,9 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
                 sprod2p(pTd, r, g, sS, c1);
                 sprod2p(pT, r, g, sDq, c2);
             }
+            ts_cyc<DBG>(tsr, 10, tsi);
             lds_barrier();            // role 1's dP1 is in LDS
+            ts_cyc<DBG>(tsr, 11, tsi);
             f4 wc[2], wd[2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -1328,14 +1499,18 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
                 __builtin_amdgcn_sched_barrier(0);
             }
             half8 W0, W1;
+            ts_cyc<DBG>(tsr, 12, tsi);
             split_w(wc[0], wc[1], W0, W1);
             xch_put(xch + 2048, W0, W1);
             split_w(wd[0], wd[1], W0, W1);
             lds_barrier();            // role 1 has its weights
+            ts_cyc<DBG>(tsr, 13, tsi);
             if (!(dbg & 4)) pvprodp(pTd, tr, W0, W1, O);
+            ts_cyc<DBG>(tsr, 14, tsi);
         }
         dc = kg_allsum(dc);
         __syncthreads();
+        ts_mark<DBG>(a, 3, 2);
         if (dbg & 8) return;
         const float scale = 1.0f / cS;
 #pragma unroll
@@ -1354,31 +1529,53 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         zero_acc(O);
 #pragma unroll 1
         for (int pi = 0; pi < np; ++pi) {
+            const bool tsi = pi == 1;
+            ts_cyc<DBG>(tsr, 8, tsi);
             if (sck < NSC) sc[sck * 32 + scr] = sc_next;
             dma_sync();
             issue_top(pi);
             if (NT == 4 && pi > 0) dma_sync();
             if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            ts_cyc<DBG>(tsr, 9, tsi);
             const char* pDa = ring_slot(smem, pi * NT + X_DA);
             const char* pDb = ring_slot(smem, pi * NT + X_DB);
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
+            const bool more = pi + 1 < np;
+            auto hookA = [&](int k) { if (more) piece1(pi + 1, 0, k); };
+            auto hookB = [&](int k) { if (more && NT == 3) piece1(pi + 1, 1, k); };
+            auto hookC = [&](int k) {
+                if (more && k < 7) {
+                    if (NT == 4) piece1(pi + 1, 1, k);
+                    piece1(pi + 1, 2, k);
+                }
+            };
             if (!(dbg & 2)) {
-                sprod2p(pDb, r, g, sQ, c2);
-                sprod2p(pDa, r, g, sM, c1);
+                sprod2p(pDb, r, g, sQ, c2, hookA);
+                sprod2p(pDa, r, g, sM, c1, hookB);
+            } else {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) { hookA(k); hookB(k); }
             }
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 const f4 sDa = *reinterpret_cast<const f4*>(sg + 7 * 32 + mb * 16), sDb = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16);
                 *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sDa * inM) + c2[mb] * (sDb * inQ);
             }
+            ts_cyc<DBG>(tsr, 10, tsi);
+            lds_barrier();            // the S-only panels are dead
+            ts_cyc<DBG>(tsr, 11, tsi);
             lds_barrier();
-            issue_mid(pi);            // the S-only panels are dead: re-fill their slots under role 0's arithmetic
-            lds_barrier();
+            ts_cyc<DBG>(tsr, 12, tsi);
             half8 W0, W1;
             xch_get(xch + 2048, W0, W1);
-            if (!(dbg & 4)) pvprodp(pDa, tr, W0, W1, O);
+            if (!(dbg & 4)) pvprodp<2>(pDa, tr, W0, W1, O, hookC);
+            else {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) hookC(k);
+            }
+            ts_cyc<DBG>(tsr, 13, tsi);
         }
         __syncthreads();
         if (dbg & 8) return;
@@ -1387,6 +1584,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(eC + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
     }
     __syncthreads();
+    ts_mark<DBG>(a, 3, 3);
     // ---- epilogue: whole rows, one per wave-instruction (role 0 parked dmodd and dc, role 1 dmodc)
     float* part = dcs + 64;                                     // [8][256] per-wave partial sums of d_w_m
     const int row0 = tile * 64, d4 = 4 * lane;
@@ -1427,20 +1625,24 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         for (int w = 0; w < 8; ++w) acc += part[w * 256 + tid];
         atomicAdd(A.d_w_m + tid, acc);
     }
+    ts_mark<DBG>(a, 3, 4);
+    ts_flush<DBG>(a, 3, tsr);
 }
 
-template <bool DBG, bool SAME>
+template <int DBG, bool SAME>
 __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, int local, char* smem) {
-    const int dbg = DBG ? a.dbg : 0;
+    const int dbg = DBG == 1 ? a.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int role = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
     const int r = lane & 15, g = lane >> 4;
     const int T = A.T, M = A.M, D = a.D, Tp = pad32(T), Mp = pad32(M);
     int tile, b;
-    if (!decode_local(local, (T + 63) / 64, a.B, tile, b)) return;
+    if (!decode_local_sm(local, (T + 63) / 64, a.B, tile, b)) return;
     const int n = (tile * 4 + w4) * 16 + r;  // text row i
     const bool wave_on = (tile * 4 + w4) * 16 < T;
     const bool nin = n < T;
+    ts_mark<DBG>(a, 3, 0);
+    TsRec tsr{};
 
     // streamed tensors in ring order: q, mod, [mod_d], dq.  Without dropped copies the similarity is formed as
     // (text * w_tm) . mod, so the mod panel serves the similarity, da . mod and the value rows of dX.
@@ -1464,7 +1666,6 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
 
     const int np = (dbg & 16) ? 0 : (M + PR - 1) / PR;
     auto issue8 = [&](int pi, int x) { stage_panel_w<8>(ring_slot(smem, pi * NT + x), src[x], pi * PR, wave, lane); };
-    auto issue4 = [&](int pi, int x) { stage_panel_w<4>(ring_slot(smem, pi * NT + x), src[x], pi * PR, w4, lane); };
     if (np > 0 || !(dbg & 64)) {
 #pragma unroll
         for (int x = 0; x < NT; ++x) issue8(0, x);
@@ -1514,16 +1715,21 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     auto issue_top = [&](int pi) {
         if (NT == 4 && pi > 0) issue8(pi, 3);                   // training mode: the 4th tensor of THIS panel, just in time
     };
-    // The whole next panel is issued by the role-1 waves right after the S-type products (they idle while role 0 does the
-    // tile's arithmetic): two pieces into the spare slots, the last into the slot the S-only tensor of this panel has just
-    // vacated.  vmcnt counts in issue order, so a wave with DMA in flight would stall at its next scratch reload: role 0
-    // never issues DMA inside the loop, and role 1 issues it BEHIND the reloads of its S-type products.
-    auto issue_mid = [&](int pi) {
-        if (pi + 1 < np) {
-            issue4(pi + 1, 0);
-            issue4(pi + 1, 1);
-            issue4(pi + 1, 2);
-        }
+    // The next panel is issued by the role-1 waves ONE PIECE PER STEP of their products (round 4; as three bursts of 7 pieces per
+    // wave behind the S-type products, rounds 2-3, the issue alone took the wave 1 300-2 000 clocks at 100-185 per piece, and
+    // the panel landed 2 000+ clocks after the top barrier of the next iteration was reached).  Slots (ring of 5): tensor 0 of
+    // panel p + 1 goes where a value tensor of panel p - 1 was -- free from the top barrier of iteration p on, as is tensor 1's
+    // slot with 3 tensors per panel; the last S-only slot of panel p comes free at the middle barrier.  So: first S-type
+    // product <- tensor 0, second <- tensor 1 (NT = 3), PV product <- the rest.  vmcnt counts in issue order, so a wave with
+    // DMA in flight would stall at its next scratch reload: role 0 never issues DMA inside the loop.
+    const int w4u = __builtin_amdgcn_readfirstlane(w4);
+    const bool nodma = DBG == 2 && (a.dbg & 1);        // timing only (with the time stamps): no LDS-DMA inside the loop
+    auto piece1 = [&](int pn, int x, int k) {          // piece w4 + 4 k (k = 0..6) of tensor x of panel pn
+        if (nodma) return;
+        const int piece = w4u + 4 * k;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src[x] + (size_t)((pn * PR) >> 4) * PRB + lane * 16 + piece * 1024),
+            (__attribute__((address_space(3))) void*)(ring_slot(smem, pn * NT + x) + piece * 1024), 16, 0, 0);
     };
 
     if (role == 0) {
@@ -1546,13 +1752,17 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         acc_t O;        // sum_j P2 dq
         zero_acc(O);
         float dr = 0.f;
+        ts_mark<DBG>(a, 3, 1);
 #pragma unroll 1
         for (int pi = 0; pi < np; ++pi) {
+            const bool tsi = pi == 1;
+            ts_cyc<DBG>(tsr, 8, tsi);
             if (sck < NSC) sc[sck * 32 + scr] = sc_next;
             dma_sync();               // this panel's DMA has landed, its scalars are visible
             issue_top(pi);
             if (NT == 4 && pi > 0) dma_sync();
             if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            ts_cyc<DBG>(tsr, 9, tsi);
             const char* pMd = ring_slot(smem, pi * NT + X_MD);
             const char* pDq = ring_slot(smem, pi * NT + X_DQ);
             f4 c1[2], c2[2];
@@ -1562,7 +1772,9 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
                 sprod2p(pMd, r, g, sS, c1);
                 sprod2p(pDq, r, g, sT, c2);
             }
+            ts_cyc<DBG>(tsr, 10, tsi);
             lds_barrier();            // role 1's dP1 is in LDS
+            ts_cyc<DBG>(tsr, 11, tsi);
             f4 wt[2], wx[2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -1586,14 +1798,18 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
                 __builtin_amdgcn_sched_barrier(0);
             }
             half8 W0, W1;
+            ts_cyc<DBG>(tsr, 12, tsi);
             split_w(wx[0], wx[1], W0, W1);
             xch_put(xch + 2048, W0, W1);
             split_w(wt[0], wt[1], W0, W1);
             lds_barrier();            // role 1 has its weights
+            ts_cyc<DBG>(tsr, 13, tsi);
             if (!(dbg & 4)) pvprodp(pDq, tr, W0, W1, O);
+            ts_cyc<DBG>(tsr, 14, tsi);
         }
         dr = kg_allsum(dr);
         __syncthreads();
+        ts_mark<DBG>(a, 3, 2);
         if (dbg & 8) return;
         const float scale = 1.0f / cDq;
 #pragma unroll
@@ -1613,32 +1829,54 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         zero_acc(O);
 #pragma unroll 1
         for (int pi = 0; pi < np; ++pi) {
+            const bool tsi = pi == 1;
+            ts_cyc<DBG>(tsr, 8, tsi);
             if (sck < NSC) sc[sck * 32 + scr] = sc_next;
             dma_sync();
             issue_top(pi);
             if (NT == 4 && pi > 0) dma_sync();
             if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            ts_cyc<DBG>(tsr, 9, tsi);
             const char* pM = ring_slot(smem, pi * NT + X_M);
             const char* pQ = ring_slot(smem, pi * NT + X_Q);
             const char* pMd = ring_slot(smem, pi * NT + X_MD);
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
+            const bool more = pi + 1 < np;
+            auto hookA = [&](int k) { if (more) piece1(pi + 1, 0, k); };
+            auto hookB = [&](int k) { if (more && NT == 3) piece1(pi + 1, 1, k); };
+            auto hookC = [&](int k) {
+                if (more && k < 7) {
+                    if (NT == 4) piece1(pi + 1, 1, k);
+                    piece1(pi + 1, 2, k);
+                }
+            };
             if (!(dbg & 2)) {
-                sprod2p(pQ, r, g, sDb, c2);
-                sprod2p(pM, r, g, sDa, c1);
+                sprod2p(pQ, r, g, sDb, c2, hookA);
+                sprod2p(pM, r, g, sDa, c1, hookB);
+            } else {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) { hookA(k); hookB(k); }
             }
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 const f4 sM = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16), sQ = *reinterpret_cast<const f4*>(sg + 9 * 32 + mb * 16);
                 *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sM * inDa) + c2[mb] * (sQ * inDb);
             }
+            ts_cyc<DBG>(tsr, 10, tsi);
+            lds_barrier();            // the S-only panels are dead
+            ts_cyc<DBG>(tsr, 11, tsi);
             lds_barrier();
-            issue_mid(pi);            // the S-only panels are dead: re-fill their slots under role 0's arithmetic
-            lds_barrier();
+            ts_cyc<DBG>(tsr, 12, tsi);
             half8 W0, W1;
             xch_get(xch + 2048, W0, W1);
-            if (!(dbg & 4)) pvprodp(pMd, tr, W0, W1, O);
+            if (!(dbg & 4)) pvprodp<2>(pMd, tr, W0, W1, O, hookC);
+            else {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) hookC(k);
+            }
+            ts_cyc<DBG>(tsr, 13, tsi);
         }
         __syncthreads();
         if (dbg & 8) return;
@@ -1647,6 +1885,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f4*>(eX + (w4 * 16 + r) * LDP + 16 * dt + 4 * g) = O[dt] * scale;
     }
     __syncthreads();
+    ts_mark<DBG>(a, 3, 3);
     // ---- epilogue.  The accumulator tiles hold 16 rows x 64-B pieces per instruction; role 1 parked dX, role 0 the P2.dq
     // sum and dr in LDS (the panels are dead) and the workgroup now works on whole rows -- one text row per
     // wave-instruction, lane = 16-B chunk -- so that text_d, the d_text read-modify-write and d_text_d are fully coalesced,
@@ -1702,15 +1941,17 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         const float sb_ = wave_allsum(drs[lane]);
         if (lane == 0) atomicAdd(A.d_bias, sb_);
     }
+    ts_mark<DBG>(a, 3, 4);
+    ts_flush<DBG>(a, 3, tsr);
 }
 
-template <bool DBG, bool SAME>
+template <int DBG, bool SAME>
 __global__ __launch_bounds__(NT8) void att_bwd_sweep_kernel(const GroupArgs a, const SweepMap sm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int local;
-    if (DBG && (a.dbg & 512)) return;                                  // timing only: launch floor
-    if (DBG && (a.dbg & 1024) && (int)blockIdx.x < sm.i_begin) return;  // timing only: i sweep alone
-    if (DBG && (a.dbg & 2048) && (int)blockIdx.x >= sm.i_begin) return; // timing only: j sweep alone
+    if (DBG == 1 && (a.dbg & 512)) return;                                  // timing only: launch floor
+    if (DBG == 1 && (a.dbg & 1024) && (int)blockIdx.x < sm.i_begin) return;  // timing only: i sweep alone
+    if (DBG == 1 && (a.dbg & 2048) && (int)blockIdx.x >= sm.i_begin) return; // timing only: j sweep alone
     if ((int)blockIdx.x < sm.i_begin) {
         const AttG& A = a.g[find_att(sm.j, a.n, blockIdx.x, local)];
         sweep_j_body<DBG, SAME>(a, A, local, smem);
@@ -1779,11 +2020,11 @@ static int allow_lds(K kernel, size_t bytes) {
 static int sweep_blocks(int rows, int B) { return (((rows + 63) / 64) * B + 7) / 8 * 8; }
 
 // stand-alone wrappers so that a profile names the forward column pass and the backward dq sweep apart
-template <bool DBG>
+template <int DBG>
 __global__ __launch_bounds__(NT8) void att_col_kernel(const GroupArgs a, const BlkMap bm) {
     att_jsweep_body<0, DBG>(a, bm);
 }
-template <bool DBG>
+template <int DBG>
 __global__ __launch_bounds__(NT8) void att_bwd_dq_kernel(const GroupArgs a, const BlkMap bm) {
     att_jsweep_body<1, DBG>(a, bm);
 }
@@ -1800,6 +2041,10 @@ static int check_att_dims(int B, int T, int M, int D) {
 }
 
 extern "C" void mmb_set_att_debug(int mask) { mmb::g_att_dbg = mask; }
+extern "C" size_t mmb_set_att_timestamps(void* buf) {
+    mmb::g_att_ts = static_cast<unsigned long long*>(buf);
+    return (size_t)4 * mmb::TS_BLOCKS * mmb::TS_SLOTS * sizeof(unsigned long long);
+}
 
 extern "C" size_t mmb_bidaf_saved_bytes(int B, int T, int M, int D, int has_drop) {
     if (B < 1 || T < 1 || M < 1 || D < 4) return 0;
@@ -1823,7 +2068,8 @@ extern "C" size_t mmb_bidaf_bwd_workspace_bytes(int B, int T, int M, int D) {
 static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backward, GroupArgs& ga) {
     MMB_REQUIRE(d && n >= 1 && n <= MAXG, "bidaf group: 1..%d attentions per call", MAXG);
     memset(&ga, 0, sizeof(ga));
-    ga.n = n; ga.B = B; ga.D = D; ga.dbg = att_dbg();
+    ga.n = n; ga.B = B; ga.D = D; ga.dbg = att_dbg(); ga.ts = (ga.dbg & 4096) ? g_att_ts : nullptr;
+    ga.dbg &= ~4096;
     const bool drop = d[0].text_d != nullptr;
     for (int k = 0; k < n; ++k) {
         const mmb_bidaf_desc& s = d[k];
@@ -1957,7 +2203,7 @@ extern "C" int mmb_bidaf_group_fwd(const mmb_bidaf_desc* d, int n, int B, int D,
         for (int k = 0; k < n; ++k) bm.begin[k + 1] = bm.begin[k] + sweep_blocks(ga.g[k].M, B);
         for (int k = n; k < MAXG; ++k) bm.begin[k + 1] = bm.begin[n];
         const size_t lds = (size_t)(drop ? 1 : 2) * 2 * (drop ? 2 : 1) * PANEL_B + (2 * 4 * 64 + 64) * sizeof(float);
-        auto kern = ga.dbg ? att_col_kernel<true> : att_col_kernel<false>;
+        auto kern = ga.ts ? att_col_kernel<2> : ga.dbg ? att_col_kernel<1> : att_col_kernel<0>;
         if (int rc = allow_lds(kern, lds)) return rc;
         ProfScope ps_(MMB_K_ATT_COL, stream);
         hipLaunchKernelGGL(kern, dim3(bm.begin[n]), dim3(NT8), lds, stream, ga, bm);
@@ -1971,7 +2217,7 @@ extern "C" int mmb_bidaf_group_fwd(const mmb_bidaf_desc* d, int n, int B, int D,
         size_t lds = (size_t)(drop ? 3 : 2) * PANEL_B + (5 * 32 + 16) * sizeof(float);
         const size_t epi = (size_t)64 * LDP * sizeof(float);
         if (lds < epi) lds = epi;
-        auto kern = ga.dbg ? att_row_kernel<true> : att_row_kernel<false>;
+        auto kern = ga.ts ? att_row_kernel<2> : ga.dbg ? att_row_kernel<1> : att_row_kernel<0>;
         if (int rc = allow_lds(kern, lds)) return rc;
         ProfScope ps_(MMB_K_ATT_ROW, stream);
         hipLaunchKernelGGL(kern, dim3(bm.begin[n]), dim3(NTHR), lds, stream, ga, bm);
@@ -2021,7 +2267,7 @@ extern "C" int mmb_bidaf_group_bwd(const mmb_bidaf_desc* d, int n, int B, int D,
         for (int k = 0; k < n; ++k) bm.begin[k + 1] = bm.begin[k] + sweep_blocks(ga.g[k].M, B);
         for (int k = n; k < MAXG; ++k) bm.begin[k + 1] = bm.begin[n];
         const size_t lds = (size_t)2 * 2 * PANEL_B + (2 * 5 * 64 + 64) * sizeof(float);
-        auto kern = ga.dbg ? att_bwd_dq_kernel<true> : att_bwd_dq_kernel<false>;
+        auto kern = ga.ts ? att_bwd_dq_kernel<2> : ga.dbg ? att_bwd_dq_kernel<1> : att_bwd_dq_kernel<0>;
         if (int rc = allow_lds(kern, lds)) return rc;
         ProfScope ps_(MMB_K_ATT_BWD_J1, stream);
         hipLaunchKernelGGL(kern, dim3(bm.begin[n]), dim3(NT8), lds, stream, ga, bm);
@@ -2039,8 +2285,9 @@ extern "C" int mmb_bidaf_group_bwd(const mmb_bidaf_desc* d, int n, int B, int D,
         const size_t loop_b = SWEEP_LOOP_LDS;
         const size_t epi = ((size_t)2 * 64 * LDP + 64 + 8 * 2 * 256) * sizeof(float);
         const size_t lds = loop_b > epi ? loop_b : epi;
-        auto kern = ga.dbg ? (drop ? att_bwd_sweep_kernel<true, false> : att_bwd_sweep_kernel<true, true>)
-                           : (drop ? att_bwd_sweep_kernel<false, false> : att_bwd_sweep_kernel<false, true>);
+        auto kern = ga.ts    ? (drop ? att_bwd_sweep_kernel<2, false> : att_bwd_sweep_kernel<2, true>)
+                    : ga.dbg ? (drop ? att_bwd_sweep_kernel<1, false> : att_bwd_sweep_kernel<1, true>)
+                             : (drop ? att_bwd_sweep_kernel<0, false> : att_bwd_sweep_kernel<0, true>);
         if (int rc = allow_lds(kern, lds)) return rc;
         ProfScope ps_(MMB_K_ATT_BWD_I, stream);
         hipLaunchKernelGGL(kern, dim3(sm.i.begin[n]), dim3(NT8), lds, stream, ga, sm);

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Where a workgroup of the fused attention kernels spends its time: phase time stamps (debug mask 4096 of
+mmb_set_att_debug: nothing ablated; thread 0 of each workgroup writes the 100-MHz s_memrealtime at entry / loop start /
+loop end / epilogue start / end) on the cfg2 shapes.
+
+    python tools/att_phases.py [--B 32 --T 400 --D 200 --Ms 256,64] [--drop]
+
+GPU box only.  Prints, per kernel and per workgroup class, the mean duration of every phase, the span of the launch
+(first entry -> last end) and how many workgroups were resident over time."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from mmbidaf_amd import _lib, functional as MF
+
+KN = ["att_col", "att_row", "att_bwd_dq", "att_bwd_sweep"]
+PH = {0: ["prologue", "loop", "merge", "epilogue"], 1: ["prologue", "loop", "epilogue"], 2: ["prologue", "loop", "merge", "epilogue"],
+      3: ["prologue", "loop", "park", "epilogue"]}
+
+
+CY = {0: ["sync+stage", "S", "softmax", "midsync+split", "PV"], 2: ["sync+stage", "S", "softmax", "midsync+split", "PV"],
+      1: ["sync+stage", "S", "softmax", "scale+split", "PV0", "split+PV1"],
+      3: ["sync+issue", "2xS", "wait-dP1", "dS-arith", "split+xch+barrier", "PV"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--T", type=int, default=400)
+    ap.add_argument("--D", type=int, default=200)
+    ap.add_argument("--Ms", default="256,64")
+    ap.add_argument("--drop", action="store_true")
+    ap.add_argument("--extra-mask", type=int, default=0, help="1 = no LDS-DMA inside the gradient sweeps' loops (timing only)")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(1)
+    B, T, D = a.B, a.T, a.D
+    Ms = [int(m) for m in a.Ms.split(",")]
+    text = torch.randn(B, T, D, generator=g).to(dev).requires_grad_(True)
+    tl = torch.full((B,), T, dtype=torch.int32, device=dev)
+    tm = MF.PrefixMask([T] * B, T, tl)
+    probs, leaves, cots = [], [text], []
+    for M in Ms:
+        mod = torch.randn(B, M, D, generator=g).to(dev).requires_grad_(True)
+        ps = [(torch.randn(D, 1, generator=g) * 0.1).to(dev).requires_grad_(True), (torch.randn(D, 1, generator=g) * 0.1).to(dev).requires_grad_(True),
+              (torch.randn(1, 1, D, generator=g) * 0.1).to(dev).requires_grad_(True), torch.zeros(1, device=dev, requires_grad=True)]
+        ml = torch.full((B,), M, dtype=torch.int32, device=dev)
+        mm = MF.PrefixMask([M] * B, M, ml)
+        drops = (None, None)
+        if a.drop:
+            drops = (text * (torch.rand(B, T, D, device=dev) > 0.2).float() / 0.8, mod * (torch.rand(B, M, D, device=dev) > 0.2).float() / 0.8)
+        probs.append((text, mod, tm, mm, *ps, *drops))
+        leaves += [mod] + ps
+        cots.append(torch.randn(B, T, 4 * D, generator=g).to(dev))
+
+    def step():
+        for t in leaves:
+            t.grad = None
+        outs = MF.bidaf_attention_group(probs)
+        torch.autograd.backward(outs, cots)
+
+    nbytes = lib.mmb_set_att_timestamps(None)
+    buf = torch.zeros(nbytes // 8, dtype=torch.int64, device=dev)
+    lib.mmb_set_att_debug(4096 | a.extra_mask)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    buf.zero_()
+    lib.mmb_set_att_timestamps(buf.data_ptr())
+    step()
+    torch.cuda.synchronize()
+    lib.mmb_set_att_timestamps(None)
+    lib.mmb_set_att_debug(0)
+    raw = buf.cpu().numpy().reshape(4, -1, 24)
+    ts = raw[:, :, :8].astype(np.float64) / 100.0      # us
+    cyc = raw[:, :, 8:16].astype(np.float64)
+    cyc1 = raw[:, :, 16:24].astype(np.float64)         # wave 4 (role 1 of the gradient sweeps)              # shader-clock stamps inside one iteration
+    jblk = [((M + 63) // 64 * B + 7) // 8 * 8 for M in Ms]
+    iblk = [((T + 63) // 64 * B + 7) // 8 * 8 for _ in Ms]
+    classes = {0: [(f"M={M}", sum(jblk[:k]), sum(jblk[:k + 1])) for k, M in enumerate(Ms)],
+               2: [(f"M={M}", sum(jblk[:k]), sum(jblk[:k + 1])) for k, M in enumerate(Ms)],
+               1: [(f"M={M}", sum(iblk[:k]), sum(iblk[:k + 1])) for k, M in enumerate(Ms)],
+               3: [(f"j M={M}", sum(jblk[:k]), sum(jblk[:k + 1])) for k, M in enumerate(Ms)] +
+                  [(f"i M={M}", sum(jblk) + sum(iblk[:k]), sum(jblk) + sum(iblk[:k + 1])) for k, M in enumerate(Ms)]}
+    for kern in range(4):
+        t = ts[kern]
+        nph = len(PH[kern])
+        live = t[:, 0] > 0
+        if not live.any():
+            continue
+        t0 = t[live, 0].min()
+        end = t[live, nph].max()
+        print(f"\n{KN[kern]}: {int(live.sum())} workgroups, span {end - t0:.1f} us (first entry -> last end)")
+        print(f"  {'class':10s}{'n':>5s}{'entry@':>9s}" + "".join(f"{p:>10s}" for p in PH[kern]) + f"{'total':>9s}{'end@max':>9s}")
+        for name, lo, hi in classes[kern]:
+            sel = np.zeros(t.shape[0], bool)
+            sel[lo:hi] = True
+            sel &= live
+            if not sel.any():
+                continue
+            d = np.diff(t[sel, :nph + 1], axis=1)
+            print(f"  {name:10s}{int(sel.sum()):5d}{(t[sel, 0] - t0).mean():9.1f}" + "".join(f"{x:10.2f}" for x in d.mean(axis=0)) +
+                  f"{d.sum(axis=1).mean():9.2f}{(t[sel, nph] - t0).max():9.1f}")
+        # residency over time
+        edges = np.linspace(t0, end, 11)
+        res = [int(((t[live, 0] <= e) & (t[live, nph] > e)).sum()) for e in edges[:-1] + 0.5 * (edges[1] - edges[0])]
+        print("  resident workgroups at 10 points of the span: " + " ".join(str(x) for x in res))
+        # inside one iteration of wave 0 (shader clocks between consecutive stamps)
+        names = CY[kern]
+        for name, lo, hi in classes[kern]:
+            c = cyc[kern, lo:hi]
+            ok = (c[:, 0] > 0) & (c[:, len(names)] > 0)
+            if not ok.any():
+                continue
+            d = np.diff(c[ok, :len(names) + 1], axis=1)
+            print(f"  one iteration, {name:9s} (clocks): " + "  ".join(f"{n} {x:.0f}" for n, x in zip(names, d.mean(axis=0))) + f"  | sum {d.sum(axis=1).mean():.0f}")
+            if kern == 3:
+                c1 = cyc1[kern, lo:hi]
+                ok1 = ok & (c1[:, 0] > 0) & (c1[:, 5] > 0)
+                if ok1.any():
+                    n1 = ["sync+issue", "2xS'+dP1", "barrier1", "barrier2", "PV"]
+                    d1 = np.diff(c1[ok1, :6], axis=1)
+                    skew = (c1[ok1, 0] - c[ok1, 0]).mean()
+                    print(f"      role 1 (wave 4)          : " + "  ".join(f"{n} {x:.0f}" for n, x in zip(n1, d1.mean(axis=0))) + f"  | sum {d1.sum(axis=1).mean():.0f}; top reached {skew:+.0f} clocks after wave 0")
+
+
+if __name__ == "__main__":
+    main()
