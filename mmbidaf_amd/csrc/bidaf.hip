@@ -418,6 +418,45 @@ __device__ __forceinline__ bool mask_live(const uint8_t* mask, const int* len, i
     return len ? (m < len[b]) : (mask[(size_t)b * R + m] != 0);
 }
 
+// What ONE thread fetches per streamed row for the panel loops' per-row scalars (staged in LDS one panel ahead): a float, a
+// float whose reciprocal is wanted, or a mask code.  Decided once per thread before the loop.  (Rounds 2-3 ran a switch over
+// the scalar's kind inside the loop: the kinds of a wave's two halves became two divergent branches, each with its own load
+// and -- for the reciprocals and the byte masks -- its own s_waitcnt vmcnt(0), 600-1 200 clocks at the top of every iteration,
+// and for a wave with LDS-DMA in flight a wait for all of its pieces.)  The loop now holds ONE load per thread, left in flight
+// for the whole iteration; the reciprocal is taken when the value is put into LDS.
+struct RowScalar {
+    const float* p;       // element of row 0 (already offset to the sample), or null: mask code
+    int stride;           // floats per row
+    float dflt;           // value beyond the range (plain floats; a reciprocal gives 0 there)
+    int op;               // 0 plain, 1 reciprocal, 2 mask code 0 / 1 / 2 (beyond / masked / live), 3 mask -1 / 0 / 1
+};
+struct RowMask {
+    const uint8_t* mask;  // sample's row of the u8 mask, or null with the length
+    int len;
+};
+// the load (from a clamped row: never guarded, so nothing has to wait for it here) ...
+__device__ __forceinline__ unsigned row_scalar_fetch(const RowScalar& rs, const RowMask& rm, int t, int R) {
+    const int tc = min(t, R - 1);
+    if (rs.op >= 2) return rm.mask ? (unsigned)rm.mask[tc] : (tc < rm.len ? 1u : 0u);
+    return __float_as_uint(rs.p[(size_t)tc * rs.stride]);
+}
+// ... and the value of row t that goes into LDS, one iteration later
+__device__ __forceinline__ float row_scalar_value(const RowScalar& rs, unsigned raw, int t, int R) {
+    const bool in = t < R;
+    switch (rs.op) {
+        case 0: return in ? __uint_as_float(raw) : rs.dflt;
+        case 1: return in ? 1.0f / __uint_as_float(raw) : 0.f;
+        case 2: return in ? (raw ? 2.f : 1.f) : 0.f;
+        default: return in ? (raw ? 1.f : 0.f) : -1.f;
+    }
+}
+__device__ __forceinline__ RowMask make_row_mask(const uint8_t* mask, const int* len, int b, int R) {
+    RowMask rm;
+    rm.mask = len ? nullptr : mask + (size_t)b * R;
+    rm.len = len ? len[b] : 0;
+    return rm;
+}
+
 // ------------------------------------------------------------------------------------------ grouped launches
 // One call handles up to MAXG attentions (the model's text<->audio and text<->image pair, models.py:131-132) with ONE
 // launch per stage: the kernels take a table of per-attention pointers and decode (attention, tile, sample) from the block
@@ -764,8 +803,11 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
         if (db) stage(smem, 0);
         else stage_one(0, true);
     }
+    // lane-side rows: waves w and w + 4 own the same 16 rows -- group 0 loads and splits them, group 1 takes the split operand
+    // from LDS (round 4; loaded by both, they were 100 of the 158 KB a workgroup requests in its prologue, and the prologue's
+    // length is those bytes at the ~11 B/clk a CU gets while every CU asks at once)
     float xrow[KT][8];
-    load_row_regs(xrow, A.mod_d + (size_t)b * N * D, n, N, D, g, A.w_tm);
+    if (grp == 0) load_row_regs(xrow, A.mod_d + (size_t)b * N * D, n, N, D, g, A.w_tm);
     const bool nin = n < N;
     const float nterm = nin ? A.cterm[(size_t)b * N + n] : 0.f;
     const bool mm = nin ? mask_live(A.mod_mask, A.mod_len, b, N, n) : false;
@@ -775,37 +817,56 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
 
     // per-row scalars of streamed row m (fetched by thread (k = tid >> 6, rr = tid & 63) for row 64 it + rr)
     const int sck = tid >> 6, scr = tid & 63;
-    auto fetch = [&](int m) -> float {
-        const bool in = m < R;
-        const size_t bm_ = (size_t)b * R + m;
-        if (KIND == 0) {
-            switch (sck) {
-                case 0: return in ? A.rterm[bm_] : 0.f;
-                case 1: return (float)mask_code(in, A.text_mask, A.text_len, b, R, m);
-                case 2: return in ? iS_b[m] : 0.f;
-                default: return in ? iV_b[m] : 0.f;
-            }
-        } else {
-            switch (sck) {
-                case 0: return in ? A.rterm[bm_] : 0.f;
-                case 1: return in ? A.row_stat[bm_ * 2] : INFINITY;          // exp(x - inf) = 0 beyond the range
-                case 2: return in ? 1.0f / A.row_stat[bm_ * 2 + 1] : 0.f;
-                case 3: return in ? iS_b[m] : 0.f;
-                default: return in ? iV_b[m] : 0.f;
-            }
+    RowScalar rs{nullptr, 1, 0.f, 0};
+    if (KIND == 0) {
+        switch (sck) {
+            case 0: rs.p = A.rterm + (size_t)b * R; break;
+            case 1: rs.op = 2; break;
+            case 2: rs.p = iS_b; break;
+            default: rs.p = iV_b; break;
         }
-    };
-    float sc_next = 0.f;
-    auto sc_fetch = [&](int it) { if (sck < NSC) sc_next = fetch(64 * it + scr); };
-    auto sc_commit = [&](int buf) { if (sck < NSC) sc[(buf * NSC + sck) * 64 + scr] = sc_next; };
+    } else {
+        switch (sck) {
+            case 0: rs.p = A.rterm + (size_t)b * R; break;
+            case 1: rs.p = A.row_stat + (size_t)b * R * 2; rs.stride = 2; rs.dflt = INFINITY; break;      // exp(x - inf) = 0 beyond the range
+            case 2: rs.p = A.row_stat + (size_t)b * R * 2 + 1; rs.stride = 2; rs.dflt = INFINITY; rs.op = 1; break;
+            case 3: rs.p = iS_b; break;
+            default: rs.p = iV_b; break;
+        }
+    }
+    const RowMask rmk = make_row_mask(A.text_mask, A.text_len, b, R);
+    unsigned sc_next = 0u;
+    int sc_row = 0;
+    auto sc_fetch = [&](int it) { if (sck < NSC) { sc_row = 64 * it + scr; sc_next = row_scalar_fetch(rs, rmk, sc_row, R); } };
+    auto sc_commit = [&](int buf) { if (sck < NSC) sc[(buf * NSC + sck) * 64 + scr] = row_scalar_value(rs, sc_next, sc_row, R); };
 
     if (niter > 0) sc_fetch(0);
     side_t side;
-    float inv_n;
-    side_from_regs(xrow, side, inv_n);
+    float inv_n = 0.f;
+    // exchange area: 14 KiB per wave in panel slots no DMA touches before the first barrier of the loop (the second stage, or
+    // the value-panel slots of the one stage); the inverse scales in the second scalar buffer (first written in iteration 1)
+    char* xs = (db ? smem + stage_b : smem) + (w4 >> 1) * (db ? PANEL_B : 2 * PANEL_B) + (w4 & 1) * (2 * KT * 1024) + lane * 16;
+    float* xinv = sc + NSC * 64 + w4 * 64 + lane;
+    if (grp == 0) {
+        side_from_regs(xrow, side, inv_n);
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            *reinterpret_cast<half8*>(xs + (2 * kt) * 1024) = side.h[kt][0];
+            *reinterpret_cast<half8*>(xs + (2 * kt + 1) * 1024) = side.h[kt][1];
+        }
+        *xinv = inv_n;
+    }
     // c: power of two mapping the largest inverse scale of the value rows to 2^14
-    wg_allmax_w<1, 8>(im, red, tid);
+    wg_allmax_w<1, 8>(im, red, tid);     // (its barriers also publish the exchange area)
     const float cV = cmap(im[0]);
+    if (grp == 1) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            side.h[kt][0] = *reinterpret_cast<const half8*>(xs + (2 * kt) * 1024);
+            side.h[kt][1] = *reinterpret_cast<const half8*>(xs + (2 * kt + 1) * 1024);
+        }
+        inv_n = *xinv;
+    }
     ts_mark<DBG>(a, TSK, 1);
 
     acc_t O;
@@ -917,6 +978,23 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
             for (int k = 0; k < KT; ++k) hookP(k);
         }
     }
+    // dq sweep: the q rows that delta2 needs (8 rows per wave, as raw planes values) are requested HERE, so that the merge and the
+    // parking below cover their latency (requested in the epilogue itself, rounds 2-3, they were 2-4 us of its 9.5)
+    half4 qh0[8], qh1[8];
+    float qiv[8];
+    if (KIND == 1) {
+        const char* q_p = A.pQ + (size_t)b * planes_sample_bytes(N);
+        const float* q_i = A.iQ + (size_t)b * pad32(N);
+        const int cq = min(lane, 8 * KT - 1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int gn = min(tile * 64 + wave + 8 * k, pad32(N) - 1);
+            const char* d = q_p + pl_off_att(gn, cq >> 1) + (cq & 1) * 8;
+            qh0[k] = *reinterpret_cast<const half4*>(d);
+            qh1[k] = *reinterpret_cast<const half4*>(d + 1024);
+            qiv[k] = q_i[gn];
+        }
+    }
     __syncthreads();      // all panels are dead
     ts_mark<DBG>(a, TSK, 2);
 
@@ -964,16 +1042,6 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
     const int row0 = tile * 64;
     char* dst_p = (KIND == 0 ? A.pQ : A.pDq) + (size_t)b * planes_sample_bytes(N);
     float* dst_i = (KIND == 0 ? A.iQ : A.iDq) + (size_t)b * Np;
-    f4 qrow[8];
-    if (KIND == 1) {         // delta2_j = q_j . dq_j: the q rows of the wave's 8 rows, all loads in flight together
-        const char* q_p = A.pQ + (size_t)b * planes_sample_bytes(N);
-        const float* q_i = A.iQ + (size_t)b * Np;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int gn = min(row0 + wave + 8 * k, Np - 1);
-            qrow[k] = lane < 8 * KT ? planes_row_f32(q_p, q_i, gn, lane) : f4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int rr = wave + 8 * k, gn = row0 + rr;
@@ -989,7 +1057,11 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
                     A.col_stat[((size_t)b * N + gn) * 2 + 1] = est[rr * 2 + 1];
                 }
             } else {
-                const float dot = wave_allsum(f4sum(x * qrow[k]));
+                f4 qv = f4{0.f, 0.f, 0.f, 0.f};
+                if (lane < 8 * KT)
+                    qv = f4{((float)qh0[k][0] + (float)qh1[k][0]) * qiv[k], ((float)qh0[k][1] + (float)qh1[k][1]) * qiv[k],
+                            ((float)qh0[k][2] + (float)qh1[k][2]) * qiv[k], ((float)qh0[k][3] + (float)qh1[k][3]) * qiv[k]};
+                const float dot = wave_allsum(f4sum(x * qv));
                 if (lane == 0) A.delta2[(size_t)b * N + gn] = dot;
             }
         }
@@ -1032,8 +1104,8 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
     float* sc = reinterpret_cast<float*>(smem + npan * PANEL_B);    // [NSC][32]
     float* red = sc + NSC * 32;
 
-    // prologue: the first panel, the lane-side rows, the text rows of the verbatim copy, the maxima pass and the first scalars are
-    // all requested before anything waits
+    // prologue: the first panel, the lane-side rows, the maxima pass and the first scalars are all requested before anything waits
+    // (the verbatim copy of text into `out` is made by the epilogue from the text rows it loads anyway)
     const int row_end = (dbg & 16) ? 0 : R;
     auto stage = [&](int p0) {
         stage_panel_w<NW>(smem, pV0_b, p0, wave, lane);
@@ -1046,39 +1118,22 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
     const float nterm = n < N ? A.rterm[(size_t)b * N + n] : 0.f;
     const tr_off tr = make_tr_off(lane);
     const int sck = tid >> 5, scr = tid & 31;
-    auto fetch = [&](int m) -> float {
-        const bool in = m < R;
-        switch (sck) {
-            case 0: return in ? A.cterm[(size_t)b * R + m] : 0.f;
-            case 1: return (float)mask_code(in, A.mod_mask, A.mod_len, b, R, m);
-            case 2: return in ? iS_b[m] : 0.f;
-            case 3: return in ? iV0_b[m] : 0.f;
-            default: return in ? iV1_b[m] : 0.f;
-        }
-    };
-    float sc_next = 0.f;
+    RowScalar rs{nullptr, 1, 0.f, 0};
+    switch (sck) {
+        case 0: rs.p = A.cterm + (size_t)b * R; break;
+        case 1: rs.op = 2; break;
+        case 2: rs.p = iS_b; break;
+        case 3: rs.p = iV0_b; break;
+        default: rs.p = iV1_b; break;
+    }
+    const RowMask rmk = make_row_mask(A.mod_mask, A.mod_len, b, R);
+    auto fetch = [&](int m) -> unsigned { return row_scalar_fetch(rs, rmk, m, R); };
+    unsigned sc_next = 0u;
     if (row_end > 0 && sck < NSC) sc_next = fetch(scr);
     float im[2] = {0.f, 0.f};
     for (int i = tid; i < R; i += NTHR) {
         im[0] = fmaxf(im[0], iV0_b[i]);
         im[1] = fmaxf(im[1], iV1_b[i]);
-    }
-    // first quarter of `out` = verbatim copy of text (attention.py:52): one row per wave-instruction, 16 rows per wave
-    {
-        const float* tx = A.text + (size_t)b * N * D;
-        float* oo = A.out + (size_t)b * N * 4 * D;
-        const bool cin = 4 * lane < D;
-        f4 t[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int gn = tile * 64 + wave + NW * k;
-            t[k] = (gn < N && cin) ? *reinterpret_cast<const f4*>(tx + (size_t)gn * D + 4 * lane) : f4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int gn = tile * 64 + wave + NW * k;
-            if (gn < N && cin) *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 4 * lane) = t[k];
-        }
     }
     side_t side;
     float inv_n;
@@ -1098,7 +1153,7 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
             __syncthreads();
             stage(p0);
         }
-        if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+        if (sck < NSC) sc[sck * 32 + scr] = row_scalar_value(rs, sc_next, p0 + scr, R);
         dma_sync();               // the panel staged above (or by the prologue) has landed
         if (p0 + PR < row_end && sck < NSC) sc_next = fetch(p0 + PR + scr);
         ts_cyc<DBG>(tsr, 9, tsi);
@@ -1212,6 +1267,7 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
         if (gn < N && 4 * c4 < D) {
             const f4 av = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
             float* o = oo + (size_t)gn * 4 * D + 4 * c4;
+            *reinterpret_cast<f4*>(o) = trow[k];              // first quarter of `out` = verbatim copy of text (attention.py:52)
             *reinterpret_cast<f4*>(o + D) = av;
             *reinterpret_cast<f4*>(o + 2 * D) = trow[k] * av;
         }
@@ -1388,21 +1444,21 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     };
     // per-row scalars of streamed text row t, fetched one panel ahead by thread (k = tid >> 5, rr = tid & 31)
     const int sck = tid >> 5, scr = tid & 31;
-    auto fetch = [&](int t) -> float {
-        const bool in = t < T;
-        const size_t bt = (size_t)b * T + t;
-        switch (sck) {
-            case 0: return in ? A.rterm[bt] : 0.f;
-            case 1: return in ? A.row_stat[bt * 2] : INFINITY;      // exp(x - inf) = 0 beyond the range
-            case 2: return in ? 1.0f / A.row_stat[bt * 2 + 1] : 0.f;
-            case 3: return in ? A.delta1[bt] : 0.f;
-            case 4: return (float)mask_code(in, A.text_mask, A.text_len, b, T, t);
-            case 5: return in ? iTd_b[t] : 0.f;
-            case 6: return in ? iT_b[t] : 0.f;
-            case 7: return in ? iDa_b[t] : 0.f;
-            default: return in ? iDb_b[t] : 0.f;
-        }
-    };
+    RowScalar rs{nullptr, 1, 0.f, 0};
+    switch (sck) {
+        case 0: rs.p = A.rterm + (size_t)b * T; break;
+        case 1: rs.p = A.row_stat + (size_t)b * T * 2; rs.stride = 2; rs.dflt = INFINITY; break;          // exp(x - inf) = 0 beyond the range
+        case 2: rs.p = A.row_stat + (size_t)b * T * 2 + 1; rs.stride = 2; rs.dflt = INFINITY; rs.op = 1; break;
+        case 3: rs.p = A.delta1 + (size_t)b * T; break;
+        case 4: rs.op = 2; break;
+        case 5: rs.p = iTd_b; break;
+        case 6: rs.p = iT_b; break;
+        case 7: rs.p = iDa_b; break;
+        default: rs.p = iDb_b; break;
+    }
+    const RowMask rmk = make_row_mask(A.text_mask, A.text_len, b, T);
+    auto fetch = [&](int t) -> unsigned { return row_scalar_fetch(rs, rmk, t, T); };
+    constexpr bool IS_J = true;
     const float* sg = sc + 4 * g;            // scalar k of the lane's 4 rows of block mb: f4 at sg[k * 32 + mb * 16]
     const tr_off tr = make_tr_off(lane);
     float* eD = reinterpret_cast<float*>(smem);                 // epilogue: [64][LDP]  sum_i dS text_d
@@ -1444,7 +1500,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         const float delta2 = nin ? A.delta2[(size_t)b * M + n] : 0.f;
         const bool mm = nin ? mask_live(A.mod_mask, A.mod_len, b, M, n) : false;
         const float mmf = mm ? 1.f : 0.f;
-        float sc_next = 0.f;
+        unsigned sc_next = 0u;
         if (np > 0 && sck < NSC) sc_next = fetch(scr);
         maxima();             // every load of the prologue is in flight by now: ONE round trip to memory, not one per stage
         const float cDa = cmap(im[2]);
@@ -1458,7 +1514,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         for (int pi = 0; pi < np; ++pi) {
             const bool tsi = pi == 1;
             ts_cyc<DBG>(tsr, 8, tsi);
-            if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+            if (sck < NSC) sc[sck * 32 + scr] = row_scalar_value(rs, sc_next, pi * PR + scr, IS_J ? T : M);
             dma_sync();               // this panel's DMA has landed, its scalars are visible
             issue_top(pi);
             if (NT == 4 && pi > 0) dma_sync();
@@ -1521,7 +1577,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         float inM, inQ;
         load_side_planes(sM, inM, A.pM + (size_t)b * szM, A.iM + (size_t)b * Mp, n, M, g);
         load_side_planes(sQ, inQ, A.pQ + (size_t)b * szM, A.iQ + (size_t)b * Mp, n, M, g);
-        float sc_next = 0.f;
+        unsigned sc_next = 0u;
         if (np > 0 && sck < NSC) sc_next = fetch(scr);
         maxima();
         const float cDa = cmap(im[2]);
@@ -1531,7 +1587,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         for (int pi = 0; pi < np; ++pi) {
             const bool tsi = pi == 1;
             ts_cyc<DBG>(tsr, 8, tsi);
-            if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+            if (sck < NSC) sc[sck * 32 + scr] = row_scalar_value(rs, sc_next, pi * PR + scr, IS_J ? T : M);
             dma_sync();
             issue_top(pi);
             if (NT == 4 && pi > 0) dma_sync();
@@ -1690,22 +1746,22 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     };
 
     const int sck = tid >> 5, scr = tid & 31;
-    auto fetch = [&](int j) -> float {
-        const bool in = j < M;
-        const size_t bj = (size_t)b * M + j;
-        switch (sck) {
-            case 0: return in ? A.cterm[bj] : 0.f;
-            case 1: return in ? A.col_stat[bj * 2] : 0.f;
-            case 2: return in ? 1.0f / A.col_stat[bj * 2 + 1] : 0.f;
-            case 3: return in ? A.delta2[bj] : 0.f;
-            case 4: return in ? (mask_live(A.mod_mask, A.mod_len, b, M, j) ? 1.f : 0.f) : -1.f;   // modality mask, -1 beyond M
-            case 5: return in ? iMd_b[j] : 0.f;      // streamed similarity operand (= mod without dropped copies)
-            case 6: return in ? iDq_b[j] : 0.f;
-            case 7: return in ? iMd_b[j] : 0.f;
-            case 8: return in ? iM_b[j] : 0.f;
-            default: return in ? iQ_b[j] : 0.f;
-        }
-    };
+    RowScalar rs{nullptr, 1, 0.f, 0};
+    switch (sck) {
+        case 0: rs.p = A.cterm + (size_t)b * M; break;
+        case 1: rs.p = A.col_stat + (size_t)b * M * 2; rs.stride = 2; break;
+        case 2: rs.p = A.col_stat + (size_t)b * M * 2 + 1; rs.stride = 2; rs.dflt = INFINITY; rs.op = 1; break;
+        case 3: rs.p = A.delta2 + (size_t)b * M; break;
+        case 4: rs.op = 3; break;                    // modality mask, -1 beyond M
+        case 5: rs.p = iMd_b; break;                 // streamed similarity operand (= mod without dropped copies)
+        case 6: rs.p = iDq_b; break;
+        case 7: rs.p = iMd_b; break;
+        case 8: rs.p = iM_b; break;
+        default: rs.p = iQ_b; break;
+    }
+    const RowMask rmk = make_row_mask(A.mod_mask, A.mod_len, b, M);
+    auto fetch = [&](int j) -> unsigned { return row_scalar_fetch(rs, rmk, j, M); };
+    constexpr bool IS_J = false;
     const float* sg = sc + 4 * g;            // scalar k of the lane's 4 rows of block mb: f4 at sg[k * 32 + mb * 16]
     const tr_off tr = make_tr_off(lane);
     float* eX = reinterpret_cast<float*>(smem);                 // epilogue: [64][LDP]  dX
@@ -1746,7 +1802,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         const float dl1 = nin ? A.delta1[(size_t)b * T + n] : 0.f;
         const bool tm = nin ? mask_live(A.text_mask, A.text_len, b, T, n) : false;
         const float tmf = tm ? 1.f : 0.f;
-        float sc_next = 0.f;
+        unsigned sc_next = 0u;
         if (np > 0 && sck < NSC) sc_next = fetch(scr);
         maxima();             // every load of the prologue is in flight by now
         acc_t O;        // sum_j P2 dq
@@ -1757,7 +1813,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         for (int pi = 0; pi < np; ++pi) {
             const bool tsi = pi == 1;
             ts_cyc<DBG>(tsr, 8, tsi);
-            if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+            if (sck < NSC) sc[sck * 32 + scr] = row_scalar_value(rs, sc_next, pi * PR + scr, IS_J ? T : M);
             dma_sync();               // this panel's DMA has landed, its scalars are visible
             issue_top(pi);
             if (NT == 4 && pi > 0) dma_sync();
@@ -1822,7 +1878,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         load_side_planes(sDa, iDa_, A.pDa + (size_t)b * szT, A.iDa + (size_t)b * Tp, n, T, g);
         load_side_planes(sDb, iDb_, A.pDb + (size_t)b * szT, A.iDb + (size_t)b * Tp, n, T, g);
         }
-        float sc_next = 0.f;
+        unsigned sc_next = 0u;
         if (np > 0 && sck < NSC) sc_next = fetch(scr);
         maxima();
         acc_t O;        // dX = sum_j dS mod_d
@@ -1831,7 +1887,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         for (int pi = 0; pi < np; ++pi) {
             const bool tsi = pi == 1;
             ts_cyc<DBG>(tsr, 8, tsi);
-            if (sck < NSC) sc[sck * 32 + scr] = sc_next;
+            if (sck < NSC) sc[sck * 32 + scr] = row_scalar_value(rs, sc_next, pi * PR + scr, IS_J ? T : M);
             dma_sync();
             issue_top(pi);
             if (NT == 4 && pi > 0) dma_sync();
