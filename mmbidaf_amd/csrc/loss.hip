@@ -2,8 +2,7 @@
 // The synthetic objective the throughput measurement back-propagates (<y_a,R_a> + <y_i,R_i> +
 // sum(h_a) + sum(h_i)) -- in the reference the objective is the decoder's summed negative log-likelihood
 // (models.py:168-176); written as stock torch ops it costs ~20 tiny launches per step around a 3-ms step.
-// One launch each way: per-workgroup partial sums, the LAST workgroup to finish (ticket counter) adds them up in a fixed
-// order, so the result is deterministic; the counter resets itself.
+// Forward: per-workgroup partial sums, then a one-workgroup launch that adds them up in a fixed order (deterministic).
 #include <stdlib.h>
 
 #include "common.h"
@@ -17,15 +16,13 @@ struct WSumArgs {
     long n[MMB_WSUM_MAX];
     int blk_begin[MMB_WSUM_MAX + 1];
     int k;
-    int reps;          // chunks of WS_PER_BLOCK elements per workgroup (keeps the grid near one workgroup per CU x 2: the
-                       // ticket atomics and fences of the forward are per workgroup)
+    int reps;          // chunks of WS_PER_BLOCK elements per workgroup (keeps the grid near one workgroup per CU x 2)
 };
 constexpr int WS_PER_BLOCK = 256 * 4 * 8;   // elements one workgroup covers
 __device__ __forceinline__ float f4sum(const f4 v) { return (v.x + v.y) + (v.z + v.w); }
 
-__global__ __launch_bounds__(256) void wsum_fwd_kernel(const WSumArgs a, float* partial, unsigned* ticket, float* out) {
+__global__ __launch_bounds__(256) void wsum_fwd_kernel(const WSumArgs a, float* partial) {
     __shared__ float red[4];
-    __shared__ bool last;
     int k = 0;
     for (int i = 1; i < a.k; ++i)
         if ((int)blockIdx.x >= a.blk_begin[i]) k = i;
@@ -36,15 +33,28 @@ __global__ __launch_bounds__(256) void wsum_fwd_kernel(const WSumArgs a, float* 
     for (int rep = 0; rep < a.reps; ++rep) {
         const long base = ((long)(blockIdx.x - a.blk_begin[k]) * a.reps + rep) * WS_PER_BLOCK;
         if (base >= n) break;
+        if (base + WS_PER_BLOCK <= n) {
+            // whole chunk: all 16 loads of a thread requested before the first use (with the tail test inside the unrolled loop,
+            // rounds 1-4, every iteration was its own load -> wait -> add: 8 memory round trips per chunk, 24 us for 41 MB)
+            f4 xv[8], wv[8];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const long i = base + ((long)it * 256 + threadIdx.x) * 4;
-            if (i + 3 < n) {
-                const f4 v = *reinterpret_cast<const f4*>(x + i);
-                if (w) acc += f4sum(v * *reinterpret_cast<const f4*>(w + i));
-                else acc += f4sum(v);
-            } else {
-                for (long j = i; j < n; ++j) acc += x[j] * (w ? w[j] : 1.0f);
+            for (int it = 0; it < 8; ++it) {
+                const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+                xv[it] = *reinterpret_cast<const f4*>(x + i);
+                wv[it] = w ? *reinterpret_cast<const f4*>(w + i) : f4{1.f, 1.f, 1.f, 1.f};
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) acc += f4sum(xv[it] * wv[it]);
+        } else {
+            for (int it = 0; it < 8; ++it) {
+                const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+                if (i + 3 < n) {
+                    const f4 v = *reinterpret_cast<const f4*>(x + i);
+                    if (w) acc += f4sum(v * *reinterpret_cast<const f4*>(w + i));
+                    else acc += f4sum(v);
+                } else {
+                    for (long j = i; j < n; ++j) acc += x[j] * (w ? w[j] : 1.0f);
+                }
             }
         }
     }
@@ -52,25 +62,20 @@ __global__ __launch_bounds__(256) void wsum_fwd_kernel(const WSumArgs a, float* 
     for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-        __threadfence();
-        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// second launch: ONE workgroup adds the partial sums in a fixed order (deterministic).  Rounds 1-4 had the last workgroup of the
+// first launch do this behind a ticket counter: its __threadfence() per workgroup is an L2 write-back on this multi-die part, with
+// the encoders' freshly written outputs dirty in L2 -- 23 us for a 41-MB pass, whatever the grid.
+__global__ __launch_bounds__(256) void wsum_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ float red[4];
     float s = 0.f;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) s += __builtin_nontemporal_load(partial + i);
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-    __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        out[0] = (red[0] + red[1]) + (red[2] + red[3]);
-        *ticket = 0u;
-    }
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // dx_k = g * w_k (or g where w_k is null), g a device scalar
@@ -85,15 +90,28 @@ __global__ __launch_bounds__(256) void wsum_bwd_kernel(const WSumArgs a, const f
     for (int rep = 0; rep < a.reps; ++rep) {
         const long base = ((long)(blockIdx.x - a.blk_begin[k]) * a.reps + rep) * WS_PER_BLOCK;
         if (base >= n) break;
+        if (base + WS_PER_BLOCK <= n) {
+            f4 wv[8];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const long i = base + ((long)it * 256 + threadIdx.x) * 4;
-            if (i + 3 < n) {
-                f4 v = f4{g, g, g, g};
-                if (w) v = *reinterpret_cast<const f4*>(w + i) * g;
-                *reinterpret_cast<f4*>(dx + i) = v;
-            } else {
-                for (long j = i; j < n; ++j) dx[j] = g * (w ? w[j] : 1.0f);
+            for (int it = 0; it < 8; ++it) {
+                const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+                wv[it] = w ? *reinterpret_cast<const f4*>(w + i) : f4{1.f, 1.f, 1.f, 1.f};
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+                *reinterpret_cast<f4*>(dx + i) = wv[it] * g;
+            }
+        } else {
+            for (int it = 0; it < 8; ++it) {
+                const long i = base + ((long)it * 256 + threadIdx.x) * 4;
+                if (i + 3 < n) {
+                    f4 v = f4{g, g, g, g};
+                    if (w) v = *reinterpret_cast<const f4*>(w + i) * g;
+                    *reinterpret_cast<f4*>(dx + i) = v;
+                } else {
+                    for (long j = i; j < n; ++j) dx[j] = g * (w ? w[j] : 1.0f);
+                }
             }
         }
     }
@@ -148,9 +166,10 @@ extern "C" int mmb_weighted_sums_fwd(const float* const* x, const float* const* 
         MMB_HIP(hipMemsetAsync(out, 0, sizeof(float), stream));
         return MMB_OK;
     }
-    // ws: [ticket (zero before the first use; the kernel leaves it zero) | pad to 256 B | partials]
-    hipLaunchKernelGGL(wsum_fwd_kernel, dim3(blocks), dim3(256), 0, stream, a, reinterpret_cast<float*>(static_cast<char*>(ws) + 256),
-                       static_cast<unsigned*>(ws), out);
+    // ws: [256 B unused (the ticket word of rounds 1-4) | partials]
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + 256);
+    hipLaunchKernelGGL(wsum_fwd_kernel, dim3(blocks), dim3(256), 0, stream, a, partial);
+    hipLaunchKernelGGL(wsum_final_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, out);
     MMB_HIP(hipGetLastError());
     return MMB_OK;
 }
