@@ -60,6 +60,9 @@ constexpr float WMAX = 16384.0f;   // 2^14: where the largest split operand is m
 // timing-only ablations (mmb_set_att_debug / MMB_ATT_DBG; never set by the product path; results are then WRONG):
 // 1 = stage only the first panel, 2 = no S-type products, 4 = no PV-type products, 8 = no epilogue stores,
 // 16 = no panel loop at all (prologue + epilogue only)
+// 8192 = att_row also writes the rows of `out` as the fp16 planes of the next layer's projection operand (tiled layout of
+// planes.hip, 25 K tiles, a fixed scale) into the buffer given to mmb_set_att_timestamps (>= 2 x 41 MB at cfg2): what
+// producer-written planes would cost the row pass (tools/att_bench.py --masks 32,8224)
 // 4096 = phase time stamps (DBG kernels, nothing ablated): thread 0 of every workgroup writes s_memrealtime (100 MHz) at
 // its phase boundaries into the buffer given to mmb_set_att_timestamps: [kernel 0..3][block][8] u64 (tools/att_phases.py)
 static int g_att_dbg = -1;
@@ -483,6 +486,7 @@ struct GroupArgs {
     AttG g[MAXG];
     int n, B, D, dbg;
     unsigned long long* ts;
+    char* scr;             // timing experiment (debug mask 8192): where att_row ALSO writes its output rows as fp16 planes
 };
 // DBG template value of the kernels: 0 = product, 1 = timing-only ablations (a.dbg), 2 = time stamps, nothing ablated
 template <int DBG>
@@ -1071,6 +1075,23 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
 }
 
 
+// (timing experiment, debug mask 8192) 4 consecutive features of plane row `row` as the two fp16 planes of a 25-K-tile tensor
+__device__ __forceinline__ void plane_store_dbg(char* scr, bool second, int row, int col, f4 v) {
+    const int rl = row & 15;
+    char* d = scr + (second ? (size_t)48 << 20 : 0) + ((size_t)(row >> 4) * 25 + (col >> 5)) * 2048 + rl * 64 +
+              ((((col >> 3) & 3) ^ (((rl >> 3) & 1) << 1)) << 4) + (col & 7) * 2;
+    half4 h0, h1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x = v[j] * 4096.0f;
+        const _Float16 a = (_Float16)x;
+        h0[j] = a;
+        h1[j] = (_Float16)(x - (float)a);
+    }
+    *reinterpret_cast<half4*>(d) = h0;
+    *reinterpret_cast<half4*>(d + 1024) = h1;
+}
+
 // ------------------------------------------------------------------------------------------ row pass (forward)
 // Lane side = 64 text rows (text_d * w_tm, split in registers from fp32), streams the modality rows with values
 // [mod | q]: a = P1 mod, b = P1 q, out = [text, a, text*a, text*b].  4 waves with one 16-row tile each, at most 256
@@ -1270,6 +1291,11 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
             *reinterpret_cast<f4*>(o) = trow[k];              // first quarter of `out` = verbatim copy of text (attention.py:52)
             *reinterpret_cast<f4*>(o + D) = av;
             *reinterpret_cast<f4*>(o + 2 * D) = trow[k] * av;
+            if (DBG == 1 && (dbg & 8192)) {
+                plane_store_dbg(a.scr, blockIdx.x >= (unsigned)bm.begin[1], b * N + gn, 4 * c4, trow[k]);
+                plane_store_dbg(a.scr, blockIdx.x >= (unsigned)bm.begin[1], b * N + gn, D + 4 * c4, av);
+                plane_store_dbg(a.scr, blockIdx.x >= (unsigned)bm.begin[1], b * N + gn, 2 * D + 4 * c4, trow[k] * av);
+            }
         }
     }
     park(O1, 1.0f / (l * c1));
@@ -1279,6 +1305,7 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
         if (gn < N && 4 * c4 < D) {
             const f4 bv = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * c4);
             *reinterpret_cast<f4*>(oo + (size_t)gn * 4 * D + 3 * D + 4 * c4) = trow[k] * bv;
+            if (DBG == 1 && (dbg & 8192)) plane_store_dbg(a.scr, blockIdx.x >= (unsigned)bm.begin[1], b * N + gn, 3 * D + 4 * c4, trow[k] * bv);
             *reinterpret_cast<f4*>(bo + (size_t)gn * D + 4 * c4) = bv;
         }
     }
@@ -1378,10 +1405,19 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // spare slots, the third into the slot the S-only tensor of panel p has just vacated -- so the LDS-DMA runs under the tile
 // arithmetic and the PV products, and the one full wait per iteration (top of the loop) finds its data landed.
 constexpr int RING_NS = 5;
-__device__ __forceinline__ char* ring_slot(char* smem, int piece) {
-    // opaque to the optimiser: seen as a function of the loop counter, the slot address is strength-reduced into one
-    // induction variable PER fragment read (52 VGPRs in a PV product, all spilled) instead of one base + immediate offsets
-    int off = (piece % RING_NS) * PANEL_B;
+// LDS slot of tensor x of panel pn.  opaque to the optimiser: seen as a function of the loop counter, the slot address is
+// strength-reduced into one induction variable PER fragment read (52 VGPRs in a PV product, all spilled) instead of one base +
+// immediate offsets.
+//   4 tensors per panel (training mode): the modulo ring described above.
+//   3 tensors per panel (round 4): FIXED slots -- 0: the S-only tensor (x = XS); 1 + parity(pn): the tensor role 0's PV product
+//   reads (x = XR0); 3 + parity(pn): the tensor role 1's PV product reads (x = XR1) -- because role 1 now runs the PV product of
+//   panel p - 1 under role 0's tile arithmetic of panel p (see sweep_j_body), so its value tensor lives one iteration longer.
+template <bool SAME, int NT, int XS, int XR0>
+__device__ __forceinline__ char* sweep_slot(char* smem, int pn, int x) {
+    int idx;
+    if constexpr (SAME) idx = x == XS ? 0 : (x == XR0 ? 1 + (pn & 1) : 3 + (pn & 1));
+    else idx = (pn * NT + x) % RING_NS;
+    int off = idx * PANEL_B;
     asm volatile("" : "+s"(off));
     return smem + off;
 }
@@ -1425,7 +1461,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     const float* iDb_b = A.iDb + (size_t)b * Tp;
 
     const int np = (dbg & 16) ? 0 : (T + PR - 1) / PR;       // panels
-    auto issue8 = [&](int pi, int x) { stage_panel_w<8>(ring_slot(smem, pi * NT + x), src[x], pi * PR, wave, lane); };
+    auto issue8 = [&](int pi, int x) { stage_panel_w<8>(sweep_slot<SAME, NT, X_DB, X_TD>(smem, pi, x), src[x], pi * PR, wave, lane); };
     if (np > 0) {          // first panel in flight under the operand loads below
 #pragma unroll
         for (int x = 0; x < NT; ++x) issue8(0, x);
@@ -1483,7 +1519,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         const int piece = w4u + 4 * k;
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(src[x] + (size_t)((pn * PR) >> 4) * PRB + lane * 16 + piece * 1024),
-            (__attribute__((address_space(3))) void*)(ring_slot(smem, pn * NT + x) + piece * 1024), 16, 0, 0);
+            (__attribute__((address_space(3))) void*)(sweep_slot<SAME, NT, X_DB, X_TD>(smem, pn, x) + piece * 1024), 16, 0, 0);
     };
 
     // Each role runs its OWN copy of the panel loop (same barrier sequence): the register allocator then sees role 0's
@@ -1520,8 +1556,8 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
             if (NT == 4 && pi > 0) dma_sync();
             if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
             ts_cyc<DBG>(tsr, 9, tsi);
-            const char* pTd = ring_slot(smem, pi * NT + X_TD);
-            const char* pT = ring_slot(smem, pi * NT + X_T);
+            const char* pTd = sweep_slot<SAME, NT, X_DB, X_TD>(smem, pi, X_TD);
+            const char* pT = sweep_slot<SAME, NT, X_DB, X_TD>(smem, pi, X_T);
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
@@ -1583,6 +1619,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         const float cDa = cmap(im[2]);
         acc_t O;        // dmodc = sum_i P1 da
         zero_acc(O);
+        half8 Wp0 = {0, 0, 0, 0, 0, 0, 0, 0}, Wp1 = Wp0;      // weights of the previous panel (3-tensor schedule)
 #pragma unroll 1
         for (int pi = 0; pi < np; ++pi) {
             const bool tsi = pi == 1;
@@ -1593,45 +1630,89 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
             if (NT == 4 && pi > 0) dma_sync();
             if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
             ts_cyc<DBG>(tsr, 9, tsi);
-            const char* pDa = ring_slot(smem, pi * NT + X_DA);
-            const char* pDb = ring_slot(smem, pi * NT + X_DB);
+            const char* pDa = sweep_slot<SAME, NT, X_DB, X_TD>(smem, pi, X_DA);
+            const char* pDb = sweep_slot<SAME, NT, X_DB, X_TD>(smem, pi, X_DB);
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
             const bool more = pi + 1 < np;
-            auto hookA = [&](int k) { if (more) piece1(pi + 1, 0, k); };
-            auto hookB = [&](int k) { if (more && NT == 3) piece1(pi + 1, 1, k); };
-            auto hookC = [&](int k) {
-                if (more && k < 7) {
-                    if (NT == 4) piece1(pi + 1, 1, k);
-                    piece1(pi + 1, 2, k);
+            if constexpr (SAME) {
+                // Round 4 schedule (3 tensors): role 1 runs the PV product of panel pi - 1 BETWEEN the two middle barriers, under
+                // role 0's tile arithmetic of panel pi (until round 4 it idled there, and both roles' PV products then shared the
+                // matrix pipe behind the second barrier: 1 900 clocks for role 1's where role 0's alone takes 700).  Its weights
+                // (Wp: read right behind the second barrier of the iteration that made them) wait in registers; before the first
+                // panel they are zero, and the product runs on the landed panel 0 (plane values are finite by construction: + 0).
+                // Next panel: role 0's value tensor (slot free from the top barrier on) rides in the first S-type product, the
+                // S-only tensor (free behind the first middle barrier) in the PV product, role 1's own value tensor (the slot
+                // of panel pi - 1's, free behind the second) is issued at once behind that barrier.
+                auto hookA = [&](int k) { if (more) piece1(pi + 1, X_TD, k); };
+                auto hookC = [&](int k) { if (more && k < 7) piece1(pi + 1, X_DB, k); };
+                if (!(dbg & 2)) {
+                    sprod2p(pDb, r, g, sQ, c2, hookA);
+                    sprod2p(pDa, r, g, sM, c1);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) hookA(k);
                 }
-            };
-            if (!(dbg & 2)) {
-                sprod2p(pDb, r, g, sQ, c2, hookA);
-                sprod2p(pDa, r, g, sM, c1, hookB);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const f4 sDa = *reinterpret_cast<const f4*>(sg + 7 * 32 + mb * 16), sDb = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16);
+                    *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sDa * inM) + c2[mb] * (sDb * inQ);
+                }
+                ts_cyc<DBG>(tsr, 10, tsi);
+                lds_barrier();            // dP1 is out; the S-only panel is dead
+                ts_cyc<DBG>(tsr, 11, tsi);
+                const char* pPrev = sweep_slot<SAME, NT, X_DB, X_TD>(smem, pi > 0 ? pi - 1 : 0, X_DA);
+                if (!(dbg & 4)) pvprodp<2>(pPrev, tr, Wp0, Wp1, O, hookC);
+                else {
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) hookC(k);
+                }
+                ts_cyc<DBG>(tsr, 12, tsi);
+                lds_barrier();            // role 0's weights of this panel are in LDS; panel pi - 1's value tensor is dead
+                xch_get(xch + 2048, Wp0, Wp1);
+                if (more) {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) piece1(pi + 1, X_DA, k);
+                }
+                ts_cyc<DBG>(tsr, 13, tsi);
             } else {
+                auto hookA = [&](int k) { if (more) piece1(pi + 1, 0, k); };
+                auto hookC = [&](int k) {
+                    if (more && k < 7) {
+                        piece1(pi + 1, 1, k);
+                        piece1(pi + 1, 2, k);
+                    }
+                };
+                if (!(dbg & 2)) {
+                    sprod2p(pDb, r, g, sQ, c2, hookA);
+                    sprod2p(pDa, r, g, sM, c1);
+                } else {
 #pragma unroll
-                for (int k = 0; k < KT; ++k) { hookA(k); hookB(k); }
-            }
+                    for (int k = 0; k < KT; ++k) hookA(k);
+                }
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const f4 sDa = *reinterpret_cast<const f4*>(sg + 7 * 32 + mb * 16), sDb = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16);
-                *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sDa * inM) + c2[mb] * (sDb * inQ);
-            }
-            ts_cyc<DBG>(tsr, 10, tsi);
-            lds_barrier();            // the S-only panels are dead
-            ts_cyc<DBG>(tsr, 11, tsi);
-            lds_barrier();
-            ts_cyc<DBG>(tsr, 12, tsi);
-            half8 W0, W1;
-            xch_get(xch + 2048, W0, W1);
-            if (!(dbg & 4)) pvprodp<2>(pDa, tr, W0, W1, O, hookC);
-            else {
+                for (int mb = 0; mb < 2; ++mb) {
+                    const f4 sDa = *reinterpret_cast<const f4*>(sg + 7 * 32 + mb * 16), sDb = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16);
+                    *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sDa * inM) + c2[mb] * (sDb * inQ);
+                }
+                ts_cyc<DBG>(tsr, 10, tsi);
+                lds_barrier();            // the S-only panels are dead
+                ts_cyc<DBG>(tsr, 11, tsi);
+                lds_barrier();
+                ts_cyc<DBG>(tsr, 12, tsi);
+                half8 W0, W1;
+                xch_get(xch + 2048, W0, W1);
+                if (!(dbg & 4)) pvprodp<2>(pDa, tr, W0, W1, O, hookC);
+                else {
 #pragma unroll
-                for (int k = 0; k < KT; ++k) hookC(k);
+                    for (int k = 0; k < KT; ++k) hookC(k);
+                }
+                ts_cyc<DBG>(tsr, 13, tsi);
             }
-            ts_cyc<DBG>(tsr, 13, tsi);
+        }
+        if constexpr (SAME) {        // the last panel's PV product (its value tensor is still in its slot)
+            if (np > 0 && !(dbg & 4)) pvprodp<2>(sweep_slot<SAME, NT, X_DB, X_TD>(smem, np - 1, X_DA), tr, Wp0, Wp1, O);
         }
         __syncthreads();
         if (dbg & 8) return;
@@ -1721,7 +1802,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     const float* iDq_b = A.iDq + (size_t)b * Mp;
 
     const int np = (dbg & 16) ? 0 : (M + PR - 1) / PR;
-    auto issue8 = [&](int pi, int x) { stage_panel_w<8>(ring_slot(smem, pi * NT + x), src[x], pi * PR, wave, lane); };
+    auto issue8 = [&](int pi, int x) { stage_panel_w<8>(sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, x), src[x], pi * PR, wave, lane); };
     if (np > 0 || !(dbg & 64)) {
 #pragma unroll
         for (int x = 0; x < NT; ++x) issue8(0, x);
@@ -1785,7 +1866,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         const int piece = w4u + 4 * k;
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(src[x] + (size_t)((pn * PR) >> 4) * PRB + lane * 16 + piece * 1024),
-            (__attribute__((address_space(3))) void*)(ring_slot(smem, pn * NT + x) + piece * 1024), 16, 0, 0);
+            (__attribute__((address_space(3))) void*)(sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pn, x) + piece * 1024), 16, 0, 0);
     };
 
     if (role == 0) {
@@ -1819,8 +1900,8 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
             if (NT == 4 && pi > 0) dma_sync();
             if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
             ts_cyc<DBG>(tsr, 9, tsi);
-            const char* pMd = ring_slot(smem, pi * NT + X_MD);
-            const char* pDq = ring_slot(smem, pi * NT + X_DQ);
+            const char* pMd = sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, X_MD);
+            const char* pDq = sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, X_DQ);
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
@@ -1883,6 +1964,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         maxima();
         acc_t O;        // dX = sum_j dS mod_d
         zero_acc(O);
+        half8 Wp0 = {0, 0, 0, 0, 0, 0, 0, 0}, Wp1 = Wp0;      // weights of the previous panel (3-tensor schedule)
 #pragma unroll 1
         for (int pi = 0; pi < np; ++pi) {
             const bool tsi = pi == 1;
@@ -1893,46 +1975,83 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
             if (NT == 4 && pi > 0) dma_sync();
             if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
             ts_cyc<DBG>(tsr, 9, tsi);
-            const char* pM = ring_slot(smem, pi * NT + X_M);
-            const char* pQ = ring_slot(smem, pi * NT + X_Q);
-            const char* pMd = ring_slot(smem, pi * NT + X_MD);
+            const char* pM = sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, X_M);
+            const char* pQ = sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, X_Q);
+            const char* pMd = sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, X_MD);
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
             const bool more = pi + 1 < np;
-            auto hookA = [&](int k) { if (more) piece1(pi + 1, 0, k); };
-            auto hookB = [&](int k) { if (more && NT == 3) piece1(pi + 1, 1, k); };
-            auto hookC = [&](int k) {
-                if (more && k < 7) {
-                    if (NT == 4) piece1(pi + 1, 1, k);
-                    piece1(pi + 1, 2, k);
+            if constexpr (SAME) {
+                // 3-tensor schedule of round 4 (see sweep_j_body): the PV product of panel pi - 1 between the middle barriers
+                auto hookA = [&](int k) { if (more) piece1(pi + 1, X_DQ, k); };
+                auto hookC = [&](int k) { if (more && k < 7) piece1(pi + 1, X_Q, k); };
+                if (!(dbg & 2)) {
+                    sprod2p(pQ, r, g, sDb, c2, hookA);
+                    sprod2p(pM, r, g, sDa, c1);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) hookA(k);
                 }
-            };
-            if (!(dbg & 2)) {
-                sprod2p(pQ, r, g, sDb, c2, hookA);
-                sprod2p(pM, r, g, sDa, c1, hookB);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const f4 sM = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16), sQ = *reinterpret_cast<const f4*>(sg + 9 * 32 + mb * 16);
+                    *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sM * inDa) + c2[mb] * (sQ * inDb);
+                }
+                ts_cyc<DBG>(tsr, 10, tsi);
+                lds_barrier();            // dP1 is out; the S-only panel is dead
+                ts_cyc<DBG>(tsr, 11, tsi);
+                const char* pPrev = sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi > 0 ? pi - 1 : 0, X_MD);
+                if (!(dbg & 4)) pvprodp<2>(pPrev, tr, Wp0, Wp1, O, hookC);
+                else {
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) hookC(k);
+                }
+                ts_cyc<DBG>(tsr, 12, tsi);
+                lds_barrier();            // role 0's weights of this panel are in LDS; panel pi - 1's value tensor is dead
+                xch_get(xch + 2048, Wp0, Wp1);
+                if (more) {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) piece1(pi + 1, X_M, k);
+                }
+                ts_cyc<DBG>(tsr, 13, tsi);
             } else {
+                auto hookA = [&](int k) { if (more) piece1(pi + 1, 0, k); };
+                auto hookC = [&](int k) {
+                    if (more && k < 7) {
+                        piece1(pi + 1, 1, k);
+                        piece1(pi + 1, 2, k);
+                    }
+                };
+                if (!(dbg & 2)) {
+                    sprod2p(pQ, r, g, sDb, c2, hookA);
+                    sprod2p(pM, r, g, sDa, c1);
+                } else {
 #pragma unroll
-                for (int k = 0; k < KT; ++k) { hookA(k); hookB(k); }
-            }
+                    for (int k = 0; k < KT; ++k) hookA(k);
+                }
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const f4 sM = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16), sQ = *reinterpret_cast<const f4*>(sg + 9 * 32 + mb * 16);
-                *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sM * inDa) + c2[mb] * (sQ * inDb);
-            }
-            ts_cyc<DBG>(tsr, 10, tsi);
-            lds_barrier();            // the S-only panels are dead
-            ts_cyc<DBG>(tsr, 11, tsi);
-            lds_barrier();
-            ts_cyc<DBG>(tsr, 12, tsi);
-            half8 W0, W1;
-            xch_get(xch + 2048, W0, W1);
-            if (!(dbg & 4)) pvprodp<2>(pMd, tr, W0, W1, O, hookC);
-            else {
+                for (int mb = 0; mb < 2; ++mb) {
+                    const f4 sM = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16), sQ = *reinterpret_cast<const f4*>(sg + 9 * 32 + mb * 16);
+                    *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sM * inDa) + c2[mb] * (sQ * inDb);
+                }
+                ts_cyc<DBG>(tsr, 10, tsi);
+                lds_barrier();            // the S-only panels are dead
+                ts_cyc<DBG>(tsr, 11, tsi);
+                lds_barrier();
+                ts_cyc<DBG>(tsr, 12, tsi);
+                half8 W0, W1;
+                xch_get(xch + 2048, W0, W1);
+                if (!(dbg & 4)) pvprodp<2>(pMd, tr, W0, W1, O, hookC);
+                else {
 #pragma unroll
-                for (int k = 0; k < KT; ++k) hookC(k);
+                    for (int k = 0; k < KT; ++k) hookC(k);
+                }
+                ts_cyc<DBG>(tsr, 13, tsi);
             }
-            ts_cyc<DBG>(tsr, 13, tsi);
+        }
+        if constexpr (SAME) {        // the last panel's PV product (its value tensor is still in its slot)
+            if (np > 0 && !(dbg & 4)) pvprodp<2>(sweep_slot<SAME, NT, X_Q, X_DQ>(smem, np - 1, X_MD), tr, Wp0, Wp1, O);
         }
         __syncthreads();
         if (dbg & 8) return;
@@ -2125,6 +2244,7 @@ static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backwar
     MMB_REQUIRE(d && n >= 1 && n <= MAXG, "bidaf group: 1..%d attentions per call", MAXG);
     memset(&ga, 0, sizeof(ga));
     ga.n = n; ga.B = B; ga.D = D; ga.dbg = att_dbg(); ga.ts = (ga.dbg & 4096) ? g_att_ts : nullptr;
+    ga.scr = (ga.dbg & 8192) ? reinterpret_cast<char*>(g_att_ts) : nullptr;
     ga.dbg &= ~4096;
     const bool drop = d[0].text_d != nullptr;
     for (int k = 0; k < n; ++k) {

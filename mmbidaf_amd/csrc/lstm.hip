@@ -85,6 +85,7 @@ struct RecFwdProb {
     float* h_n;            // (2,B,H), or (B,2,H) rows hn_pos[b] when hn_pos is given
     float* c_n;            // (2,B,H)
     const int* hn_pos;     // (B) or null
+    char* dbg_planes;      // timing experiment only (DBG & 4, tools/lstm_bench.py variant 5): where h is ALSO written as fp16 planes
     int B, T, H, wg_begin;
 };
 struct RecFwdArgs {
@@ -92,7 +93,9 @@ struct RecFwdArgs {
     int n;
 };
 
-// DBG (timing-only ablations, never used by the product path): 1 = skip the per-step global stores, 2 = skip the gx loads
+// DBG (timing-only ablations, never used by the product path): 1 = skip the per-step global stores, 2 = skip the gx loads,
+// 4 = ALSO write h as the two fp16 planes (fixed scale 2^13, |h| < 1) of the next layer's projection operand, in the tiled
+//     layout of planes.hip (what the producer-written planes cost the recurrence)
 template <int KQ, int PFD = PF, int DBG = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_rec_fwd_kernel(const RecFwdArgs args) {
     constexpr int KQP = (KQ + 3) & ~3;
@@ -149,6 +152,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int st_off = t0 * 2 * H + dir * H + u;
     float* hw0 = &hbuf[0][u / KQ][u % KQ];                  // h_t slot of this unit (buffer 0)
     const int hstride = 4 * KQP;
+    // (DBG & 4) planes row of (b, t) and the constant part of this lane's byte offset: K tile, element, plane (kq 2 -> h0, 3 -> h1)
+    int prow = b * T + t0;
+    const int pcol = dir * H + u, psl = (pcol >> 3) & 3;
+    const int pc_off = (pcol >> 5) * 2048 + (pcol & 7) * 2 + (kq & 1) * 1024;
 
     float c2 = 0.f, c = 0.f, h = 0.f;     // c2 = 2 log2(e) c: the cell state as the exponent of its own tanh
     const bool is_tanh = kq == 2;
@@ -212,6 +219,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (!(DBG & 1)) {
             gates_b[g_off] = fmaf(act_mul, sg, -act_sub);      // the activation itself (tanh for the g gate): off the chain
             st_base[st_off] = (kq & 1) ? c : h;
+        }
+        if (DBG & 4) {
+            const int rl = prow & 15;
+            const size_t off = (size_t)(prow >> 4) * (7 * 2048) + pc_off + rl * 64 + ((psl ^ (((rl >> 3) & 1) << 1)) << 4);
+            const float hs = h * 8192.0f;
+            const _Float16 h0 = (_Float16)hs, h1 = (_Float16)(hs - (float)h0);
+            if (kq >= 2) *reinterpret_cast<_Float16*>(P.dbg_planes + off) = (kq & 1) ? h1 : h0;
+            prow += sgn;
         }
         g_off += g_step;
         st_off += s_step;
@@ -952,6 +967,16 @@ extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int devic
                 case 2: return launch_rec(lstm_rec_fwd_kernel<25, 8, 1>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
                 case 3: return launch_rec(lstm_rec_fwd_kernel<25, 8, 2>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
                 case 4: return launch_rec(lstm_rec_fwd_kernel<25, 8, 3>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+                case 5: {   // product kernel + h written as planes too (into a scratch buffer of the library's own; tools only)
+                    static char* scratch = nullptr;
+                    const size_t per = (size_t)64 << 20;
+                    if (!scratch) MMB_HIP(hipMalloc(&scratch, per * MMB_MAX_GROUP));
+                    for (int i = 0; i < n; ++i) {
+                        MMB_REQUIRE((size_t)(((long)d[i].B * d[i].T + 15) / 16) * 7 * 2048 <= per && 2 * H <= 224, "variant 5: problem too large");
+                        ra.p[i].dbg_planes = scratch + per * i;
+                    }
+                    return launch_rec(lstm_rec_fwd_kernel<25, PF, 4>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+                }
                 default: return launch_rec(lstm_rec_fwd_kernel<25>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
             }
         }

@@ -55,7 +55,11 @@ def main():
         outs = MF.bidaf_attention_group(probs)
         torch.autograd.backward(outs, cots)
     table = {}
+    scratch = None
     for mask in [int(x) for x in a.masks.split(",")]:
+        if mask & 8192 and scratch is None:      # att_row also writes its output as fp16 planes (timing experiment): 2 x 48 MB
+            scratch = torch.empty(96 << 20, dtype=torch.uint8, device=dev)
+            lib.mmb_set_att_timestamps(scratch.data_ptr())
         lib.mmb_set_att_debug(mask)
         for _ in range(3):
             step()
@@ -67,6 +71,7 @@ def main():
         _lib.profile_enable([])
         table[mask] = {k: _lib.profile_read(k) for k in KERNELS}
     lib.mmb_set_att_debug(0)
+    lib.mmb_set_att_timestamps(None)
     print(f"\nB={B} T={T} Ms={Ms} D={D} drop={a.drop}: us per grouped launch by ablation mask "
           f"(2 no S products, 4 no PV products, 8 no epilogue, 16 no panel loop)")
     print(f"{'kernel':14s}" + "".join(f"{m:>9d}" for m in table))
