@@ -565,6 +565,13 @@ __device__ __forceinline__ bool decode_local_sm(int id, int tiles, int B, int& t
 // seven steps at cfg4's 50 panels per workgroup (2-6e-4 errors in d_mod of a few 64-row tiles, tools/diag_determinism.py).
 __device__ __forceinline__ void dma_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// a pointer the caller knows to be wave-uniform, moved into SGPRs
+__device__ __forceinline__ const char* sgpr_ptr(const char* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
 // stage one 32-row panel with all NWV waves of the workgroup (28 LDS-DMA pieces of 1 KiB)
 template <int NWV>
 __device__ __forceinline__ void stage_panel_w(char* panel, const char* planes_b, int p0, int wave_, int lane) {
@@ -1409,18 +1416,32 @@ constexpr int RING_NS = 5;
 // strength-reduced into one induction variable PER fragment read (52 VGPRs in a PV product, all spilled) instead of one base +
 // immediate offsets.
 //   4 tensors per panel (training mode): the modulo ring described above.
-//   3 tensors per panel (round 4): FIXED slots -- 0: the S-only tensor (x = XS); 1 + parity(pn): the tensor role 0's PV product
-//   reads (x = XR0); 3 + parity(pn): the tensor role 1's PV product reads (x = XR1) -- because role 1 now runs the PV product of
-//   panel p - 1 under role 0's tile arithmetic of panel p (see sweep_j_body), so its value tensor lives one iteration longer.
+//   3 tensors per panel (round 4): role 1 runs the PV product of panel p - 1 under role 0's tile arithmetic of panel p (see
+//   sweep_j_body), so its value tensor (x = XR1) lives one iteration longer: slots 1 + parity(pn) for the tensor role 0's PV
+//   product reads (x = XR0); the three others rotate: XR1 of panel pn in F[pn % 3], the S-only tensor (x = XS) in
+//   F[(pn + 1) % 3] -- XR1 of panel p + 1 takes over the slot of panel p's S-only tensor (dead behind the first middle barrier of
+//   iteration p), the S-only tensor of panel p + 1 the slot of panel p - 1's XR1 (dead behind the second).
 template <bool SAME, int NT, int XS, int XR0>
 __device__ __forceinline__ char* sweep_slot(char* smem, int pn, int x) {
     int idx;
-    if constexpr (SAME) idx = x == XS ? 0 : (x == XR0 ? 1 + (pn & 1) : 3 + (pn & 1));
-    else idx = (pn * NT + x) % RING_NS;
+    if constexpr (SAME) {
+        const int f = (pn + (x == XS ? 1 : 0)) % 3;
+        idx = x == XR0 ? 1 + (pn & 1) : (f == 0 ? 0 : 2 + f);
+    } else {
+        idx = (pn * NT + x) % RING_NS;
+    }
     int off = idx * PANEL_B;
     asm volatile("" : "+s"(off));
     return smem + off;
 }
+// barriers of the 3-tensor schedule: the top barrier of a role-1 wave leaves its 7 newest LDS-DMA pieces in flight (the S-only
+// tensor of the panel it is about to start, needed only by its SECOND S-type product); the barrier between the two S-type
+// products waits for them (7 newer pieces -- the next panel's -- are in flight by then when there is a next panel).  vmcnt
+// retires in order, so "at most 7 outstanding" implies everything older than the 7 newest has landed.
+__device__ __forceinline__ void dma_sync_keep7() { asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void vm_keep7_barrier() { asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void vm0_barrier() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void plain_barrier() { asm volatile("s_barrier" ::: "memory"); }
 constexpr int SWEEP_SC_OFF = RING_NS * PANEL_B;          // per-row scalars [10][32] floats
 constexpr int SWEEP_XCH_OFF = SWEEP_SC_OFF + 10 * 32 * 4;
 constexpr int SWEEP_RED_OFF = SWEEP_XCH_OFF + 4 * XCH_PAIR;
@@ -1479,9 +1500,14 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         wg_allmax_w<4, 8>(im, red, tid);
     };
     // per-row scalars of streamed text row t, fetched one panel ahead by thread (k = tid >> 5, rr = tid & 31)
+    // 4 tensors: thread (k = tid >> 5 < 9, rr = tid & 31) fetches scalar k.  3 tensors (text_d = text): the 8 distinct scalars are
+    // fetched by the 8 half-waves of ROLE 0 alone (scalar 5 also fills slot 6), so that the role-1 waves -- the ones with LDS-DMA
+    // in flight across the top barrier -- have no vector-memory load of their own in the loop (and no reload of its descriptor).
     const int sck = tid >> 5, scr = tid & 31;
+    const int skind = SAME ? (sck < 6 ? sck : sck + 1) : sck;
+    const int sdup = (SAME && sck == 5) ? 6 : -1;
     RowScalar rs{nullptr, 1, 0.f, 0};
-    switch (sck) {
+    switch (skind) {
         case 0: rs.p = A.rterm + (size_t)b * T; break;
         case 1: rs.p = A.row_stat + (size_t)b * T * 2; rs.stride = 2; rs.dflt = INFINITY; break;          // exp(x - inf) = 0 beyond the range
         case 2: rs.p = A.row_stat + (size_t)b * T * 2 + 1; rs.stride = 2; rs.dflt = INFINITY; rs.op = 1; break;
@@ -1513,12 +1539,16 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     // product <- tensor 0, second <- tensor 1 (NT = 3), PV product <- the rest.  vmcnt counts in issue order, so a wave with
     // DMA in flight would stall at its next scratch reload: role 0 never issues DMA inside the loop.
     const int w4u = __builtin_amdgcn_readfirstlane(w4);
+    const unsigned lane16 = lane * 16;
     const bool nodma = DBG == 2 && (a.dbg & 1);        // timing only (with the time stamps): no LDS-DMA inside the loop
     auto piece1 = [&](int pn, int x, int k) {          // piece w4 + 4 k (k = 0..6) of tensor x of panel pn
         if (nodma) return;
         const int piece = w4u + 4 * k;
+        // uniform base forced into SGPRs + one 32-bit per-lane offset: the DMA address costs the loop ONE vector register for all
+        // tensors (as 64-bit per-lane pointers they were three register pairs, spilled and reloaded in front of every piece)
+        const char* ub = sgpr_ptr(src[x] + (size_t)((pn * PR) >> 4) * PRB + piece * 1024);
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src[x] + (size_t)((pn * PR) >> 4) * PRB + lane * 16 + piece * 1024),
+            (const __attribute__((address_space(1))) void*)(ub + lane16),
             (__attribute__((address_space(3))) void*)(sweep_slot<SAME, NT, X_DB, X_TD>(smem, pn, x) + piece * 1024), 16, 0, 0);
     };
 
@@ -1537,7 +1567,8 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         const bool mm = nin ? mask_live(A.mod_mask, A.mod_len, b, M, n) : false;
         const float mmf = mm ? 1.f : 0.f;
         unsigned sc_next = 0u;
-        if (np > 0 && sck < NSC) sc_next = fetch(scr);
+        const bool f_on = SAME ? true : sck < NSC;       // (role 0: half-waves 0..7)
+        if (np > 0 && f_on) sc_next = fetch(scr);
         maxima();             // every load of the prologue is in flight by now: ONE round trip to memory, not one per stage
         const float cDa = cmap(im[2]);
         // |dS_ij| <= |dP1| + |delta1| + |dP2| + |delta2| <= 2 D 2^28 (inv_da_i inv_mod_j + inv_db_i inv_q_j + inv_t_i inv_dq_j)
@@ -1550,21 +1581,27 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         for (int pi = 0; pi < np; ++pi) {
             const bool tsi = pi == 1;
             ts_cyc<DBG>(tsr, 8, tsi);
-            if (sck < NSC) sc[sck * 32 + scr] = row_scalar_value(rs, sc_next, pi * PR + scr, IS_J ? T : M);
+            if (f_on) {
+                const float sv = row_scalar_value(rs, sc_next, pi * PR + scr, IS_J ? T : M);
+                sc[skind * 32 + scr] = sv;
+                if (sdup >= 0) {
+                    sc[sdup * 32 + scr] = sv;
+                    if (!IS_J) sc[(sdup + 1) * 32 + scr] = sv;
+                }
+            }
             dma_sync();               // this panel's DMA has landed, its scalars are visible
             issue_top(pi);
             if (NT == 4 && pi > 0) dma_sync();
-            if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            if (pi + 1 < np && f_on) sc_next = fetch((pi + 1) * PR + scr);
             ts_cyc<DBG>(tsr, 9, tsi);
             const char* pTd = sweep_slot<SAME, NT, X_DB, X_TD>(smem, pi, X_TD);
             const char* pT = sweep_slot<SAME, NT, X_DB, X_TD>(smem, pi, X_T);
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
-            if (!(dbg & 2)) {
-                sprod2p(pTd, r, g, sS, c1);
-                sprod2p(pT, r, g, sDq, c2);
-            }
+            if (!(dbg & 2)) sprod2p(pTd, r, g, sS, c1);
+            if (SAME) plain_barrier();      // (3-tensor schedule: the role-1 waves' rendezvous between their S-type products)
+            if (!(dbg & 2)) sprod2p(pT, r, g, sDq, c2);
             ts_cyc<DBG>(tsr, 10, tsi);
             lds_barrier();            // role 1's dP1 is in LDS
             ts_cyc<DBG>(tsr, 11, tsi);
@@ -1614,7 +1651,8 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         load_side_planes(sM, inM, A.pM + (size_t)b * szM, A.iM + (size_t)b * Mp, n, M, g);
         load_side_planes(sQ, inQ, A.pQ + (size_t)b * szM, A.iQ + (size_t)b * Mp, n, M, g);
         unsigned sc_next = 0u;
-        if (np > 0 && sck < NSC) sc_next = fetch(scr);
+        const bool f_on = SAME ? false : sck < NSC;      // (role 1: half-waves 8..15)
+        if (np > 0 && f_on) sc_next = fetch(scr);
         maxima();
         const float cDa = cmap(im[2]);
         acc_t O;        // dmodc = sum_i P1 da
@@ -1624,11 +1662,19 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         for (int pi = 0; pi < np; ++pi) {
             const bool tsi = pi == 1;
             ts_cyc<DBG>(tsr, 8, tsi);
-            if (sck < NSC) sc[sck * 32 + scr] = row_scalar_value(rs, sc_next, pi * PR + scr, IS_J ? T : M);
-            dma_sync();
+            if (f_on) {
+                const float sv = row_scalar_value(rs, sc_next, pi * PR + scr, IS_J ? T : M);
+                sc[skind * 32 + scr] = sv;
+                if (sdup >= 0) {
+                    sc[sdup * 32 + scr] = sv;
+                    if (!IS_J) sc[(sdup + 1) * 32 + scr] = sv;
+                }
+            }
+            if (SAME && pi > 0) dma_sync_keep7();     // 3 tensors: this panel's S-only tensor (the 7 newest pieces) may still be in flight
+            else dma_sync();
             issue_top(pi);
             if (NT == 4 && pi > 0) dma_sync();
-            if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            if (pi + 1 < np && f_on) sc_next = fetch((pi + 1) * PR + scr);
             ts_cyc<DBG>(tsr, 9, tsi);
             const char* pDa = sweep_slot<SAME, NT, X_DB, X_TD>(smem, pi, X_DA);
             const char* pDb = sweep_slot<SAME, NT, X_DB, X_TD>(smem, pi, X_DB);
@@ -1646,14 +1692,15 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
                 // S-only tensor (free behind the first middle barrier) in the PV product, role 1's own value tensor (the slot
                 // of panel pi - 1's, free behind the second) is issued at once behind that barrier.
                 auto hookA = [&](int k) { if (more) piece1(pi + 1, X_TD, k); };
-                auto hookC = [&](int k) { if (more && k < 7) piece1(pi + 1, X_DB, k); };
-                if (!(dbg & 2)) {
-                    sprod2p(pDb, r, g, sQ, c2, hookA);
-                    sprod2p(pDa, r, g, sM, c1);
-                } else {
+                auto hookC = [&](int k) { if (more && k < 7) piece1(pi + 1, X_DA, k); };
+                if (!(dbg & 2)) sprod2p(pDa, r, g, sM, c1, hookA);
+                else {
 #pragma unroll
                     for (int k = 0; k < KT; ++k) hookA(k);
                 }
+                if (more) vm_keep7_barrier();      // the S-only tensor of THIS panel (issued behind the last barrier of the
+                else vm0_barrier();                //  previous iteration) has landed in every role-1 wave
+                if (!(dbg & 2)) sprod2p(pDb, r, g, sQ, c2);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
                     const f4 sDa = *reinterpret_cast<const f4*>(sg + 7 * 32 + mb * 16), sDb = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16);
@@ -1673,7 +1720,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
                 xch_get(xch + 2048, Wp0, Wp1);
                 if (more) {
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) piece1(pi + 1, X_DA, k);
+                    for (int k = 0; k < 7; ++k) piece1(pi + 1, X_DB, k);
                 }
                 ts_cyc<DBG>(tsr, 13, tsi);
             } else {
@@ -1826,9 +1873,12 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         cS = cmap_bound(im[1], 1.3743895e11f /* 2^37 */ * (inDa * im[0] + inDb * im[2] + im[3] * inT));   // the same value in both roles
     };
 
+    // (as in the j sweep; 3 tensors: half-wave 5 of role 0 fetches the mod scale for slots 5, 7 and 8, 6 the dq scale, 7 the q scale)
     const int sck = tid >> 5, scr = tid & 31;
+    const int skind = SAME ? (sck < 7 ? sck : 9) : sck;
+    const int sdup = (SAME && sck == 5) ? 7 : -1;
     RowScalar rs{nullptr, 1, 0.f, 0};
-    switch (sck) {
+    switch (skind) {
         case 0: rs.p = A.cterm + (size_t)b * M; break;
         case 1: rs.p = A.col_stat + (size_t)b * M * 2; rs.stride = 2; break;
         case 2: rs.p = A.col_stat + (size_t)b * M * 2 + 1; rs.stride = 2; rs.dflt = INFINITY; rs.op = 1; break;
@@ -1860,12 +1910,16 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     // product <- tensor 0, second <- tensor 1 (NT = 3), PV product <- the rest.  vmcnt counts in issue order, so a wave with
     // DMA in flight would stall at its next scratch reload: role 0 never issues DMA inside the loop.
     const int w4u = __builtin_amdgcn_readfirstlane(w4);
+    const unsigned lane16 = lane * 16;
     const bool nodma = DBG == 2 && (a.dbg & 1);        // timing only (with the time stamps): no LDS-DMA inside the loop
     auto piece1 = [&](int pn, int x, int k) {          // piece w4 + 4 k (k = 0..6) of tensor x of panel pn
         if (nodma) return;
         const int piece = w4u + 4 * k;
+        // uniform base forced into SGPRs + one 32-bit per-lane offset: the DMA address costs the loop ONE vector register for all
+        // tensors (as 64-bit per-lane pointers they were three register pairs, spilled and reloaded in front of every piece)
+        const char* ub = sgpr_ptr(src[x] + (size_t)((pn * PR) >> 4) * PRB + piece * 1024);
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src[x] + (size_t)((pn * PR) >> 4) * PRB + lane * 16 + piece * 1024),
+            (const __attribute__((address_space(1))) void*)(ub + lane16),
             (__attribute__((address_space(3))) void*)(sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pn, x) + piece * 1024), 16, 0, 0);
     };
 
@@ -1884,7 +1938,8 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         const bool tm = nin ? mask_live(A.text_mask, A.text_len, b, T, n) : false;
         const float tmf = tm ? 1.f : 0.f;
         unsigned sc_next = 0u;
-        if (np > 0 && sck < NSC) sc_next = fetch(scr);
+        const bool f_on = SAME ? true : sck < NSC;       // (role 0: half-waves 0..7)
+        if (np > 0 && f_on) sc_next = fetch(scr);
         maxima();             // every load of the prologue is in flight by now
         acc_t O;        // sum_j P2 dq
         zero_acc(O);
@@ -1894,21 +1949,27 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         for (int pi = 0; pi < np; ++pi) {
             const bool tsi = pi == 1;
             ts_cyc<DBG>(tsr, 8, tsi);
-            if (sck < NSC) sc[sck * 32 + scr] = row_scalar_value(rs, sc_next, pi * PR + scr, IS_J ? T : M);
+            if (f_on) {
+                const float sv = row_scalar_value(rs, sc_next, pi * PR + scr, IS_J ? T : M);
+                sc[skind * 32 + scr] = sv;
+                if (sdup >= 0) {
+                    sc[sdup * 32 + scr] = sv;
+                    if (!IS_J) sc[(sdup + 1) * 32 + scr] = sv;
+                }
+            }
             dma_sync();               // this panel's DMA has landed, its scalars are visible
             issue_top(pi);
             if (NT == 4 && pi > 0) dma_sync();
-            if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            if (pi + 1 < np && f_on) sc_next = fetch((pi + 1) * PR + scr);
             ts_cyc<DBG>(tsr, 9, tsi);
             const char* pMd = sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, X_MD);
             const char* pDq = sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, X_DQ);
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
-            if (!(dbg & 2)) {
-                sprod2p(pMd, r, g, sS, c1);
-                sprod2p(pDq, r, g, sT, c2);
-            }
+            if (!(dbg & 2)) sprod2p(pMd, r, g, sS, c1);
+            if (SAME) plain_barrier();      // (3-tensor schedule: the role-1 waves' rendezvous between their S-type products)
+            if (!(dbg & 2)) sprod2p(pDq, r, g, sT, c2);
             ts_cyc<DBG>(tsr, 10, tsi);
             lds_barrier();            // role 1's dP1 is in LDS
             ts_cyc<DBG>(tsr, 11, tsi);
@@ -1960,7 +2021,8 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         load_side_planes(sDb, iDb_, A.pDb + (size_t)b * szT, A.iDb + (size_t)b * Tp, n, T, g);
         }
         unsigned sc_next = 0u;
-        if (np > 0 && sck < NSC) sc_next = fetch(scr);
+        const bool f_on = SAME ? false : sck < NSC;      // (role 1: half-waves 8..15)
+        if (np > 0 && f_on) sc_next = fetch(scr);
         maxima();
         acc_t O;        // dX = sum_j dS mod_d
         zero_acc(O);
@@ -1969,11 +2031,19 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         for (int pi = 0; pi < np; ++pi) {
             const bool tsi = pi == 1;
             ts_cyc<DBG>(tsr, 8, tsi);
-            if (sck < NSC) sc[sck * 32 + scr] = row_scalar_value(rs, sc_next, pi * PR + scr, IS_J ? T : M);
-            dma_sync();
+            if (f_on) {
+                const float sv = row_scalar_value(rs, sc_next, pi * PR + scr, IS_J ? T : M);
+                sc[skind * 32 + scr] = sv;
+                if (sdup >= 0) {
+                    sc[sdup * 32 + scr] = sv;
+                    if (!IS_J) sc[(sdup + 1) * 32 + scr] = sv;
+                }
+            }
+            if (SAME && pi > 0) dma_sync_keep7();     // 3 tensors: this panel's S-only tensor (the 7 newest pieces) may still be in flight
+            else dma_sync();
             issue_top(pi);
             if (NT == 4 && pi > 0) dma_sync();
-            if (pi + 1 < np && sck < NSC) sc_next = fetch((pi + 1) * PR + scr);
+            if (pi + 1 < np && f_on) sc_next = fetch((pi + 1) * PR + scr);
             ts_cyc<DBG>(tsr, 9, tsi);
             const char* pM = sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, X_M);
             const char* pQ = sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, X_Q);
@@ -1985,14 +2055,15 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
             if constexpr (SAME) {
                 // 3-tensor schedule of round 4 (see sweep_j_body): the PV product of panel pi - 1 between the middle barriers
                 auto hookA = [&](int k) { if (more) piece1(pi + 1, X_DQ, k); };
-                auto hookC = [&](int k) { if (more && k < 7) piece1(pi + 1, X_Q, k); };
-                if (!(dbg & 2)) {
-                    sprod2p(pQ, r, g, sDb, c2, hookA);
-                    sprod2p(pM, r, g, sDa, c1);
-                } else {
+                auto hookC = [&](int k) { if (more && k < 7) piece1(pi + 1, X_M, k); };
+                if (!(dbg & 2)) sprod2p(pM, r, g, sDa, c1, hookA);
+                else {
 #pragma unroll
                     for (int k = 0; k < KT; ++k) hookA(k);
                 }
+                if (more) vm_keep7_barrier();      // this panel's S-only tensor has landed in every role-1 wave
+                else vm0_barrier();
+                if (!(dbg & 2)) sprod2p(pQ, r, g, sDb, c2);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
                     const f4 sM = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16), sQ = *reinterpret_cast<const f4*>(sg + 9 * 32 + mb * 16);
@@ -2012,7 +2083,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
                 xch_get(xch + 2048, Wp0, Wp1);
                 if (more) {
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) piece1(pi + 1, X_M, k);
+                    for (int k = 0; k < 7; ++k) piece1(pi + 1, X_Q, k);
                 }
                 ts_cyc<DBG>(tsr, 13, tsi);
             } else {
