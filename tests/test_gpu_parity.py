@@ -6,6 +6,7 @@ B*T terms such as weight gradients grow with the problem size)."""
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -1946,3 +1947,64 @@ def test_region_step_repeats_bit_for_bit_at_cfg4_size():
             assert torch.equal(a, b), f"run {it}: tensor {k} differs from the first run by {(a - b).abs().max().item():.3e}"
         for n in grads:
             close(grads[n], first_g[n].cpu(), f"repeat grad {n}", tol=1e-5)
+
+
+@pytest.mark.parametrize("drop", [False, True])
+def test_attention_phase_stamp_build_matches_the_product_kernels(drop):
+    """The time-stamped instantiation of the four loop kernels (mmb_set_att_debug(4096) + mmb_set_att_timestamps,
+    tools/att_phases.py) ablates nothing: outputs and gradients equal the product kernels' bit for bit (sums of atomics: to
+    round-off), and the stamps it leaves are ordered.  Shapes with several panels per workgroup and both sweeps' roles."""
+    from mmbidaf_amd import _lib, functional as MF
+    d = dev()
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(77 + int(drop))
+    B, T, D = 8, 200, 200
+    Ms = [96, 40]
+    text0 = torch.randn(B, T, D, generator=g)
+    mods0 = [torch.randn(B, m, D, generator=g) for m in Ms]
+    params0 = [[torch.randn(D, 1, generator=g) * 0.1, torch.randn(D, 1, generator=g) * 0.1, torch.randn(1, 1, D, generator=g) * 0.1,
+                torch.randn(1, generator=g) * 0.1] for _ in Ms]
+    cots = [torch.randn(B, T, 4 * D, generator=g).to(d) for _ in Ms]
+    keep = lambda *sh: (torch.rand(*sh, generator=g) > 0.2).float() / 0.8
+    kt, km = [keep(B, T, D).to(d) for _ in Ms], [keep(B, m, D).to(d) for m in Ms]
+    tl = torch.tensor([T, T - 3, 150, 97, T, 64, 33, 1], dtype=torch.int32, device=d)
+    mls = [torch.tensor([m, m - 1, max(1, m // 2), m, 7, m, 1, m], dtype=torch.int32, device=d) for m in Ms]
+
+    def run():
+        text = text0.clone().to(d).requires_grad_(True)
+        mods = [m.clone().to(d).requires_grad_(True) for m in mods0]
+        ps = [[p_.clone().to(d).requires_grad_(True) for p_ in pk] for pk in params0]
+        tm = MF.PrefixMask(tl.tolist(), T, tl)
+        probs = []
+        for k, M in enumerate(Ms):
+            mm = MF.PrefixMask(mls[k].tolist(), M, mls[k])
+            drops = (text * kt[k], mods[k] * km[k]) if drop else (None, None)
+            probs.append((text, mods[k], tm, mm, *ps[k], *drops))
+        outs = MF.bidaf_attention_group(probs)
+        torch.autograd.backward(outs, cots)
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in outs], [text.grad.clone()] + [m.grad.clone() for m in mods], [[p_.grad.clone() for p_ in pk[:3]] for pk in ps]
+
+    ref = run()
+    nbytes = lib.mmb_set_att_timestamps(None)
+    buf = torch.zeros(nbytes // 8, dtype=torch.int64, device=d)
+    lib.mmb_set_att_timestamps(buf.data_ptr())
+    lib.mmb_set_att_debug(4096)
+    try:
+        got = run()
+    finally:
+        lib.mmb_set_att_debug(0)
+        lib.mmb_set_att_timestamps(None)
+    for k in range(len(Ms)):
+        assert torch.equal(got[0][k], ref[0][k]), f"out {k} differs in the stamped build"
+    for k, (a_, b_) in enumerate(zip(got[1], ref[1])):
+        assert torch.equal(a_, b_), f"input gradient {k} differs in the stamped build"
+    for k in range(len(Ms)):
+        for n, a_, b_ in zip(("w_t", "w_m", "w_tm"), got[2][k], ref[2][k]):
+            close(a_, b_.cpu(), f"stamped build d_{n} {k}")          # sums of atomics
+    ts = buf.cpu().numpy().reshape(4, -1, nbytes // 8 // 4 // 2048)
+    for kern, nph in ((0, 4), (1, 3), (2, 4), (3, 4)):
+        live = ts[kern][:, 0] > 0
+        assert live.any(), f"kernel {kern} left no stamps"
+        ph = ts[kern][live][:, :nph + 1]
+        assert (np.diff(ph, axis=1) >= 0).all(), f"kernel {kern}: phase stamps out of order"
