@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMB_VERSION 402            /* round 4 ABI: + persistent-recurrence reset / enable, mmb_stream_occupy, attention phase stamps */
+#define MMB_VERSION 403            /* round 4 ABI: + persistent-recurrence reset / enable, mmb_stream_occupy, attention phase stamps, mmb_masked_mul / _sum */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
 #define MMB_ATT_MAX_D 208          /* attention feature width D = 2H of the fused (register-resident) kernels */
 #define MMB_ATT_GENERAL_MAX_D 4096 /* wider D (up to this) runs the general path: similarity matrix in a workspace */
@@ -272,6 +272,28 @@ size_t mmb_weighted_sums_ws_bytes(const long* n, int k);
 int mmb_weighted_sums_fwd(const float* const* x, const float* const* w, const long* n, int k, float* out,
                           void* ws, size_t ws_bytes, int device, void* stream);
 int mmb_weighted_sums_bwd(const float* g, const float* const* w, float* const* dx, const long* n, int k, int device, void* stream);
+
+/* Dropout masks applied in ONE launch for up to MMB_MASK_MAX tensors: dst_k = a_k * m_k (accumulate = 0) or dst_k += a_k * m_k
+ * (accumulate != 0), n[k] floats each; all pointers 16-byte aligned; dst_k may alias a_k.  Replaces the products of the
+ * reference's F.dropout calls (layers/encoding.py:81,104, layers/attention.py:66-67) with masks the host has drawn with torch's
+ * generator (the dropout decisions stay torch's; only the multiplications are fused per stage). */
+#define MMB_MASK_MAX 8
+int mmb_masked_mul(const float* const* a, const float* const* m, float* const* dst, const long* n, int k, int accumulate,
+                   int device, void* stream);
+/* dst = (sum_{t < nterms} x[t] * m[t]) * mo for up to MMB_MASK_MAX tensors in one launch; m[t] / mo NULL = 1; dst may alias an
+ * x[t].  The cotangents the attention's backward hands to the input encoders (models.py:131-132 feed one text tensor to both
+ * attentions, attention.py:66-67 drops it once more for the similarity): their sum, the dropped copies' terms through their masks
+ * and the encoder's output-dropout mask in one pass. */
+#define MMB_MASK_TERMS 4
+typedef struct {
+    float* dst;
+    const float* x[MMB_MASK_TERMS];
+    const float* m[MMB_MASK_TERMS];
+    const float* mo;
+    long n;
+    int nterms;
+} mmb_masked_sum_desc;
+int mmb_masked_sum(const mmb_masked_sum_desc* d, int k, int device, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Decoder step.  Replaces MultimodalAttentionDecoder.forward (reference

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 SOURCES = ["api.hip", "gemm.hip", "gemm_bf16.hip", "planes.hip", "lstm.hip", "lstm_big.hip", "lstm_fs.hip", "bidaf.hip", "bidaf_big.hip",
-           "decoder.hip", "highway.hip", "loss.hip"]
+           "decoder.hip", "highway.hip", "loss.hip", "masks.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "mmbidaf.h")]
 LIB = os.path.join(_HERE, "libmmbidaf_hip.so")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-result"]

@@ -287,6 +287,20 @@ def _drop_conf(R):
 _ones = {}
 
 
+def _masked_mul(lib, di, stream, a_list, m_list, dst_list=None, accumulate=False):
+    """dst_k = a_k * m_k (new tensors when dst_list is None) or dst_k += a_k * m_k for a stage's tensors in ONE launch
+    (mmb_masked_mul: the products of the reference's F.dropout calls with masks torch has drawn)."""
+    k = len(a_list)
+    if dst_list is None:
+        dst_list = [torch.empty_like(a) for a in a_list]
+    ap = (ctypes.c_void_p * k)(*[a.data_ptr() for a in a_list])
+    mp = (ctypes.c_void_p * k)(*[m.data_ptr() for m in m_list])
+    dp = (ctypes.c_void_p * k)(*[d.data_ptr() for d in dst_list])
+    np_ = (ctypes.c_long * k)(*[a.numel() for a in a_list])
+    _lib.check(lib.mmb_masked_mul(ap, mp, dp, np_, k, 1 if accumulate else 0, di, stream), "mmb_masked_mul")
+    return dst_list
+
+
 def _ones_flat(total, dev):
     key = (dev.index, total)
     o = _ones.get(key)
@@ -566,11 +580,11 @@ class _RegionFn(torch.autograd.Function):
         att_d = (None, None, None, None)
         if drop:
             ys = [view(ko["et.y"], (B, T, D)), view(ko["ea.y"], (B, Ma, D)), view(ko["ei.y"], (B, Mi, D))]
-            yd = torch._foreach_mul(ys, [masks["out_et"], masks["out_ea"], masks["out_ei"]])
+            yd = _masked_mul(lib, di, stream, ys, [masks["out_et"], masks["out_ea"], masks["out_ei"]])
             held += yd
             enc_out = (yd[0].data_ptr(), yd[1].data_ptr(), yd[2].data_ptr())
             # dropped copies seen by the similarity only (attention.py:66-67)
-            dd = torch._foreach_mul([yd[0], yd[1], yd[0], yd[2]], [masks["aa_t"], masks["aa_m"], masks["ai_t"], masks["ai_m"]])
+            dd = _masked_mul(lib, di, stream, [yd[0], yd[1], yd[0], yd[2]], [masks["aa_t"], masks["aa_m"], masks["ai_t"], masks["ai_m"]])
             held += dd
             att_d = (dd[0].data_ptr(), dd[1].data_ptr(), dd[2].data_ptr(), dd[3].data_ptr())
         # ---- the two attentions (models.py:131-132), one grouped call, shared text planes
@@ -582,14 +596,14 @@ class _RegionFn(torch.autograd.Function):
         _lib.check(lib.mmb_bilstm_layer_fwd(d_, 2, di, stream), "mmb_bilstm_layer_fwd")
         l1_in = (kb + ko["a0.y"], kb + ko["i0.y"])
         if drop:
-            y0d = torch._foreach_mul([view(ko["a0.y"], (B, T, D)), view(ko["i0.y"], (B, T, D))], [masks["inter_a"], masks["inter_i"]])
+            y0d = _masked_mul(lib, di, stream, [view(ko["a0.y"], (B, T, D)), view(ko["i0.y"], (B, T, D))], [masks["inter_a"], masks["inter_i"]])
             held += y0d
             l1_in = (y0d[0].data_ptr(), y0d[1].data_ptr())
         d_, w_ = tm["f_l1"].build(bases, pp, x0=l1_in[0], x1=l1_in[1])
         _lib.check(lib.mmb_bilstm_layer_fwd(d_, 2, di, stream), "mmb_bilstm_layer_fwd")
         mod_out = [view(ko["a1.y"], (B, T, D)), view(ko["i1.y"], (B, T, D))]
         if drop:
-            mod_out = torch._foreach_mul(mod_out, [masks["out_a"], masks["out_i"]])
+            mod_out = _masked_mul(lib, di, stream, mod_out, [masks["out_a"], masks["out_i"]])
         # ---- final hidden states (encoding.py:101-103) and the decoder's initial hidden state (models.py:143)
         hid_a = torch.empty(B, 4, H, device=dev, dtype=torch.float32)
         hid_i = torch.empty(B, 4, H, device=dev, dtype=torch.float32)
@@ -651,7 +665,7 @@ class _RegionFn(torch.autograd.Function):
             g = g.contiguous()
             if drop and mask_key is not None:
                 o = bview(bo[tag + ".d_y"], shape)
-                torch.mul(g, masks[mask_key], out=o)
+                _masked_mul(lib, di, ms, [g], [masks[mask_key]], [o])
                 return o.data_ptr(), o
             return g.data_ptr(), g
 
@@ -686,7 +700,7 @@ class _RegionFn(torch.autograd.Function):
 
         # ---- modelling encoders, layer 1 (first recurrence of the pass: every layer's operand planes are prepared beside it)
         if drop and g_mod_a is not None and g_mod_i is not None:
-            gy = torch._foreach_mul([g_mod_a.contiguous(), g_mod_i.contiguous()], [masks["out_a"], masks["out_i"]])
+            gy = _masked_mul(lib, di, ms, [g_mod_a.contiguous(), g_mod_i.contiguous()], [masks["out_a"], masks["out_i"]])
             pa, pi, ta, ti = gy[0].data_ptr(), gy[1].data_ptr(), gy[0], gy[1]
         else:
             pa, ta = cot("a1", g_mod_a, (B, T, D), "out_a")
@@ -723,7 +737,8 @@ class _RegionFn(torch.autograd.Function):
             f0 = 0
         # inter-layer dropout backward, then layer 0
         if drop:
-            torch._foreach_mul_([bview(bo["a1.d_x"], (B, T, D)), bview(bo["i1.d_x"], (B, T, D))], [masks["inter_a"], masks["inter_i"]])
+            dxs1 = [bview(bo["a1.d_x"], (B, T, D)), bview(bo["i1.d_x"], (B, T, D))]
+            _masked_mul(lib, di, ms, dxs1, [masks["inter_a"], masks["inter_i"]], dxs1)
         if two:
             main.wait_event(prepared)
             before = torch.cuda.Event()
@@ -744,15 +759,24 @@ class _RegionFn(torch.autograd.Function):
                                    text_d0=c.att_d[0], mod_d0=c.att_d[1], text_d1=c.att_d[2], mod_d1=c.att_d[3], **adyn)
         _lib.check(lib.mmb_bidaf_group_bwd(AT, 2, B, D, di, ms), "mmb_bidaf_group_bwd")
         # cotangents of the input encoders' outputs: text gets both attentions' (+ the dropped copies' through their masks)
+        # ONE pass (mmb_masked_sum): d_text = (d_text_aa + d_text_ai [+ d_text_d_aa m_aa + d_text_d_ai m_ai]) [m_out], likewise audio, image
         d_text = bview(bo["aa.d_text"], (B, T, D))
-        d_text.add_(bview(bo["ai.d_text"], (B, T, D)))
+        sd = (_lib.MaskedSumDesc * 3)()
+        nsd = 1
+        sd[0].dst = d_text.data_ptr(); sd[0].n = B * T * D
+        sd[0].x[0] = d_text.data_ptr(); sd[0].x[1] = bb + bo["ai.d_text"]; sd[0].nterms = 2
         if drop:
             d_aud, d_img = bview(bo["aa.d_mod"], (B, Ma, D)), bview(bo["ai.d_mod"], (B, Mi, D))
-            # (d_text takes a term from each attention: two launches, a tensor must not appear twice in one multi-tensor update)
-            for tag, M, dm in (("aa", Ma, d_aud), ("ai", Mi, d_img)):
-                torch._foreach_addcmul_([d_text, dm], [bview(bo[tag + ".d_text_d"], (B, T, D)), bview(bo[tag + ".d_mod_d"], (B, M, D))],
-                                        [masks[tag + "_t"], masks[tag + "_m"]])
-            torch._foreach_mul_([d_text, d_aud, d_img], [masks["out_et"], masks["out_ea"], masks["out_ei"]])
+            sd[0].x[2] = bb + bo["aa.d_text_d"]; sd[0].m[2] = masks["aa_t"].data_ptr()
+            sd[0].x[3] = bb + bo["ai.d_text_d"]; sd[0].m[3] = masks["ai_t"].data_ptr()
+            sd[0].nterms = 4; sd[0].mo = masks["out_et"].data_ptr()
+            for j, (tag, M, dm, mk, mo_) in enumerate((("aa", Ma, d_aud, "aa_m", "out_ea"), ("ai", Mi, d_img, "ai_m", "out_ei")), 1):
+                sd[j].dst = dm.data_ptr(); sd[j].n = B * M * D
+                sd[j].x[0] = dm.data_ptr(); sd[j].x[1] = bb + bo[tag + ".d_mod_d"]; sd[j].m[1] = masks[mk].data_ptr()
+                sd[j].nterms = 2; sd[j].mo = masks[mo_].data_ptr()
+            nsd = 3
+        _lib.check(lib.mmb_masked_sum(sd, nsd, di, ms), "mmb_masked_sum")
+        hold.append(sd)
         if two:
             before = torch.cuda.Event()
             before.record(main)
