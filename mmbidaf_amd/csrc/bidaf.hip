@@ -1372,7 +1372,8 @@ __global__ __launch_bounds__(256) void att_bwd_pre_kernel(const GroupArgs a) {
 // (w, w + 4: the two waves of one SIMD) owns the 16 rows and splits the PRODUCTS, not the data:
 //   role 0: similarity + dP2, then the softmax / gradient arithmetic of the tile, then one PV product;
 //   role 1: the two halves of dP1 (sent to role 0 through 2 KiB of LDS), then the other PV product with the weights
-//           role 0 sends back.
+//           role 0 sends back -- of the SAME panel behind the second middle barrier (4 tensors), or of the PREVIOUS panel
+//           between the two middle barriers, under role 0's arithmetic (3 tensors, round 4).
 // Each wave carries two lane-side operands and one accumulator set (<= 256 registers: two waves per SIMD, which is what a
 // single wave lacks here -- its instruction stream of one panel is ~8000 issue cycles for 3900 cycles of MFMA, and two waves
 // of a SIMD issue alternately), no product is computed twice, and the two roles run the SAME matrix-core instruction stream
@@ -1405,12 +1406,12 @@ constexpr int XCH_PAIR = 4096;     // per pair: [dp1: 2 x 1 KiB][weights: 2 x 1 
 // workgroup barrier that orders LDS traffic only: the LDS-DMA of the next panel stays in flight across it
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Panel ring of the gradient sweeps: NS = 5 LDS slots of one 28-KiB panel each for the NT = 3 (eval mode) or 4 (training
-// mode) tensors a sweep streams.  Piece q = (panel index) * NT + x lives in slot q % NS; tensor order x: first the tensors
-// only the S-type products read (their slots come free in the MIDDLE of an iteration), then the value tensors of the PV
-// products (free at its end).  With NT = 3 all of panel p + 1 is issued in the middle of iteration p -- two pieces into the
-// spare slots, the third into the slot the S-only tensor of panel p has just vacated -- so the LDS-DMA runs under the tile
-// arithmetic and the PV products, and the one full wait per iteration (top of the loop) finds its data landed.
+// Panel slots of the gradient sweeps: NS = 5 LDS slots of one 28-KiB panel each for the NT = 3 (eval mode / no dropped copies)
+// or 4 (training mode) tensors a sweep streams.
+//   NT = 4, the modulo ring: piece q = (panel index) * NT + x lives in slot q % NS; tensor order x: first the tensors only the
+//   S-type products read (their slots come free in the MIDDLE of an iteration), then the value tensors of the PV products (free
+//   at its end); the 4th tensor of a panel is issued just in time behind the top barrier (one exposed wait per iteration).
+//   NT = 3 (round 4): a different schedule altogether -- see sweep_slot below and the role-1 loop of sweep_j_body.
 constexpr int RING_NS = 5;
 // LDS slot of tensor x of panel pn.  opaque to the optimiser: seen as a function of the loop counter, the slot address is
 // strength-reduced into one induction variable PER fragment read (52 VGPRs in a PV product, all spilled) instead of one base +

@@ -22,9 +22,9 @@ __global__ __launch_bounds__(256) void masked_mul_kernel(const MaskMulArgs p) {
     int k = 0;
     for (int i = 1; i < p.k; ++i)
         if ((int)blockIdx.x >= p.blk_begin[i]) k = i;
-    const float* __restrict__ a = p.a[k];
-    const float* __restrict__ m = p.m[k];
-    float* __restrict__ dst = p.dst[k];
+    const float* a = p.a[k];          // (dst may alias a: no __restrict__)
+    const float* m = p.m[k];
+    float* dst = p.dst[k];
     const long n = p.n[k];
     const long base = (long)(blockIdx.x - p.blk_begin[k]) * MK_PER_BLOCK;
     if (base + MK_PER_BLOCK <= n) {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void masked_sum_kernel(const MaskSumArgs p) {
     int k = 0;
     for (int i = 1; i < p.k; ++i)
         if ((int)blockIdx.x >= p.blk_begin[i]) k = i;
-    float* __restrict__ dst = p.dst[k];
+    float* dst = p.dst[k];             // (may alias a term: no __restrict__)
     const long n = p.n[k];
     const int nt = p.nterms[k];
     const float* mo = p.mo[k];
