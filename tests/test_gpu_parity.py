@@ -187,6 +187,28 @@ def test_attention_vs_oracle(B, T, M, D, use_drop):
         close(g, p.grad, k)
 
 
+@pytest.mark.parametrize("T,M", [(1, 33), (31, 1), (32, 32), (33, 31), (64, 65), (65, 96), (97, 97), (160, 129), (129, 160)])
+def test_attention_panel_counts_of_the_pipelined_sweeps_vs_oracle(T, M):
+    """The 3-tensor gradient sweeps run role 1's PV product one panel behind, with rotating LDS slots and LDS-DMA pieces in flight
+    across the top barrier (round 4): every panel count from 1 to 5 on either side, with lengths that end inside a panel, inside a
+    16-row block and on their boundaries."""
+    B, D = 3, 200
+    c, _ = _random_att_case(7000 + 37 * T + M, B, T, M, D, False)
+    c["text_mask"] = O.get_mask(T, [T, max(1, T - 1), max(1, (2 * T) // 3)])
+    c["mod_mask"] = O.get_mask(M, [M, max(1, M // 2), max(1, M - 1)])
+    t_ = c["text"].clone().requires_grad_(True)
+    m_ = c["mod"].clone().requires_grad_(True)
+    ps = [c[k].clone().requires_grad_(True) for k in ("w_t", "w_m", "w_tm", "bias")]
+    ref = O.bidaf_attention(t_, m_, c["text_mask"], c["mod_mask"], *ps)
+    (ref * c["cot"]).sum().backward()
+    out, dt, dm, dps = _run_att(c, None)
+    close(out, ref, "out")
+    close(dt, t_.grad, "d_text")
+    close(dm, m_.grad, "d_mod")
+    for k, g, p in zip(("d_w_t", "d_w_m", "d_w_tm"), dps, ps):
+        close(g, p.grad, k)
+
+
 @pytest.mark.parametrize("B,T,M,D,use_drop", [(2, 37, 29, 212, False), (3, 50, 70, 256, True), (2, 9, 300, 512, False),
                                               (1, 70, 5, 1024, True), (2, 400, 256, 1024, False)])
 def test_attention_general_width_vs_oracle(B, T, M, D, use_drop):
