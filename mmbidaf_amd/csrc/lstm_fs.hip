@@ -75,8 +75,17 @@ __device__ __forceinline__ f4 fs_prod(const u4 (&a)[NPL], const u4 (&b)[NPL], f4
 //                    mode 1 (BPTT):    plane row u holds W_hh[gate*H+u'][u] at k = 4u'+gate     (rows H,  K = 4H)
 // one wave per plane row: NPL = 2: row maximum -> power-of-two scale (max to [2^13, 2^14)) -> two fp16 terms;
 // NPL = 1: plain bf16, inverse scale 1; padding = zeros
-__global__ __launch_bounds__(256) void lstm_fs_wprep_kernel(const float* __restrict__ w_hh, char* __restrict__ planes,
-                                                            float* __restrict__ inv, int H, int mode, int rows_p, int nkt, int npl) {
+// (one launch for all (problem, direction) pairs of a layer call: blockIdx.y -- as 14 launches of their own per layer call they
+//  were 0.8 ms of the cfg5 step, each bound by its launch)
+struct FsWprepGroup {
+    const float* w[2 * MMB_MAX_GROUP];
+    char* planes[2 * MMB_MAX_GROUP];
+    float* inv[2 * MMB_MAX_GROUP];
+};
+__global__ __launch_bounds__(256) void lstm_fs_wprep_kernel(const FsWprepGroup G, int H, int mode, int rows_p, int nkt, int npl) {
+    const float* __restrict__ w_hh = G.w[blockIdx.y];
+    char* __restrict__ planes = G.planes[blockIdx.y];
+    float* __restrict__ inv = G.inv[blockIdx.y];
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows_p) return;
     const int rows = mode ? H : 4 * H, K = mode ? 4 * H : H;
@@ -989,6 +998,7 @@ int lstm_fs_reset_timeouts() {
 int lstm_fs_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* ws, hipStream_t stream) {
     FsFwdArgs a{};
     a.n = n;
+    FsWprepGroup wg{};
     const int npl = precision_mode() == 1 ? 1 : 2;
     const int H = d[0].H;
     int maxT = 0, maxB = 0;
@@ -1000,18 +1010,19 @@ int lstm_fs_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* ws, hipStream_t 
         FsFwdProb& q = a.p[i];
         q.gx = p.gx; q.len = p.lengths; q.y = p.y; q.gates = p.gates; q.cs = p.cs; q.h_n = p.h_n; q.c_n = p.c_n; q.hn_pos = p.hn_pos;
         q.B = p.B; q.T = p.T; q.H = H;
-        const int rows_p = fs_pad(4 * H, 64);
         for (int dir = 0; dir < 2; ++dir) {
             q.wp[dir] = ws[i] + L.wp[dir];
             q.winv[dir] = reinterpret_cast<const float*>(ws[i] + L.winv[dir]);
             q.hp[dir][0] = ws[i] + L.hp[dir][0];
             q.hp[dir][1] = ws[i] + L.hp[dir][1];
-            hipLaunchKernelGGL(lstm_fs_wprep_kernel, dim3((rows_p + 3) / 4), dim3(256), 0, stream, p.w_hh[dir], ws[i] + L.wp[dir],
-                               reinterpret_cast<float*>(ws[i] + L.winv[dir]), H, 0, rows_p, L.nkt, npl);
+            wg.w[2 * i + dir] = p.w_hh[dir];
+            wg.planes[2 * i + dir] = ws[i] + L.wp[dir];
+            wg.inv[2 * i + dir] = reinterpret_cast<float*>(ws[i] + L.winv[dir]);
         }
         maxT = max(maxT, p.T);
         maxB = max(maxB, p.B);
     }
+    hipLaunchKernelGGL(lstm_fs_wprep_kernel, dim3((fs_pad(4 * H, 64) + 3) / 4, 2 * n), dim3(256), 0, stream, wg, H, 0, fs_pad(4 * H, 64), a.nkt, npl);
     MMB_HIP(hipGetLastError());
     a.nslices = (H + 15) / 16;
     if (fs_persist_mode() && a.nkt <= 16) {
@@ -1070,6 +1081,7 @@ int lstm_fs_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* ws, hipStream_t 
     if (db_done) *db_done = false;
     FsBwdArgs a{};
     a.n = n;
+    FsWprepGroup wg{};
     const int npl = precision_mode() == 1 ? 1 : 2;
     const int H = d[0].H;
     int maxT = 0, maxB = 0;
@@ -1088,19 +1100,20 @@ int lstm_fs_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* ws, hipStream_t 
             hipLaunchKernelGGL(lstm_fs_absmax_kernel, dim3(256), dim3(256), 0, stream, p.d_y, (long)p.B * p.T * 2 * H, bound);
             hipLaunchKernelGGL(lstm_fs_absmax_kernel, dim3(16), dim3(256), 0, stream, p.d_hn, (long)2 * p.B * H, bound + 1);
         }
-        const int rows_p = fs_pad(H, 32);
         for (int dir = 0; dir < 2; ++dir) {
             q.wtp[dir] = ws[i] + L.wtp[dir];
             q.wtinv[dir] = reinterpret_cast<const float*>(ws[i] + L.wtinv[dir]);
             q.ap[dir][0] = ws[i] + L.ap[dir][0];
             q.ap[dir][1] = ws[i] + L.ap[dir][1];
             q.amax[dir] = reinterpret_cast<float*>(ws[i] + L.amax[dir]);
-            hipLaunchKernelGGL(lstm_fs_wprep_kernel, dim3((rows_p + 3) / 4), dim3(256), 0, stream, p.w_hh[dir], ws[i] + L.wtp[dir],
-                               reinterpret_cast<float*>(ws[i] + L.wtinv[dir]), H, 1, rows_p, L.nkt4, npl);
+            wg.w[2 * i + dir] = p.w_hh[dir];
+            wg.planes[2 * i + dir] = ws[i] + L.wtp[dir];
+            wg.inv[2 * i + dir] = reinterpret_cast<float*>(ws[i] + L.wtinv[dir]);
         }
         maxT = max(maxT, p.T);
         maxB = max(maxB, p.B);
     }
+    hipLaunchKernelGGL(lstm_fs_wprep_kernel, dim3((fs_pad(H, 32) + 3) / 4, 2 * n), dim3(256), 0, stream, wg, H, 1, fs_pad(H, 32), a.nkt4, npl);
     MMB_HIP(hipGetLastError());
     if (fs_persist_mode() && a.nkt4 <= 64) {
         // one launch for the whole time loop when every workgroup gets a CU of its own: 32 units x 32 samples per workgroup,
