@@ -1466,6 +1466,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     // streamed tensors in ring order: db, [text], text_d, da   (text only with dropped copies)
     constexpr int NT = SAME ? 3 : 4;
     constexpr int X_DB = 0, X_T = 1, X_TD = SAME ? 1 : 2, X_DA = SAME ? 2 : 3;
+    constexpr int XS_ = X_DB, XR0_ = X_TD;
     constexpr int NSC = 9;
     float* sc = reinterpret_cast<float*>(smem + SWEEP_SC_OFF);   // [NSC][32]
     char* xch = smem + SWEEP_XCH_OFF + w4 * XCH_PAIR + lane * 16;
@@ -1528,10 +1529,6 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     float* eC = eD + 64 * LDP;                                  //           [64][LDP]  sum_i P1 da
     float* dcs = eC + 64 * LDP;                                 //           [64]       dc
 
-    // top of iteration pi, behind the full barrier: the value tensors of panel pi - 1 are free
-    auto issue_top = [&](int pi) {
-        if (NT == 4 && pi > 0) issue8(pi, 3);                   // training mode: the 4th tensor of THIS panel, just in time
-    };
     // The next panel is issued by the role-1 waves ONE PIECE PER STEP of their products (round 4; as three bursts of 7 pieces per
     // wave behind the S-type products, rounds 2-3, the issue alone took the wave 1 300-2 000 clocks at 100-185 per piece, and
     // the panel landed 2 000+ clocks after the top barrier of the next iteration was reached).  Slots (ring of 5): tensor 0 of
@@ -1542,6 +1539,13 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     const int w4u = __builtin_amdgcn_readfirstlane(w4);
     const unsigned lane16 = lane * 16;
     const bool nodma = DBG == 2 && (a.dbg & 1);        // timing only (with the time stamps): no LDS-DMA inside the loop
+    auto piece_at = [&](int pn, int x, int piece) {    // piece 0..27 of tensor x of panel pn
+        if (nodma || piece >= 28) return;
+        const char* ub = sgpr_ptr(src[x] + (size_t)((pn * PR) >> 4) * PRB + piece * 1024);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(ub + lane16),
+            (__attribute__((address_space(3))) void*)(sweep_slot<SAME, NT, XS_, XR0_>(smem, pn, x) + piece * 1024), 16, 0, 0);
+    };
     auto piece1 = [&](int pn, int x, int k) {          // piece w4 + 4 k (k = 0..6) of tensor x of panel pn
         if (nodma) return;
         const int piece = w4u + 4 * k;
@@ -1590,9 +1594,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
                     if (!IS_J) sc[(sdup + 1) * 32 + scr] = sv;
                 }
             }
-            dma_sync();               // this panel's DMA has landed, its scalars are visible
-            issue_top(pi);
-            if (NT == 4 && pi > 0) dma_sync();
+            dma_sync();               // this panel's DMA has landed (4 tensors: all but the last, see role 1), its scalars are visible
             if (pi + 1 < np && f_on) sc_next = fetch((pi + 1) * PR + scr);
             ts_cyc<DBG>(tsr, 9, tsi);
             const char* pTd = sweep_slot<SAME, NT, X_DB, X_TD>(smem, pi, X_TD);
@@ -1601,7 +1603,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
             if (!(dbg & 2)) sprod2p(pTd, r, g, sS, c1);
-            if (SAME) plain_barrier();      // (3-tensor schedule: the role-1 waves' rendezvous between their S-type products)
+            plain_barrier();                // the role-1 waves' rendezvous: their late tensor of THIS panel has landed (see role 1)
             if (!(dbg & 2)) sprod2p(pT, r, g, sDq, c2);
             ts_cyc<DBG>(tsr, 10, tsi);
             lds_barrier();            // role 1's dP1 is in LDS
@@ -1673,8 +1675,13 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
             }
             if (SAME && pi > 0) dma_sync_keep7();     // 3 tensors: this panel's S-only tensor (the 7 newest pieces) may still be in flight
             else dma_sync();
-            issue_top(pi);
-            if (NT == 4 && pi > 0) dma_sync();
+            // 4 tensors: the last tensor of THIS panel, just in time (its slot held a value tensor of panel pi - 1); awaited at the
+            // barrier between the S-type products.  Issued by the role-1 waves 5-7 alone: wave 4 fetches per-row scalars here, and the
+            // reload of that fetch's descriptor from scratch comes with a vmcnt(0) that must not find DMA in flight.
+            if (NT == 4 && pi > 0 && w4u > 0) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) piece_at(pi, 3, (w4u - 1) + 3 * k);
+            }
             if (pi + 1 < np && f_on) sc_next = fetch((pi + 1) * PR + scr);
             ts_cyc<DBG>(tsr, 9, tsi);
             const char* pDa = sweep_slot<SAME, NT, X_DB, X_TD>(smem, pi, X_DA);
@@ -1732,30 +1739,29 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
                         piece1(pi + 1, 2, k);
                     }
                 };
-                if (!(dbg & 2)) {
-                    sprod2p(pDb, r, g, sQ, c2, hookA);
-                    sprod2p(pDa, r, g, sM, c1);
-                } else {
+                if (!(dbg & 2)) sprod2p(pDb, r, g, sQ, c2, hookA);
+                else {
 #pragma unroll
                     for (int k = 0; k < KT; ++k) hookA(k);
                 }
+                if (more) vm_keep7_barrier();      // the just-in-time tensor of this panel (da) has landed in every role-1 wave: it had
+                else vm0_barrier();                //  the first S-type product to do so (rounds 2-4: awaited at the top, fully exposed)
+                if (!(dbg & 2)) sprod2p(pDa, r, g, sM, c1);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
                     const f4 sDa = *reinterpret_cast<const f4*>(sg + 7 * 32 + mb * 16), sDb = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16);
                     *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sDa * inM) + c2[mb] * (sDb * inQ);
                 }
                 ts_cyc<DBG>(tsr, 10, tsi);
-                lds_barrier();            // the S-only panels are dead
+                lds_barrier();            // the S-only panels are dead: the next panel's tensors 1 and 2 take their slots NOW, while this
+#pragma unroll                            // role waits for role 0's arithmetic (issued from the PV product they land 4 000-5 000 clocks
+                for (int k = 0; k < KT; ++k) hookC(k);          // after the next top barrier is reached: in-kernel stamps, round 4)
                 ts_cyc<DBG>(tsr, 11, tsi);
                 lds_barrier();
                 ts_cyc<DBG>(tsr, 12, tsi);
                 half8 W0, W1;
                 xch_get(xch + 2048, W0, W1);
-                if (!(dbg & 4)) pvprodp<2>(pDa, tr, W0, W1, O, hookC);
-                else {
-#pragma unroll
-                    for (int k = 0; k < KT; ++k) hookC(k);
-                }
+                if (!(dbg & 4)) pvprodp<2>(pDa, tr, W0, W1, O);
                 ts_cyc<DBG>(tsr, 13, tsi);
             }
         }
@@ -1833,6 +1839,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     // (text * w_tm) . mod, so the mod panel serves the similarity, da . mod and the value rows of dX.
     constexpr int NT = SAME ? 3 : 4;
     constexpr int X_Q = 0, X_M = 1, X_MD = SAME ? 1 : 2, X_DQ = SAME ? 2 : 3;
+    constexpr int XS_ = X_Q, XR0_ = X_DQ;
     constexpr int NSC = 10;
     float* sc = reinterpret_cast<float*>(smem + SWEEP_SC_OFF);    // [NSC][32]
     char* xch = smem + SWEEP_XCH_OFF + w4 * XCH_PAIR + lane * 16;
@@ -1900,9 +1907,6 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     float* eT = eX + 64 * LDP;                                  //           [64][LDP]  sum_j P2 dq
     float* drs = eT + 64 * LDP;                                 //           [64]       dr
 
-    auto issue_top = [&](int pi) {
-        if (NT == 4 && pi > 0) issue8(pi, 3);                   // training mode: the 4th tensor of THIS panel, just in time
-    };
     // The next panel is issued by the role-1 waves ONE PIECE PER STEP of their products (round 4; as three bursts of 7 pieces per
     // wave behind the S-type products, rounds 2-3, the issue alone took the wave 1 300-2 000 clocks at 100-185 per piece, and
     // the panel landed 2 000+ clocks after the top barrier of the next iteration was reached).  Slots (ring of 5): tensor 0 of
@@ -1913,6 +1917,13 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     const int w4u = __builtin_amdgcn_readfirstlane(w4);
     const unsigned lane16 = lane * 16;
     const bool nodma = DBG == 2 && (a.dbg & 1);        // timing only (with the time stamps): no LDS-DMA inside the loop
+    auto piece_at = [&](int pn, int x, int piece) {    // piece 0..27 of tensor x of panel pn
+        if (nodma || piece >= 28) return;
+        const char* ub = sgpr_ptr(src[x] + (size_t)((pn * PR) >> 4) * PRB + piece * 1024);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(ub + lane16),
+            (__attribute__((address_space(3))) void*)(sweep_slot<SAME, NT, XS_, XR0_>(smem, pn, x) + piece * 1024), 16, 0, 0);
+    };
     auto piece1 = [&](int pn, int x, int k) {          // piece w4 + 4 k (k = 0..6) of tensor x of panel pn
         if (nodma) return;
         const int piece = w4u + 4 * k;
@@ -1958,9 +1969,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
                     if (!IS_J) sc[(sdup + 1) * 32 + scr] = sv;
                 }
             }
-            dma_sync();               // this panel's DMA has landed, its scalars are visible
-            issue_top(pi);
-            if (NT == 4 && pi > 0) dma_sync();
+            dma_sync();               // this panel's DMA has landed (4 tensors: all but the last, see role 1), its scalars are visible
             if (pi + 1 < np && f_on) sc_next = fetch((pi + 1) * PR + scr);
             ts_cyc<DBG>(tsr, 9, tsi);
             const char* pMd = sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, X_MD);
@@ -1969,7 +1978,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
             if (!(dbg & 2)) sprod2p(pMd, r, g, sS, c1);
-            if (SAME) plain_barrier();      // (3-tensor schedule: the role-1 waves' rendezvous between their S-type products)
+            plain_barrier();                // the role-1 waves' rendezvous: their late tensor of THIS panel has landed (see role 1)
             if (!(dbg & 2)) sprod2p(pDq, r, g, sT, c2);
             ts_cyc<DBG>(tsr, 10, tsi);
             lds_barrier();            // role 1's dP1 is in LDS
@@ -2042,8 +2051,13 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
             }
             if (SAME && pi > 0) dma_sync_keep7();     // 3 tensors: this panel's S-only tensor (the 7 newest pieces) may still be in flight
             else dma_sync();
-            issue_top(pi);
-            if (NT == 4 && pi > 0) dma_sync();
+            // 4 tensors: the last tensor of THIS panel, just in time (its slot held a value tensor of panel pi - 1); awaited at the
+            // barrier between the S-type products.  Issued by the role-1 waves 5-7 alone: wave 4 fetches per-row scalars here, and the
+            // reload of that fetch's descriptor from scratch comes with a vmcnt(0) that must not find DMA in flight.
+            if (NT == 4 && pi > 0 && w4u > 0) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) piece_at(pi, 3, (w4u - 1) + 3 * k);
+            }
             if (pi + 1 < np && f_on) sc_next = fetch((pi + 1) * PR + scr);
             ts_cyc<DBG>(tsr, 9, tsi);
             const char* pM = sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, X_M);
@@ -2095,30 +2109,29 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
                         piece1(pi + 1, 2, k);
                     }
                 };
-                if (!(dbg & 2)) {
-                    sprod2p(pQ, r, g, sDb, c2, hookA);
-                    sprod2p(pM, r, g, sDa, c1);
-                } else {
+                if (!(dbg & 2)) sprod2p(pQ, r, g, sDb, c2, hookA);
+                else {
 #pragma unroll
                     for (int k = 0; k < KT; ++k) hookA(k);
                 }
+                if (more) vm_keep7_barrier();      // the just-in-time tensor of this panel (dq: role 0's second product) has landed
+                else vm0_barrier();
+                if (!(dbg & 2)) sprod2p(pM, r, g, sDa, c1);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
                     const f4 sM = *reinterpret_cast<const f4*>(sg + 8 * 32 + mb * 16), sQ = *reinterpret_cast<const f4*>(sg + 9 * 32 + mb * 16);
                     *reinterpret_cast<f4*>(xch + mb * 1024) = c1[mb] * (sM * inDa) + c2[mb] * (sQ * inDb);
                 }
                 ts_cyc<DBG>(tsr, 10, tsi);
-                lds_barrier();            // the S-only panels are dead
+                lds_barrier();            // the S-only panels are dead: the next panel's tensors 1 and 2 take their slots now (see the j sweep)
+#pragma unroll
+                for (int k = 0; k < KT; ++k) hookC(k);
                 ts_cyc<DBG>(tsr, 11, tsi);
                 lds_barrier();
                 ts_cyc<DBG>(tsr, 12, tsi);
                 half8 W0, W1;
                 xch_get(xch + 2048, W0, W1);
-                if (!(dbg & 4)) pvprodp<2>(pMd, tr, W0, W1, O, hookC);
-                else {
-#pragma unroll
-                    for (int k = 0; k < KT; ++k) hookC(k);
-                }
+                if (!(dbg & 4)) pvprodp<2>(pMd, tr, W0, W1, O);
                 ts_cyc<DBG>(tsr, 13, tsi);
             }
         }

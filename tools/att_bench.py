@@ -42,17 +42,16 @@ def main():
               (torch.randn(1, 1, D, generator=g) * 0.1).to(dev).requires_grad_(True), torch.zeros(1, device=dev, requires_grad=True)]
         ml = torch.full((B,), M, dtype=torch.int32, device=dev)
         mm = MF.PrefixMask([M] * B, M, ml)
-        drops = (None, None)
-        if a.drop:
-            drops = (text * (torch.rand(B, T, D, device=dev) > 0.2).float() / 0.8, mod * (torch.rand(B, M, D, device=dev) > 0.2).float() / 0.8)
-        probs.append((text, mod, tm, mm, *ps, *drops))
+        keep = ((torch.rand(B, T, D, device=dev) > 0.2).float() / 0.8, (torch.rand(B, M, D, device=dev) > 0.2).float() / 0.8) if a.drop else None
+        probs.append((text, mod, tm, mm, *ps, keep))
         leaves += [mod] + ps
         cots.append(torch.randn(B, T, 4 * D, generator=g).to(dev))
 
     def step():
         for t in leaves:
             t.grad = None
-        outs = MF.bidaf_attention_group(probs)
+        # (the dropped copies are made inside the step: they are part of its autograd graph)
+        outs = MF.bidaf_attention_group([(*pr[:-1], *((pr[0] * pr[-1][0], pr[1] * pr[-1][1]) if pr[-1] is not None else (None, None))) for pr in probs])
         torch.autograd.backward(outs, cots)
     table = {}
     scratch = None
