@@ -1439,6 +1439,7 @@ __device__ __forceinline__ char* sweep_slot(char* smem, int pn, int x) {
 // tensor of the panel it is about to start, needed only by its SECOND S-type product); the barrier between the two S-type
 // products waits for them (7 newer pieces -- the next panel's -- are in flight by then when there is a next panel).  vmcnt
 // retires in order, so "at most 7 outstanding" implies everything older than the 7 newest has landed.
+static_assert(2 * KT * 2 == 28 && 28 / 4 == 7 && KT == 7, "a panel is 28 pieces: 7 per role-1 wave, one per k-tile step of a product (the counted vmcnt(7) waits rely on it)");
 __device__ __forceinline__ void dma_sync_keep7() { asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void vm_keep7_barrier() { asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void vm0_barrier() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
