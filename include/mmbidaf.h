@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMB_VERSION 403            /* round 4 ABI: + persistent-recurrence reset / enable, mmb_stream_occupy, attention phase stamps, mmb_masked_mul / _sum */
+#define MMB_VERSION 404            /* round 4 ABI: + persistent-recurrence reset / enable, mmb_stream_occupy, attention phase stamps, mmb_masked_mul / _sum */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
 #define MMB_ATT_MAX_D 208          /* attention feature width D = 2H of the fused (register-resident) kernels */
 #define MMB_ATT_GENERAL_MAX_D 4096 /* wider D (up to this) runs the general path: similarity matrix in a workspace */
@@ -276,10 +276,12 @@ int mmb_weighted_sums_bwd(const float* g, const float* const* w, float* const* d
 /* Dropout masks applied in ONE launch for up to MMB_MASK_MAX tensors: dst_k = a_k * m_k (accumulate = 0) or dst_k += a_k * m_k
  * (accumulate != 0), n[k] floats each; all pointers 16-byte aligned; dst_k may alias a_k.  Replaces the products of the
  * reference's F.dropout calls (layers/encoding.py:81,104, layers/attention.py:66-67) with masks the host has drawn with torch's
- * generator (the dropout decisions stay torch's; only the multiplications are fused per stage). */
+ * generator (the dropout decisions stay torch's; only the multiplications are fused per stage).  keep < 0: m_k are the masks
+ * themselves (0 or 1/(1-p)); keep >= 0: m_k are the UNIFORM draws in [0,1) that decide them, mask = m < keep ? scale : 0 (keep = 1-p,
+ * scale = 1/(1-p): F.dropout's Bernoulli(1-p) keep decision from torch.rand of the same generator). */
 #define MMB_MASK_MAX 8
 int mmb_masked_mul(const float* const* a, const float* const* m, float* const* dst, const long* n, int k, int accumulate,
-                   int device, void* stream);
+                   float keep, float scale, int device, void* stream);
 /* dst = (sum_{t < nterms} x[t] * m[t]) * mo for up to MMB_MASK_MAX tensors in one launch; m[t] / mo NULL = 1; dst may alias an
  * x[t].  The cotangents the attention's backward hands to the input encoders (models.py:131-132 feed one text tensor to both
  * attentions, attention.py:66-67 drops it once more for the similarity): their sum, the dropped copies' terms through their masks
@@ -293,7 +295,7 @@ typedef struct {
     long n;
     int nterms;
 } mmb_masked_sum_desc;
-int mmb_masked_sum(const mmb_masked_sum_desc* d, int k, int device, void* stream);
+int mmb_masked_sum(const mmb_masked_sum_desc* d, int k, float keep, float scale, int device, void* stream);   /* keep, scale: as mmb_masked_mul */
 
 /* ------------------------------------------------------------------------------------------
  * Decoder step.  Replaces MultimodalAttentionDecoder.forward (reference

@@ -16,7 +16,7 @@ ATT_GENERAL_MAX_D = 4096     # general path (similarity matrix in a workspace)
 LSTM_MAX_H = 128            # register-resident recurrence (one launch per layer)
 LSTM_GENERAL_MAX_H = 1024   # general recurrence (one launch per time step)
 
-ABI_VERSION = 403           # MMB_VERSION the signatures below were written for (include/mmbidaf.h)
+ABI_VERSION = 404           # MMB_VERSION the signatures below were written for (include/mmbidaf.h)
 
 c_f = ctypes.c_void_p  # device pointers travel as raw addresses
 c_i = ctypes.c_int
@@ -111,8 +111,8 @@ SIGNATURES = {
     "mmb_weighted_sums_bwd": (c_i, [c_f, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_long), c_i,
                                     c_i, c_f]),
     "mmb_masked_mul": (c_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
-                             ctypes.POINTER(ctypes.c_long), c_i, c_i, c_i, c_f]),
-    "mmb_masked_sum": (c_i, [ctypes.POINTER(MaskedSumDesc), c_i, c_i, c_f]),
+                             ctypes.POINTER(ctypes.c_long), c_i, c_i, ctypes.c_float, ctypes.c_float, c_i, c_f]),
+    "mmb_masked_sum": (c_i, [ctypes.POINTER(MaskedSumDesc), c_i, ctypes.c_float, ctypes.c_float, c_i, c_f]),
     "mmb_stream_create_cu_mask": (c_i, [c_i, ctypes.POINTER(ctypes.c_uint32), c_i, ctypes.POINTER(ctypes.c_void_p)]),
     "mmb_stream_destroy": (c_i, [c_i, c_f]),
     "mmb_gemm_tn_planes": (c_i, [c_f] * 3 + [c_i] * 3 + [c_f, ctypes.c_size_t, c_i, c_f]),

@@ -8,6 +8,14 @@
 namespace mmb {
 
 constexpr int MK_PER_BLOCK = 256 * 4 * 8;      // elements one workgroup covers
+// a mask operand is either the mask itself (keep < 0) or the UNIFORM draw u in [0, 1) it is decided by: m = u < keep ? scale : 0
+// (keep = 1 - p, scale = 1 / (1 - p): F.dropout's Bernoulli(1 - p) from torch.rand of the same generator -- one 14-us kernel per step
+// where F.dropout over a vector of ones took 40)
+__device__ __forceinline__ f4 mask_of(f4 u, float keep, float scale) {
+    if (keep < 0.f) return u;
+    return f4{u.x < keep ? scale : 0.f, u.y < keep ? scale : 0.f, u.z < keep ? scale : 0.f, u.w < keep ? scale : 0.f};
+}
+__device__ __forceinline__ float mask_of(float u, float keep, float scale) { return keep < 0.f ? u : (u < keep ? scale : 0.f); }
 struct MaskMulArgs {
     const float* a[MMB_MASK_MAX];
     const float* m[MMB_MASK_MAX];
@@ -15,6 +23,7 @@ struct MaskMulArgs {
     long n[MMB_MASK_MAX];
     int blk_begin[MMB_MASK_MAX + 1];
     int k;
+    float keep, scale;
 };
 
 template <bool ACC>
@@ -33,7 +42,7 @@ __global__ __launch_bounds__(256) void masked_mul_kernel(const MaskMulArgs p) {
         for (int it = 0; it < 8; ++it) {
             const long i = base + ((long)it * 256 + threadIdx.x) * 4;
             av[it] = *reinterpret_cast<const f4*>(a + i);
-            mv[it] = *reinterpret_cast<const f4*>(m + i);
+            mv[it] = mask_of(*reinterpret_cast<const f4*>(m + i), p.keep, p.scale);
             if (ACC) dv[it] = *reinterpret_cast<const f4*>(dst + i);
         }
 #pragma unroll
@@ -45,10 +54,10 @@ __global__ __launch_bounds__(256) void masked_mul_kernel(const MaskMulArgs p) {
         for (int it = 0; it < 8; ++it) {
             const long i = base + ((long)it * 256 + threadIdx.x) * 4;
             if (i + 3 < n) {
-                const f4 v = *reinterpret_cast<const f4*>(a + i) * *reinterpret_cast<const f4*>(m + i);
+                const f4 v = *reinterpret_cast<const f4*>(a + i) * mask_of(*reinterpret_cast<const f4*>(m + i), p.keep, p.scale);
                 *reinterpret_cast<f4*>(dst + i) = ACC ? *reinterpret_cast<const f4*>(dst + i) + v : v;
             } else {
-                for (long j = i; j < n; ++j) dst[j] = ACC ? dst[j] + a[j] * m[j] : a[j] * m[j];
+                for (long j = i; j < n; ++j) dst[j] = ACC ? dst[j] + a[j] * mask_of(m[j], p.keep, p.scale) : a[j] * mask_of(m[j], p.keep, p.scale);
             }
         }
     }
@@ -66,6 +75,7 @@ struct MaskSumArgs {
     int nterms[MMB_MASK_MAX];
     int blk_begin[MMB_MASK_MAX + 1];
     int k;
+    float keep, scale;
 };
 constexpr int MS_PER_BLOCK = 256 * 4 * 4;
 __global__ __launch_bounds__(256) void masked_sum_kernel(const MaskSumArgs p) {
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(256) void masked_sum_kernel(const MaskSumArgs p) {
                 for (int it = 0; it < 4; ++it) {
                     const long i = base + ((long)it * 256 + threadIdx.x) * 4;
                     xv[it] = *reinterpret_cast<const f4*>(x + i);
-                    mv[it] = m ? *reinterpret_cast<const f4*>(m + i) : f4{1.f, 1.f, 1.f, 1.f};
+                    mv[it] = m ? mask_of(*reinterpret_cast<const f4*>(m + i), p.keep, p.scale) : f4{1.f, 1.f, 1.f, 1.f};
                 }
 #pragma unroll
                 for (int it = 0; it < 4; ++it) acc[it] += xv[it] * mv[it];
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256) void masked_sum_kernel(const MaskSumArgs p) {
         }
         if (mo) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) ov[it] = *reinterpret_cast<const f4*>(mo + base + ((long)it * 256 + threadIdx.x) * 4);
+            for (int it = 0; it < 4; ++it) ov[it] = mask_of(*reinterpret_cast<const f4*>(mo + base + ((long)it * 256 + threadIdx.x) * 4), p.keep, p.scale);
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) *reinterpret_cast<f4*>(dst + base + ((long)it * 256 + threadIdx.x) * 4) = acc[it] * ov[it];
@@ -113,8 +123,8 @@ __global__ __launch_bounds__(256) void masked_sum_kernel(const MaskSumArgs p) {
             const long i0 = base + ((long)it * 256 + threadIdx.x) * 4;
             for (long j = i0; j < i0 + 4 && j < n; ++j) {
                 float a = 0.f;
-                for (int t = 0; t < nt; ++t) a += p.x[k][t][j] * (p.m[k][t] ? p.m[k][t][j] : 1.f);
-                dst[j] = a * (mo ? mo[j] : 1.f);
+                for (int t = 0; t < nt; ++t) a += p.x[k][t][j] * (p.m[k][t] ? mask_of(p.m[k][t][j], p.keep, p.scale) : 1.f);
+                dst[j] = a * (mo ? mask_of(mo[j], p.keep, p.scale) : 1.f);
             }
         }
     }
@@ -124,11 +134,11 @@ __global__ __launch_bounds__(256) void masked_sum_kernel(const MaskSumArgs p) {
 
 using namespace mmb;
 
-extern "C" int mmb_masked_sum(const mmb_masked_sum_desc* d, int k, int device, void* stream_) {
+extern "C" int mmb_masked_sum(const mmb_masked_sum_desc* d, int k, float keep, float scale, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MMB_REQUIRE(d && k >= 1 && k <= MMB_MASK_MAX, "mmb_masked_sum: 1..%d tensors", MMB_MASK_MAX);
     MaskSumArgs p{};
-    p.k = k;
+    p.k = k; p.keep = keep; p.scale = scale;
     int blk = 0;
     for (int i = 0; i < k; ++i) {
         MMB_REQUIRE(d[i].dst && d[i].n >= 0 && d[i].nterms >= 1 && d[i].nterms <= MMB_MASK_TERMS, "mmb_masked_sum: bad descriptor %d", i);
@@ -153,11 +163,11 @@ extern "C" int mmb_masked_sum(const mmb_masked_sum_desc* d, int k, int device, v
 }
 
 extern "C" int mmb_masked_mul(const float* const* a, const float* const* m, float* const* dst, const long* n, int k, int accumulate,
-                              int device, void* stream_) {
+                              float keep, float scale, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MMB_REQUIRE(a && m && dst && n && k >= 1 && k <= MMB_MASK_MAX, "mmb_masked_mul: 1..%d tensors", MMB_MASK_MAX);
     MaskMulArgs p{};
-    p.k = k;
+    p.k = k; p.keep = keep; p.scale = scale;
     int blk = 0;
     for (int i = 0; i < k; ++i) {
         MMB_REQUIRE(a[i] && m[i] && dst[i] && n[i] >= 0, "mmb_masked_mul: null tensor %d", i);

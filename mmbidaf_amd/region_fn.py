@@ -14,8 +14,8 @@ calls are issued by one `torch.autograd.Function`:
     weight-gradient phase of layer k on the side stream beside the recurrence of layer k - 1) but as straight-line code with
     one join at its end: no deferred-work queue, no per-tensor `record_stream`, no end-of-backward engine callback.
 
-Results are those of the modular path bit for bit in eval mode, and in training mode under the same generator state (the
-eleven dropout masks are drawn by the same `F.dropout` calls in the same order).  The modular path stays the general one:
+Results are those of the modular path bit for bit in eval mode; in training mode the eleven dropout masks of a step are decided
+by ONE `torch.rand` draw (Bernoulli(1 - p) keep decisions, as F.dropout's) and applied inside the library.  The modular path stays the general one:
 this node is taken only for the exact module structure of the reference's region on a GPU, with the fused attention width
 (D = 2H <= 208), plain leaf parameters and no module hooks -- anything else falls back (`eligible`).
 """
@@ -114,7 +114,7 @@ class _Plan:
                 bw.add(tag + ".d_text_d", B * T * D * f)
                 bw.add(tag + ".d_mod_d", B * M * D * f)
         self.bw = bw
-        # training mode: the eleven dropout masks of a step are ONE F.dropout draw over a flat vector of ones, cut in this order
+        # training mode: the eleven dropout masks of a step are decided by ONE torch.rand over a flat vector, cut in this order
         # (the call order of the modular path: encoders' output dropout, dropped copies of (text, audio) and (text, image),
         # inter-layer dropout of the two modelling encoders, their output dropout)
         self.tm = _build_templates(self)
@@ -140,12 +140,18 @@ def mask_layout(B, T, Ma, Mi, H):
 
 
 def draw_masks(B, T, Ma, Mi, H, p, dev):
-    """The masks a training-mode step of these sizes draws from torch's generator in its current state: {name: (shape) tensor of
+    """The masks a training-mode step of these sizes decides with torch's generator in its current state: {name: (shape) tensor of
     0 / 1/(1-p)}.  Tests replay a step's masks with it (same generator state -> same masks) for their CPU comparison."""
     lay = mask_layout(B, T, Ma, Mi, H)
     total = lay[-1][2] + (lay[-1][3] + 3) // 4 * 4
-    flat = F.dropout(_ones_flat(total, dev), p, True)
+    keep, scale = _keep_scale(p)
+    flat = (torch.rand(total, device=dev) < keep).float() * scale       # the step's ONE draw (see _RegionFn.forward) made explicit
     return {name: flat[o:o + n].view(sh) for name, sh, o, n in lay}, flat
+
+
+def _keep_scale(p):
+    """(1 - p, 1 / (1 - p)) as the float32 values the library compares / multiplies with"""
+    return float(np.float32(1.0 - p)), float(np.float32(1.0 / (1.0 - p)))
 
 
 _plans = {}
@@ -284,12 +290,10 @@ def _drop_conf(R):
     return ps[0]
 
 
-_ones = {}
-
-
-def _masked_mul(lib, di, stream, a_list, m_list, dst_list=None, accumulate=False):
+def _masked_mul(lib, di, stream, a_list, m_list, dst_list=None, accumulate=False, p=None):
     """dst_k = a_k * m_k (new tensors when dst_list is None) or dst_k += a_k * m_k for a stage's tensors in ONE launch
-    (mmb_masked_mul: the products of the reference's F.dropout calls with masks torch has drawn)."""
+    (mmb_masked_mul: the products of the reference's F.dropout calls with masks torch has decided).  p given: m_k are the
+    uniform draws, the mask is (m < 1 - p) / (1 - p)."""
     k = len(a_list)
     if dst_list is None:
         dst_list = [torch.empty_like(a) for a in a_list]
@@ -297,18 +301,9 @@ def _masked_mul(lib, di, stream, a_list, m_list, dst_list=None, accumulate=False
     mp = (ctypes.c_void_p * k)(*[m.data_ptr() for m in m_list])
     dp = (ctypes.c_void_p * k)(*[d.data_ptr() for d in dst_list])
     np_ = (ctypes.c_long * k)(*[a.numel() for a in a_list])
-    _lib.check(lib.mmb_masked_mul(ap, mp, dp, np_, k, 1 if accumulate else 0, di, stream), "mmb_masked_mul")
+    keep, scale = (-1.0, 1.0) if p is None else _keep_scale(p)
+    _lib.check(lib.mmb_masked_mul(ap, mp, dp, np_, k, 1 if accumulate else 0, keep, scale, di, stream), "mmb_masked_mul")
     return dst_list
-
-
-def _ones_flat(total, dev):
-    key = (dev.index, total)
-    o = _ones.get(key)
-    if o is None:
-        if len(_ones) > 8:
-            _ones.clear()
-        o = _ones[key] = torch.ones(total, device=dev, dtype=torch.float32)
-    return o
 
 
 class _Tmpl:
@@ -567,10 +562,11 @@ class _RegionFn(torch.autograd.Function):
 
         masks, held = {}, []
         if drop:
-            # ONE generator call for the step's eleven masks (a flat vector of ones through F.dropout, cut by plan.mask_layout),
-            # and one multi-tensor launch per stage to apply them -- 5 launches where eleven F.dropout calls and eleven products
+            # ONE generator call for the step's eleven masks (torch.rand over a flat vector, cut by plan.mask_layout: F.dropout's
+            # Bernoulli(1 - p) keep decisions; F.dropout itself over a vector of ones cost 40 us, the draw alone 14), and one library
+            # launch per stage to apply them -- 5 launches where eleven F.dropout calls and eleven products
             # took 22
-            flat = F.dropout(_ones_flat(plan.mask_total, dev), drop, True)
+            flat = torch.rand(plan.mask_total, device=dev)          # uniforms: mask = (u < 1 - p) / (1 - p), formed where it is applied
             masks = {name: flat[o:o + n].view(sh) for name, sh, o, n in plan.mask_layout}
 
         # ---- input encoders (models.py:97,102,113) + their output dropout (encoding.py:104)
@@ -580,11 +576,11 @@ class _RegionFn(torch.autograd.Function):
         att_d = (None, None, None, None)
         if drop:
             ys = [view(ko["et.y"], (B, T, D)), view(ko["ea.y"], (B, Ma, D)), view(ko["ei.y"], (B, Mi, D))]
-            yd = _masked_mul(lib, di, stream, ys, [masks["out_et"], masks["out_ea"], masks["out_ei"]])
+            yd = _masked_mul(lib, di, stream, ys, [masks["out_et"], masks["out_ea"], masks["out_ei"]], p=drop)
             held += yd
             enc_out = (yd[0].data_ptr(), yd[1].data_ptr(), yd[2].data_ptr())
             # dropped copies seen by the similarity only (attention.py:66-67)
-            dd = _masked_mul(lib, di, stream, [yd[0], yd[1], yd[0], yd[2]], [masks["aa_t"], masks["aa_m"], masks["ai_t"], masks["ai_m"]])
+            dd = _masked_mul(lib, di, stream, [yd[0], yd[1], yd[0], yd[2]], [masks["aa_t"], masks["aa_m"], masks["ai_t"], masks["ai_m"]], p=drop)
             held += dd
             att_d = (dd[0].data_ptr(), dd[1].data_ptr(), dd[2].data_ptr(), dd[3].data_ptr())
         # ---- the two attentions (models.py:131-132), one grouped call, shared text planes
@@ -596,14 +592,14 @@ class _RegionFn(torch.autograd.Function):
         _lib.check(lib.mmb_bilstm_layer_fwd(d_, 2, di, stream), "mmb_bilstm_layer_fwd")
         l1_in = (kb + ko["a0.y"], kb + ko["i0.y"])
         if drop:
-            y0d = _masked_mul(lib, di, stream, [view(ko["a0.y"], (B, T, D)), view(ko["i0.y"], (B, T, D))], [masks["inter_a"], masks["inter_i"]])
+            y0d = _masked_mul(lib, di, stream, [view(ko["a0.y"], (B, T, D)), view(ko["i0.y"], (B, T, D))], [masks["inter_a"], masks["inter_i"]], p=drop)
             held += y0d
             l1_in = (y0d[0].data_ptr(), y0d[1].data_ptr())
         d_, w_ = tm["f_l1"].build(bases, pp, x0=l1_in[0], x1=l1_in[1])
         _lib.check(lib.mmb_bilstm_layer_fwd(d_, 2, di, stream), "mmb_bilstm_layer_fwd")
         mod_out = [view(ko["a1.y"], (B, T, D)), view(ko["i1.y"], (B, T, D))]
         if drop:
-            mod_out = _masked_mul(lib, di, stream, mod_out, [masks["out_a"], masks["out_i"]])
+            mod_out = _masked_mul(lib, di, stream, mod_out, [masks["out_a"], masks["out_i"]], p=drop)
         # ---- final hidden states (encoding.py:101-103) and the decoder's initial hidden state (models.py:143)
         hid_a = torch.empty(B, 4, H, device=dev, dtype=torch.float32)
         hid_i = torch.empty(B, 4, H, device=dev, dtype=torch.float32)
@@ -665,7 +661,7 @@ class _RegionFn(torch.autograd.Function):
             g = g.contiguous()
             if drop and mask_key is not None:
                 o = bview(bo[tag + ".d_y"], shape)
-                _masked_mul(lib, di, ms, [g], [masks[mask_key]], [o])
+                _masked_mul(lib, di, ms, [g], [masks[mask_key]], [o], p=drop)
                 return o.data_ptr(), o
             return g.data_ptr(), g
 
@@ -700,7 +696,7 @@ class _RegionFn(torch.autograd.Function):
 
         # ---- modelling encoders, layer 1 (first recurrence of the pass: every layer's operand planes are prepared beside it)
         if drop and g_mod_a is not None and g_mod_i is not None:
-            gy = _masked_mul(lib, di, ms, [g_mod_a.contiguous(), g_mod_i.contiguous()], [masks["out_a"], masks["out_i"]])
+            gy = _masked_mul(lib, di, ms, [g_mod_a.contiguous(), g_mod_i.contiguous()], [masks["out_a"], masks["out_i"]], p=drop)
             pa, pi, ta, ti = gy[0].data_ptr(), gy[1].data_ptr(), gy[0], gy[1]
         else:
             pa, ta = cot("a1", g_mod_a, (B, T, D), "out_a")
@@ -738,7 +734,7 @@ class _RegionFn(torch.autograd.Function):
         # inter-layer dropout backward, then layer 0
         if drop:
             dxs1 = [bview(bo["a1.d_x"], (B, T, D)), bview(bo["i1.d_x"], (B, T, D))]
-            _masked_mul(lib, di, ms, dxs1, [masks["inter_a"], masks["inter_i"]], dxs1)
+            _masked_mul(lib, di, ms, dxs1, [masks["inter_a"], masks["inter_i"]], dxs1, p=drop)
         if two:
             main.wait_event(prepared)
             before = torch.cuda.Event()
@@ -775,7 +771,8 @@ class _RegionFn(torch.autograd.Function):
                 sd[j].x[0] = dm.data_ptr(); sd[j].x[1] = bb + bo[tag + ".d_mod_d"]; sd[j].m[1] = masks[mk].data_ptr()
                 sd[j].nterms = 2; sd[j].mo = masks[mo_].data_ptr()
             nsd = 3
-        _lib.check(lib.mmb_masked_sum(sd, nsd, di, ms), "mmb_masked_sum")
+        ks = _keep_scale(drop) if drop else (-1.0, 1.0)
+        _lib.check(lib.mmb_masked_sum(sd, nsd, ks[0], ks[1], di, ms), "mmb_masked_sum")
         hold.append(sd)
         if two:
             before = torch.cuda.Event()

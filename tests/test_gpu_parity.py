@@ -1655,8 +1655,8 @@ def _region_mask_shapes(B, T, Ma, Mi, H):
 
 def _replay_region_masks(shape, p, d, single_node=True):
     """The eleven masks a training-mode region step draws from torch's device generator in its CURRENT state, keyed as the oracle
-    wants them.  The single-node path (mmbidaf_amd/region_fn.py, what HotRegion / MMBiDAF run) makes ONE F.dropout draw over a flat
-    vector of ones and cuts it (region_fn.draw_masks); the modular path calls F.dropout eleven times in the reference's order."""
+    wants them.  The single-node path (mmbidaf_amd/region_fn.py, what HotRegion / MMBiDAF run) decides them with ONE torch.rand over a
+    flat vector and cuts it (region_fn.draw_masks); the modular path calls F.dropout eleven times in the reference's order."""
     import torch.nn.functional as F
     from mmbidaf_amd import region_fn
     if single_node:
@@ -1709,10 +1709,10 @@ def test_hot_region_training_mode_cfg2_lengths_vs_oracle_with_replayed_masks():
 
 def test_region_graph_replay_with_dropout_draws_fresh_masks_every_replay(monkeypatch):
     """hipGraph replay in training mode: torch's graph-safe generator advances its offset per replay, so two replays of ONE
-    captured step must use DIFFERENT dropout masks, and each replay must match the oracle under the masks it used.  The masks
-    are made observable by routing F.dropout through `x * F.dropout(ones)` (the same generator calls, the same values): the
-    (flat) mask tensor lives in the graph's pool and holds the masks of the latest replay."""
-    import torch.nn.functional as F
+    captured step must use DIFFERENT dropout masks, and each replay must match the oracle under the masks it used.  The
+    single-node path decides a step's eleven masks with ONE torch.rand over a flat vector (mask = (u < 1 - p) / (1 - p), formed
+    inside the library where it is applied); the draw is observed by wrapping torch.rand: the flat tensor lives in the graph's
+    pool and holds the uniforms of the latest replay."""
     from mmbidaf_amd import synth
     from mmbidaf_amd.hot_region import HotRegion
     d = dev()
@@ -1724,15 +1724,13 @@ def test_region_graph_replay_with_dropout_draws_fresh_masks_every_replay(monkeyp
     xs = [gpu[k].requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
     params = list(region.parameters())
     seen = []
-    orig = F.dropout
+    orig = torch.rand
 
-    def spy(x, p=0.5, training=True, inplace=False):
-        if not training or p == 0.0:
-            return x
-        m = orig(torch.ones_like(x), p, True)
-        seen.append(m)
-        return x * m
-    monkeypatch.setattr(F, "dropout", spy)
+    def spy(*a, **k):
+        u = orig(*a, **k)
+        seen.append(u)
+        return u
+    monkeypatch.setattr(torch, "rand", spy)
 
     def step():
         outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
@@ -1754,13 +1752,14 @@ def test_region_graph_replay_with_dropout_draws_fresh_masks_every_replay(monkeyp
     with torch.cuda.graph(g):
         outs = step()
     from mmbidaf_amd import region_fn
-    assert len(seen) == 1, f"{len(seen)} dropout draws in one training-mode step of the single-node path, expected ONE flat draw"
+    assert len(seen) == 1, f"{len(seen)} draws in one training-mode step of the single-node path, expected ONE flat draw"
     lay = region_fn.mask_layout(*shape)
+    keep, scale = region_fn._keep_scale(0.2)
     kept = []
     for rep in range(2):
         g.replay()
         torch.cuda.synchronize()
-        flat = seen[0].detach()
+        flat = (seen[0].detach() < keep).float() * scale
         masks = {k: flat[o:o + n].view(sh).cpu().clone() for k, (_, sh, o, n) in zip(_MASK_ORDER, lay)}
         kept.append(masks)
         _check_region_against_masked_oracle(region, batch, [o.detach().clone() for o in outs], xs, masks, f"graph replay {rep} with dropout")
