@@ -255,7 +255,9 @@ class Leg:
     fixed variants of the same workload family)."""
 
     def __init__(self, config="cfg2", steps=50, warmup=10, batch=None, ragged=False, fresh_lengths=False, eager=False, graph=False,
-                 profile_all=False, drop_prob=0.0, dtype=None):
+                 profile_all=False, drop_prob=0.0, dtype=None, regions=1):
+        self.regions = regions      # timed regions of `steps` steps each; the fastest is reported (secondary legs only: one host hiccup
+        #                             inside a 45-ms region once made a leg read 20 % slow; the headline leg times ONE region, as contracted)
         self.config, self.steps, self.warmup, self.batch = config, steps, warmup, batch
         self.ragged, self.fresh_lengths, self.eager, self.graph = ragged, fresh_lengths, eager, graph
         self.profile_all, self.drop_prob, self.dtype = profile_all, drop_prob, dtype
@@ -349,14 +351,17 @@ def run_leg(a, rank, world, local, dev):
     timed = ALL_KERNELS if a.profile_all else (ATT_GROUPS if fused_att else LSTM_GEMM_GROUPS)
     if graph is not None:
         timed = []          # the event pairs of the timing hook cannot be recorded inside a replayed graph: see below
-    fence()
-    _lib.profile_enable(timed)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    _lib.profile_enable([])
+    dt = None
+    for _ in range(max(1, getattr(a, "regions", 1))):
+        fence()
+        _lib.profile_enable(timed)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        fence()
+        d1 = time.perf_counter() - t0
+        _lib.profile_enable([])
+        dt = d1 if dt is None else min(dt, d1)
     # a persistent recurrence launch (H > 128) that timed out at its per-step barrier leaves invalid results; inside a replayed
     # graph nothing but this look at the status word can notice
     timeouts = _lib.persist_timeouts()
@@ -442,9 +447,9 @@ def run_leg(a, rank, world, local, dev):
 SECONDARY = [
     ("cfg4_long_sequences", Leg(config="cfg4", steps=5, warmup=2)),
     ("cfg5_h512_bf16", Leg(config="cfg5", steps=3, warmup=2)),
-    ("cfg2_ragged", Leg(config="cfg2", steps=20, warmup=5, ragged=True)),
-    ("cfg2_training_drop0.2", Leg(config="cfg2", steps=20, warmup=5, drop_prob=0.2)),
-    ("cfg2_eager_fresh_lengths", Leg(config="cfg2", steps=20, warmup=5, fresh_lengths=True)),
+    ("cfg2_ragged", Leg(config="cfg2", steps=20, warmup=5, ragged=True, regions=2)),
+    ("cfg2_training_drop0.2", Leg(config="cfg2", steps=20, warmup=5, drop_prob=0.2, regions=2)),
+    ("cfg2_eager_fresh_lengths", Leg(config="cfg2", steps=20, warmup=5, fresh_lengths=True, regions=2)),
 ]
 SECONDARY_BUDGET_S = 45.0
 
@@ -464,7 +469,8 @@ def run_secondary(rank, world, local, dev):
             del region
             r = out.get("roofline") or {}
             res[name] = {"workload": out["config"]["workload"], "launch": out["config"]["launch"], "dtype": out["dtype"],
-                         "steps": out["steps"], "warmup": out["warmup"], "ms_per_step": out["ms_per_step"], "value": out["value"],
+                         "steps": out["steps"], "warmup": out["warmup"], "timed_regions": getattr(leg, "regions", 1),
+                         "ms_per_step": out["ms_per_step"], "value": out["value"],
                          "unit": out["unit"],
                          "roofline": {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "us_per_step")} if r else None}
         except Exception as e:      # noqa: BLE001  (a secondary leg never costs the headline line)
