@@ -368,7 +368,7 @@ def run_leg(a, rank, world, local, dev):
     if timeouts > 0:
         raise _lib.PersistentRecurrenceTimeout(f"bench.py {a.config}: {timeouts} workgroup(s) of a persistent recurrence launch timed out "
                                                "inside the timed region: the step times are INVALID")
-    prof_steps = a.steps
+    prof_steps = a.steps * max(1, getattr(a, "regions", 1))      # (the library's event pairs accumulate over all timed regions)
     if graph is not None:
         # attention kernel times for the roofline figure: HIP events cannot bracket kernels inside a replayed graph, so the same
         # step is issued eagerly a few times right after the timed region, with the library's event pairs around the grouped

@@ -630,15 +630,32 @@ struct PrepArgs {
     int n, D, B;
 };
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float wave_allmax(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+// Whole-wave reductions on the DPP path: an inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), row 0 / 2 totals into
+// rows 1 / 3 (row_bcast:15), the lower half's total into the upper (row_bcast:31) -- lane 63 then holds the wave's value, read
+// back as a scalar.  6 vector instructions + 1 v_readlane; __shfl_xor compiles to ds_bpermute_b32 here (72 dependent LDS round
+// trips per wave in the split pass: found in round 4).  Lanes shifted in from outside a row, and rows a broadcast does not
+// reach, contribute 0: the identity of a sum and of a maximum of non-negative values (both uses).
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_mov0(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, BOUND));
+}
+__device__ __forceinline__ float wave_allmax(float v) {          // v >= 0
+    v = fmaxf(v, dpp_mov0<0x111, 0xf, true>(v));
+    v = fmaxf(v, dpp_mov0<0x112, 0xf, true>(v));
+    v = fmaxf(v, dpp_mov0<0x114, 0xf, true>(v));
+    v = fmaxf(v, dpp_mov0<0x118, 0xf, true>(v));
+    v = fmaxf(v, dpp_mov0<0x142, 0xa, false>(v));
+    v = fmaxf(v, dpp_mov0<0x143, 0xc, false>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_allsum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_mov0<0x111, 0xf, true>(v);
+    v += dpp_mov0<0x112, 0xf, true>(v);
+    v += dpp_mov0<0x114, 0xf, true>(v);
+    v += dpp_mov0<0x118, 0xf, true>(v);
+    v += dpp_mov0<0x142, 0xa, false>(v);
+    v += dpp_mov0<0x143, 0xc, false>(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // lane c (< 8 KT) holds features 4c..4c+3 of `row`; amax = the row's max |x| (wave-uniform)
 __device__ __forceinline__ void store_split_row(char* planes_b, float* inv_row, int row, int c, f4 x, float amax) {
