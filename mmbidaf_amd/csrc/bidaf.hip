@@ -586,14 +586,38 @@ __device__ __forceinline__ void stage_panel_w(char* panel, const char* planes_b,
     }
 }
 
+// Whole-wave reductions on the DPP path: an inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), row 0 / 2 totals into
+// rows 1 / 3 (row_bcast:15), the lower half's total into the upper (row_bcast:31) -- lane 63 then holds the wave's value, read
+// back as a scalar.  6 vector instructions + 1 v_readlane; __shfl_xor compiles to ds_bpermute_b32 here (72 dependent LDS round
+// trips per wave in the split pass: found in round 4).  Lanes shifted in from outside a row, and rows a broadcast does not
+// reach, contribute 0: the identity of a sum and of a maximum of non-negative values (both uses).
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_mov0(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, BOUND));
+}
+__device__ __forceinline__ float wave_allmax(float v) {          // v >= 0
+    v = fmaxf(v, dpp_mov0<0x111, 0xf, true>(v));
+    v = fmaxf(v, dpp_mov0<0x112, 0xf, true>(v));
+    v = fmaxf(v, dpp_mov0<0x114, 0xf, true>(v));
+    v = fmaxf(v, dpp_mov0<0x118, 0xf, true>(v));
+    v = fmaxf(v, dpp_mov0<0x142, 0xa, false>(v));
+    v = fmaxf(v, dpp_mov0<0x143, 0xc, false>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_allsum(float v) {
+    v += dpp_mov0<0x111, 0xf, true>(v);
+    v += dpp_mov0<0x112, 0xf, true>(v);
+    v += dpp_mov0<0x114, 0xf, true>(v);
+    v += dpp_mov0<0x118, 0xf, true>(v);
+    v += dpp_mov0<0x142, 0xa, false>(v);
+    v += dpp_mov0<0x143, 0xc, false>(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 // workgroup-wide maxima of NV_ non-negative per-thread values over NWV waves (red: >= NV_ * NWV floats of LDS)
 template <int NV_, int NWV>
 __device__ __forceinline__ void wg_allmax_w(float (&v)[NV_], float* red, int tid) {
 #pragma unroll
-    for (int k = 0; k < NV_; ++k) {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v[k] = fmaxf(v[k], __shfl_xor(v[k], o));
-    }
+    for (int k = 0; k < NV_; ++k) v[k] = wave_allmax(v[k]);
     __syncthreads();
     if ((tid & 63) == 0) {
 #pragma unroll
@@ -630,33 +654,6 @@ struct PrepArgs {
     int n, D, B;
 };
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-// Whole-wave reductions on the DPP path: an inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), row 0 / 2 totals into
-// rows 1 / 3 (row_bcast:15), the lower half's total into the upper (row_bcast:31) -- lane 63 then holds the wave's value, read
-// back as a scalar.  6 vector instructions + 1 v_readlane; __shfl_xor compiles to ds_bpermute_b32 here (72 dependent LDS round
-// trips per wave in the split pass: found in round 4).  Lanes shifted in from outside a row, and rows a broadcast does not
-// reach, contribute 0: the identity of a sum and of a maximum of non-negative values (both uses).
-template <int CTRL, int ROW_MASK, bool BOUND>
-__device__ __forceinline__ float dpp_mov0(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, BOUND));
-}
-__device__ __forceinline__ float wave_allmax(float v) {          // v >= 0
-    v = fmaxf(v, dpp_mov0<0x111, 0xf, true>(v));
-    v = fmaxf(v, dpp_mov0<0x112, 0xf, true>(v));
-    v = fmaxf(v, dpp_mov0<0x114, 0xf, true>(v));
-    v = fmaxf(v, dpp_mov0<0x118, 0xf, true>(v));
-    v = fmaxf(v, dpp_mov0<0x142, 0xa, false>(v));
-    v = fmaxf(v, dpp_mov0<0x143, 0xc, false>(v));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-__device__ __forceinline__ float wave_allsum(float v) {
-    v += dpp_mov0<0x111, 0xf, true>(v);
-    v += dpp_mov0<0x112, 0xf, true>(v);
-    v += dpp_mov0<0x114, 0xf, true>(v);
-    v += dpp_mov0<0x118, 0xf, true>(v);
-    v += dpp_mov0<0x142, 0xa, false>(v);
-    v += dpp_mov0<0x143, 0xc, false>(v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
 // lane c (< 8 KT) holds features 4c..4c+3 of `row`; amax = the row's max |x| (wave-uniform)
 __device__ __forceinline__ void store_split_row(char* planes_b, float* inv_row, int row, int c, f4 x, float amax) {
     // a NaN / infinity anywhere in the row (x - x != 0 exactly for those) poisons the row's inverse scale: every product the
