@@ -19,7 +19,7 @@ SHAPES = [
     ("dW mod L0   ", 800, 1000, 12800), ("dW mod L1   ", 800, 400, 12800), ("dW text-enc ", 800, 500, 12800),
     ("dW aud-enc  ", 800, 328, 8192), ("dW img-enc  ", 800, 300, 2048), ("gx img-enc  ", 2048, 800, 100),
     ("dx aud-enc  ", 8192, 128, 800), ("gx cfg4 L0  ", 51200, 800, 800), ("dW cfg4 L0  ", 800, 1000, 51200),
-    ("gx cfg1 L0  ", 150, 800, 800), ("dW cfg1 L0  ", 800, 1000, 150),
+    ("gx cfg1 L0  ", 150, 800, 800),
 ]
 lib = _lib.load()
 ALL = []
