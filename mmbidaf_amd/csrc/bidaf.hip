@@ -431,8 +431,17 @@ struct RowScalar {
     const float* p;       // element of row 0 (already offset to the sample), or null: mask code
     int stride;           // floats per row
     float dflt;           // value beyond the range (plain floats; a reciprocal gives 0 there)
-    int op;               // 0 plain, 1 reciprocal, 2 mask code 0 / 1 / 2 (beyond / masked / live), 3 mask -1 / 0 / 1
+    int op;               // 0 plain, 1 reciprocal, 2 mask code 0 / 1 / 2 (beyond / masked / live), 3 mask -1 / 0 / 1,
+                          // 4 reciprocal of a softmax's sum of exponentials, NEGATED when that sum is exactly 1 (see onehot_inv)
 };
+// A softmax whose saved sum of exponentials is exactly 1 is one-hot (one live element, or every other exponential underflowed):
+// its Jacobian is exactly zero, and torch's softmax backward P (dP - sum P dP) cancels to the bit there, while the fused backward
+// takes delta from the flash-attention identity and dP from the matrix cores -- fp32 round-off of |dP| per element instead of 0,
+// which the sums over 400 rows into d_w_m / d_w_t turned into 5e-4..1e-3 absolute when every sample is degenerate (M = 1 or
+// T = 1).  The gradient sweeps therefore take the softmax-gradient term of such a row / column as exactly 0: on the
+// lane side its reciprocal sum becomes 0 (the probability is used for nothing else there), on the streamed side the reciprocal
+// travels with a NEGATIVE sign -- |P| still weights the PV product, max(P, 0) = 0 gates the gradient term (one v_max per element).
+__device__ __forceinline__ float onehot_inv(float sum) { return sum == 1.0f ? -1.0f : 1.0f / sum; }
 struct RowMask {
     const uint8_t* mask;  // sample's row of the u8 mask, or null with the length
     int len;
@@ -449,6 +458,7 @@ __device__ __forceinline__ float row_scalar_value(const RowScalar& rs, unsigned 
     switch (rs.op) {
         case 0: return in ? __uint_as_float(raw) : rs.dflt;
         case 1: return in ? 1.0f / __uint_as_float(raw) : 0.f;
+        case 4: return in ? onehot_inv(__uint_as_float(raw)) : 0.f;
         case 2: return in ? (raw ? 2.f : 1.f) : 0.f;
         default: return in ? (raw ? 1.f : 0.f) : -1.f;
     }
@@ -1527,7 +1537,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     switch (skind) {
         case 0: rs.p = A.rterm + (size_t)b * T; break;
         case 1: rs.p = A.row_stat + (size_t)b * T * 2; rs.stride = 2; rs.dflt = INFINITY; break;          // exp(x - inf) = 0 beyond the range
-        case 2: rs.p = A.row_stat + (size_t)b * T * 2 + 1; rs.stride = 2; rs.dflt = INFINITY; rs.op = 1; break;
+        case 2: rs.p = A.row_stat + (size_t)b * T * 2 + 1; rs.stride = 2; rs.dflt = INFINITY; rs.op = 4; break;
         case 3: rs.p = A.delta1 + (size_t)b * T; break;
         case 4: rs.op = 2; break;
         case 5: rs.p = iTd_b; break;
@@ -1582,7 +1592,8 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
         const float inM = nin ? A.iM[(size_t)b * Mp + n] : 0.f, inQ = nin ? A.iQ[(size_t)b * Mp + n] : 0.f;
         const float cterm = nin ? A.cterm[(size_t)b * M + n] : 0.f;
         const float cmax = nin ? A.col_stat[((size_t)b * M + n) * 2] : 0.f;
-        const float cinv = nin ? 1.0f / A.col_stat[((size_t)b * M + n) * 2 + 1] : 0.f;
+        // (a one-hot column softmax has no gradient: P2 serves nothing but that term in this sweep)
+        const float cinv = nin ? fmaxf(onehot_inv(A.col_stat[((size_t)b * M + n) * 2 + 1]), 0.f) : 0.f;
         const float delta2 = nin ? A.delta2[(size_t)b * M + n] : 0.f;
         const bool mm = nin ? mask_live(A.mod_mask, A.mod_len, b, M, n) : false;
         const float mmf = mm ? 1.f : 0.f;
@@ -1635,11 +1646,12 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
                 for (int e = 0; e < 4; ++e) {
                     const float code = s_code[e];
                     const float xr = c1[mb][e] * (s_sTd[e] * inS) + s_rt[e] + cterm;
-                    const float P1 = __expf((mm ? xr : NEG) - s_rmax[e]) * s_rinv[e];     // 0 beyond the range (rinv = 0)
+                    const float P1s = __expf((mm ? xr : NEG) - s_rmax[e]) * s_rinv[e];    // 0 beyond the range (rinv = 0); < 0: one-hot row
+                    const float P1 = fabsf(P1s);
                     const float P2 = code != 0.f ? __expf((code == 2.f ? xr : NEG) - cmax) * cinv : 0.f;
-                    const float g1 = P1 * (dp1[e] - s_dl1[e]) * mmf;
+                    const float g1 = fmaxf(P1s, 0.f) * (dp1[e] - s_dl1[e]) * mmf;
                     const float g2 = code == 2.f ? P2 * (c2[mb][e] * (s_sT[e] * inDq) - delta2) : 0.f;
-                    dc += g1 + g2;
+                    dc += g1;          // sum_i g2_ij = 0 identically (a softmax gradient sums to zero along its axis): only round-off to add
                     wc[mb][e] = P1 * (s_sDa[e] * cDa);
                     wd[mb][e] = (g1 + g2) * (s_sTd[e] * cS);
                 }
@@ -1904,7 +1916,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     switch (skind) {
         case 0: rs.p = A.cterm + (size_t)b * M; break;
         case 1: rs.p = A.col_stat + (size_t)b * M * 2; rs.stride = 2; break;
-        case 2: rs.p = A.col_stat + (size_t)b * M * 2 + 1; rs.stride = 2; rs.dflt = INFINITY; rs.op = 1; break;
+        case 2: rs.p = A.col_stat + (size_t)b * M * 2 + 1; rs.stride = 2; rs.dflt = INFINITY; rs.op = 4; break;
         case 3: rs.p = A.delta2 + (size_t)b * M; break;
         case 4: rs.op = 3; break;                    // modality mask, -1 beyond M
         case 5: rs.p = iMd_b; break;                 // streamed similarity operand (= mod without dropped copies)
@@ -1960,7 +1972,8 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
         }
         const float rterm = nin ? A.rterm[(size_t)b * T + n] : 0.f;
         const float rmax = nin ? A.row_stat[((size_t)b * T + n) * 2] : 0.f;
-        const float rinv = nin ? 1.0f / A.row_stat[((size_t)b * T + n) * 2 + 1] : 0.f;
+        // (a one-hot row softmax has no gradient: P1 serves nothing but that term in this sweep)
+        const float rinv = nin ? fmaxf(onehot_inv(A.row_stat[((size_t)b * T + n) * 2 + 1]), 0.f) : 0.f;
         const float dl1 = nin ? A.delta1[(size_t)b * T + n] : 0.f;
         const bool tm = nin ? mask_live(A.text_mask, A.text_len, b, T, n) : false;
         const float tmf = tm ? 1.f : 0.f;
@@ -2011,10 +2024,11 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
                     const float mf = s_mf[e];
                     const float x = c1[mb][e] * (s_sSp[e] * inS) + rterm + s_ct[e];
                     const float P1 = mf >= 0.f ? __expf((mf > 0.f ? x : NEG) - rmax) * rinv : 0.f;
-                    const float P2 = mf >= 0.f ? __expf((tm ? x : NEG) - s_cmax[e]) * s_cinv[e] : 0.f;
+                    const float P2s = mf >= 0.f ? __expf((tm ? x : NEG) - s_cmax[e]) * s_cinv[e] : 0.f;    // < 0: one-hot column
+                    const float P2 = fabsf(P2s);
                     const float g1 = mf > 0.f ? P1 * (dp1[e] - dl1) : 0.f;
-                    const float g2 = P2 * (c2[mb][e] * (s_sDq[e] * inT) - s_dl2[e]) * tmf;
-                    dr += g1 + g2;
+                    const float g2 = fmaxf(P2s, 0.f) * (c2[mb][e] * (s_sDq[e] * inT) - s_dl2[e]) * tmf;
+                    dr += g2;          // sum_j g1_ij = 0 identically (see the j sweep)
                     wt[mb][e] = P2 * (s_sDq[e] * cDq);
                     wx[mb][e] = (g1 + g2) * (s_sMd[e] * cS);
                 }

@@ -72,7 +72,8 @@ class _Plan:
         # LSTM problems: (tag, T, I, has hn_pos-ordered h_n)
         self.lstm = [("et", T, H), ("ea", Ma, H), ("ei", Mi, H), ("a0", T, 8 * H), ("i0", T, 8 * H), ("a1", T, 2 * H), ("i1", T, 2 * H)]
         for tag, Tn, I in self.lstm:
-            keep.add(tag + ".y", B * Tn * D * f)
+            if tag not in ("a1", "i1"):      # layer 1's y is the region's output: a tensor of its own (see _RegionFn.forward)
+                keep.add(tag + ".y", B * Tn * D * f)
             keep.add(tag + ".gates", B * Tn * 8 * H * f)
             keep.add(tag + ".cs", B * Tn * D * f)
             keep.add(tag + ".hn", 2 * B * H * f)
@@ -169,6 +170,7 @@ def _plan(B, T, Ma, Mi, H, drop):
 
 # ---- per-lengths device metadata: [len_t | len_a | len_i | pos_t | pos_a | pos_i] int32, one pinned copy
 _meta_cache = {}
+_meta_captured = []      # metadata vectors a captured hipGraph holds the raw address of: never evicted (a replay does not touch the LRU)
 
 
 def _meta(dev, lens3):
@@ -186,6 +188,8 @@ def _meta(dev, lens3):
         if len(_meta_cache) >= 256:
             _meta_cache.pop(next(iter(_meta_cache)))
     _meta_cache[key] = m
+    if torch.cuda.is_current_stream_capturing() and not any(t is m for t in _meta_captured):
+        _meta_captured.append(m)       # (after 256 other length sets the LRU would free what the graph still reads)
     return m
 
 
@@ -391,7 +395,7 @@ def _build_templates(plan):
     F_, Bk = _lib.LstmFwdDesc, _lib.LstmBwdDesc
     tm = {}
 
-    def fwd(tags, x_src):
+    def fwd(tags, x_src, y_dyn=False):
         t = _Tmpl(F_, len(tags))
         for i, tag in enumerate(tags):
             q = _P_LSTM[tag]
@@ -407,13 +411,16 @@ def _build_templates(plan):
                     t.param(i, fld, q + 4 * dir_ + j, k=dir_)
             for fld, base, name in (("y", "keep", ".y"), ("h_n", "keep", ".hn"), ("gates", "keep", ".gates"), ("cs", "keep", ".cs"),
                                     ("x_absmax", "keep", ".absmax"), ("c_n", "scr", ".cn"), ("gx", "scr", ".gx"), ("ws", "scr", ".ws")):
+                if fld == "y" and y_dyn:
+                    t.dynamic(i, "y", f"y{i}")
+                    continue
                 t.ptr(i, fld, base, (ko if base == "keep" else so)[tag + name])
             t.ints(i, B=B, T=Tn[tag], I=In[tag], H=H)
         return t.freeze()
 
     tm["f_enc"] = fwd(("et", "ea", "ei"), [("dyn", "x0"), ("dyn", "x1"), ("dyn", "x2")])
     tm["f_l0"] = fwd(("a0", "i0"), [("keep", ko["aa.out"]), ("keep", ko["ai.out"])])
-    tm["f_l1"] = fwd(("a1", "i1"), [("dyn", "x0"), ("dyn", "x1")])
+    tm["f_l1"] = fwd(("a1", "i1"), [("dyn", "x0"), ("dyn", "x1")], y_dyn=True)
 
     def att(backward):
         t = _Tmpl(_lib.BidafDesc, 2)
@@ -451,7 +458,7 @@ def _build_templates(plan):
 
     tm["f_att"], tm["b_att"] = att(False), att(True)
 
-    def bwd(tags, x_src, dy_src):
+    def bwd(tags, x_src, dy_src, y_dyn=False):
         t = _Tmpl(Bk, len(tags))
         for i, tag in enumerate(tags):
             q = _P_LSTM[tag]
@@ -465,7 +472,10 @@ def _build_templates(plan):
             t.dynamic(i, "d_w_ih", f"d_w_ih{i}")
             t.dynamic(i, "d_w_hh", f"d_w_hh{i}")
             t.dynamic(i, "d_b", f"d_b{i}")
-            t.ptr(i, "y", "keep", ko[tag + ".y"])
+            if y_dyn:
+                t.dynamic(i, "y", f"y{i}")
+            else:
+                t.ptr(i, "y", "keep", ko[tag + ".y"])
             t.ptr(i, "lengths", "meta", len_off[tag])
             t.ptr(i, "hn_pos", "meta", pos_off[tag])
             t.param(i, "w_ih", q, k=0)
@@ -481,7 +491,7 @@ def _build_templates(plan):
             t.ints(i, B=B, T=Tn[tag], I=In[tag], H=H)
         return t.freeze()
 
-    tm["b_l1"] = bwd(("a1", "i1"), [("dyn", "x0"), ("dyn", "x1")], [("dyn", "dy0"), ("dyn", "dy1")])
+    tm["b_l1"] = bwd(("a1", "i1"), [("dyn", "x0"), ("dyn", "x1")], [("dyn", "dy0"), ("dyn", "dy1")], y_dyn=True)
     tm["b_l0"] = bwd(("a0", "i0"), [("keep", ko["aa.out"]), ("keep", ko["ai.out"])], [("bw", bo["a1.d_x"]), ("bw", bo["i1.d_x"])])
     tm["b_en"] = bwd(("et", "ea", "ei"), [("dyn", "x0"), ("dyn", "x1"), ("dyn", "x2")],
                      [("bw", bo["aa.d_text"]), ("bw", bo["aa.d_mod"]), ("bw", bo["ai.d_mod"])])
@@ -595,11 +605,15 @@ class _RegionFn(torch.autograd.Function):
             y0d = _masked_mul(lib, di, stream, [view(ko["a0.y"], (B, T, D)), view(ko["i0.y"], (B, T, D))], [masks["inter_a"], masks["inter_i"]], p=drop)
             held += y0d
             l1_in = (y0d[0].data_ptr(), y0d[1].data_ptr())
-        d_, w_ = tm["f_l1"].build(bases, pp, x0=l1_in[0], x1=l1_in[1])
+        # layer 1's y: tensors of their own, not views into the arena -- in eval mode they ARE the region's outputs, registered with
+        # save_for_backward below so that a caller's in-place write trips autograd's version check instead of silently corrupting the
+        # saved activations, and an output held under no_grad does not pin the arena
+        y1 = [torch.empty(B, T, D, device=dev, dtype=torch.float32), torch.empty(B, T, D, device=dev, dtype=torch.float32)]
+        d_, w_ = tm["f_l1"].build(bases, pp, x0=l1_in[0], x1=l1_in[1], y0=y1[0].data_ptr(), y1=y1[1].data_ptr())
         _lib.check(lib.mmb_bilstm_layer_fwd(d_, 2, di, stream), "mmb_bilstm_layer_fwd")
-        mod_out = [view(ko["a1.y"], (B, T, D)), view(ko["i1.y"], (B, T, D))]
+        mod_out = y1
         if drop:
-            mod_out = _masked_mul(lib, di, stream, mod_out, [masks["out_a"], masks["out_i"]], p=drop)
+            mod_out = _masked_mul(lib, di, stream, y1, [masks["out_a"], masks["out_i"]], p=drop)
         # ---- final hidden states (encoding.py:101-103) and the decoder's initial hidden state (models.py:143)
         hid_a = torch.empty(B, 4, H, device=dev, dtype=torch.float32)
         hid_i = torch.empty(B, 4, H, device=dev, dtype=torch.float32)
@@ -613,7 +627,7 @@ class _RegionFn(torch.autograd.Function):
         c.att_d, c.held = att_d, held
         c.need_dx = [bool(ctx.needs_input_grad[1 + i]) for i in range(3)]
         ctx.c = c
-        ctx.save_for_backward(*params)
+        ctx.save_for_backward(*params, *y1)
         ctx.set_materialize_grads(False)
         return (mod_out[0], hid_a, mod_out[1], hid_i, dec)
 
@@ -621,7 +635,7 @@ class _RegionFn(torch.autograd.Function):
     def backward(ctx, g_mod_a, g_hid_a, g_mod_i, g_hid_i, g_dec):
         lib = _lib.load()
         c = ctx.c
-        params = ctx.saved_tensors
+        params, y1 = ctx.saved_tensors[:64], ctx.saved_tensors[64:]
         plan, meta, drop, masks, keep = c.plan, c.meta, c.drop, c.masks, c.keep
         tm = plan.tm
         B, T, Ma, Mi, H = plan.dims
@@ -702,7 +716,8 @@ class _RegionFn(torch.autograd.Function):
             pa, ta = cot("a1", g_mod_a, (B, T, D), "out_a")
             pi, ti = cot("i1", g_mod_i, (B, T, D), "out_i")
         hold += [ta, ti]
-        L1, w1 = tm["b_l1"].build(bases, pp, x0=c.l1_in[0], x1=c.l1_in[1], dy0=pa, dy1=pi, d_hn0=dh["a1"], d_hn1=dh["i1"],
+        L1, w1 = tm["b_l1"].build(bases, pp, x0=c.l1_in[0], x1=c.l1_in[1], dy0=pa, dy1=pi, y0=y1[0].data_ptr(), y1=y1[1].data_ptr(),
+                                  d_hn0=dh["a1"], d_hn1=dh["i1"],
                                   **lstm_dyn(("a1", "i1"), (True, True)))
         L0, w0 = tm["b_l0"].build(bases, pp, d_hn0=dh["a0"], d_hn1=dh["i0"], **lstm_dyn(("a0", "i0"), (True, True)))
         EN, we = tm["b_en"].build(bases, pp, x0=c.xs[0].data_ptr(), x1=c.xs[1].data_ptr(), x2=c.xs[2].data_ptr(),
@@ -793,7 +808,7 @@ class _RegionFn(torch.autograd.Function):
         views = torch._C._nn.unflatten_dense_tensors(gflat, plan.grad_templates(dev))
         grads = [views[j] for j in gslot]
         dxs = [bview(bo[t + ".d_x"], (B, plan.Tn[t], H)) if nd else None for t, nd in zip(("et", "ea", "ei"), c.need_dx)]
-        ctx.c = None
+        # (ctx.c stays: a second backward through a retained graph reads the same saved arena; the graph's release frees it)
         return (None, *dxs, *grads)
 
 

