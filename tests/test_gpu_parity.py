@@ -1019,6 +1019,87 @@ def test_whole_model_golden_h100():
     assert _close_grads([(n, p) for n, p in model.named_parameters() if not n.startswith("image_keyframes_emb")], g, tol=3e-4) >= 100
 
 
+class _EMA:
+    """util.EMA of the reference (util.py:154-180) restated for the replay below: shadow <- (1 - d) p + d shadow with
+    d = min(decay, (1 + n) / (10 + n)), keyed by parameter name."""
+
+    def __init__(self, model, decay):
+        self.decay = decay
+        self.shadow = {n: p.data.clone() for n, p in model.named_parameters() if p.requires_grad}
+
+    def __call__(self, model, num_updates):
+        decay = min(self.decay, (1.0 + num_updates) / (10.0 + num_updates))
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                self.shadow[n] = ((1.0 - decay) * p.data + decay * self.shadow[n]).clone()
+
+
+def test_training_trajectory_golden_through_the_train_py_caller_contract():
+    """G9: three optimiser steps of the REFERENCE driven exactly as its train.py drives it (train.py:91-157), replayed through
+    the drop-in import path with the same caller code: `from models import MMBiDAF`, nn.DataParallel(model, gpu_ids) with the
+    device ids of the box (train.py:42,92 -- one GPU here, for which DataParallel scatters the arguments and calls the module),
+    model.train(), EMA(0.999), Adadelta(lr 0.5), constant LambdaLR, and per step zero_grad / forward with NEW lengths / loss.item()
+    / backward / clip_grad_norm_(2.0) / optimizer.step() / scheduler.step / ema.  Compared after EVERY step: the loss, the total
+    gradient norm clip_grad_norm_ returns, every parameter (projections), and at the end the EMA shadow.  Nothing in the caller
+    code is changed for the build: INTEGRATION.md's "replace DataParallel" only concerns N > 1 GPUs."""
+    import torch.nn as nn
+    import torch.optim as optim
+    import torch.optim.lr_scheduler as sched
+    from golden_recipe import fill_parameters, projections
+    from models import MMBiDAF
+    g = load_flat("g9_training_trajectory.npz")
+    d = dev()
+    gpu_ids = [0]                                   # util.get_available_devices() on a one-GPU box (util.py:115-128)
+    model = MMBiDAF(100, 24, 12, 20, d, 0.0, 60, image_backbone=_Stub(g["resnet_w"], g["resnet_b"]))
+    csum = fill_parameters(list(model.named_parameters()), seed=900, bound=0.3)     # (U(-0.3, 0.3): gradient norms of 4-5, so the clip at 2.0 acts)
+    assert abs(csum[1] - g["param_checksum"][1].item()) < 1e-4
+    assert float(g["grad_norms"].min()) > 2.0
+    model = nn.DataParallel(model, gpu_ids)
+    model = model.to(d)
+    model.train()
+    ema = _EMA(model, 0.999)
+    optimizer = optim.Adadelta(model.parameters(), 0.5, weight_decay=0)
+    scheduler = sched.LambdaLR(optimizer, lambda s_: 1.)
+    step = 0
+    n_steps = int(g["n_steps"])
+    import warnings
+    for k in range(n_steps):
+        batch_text, batch_audio, batch_images = g[f"s{k}__text"].to(d), g[f"s{k}__audio"].to(d), g[f"s{k}__images"].to(d)
+        batch_target_indices = g[f"s{k}__targets"].to(d)
+        tl, al, il = g[f"s{k}__text_len"].tolist(), g[f"s{k}__audio_len"].tolist(), g[f"s{k}__image_len"].tolist()
+        original_target_len = torch.tensor([batch_target_indices.size(1)] * batch_text.size(0))
+        max_dec_len = torch.max(original_target_len)
+        batch_size = batch_text.size(0)
+        optimizer.zero_grad()
+        _, loss = model(batch_text, tl, batch_audio, al, batch_images, il, batch_target_indices, original_target_len, max_dec_len)
+        loss_val = loss.item()
+        loss.backward()
+        norm = float(nn.utils.clip_grad_norm_(model.parameters(), 2.0))
+        optimizer.step()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            scheduler.step(step // batch_size)
+        ema(model, step // batch_size)
+        step += batch_size
+        close(torch.tensor(loss_val), g["losses"][k].float().reshape(()), f"step {k} loss")
+        close(torch.tensor(norm), g["grad_norms"][k].float().reshape(()), f"step {k} gradient norm")
+        n_cmp = 0
+        for n, p in model.named_parameters():
+            if not p.requires_grad or "image_keyframes_emb" in n:
+                continue
+            for kind, v in projections(n, p.data).items():
+                # parameters are O(0.1) and move by <= ~3e-3 per Adadelta step: absolute 2e-5 on the projections (sums over up to
+                # 800 entries against N(0,1) vectors) holds every entry's trajectory to ~1e-6
+                close(v, g[f"s{k}__param__{n}__{kind}"], f"step {k} {n} ({kind})", tol=2e-5, absolute=True)
+                n_cmp += 1
+        assert n_cmp >= 200
+    for n, v in ema.shadow.items():
+        if "image_keyframes_emb" in n:
+            continue
+        for kind, pv in projections(n, v).items():
+            close(pv, g[f"ema__{n}__{kind}"], f"ema {n} ({kind})", tol=2e-5, absolute=True)
+
+
 # ------------------------------------------------------------------------------------------- region at the BASELINE.json configs
 def _region_vs_oracle(shape, ragged=True, seed=224, lengths=None, grads=True, tol=TOL, absolute=True):
     """HotRegion on the GPU vs oracle.HotRegionCPU (the reference's op sequence on torch CPU): the 5 outputs and the input

@@ -306,20 +306,91 @@ def gen_model_h100(ref_models):
     _save("g8_model_h100", **out)
 
 
+def gen_training_trajectory(ref_models, ref_util):
+    """G9: THREE optimiser steps of the reference exactly as its training driver takes them (train.py:91-157): the model wrapped
+    in nn.DataParallel with the device ids util.get_available_devices() reports (train.py:42,92 -- none on this CPU: the wrapper
+    then calls the module directly), model.train(), util.EMA(model, 0.999) (train.py:100, args.py:47), Adadelta(lr 0.5, weight
+    decay 0) (train.py:110, args.py:17-24), constant LambdaLR (train.py:111); per step: zero_grad, forward, loss.item(),
+    backward, clip_grad_norm_(2.0) (train.py:154, args.py:41), optimizer.step(), scheduler.step(step // batch_size),
+    ema(model, step // batch_size), step += batch_size (train.py:141-160).  cfg-1 shapes, the model's H = 100, drop_prob 0 (the one
+    thing that is not train.py:210's: dropout draws cannot be replayed across devices), parameters by the shared recipe.
+    Stored: the inputs, the loss of every step, and after every step the projections (tests/golden_recipe.py) of every
+    parameter; after the last step also those of the EMA shadow and the total gradient norms clip_grad_norm_ returned."""
+    import torch.optim as optim
+    import torch.optim.lr_scheduler as sched
+    from golden_recipe import fill_parameters, projections
+    B, T, Ma, Mi, H = 3, 50, 32, 8, 100
+    Et, Ea, Ei = 24, 12, 20
+    device, gpu_ids = ref_util.get_available_devices()
+    model = ref_models.MMBiDAF(H, Et, Ea, Ei, device, 0.0, 60)
+    csum = fill_parameters(list(model.named_parameters()), seed=900, bound=0.3)
+    model = nn.DataParallel(model, gpu_ids)
+    model = model.to(device)
+    model.train()
+    ema = ref_util.EMA(model, 0.999)
+    optimizer = optim.Adadelta(model.parameters(), 0.5, weight_decay=0)
+    scheduler = sched.LambdaLR(optimizer, lambda s: 1.)
+    g = torch.Generator().manual_seed(901)
+    n_steps, dec_steps = 3, 9
+    out = dict(param_checksum=np.asarray(csum, dtype=np.float64), n_steps=np.asarray(n_steps),
+               resnet_w=_np(model.module.image_keyframes_emb.resnet.fc.weight), resnet_b=_np(model.module.image_keyframes_emb.resnet.fc.bias))
+    lens = [([50, 31, 17], [32, 20, 9], [8, 5, 2]), ([44, 50, 9], [32, 7, 25], [3, 8, 8]), ([50, 50, 26], [11, 32, 32], [8, 1, 6])]
+    step = 0
+    losses, norms = [], []
+    for k in range(n_steps):
+        text = torch.randn(B, T, Et, generator=g)
+        audio = torch.randn(B, Ma, Ea, generator=g)
+        images = torch.randn(B, Mi, 3, 4, 4, generator=g)
+        targets = torch.randint(0, 9, (B, dec_steps, 1), generator=g).float()
+        tl, al, il = lens[k]
+        out.update({f"s{k}__text": _np(text), f"s{k}__audio": _np(audio), f"s{k}__images": _np(images), f"s{k}__targets": _np(targets),
+                    f"s{k}__text_len": np.asarray(tl), f"s{k}__audio_len": np.asarray(al), f"s{k}__image_len": np.asarray(il)})
+        original_target_len = torch.tensor([dec_steps] * B)
+        max_dec_len = torch.max(original_target_len)
+        batch_size = text.size(0)
+        optimizer.zero_grad()
+        _, loss = model(text, tl, audio, al, images, il, targets, original_target_len, max_dec_len)
+        losses.append(loss.item())
+        loss.backward()
+        norms.append(float(nn.utils.clip_grad_norm_(model.parameters(), 2.0)))
+        optimizer.step()
+        scheduler.step(step // batch_size)
+        ema(model, step // batch_size)
+        step += batch_size
+        for n, p in model.named_parameters():
+            if p.requires_grad and "image_keyframes_emb" not in n:
+                for kind, v in projections(n, p.data).items():
+                    out[f"s{k}__param__{n}__{kind}"] = _np(v)
+    for n, v in ema.shadow.items():
+        if "image_keyframes_emb" not in n:
+            for kind, pv in projections(n, v).items():
+                out[f"ema__{n}__{kind}"] = _np(pv)
+    out["losses"] = np.asarray(losses, dtype=np.float64)
+    out["grad_norms"] = np.asarray(norms, dtype=np.float64)
+    _save("g9_training_trajectory", **out)
+
+
 def main():
     sys.path.insert(0, OUT[:-len("golden")])   # tests/: golden_recipe.py
     _install_torchvision_stub()
+    import json as _json
+    sys.modules.setdefault("ujson", _json)     # util.py:13 imports ujson (absent here; used by nothing G9 touches): the stdlib module stands in
     sys.path.insert(0, REF)
     import layers.attention as ref_att
     import layers.encoding as ref_enc
     import models as ref_models
+    import util as ref_util
     torch.set_num_threads(1)  # fixed summation order on the generating side
-    gen_masked_softmax(ref_att)
-    gen_attention(ref_att)
-    gen_rnn(ref_enc)
-    gen_hot_region(ref_models)
-    gen_rnn_modelling_shape(ref_enc)
-    gen_model_h100(ref_models)
+    only = sys.argv[1:]
+    if not only or "g1-g8" in only:
+        gen_masked_softmax(ref_att)
+        gen_attention(ref_att)
+        gen_rnn(ref_enc)
+        gen_hot_region(ref_models)
+        gen_rnn_modelling_shape(ref_enc)
+        gen_model_h100(ref_models)
+    if not only or "g9" in only:
+        gen_training_trajectory(ref_models, ref_util)
 
 
 if __name__ == "__main__":
