@@ -449,7 +449,7 @@ struct RowMask {
 // the load (from a clamped row: never guarded, so nothing has to wait for it here) ...
 __device__ __forceinline__ unsigned row_scalar_fetch(const RowScalar& rs, const RowMask& rm, int t, int R) {
     const int tc = min(t, R - 1);
-    if (rs.op >= 2) return rm.mask ? (unsigned)rm.mask[tc] : (tc < rm.len ? 1u : 0u);
+    if (rs.op == 2 || rs.op == 3) return rm.mask ? (unsigned)rm.mask[tc] : (tc < rm.len ? 1u : 0u);
     return __float_as_uint(rs.p[(size_t)tc * rs.stride]);
 }
 // ... and the value of row t that goes into LDS, one iteration later
