@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMB_VERSION 404            /* round 4 ABI: + persistent-recurrence reset / enable, mmb_stream_occupy, attention phase stamps, mmb_masked_mul / _sum */
+#define MMB_VERSION 500            /* round 5 ABI: + mmb_bilstm_layer_fwd_phase (streamed input projection) */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
 #define MMB_ATT_MAX_D 208          /* attention feature width D = 2H of the fused (register-resident) kernels */
 #define MMB_ATT_GENERAL_MAX_D 4096 /* wider D (up to this) runs the general path: similarity matrix in a workspace */
@@ -199,6 +199,28 @@ size_t mmb_bilstm_absmax_floats(int B, int T, int H);
 size_t mmb_bilstm_ws_bytes(int B, int T, int I, int H, int backward);
 
 int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* descs, int n, int device, void* stream);
+
+/* The same layer call with a STREAMED input projection, in three separately enqueued parts (register-resident recurrence:
+ * H <= MMB_LSTM_MAX_H; ws and x_absmax required; n <= MMB_MAX_GROUP / 2).  The projection Gx = x . W_ih^T (reference: inside
+ * torch.nn.LSTM, layers/encoding.py:79-81,96) is cut into K time chunks per direction, taken from both ends of the sequences
+ * inwards -- the order in which the two directions of the recurrence consume them:
+ *   MMB_LSTM_FWD_HEAD  on `stream`: weight planes, the first KH chunks of the x planes and of Gx, zeroed progress words;
+ *   MMB_LSTM_FWD_REC   on the same stream: the recurrence, which starts at once and waits (bounded) only for a chunk that has
+ *                      not been published yet;
+ *   MMB_LSTM_FWD_TAIL  on a SECOND stream that the caller has ordered behind HEAD (an event recorded after the HEAD call): a
+ *                      gate that lets the recurrence's workgroups take their CUs first, then chunks KH..K-1, each published
+ *                      as its GEMM completes.  The caller joins the second stream into the first afterwards.
+ * The recurrence keeps 2 B n of the 256 CUs busy; the tail's GEMMs run on the others beside it.  desc.gx is scratch of the same
+ * size as for mmb_bilstm_layer_fwd (laid out (2,T,B,H,4) here); every other output is identical -- bit for bit -- to the
+ * one-launch form.  All three calls take the same descriptors and the same K, KH:
+ *   phase = MMB_LSTM_FWD_HEAD | MMB_LSTM_FWD_CHUNKS(K, KH)      2 <= K <= 64, 1 <= KH < K.
+ * TAIL enqueued on the SAME stream as REC can never run before it: REC's waits then give up after 2 s, the step's results are
+ * invalid and mmb_lstm_persist_timeouts() says so (as for the persistent recurrence below). */
+#define MMB_LSTM_FWD_HEAD 1
+#define MMB_LSTM_FWD_REC 2
+#define MMB_LSTM_FWD_TAIL 4
+#define MMB_LSTM_FWD_CHUNKS(K, KH) (((K) << 8) | ((KH) << 16))
+int mmb_bilstm_layer_fwd_phase(const mmb_lstm_fwd_desc* descs, int n, int phase, int device, void* stream);
 
 typedef struct {
     /* inputs */

@@ -16,7 +16,7 @@ ATT_GENERAL_MAX_D = 4096     # general path (similarity matrix in a workspace)
 LSTM_MAX_H = 128            # register-resident recurrence (one launch per layer)
 LSTM_GENERAL_MAX_H = 1024   # general recurrence (one launch per time step)
 
-ABI_VERSION = 404           # MMB_VERSION the signatures below were written for (include/mmbidaf.h)
+ABI_VERSION = 500           # MMB_VERSION the signatures below were written for (include/mmbidaf.h)
 
 c_f = ctypes.c_void_p  # device pointers travel as raw addresses
 c_i = ctypes.c_int
@@ -89,6 +89,7 @@ SIGNATURES = {
     "mmb_bidaf_group_fwd": (c_i, [ctypes.POINTER(BidafDesc), c_i, c_i, c_i, c_i, c_f]),
     "mmb_bidaf_group_bwd": (c_i, [ctypes.POINTER(BidafDesc), c_i, c_i, c_i, c_i, c_f]),
     "mmb_bilstm_layer_fwd": (c_i, [ctypes.POINTER(LstmFwdDesc), c_i, c_i, c_f]),
+    "mmb_bilstm_layer_fwd_phase": (c_i, [ctypes.POINTER(LstmFwdDesc), c_i, c_i, c_i, c_f]),
     "mmb_bilstm_layer_bwd": (c_i, [ctypes.POINTER(LstmBwdDesc), c_i, c_i, c_f]),
     "mmb_bilstm_layer_bwd_phase": (c_i, [ctypes.POINTER(LstmBwdDesc), c_i, c_i, c_i, c_f]),
     "mmb_gemm_f32": (c_i, [c_f] * 4 + [c_i] * 10 + [c_f]),

@@ -138,6 +138,11 @@ struct SplitRowsArgs {
     // can also be read k-major (transpose reads) by a GEMM that contracts over the ROWS (PlanesGemmArgs::ta)
     const float* tensor_absmax; int tensor_absmax_n;
     int Rpad;            // rows of zeros written beyond R up to this many rows (0: to the end of the last 16-row block)
+    // time-major row order (perm_B > 0): plane row t * perm_B + b is source row b * perm_T + t -- the planes of a (B,T,C) tensor with
+    // the rows of one time step adjacent, so that a time chunk is ONE contiguous run of plane rows (the streamed input projection
+    // of lstm.hip); and a pass over part of the row blocks only: [rb0, rb0 + nrb) (nrb == 0: all of them)
+    int perm_B, perm_T;
+    int rb0, nrb;
 };
 struct SplitTArgs {
     int nseg;
@@ -167,6 +172,7 @@ struct PlanesGemmArgs {
                      // then forms its A fragments with transposing LDS reads (ds_read_b64_tr_b16).  np == 2 only; K % 32 == 0
                      // rows must exist (zero padding); tile shapes with BM % 32 == 0
     int prezeroed;   // C is already zero (a split pass did it): skip the memset a K split needs
+    int no_splitk;   // never split K (no atomics: the summation order, hence the result bit for bit, is that of the unsplit product)
     int splitk;      // set by planes_gemm
     int dbg;      // timing-only ablation (MMB_PLANES_DBG): 2 = no MFMA
 };
@@ -205,6 +211,7 @@ size_t lstm_fs_bwd_ws_bytes(int B, int T, int H);
 int lstm_fs_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* ws, hipStream_t stream);
 int lstm_fs_bwd(const mmb_lstm_bwd_desc* d, int n, char* const* ws, hipStream_t stream, bool* db_done);
 int lstm_fs_timeouts();   // persistent recurrence: value of the time-out word (0 on a healthy process; -1: no pinned memory)
+unsigned* lstm_timeout_word();   // the word itself (host-pinned, device-visible), or null
 int lstm_fs_reset_timeouts();     // clears the word, returns what it held
 int lstm_fs_set_persist(int on);  // 0: launch-per-step kernels only; returns the previous setting
 int lstm_big_fwd(const mmb_lstm_fwd_desc* d, int n, char* const* big_ws, hipStream_t stream);

@@ -87,16 +87,56 @@ struct RecFwdProb {
     const int* hn_pos;     // (B) or null
     char* dbg_planes;      // timing experiment only (DBG & 4, tools/lstm_bench.py variant 5): where h is ALSO written as fp16 planes
     int B, T, H, wg_begin;
+    int chunk, nchunks;    // streamed projection (STREAM kernels): time steps per interval of this problem and their number; gx is then (2,T,B,H,4)
 };
 struct RecFwdArgs {
     RecFwdProb p[MMB_MAX_GROUP];
     int n;
+    // streamed projection: [0] chunks published so far by the tail, [1] workgroups of this launch that have started (the
+    // side stream's gate waits for them), [2] set when a bounded wait gave up; the chunks complete at launch; their number
+    unsigned* sync;
+    unsigned* tmo_host;    // host-visible time-out word (the persistent recurrence's, lstm_fs.hip)
+    int chunks_ready, chunks_total, gate_wgs;
 };
+
+// ---- streamed input projection (round 5).  The projection Gx = x . W_ih^T of a layer call is 46-145 us of full-chip work in front
+// of a recurrence that keeps 2 B n of the 256 CUs busy for 200 us.  In the streamed form the projection is cut into time chunks;
+// the head chunks are computed before the recurrence starts, the others BESIDE it on a second stream (mmb_bilstm_layer_fwd_phase),
+// and the recurrence consumes them as they are published: a chunk's GEMM kernel has completed (its stores are written back
+// at the kernel boundary), a one-thread kernel behind it stores the count of finished chunks with an agent-scope atomic, and
+// the recurrence polls that word and reads Gx with sc1 loads (L2-served: this CU's L1 is never asked for a line another kernel
+// wrote while this one was running) -- MI355X_MICROARCH.md, inter-workgroup visibility, the counter form with sc1 loads.
+// Every wait is bounded; a wait that gives up marks the step invalid through the host-visible time-out word.
+__device__ __forceinline__ unsigned ld_sc1_u32(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1_f32(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr long long STREAM_WAIT_TICKS = 200000000LL;   // 2 s of the 100-MHz wall clock
+// wait until `need` chunks are published; returns the published count (>= need unless the wait gave up)
+__device__ __forceinline__ unsigned stream_wait_chunks(const RecFwdArgs& args, unsigned need) {
+    unsigned have = ld_sc1_u32(args.sync);
+    if (have >= need) return have;
+    const long long t0 = wall_clock64();
+    while (true) {
+        __builtin_amdgcn_s_sleep(4);
+        have = ld_sc1_u32(args.sync);
+        if (have >= need) return have;
+        if (wall_clock64() - t0 > STREAM_WAIT_TICKS) {
+            if ((threadIdx.x & 63) == 0) {
+                __hip_atomic_store(args.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (args.tmo_host) __hip_atomic_fetch_add(args.tmo_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return need;      // give up: the step's results are invalid, the host learns it from the time-out word
+        }
+    }
+}
 
 // DBG (timing-only ablations, never used by the product path): 1 = skip the per-step global stores, 2 = skip the gx loads,
 // 4 = ALSO write h as the two fp16 planes (fixed scale 2^13, |h| < 1) of the next layer's projection operand, in the tiled
 //     layout of planes.hip (what the producer-written planes cost the recurrence)
-template <int KQ, int PFD = PF, int DBG = 0>
+template <int KQ, int PFD = PF, int DBG = 0, bool STREAM = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_rec_fwd_kernel(const RecFwdArgs args) {
     constexpr int KQP = (KQ + 3) & ~3;
     __shared__ __attribute__((aligned(16))) float hbuf[2][4][KQP];
@@ -113,6 +153,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // threads beyond 4H (the block is rounded up to whole waves) shadow unit H-1: they compute and store exactly
     // the same values to the same addresses, so the step loop needs no "live" predicate at all
     const int u = min(tid >> 2, H - 1);
+    if (STREAM && tid == 0 && (int)blockIdx.x < args.gate_wgs)      // "resident": what the side stream's gate counts
+        __hip_atomic_fetch_add(args.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- W_hh slice into registers.  Accumulator j of lane kq belongs to gate (kq + j) & 3 (ROTATED order, see the reduction in
     // step()), and every weight already carries the factor its gate's sigmoid needs in front of v_exp_f32 (-log2 e; -2 log2 e
@@ -141,7 +183,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int rev = dir;
     const int t0 = rev ? len - 1 : 0;
     const int sgn = rev ? -1 : 1;
-    const float* gx_b = P.gx + (size_t)b * T * 8 * H;       // (T, 2, H, 4)
+    // classic: (B,T,2,H,4), the sample's slab; streamed: (2,T,B,H,4), the direction's slab offset to the sample
+    const float* gx_b = STREAM ? P.gx + ((size_t)dir * T * P.B + b) * 4 * H : P.gx + (size_t)b * T * 8 * H;
     float* gates_b = P.gates + (size_t)b * T * 8 * H;
     float* cs_b = P.cs + (size_t)b * T * 2 * H;
     float* y_b = P.y + (size_t)b * T * 2 * H;
@@ -236,12 +279,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // prefetch ring: gxr[j] holds gx of step (s + j); refills are unconditional loads from a clamped step index, so the
     // main loop body is straight-line code and the compiler keeps counted vmcnt waits (see the note on the ring above)
-    const int gx_base = dir * 4 * H + u * 4 + kq;
-    auto gx_at = [&](int sidx) { return (DBG & 2) ? 0.01f * sidx : gx_b[(t0 + sgn * min(sidx, len - 1)) * 8 * H + gx_base]; };
+    const int gx_base = STREAM ? u * 4 + kq : dir * 4 * H + u * 4 + kq;
+    const int gx_tstride = STREAM ? P.B * 4 * H : 8 * H;      // elements from one time step to the next
+    auto gx_at = [&](int sidx) {
+        if (DBG & 2) return 0.01f * sidx;
+        const float* p = gx_b + (size_t)(t0 + sgn * min(sidx, len - 1)) * gx_tstride + gx_base;
+        return STREAM ? ld_sc1_f32(p) : *p;
+    };
+    // streamed projection: step s reads time row t0 + sgn s of interval (row / chunk); the tail publishes the intervals from both
+    // ends inwards.  `confirmed` launches are known to be complete; ensure(s_last) is called before any load of a step <= s_last is issued.
+    // The count is peeked one block (PFD steps) ahead of need with a load that stays in flight, so that a chunk crossing costs a
+    // compare when the producer is ahead; only a chunk that is really not there yet makes the workgroup wait.
+    const int chunk = STREAM ? max(P.chunk, 1) : 1;
+    const int nK = STREAM ? P.nchunks : 1;
+    unsigned confirmed = STREAM ? (unsigned)args.chunks_ready : 0u;
+    unsigned peek = 0u;
+    bool peeking = false;
+    // launches that must be complete before step s_last may be loaded: the time row's interval t / chunk, counted from the start
+    // (forward: launch k carries interval k) or from the end (reverse: launch k carries interval nK - 1 - k)
+    auto need_for = [&](int s_last) {
+        const int tt = t0 + sgn * min(s_last, len - 1);
+        return (unsigned)min(rev ? nK - tt / chunk : tt / chunk + 1, args.chunks_total);
+    };
+    auto ensure = [&](int s_last) {
+        if constexpr (STREAM) {
+            if (len <= 0) return;
+            if (peeking) { confirmed = max(confirmed, peek); peeking = false; }
+            const unsigned need = need_for(s_last);
+            if (need > confirmed) confirmed = max(confirmed, stream_wait_chunks(args, need));
+            if (need_for(s_last + PFD) > confirmed) { peek = ld_sc1_u32(args.sync); peeking = true; }
+        }
+    };
     float gxr[PFD];
     __syncthreads();
     int s = 0;
     auto block = [&](int s0) {     // PFD steps s0 .. s0 + PFD - 1, each refilling its slot for step + PFD
+        ensure(s0 + 2 * PFD - 1);
 #pragma unroll
         for (int j = 0; j < PFD; ++j) {
             const float seed = gxr[j] * act_in2;
@@ -252,11 +325,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     if (len >= PFD) {
+        ensure(PFD - 1);
 #pragma unroll
         for (int j = 0; j < PFD; ++j) gxr[j] = gx_at(j);
         block(0);                                        // peeled: see the note on the ring
         for (s = PFD; s + PFD <= len; s += PFD) block(s);
     }
+    ensure(len - 1);
     for (; s < len; ++s) step(gx_at(s) * act_in2);  // tail (< PF steps): synchronous loads
 
     if (tid < 4 * H) {
@@ -594,7 +669,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ p
 // ---- operand-plane scratch layout (planes.hip): byte offsets inside desc.ws
 static size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static bool planes_ok(int I, int H) { return I % 4 == 0 && H % 4 == 0 && gemm_mode() != 0; }
-struct WsFwd { size_t xP, wP, bias, xinv, winv, big, total; int Ip; };
+struct WsFwd { size_t xP, wP, bias, xinv, winv, sync, big, total; int Ip; };
 static WsFwd ws_fwd_layout(long BT, int B, int I, int H) {
     WsFwd w{};
     w.Ip = (int)rup(I, 32);
@@ -604,6 +679,7 @@ static WsFwd ws_fwd_layout(long BT, int B, int I, int H) {
     w.bias = o; o += rup((size_t)8 * H * 4, 256);
     w.xinv = o; o += rup((size_t)BT * 4, 256);          // inverse row scales of the fp16 planes (np = 2)
     w.winv = o; o += rup((size_t)8 * H * 4, 256);
+    w.sync = o; o += 256;                               // streamed projection: progress / gate / time-out words (problem 0's are used)
     w.big = o;  if (H > MMB_LSTM_MAX_H) o += rup(lstm_big_fwd_ws_bytes(B, H), 256);
     w.total = o;
     return w;
@@ -683,6 +759,116 @@ static int gx_planes_group(const mmb_lstm_fwd_desc* d, const int* idx, int m, hi
 
 // weight and input gradients of the layer call's problems through the operand planes (defined below)
 static int grads_planes_group(const mmb_lstm_bwd_desc* d, const int* idx, int m, hipStream_t stream, bool db_partials, int phase_bits);
+
+// ------------------------------------------------------------------------------------------ streamed projection (host side)
+// one-thread kernels on the tail's stream: the gate in front of the tail (the recurrence's workgroups take their CUs before the
+// first chunk GEMM may take any: an explicit dependency on their dispatch, bounded at 200 us, where round 3 used a fixed
+// delay), and the publication of a finished chunk
+__global__ __launch_bounds__(64) void stream_gate_kernel(unsigned* sync, unsigned target, long long ticks) {
+    const long long t0 = wall_clock64();
+    while (ld_sc1_u32(sync + 1) < target && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+__global__ __launch_bounds__(64) void stream_publish_kernel(unsigned* sync, unsigned chunks) {
+    if (threadIdx.x == 0) __hip_atomic_store(sync, chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct StreamPlan {
+    int K, KH;                         // launches (chunks per direction), of which the first KH make the head
+    int C[MMB_MAX_GROUP];              // time steps per interval of problem p (a multiple of 16 / gcd(B, 16): interval boundaries
+    int nK[MMB_MAX_GROUP];             //  are row-block boundaries of the time-major planes); intervals of problem p: ceil(T / C)
+};
+static int gcd_(int a, int b) { return b ? gcd_(b, a % b) : a; }
+static void stream_plan(const mmb_lstm_fwd_desc* d, int n, int K, int KH, StreamPlan& sp) {
+    sp.K = K; sp.KH = KH;
+    for (int p = 0; p < n; ++p) {
+        const int q = 16 / gcd_(d[p].B, 16);
+        int c = (d[p].T + K - 1) / K;
+        c = (c + q - 1) / q * q;
+        sp.C[p] = c;
+        sp.nK[p] = (d[p].T + c - 1) / c;
+    }
+}
+// phase word of mmb_bilstm_layer_fwd_phase: bits 0-2 the phase, bits 8-15 K, bits 16-23 KH
+static bool stream_decode(int phase, int& which, int& K, int& KH) {
+    which = phase & 7; K = (phase >> 8) & 0xFF; KH = (phase >> 16) & 0xFF;
+    return (which == MMB_LSTM_FWD_HEAD || which == MMB_LSTM_FWD_REC || which == MMB_LSTM_FWD_TAIL) && K >= 2 && K <= 64 && KH >= 1 && KH < K &&
+           !(phase & ~(7 | 0xFFFF00));
+}
+
+// launch k of the streamed projection: the x planes of the intervals first needed now (time-major rows), then Gx of interval k for
+// the forward direction and of interval nK - 1 - k for the reverse direction of every problem -- ONE split launch and ONE GEMM launch
+static int stream_chunk(const mmb_lstm_fwd_desc* d, int n, const StreamPlan& sp, int k, hipStream_t stream) {
+    const int np = planes_terms();
+    SplitRowsArgs sx[MMB_MAX_GROUP];
+    PlanesGemmArgs gs[MMB_MAX_GROUP];
+    int ns = 0, ng = 0;
+    for (int p = 0; p < n; ++p) {
+        const mmb_lstm_fwd_desc& P = d[p];
+        const int H = P.H, C = sp.C[p], nK = sp.nK[p];
+        if (k >= nK) continue;
+        const long BT = (long)P.B * P.T;
+        const WsFwd L = ws_fwd_layout(BT, P.B, P.I, H);
+        char* ws = static_cast<char*>(P.ws);
+        bf16_t* xP = reinterpret_cast<bf16_t*>(ws + L.xP);
+        bf16_t* wP = reinterpret_cast<bf16_t*>(ws + L.wP);
+        float* bias = reinterpret_cast<float*>(ws + L.bias);
+        float* xinv = reinterpret_cast<float*>(ws + L.xinv);
+        float* winv = reinterpret_cast<float*>(ws + L.winv);
+        const size_t rb_bytes = (size_t)(L.Ip / 32) * np * 1024;      // bytes of one 16-row block of planes
+        const int iv[2] = {k, nK - 1 - k};                            // interval of the forward / of the reverse direction
+        for (int dir = 0; dir < 2; ++dir) {
+            const int i = iv[dir];
+            const int t_lo = i * C, t_hi = min((i + 1) * C, P.T);
+            const long row0 = (long)t_lo * P.B, rows = (long)(t_hi - t_lo) * P.B;
+            // x planes of the interval: made by whichever direction needs it first (launch min(i, nK - 1 - i))
+            const bool first_use = dir == 0 ? (i <= nK - 1 - i) : (i > nK - 1 - i);
+            if (first_use) {
+                MMB_REQUIRE(ns < MMB_MAX_GROUP, "streamed projection: too many split passes in one launch");
+                SplitRowsArgs& x = sx[ns++];
+                x = SplitRowsArgs{};
+                x.src1 = P.x; x.src2 = P.x; x.R1 = (int)BT; x.R = (int)BT; x.C = P.I; x.ld = P.I; x.Cp = L.Ip; x.gate_H = 0;
+                x.planes = xP; x.np = np; x.inv_out = xinv; x.absmax_out = P.x_absmax; x.absmax_partials = 1;
+                x.perm_B = P.B; x.perm_T = P.T;
+                x.rb0 = (int)(row0 / 16); x.nrb = (int)((rows + 15) / 16);
+            }
+            MMB_REQUIRE(ng < MMB_MAX_GROUP, "streamed projection: too many products in one launch");
+            PlanesGemmArgs& g = gs[ng++];
+            g = PlanesGemmArgs{};
+            g.A = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(xP) + (size_t)(row0 / 16) * rb_bytes);
+            g.B = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(wP) + (size_t)(dir * 4 * H / 16) * rb_bytes);
+            g.C = P.gx + ((size_t)dir * BT + row0) * 4 * H; g.ldc = 4 * H;        // (2,T,B,H,4): the direction's slab, time-major rows
+            g.bias = bias + dir * 4 * H; g.M = (int)rows; g.N = 4 * H; g.K = L.Ip;
+            g.np = np; g.a_inv = xinv + row0; g.b_inv = winv + dir * 4 * H;
+            g.no_splitk = 1;      // same summation order as the one-launch projection: identical results
+        }
+    }
+    if (ns)
+        if (int rc = planes_split_rows_group(sx, ns, stream)) return rc;
+    if (ng)
+        if (int rc = planes_gemm_group(gs, ng, stream)) return rc;
+    return MMB_OK;
+}
+
+static int stream_weights(const mmb_lstm_fwd_desc* d, int n, hipStream_t stream) {
+    const int np = planes_terms();
+    SplitRowsArgs sw[MMB_MAX_GROUP];
+    for (int p = 0; p < n; ++p) {
+        const mmb_lstm_fwd_desc& P = d[p];
+        const int H = P.H;
+        const long BT = (long)P.B * P.T;
+        const WsFwd L = ws_fwd_layout(BT, P.B, P.I, H);
+        char* ws = static_cast<char*>(P.ws);
+        const int nbx = (int)((BT + 15) / 16);
+        SplitRowsArgs& w = sw[p];
+        w = SplitRowsArgs{};
+        w.src1 = P.w_ih[0]; w.src2 = P.w_ih[1]; w.R1 = 4 * H; w.R = 8 * H; w.C = P.I; w.ld = P.I; w.Cp = L.Ip; w.gate_H = H;
+        w.planes = reinterpret_cast<bf16_t*>(ws + L.wP);
+        w.b1a = P.b_ih[0]; w.b2a = P.b_hh[0]; w.b1b = P.b_ih[1]; w.b2b = P.b_hh[1]; w.bias_out = reinterpret_cast<float*>(ws + L.bias);
+        w.np = np; w.inv_out = reinterpret_cast<float*>(ws + L.winv);
+        w.absmax_out = P.x_absmax ? P.x_absmax + nbx : nullptr; w.absmax_partials = 1;
+    }
+    return planes_split_rows_group(sw, n, stream);
+}
 
 template <typename ArgsT, typename K>
 static int launch_rec(K kernel, const ArgsT& a, int total_wgs, int H, hipStream_t stream, int kid) {
@@ -981,6 +1167,67 @@ extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int devic
             }
         }
         default: return launch_rec(lstm_rec_fwd_kernel<32>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+    }
+}
+
+extern "C" int mmb_bilstm_layer_fwd_phase(const mmb_lstm_fwd_desc* d, int n, int phase, int device, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int which, K, KH;
+    MMB_REQUIRE(stream_decode(phase, which, K, KH), "mmb_bilstm_layer_fwd_phase: phase word 0x%x (MMB_LSTM_FWD_HEAD / _REC / _TAIL | MMB_LSTM_FWD_CHUNKS(K, KH), "
+                "2 <= K <= 64, 1 <= KH < K)", phase);
+    MMB_REQUIRE(d && n >= 1 && 2 * n <= MMB_MAX_GROUP, "mmb_bilstm_layer_fwd_phase: n=%d problems (at most %d: two products per problem and launch)", n, MMB_MAX_GROUP / 2);
+    MMB_HIP(hipSetDevice(device));
+    const int H = d[0].H;
+    for (int i = 0; i < n; ++i) {
+        const mmb_lstm_fwd_desc& p = d[i];
+        MMB_REQUIRE(p.H == H && H >= 1 && H <= MMB_LSTM_MAX_H, "mmb_bilstm_layer_fwd_phase: the streamed projection serves the register-resident recurrence (H <= %d, one H per call)", MMB_LSTM_MAX_H);
+        MMB_REQUIRE(p.B >= 1 && p.T >= 1 && p.I >= 1, "bad LSTM sizes B=%d T=%d I=%d", p.B, p.T, p.I);
+        MMB_REQUIRE(p.x && p.lengths && p.y && p.h_n && p.c_n && p.gx && p.gates && p.cs && p.ws && p.x_absmax, "null pointer in desc %d (the streamed projection needs ws and x_absmax)", i);
+        MMB_REQUIRE(planes_ok(p.I, H), "mmb_bilstm_layer_fwd_phase: I and H must be multiples of 4 (operand planes)");
+        for (int dir = 0; dir < 2; ++dir)
+            MMB_REQUIRE(p.w_ih[dir] && p.w_hh[dir] && p.b_ih[dir] && p.b_hh[dir], "null weight in desc %d", i);
+    }
+    StreamPlan sp;
+    stream_plan(d, n, K, KH, sp);
+    unsigned* sync = reinterpret_cast<unsigned*>(static_cast<char*>(d[0].ws) + ws_fwd_layout((long)d[0].B * d[0].T, d[0].B, d[0].I, H).sync);
+    int total_wgs = 0;
+    for (int i = 0; i < n; ++i) total_wgs += 2 * d[i].B;
+    const int gate_wgs = total_wgs < 256 ? total_wgs : 256;
+    if (which == MMB_LSTM_FWD_HEAD) {
+        MMB_HIP(hipMemsetAsync(sync, 0, 64, stream));
+        if (int rc = stream_weights(d, n, stream)) return rc;
+        for (int k = 0; k < KH; ++k)
+            if (int rc = stream_chunk(d, n, sp, k, stream)) return rc;
+        return MMB_OK;
+    }
+    if (which == MMB_LSTM_FWD_TAIL) {
+        hipLaunchKernelGGL(stream_gate_kernel, dim3(1), dim3(64), 0, stream, sync, (unsigned)gate_wgs, 20000LL);      // <= 200 us
+        MMB_HIP(hipGetLastError());
+        for (int k = KH; k < K; ++k) {
+            if (int rc = stream_chunk(d, n, sp, k, stream)) return rc;
+            hipLaunchKernelGGL(stream_publish_kernel, dim3(1), dim3(64), 0, stream, sync, (unsigned)(k + 1));
+            MMB_HIP(hipGetLastError());
+        }
+        return MMB_OK;
+    }
+    // the recurrence, consuming Gx chunk by chunk
+    RecFwdArgs ra{};
+    ra.n = n;
+    int wg = 0;
+    for (int i = 0; i < n; ++i) {
+        const mmb_lstm_fwd_desc& p = d[i];
+        RecFwdProb& q = ra.p[i];
+        q.gx = p.gx; q.w_hh[0] = p.w_hh[0]; q.w_hh[1] = p.w_hh[1]; q.len = p.lengths;
+        q.y = p.y; q.gates = p.gates; q.cs = p.cs; q.h_n = p.h_n; q.c_n = p.c_n; q.hn_pos = p.hn_pos;
+        q.B = p.B; q.T = p.T; q.H = p.H; q.wg_begin = wg; q.chunk = sp.C[i]; q.nchunks = sp.nK[i];
+        wg += 2 * p.B;
+    }
+    ra.sync = sync; ra.tmo_host = lstm_timeout_word(); ra.chunks_ready = KH; ra.chunks_total = K; ra.gate_wgs = gate_wgs;
+    switch (kq_for(H)) {
+        case 8: return launch_rec(lstm_rec_fwd_kernel<8, PF, 0, true>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+        case 16: return launch_rec(lstm_rec_fwd_kernel<16, PF, 0, true>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+        case 25: return launch_rec(lstm_rec_fwd_kernel<25, PF, 0, true>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
+        default: return launch_rec(lstm_rec_fwd_kernel<32, PF, 0, true>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
     }
 }
 

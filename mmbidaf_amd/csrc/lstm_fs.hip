@@ -986,6 +986,7 @@ static int fs_check_timeout() {
     return MMB_OK;
 }
 int lstm_fs_timeouts() { unsigned* w = fs_timeout_word(); return w ? (int)*reinterpret_cast<volatile unsigned*>(w) : -1; }
+unsigned* lstm_timeout_word() { return fs_timeout_word(); }   // (the streamed projection of lstm.hip reports through the same word)
 int lstm_fs_reset_timeouts() {
     unsigned* w = fs_timeout_word();
     if (!w) return -1;

@@ -102,14 +102,15 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsGroup G)
     const int nkt = a.Cp / 32;
     const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int rb = pair / nkt, kt = pair - (long)rb * nkt;
-    if (rb >= (a.R + 15) / 16) return;
+    const int rbl = pair / nkt, kt = pair - (long)rbl * nkt, rb = a.rb0 + rbl;
+    if (rb >= (a.R + 15) / 16 || (a.nrb > 0 && rbl >= a.nrb)) return;
     const int dr = rb * 16 + (lane >> 2), oct = kt * 4 + (lane & 3);
     int sr = dr;
     if (a.gate_H > 0) {  // plane row u*4+g of a 4H block <- source row g*H+u
         const int H = a.gate_H, blk = dr / (4 * H), rem = dr % (4 * H);
         sr = blk * 4 * H + (rem & 3) * H + (rem >> 2);
     }
+    if (a.perm_B > 0) sr = (dr % a.perm_B) * a.perm_T + dr / a.perm_B;     // time-major planes of a (B,T,C) tensor
     const bool second = sr >= a.R1;
     const int lr = second ? sr - a.R1 : sr;
     float x[8];
@@ -131,14 +132,15 @@ __global__ __launch_bounds__(256) void split_rows16_kernel(const SplitRowsGroup 
     __shared__ float sc[16], bmx[16];
     const SplitRowsArgs& a = G.a[blockIdx.y];
     const int nkt = a.Cp / 32;
-    const int rb = blockIdx.x, t = threadIdx.x;
-    if (rb >= ((a.Rpad > a.R ? a.Rpad : a.R) + 15) / 16) return;
+    const int rb = a.rb0 + blockIdx.x, t = threadIdx.x;
+    if (rb >= ((a.Rpad > a.R ? a.Rpad : a.R) + 15) / 16 || (a.nrb > 0 && (int)blockIdx.x >= a.nrb)) return;
     auto src_row = [&](int dr, const float*& base) {
         int sr = dr;
         if (a.gate_H > 0) {  // plane row u*4+g of a 4H block <- source row g*H+u
             const int H = a.gate_H, blk = dr / (4 * H), rem = dr % (4 * H);
             sr = blk * 4 * H + (rem & 3) * H + (rem >> 2);
         }
+        if (a.perm_B > 0) sr = (dr % a.perm_B) * a.perm_T + dr / a.perm_B;
         const bool second = sr >= a.R1;
         const int lr = second ? sr - a.R1 : sr;
         base = (second ? a.src2 : a.src1) + (size_t)lr * a.ld;
@@ -207,14 +209,15 @@ __global__ __launch_bounds__(256) void split_rows16_reg_kernel(const SplitRowsGr
     __shared__ float wmax[4][16];
     const SplitRowsArgs& a = G.a[blockIdx.y];
     const int nkt = a.Cp / 32;
-    const int rb = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (rb >= ((a.Rpad > a.R ? a.Rpad : a.R) + 15) / 16) return;
+    const int rb = a.rb0 + blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (rb >= ((a.Rpad > a.R ? a.Rpad : a.R) + 15) / 16 || (a.nrb > 0 && (int)blockIdx.x >= a.nrb)) return;
     const int rl = lane >> 2, dr = rb * 16 + rl;
     int sr = dr;
     if (a.gate_H > 0) {  // plane row u*4+g of a 4H block <- source row g*H+u
         const int H = a.gate_H, blk = dr / (4 * H), rem = dr % (4 * H);
         sr = blk * 4 * H + (rem & 3) * H + (rem >> 2);
     }
+    if (a.perm_B > 0) sr = (dr % a.perm_B) * a.perm_T + dr / a.perm_B;     // time-major planes of a (B,T,C) tensor
     const bool second = sr >= a.R1;
     const int lr = second ? sr - a.R1 : sr;
     const float* base = (second ? a.src2 : a.src1) + (size_t)lr * a.ld;
@@ -662,8 +665,9 @@ int planes_split_rows_group(const SplitRowsArgs* as, int n, hipStream_t stream) 
             const SplitRowsArgs& a = as[j];
             G.a[m++] = a;
             done[j] = true;
-            const long rbs = ((a.Rpad > a.R ? a.Rpad : a.R) + 15) / 16;
-            const long b = v == 0 ? (((long)((a.R + 15) / 16) * (a.Cp / 32)) + 3) / 4 : rbs;
+            const long rbs_all = ((a.Rpad > a.R ? a.Rpad : a.R) + 15) / 16;
+            const long rbs = a.nrb > 0 ? std::min<long>(a.nrb, std::max<long>(rbs_all - a.rb0, 0)) : rbs_all;
+            const long b = v == 0 ? ((a.nrb > 0 ? rbs : (long)((a.R + 15) / 16)) * (a.Cp / 32) + 3) / 4 : rbs;
             blocks = b > blocks ? b : blocks;
         }
         ProfScope ps_(MMB_K_SPLIT, stream);
@@ -812,14 +816,14 @@ static double planes_choose(const PlanesGemmArgs& g, int& best, int& best_s, int
             if (only_cfg >= 0 && c != only_cfg) break;
             if (c == 7 && g.np != 1) break;   // the 256x256 tile: 64 KB of LDS stages with one plane; the cost model was not fitted to it for the others
             if (g.ta && (PLANES_CFGS[c].wm * PLANES_CFGS[c].mt * 16) % 32) break;   // k-major A: BM a multiple of 32
-            if (s > 1 && g.K / s < 512) break;
+            if (s > 1 && (g.K / s < 512 || g.no_splitk)) break;
             const double cost = planes_cost(g, PLANES_CFGS[c], s);
             if (cost < best_cost) { best_cost = cost; best = c; best_s = s; }
         }
     if (only_cfg < 0 && g_planes_force >= 0 && !((g_planes_force / 100) % N_PLANES_CFGS == 7 && g.np != 1) &&
         !(g.ta && (PLANES_CFGS[(g_planes_force / 100) % N_PLANES_CFGS].wm * PLANES_CFGS[(g_planes_force / 100) % N_PLANES_CFGS].mt * 16) % 32)) {
         best = (g_planes_force / 100) % N_PLANES_CFGS;
-        if (g_planes_force % 100 > 0) best_s = g_planes_force % 100;
+        if (g_planes_force % 100 > 0 && !g.no_splitk) best_s = g_planes_force % 100;
     }
     return best_cost;
 }

@@ -32,6 +32,26 @@ from .encoding import sorted_order
 
 _ENABLED = os.environ.get("MMB_REGION_FN", "1") != "0"
 PREPARE, HAVE_XC, HAVE_WT = 4, 8, 16
+FWD_HEAD, FWD_REC, FWD_TAIL = 1, 2, 4
+
+
+def _parse_stream_cfg(text):
+    """"K,KH;K,KH;K,KH" for the three forward layer calls (input encoders, modelling layer 0, modelling layer 1); "0" = off"""
+    if text.strip() in ("0", "off", ""):
+        return None
+    cfg = []
+    for part in text.split(";"):
+        k, kh = (int(v) for v in part.split(","))
+        cfg.append(None if k < 2 else (k, max(1, min(kh, k - 1))))
+    if len(cfg) != 3:
+        raise ValueError("MMB_FWD_STREAM: three K,KH pairs separated by ';'")
+    return cfg
+
+
+# Streamed input projection of the forward layer calls (mmb_bilstm_layer_fwd_phase): the projection GEMM of a layer call runs
+# beside its recurrence on the side stream, in K time chunks per direction of which the first KH are computed up front.
+_FWD_STREAM = _parse_stream_cfg(os.environ.get("MMB_FWD_STREAM", "8,1;8,3;8,1"))
+_FWD_STREAM_MIN_ROWS = 4096          # B * T below this: the one-launch projection (a few microseconds) is not worth 2 K launches
 
 
 def _al(n):
@@ -579,9 +599,29 @@ class _RegionFn(torch.autograd.Function):
             flat = torch.rand(plan.mask_total, device=dev)          # uniforms: mask = (u < 1 - p) / (1 - p), formed where it is applied
             masks = {name: flat[o:o + n].view(sh) for name, sh, o, n in plan.mask_layout}
 
+        main_s = torch.cuda.current_stream(dev)
+        side_s = MF.side_stream(dev) if MF._USE_SIDE else main_s
+        streamed = _FWD_STREAM is not None and side_s is not main_s and B * T >= _FWD_STREAM_MIN_ROWS
+
+        def lstm_fwd(d_, n, stage):
+            """one forward layer call: one-launch projection + recurrence, or -- streamed -- head chunks of the projection, the
+            recurrence, and the remaining chunks beside it on the side stream (ordered behind the head, joined afterwards)"""
+            cfg = _FWD_STREAM[stage] if streamed else None
+            if cfg is None:
+                _lib.check(lib.mmb_bilstm_layer_fwd(d_, n, di, stream), "mmb_bilstm_layer_fwd")
+                return
+            word = (cfg[0] << 8) | (cfg[1] << 16)
+            _lib.check(lib.mmb_bilstm_layer_fwd_phase(d_, n, FWD_HEAD | word, di, stream), "mmb_bilstm_layer_fwd_phase(head)")
+            head = torch.cuda.Event()
+            head.record(main_s)
+            _lib.check(lib.mmb_bilstm_layer_fwd_phase(d_, n, FWD_REC | word, di, stream), "mmb_bilstm_layer_fwd_phase(recurrence)")
+            side_s.wait_event(head)
+            _lib.check(lib.mmb_bilstm_layer_fwd_phase(d_, n, FWD_TAIL | word, di, side_s.cuda_stream), "mmb_bilstm_layer_fwd_phase(tail)")
+            main_s.wait_stream(side_s)
+
         # ---- input encoders (models.py:97,102,113) + their output dropout (encoding.py:104)
         d_, w_ = tm["f_enc"].build(bases, pp, x0=xs[0].data_ptr(), x1=xs[1].data_ptr(), x2=xs[2].data_ptr())
-        _lib.check(lib.mmb_bilstm_layer_fwd(d_, 3, di, stream), "mmb_bilstm_layer_fwd")
+        lstm_fwd(d_, 3, 0)
         enc_out = (kb + ko["et.y"], kb + ko["ea.y"], kb + ko["ei.y"])
         att_d = (None, None, None, None)
         if drop:
@@ -599,7 +639,7 @@ class _RegionFn(torch.autograd.Function):
         _lib.check(lib.mmb_bidaf_group_fwd(d_, 2, B, D, di, stream), "mmb_bidaf_group_fwd")
         # ---- modelling encoders (models.py:134-135): layer 0, inter-layer dropout (encoding.py:81), layer 1, output dropout
         d_, w_ = tm["f_l0"].build(bases, pp)
-        _lib.check(lib.mmb_bilstm_layer_fwd(d_, 2, di, stream), "mmb_bilstm_layer_fwd")
+        lstm_fwd(d_, 2, 1)
         l1_in = (kb + ko["a0.y"], kb + ko["i0.y"])
         if drop:
             y0d = _masked_mul(lib, di, stream, [view(ko["a0.y"], (B, T, D)), view(ko["i0.y"], (B, T, D))], [masks["inter_a"], masks["inter_i"]], p=drop)
@@ -610,7 +650,7 @@ class _RegionFn(torch.autograd.Function):
         # saved activations, and an output held under no_grad does not pin the arena
         y1 = [torch.empty(B, T, D, device=dev, dtype=torch.float32), torch.empty(B, T, D, device=dev, dtype=torch.float32)]
         d_, w_ = tm["f_l1"].build(bases, pp, x0=l1_in[0], x1=l1_in[1], y0=y1[0].data_ptr(), y1=y1[1].data_ptr())
-        _lib.check(lib.mmb_bilstm_layer_fwd(d_, 2, di, stream), "mmb_bilstm_layer_fwd")
+        lstm_fwd(d_, 2, 2)
         mod_out = y1
         if drop:
             mod_out = _masked_mul(lib, di, stream, y1, [masks["out_a"], masks["out_i"]], p=drop)

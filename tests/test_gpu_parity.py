@@ -1565,6 +1565,74 @@ def test_region_node_second_backward_and_output_version_tracking():
     assert outs[2].untyped_storage().nbytes() == outs[2].numel() * 4
 
 
+@pytest.mark.parametrize("shape,cfg", [((16, 300, 190, 40, 100), [(8, 1), (8, 3), (8, 1)]),
+                                       ((12, 411, 256, 64, 100), [(5, 2), (16, 4), (3, 1)]),
+                                       ((32, 400, 256, 64, 100), [(8, 1), (8, 3), (8, 1)])])
+def test_streamed_projection_equals_the_one_launch_form_bit_for_bit(monkeypatch, shape, cfg):
+    """mmb_bilstm_layer_fwd_phase (round 5): the input projection of every forward layer call cut into K time chunks per
+    direction, the first KH in front of the recurrence, the rest beside it on the side stream, published chunk by chunk and
+    awaited by the recurrence.  Same arithmetic in the same order: every output, input gradient and LSTM parameter gradient
+    must be IDENTICAL to the one-launch form (the attentions' parameter gradients are sums of atomics); ragged lengths (the
+    reverse direction starts inside the sequence), batch sizes whose time-major rows need padded chunk boundaries, chunk
+    counts that do not divide the lengths; no bounded wait may have given up."""
+    from mmbidaf_amd import synth, region_fn, _lib
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    torch.manual_seed(224)
+    region = HotRegion(shape[4]).to(d).eval()
+    batch = synth.make_batch(shape, ragged=True)
+    gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    monkeypatch.setattr(region_fn, "_FWD_STREAM_MIN_ROWS", 0)
+
+    def run(stream_cfg):
+        monkeypatch.setattr(region_fn, "_FWD_STREAM", stream_cfg)
+        for p in region.parameters():
+            p.grad = None
+        xs = [gpu[k].detach().clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+        outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+        synth.region_loss(outs, gpu).backward()
+        torch.cuda.synchronize()
+        assert _lib.persist_timeouts() == 0
+        return [o.detach().clone() for o in outs], [x.grad.clone() for x in xs], {n: p.grad.clone() for n, p in region.named_parameters()}
+    o1, g1, p1 = run(cfg)
+    o0, g0, p0 = run(None)
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)
+    for n in p1:
+        if "bidaf_att" in n:
+            close(p1[n], p0[n].cpu(), "streamed grad " + n, tol=2e-6)
+        else:
+            assert torch.equal(p1[n], p0[n]), n
+    # and replayed from a captured graph (the tail is a second branch of the graph)
+    monkeypatch.setattr(region_fn, "_FWD_STREAM", cfg)
+    xs = [gpu[k].detach().clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+            synth.region_loss(outs, gpu).backward()
+    torch.cuda.current_stream().wait_stream(side)
+    for p in region.parameters():
+        p.grad = None
+    for x in xs:
+        x.grad = None
+    g_ = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_):
+        outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+        synth.region_loss(outs, gpu).backward()
+    for _ in range(3):
+        g_.replay()
+    torch.cuda.synchronize()
+    assert _lib.persist_timeouts() == 0
+    for a, b in zip(outs, o0):
+        assert torch.equal(a, b)
+    for x, b in zip(xs, g0):
+        assert torch.equal(x.grad, b)
+
+
 def test_cu_masked_stream_runs_kernels():
     """mmb_stream_create_cu_mask / mmb_stream_destroy: a stream restricted to half of the CUs computes the same GEMM
     (the option is measured and not used by default, profiles/r02_side_stream.md; the entry points stay covered)."""
