@@ -203,17 +203,19 @@ int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* descs, int n, int device, void
 /* The same layer call with a STREAMED input projection, in three separately enqueued parts (register-resident recurrence:
  * H <= MMB_LSTM_MAX_H; ws and x_absmax required; n <= MMB_MAX_GROUP / 2).  The projection Gx = x . W_ih^T (reference: inside
  * torch.nn.LSTM, layers/encoding.py:79-81,96) is cut into K time chunks per direction, taken from both ends of the sequences
- * inwards -- the order in which the two directions of the recurrence consume them:
- *   MMB_LSTM_FWD_HEAD  on `stream`: weight planes, the first KH chunks of the x planes and of Gx, zeroed progress words;
- *   MMB_LSTM_FWD_REC   on the same stream: the recurrence, which starts at once and waits (bounded) only for a chunk that has
- *                      not been published yet;
+ * inwards -- the order in which the two directions of the recurrence consume them -- and computed by ONE chunk-ordered GEMM
+ * launch whose workgroups publish every chunk they complete:
+ *   MMB_LSTM_FWD_HEAD  on `stream`: zeroed chunk counters, the operand planes of x (time-major rows) and of the weights, and the
+ *                      first KH chunks of Gx (KH may be 0);
+ *   MMB_LSTM_FWD_REC   on the same stream: the recurrence, which starts at once and waits (bounded) only for a chunk that is not
+ *                      complete yet;
  *   MMB_LSTM_FWD_TAIL  on a SECOND stream that the caller has ordered behind HEAD (an event recorded after the HEAD call): a
- *                      gate that lets the recurrence's workgroups take their CUs first, then chunks KH..K-1, each published
- *                      as its GEMM completes.  The caller joins the second stream into the first afterwards.
- * The recurrence keeps 2 B n of the 256 CUs busy; the tail's GEMMs run on the others beside it.  desc.gx is scratch of the same
+ *                      gate that lets the recurrence's workgroups take their CUs first, then chunks KH..K-1.  The caller joins
+ *                      the second stream into the first afterwards.
+ * The recurrence keeps 2 B n of the 256 CUs busy; the tail's GEMM runs on the others beside it.  desc.gx is scratch of the same
  * size as for mmb_bilstm_layer_fwd (laid out (2,T,B,H,4) here); every other output is identical -- bit for bit -- to the
  * one-launch form.  All three calls take the same descriptors and the same K, KH:
- *   phase = MMB_LSTM_FWD_HEAD | MMB_LSTM_FWD_CHUNKS(K, KH)      2 <= K <= 64, 1 <= KH < K.
+ *   phase = MMB_LSTM_FWD_HEAD | MMB_LSTM_FWD_CHUNKS(K, KH)      2 <= K <= 64, 0 <= KH < K.
  * TAIL enqueued on the SAME stream as REC can never run before it: REC's waits then give up after 2 s, the step's results are
  * invalid and mmb_lstm_persist_timeouts() says so (as for the persistent recurrence below). */
 #define MMB_LSTM_FWD_HEAD 1

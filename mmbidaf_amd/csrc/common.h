@@ -186,6 +186,10 @@ int planes_split_transpose(const SplitTArgs& a, hipStream_t stream);
 int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream);
 // up to MMB_MAX_GROUP independent products (same plane format) in ONE launch with one tile shape
 int planes_gemm_group(const PlanesGemmArgs* gs, int n, hipStream_t stream);
+// chunk-ordered launches with per-chunk completion counters (the streamed input projection of lstm.hip; see PlanesGroup in planes.hip)
+int planes_chunked_plan(const PlanesGemmArgs* gs, const int* rows_per_iv, int n, int* cfg_out, int* step_blocks_out);
+int planes_gemm_chunked(const PlanesGemmArgs* gs, const int* rows_per_iv, const int* n_iv, const int* rev, int n, int cfg, int step_blocks,
+                        int c0, int c1, unsigned* done, hipStream_t stream);
 void planes_set_tune(int code);
 int planes_terms();   // 2 (default) or 3 (MMB_PLANES_TERMS=3): which split the operand-plane path uses
 int planes_plan_splitk(const PlanesGemmArgs& g);   // the K split planes_gemm will use for g

@@ -92,20 +92,23 @@ struct RecFwdProb {
 struct RecFwdArgs {
     RecFwdProb p[MMB_MAX_GROUP];
     int n;
-    // streamed projection: [0] chunks published so far by the tail, [1] workgroups of this launch that have started (the
-    // side stream's gate waits for them), [2] set when a bounded wait gave up; the chunks complete at launch; their number
+    // streamed projection: sync[c], c < 64: workgroups of the chunk-ordered projection GEMM that have finished chunk c (complete at
+    // chunk_blocks); sync[64]: workgroups of this launch that have started (the side stream's gate waits for them); sync[65]: set
+    // when a bounded wait gave up.  chunks_ready: chunks complete before this launch (stream order); chunks_total: their number
     unsigned* sync;
     unsigned* tmo_host;    // host-visible time-out word (the persistent recurrence's, lstm_fs.hip)
-    int chunks_ready, chunks_total, gate_wgs;
+    int chunks_ready, chunks_total, gate_wgs, chunk_blocks;
 };
+constexpr int SYNC_STARTED = 64, SYNC_TIMEOUT = 65, SYNC_BYTES = 512;
 
 // ---- streamed input projection (round 5).  The projection Gx = x . W_ih^T of a layer call is 46-145 us of full-chip work in front
-// of a recurrence that keeps 2 B n of the 256 CUs busy for 200 us.  In the streamed form the projection is cut into time chunks;
-// the head chunks are computed before the recurrence starts, the others BESIDE it on a second stream (mmb_bilstm_layer_fwd_phase),
-// and the recurrence consumes them as they are published: a chunk's GEMM kernel has completed (its stores are written back
-// at the kernel boundary), a one-thread kernel behind it stores the count of finished chunks with an agent-scope atomic, and
-// the recurrence polls that word and reads Gx with sc1 loads (L2-served: this CU's L1 is never asked for a line another kernel
-// wrote while this one was running) -- MI355X_MICROARCH.md, inter-workgroup visibility, the counter form with sc1 loads.
+// of a recurrence that keeps 2 B n of the 256 CUs busy for 200 us.  In the streamed form the projection GEMM is ONE chunk-ordered
+// launch (planes.hip, PlanesGroup::chunked) whose workgroups compute the time chunks in the order the two directions of the
+// recurrence consume them -- from both ends of the sequences inwards -- on a second stream BESIDE the recurrence
+// (mmb_bilstm_layer_fwd_phase); the first chunks may be computed up front.  Hand-off per chunk: the GEMM's workgroups store
+// write-through (sc1), drain, and add to the chunk's counter (one agent-scope add per workgroup); the recurrence polls the counter
+// and reads Gx with sc1 loads (L2-served: this CU's L1 is never asked for a line another kernel wrote while this one was
+// running) -- MI355X_MICROARCH.md, inter-workgroup visibility, the counter form with sc1 stores and loads.
 // Every wait is bounded; a wait that gives up marks the step invalid through the host-visible time-out word.
 __device__ __forceinline__ unsigned ld_sc1_u32(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -114,21 +117,20 @@ __device__ __forceinline__ float ld_sc1_f32(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 constexpr long long STREAM_WAIT_TICKS = 200000000LL;   // 2 s of the 100-MHz wall clock
-// wait until `need` chunks are published; returns the published count (>= need unless the wait gave up)
-__device__ __forceinline__ unsigned stream_wait_chunks(const RecFwdArgs& args, unsigned need) {
-    unsigned have = ld_sc1_u32(args.sync);
-    if (have >= need) return have;
+// wait until chunk c is complete (every workgroup of its step has arrived); false when the wait gave up
+__device__ __forceinline__ bool stream_wait_chunk(const RecFwdArgs& args, unsigned c) {
+    const unsigned full = (unsigned)args.chunk_blocks;
+    if (ld_sc1_u32(args.sync + c) >= full) return true;
     const long long t0 = wall_clock64();
     while (true) {
         __builtin_amdgcn_s_sleep(4);
-        have = ld_sc1_u32(args.sync);
-        if (have >= need) return have;
+        if (ld_sc1_u32(args.sync + c) >= full) return true;
         if (wall_clock64() - t0 > STREAM_WAIT_TICKS) {
             if ((threadIdx.x & 63) == 0) {
-                __hip_atomic_store(args.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(args.sync + SYNC_TIMEOUT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (args.tmo_host) __hip_atomic_fetch_add(args.tmo_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            return need;      // give up: the step's results are invalid, the host learns it from the time-out word
+            return false;      // give up: the step's results are invalid, the host learns it from the time-out word
         }
     }
 }
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the same values to the same addresses, so the step loop needs no "live" predicate at all
     const int u = min(tid >> 2, H - 1);
     if (STREAM && tid == 0 && (int)blockIdx.x < args.gate_wgs)      // "resident": what the side stream's gate counts
-        __hip_atomic_fetch_add(args.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(args.sync + SYNC_STARTED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- W_hh slice into registers.  Accumulator j of lane kq belongs to gate (kq + j) & 3 (ROTATED order, see the reduction in
     // step()), and every weight already carries the factor its gate's sigmoid needs in front of v_exp_f32 (-log2 e; -2 log2 e
@@ -304,10 +306,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto ensure = [&](int s_last) {
         if constexpr (STREAM) {
             if (len <= 0) return;
-            if (peeking) { confirmed = max(confirmed, peek); peeking = false; }
+            if (peeking) {      // the peek of the previous block has long arrived: the next chunk was complete by then, or not
+                if (peek >= (unsigned)args.chunk_blocks) ++confirmed;
+                peeking = false;
+            }
             const unsigned need = need_for(s_last);
-            if (need > confirmed) confirmed = max(confirmed, stream_wait_chunks(args, need));
-            if (need_for(s_last + PFD) > confirmed) { peek = ld_sc1_u32(args.sync); peeking = true; }
+            while (need > confirmed) {
+                stream_wait_chunk(args, confirmed);      // (a wait that gave up has marked the step invalid: go on regardless)
+                ++confirmed;
+            }
+            if (need_for(s_last + PFD) > confirmed) { peek = ld_sc1_u32(args.sync + confirmed); peeking = true; }
         }
     };
     float gxr[PFD];
@@ -679,7 +687,7 @@ static WsFwd ws_fwd_layout(long BT, int B, int I, int H) {
     w.bias = o; o += rup((size_t)8 * H * 4, 256);
     w.xinv = o; o += rup((size_t)BT * 4, 256);          // inverse row scales of the fp16 planes (np = 2)
     w.winv = o; o += rup((size_t)8 * H * 4, 256);
-    w.sync = o; o += 256;                               // streamed projection: progress / gate / time-out words (problem 0's are used)
+    w.sync = o; o += 512;                               // streamed projection: chunk counters, gate and time-out words (problem 0's are used)
     w.big = o;  if (H > MMB_LSTM_MAX_H) o += rup(lstm_big_fwd_ws_bytes(B, H), 256);
     w.total = o;
     return w;
@@ -761,97 +769,66 @@ static int gx_planes_group(const mmb_lstm_fwd_desc* d, const int* idx, int m, hi
 static int grads_planes_group(const mmb_lstm_bwd_desc* d, const int* idx, int m, hipStream_t stream, bool db_partials, int phase_bits);
 
 // ------------------------------------------------------------------------------------------ streamed projection (host side)
-// one-thread kernels on the tail's stream: the gate in front of the tail (the recurrence's workgroups take their CUs before the
-// first chunk GEMM may take any: an explicit dependency on their dispatch, bounded at 200 us, where round 3 used a fixed
-// delay), and the publication of a finished chunk
+// The gate in front of the tail, a one-wave kernel on the tail's stream: the recurrence's workgroups take their CUs before the
+// projection GEMM may take any -- an explicit dependency on their dispatch (they count themselves in at their start), bounded
+// at 200 us, where round 3 put a fixed delay.
 __global__ __launch_bounds__(64) void stream_gate_kernel(unsigned* sync, unsigned target, long long ticks) {
     const long long t0 = wall_clock64();
-    while (ld_sc1_u32(sync + 1) < target && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-__global__ __launch_bounds__(64) void stream_publish_kernel(unsigned* sync, unsigned chunks) {
-    if (threadIdx.x == 0) __hip_atomic_store(sync, chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (ld_sc1_u32(sync + SYNC_STARTED) < target && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
 struct StreamPlan {
-    int K, KH;                         // launches (chunks per direction), of which the first KH make the head
-    int C[MMB_MAX_GROUP];              // time steps per interval of problem p (a multiple of 16 / gcd(B, 16): interval boundaries
-    int nK[MMB_MAX_GROUP];             //  are row-block boundaries of the time-major planes); intervals of problem p: ceil(T / C)
+    int K, KH;                         // chunks per direction, of which the first KH make the head
+    int C[MMB_MAX_GROUP];              // time steps per interval of problem p (C * B a multiple of 128: whole row tiles of the GEMM)
+    int nK[MMB_MAX_GROUP];             // intervals of problem p: ceil(T / C) <= K
+    PlanesGemmArgs sub[MMB_MAX_GROUP]; // products: (problem p, direction) = sub[2 p + dir]
+    int rows_per_iv[MMB_MAX_GROUP], n_iv[MMB_MAX_GROUP], rev[MMB_MAX_GROUP];
+    int nsub, cfg, step_blocks;
 };
 static int gcd_(int a, int b) { return b ? gcd_(b, a % b) : a; }
-static void stream_plan(const mmb_lstm_fwd_desc* d, int n, int K, int KH, StreamPlan& sp) {
-    sp.K = K; sp.KH = KH;
+static int stream_plan(const mmb_lstm_fwd_desc* d, int n, int K, int KH, StreamPlan& sp) {
+    const int np = planes_terms();
+    sp.K = K; sp.KH = KH; sp.nsub = 2 * n;
     for (int p = 0; p < n; ++p) {
-        const int q = 16 / gcd_(d[p].B, 16);
-        int c = (d[p].T + K - 1) / K;
+        const mmb_lstm_fwd_desc& P = d[p];
+        const int H = P.H;
+        const int q = 128 / gcd_(P.B, 128);
+        int c = (P.T + K - 1) / K;
         c = (c + q - 1) / q * q;
         sp.C[p] = c;
-        sp.nK[p] = (d[p].T + c - 1) / c;
+        sp.nK[p] = (P.T + c - 1) / c;
+        const long BT = (long)P.B * P.T;
+        const WsFwd L = ws_fwd_layout(BT, P.B, P.I, H);
+        char* ws = static_cast<char*>(P.ws);
+        for (int dir = 0; dir < 2; ++dir) {
+            PlanesGemmArgs& g = sp.sub[2 * p + dir];
+            g = PlanesGemmArgs{};
+            g.A = reinterpret_cast<const bf16_t*>(ws + L.xP);
+            g.B = reinterpret_cast<const bf16_t*>(ws + L.wP + (size_t)(dir * 4 * H / 16) * (size_t)(L.Ip / 32) * np * 1024);
+            g.C = P.gx + (size_t)dir * BT * 4 * H; g.ldc = 4 * H;        // (2,T,B,H,4): the direction's slab, time-major rows
+            g.bias = reinterpret_cast<const float*>(ws + L.bias) + dir * 4 * H;
+            g.M = (int)BT; g.N = 4 * H; g.K = L.Ip;
+            g.np = np; g.a_inv = reinterpret_cast<const float*>(ws + L.xinv); g.b_inv = reinterpret_cast<const float*>(ws + L.winv) + dir * 4 * H;
+            g.no_splitk = 1;      // same summation order as the one-launch projection: identical results
+            sp.rows_per_iv[2 * p + dir] = c * P.B;
+            sp.n_iv[2 * p + dir] = sp.nK[p];
+            sp.rev[2 * p + dir] = dir;
+        }
     }
+    return planes_chunked_plan(sp.sub, sp.rows_per_iv, sp.nsub, &sp.cfg, &sp.step_blocks);
 }
 // phase word of mmb_bilstm_layer_fwd_phase: bits 0-2 the phase, bits 8-15 K, bits 16-23 KH
 static bool stream_decode(int phase, int& which, int& K, int& KH) {
     which = phase & 7; K = (phase >> 8) & 0xFF; KH = (phase >> 16) & 0xFF;
-    return (which == MMB_LSTM_FWD_HEAD || which == MMB_LSTM_FWD_REC || which == MMB_LSTM_FWD_TAIL) && K >= 2 && K <= 64 && KH >= 1 && KH < K &&
+    return (which == MMB_LSTM_FWD_HEAD || which == MMB_LSTM_FWD_REC || which == MMB_LSTM_FWD_TAIL) && K >= 2 && K <= 64 && KH >= 0 && KH < K &&
            !(phase & ~(7 | 0xFFFF00));
 }
 
-// launch k of the streamed projection: the x planes of the intervals first needed now (time-major rows), then Gx of interval k for
-// the forward direction and of interval nK - 1 - k for the reverse direction of every problem -- ONE split launch and ONE GEMM launch
-static int stream_chunk(const mmb_lstm_fwd_desc* d, int n, const StreamPlan& sp, int k, hipStream_t stream) {
+// operand planes of the head: x in TIME-MAJOR row order (plane row t B + b: a time chunk is one run of rows) and the stacked,
+// gate-interleaved weights with the bias row -- one launch
+static int stream_split(const mmb_lstm_fwd_desc* d, int n, hipStream_t stream) {
     const int np = planes_terms();
-    SplitRowsArgs sx[MMB_MAX_GROUP];
-    PlanesGemmArgs gs[MMB_MAX_GROUP];
-    int ns = 0, ng = 0;
-    for (int p = 0; p < n; ++p) {
-        const mmb_lstm_fwd_desc& P = d[p];
-        const int H = P.H, C = sp.C[p], nK = sp.nK[p];
-        if (k >= nK) continue;
-        const long BT = (long)P.B * P.T;
-        const WsFwd L = ws_fwd_layout(BT, P.B, P.I, H);
-        char* ws = static_cast<char*>(P.ws);
-        bf16_t* xP = reinterpret_cast<bf16_t*>(ws + L.xP);
-        bf16_t* wP = reinterpret_cast<bf16_t*>(ws + L.wP);
-        float* bias = reinterpret_cast<float*>(ws + L.bias);
-        float* xinv = reinterpret_cast<float*>(ws + L.xinv);
-        float* winv = reinterpret_cast<float*>(ws + L.winv);
-        const size_t rb_bytes = (size_t)(L.Ip / 32) * np * 1024;      // bytes of one 16-row block of planes
-        const int iv[2] = {k, nK - 1 - k};                            // interval of the forward / of the reverse direction
-        for (int dir = 0; dir < 2; ++dir) {
-            const int i = iv[dir];
-            const int t_lo = i * C, t_hi = min((i + 1) * C, P.T);
-            const long row0 = (long)t_lo * P.B, rows = (long)(t_hi - t_lo) * P.B;
-            // x planes of the interval: made by whichever direction needs it first (launch min(i, nK - 1 - i))
-            const bool first_use = dir == 0 ? (i <= nK - 1 - i) : (i > nK - 1 - i);
-            if (first_use) {
-                MMB_REQUIRE(ns < MMB_MAX_GROUP, "streamed projection: too many split passes in one launch");
-                SplitRowsArgs& x = sx[ns++];
-                x = SplitRowsArgs{};
-                x.src1 = P.x; x.src2 = P.x; x.R1 = (int)BT; x.R = (int)BT; x.C = P.I; x.ld = P.I; x.Cp = L.Ip; x.gate_H = 0;
-                x.planes = xP; x.np = np; x.inv_out = xinv; x.absmax_out = P.x_absmax; x.absmax_partials = 1;
-                x.perm_B = P.B; x.perm_T = P.T;
-                x.rb0 = (int)(row0 / 16); x.nrb = (int)((rows + 15) / 16);
-            }
-            MMB_REQUIRE(ng < MMB_MAX_GROUP, "streamed projection: too many products in one launch");
-            PlanesGemmArgs& g = gs[ng++];
-            g = PlanesGemmArgs{};
-            g.A = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(xP) + (size_t)(row0 / 16) * rb_bytes);
-            g.B = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(wP) + (size_t)(dir * 4 * H / 16) * rb_bytes);
-            g.C = P.gx + ((size_t)dir * BT + row0) * 4 * H; g.ldc = 4 * H;        // (2,T,B,H,4): the direction's slab, time-major rows
-            g.bias = bias + dir * 4 * H; g.M = (int)rows; g.N = 4 * H; g.K = L.Ip;
-            g.np = np; g.a_inv = xinv + row0; g.b_inv = winv + dir * 4 * H;
-            g.no_splitk = 1;      // same summation order as the one-launch projection: identical results
-        }
-    }
-    if (ns)
-        if (int rc = planes_split_rows_group(sx, ns, stream)) return rc;
-    if (ng)
-        if (int rc = planes_gemm_group(gs, ng, stream)) return rc;
-    return MMB_OK;
-}
-
-static int stream_weights(const mmb_lstm_fwd_desc* d, int n, hipStream_t stream) {
-    const int np = planes_terms();
-    SplitRowsArgs sw[MMB_MAX_GROUP];
+    SplitRowsArgs all[MMB_MAX_GROUP];
     for (int p = 0; p < n; ++p) {
         const mmb_lstm_fwd_desc& P = d[p];
         const int H = P.H;
@@ -859,15 +836,21 @@ static int stream_weights(const mmb_lstm_fwd_desc* d, int n, hipStream_t stream)
         const WsFwd L = ws_fwd_layout(BT, P.B, P.I, H);
         char* ws = static_cast<char*>(P.ws);
         const int nbx = (int)((BT + 15) / 16);
-        SplitRowsArgs& w = sw[p];
+        SplitRowsArgs& x = all[p];
+        x = SplitRowsArgs{};
+        x.src1 = P.x; x.src2 = P.x; x.R1 = (int)BT; x.R = (int)BT; x.C = P.I; x.ld = P.I; x.Cp = L.Ip; x.gate_H = 0;
+        x.planes = reinterpret_cast<bf16_t*>(ws + L.xP); x.np = np; x.inv_out = reinterpret_cast<float*>(ws + L.xinv);
+        x.absmax_out = P.x_absmax; x.absmax_partials = 1;
+        x.perm_B = P.B; x.perm_T = P.T;
+        SplitRowsArgs& w = all[n + p];
         w = SplitRowsArgs{};
         w.src1 = P.w_ih[0]; w.src2 = P.w_ih[1]; w.R1 = 4 * H; w.R = 8 * H; w.C = P.I; w.ld = P.I; w.Cp = L.Ip; w.gate_H = H;
         w.planes = reinterpret_cast<bf16_t*>(ws + L.wP);
         w.b1a = P.b_ih[0]; w.b2a = P.b_hh[0]; w.b1b = P.b_ih[1]; w.b2b = P.b_hh[1]; w.bias_out = reinterpret_cast<float*>(ws + L.bias);
         w.np = np; w.inv_out = reinterpret_cast<float*>(ws + L.winv);
-        w.absmax_out = P.x_absmax ? P.x_absmax + nbx : nullptr; w.absmax_partials = 1;
+        w.absmax_out = P.x_absmax + nbx; w.absmax_partials = 1;
     }
-    return planes_split_rows_group(sw, n, stream);
+    return planes_split_rows_group(all, 2 * n, stream);
 }
 
 template <typename ArgsT, typename K>
@@ -1174,7 +1157,7 @@ extern "C" int mmb_bilstm_layer_fwd_phase(const mmb_lstm_fwd_desc* d, int n, int
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int which, K, KH;
     MMB_REQUIRE(stream_decode(phase, which, K, KH), "mmb_bilstm_layer_fwd_phase: phase word 0x%x (MMB_LSTM_FWD_HEAD / _REC / _TAIL | MMB_LSTM_FWD_CHUNKS(K, KH), "
-                "2 <= K <= 64, 1 <= KH < K)", phase);
+                "2 <= K <= 64, 0 <= KH < K)", phase);
     MMB_REQUIRE(d && n >= 1 && 2 * n <= MMB_MAX_GROUP, "mmb_bilstm_layer_fwd_phase: n=%d problems (at most %d: two products per problem and launch)", n, MMB_MAX_GROUP / 2);
     MMB_HIP(hipSetDevice(device));
     const int H = d[0].H;
@@ -1188,27 +1171,21 @@ extern "C" int mmb_bilstm_layer_fwd_phase(const mmb_lstm_fwd_desc* d, int n, int
             MMB_REQUIRE(p.w_ih[dir] && p.w_hh[dir] && p.b_ih[dir] && p.b_hh[dir], "null weight in desc %d", i);
     }
     StreamPlan sp;
-    stream_plan(d, n, K, KH, sp);
+    if (int rc = stream_plan(d, n, K, KH, sp)) return rc;
     unsigned* sync = reinterpret_cast<unsigned*>(static_cast<char*>(d[0].ws) + ws_fwd_layout((long)d[0].B * d[0].T, d[0].B, d[0].I, H).sync);
     int total_wgs = 0;
     for (int i = 0; i < n; ++i) total_wgs += 2 * d[i].B;
     const int gate_wgs = total_wgs < 256 ? total_wgs : 256;
     if (which == MMB_LSTM_FWD_HEAD) {
-        MMB_HIP(hipMemsetAsync(sync, 0, 64, stream));
-        if (int rc = stream_weights(d, n, stream)) return rc;
-        for (int k = 0; k < KH; ++k)
-            if (int rc = stream_chunk(d, n, sp, k, stream)) return rc;
+        MMB_HIP(hipMemsetAsync(sync, 0, SYNC_BYTES, stream));
+        if (int rc = stream_split(d, n, stream)) return rc;
+        if (KH > 0) return planes_gemm_chunked(sp.sub, sp.rows_per_iv, sp.n_iv, sp.rev, sp.nsub, sp.cfg, sp.step_blocks, 0, KH, sync, stream);
         return MMB_OK;
     }
     if (which == MMB_LSTM_FWD_TAIL) {
         hipLaunchKernelGGL(stream_gate_kernel, dim3(1), dim3(64), 0, stream, sync, (unsigned)gate_wgs, 20000LL);      // <= 200 us
         MMB_HIP(hipGetLastError());
-        for (int k = KH; k < K; ++k) {
-            if (int rc = stream_chunk(d, n, sp, k, stream)) return rc;
-            hipLaunchKernelGGL(stream_publish_kernel, dim3(1), dim3(64), 0, stream, sync, (unsigned)(k + 1));
-            MMB_HIP(hipGetLastError());
-        }
-        return MMB_OK;
+        return planes_gemm_chunked(sp.sub, sp.rows_per_iv, sp.n_iv, sp.rev, sp.nsub, sp.cfg, sp.step_blocks, KH, K, sync, stream);
     }
     // the recurrence, consuming Gx chunk by chunk
     RecFwdArgs ra{};
@@ -1223,6 +1200,7 @@ extern "C" int mmb_bilstm_layer_fwd_phase(const mmb_lstm_fwd_desc* d, int n, int
         wg += 2 * p.B;
     }
     ra.sync = sync; ra.tmo_host = lstm_timeout_word(); ra.chunks_ready = KH; ra.chunks_total = K; ra.gate_wgs = gate_wgs;
+    ra.chunk_blocks = sp.step_blocks;
     switch (kq_for(H)) {
         case 8: return launch_rec(lstm_rec_fwd_kernel<8, PF, 0, true>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);
         case 16: return launch_rec(lstm_rec_fwd_kernel<16, PF, 0, true>, ra, wg, H, stream, MMB_K_LSTM_REC_FWD);

@@ -390,18 +390,44 @@ struct PlanesGroup {
     PlanesGemmArgs g[MMB_MAX_GROUP];
     int kchunk[MMB_MAX_GROUP], tiles_n[MMB_MAX_GROUP], ntiles[MMB_MAX_GROUP], blk_begin[MMB_MAX_GROUP + 1];
     int n;
+    // Chunk-ordered form (chunked != 0; the streamed input projection of lstm.hip): the rows of every product are cut into
+    // intervals of rt_per_iv row tiles, and the grid is a sequence of STEPS of step_blocks workgroups: step j computes, for every
+    // product p, interval c0 + j (rev[p] == 0) or n_iv[p] - 1 - (c0 + j) (rev[p] != 0) -- workgroups are dispatched in id order, so
+    // the intervals complete in the order a consumer that runs BESIDE this launch needs them.  Every workgroup of step j (also the
+    // padding ones) adds 1 to done[c0 + j] once its stores (write-through, sc1) have been drained: done[c] == step_blocks tells
+    // a consumer on another CU that chunk c is complete (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 payload, drained,
+    // one agent-scope add per workgroup; the consumer polls with sc1 loads and reads the payload with sc1 loads).
+    int chunked, step_blocks, c0;
+    int sub_begin[MMB_MAX_GROUP + 1], rt_per_iv[MMB_MAX_GROUP], n_iv[MMB_MAX_GROUP], rev[MMB_MAX_GROUP];
+    unsigned* done;
 };
 
 template <int WM, int WN, int MT, int NT, int NP, int STAGES, bool TA = false>
 __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGroup G) {
     static_assert(WM * WN == 8, "8 waves");
-    int prob = 0;
-    for (int i = 1; i < G.n; ++i)
-        if ((int)blockIdx.x >= G.blk_begin[i]) prob = i;
+    int prob = 0, lid, ntiles, tm_off = 0, chunk = 0;
+    bool live = true;
+    if (G.chunked) {
+        const int step = blockIdx.x / G.step_blocks, rid = blockIdx.x - step * G.step_blocks;
+        for (int i = 1; i < G.n; ++i)
+            if (rid >= G.sub_begin[i]) prob = i;
+        lid = rid - G.sub_begin[prob];
+        chunk = G.c0 + step;
+        ntiles = G.rt_per_iv[prob] * G.tiles_n[prob];
+        live = chunk < G.n_iv[prob] && lid < ntiles;
+        tm_off = (G.rev[prob] ? G.n_iv[prob] - 1 - chunk : chunk) * G.rt_per_iv[prob];
+    } else {
+        for (int i = 1; i < G.n; ++i)
+            if ((int)blockIdx.x >= G.blk_begin[i]) prob = i;
+        lid = blockIdx.x - G.blk_begin[prob];
+        ntiles = G.ntiles[prob];
+    }
     const PlanesGemmArgs& g = G.g[prob];
-    const int kchunk = G.kchunk[prob], tiles_n = G.tiles_n[prob], ntiles = G.ntiles[prob];
-    const int lid = blockIdx.x - G.blk_begin[prob];
-    if (lid >= ntiles * g.splitk) return;
+    const int kchunk = G.kchunk[prob], tiles_n = G.tiles_n[prob];
+    if (!live || lid >= ntiles * g.splitk) {
+        if (G.chunked && threadIdx.x == 0) __hip_atomic_fetch_add(G.done + chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     static_assert(!TA || (NP == 2 && (WM * MT * 16) % 32 == 0), "k-major A: fp16 planes, BM a multiple of 32");
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16, RT = BM + BN;  // rows per plane image
     constexpr int STAGE = NP * RT * 64;                                // bytes per stage
@@ -418,7 +444,7 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGroup G) {
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int lin = xcd * q8 + min(xcd, r8) + pos;
     const int z = lin / ntiles, tile = lin - z * ntiles;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int tm = tile / tiles_n + tm_off, tn = tile - (tile / tiles_n) * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kb = z * kchunk;
     const int ke = min(g.K, kb + kchunk);
@@ -629,10 +655,16 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGroup G) {
                     float* dst = g.C + (size_t)m * g.ldc + n;
                     f4 v = *reinterpret_cast<const f4*>(stg + row * LDW + 4 * c4);
                     if (g.accumulate) v += *reinterpret_cast<const f4*>(dst);
-                    *reinterpret_cast<f4*>(dst) = v;
+                    if (G.chunked) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");   // write-through: see PlanesGroup
+                    else *reinterpret_cast<f4*>(dst) = v;
                 }
             }
         }
+    }
+    if (G.chunked) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its stores, then the workgroup's barrier,
+        __syncthreads();                                      // then ONE lane signals for all of them
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(G.done + chunk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -727,6 +759,17 @@ static int launch_planes_np(PlanesGroup& G, hipStream_t stream) {
         blk += (G.ntiles[p] * g.splitk + 7) & ~7;
     }
     G.blk_begin[G.n] = blk;
+    if (G.chunked) {      // G.rt_per_iv holds ROWS per interval on entry (a multiple of BM: checked by planes_gemm_chunked)
+        int sb = 0;
+        for (int p = 0; p < G.n; ++p) {
+            G.rt_per_iv[p] /= BM;
+            G.sub_begin[p] = sb;
+            sb += (G.rt_per_iv[p] * G.tiles_n[p] + 7) & ~7;
+        }
+        G.sub_begin[G.n] = sb;
+        MMB_REQUIRE(sb == G.step_blocks, "planes_gemm_chunked: %d blocks per step, the plan said %d", sb, G.step_blocks);
+        blk = sb * G.chunked;      // (chunked = number of steps of this launch)
+    }
     ProfScope ps_(MMB_K_GEMM, stream);
     hipLaunchKernelGGL(kern, dim3(blk), dim3(512), lds, stream, G);
     MMB_HIP(hipGetLastError());
@@ -891,6 +934,61 @@ int planes_gemm_group(const PlanesGemmArgs* gs, int n, hipStream_t stream) {
 }
 
 int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream) { return planes_gemm_group(&g, 1, stream); }
+
+// ---- chunk-ordered launches (see PlanesGroup): tile shapes whose row extent divides every product's interval
+static const int CHUNK_CFGS[] = {3, 2, 5, 4};      // 128x224, 128x160, 64x224, 64x160
+int planes_chunked_plan(const PlanesGemmArgs* gs, const int* rows_per_iv, int n, int* cfg_out, int* step_blocks_out) {
+    MMB_REQUIRE(gs && n >= 1 && n <= MMB_MAX_GROUP, "planes_chunked_plan: 1..%d products", MMB_MAX_GROUP);
+    double best_cost = 1e300;
+    int best = -1, best_sb = 0;
+    for (int ci = 0; ci < 4; ++ci) {
+        const PlanesCfg& c = PLANES_CFGS[CHUNK_CFGS[ci]];
+        const int bm = c.wm * c.mt * 16, bn = c.wn * c.nt * 16;
+        bool ok = true;
+        double cost = 0;
+        int sb = 0;
+        for (int p = 0; p < n && ok; ++p) {
+            ok = rows_per_iv[p] % bm == 0;
+            PlanesGemmArgs g = gs[p];
+            g.splitk = 1;
+            cost += planes_cost(g, c, 1);
+            sb += (rows_per_iv[p] / bm * ((g.N + bn - 1) / bn) + 7) & ~7;
+        }
+        if (ok && cost < best_cost) { best_cost = cost; best = CHUNK_CFGS[ci]; best_sb = sb; }
+    }
+    MMB_REQUIRE(best >= 0, "planes_chunked_plan: no tile shape divides the intervals (rows per interval must be a multiple of 64)");
+    *cfg_out = best;
+    *step_blocks_out = best_sb;
+    return MMB_OK;
+}
+// chunks [c0, c1) of the products gs (np, ta as in planes_gemm_group; no K split; C float4-aligned): see PlanesGroup
+int planes_gemm_chunked(const PlanesGemmArgs* gs, const int* rows_per_iv, const int* n_iv, const int* rev, int n, int cfg, int step_blocks,
+                        int c0, int c1, unsigned* done, hipStream_t stream) {
+    MMB_REQUIRE(gs && n >= 1 && n <= MMB_MAX_GROUP && c1 > c0 && done, "planes_gemm_chunked: bad argument");
+    PlanesGroup G{};
+    G.n = n;
+    for (int p = 0; p < n; ++p) {
+        PlanesGemmArgs& g = G.g[p];
+        g = gs[p];
+        g.dbg = 0;
+        if (g.np != 2 && g.np != 1) g.np = 3;
+        g.splitk = 1;
+        MMB_REQUIRE(!g.ta && g.np == G.g[0].np, "planes_gemm_chunked: row-major operands, one plane format");
+        MMB_REQUIRE(((g.ldc & 3) == 0) && ((g.N & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) && !g.accumulate,
+                    "planes_gemm_chunked: C must take float4 stores");
+        G.rt_per_iv[p] = rows_per_iv[p];      // rows on entry; launch_planes_np turns them into row tiles
+        G.n_iv[p] = n_iv[p];
+        G.rev[p] = rev[p];
+    }
+    G.chunked = c1 - c0; G.c0 = c0; G.step_blocks = step_blocks; G.done = done;
+    switch (cfg) {
+        case 2: return launch_planes<4, 2, 2, 5>(G, stream);
+        case 3: return launch_planes<4, 2, 2, 7>(G, stream);
+        case 4: return launch_planes<4, 2, 1, 5>(G, stream);
+        case 5: return launch_planes<4, 2, 1, 7>(G, stream);
+        default: return fail(MMB_ERR_ARG, "planes_gemm_chunked: tile configuration %d", cfg);
+    }
+}
 
 }  // namespace mmb
 

@@ -42,14 +42,14 @@ def _parse_stream_cfg(text):
     cfg = []
     for part in text.split(";"):
         k, kh = (int(v) for v in part.split(","))
-        cfg.append(None if k < 2 else (k, max(1, min(kh, k - 1))))
+        cfg.append(None if k < 2 else (k, max(0, min(kh, k - 1))))
     if len(cfg) != 3:
         raise ValueError("MMB_FWD_STREAM: three K,KH pairs separated by ';'")
     return cfg
 
 
 # Streamed input projection of the forward layer calls (mmb_bilstm_layer_fwd_phase): the projection GEMM of a layer call runs
-# beside its recurrence on the side stream, in K time chunks per direction of which the first KH are computed up front.
+# beside its recurrence on the side stream, in K time chunks per direction of which the first KH (possibly 0) are computed up front.
 _FWD_STREAM = _parse_stream_cfg(os.environ.get("MMB_FWD_STREAM", "8,1;8,3;8,1"))
 _FWD_STREAM_MIN_ROWS = 4096          # B * T below this: the one-launch projection (a few microseconds) is not worth 2 K launches
 
