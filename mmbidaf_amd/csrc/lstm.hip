@@ -117,6 +117,7 @@ __device__ __forceinline__ float ld_sc1_f32(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 constexpr long long STREAM_WAIT_TICKS = 200000000LL;   // 2 s of the 100-MHz wall clock
+constexpr bool STREAM_SC1_LOADS = false;               // see gx_at in lstm_rec_fwd_kernel
 // wait until chunk c is complete (every workgroup of its step has arrived); false when the wait gave up
 __device__ __forceinline__ bool stream_wait_chunk(const RecFwdArgs& args, unsigned c) {
     const unsigned full = (unsigned)args.chunk_blocks;
@@ -286,7 +287,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto gx_at = [&](int sidx) {
         if (DBG & 2) return 0.01f * sidx;
         const float* p = gx_b + (size_t)(t0 + sgn * min(sidx, len - 1)) * gx_tstride + gx_base;
-        return STREAM ? ld_sc1_f32(p) : *p;
+        // Plain loads also in the streamed form: a 128-B line of Gx lies inside ONE chunk (chunk boundaries are multiples of
+        // 128 B: C B 4H floats with C B a multiple of 128 rows), the producer writes it through (sc1) and drains before the
+        // chunk's counter moves, and this workgroup touches no line of a chunk before it has seen that counter complete (ensure()) --
+        // so neither this CU's L1 (invalidated at kernel start) nor the XCD's L2 can hold an older copy of it.  (sc1 loads measured
+        // the same speed; STREAM_SC1_LOADS selects them.)
+        return (STREAM && STREAM_SC1_LOADS) ? ld_sc1_f32(p) : *p;
     };
     // streamed projection: step s reads time row t0 + sgn s of interval (row / chunk); the tail publishes the intervals from both
     // ends inwards.  `confirmed` launches are known to be complete; ensure(s_last) is called before any load of a step <= s_last is issued.
@@ -294,28 +300,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // compare when the producer is ahead; only a chunk that is really not there yet makes the workgroup wait.
     const int chunk = STREAM ? max(P.chunk, 1) : 1;
     const int nK = STREAM ? P.nchunks : 1;
-    unsigned confirmed = STREAM ? (unsigned)args.chunks_ready : 0u;
+    // launches that must be complete before step s may be loaded: launch k carries interval k of the forward direction (time rows
+    // [k C, (k+1) C)) and interval nK - 1 - k of the reverse direction.  With `confirmed` launches known to be complete, every step
+    // s < s_lim is covered: s_lim = confirmed * C (forward: s = t) or len - (nK - confirmed) * C (reverse: s = len - 1 - t).  One
+    // compare per block of PFD steps; s_lim moves by C per confirmed launch (no division in the loop: two runtime divisions per
+    // block cost the recurrence 10 %, 220 vs 199 us per launch).
+    int confirmed = STREAM ? min(args.chunks_ready, nK) : 0;
+    int s_lim = STREAM ? (rev ? len - (nK - confirmed) * chunk : confirmed * chunk) : 0;
     unsigned peek = 0u;
     bool peeking = false;
-    // launches that must be complete before step s_last may be loaded: the time row's interval t / chunk, counted from the start
-    // (forward: launch k carries interval k) or from the end (reverse: launch k carries interval nK - 1 - k)
-    auto need_for = [&](int s_last) {
-        const int tt = t0 + sgn * min(s_last, len - 1);
-        return (unsigned)min(rev ? nK - tt / chunk : tt / chunk + 1, args.chunks_total);
-    };
     auto ensure = [&](int s_last) {
         if constexpr (STREAM) {
-            if (len <= 0) return;
-            if (peeking) {      // the peek of the previous block has long arrived: the next chunk was complete by then, or not
-                if (peek >= (unsigned)args.chunk_blocks) ++confirmed;
+            if (peeking) {      // the peek of the previous block has long arrived: the next launch was complete by then, or not
+                if (peek >= (unsigned)args.chunk_blocks) { ++confirmed; s_lim += chunk; }
                 peeking = false;
             }
-            const unsigned need = need_for(s_last);
-            while (need > confirmed) {
-                stream_wait_chunk(args, confirmed);      // (a wait that gave up has marked the step invalid: go on regardless)
+            const int sl = min(s_last, len - 1);      // (loads of later steps are clamped to the last one)
+            while (sl >= s_lim && confirmed < nK) {
+                stream_wait_chunk(args, (unsigned)confirmed);      // (a wait that gave up has marked the step invalid: go on regardless)
                 ++confirmed;
+                s_lim += chunk;
             }
-            if (need_for(s_last + PFD) > confirmed) { peek = ld_sc1_u32(args.sync + confirmed); peeking = true; }
+            if (sl + PFD >= s_lim && confirmed < nK) { peek = ld_sc1_u32(args.sync + confirmed); peeking = true; }
         }
     };
     float gxr[PFD];

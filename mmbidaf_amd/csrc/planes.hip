@@ -655,7 +655,9 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGroup G) {
                     float* dst = g.C + (size_t)m * g.ldc + n;
                     f4 v = *reinterpret_cast<const f4*>(stg + row * LDW + 4 * c4);
                     if (g.accumulate) v += *reinterpret_cast<const f4*>(dst);
-                    if (G.chunked) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");   // write-through: see PlanesGroup
+                    // write-through (see PlanesGroup); the s_nop: hipcc does not pad an asm store, and its next instruction may
+                    // overwrite the data registers before a 128-bit store has read them (cdna_hip_programming.md 5.7 item 1)
+                    if (G.chunked) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
                     else *reinterpret_cast<f4*>(dst) = v;
                 }
             }

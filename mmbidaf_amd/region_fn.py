@@ -50,7 +50,11 @@ def _parse_stream_cfg(text):
 
 # Streamed input projection of the forward layer calls (mmb_bilstm_layer_fwd_phase): the projection GEMM of a layer call runs
 # beside its recurrence on the side stream, in K time chunks per direction of which the first KH (possibly 0) are computed up front.
-_FWD_STREAM = _parse_stream_cfg(os.environ.get("MMB_FWD_STREAM", "8,1;8,3;8,1"))
+# OFF by default: built, parity-tested (bit-identical results) and measured in round 5 -- at cfg2 it does not pay (DESIGN.md 4.2:
+# the 64-128 CUs a forward recurrence leaves free cannot absorb the projection's CU-time, the chunk-ordered direction-split GEMM is
+# 1.6-1.8x less efficient than the one-launch product, and the recurrence loses 3-10 % beside it).  MMB_FWD_STREAM="0,0;8,3;0,0"
+# (modelling layer 0 only: break-even) or "8,0;8,2;8,0" select it.
+_FWD_STREAM = _parse_stream_cfg(os.environ.get("MMB_FWD_STREAM", "0"))
 _FWD_STREAM_MIN_ROWS = 4096          # B * T below this: the one-launch projection (a few microseconds) is not worth 2 K launches
 
 

@@ -11,13 +11,12 @@ gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
 region_fn._FWD_STREAM_MIN_ROWS = 0
 def run(cfg):
     region_fn._FWD_STREAM = cfg
-    for p in region.parameters(): p.grad = None
-    xs = [gpu[k].detach().clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
-    outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
-    synth.region_loss(outs, gpu).backward()
+    xs = [gpu[k].detach().clone() for k in ("x_text", "x_aud", "x_img")]
+    with torch.no_grad():
+        outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
     torch.cuda.synchronize()
-    return {n: p.grad.clone() for n, p in region.named_parameters()}
-a = run([(8,1),(8,3),(8,1)]); b = run(None); b2 = run(None)
-for n in a:
-    e = (a[n]-b[n]).abs().max().item(); e2 = (b2[n]-b[n]).abs().max().item()
-    if e or e2: print(n, "streamed-vs-classic", e, "classic-vs-classic", e2, "max", b[n].abs().max().item())
+    return [o.clone() for o in outs]
+ref = run(None)
+for name, cfg in (("enc only", [(8,1),None,None]), ("L0 only", [None,(8,3),None]), ("L1 only", [None,None,(8,1)]), ("enc KH0", [(8,0),None,None])):
+    a = run(cfg); a2 = run(cfg)
+    print(name, "vs classic", [float((x-y).abs().max()) for x, y in zip(a, ref)], "repeat", [float((x-y).abs().max()) for x, y in zip(a, a2)], "timeouts", _lib.persist_timeouts())
