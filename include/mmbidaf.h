@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMB_VERSION 500            /* round 5 ABI: + mmb_bilstm_layer_fwd_phase (streamed input projection) */
+#define MMB_VERSION 500            /* round 5 ABI: + mmb_bilstm_layer_fwd_phase (streamed input projection), mmb_stream_gate + mmb_lstm_bwd_desc.gate */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
 #define MMB_ATT_MAX_D 208          /* attention feature width D = 2H of the fused (register-resident) kernels */
 #define MMB_ATT_GENERAL_MAX_D 4096 /* wider D (up to this) runs the general path: similarity matrix in a workspace */
@@ -247,6 +247,8 @@ typedef struct {
     void* ws;                  /* scratch of mmb_bilstm_ws_bytes(B,T,I,H,1) bytes or NULL        */
     const int32_t* hn_pos;     /* (B) or NULL: layout of d_hn, as in the forward desc             */
     const float* x_absmax;     /* as left by the forward call                                     */
+    uint32_t* gate;            /* NULL, or (descs[0] only) a device word that is ZERO between steps: the first min(2 B n, 256) workgroups */
+                               /* of the BPTT recurrence add 1 to it as they start; mmb_stream_gate on another stream waits for them */
     int32_t B, T, I, H;
 } mmb_lstm_bwd_desc;
 
@@ -279,6 +281,12 @@ int mmb_stream_destroy(int device, void* stream);
  * recurrence that is launched on another stream at the same point of the dependency graph, so that the recurrence's
  * workgroups are dispatched first also when both branches of a replayed hipGraph start together (see csrc/api.hip). */
 int mmb_stream_delay(int device, void* stream, int microseconds);
+/* The explicit form of the same ordering (round 5): one idle wave that holds `stream` until *counter >= target -- the workgroups of a
+ * recurrence launched on another stream count themselves in there as they start (mmb_lstm_bwd_desc.gate) -- or `timeout_us` (<= 1000)
+ * have passed, whichever comes first; on leaving it subtracts `target` from the counter, so that the word is zero again once every
+ * counted workgroup has started, whatever the interleaving.  A dependency on the recurrence's DISPATCH instead of on elapsed time:
+ * clock, tenants or driver changes move neither the result nor, beyond the bounded wait, the schedule. */
+int mmb_stream_gate(int device, void* stream, uint32_t* counter, int target, int timeout_us);
 /* Test / rehearsal aid: `workgroups` one-wave workgroups that each hold `lds_bytes` of LDS for `microseconds` on `stream` and do
  * nothing else -- a stand-in for a long-lived kernel of another stream (e.g. an RCCL collective) sharing the chip with the
  * persistent recurrence, whose workgroups must be resident together (tests: the recurrence finishes, with correct results and

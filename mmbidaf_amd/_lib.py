@@ -39,7 +39,7 @@ class LstmBwdDesc(ctypes.Structure):
         ("d_y", c_f), ("d_hn", c_f), ("x", c_f), ("y", c_f), ("lengths", c_f),
         ("w_ih", c_f * 2), ("w_hh", c_f * 2), ("gates", c_f), ("cs", c_f),
         ("d_x", c_f), ("d_w_ih", c_f), ("d_w_hh", c_f), ("d_b", c_f), ("d_a", c_f), ("d_w_cat", c_f), ("ws", c_f),
-        ("hn_pos", c_f), ("x_absmax", c_f),
+        ("hn_pos", c_f), ("x_absmax", c_f), ("gate", c_f),
         ("B", ctypes.c_int32), ("T", ctypes.c_int32), ("I", ctypes.c_int32), ("H", ctypes.c_int32),
     ]
 
@@ -100,6 +100,7 @@ SIGNATURES = {
     "mmb_lstm_persist_reset": (c_i, []),
     "mmb_lstm_persist_enable": (c_i, [c_i]),
     "mmb_stream_delay": (c_i, [c_i, c_f, c_i]),
+    "mmb_stream_gate": (c_i, [c_i, c_f, c_f, c_i, c_i]),
     "mmb_stream_occupy": (c_i, [c_i, c_f, c_i, c_i, c_i]),
     "mmb_hidden_states_fwd": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_i, ctypes.POINTER(ctypes.c_void_p), c_f, c_i, c_i, c_i, c_f]),
     "mmb_hidden_states_bwd": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_i, c_i, c_f]),

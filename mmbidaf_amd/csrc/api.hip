@@ -179,6 +179,22 @@ extern "C" int mmb_stream_occupy(int device, void* stream, int microseconds, int
     return MMB_OK;
 }
 
+namespace mmb {
+__global__ __launch_bounds__(64) void gate_kernel(unsigned* counter, const unsigned target, const long long ticks) {
+    const long long t0 = wall_clock64();
+    while ((int)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)target && wall_clock64() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(8);
+    if (threadIdx.x == 0) __hip_atomic_fetch_sub(counter, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace mmb
+extern "C" int mmb_stream_gate(int device, void* stream, uint32_t* counter, int target, int timeout_us) {
+    MMB_REQUIRE(counter && target >= 1 && timeout_us >= 1 && timeout_us <= 1000, "mmb_stream_gate: counter, target >= 1, 1 <= timeout_us <= 1000");
+    MMB_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(mmb::gate_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), counter, (unsigned)target, (long long)timeout_us * 100);
+    MMB_HIP(hipGetLastError());
+    return MMB_OK;
+}
+
 extern "C" int mmb_stream_delay(int device, void* stream, int microseconds) {
     MMB_REQUIRE(microseconds >= 0 && microseconds <= 1000, "mmb_stream_delay: 0 <= microseconds <= 1000");
     MMB_HIP(hipSetDevice(device));

@@ -377,6 +377,8 @@ struct RecBwdProb {
 struct RecBwdArgs {
     RecBwdProb p[MMB_MAX_GROUP];
     int n;
+    unsigned* gate;        // null, or the word the first gate_wgs workgroups count themselves into as they start (mmb_stream_gate)
+    int gate_wgs;
 };
 
 // BPTT recurrence: dh_{t}[u] = sum_{g,u'} d_a_{t+1}[g][u'] W_hh[g*H+u'][u]  (K = 4H, H outputs).
@@ -417,6 +419,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int H = P.H, T = P.T;
     const int len = min(max(P.len[b], 0), T);
     const int tid = threadIdx.x, ks = tid & 15;
+    if (args.gate && tid == 0 && (int)blockIdx.x < args.gate_wgs) __hip_atomic_fetch_add(args.gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int ngroups = (H + 3) / 4;
     const bool real = (tid >> 4) < ngroups;
     const int ug = min(tid >> 4, ngroups - 1);   // surplus rows shadow the last group (same values, same addresses)
@@ -1262,6 +1265,8 @@ extern "C" int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* d, int n, int
         q.d_a = p.d_a; q.d_b = p.d_b; q.B = p.B; q.T = p.T; q.H = p.H; q.wg_begin = wg;
         wg += 2 * p.B;
     }
+    ra.gate = big ? nullptr : d[0].gate;
+    ra.gate_wgs = wg < 256 ? wg : 256;
     int rc;
     if (big) {
         char* big_ws[MMB_MAX_GROUP];

@@ -78,13 +78,48 @@ def side_stream(device):
 _SIDE_DELAY_US = int(os.environ.get("MMB_SIDE_DELAY_US", "12"))
 
 
+_SIDE_GATE = os.environ.get("MMB_SIDE_GATE", "1") != "0"
+_gate_words = {}          # device index -> int32 tensor: [0] the word the recurrences' workgroups count themselves into (zero between steps)
+_last_rec_wgs = {}        # device index -> workgroups of the BPTT recurrence launched last with that word in its descriptor
+
+
+def gate_word(dev_index):
+    """The device word of mmb_lstm_bwd_desc.gate / mmb_stream_gate for this device: zero-initialised once, and back to zero after
+    every (recurrence, gate) pair -- the gate subtracts what the recurrence's workgroups add."""
+    w = _gate_words.get(dev_index)
+    if w is None:
+        w = _gate_words[dev_index] = torch.zeros(16, device=torch.device("cuda", dev_index), dtype=torch.int32)
+    return w
+
+
+def gate_ptr(dev_index, wgs=None):
+    """Pointer for descs[0].gate of a BPTT launch whose side-stream companion will call _side_head_start (None: the gate is
+    switched off and the time delay is used); wgs given: also arm the next _side_head_start for a launch of that many workgroups."""
+    if not _SIDE_GATE:
+        return None
+    if wgs is not None:
+        arm_gate(dev_index, wgs)
+    return gate_word(dev_index).data_ptr()
+
+
+def arm_gate(dev_index, wgs):
+    """the next _side_head_start on this device waits for a recurrence launch of `wgs` workgroups (its first 256 count)"""
+    if _SIDE_GATE:
+        _last_rec_wgs[dev_index] = min(int(wgs), 256)
+
+
 def _side_head_start(dev_index, side):
     """Side-stream work ordered behind an event recorded just BEFORE a recurrence launch is meant to run beside that
     recurrence, on the CUs it leaves free.  Issued from the host it reaches the GPU after the recurrence; as parallel branches
     of a replayed hipGraph the two start together, and a GEMM that wins the race takes every CU while the recurrence's
-    workgroups wait (257 -> 326-364 us per backward recurrence, profiles/r03_side_dispatch_order.md).  A few microseconds
-    of an idle wave at the head of the side work let the recurrence's workgroups be dispatched first."""
-    if _SIDE_DELAY_US > 0:
+    workgroups wait (257 -> 326-364 us per backward recurrence, profiles/r03_side_dispatch_order.md).  Round 5: an explicit
+    dependency -- the recurrence's workgroups count themselves into a device word as they start (mmb_lstm_bwd_desc.gate) and one
+    idle wave at the head of the side work waits for that count (mmb_stream_gate, bounded at 200 us) -- where rounds 3-4 let a
+    fixed 12 us pass (MMB_SIDE_GATE=0 selects that form again)."""
+    wgs = _last_rec_wgs.pop(dev_index, None) if _SIDE_GATE else None
+    if wgs:
+        _lib.check(_lib.load().mmb_stream_gate(dev_index, side.cuda_stream, gate_word(dev_index).data_ptr(), wgs, 200), "mmb_stream_gate")
+    elif _SIDE_DELAY_US > 0:
         _lib.check(_lib.load().mmb_stream_delay(dev_index, side.cuda_stream, _SIDE_DELAY_US), "mmb_stream_delay")
 
 
@@ -602,6 +637,8 @@ class _BiLSTMLayerFn(torch.autograd.Function):
                 # workgroups are dispatched first and the side stream's kernels take the CUs that are left
                 before = torch.cuda.Event()
                 before.record(main)
+                if _deferred.get(_dev_index(dev)) or prep_todo:      # side-stream work will follow: its gate waits for this recurrence's workgroups
+                    descs[0].gate = gate_ptr(dev.index, sum(2 * sv[i * 10].shape[0] for i in range(n)))
                 _lib.check(lib.mmb_bilstm_layer_bwd_phase(descs, n, 1 | flags, dev.index, main.cuda_stream), "mmb_bilstm_layer_bwd_phase(1)")
                 flush_deferred(dev, to_side=True, after=before)
                 _prepare_enqueue(dev, prep_todo, prep, before)

@@ -492,6 +492,8 @@ def _build_templates(plan):
                 else:
                     t.ptr(i, fld, src[0], src[1])
             t.dynamic(i, "d_hn", f"d_hn{i}")
+            if i == 0:
+                t.dynamic(0, "gate", "gate")
             t.dynamic(i, "d_x", f"d_x{i}")
             t.dynamic(i, "d_w_ih", f"d_w_ih{i}")
             t.dynamic(i, "d_w_hh", f"d_w_hh{i}")
@@ -760,18 +762,23 @@ class _RegionFn(torch.autograd.Function):
             pa, ta = cot("a1", g_mod_a, (B, T, D), "out_a")
             pi, ti = cot("i1", g_mod_i, (B, T, D), "out_i")
         hold += [ta, ti]
+        two = side is not main
+        # (the word the BPTT recurrences' workgroups count themselves into for the side stream's gate, MF._side_head_start)
+        gp = MF.gate_ptr(di) if two else None
+        gate = {2: gp, 3: gp}
         L1, w1 = tm["b_l1"].build(bases, pp, x0=c.l1_in[0], x1=c.l1_in[1], dy0=pa, dy1=pi, y0=y1[0].data_ptr(), y1=y1[1].data_ptr(),
-                                  d_hn0=dh["a1"], d_hn1=dh["i1"],
+                                  d_hn0=dh["a1"], d_hn1=dh["i1"], gate=gate[2],
                                   **lstm_dyn(("a1", "i1"), (True, True)))
-        L0, w0 = tm["b_l0"].build(bases, pp, d_hn0=dh["a0"], d_hn1=dh["i0"], **lstm_dyn(("a0", "i0"), (True, True)))
+        L0, w0 = tm["b_l0"].build(bases, pp, d_hn0=dh["a0"], d_hn1=dh["i0"], gate=gate[2], **lstm_dyn(("a0", "i0"), (True, True)))
         EN, we = tm["b_en"].build(bases, pp, x0=c.xs[0].data_ptr(), x1=c.xs[1].data_ptr(), x2=c.xs[2].data_ptr(),
-                                  d_hn0=0, d_hn1=0, d_hn2=0, **lstm_dyn(("et", "ea", "ei"), c.need_dx))
+                                  d_hn0=0, d_hn1=0, d_hn2=0, gate=gate[3], **lstm_dyn(("et", "ea", "ei"), c.need_dx))
         hold += [w1, w0, we]
         if two:
             before = torch.cuda.Event()
             before.record(main)
             phase(L1, 2, 1 | HAVE_XC, ms, "bwd phase 1 (modelling layer 1)")
             side.wait_event(before)
+            MF.arm_gate(di, 4 * B)
             MF._side_head_start(di, side)
             # (PREPARE reads x, y, w_ih, x_absmax, ws, d_w_cat and the sizes only: the encoders' descriptors serve as they are)
             phase(EN, 3, PREPARE | HAVE_WT, ss, "bwd prepare x planes")
@@ -800,6 +807,7 @@ class _RegionFn(torch.autograd.Function):
             before.record(main)
             phase(L0, 2, 1 | f0, ms, "bwd phase 1 (modelling layer 0)")
             side.wait_event(before)
+            MF.arm_gate(di, 4 * B)
             MF._side_head_start(di, side)
             phase(L1, 2, 2 | HAVE_XC, ss, "bwd phase 2 (modelling layer 1)")
         else:
@@ -838,6 +846,7 @@ class _RegionFn(torch.autograd.Function):
             before.record(main)
             phase(EN, 3, 1 | f0, ms, "bwd phase 1 (input encoders)")
             side.wait_event(before)
+            MF.arm_gate(di, 6 * B)
             MF._side_head_start(di, side)
             phase(L0, 2, 2 | f0, ss, "bwd phase 2 (modelling layer 0)")
             phase(EN, 3, 2 | f0, ms, "bwd phase 2 (input encoders)")

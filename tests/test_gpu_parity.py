@@ -1646,6 +1646,63 @@ def test_streamed_projection_equals_the_one_launch_form_bit_for_bit(monkeypatch,
         assert torch.equal(x.grad, b)
 
 
+@pytest.mark.parametrize("mode", ["gate", "delay", "none"])
+def test_side_stream_head_start_forms_give_identical_results(monkeypatch, mode):
+    """The side stream's work beside a backward recurrence starts behind an explicit gate (round 5: the recurrence's workgroups
+    count themselves into a device word, one idle wave waits for the count -- mmb_stream_gate), behind the fixed delay of rounds
+    3-4, or behind nothing at all: ordering of DISPATCH only -- every result is the same in all three forms (sums of atomics to
+    round-off), and the gate's word is zero again after every step, also when the step is replayed from a captured graph."""
+    from mmbidaf_amd import synth, functional as MF
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    torch.manual_seed(224)
+    region = HotRegion(100).to(d).eval()
+    batch = synth.make_batch((8, 120, 70, 20, 100), ragged=True)
+    gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def run():
+        for p in region.parameters():
+            p.grad = None
+        xs = [gpu[k].detach().clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+        outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+        synth.region_loss(outs, gpu).backward()
+        torch.cuda.synchronize()
+        return [x.grad.clone() for x in xs], {n: p.grad.clone() for n, p in region.named_parameters()}
+    monkeypatch.setattr(MF, "_SIDE_GATE", True)
+    g_ref, p_ref = run()
+    assert int(MF.gate_word(0)[0]) == 0, "the gate's word must be back at zero after a step"
+    monkeypatch.setattr(MF, "_SIDE_GATE", mode == "gate")
+    monkeypatch.setattr(MF, "_SIDE_DELAY_US", 100 if mode == "delay" else 0)
+    g, p = run()
+    for a, b in zip(g, g_ref):
+        assert torch.equal(a, b)
+    for n in p:
+        close(p[n], p_ref[n].cpu(), f"{mode}: grad {n}", tol=2e-6)
+    assert int(MF.gate_word(0)[0]) == 0
+    if mode == "gate":
+        xs = [gpu[k].detach().clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+            synth.region_loss(outs, gpu).backward()
+        torch.cuda.current_stream().wait_stream(side)
+        for q in region.parameters():
+            q.grad = None
+        for x in xs:
+            x.grad = None
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_):
+            outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+            synth.region_loss(outs, gpu).backward()
+        for _ in range(4):
+            g_.replay()
+        torch.cuda.synchronize()
+        assert int(MF.gate_word(0)[0]) == 0
+        for x, b in zip(xs, g_ref):
+            assert torch.equal(x.grad, b)
+
+
 def test_cu_masked_stream_runs_kernels():
     """mmb_stream_create_cu_mask / mmb_stream_destroy: a stream restricted to half of the CUs computes the same GEMM
     (the option is measured and not used by default, profiles/r02_side_stream.md; the entry points stay covered)."""
