@@ -63,6 +63,8 @@ constexpr float WMAX = 16384.0f;   // 2^14: where the largest split operand is m
 // 8192 = att_row also writes the rows of `out` as the fp16 planes of the next layer's projection operand (tiled layout of
 // planes.hip, 25 K tiles, a fixed scale) into the buffer given to mmb_set_att_timestamps (>= 2 x 41 MB at cfg2): what
 // producer-written planes would cost the row pass (tools/att_bench.py --masks 32,8224)
+// 16384 = backward in its three-launch form (prologue, dq sweep, gradient sweeps) instead of the fused two-launch form; not an
+//         ablation: results are the same (tests compare the two)
 // 4096 = phase time stamps (DBG kernels, nothing ablated): thread 0 of every workgroup writes s_memrealtime (100 MHz) at
 // its phase boundaries into the buffer given to mmb_set_att_timestamps: [kernel 0..3][block][8] u64 (tools/att_phases.py)
 static int g_att_dbg = -1;
@@ -490,6 +492,7 @@ struct AttG {
     float *d_text, *d_mod, *d_text_d, *d_mod_d, *d_w_t, *d_w_m, *d_w_tm, *d_bias;
     char *pDa, *pDb, *pDq;
     float *iDa, *iDb, *iDq, *delta1, *delta2;
+    unsigned* dq_cnt;       // (B) fused backward: j tiles of sample b whose dq rows (planes, scales, delta2) are complete; zeroed by the prologue
     int T, M;
 };
 struct GroupArgs {
@@ -497,6 +500,8 @@ struct GroupArgs {
     int n, B, D, dbg;
     unsigned long long* ts;
     char* scr;             // timing experiment (debug mask 8192): where att_row ALSO writes its output rows as fp16 planes
+    unsigned* tmo_host;    // host-visible word a bounded device-side wait that gave up adds to (the LSTM kernels' word, lstm_fs.hip)
+    int fuse_dq;           // backward: the dq sweep runs inside the j blocks of the gradient-sweep launch (see att_bwd_sweep_kernel)
 };
 // DBG template value of the kernels: 0 = product, 1 = timing-only ablations (a.dbg), 2 = time stamps, nothing ablated
 template <int DBG>
@@ -665,6 +670,9 @@ struct PrepArgs {
 };
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 // lane c (< 8 KT) holds features 4c..4c+3 of `row`; amax = the row's max |x| (wave-uniform)
+// WT: write-through (sc1) stores -- rows another workgroup of the SAME launch will read once this one has signalled (the fused
+// backward's dq rows): no release fence is needed behind them, only the drain (MI355X_MICROARCH.md, inter-workgroup visibility)
+template <bool WT = false>
 __device__ __forceinline__ void store_split_row(char* planes_b, float* inv_row, int row, int c, f4 x, float amax) {
     // a NaN / infinity anywhere in the row (x - x != 0 exactly for those) poisons the row's inverse scale: every product the
     // row takes part in then comes out NaN, as in the reference, instead of the clamped finite value the split would carry
@@ -682,10 +690,19 @@ __device__ __forceinline__ void store_split_row(char* planes_b, float* inv_row, 
             h1[j] = (_Float16)(v - (float)a);
         }
         char* d = planes_b + pl_off_att(row, c >> 1) + (c & 1) * 8;
-        *reinterpret_cast<half4*>(d) = h0;
-        *reinterpret_cast<half4*>(d + 1024) = h1;
+        if constexpr (WT) {
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(d), __builtin_bit_cast(unsigned long long, h0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(d + 1024), __builtin_bit_cast(unsigned long long, h1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            *reinterpret_cast<half4*>(d) = h0;
+            *reinterpret_cast<half4*>(d + 1024) = h1;
+        }
     }
-    if (c == 0) *inv_row = bad ? __builtin_nanf("") : (amax > 0.f ? 1.0f / s : 0.f);
+    if (c == 0) {
+        const float iv = bad ? __builtin_nanf("") : (amax > 0.f ? 1.0f / s : 0.f);
+        if constexpr (WT) __hip_atomic_store(inv_row, iv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *inv_row = iv;
+    }
 }
 // fp32 value of features 4c..4c+3 of a planes row: x = (h0 + h1) * inv
 __device__ __forceinline__ f4 planes_row_f32(const char* planes_b, const float* inv_b, int row, int c) {
@@ -768,7 +785,9 @@ __global__ __launch_bounds__(256) void att_rank1_kernel(const float* __restrict_
 constexpr int NT8 = 512;
 
 // KIND 0: column pass.  KIND 1: dq sweep.
-template <int KIND, int DBG>
+// FUSED (KIND 1 only): the body runs in front of the j sweep inside the gradient-sweep launch; its results go out write-through and
+// the workgroup counts itself into dq_cnt[b] once they are drained (the i blocks of the launch wait for their sample's count).
+template <int KIND, int DBG, bool FUSED = false>
 __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap& bm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int dbg = DBG == 1 ? a.dbg : 0;
@@ -1084,7 +1103,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
         f4 x = f4{0.f, 0.f, 0.f, 0.f};
         if (gn < N && 4 * lane < D) x = *reinterpret_cast<const f4*>(et + rr * LDP + 4 * lane);
         const float amax = wave_allmax(f4amax(x));
-        store_split_row(dst_p, dst_i + gn, gn, lane, x, amax);
+        store_split_row<FUSED>(dst_p, dst_i + gn, gn, lane, x, amax);
         if (gn < N) {
             if (KIND == 0) {
                 if (lane == 0) {
@@ -1097,12 +1116,20 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
                     qv = f4{((float)qh0[k][0] + (float)qh1[k][0]) * qiv[k], ((float)qh0[k][1] + (float)qh1[k][1]) * qiv[k],
                             ((float)qh0[k][2] + (float)qh1[k][2]) * qiv[k], ((float)qh0[k][3] + (float)qh1[k][3]) * qiv[k]};
                 const float dot = wave_allsum(f4sum(x * qv));
-                if (lane == 0) A.delta2[(size_t)b * N + gn] = dot;
+                if (lane == 0) {
+                    if constexpr (FUSED) __hip_atomic_store(A.delta2 + (size_t)b * N + gn, dot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else A.delta2[(size_t)b * N + gn] = dot;
+                }
             }
         }
     }
     ts_mark<DBG>(a, TSK, 4);
     ts_flush<DBG>(a, TSK, tsr);
+    if constexpr (FUSED) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores,
+        __syncthreads();                                       // the workgroup's barrier (also: the LDS of this body is dead),
+        if (tid == 0) __hip_atomic_fetch_add(A.dq_cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ONE lane signals for all of them
+    }
 }
 
 
@@ -1355,6 +1382,7 @@ __global__ __launch_bounds__(256) void att_bwd_pre_kernel(const GroupArgs a) {
     if (blockIdx.x == 0) {  // the parameter gradients are accumulated with atomics by the sweep kernel
         for (int i = threadIdx.x; i < D; i += 256) A.d_w_t[i] = A.d_w_m[i] = A.d_w_tm[i] = 0.f;
         if (threadIdx.x == 0) A.d_bias[0] = 0.f;
+        for (int i = threadIdx.x; i < B; i += 256) A.dq_cnt[i] = 0u;      // (fused backward: counted up by the j blocks of the sweep launch)
     }
     const int Tp = pad32(T);
     const long rowi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1885,10 +1913,31 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
 
     const int np = (dbg & 16) ? 0 : (M + PR - 1) / PR;
     auto issue8 = [&](int pi, int x) { stage_panel_w<8>(sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, x), src[x], pi * PR, wave, lane); };
-    if (np > 0 || !(dbg & 64)) {
+    if (np > 0 || !(dbg & 64)) {      // first panel: everything that does not depend on dq
 #pragma unroll
-        for (int x = 0; x < NT; ++x) issue8(0, x);
+        for (int x = 0; x < NT; ++x)
+            if (x != X_DQ) issue8(0, x);
     }
+    // Fused backward: dq, its row scales and delta2 of this sample are written by the j blocks of THIS launch (dispatched first: block
+    // ids below i_begin).  Every wave waits (bounded) until all of the sample's j tiles have counted themselves in, then takes an
+    // agent-scope acquire: the rows went out write-through and drained before the count moved (att_jsweep_body<1, DBG, true>), and
+    // nothing of them has been read by this CU in this launch.  The operands that do not depend on dq were requested above.
+    if (a.fuse_dq) {
+        const unsigned want = (unsigned)((M + 63) / 64);
+        const unsigned* cnt = A.dq_cnt + b;
+        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > 200000000LL) {      // 2 s: give up, the step's results are invalid and the host is told
+                    if (lane == 0 && a.tmo_host) __hip_atomic_fetch_add(a.tmo_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    if (np > 0 || !(dbg & 64)) issue8(0, X_DQ);
     // maxima of the streamed rows' inverse scales (mod, mod_d, q, dq), run by both roles after their operand loads
     float im[4] = {0.f, 0.f, 0.f, 0.f};
     float cDq = 1.f, cS = 1.f;
@@ -2234,14 +2283,22 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     ts_flush<DBG>(a, 3, tsr);
 }
 
+// (a_dq: a second copy of the SAME argument block, read by the dq body alone.  With one copy hipcc merged the loads of the
+//  attention's pointers that both bodies make and kept them in SGPRs across the dq loop: 16-20 spill instructions per iteration
+//  of a loop that has none as a kernel of its own; two kernel arguments cannot be proven equal.)
 template <int DBG, bool SAME>
-__global__ __launch_bounds__(NT8) void att_bwd_sweep_kernel(const GroupArgs a, const SweepMap sm) {
+__global__ __launch_bounds__(NT8) void att_bwd_sweep_kernel(const GroupArgs a, const SweepMap sm, const GroupArgs a_dq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int local;
     if (DBG == 1 && (a.dbg & 512)) return;                                  // timing only: launch floor
     if (DBG == 1 && (a.dbg & 1024) && (int)blockIdx.x < sm.i_begin) return;  // timing only: i sweep alone
     if (DBG == 1 && (a.dbg & 2048) && (int)blockIdx.x >= sm.i_begin) return; // timing only: j sweep alone
     if ((int)blockIdx.x < sm.i_begin) {
+        // Fused backward (round 5): the dq sweep has the j sweep's decomposition -- 64 modality rows of one sample per workgroup, all
+        // text rows streamed -- and the j sweep needs dq only for ITS OWN rows: the workgroup runs the dq body first (dq = P1^T db as
+        // planes, delta2), publishes its rows for the i blocks of this launch, and goes on with the j sweep.  One launch and one
+        // prologue / epilogue / launch ramp less than the three-launch form, and the i blocks fill the CUs the 160 j blocks leave free.
+        if (a_dq.fuse_dq) att_jsweep_body<1, DBG, true>(a_dq, sm.j);
         const AttG& A = a.g[find_att(sm.j, a.n, blockIdx.x, local)];
         sweep_j_body<DBG, SAME>(a, A, local, smem);
     } else {
@@ -2279,7 +2336,7 @@ static SavedLayout saved_layout(int B, int T, int M, int drop) {
 }
 
 struct BwdWs {
-    size_t pDa, pDb, pDq, iDa, iDb, iDq, delta1, delta2, total;   // bytes
+    size_t pDa, pDb, pDq, iDa, iDb, iDq, delta1, delta2, dq_cnt, total;   // bytes
 };
 static BwdWs bwd_layout(int B, int T, int M) {
     BwdWs w{};
@@ -2294,6 +2351,7 @@ static BwdWs bwd_layout(int B, int T, int M) {
     w.iDq = take((size_t)B * pad32(M) * 4);
     w.delta1 = take((size_t)B * T * 4);
     w.delta2 = take((size_t)B * M * 4);
+    w.dq_cnt = take((size_t)B * 4);
     w.total = o;
     return w;
 }
@@ -2359,7 +2417,7 @@ static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backwar
     memset(&ga, 0, sizeof(ga));
     ga.n = n; ga.B = B; ga.D = D; ga.dbg = att_dbg(); ga.ts = (ga.dbg & 4096) ? g_att_ts : nullptr;
     ga.scr = (ga.dbg & 8192) ? reinterpret_cast<char*>(g_att_ts) : nullptr;
-    ga.dbg &= ~4096;
+    ga.dbg &= ~(4096 | 16384);      // (16384: three-launch backward, decided in mmb_bidaf_group_bwd: the product kernels either way)
     const bool drop = d[0].text_d != nullptr;
     for (int k = 0; k < n; ++k) {
         const mmb_bidaf_desc& s = d[k];
@@ -2404,6 +2462,7 @@ static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backwar
             g.d_w_t = s.d_w_t; g.d_w_m = s.d_w_m; g.d_w_tm = s.d_w_tm; g.d_bias = s.d_bias;
             g.pDa = ws + W.pDa; g.pDb = ws + W.pDb; g.pDq = ws + W.pDq;
             g.iDa = wf(W.iDa); g.iDb = wf(W.iDb); g.iDq = wf(W.iDq); g.delta1 = wf(W.delta1); g.delta2 = wf(W.delta2);
+            g.dq_cnt = reinterpret_cast<unsigned*>(ws + W.dq_cnt);
         }
     }
     return MMB_OK;
@@ -2551,8 +2610,17 @@ extern "C" int mmb_bidaf_group_bwd(const mmb_bidaf_desc* d, int n, int B, int D,
         hipLaunchKernelGGL(att_bwd_pre_kernel, dim3((unsigned)((rows + 3) / 4), n), dim3(256), 0, stream, ga);
         MMB_HIP(hipGetLastError());
     }
+    // Fused form (default; MMB_ATT_FUSE_DQ=0 keeps the three-launch form for A/B measurements): the dq sweep runs inside the j blocks
+    // of the gradient-sweep launch
+    static int fuse_env = -1;
+    if (fuse_env < 0) {
+        const char* e = getenv("MMB_ATT_FUSE_DQ");
+        fuse_env = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    ga.fuse_dq = fuse_env && !(att_dbg() & 16384);      // (debug mask 16384: the three-launch form, results identical: tests toggle it)
+    ga.tmo_host = lstm_timeout_word();
     // ---- dq sweep: dq = P1^T db as planes, delta2 = q . dq
-    {
+    if (!ga.fuse_dq) {
         BlkMap bm{};
         for (int k = 0; k < n; ++k) bm.begin[k + 1] = bm.begin[k] + sweep_blocks(ga.g[k].M, B);
         for (int k = n; k < MAXG; ++k) bm.begin[k + 1] = bm.begin[n];
@@ -2574,13 +2642,14 @@ extern "C" int mmb_bidaf_group_bwd(const mmb_bidaf_desc* d, int n, int B, int D,
         for (int k = n; k < MAXG; ++k) sm.i.begin[k + 1] = sm.i.begin[n];
         const size_t loop_b = SWEEP_LOOP_LDS;
         const size_t epi = ((size_t)2 * 64 * LDP + 64 + 8 * 2 * 256) * sizeof(float);
-        const size_t lds = loop_b > epi ? loop_b : epi;
+        const size_t dq_b = (size_t)2 * 2 * PANEL_B + (2 * 5 * 64 + 64) * sizeof(float);      // the dq body in front of the j sweep
+        const size_t lds = std::max(std::max(loop_b, epi), ga.fuse_dq ? dq_b : (size_t)0);
         auto kern = ga.ts    ? (drop ? att_bwd_sweep_kernel<2, false> : att_bwd_sweep_kernel<2, true>)
                     : ga.dbg ? (drop ? att_bwd_sweep_kernel<1, false> : att_bwd_sweep_kernel<1, true>)
                              : (drop ? att_bwd_sweep_kernel<0, false> : att_bwd_sweep_kernel<0, true>);
         if (int rc = allow_lds(kern, lds)) return rc;
         ProfScope ps_(MMB_K_ATT_BWD_I, stream);
-        hipLaunchKernelGGL(kern, dim3(sm.i.begin[n]), dim3(NT8), lds, stream, ga, sm);
+        hipLaunchKernelGGL(kern, dim3(sm.i.begin[n]), dim3(NT8), lds, stream, ga, sm, ga);
         MMB_HIP(hipGetLastError());
     }
     return MMB_OK;

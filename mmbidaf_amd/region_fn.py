@@ -764,8 +764,8 @@ class _RegionFn(torch.autograd.Function):
         hold += [ta, ti]
         two = side is not main
         # (the word the BPTT recurrences' workgroups count themselves into for the side stream's gate, MF._side_head_start)
-        gp = MF.gate_ptr(di) if two else None
-        gate = {2: gp, 3: gp}
+        gate_p = MF.gate_ptr(di) if two else None
+        gate = {2: gate_p, 3: gate_p}
         L1, w1 = tm["b_l1"].build(bases, pp, x0=c.l1_in[0], x1=c.l1_in[1], dy0=pa, dy1=pi, y0=y1[0].data_ptr(), y1=y1[1].data_ptr(),
                                   d_hn0=dh["a1"], d_hn1=dh["i1"], gate=gate[2],
                                   **lstm_dyn(("a1", "i1"), (True, True)))

@@ -249,6 +249,33 @@ def test_attention_single_degenerate_samples_inside_a_ragged_batch_vs_oracle():
         close(g, p.grad, k)
 
 
+@pytest.mark.parametrize("B,T,M,use_drop", [(32, 400, 256, False), (5, 130, 300, True), (3, 70, 9, False), (9, 1600, 1100, False)])
+def test_attention_backward_fused_form_equals_the_three_launch_form(B, T, M, use_drop):
+    """Round 5: the dq sweep (dq = P1^T db, delta2) runs inside the j blocks of the gradient-sweep launch, which publish their rows
+    (write-through stores, drained, one count per workgroup) for the i blocks of the SAME launch that wait for their sample's
+    count -- two launches where there were three.  Same arithmetic: every gradient equals the three-launch form's (debug mask
+    16384 selects it) to the round-off of the atomics' order; the last shape has more j blocks than the chip has CUs (the i blocks
+    then start while j blocks are still being dispatched); no bounded wait may have given up."""
+    from mmbidaf_amd import _lib
+    lib = _lib.load()
+    D = 200
+    c, drop = _random_att_case(8800 + B + T + M, B, T, M, D, use_drop)
+    try:
+        lib.mmb_set_att_debug(0)
+        out1, dt1, dm1, dps1 = _run_att(c, drop)
+        torch.cuda.synchronize()
+        assert _lib.persist_timeouts() == 0
+        lib.mmb_set_att_debug(16384)
+        out0, dt0, dm0, dps0 = _run_att(c, drop)
+        torch.cuda.synchronize()
+    finally:
+        lib.mmb_set_att_debug(0)
+    assert torch.equal(out1, out0)
+    assert torch.equal(dt1, dt0) and torch.equal(dm1, dm0)
+    for k, a, b in zip(("d_w_t", "d_w_m", "d_w_tm"), dps1, dps0):
+        close(a, b.cpu(), "fused vs three launches " + k, tol=2e-6)
+
+
 @pytest.mark.parametrize("T,M", [(1, 33), (31, 1), (32, 32), (33, 31), (64, 65), (65, 96), (97, 97), (160, 129), (129, 160)])
 def test_attention_panel_counts_of_the_pipelined_sweeps_vs_oracle(T, M):
     """The 3-tensor gradient sweeps run role 1's PV product one panel behind, with rotating LDS slots and LDS-DMA pieces in flight
