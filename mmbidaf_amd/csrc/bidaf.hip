@@ -1923,19 +1923,23 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
     // agent-scope acquire: the rows went out write-through and drained before the count moved (att_jsweep_body<1, DBG, true>), and
     // nothing of them has been read by this CU in this launch.  The operands that do not depend on dq were requested above.
     if (a.fuse_dq) {
-        const unsigned want = (unsigned)((M + 63) / 64);
-        const unsigned* cnt = A.dq_cnt + b;
-        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        // ONE wave polls (a relaxed load every ~1 us: 96+ waiting workgroups polling with all their waves would take memory bandwidth
+        // from the j blocks they wait for), takes the acquire and drains it; the workgroup's barrier then covers the other waves.
+        if (wave == 0) {
+            const unsigned want = (unsigned)((M + 63) / 64);
+            const unsigned* cnt = A.dq_cnt + b;
             const long long t0 = wall_clock64();
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(127);
                 if (wall_clock64() - t0 > 200000000LL) {      // 2 s: give up, the step's results are invalid and the host is told
                     if (lane == 0 && a.tmo_host) __hip_atomic_fetch_add(a.tmo_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
     }
     if (np > 0 || !(dbg & 64)) issue8(0, X_DQ);
     // maxima of the streamed rows' inverse scales (mod, mod_d, q, dq), run by both roles after their operand loads

@@ -201,9 +201,9 @@ def test_attention_one_element_softmaxes_at_full_batch_vs_oracle(T, M, use_drop)
     c, drop = _random_att_case(9100 + T + M + int(use_drop), B, T, M, D, use_drop, full=True)
 
     def oracle(dtype):
-        t_ = c["text"].to(dtype).requires_grad_(True)
-        m_ = c["mod"].to(dtype).requires_grad_(True)
-        ps = [c[k].to(dtype).requires_grad_(True) for k in ("w_t", "w_m", "w_tm", "bias")]
+        t_ = c["text"].detach().clone().to(dtype).requires_grad_(True)
+        m_ = c["mod"].detach().clone().to(dtype).requires_grad_(True)
+        ps = [c[k].detach().clone().to(dtype).requires_grad_(True) for k in ("w_t", "w_m", "w_tm", "bias")]
         kw = dict(text_d=t_ * drop[0].to(dtype), mod_d=m_ * drop[1].to(dtype)) if use_drop else {}
         ref = O.bidaf_attention(t_, m_, c["text_mask"], c["mod_mask"], *ps, **kw)
         (ref * c["cot"].to(dtype)).sum().backward()
