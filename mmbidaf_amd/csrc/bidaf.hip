@@ -63,8 +63,8 @@ constexpr float WMAX = 16384.0f;   // 2^14: where the largest split operand is m
 // 8192 = att_row also writes the rows of `out` as the fp16 planes of the next layer's projection operand (tiled layout of
 // planes.hip, 25 K tiles, a fixed scale) into the buffer given to mmb_set_att_timestamps (>= 2 x 41 MB at cfg2): what
 // producer-written planes would cost the row pass (tools/att_bench.py --masks 32,8224)
-// 16384 = backward in its three-launch form (prologue, dq sweep, gradient sweeps) instead of the fused two-launch form; not an
-//         ablation: results are the same (tests compare the two)
+// 16384 = backward in its fused two-launch form (the dq sweep inside the j blocks of the gradient-sweep launch) instead of the
+//         three-launch form; not an ablation: results are the same (tests compare the two)
 // 4096 = phase time stamps (DBG kernels, nothing ablated): thread 0 of every workgroup writes s_memrealtime (100 MHz) at
 // its phase boundaries into the buffer given to mmb_set_att_timestamps: [kernel 0..3][block][8] u64 (tools/att_phases.py)
 static int g_att_dbg = -1;
@@ -2421,7 +2421,7 @@ static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backwar
     memset(&ga, 0, sizeof(ga));
     ga.n = n; ga.B = B; ga.D = D; ga.dbg = att_dbg(); ga.ts = (ga.dbg & 4096) ? g_att_ts : nullptr;
     ga.scr = (ga.dbg & 8192) ? reinterpret_cast<char*>(g_att_ts) : nullptr;
-    ga.dbg &= ~(4096 | 16384);      // (16384: three-launch backward, decided in mmb_bidaf_group_bwd: the product kernels either way)
+    ga.dbg &= ~(4096 | 16384);      // (16384: fused backward, decided in mmb_bidaf_group_bwd: the product kernels either way)
     const bool drop = d[0].text_d != nullptr;
     for (int k = 0; k < n; ++k) {
         const mmb_bidaf_desc& s = d[k];
@@ -2614,14 +2614,18 @@ extern "C" int mmb_bidaf_group_bwd(const mmb_bidaf_desc* d, int n, int B, int D,
         hipLaunchKernelGGL(att_bwd_pre_kernel, dim3((unsigned)((rows + 3) / 4), n), dim3(256), 0, stream, ga);
         MMB_HIP(hipGetLastError());
     }
-    // Fused form (default; MMB_ATT_FUSE_DQ=0 keeps the three-launch form for A/B measurements): the dq sweep runs inside the j blocks
-    // of the gradient-sweep launch
+    // Fused form (MMB_ATT_FUSE_DQ=1, or debug mask 16384 -- what the tests toggle): the dq sweep runs inside the j blocks of the
+    // gradient-sweep launch.  OFF by default: built, tested (results identical) and measured in round 5 -- 194.9-195.6 us against
+    // 196.4-197.9 us for the backward of both attentions at cfg2 (profiles/r05_att_fused_dq.txt): the i blocks cannot start before
+    // their sample's dq exists, so the 96 CUs the 160 dq workgroups leave free stay idle either way, and inside the larger kernel
+    // the j sweep's panel loop picks up a scratch reload that exposes its LDS-DMA latency (sync+issue 940 -> 3 000 clocks per
+    // panel).  One launch ramp saved does not pay for a bounded spin in the product path.
     static int fuse_env = -1;
     if (fuse_env < 0) {
         const char* e = getenv("MMB_ATT_FUSE_DQ");
-        fuse_env = (e && atoi(e) == 0) ? 0 : 1;
+        fuse_env = (e && atoi(e) == 1) ? 1 : 0;
     }
-    ga.fuse_dq = fuse_env && !(att_dbg() & 16384);      // (debug mask 16384: the three-launch form, results identical: tests toggle it)
+    ga.fuse_dq = fuse_env || (att_dbg() & 16384);
     ga.tmo_host = lstm_timeout_word();
     // ---- dq sweep: dq = P1^T db as planes, delta2 = q . dq
     if (!ga.fuse_dq) {
