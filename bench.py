@@ -109,6 +109,7 @@ def rehearse_cpu(a):
         if k == a.warmup:
             if world > 1:
                 dist.barrier()
+            sync.timing = True
             t0 = time.perf_counter()
         for i, p in enumerate(params):
             p.grad = torch.full_like(p, float(rank + 1) * (1 + i % 3))
@@ -119,14 +120,42 @@ def rehearse_cpu(a):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    dist_fields = exchange_fields(sync, dt, a.steps, rank, world, [f"rank{rank}:cpu"])
     if rank == 0:
         print(json.dumps({"metric": "REHEARSAL of the --gpus N entry on CPU/gloo: launcher, rendezvous and gradient exchange only; "
                                     "no hot-path compute, not a measurement", "value": None, "unit": "samples/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / max(a.steps, 1) * 1e3, 3),
-                          "rehearsal": True, "dist": {"backend": dist.get_backend() if world > 1 else None, "world_size": world,
-                                                      "grad_buckets": len(sync.buckets), "grad_elems": sync.numel}}), flush=True)
+                          "rehearsal": True, "dist": dist_fields}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def exchange_fields(sync, dt, steps, rank, world, devices):
+    """The `dist` object of an N > 1 line (collective calls: every rank must come here): what the gradient exchange costs and how
+    even the ranks are, so that a first multi-GPU run can attribute a shortfall --
+      allreduce_us_per_step  from "bucket packed" to "bucket reduced" as the rank's stream sees it, summed over the buckets of a step;
+      exposed_us_per_step    the time the rank's stream spends inside the exchange call behind the step's last kernel (launches still
+                             missing, the wait for the collectives, the copy back): what the exchange adds to the critical path;
+      both as the MAX over ranks of the per-rank means (HIP events on the rank's stream; perf_counter on CPU tensors);
+      ms_per_step_by_rank    every rank's own wall time per step over the timed region (min / max tell a straggler)."""
+    if world > 1:
+        dev = sync.flat.device
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        exposed, allred, calls = sync.read_timing()
+        t = torch.tensor([exposed or 0.0, allred or 0.0, dt / max(steps, 1) * 1e3], dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allv, t)
+        allv = torch.stack(allv).cpu()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices[0])
+        per_rank = [round(v, 3) for v in allv[:, 2].tolist()]
+        return {"backend": dist.get_backend(), "world_size": world, "devices": gathered,
+                "grad_buckets": len(sync.buckets), "grad_elems": sync.numel, "grad_bytes": sync.numel * 4,
+                "allreduce_us_per_step": round(float(allv[:, 1].max()), 1), "exposed_us_per_step": round(float(allv[:, 0].max()), 1),
+                "exchange_calls_timed": calls,
+                "ms_per_step_by_rank": per_rank, "ms_per_step_min": min(per_rank), "ms_per_step_max": max(per_rank)}
+    return {"backend": None, "world_size": 1, "devices": devices, "grad_buckets": len(sync.buckets), "grad_elems": sync.numel}
 
 
 def cpu_baseline(region, cfg, ragged, budget_s=20.0, max_steps=10):
@@ -355,12 +384,17 @@ def run_leg(a, rank, world, local, dev):
     for _ in range(max(1, getattr(a, "regions", 1))):
         fence()
         _lib.profile_enable(timed)
+        sync.timing = world > 1
+        sync.read_timing()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             step()
         fence()
         d1 = time.perf_counter() - t0
         _lib.profile_enable([])
+        # (collective: every rank, every region -- the headline leg times ONE region; the last region's figures are reported)
+        xfields = exchange_fields(sync, d1, a.steps, rank, world, [f"rank{rank}:cuda:{local}:{torch.cuda.get_device_name(local)}"]) if world > 1 else None
+        sync.timing = False
         dt = d1 if dt is None else min(dt, d1)
     # a persistent recurrence launch (H > 128) that timed out at its per-step barrier leaves invalid results; inside a replayed
     # graph nothing but this look at the status word can notice
@@ -387,14 +421,10 @@ def run_leg(a, rank, world, local, dev):
             eager_step()
         fence()
         _lib.profile_enable([])
-    devices = [f"cuda:{local}"]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-        gathered = [None] * world
-        dist.all_gather_object(gathered, f"rank{rank}:cuda:{local}:{torch.cuda.get_device_name(local)}")
-        devices = gathered
     prof = {k: _lib.profile_read(k) for k in timed}
     out = None
     if rank == 0:
@@ -436,8 +466,7 @@ def run_leg(a, rank, world, local, dev):
         else:
             out["config"]["launch"] = "eager: every step issued from Python" + (f" ({graph_note})" if graph_note else "")
         if world > 1:
-            out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": devices,
-                           "grad_buckets": len(sync.buckets), "grad_elems": sync.numel}
+            out["dist"] = xfields
         if a.profile_all:
             out["kernel_ms_per_step"] = {k: round(v[0] / a.steps, 4) for k, v in prof.items()}
             out["kernel_launches_per_step"] = {k: v[1] / a.steps for k, v in prof.items()}

@@ -115,6 +115,11 @@ class FlatGradAllReduce:
             o += n
         self.work = [None] * len(self.buckets)
         self.pending = [0] * len(self.buckets)
+        # optional timing (bench.py, N > 1): per call, the time the caller's stream spends inside __call__ (what the exchange EXPOSES
+        # on the critical path: launches still missing, the wait for the collectives, the copy back) and, per bucket, from "packed"
+        # to "reduced" (the all-reduce as the stream sees it) -- HIP events on the current stream, perf_counter on CPU tensors
+        self.timing = False
+        self._t_calls, self._t_buckets = [], []
         self.overlap = bool(overlap) and self.world > 1
         self._hooks = []
         if self.overlap:
@@ -144,6 +149,14 @@ class FlatGradAllReduce:
         with torch.cuda.stream(stream):
             self._launch_here(bi)
 
+    def _stamp(self):
+        if self.flat.is_cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        import time
+        return time.perf_counter()
+
     def _launch_here(self, bi):
         with torch.no_grad():
             grads = [p.grad for p in self.buckets[bi]]
@@ -155,6 +168,9 @@ class FlatGradAllReduce:
                         c.zero_()
                     else:
                         c.copy_(g)
+            if self.timing:
+                self._packed = getattr(self, "_packed", {})
+                self._packed[bi] = self._stamp()
             self.work[bi] = dist.all_reduce(self.slices[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def broadcast_parameters(self, src=0):
@@ -176,6 +192,7 @@ class FlatGradAllReduce:
             _lib.persist_check("FlatGradAllReduce")
         if self.world == 1:
             return
+        t_in = self._stamp() if self.timing else None
         for bi in range(len(self.buckets)):
             if self.work[bi] is None:
                 self._launch(bi)
@@ -184,14 +201,30 @@ class FlatGradAllReduce:
                 assert self.work[bi] is not False, "a deferred bucket launch did not run before the gradients were consumed"
                 self.work[bi].wait()          # the current stream waits for the collective (no host sync with nccl)
                 self.work[bi] = None
+                if self.timing and bi in getattr(self, "_packed", {}):
+                    self._t_buckets.append((self._packed.pop(bi), self._stamp()))
                 if self.average:
                     self.slices[bi].mul_(1.0 / self.world)
                 dst = [p.grad for p in b if p.grad is not None]
                 src = [c for p, c in zip(b, self.chunks[bi]) if p.grad is not None]
                 if dst:
                     torch._foreach_copy_(dst, src)
+        if self.timing:
+            self._t_calls.append((t_in, self._stamp()))
         if self.overlap:
             self._arm()
+
+    def read_timing(self, reset=True):
+        """-> (exposed_us_per_call, allreduce_us_per_call, calls): means over the calls made since timing was switched on / last
+        read.  Synchronise the device first (the events must have completed)."""
+        def span(a, b):
+            return a.elapsed_time(b) * 1e3 if hasattr(a, "elapsed_time") else (b - a) * 1e6
+        n = len(self._t_calls)
+        exposed = sum(span(a, b) for a, b in self._t_calls) / n if n else None
+        allred = sum(span(a, b) for a, b in self._t_buckets) / n if n else None
+        if reset:
+            self._t_calls, self._t_buckets = [], []
+        return exposed, allred, n
 
     def remove_hooks(self):
         for h in self._hooks:

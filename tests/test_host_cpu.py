@@ -241,6 +241,12 @@ def test_bench_gpus2_entry_self_launches_over_gloo():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rehearsal"] is True and out["dist"]["world_size"] == 2 and out["dist"]["backend"] == "gloo"
+    # what a first multi-GPU run needs to attribute a shortfall: the exchange's own time and what of it is exposed
+    # on the step's critical path, every rank's step time, the devices the ranks ran on
+    dd = out["dist"]
+    assert dd["allreduce_us_per_step"] > 0 and dd["exposed_us_per_step"] > 0      # (bucket spans overlap: their sum may exceed the exposed time)
+    assert dd["exchange_calls_timed"] == 2 and len(dd["ms_per_step_by_rank"]) == 2 and len(dd["devices"]) == 2
+    assert dd["ms_per_step_min"] <= dd["ms_per_step_max"] and dd["grad_bytes"] == 4 * dd["grad_elems"]
     # a failing rank must surface as a non-zero exit code of the parent
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-cpu", "--config", "nope"],
                        env=env, capture_output=True, text=True, timeout=300)
