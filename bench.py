@@ -305,7 +305,7 @@ def run_leg(a, rank, world, local, dev):
     region.train(a.drop_prob > 0.0)      # drop_prob 0: train and eval mode are the same graph
     params = list(region.parameters())
     dtype = a.dtype or ("bf16" if a.config == "cfg5" else "f32")
-    MF.set_precision("bf16" if dtype == "bf16" else "fp32")
+    region.precision = "bf16" if dtype == "bf16" else "fp32"      # this leg's arithmetic travels with its calls (descriptor field `precision`): no process-wide switch to set and restore
     # hipGraph replay is the default form of the step (fixed lengths: the synthetic workload); --fresh-lengths (new lengths
     # every step), --profile-all (an event pair around every kernel) and --eager issue the step from Python
     want_graph = not a.eager and not a.fresh_lengths and not a.profile_all
@@ -442,7 +442,7 @@ def run_leg(a, rank, world, local, dev):
                            "(the builder's reading of the bar: raw errors up to ~2e-4 occur on gradients of magnitude ~100)") if dtype == "f32" else
                           ("fp32 in, fp32 out, fp32 accumulation and cell update; every matrix-core product of the LSTM layers (input "
                            "projection, recurrent product, input / weight gradients) on v_mfma_f32_16x16x32_bf16 from bf16-rounded operands "
-                           "(mmb_set_precision(1); tolerance 3e-2 of the tensor scale vs the fp32 oracle, tests/test_gpu_parity.py); the "
+                           "(descriptor precision = MMB_PRECISION_BF16; tolerance 3e-2 of the tensor scale vs the fp32 oracle, tests/test_gpu_parity.py); the "
                            + ("attention (D <= 208: fused kernels) keeps its fp32-accurate arithmetic" if fused_att else
                               "general-width attention (D = %d > 208) runs its batched similarity / context products on the two-term bf16 "
                               "split in this mode (about 2^-16 relative per product, inside the same 3e-2 bound)" % D)),
@@ -520,8 +520,6 @@ def run_secondary(rank, world, local, dev):
                 cleared = _lib.persist_fallback()
                 res[name]["persist_fallback"] = (f"persistent recurrence timed out ({cleared} workgroup(s)): status word cleared, the remaining "
                                                  "legs use the launch-per-step kernels")
-    from mmbidaf_amd import functional as MF
-    MF.set_precision("fp32")
     res["wall_s"] = round(time.perf_counter() - t_start, 1)
     return res
 

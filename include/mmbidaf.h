@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMB_VERSION 500            /* round 5 ABI: + mmb_bilstm_layer_fwd_phase (streamed input projection), mmb_stream_gate + mmb_lstm_bwd_desc.gate */
+#define MMB_VERSION 500            /* round 5 ABI: + mmb_bilstm_layer_fwd_phase (streamed input projection), mmb_stream_gate + mmb_lstm_bwd_desc.gate, per-call precision field in the descriptors */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
 #define MMB_ATT_MAX_D 208          /* attention feature width D = 2H of the fused (register-resident) kernels */
 #define MMB_ATT_GENERAL_MAX_D 4096 /* wider D (up to this) runs the general path: similarity matrix in a workspace */
@@ -60,6 +60,18 @@ enum {
 int mmb_profile_enable(uint32_t kernel_mask);
 int mmb_profile_read(int kernel_id, double* total_ms, int* launches);
 const char* mmb_kernel_name(int kernel_id);   /* device-side symbol stem, as rocprofv3 prints it */
+
+/* ------------------------------------------------------------------------------------------
+ * Arithmetic of the matrix-core products of ONE call (a per-call dtype): the `precision` field of the descriptors
+ * below.  Two callers (two models, or the forward thread and autograd's backward thread) with different values never see each
+ * other's: the value travels with the call, not in library state.
+ *   MMB_PRECISION_DEFAULT  whatever mmb_set_precision() / MMB_PRECISION last said for the process (0 when never called)
+ *   MMB_PRECISION_F32      fp32-accurate: two-term fp16 split of both operands, three products, fp32 accumulation
+ *   MMB_PRECISION_BF16     bf16-rounded operands, ONE product, fp32 accumulation (BASELINE.json's "hidden=512 bf16" form; outside
+ *                          the reference's precision class: tests state its tolerance) */
+#define MMB_PRECISION_DEFAULT 0
+#define MMB_PRECISION_F32 1
+#define MMB_PRECISION_BF16 2
 
 /* ------------------------------------------------------------------------------------------
  * BiDAF attention.  Replaces BiDAFAttention.forward / get_similarity_matrix / masked_softmax
@@ -132,6 +144,8 @@ typedef struct {
     const float* d_out;
     float *d_text, *d_mod, *d_text_d, *d_mod_d, *d_w_t, *d_w_m, *d_w_tm, *d_bias;
     int32_t T, M;
+    int32_t precision;         /* MMB_PRECISION_* of THIS call (all attentions of a grouped call carry the same value) */
+    int32_t reserved;
 } mmb_bidaf_desc;
 int mmb_bidaf_group_fwd(const mmb_bidaf_desc* d, int n, int B, int D, int device, void* stream);
 int mmb_bidaf_group_bwd(const mmb_bidaf_desc* d, int n, int B, int D, int device, void* stream);
@@ -189,6 +203,8 @@ typedef struct {
                                /* stacked |W_ih| (plain stores: no initialisation needed; saved: the backward's      */
                                /* transposed fp16 planes are scaled by their maximum); may be NULL when ws is NULL   */
     int32_t B, T, I, H;
+    int32_t precision;         /* MMB_PRECISION_* of THIS call (all problems of a grouped call carry the same value)  */
+    int32_t reserved;
 } mmb_lstm_fwd_desc;
 
 /* bytes of the optional operand-plane scratch of one problem (backward != 0: for mmb_bilstm_layer_bwd).  With it (and
@@ -250,6 +266,8 @@ typedef struct {
     uint32_t* gate;            /* NULL, or (descs[0] only) a device word that is ZERO between steps: the first min(2 B n, 256) workgroups */
                                /* of the BPTT recurrence add 1 to it as they start; mmb_stream_gate on another stream waits for them */
     int32_t B, T, I, H;
+    int32_t precision;         /* MMB_PRECISION_* of THIS call: the value the forward call of the same layer was given */
+    int32_t reserved;
 } mmb_lstm_bwd_desc;
 
 int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* descs, int n, int device, void* stream);
@@ -422,7 +440,8 @@ int mmb_hidden_states_bwd(const float* const* g_hid, const float* g_dec, float* 
  *      form of BASELINE.json's last configuration; the reference itself is fp32 throughout (layers/encoding.py:79-81), so
  *      this mode is outside the 1e-4 parity bar: tests/test_gpu_parity.py states and checks its tolerance (3e-2 of the
  *      tensor's scale).  Inputs, outputs, saved tensors, the cell update and all accumulation stay fp32.
- * Process-wide (also MMB_PRECISION=bf16 in the environment); read at every call. */
+ * The process-wide DEFAULT (also MMB_PRECISION=bf16 in the environment) that a descriptor with precision = MMB_PRECISION_DEFAULT takes;
+ * a descriptor that names MMB_PRECISION_F32 / _BF16 is not affected by it. */
 int mmb_set_precision(int mode);
 int mmb_get_precision(void);
 

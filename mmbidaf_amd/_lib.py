@@ -30,6 +30,7 @@ class LstmFwdDesc(ctypes.Structure):
         ("y", c_f), ("h_n", c_f), ("c_n", c_f),
         ("gx", c_f), ("gates", c_f), ("cs", c_f), ("ws", c_f), ("hn_pos", c_f), ("x_absmax", c_f),
         ("B", ctypes.c_int32), ("T", ctypes.c_int32), ("I", ctypes.c_int32), ("H", ctypes.c_int32),
+        ("precision", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 
@@ -41,6 +42,7 @@ class LstmBwdDesc(ctypes.Structure):
         ("d_x", c_f), ("d_w_ih", c_f), ("d_w_hh", c_f), ("d_b", c_f), ("d_a", c_f), ("d_w_cat", c_f), ("ws", c_f),
         ("hn_pos", c_f), ("x_absmax", c_f), ("gate", c_f),
         ("B", ctypes.c_int32), ("T", ctypes.c_int32), ("I", ctypes.c_int32), ("H", ctypes.c_int32),
+        ("precision", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 
@@ -51,7 +53,9 @@ class BidafDesc(ctypes.Structure):
                                    "saved")] + [("saved_bytes", ctypes.c_size_t), ("workspace", c_f),
                                                 ("workspace_bytes", ctypes.c_size_t)] + \
                [(n, c_f) for n in ("d_out", "d_text", "d_mod", "d_text_d", "d_mod_d", "d_w_t", "d_w_m", "d_w_tm", "d_bias")] + \
-               [("T", ctypes.c_int32), ("M", ctypes.c_int32)]
+               [("T", ctypes.c_int32), ("M", ctypes.c_int32), ("precision", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+PRECISION_DEFAULT, PRECISION_F32, PRECISION_BF16 = 0, 1, 2      # MMB_PRECISION_* (descriptor field `precision`)
 
 
 class MaskedSumDesc(ctypes.Structure):

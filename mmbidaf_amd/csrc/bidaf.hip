@@ -2491,6 +2491,9 @@ static int general_width_fwd(const mmb_bidaf_desc& s, int B, int D, hipStream_t 
 extern "C" int mmb_bidaf_group_fwd(const mmb_bidaf_desc* d, int n, int B, int D, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MMB_REQUIRE(d && n >= 1 && n <= MAXG, "mmb_bidaf_group_fwd: 1..%d attentions per call", MAXG);
+    for (int k = 0; k < n; ++k)
+        MMB_REQUIRE(d[k].precision >= 0 && d[k].precision <= 2 && d[k].precision == d[0].precision, "mmb_bidaf_group_fwd: desc.precision must be the same MMB_PRECISION_* for all attentions of a call");
+    PrecisionCall pc_(d[0].precision);
     MMB_HIP(hipSetDevice(device));
     if (D > MMB_ATT_MAX_D) {     // general-size path (bidaf_big.hip), one attention after the other
         for (int k = 0; k < n; ++k) {
@@ -2582,6 +2585,9 @@ extern "C" int mmb_bidaf_group_fwd(const mmb_bidaf_desc* d, int n, int B, int D,
 extern "C" int mmb_bidaf_group_bwd(const mmb_bidaf_desc* d, int n, int B, int D, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MMB_REQUIRE(d && n >= 1 && n <= MAXG, "mmb_bidaf_group_bwd: 1..%d attentions per call", MAXG);
+    for (int k = 0; k < n; ++k)
+        MMB_REQUIRE(d[k].precision >= 0 && d[k].precision <= 2 && d[k].precision == d[0].precision, "mmb_bidaf_group_bwd: desc.precision must be the same MMB_PRECISION_* for all attentions of a call");
+    PrecisionCall pc_(d[0].precision);
     MMB_HIP(hipSetDevice(device));
     if (D > MMB_ATT_MAX_D) {
         for (int k = 0; k < n; ++k) {

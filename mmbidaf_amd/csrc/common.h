@@ -181,6 +181,13 @@ int planes_split_rows_group(const SplitRowsArgs* as, int n, hipStream_t stream);
 int planes_split_transpose_group(const SplitTArgs* as, int n, hipStream_t stream);
 int precision_mode();            // 0: fp32-accurate products (default); 1: bf16 operands in every matrix-core product of the LSTM layers
 void set_precision_mode(int mode);
+// the precision of ONE C-ABI call (descriptor field `precision`, MMB_PRECISION_*): while the object lives, precision_mode() of THIS
+// thread answers with the call's value instead of the process default -- no library state is shared between callers
+struct PrecisionCall {
+    explicit PrecisionCall(int desc_precision);
+    ~PrecisionCall();
+    int saved;
+};
 bool planes_one_split();   // MMB_PLANES_ONE_SPLIT (default 1): the LSTM backward splits d_a once (k-major read in the weight-gradient GEMM)
 int planes_split_transpose(const SplitTArgs& a, hipStream_t stream);
 int planes_gemm(const PlanesGemmArgs& g, hipStream_t stream);

@@ -1091,6 +1091,9 @@ extern "C" size_t mmb_bilstm_ws_bytes(int B, int T, int I, int H, int backward) 
 extern "C" int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* d, int n, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MMB_REQUIRE(d && n >= 1 && n <= MMB_MAX_GROUP, "mmb_bilstm_layer_fwd: n=%d out of range", n);
+    for (int i = 0; i < n; ++i)
+        MMB_REQUIRE(d[i].precision >= 0 && d[i].precision <= 2 && d[i].precision == d[0].precision, "mmb_bilstm_layer_fwd: desc.precision must be MMB_PRECISION_DEFAULT / _F32 / _BF16, the same for all problems of a call");
+    PrecisionCall pc_(d[0].precision);
     MMB_HIP(hipSetDevice(device));
     RecFwdArgs ra{};
     ra.n = n;
@@ -1168,6 +1171,9 @@ extern "C" int mmb_bilstm_layer_fwd_phase(const mmb_lstm_fwd_desc* d, int n, int
     MMB_REQUIRE(stream_decode(phase, which, K, KH), "mmb_bilstm_layer_fwd_phase: phase word 0x%x (MMB_LSTM_FWD_HEAD / _REC / _TAIL | MMB_LSTM_FWD_CHUNKS(K, KH), "
                 "2 <= K <= 64, 0 <= KH < K)", phase);
     MMB_REQUIRE(d && n >= 1 && 2 * n <= MMB_MAX_GROUP, "mmb_bilstm_layer_fwd_phase: n=%d problems (at most %d: two products per problem and launch)", n, MMB_MAX_GROUP / 2);
+    for (int i = 0; i < n; ++i)
+        MMB_REQUIRE(d[i].precision >= 0 && d[i].precision <= 2 && d[i].precision == d[0].precision, "mmb_bilstm_layer_fwd_phase: desc.precision must be the same MMB_PRECISION_* for all problems of a call");
+    PrecisionCall pc_(d[0].precision);
     MMB_HIP(hipSetDevice(device));
     const int H = d[0].H;
     for (int i = 0; i < n; ++i) {
@@ -1225,6 +1231,9 @@ extern "C" int mmb_bilstm_layer_bwd(const mmb_lstm_bwd_desc* d, int n, int devic
 extern "C" int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* d, int n, int phase, int device, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     MMB_REQUIRE(d && n >= 1 && n <= MMB_MAX_GROUP, "mmb_bilstm_layer_bwd: n=%d out of range", n);
+    for (int i = 0; i < n; ++i)
+        MMB_REQUIRE(d[i].precision >= 0 && d[i].precision <= 2 && d[i].precision == d[0].precision, "mmb_bilstm_layer_bwd: desc.precision must be the same MMB_PRECISION_* for all problems of a call");
+    PrecisionCall pc_(d[0].precision);
     const int phase_bits = phase;
     phase &= 3;
     const bool prep = (phase_bits & MMB_LSTM_BWD_PREPARE) != 0;

@@ -798,7 +798,14 @@ bool planes_one_split() {
 }
 
 static std::atomic<int> g_precision{-1};   // 0 = fp32-accurate, 1 = bf16 operands (mmb_set_precision / MMB_PRECISION=bf16)
+static thread_local int tl_precision = -1;   // >= 0: the precision of the C-ABI call this thread is inside (PrecisionCall)
+PrecisionCall::PrecisionCall(int desc_precision) : saved(tl_precision) {
+    if (desc_precision == MMB_PRECISION_F32) tl_precision = 0;
+    else if (desc_precision == MMB_PRECISION_BF16) tl_precision = 1;
+}
+PrecisionCall::~PrecisionCall() { tl_precision = saved; }
 int precision_mode() {
+    if (tl_precision >= 0) return tl_precision;
     int v = g_precision.load(std::memory_order_relaxed);
     if (v < 0) {
         const char* e = getenv("MMB_PRECISION");

@@ -5,7 +5,9 @@ the library never owns memory; kernels are enqueued on torch's current stream.  
 on the autograd worker thread: the device ordinal is passed explicitly on every call.
 """
 import ctypes
+import contextlib
 import os
+import threading
 import weakref
 
 import torch
@@ -229,6 +231,7 @@ class _BwdPrep:
         self.have_xc = self.have_wt = False
         self.event = None
         self.consumed = False     # a backward pass has used (and overwritten) the prepared buffers
+        self.precision = precision_code()      # of the forward call that made the record (its backward's descriptors carry it)
 
 
 _bwd_preps = {}           # device index -> list of weakrefs to _BwdPrep (forward order)
@@ -241,6 +244,7 @@ def _prep_descs(rec, idx):
     for k, i in enumerate(idx):
         x, y, w_ih_f, w_ih_r, x_absmax = rec.probs[i]
         d = descs[k]
+        d.precision = rec.precision
         B, T, I = x.shape
         H = w_ih_f.shape[0] // 4
         d.x, d.y = _ptr(x), _ptr(y)
@@ -355,6 +359,9 @@ class _BiDAFAttentionGroupFn(torch.autograd.Function):
         n = len(flat) // _ATT_ARGS
         assert len(flat) == n * _ATT_ARGS and 1 <= n <= _lib.MAX_ATT_GROUP
         descs = (_lib.BidafDesc * n)()
+        ctx.precision = precision_code()
+        for k in range(n):
+            descs[k].precision = ctx.precision
         saved, outs, meta, keep = [], [], [], []
         B = D = dev = None
         for k in range(n):
@@ -419,6 +426,8 @@ class _BiDAFAttentionGroupFn(torch.autograd.Function):
         n = ctx.n
         sv_all = ctx.saved_tensors
         descs = (_lib.BidafDesc * n)()
+        for k in range(n):
+            descs[k].precision = ctx.precision
         results, keep = [], []
         B = D = dev = None
         for k in range(n):
@@ -503,6 +512,9 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         n = len(lengths_dev)
         assert len(flat) == n * _PER_PROBLEM and 1 <= n <= _lib.MAX_GROUP
         descs = (_lib.LstmFwdDesc * n)()
+        ctx.precision = precision_code()
+        for i in range(n):
+            descs[i].precision = ctx.precision
         keep, outs, saved = [], [], []
         dev = flat[0].device
         ctx.set_materialize_grads(False)     # an unused output (h_n of the input encoders) arrives as None, not as a zero fill
@@ -513,7 +525,7 @@ class _BiLSTMLayerFn(torch.autograd.Function):
                                                  flat[i * _PER_PROBLEM + 2].shape[1])) for i in range(n)]
         # (bf16 mode: the one-plane split pass records no maxima -- zeros, so that a backward pass run after a switch back to
         #  fp32 finds a defined (degenerate) bound instead of uninitialised memory)
-        am_flat = (torch.zeros if get_precision() == "bf16" else torch.empty)(sum(am_n), device=dev, dtype=torch.float32)
+        am_flat = (torch.zeros if current_precision() == "bf16" else torch.empty)(sum(am_n), device=dev, dtype=torch.float32)
         am_off = [sum(am_n[:i]) for i in range(n)]
         x_absmax = [am_flat[am_off[i]:am_off[i] + am_n[i]] for i in range(n)]
         for i in range(n):
@@ -571,6 +583,8 @@ class _BiLSTMLayerFn(torch.autograd.Function):
         n = ctx.n
         sv = ctx.saved_tensors
         descs = (_lib.LstmBwdDesc * n)()
+        for i in range(n):
+            descs[i].precision = ctx.precision
         keep, results = [], []
         dev = sv[0].device
         # all bias gradients of the call live in one flat buffer: b_ih and b_hh have the same gradient but must not share
@@ -729,14 +743,46 @@ def hidden_states(per_layer):
 
 
 def set_precision(mode):
-    """'fp32' (default: fp32-accurate products) or 'bf16' (bf16 operands, one product, fp32 accumulation) for every
-    matrix-core product of the LSTM layers (mmb_set_precision)."""
+    """The process-wide DEFAULT arithmetic of the LSTM layers' matrix-core products: 'fp32' (fp32-accurate split, the library's
+    default) or 'bf16' (bf16 operands, one product, fp32 accumulation) -- mmb_set_precision.  A call made inside
+    precision_scope(...) (a module with a `precision` attribute) does not depend on it: the value travels in the descriptors."""
     code = {"fp32": 0, "f32": 0, 0: 0, "bf16": 1, 1: 1}[mode]
     _lib.check(_lib.load().mmb_set_precision(code), "mmb_set_precision")
 
 
 def get_precision():
+    """the process-wide default (see current_precision for what a call made here and now would use)"""
     return "bf16" if _lib.load().mmb_get_precision() == 1 else "fp32"
+
+
+_prec_tl = threading.local()
+
+
+@contextlib.contextmanager
+def precision_scope(mode):
+    """Every library call issued by THIS thread inside the block carries `mode` ('fp32' / 'bf16') in its descriptors
+    (mmb_*_desc.precision: a per-call value, no library state); the autograd nodes made inside remember it for their backward
+    calls, whichever thread runs them.  None: no override (the process default applies)."""
+    prev = getattr(_prec_tl, "mode", None)
+    if mode is not None:
+        mode = {"fp32": "fp32", "f32": "fp32", "bf16": "bf16"}[mode]
+        _prec_tl.mode = mode
+    try:
+        yield
+    finally:
+        _prec_tl.mode = prev
+
+
+def current_precision():
+    """'fp32' / 'bf16': what a library call issued here and now computes in (the enclosing precision_scope, else the default)"""
+    m = getattr(_prec_tl, "mode", None)
+    return m if m is not None else get_precision()
+
+
+def precision_code():
+    """descriptor value (MMB_PRECISION_*) of a call issued here and now: explicit inside a precision_scope, DEFAULT outside"""
+    m = getattr(_prec_tl, "mode", None)
+    return _lib.PRECISION_DEFAULT if m is None else (_lib.PRECISION_BF16 if m == "bf16" else _lib.PRECISION_F32)
 
 
 def gemm(a, b, bias=None, ta=False, tb=False, out=None, accumulate=False):

@@ -50,6 +50,15 @@ class MMBiDAF(nn.Module):
         their (length-sorted) final hidden states (+ the text mask); with_decoder_hidden=True appends the decoder's initial
         hidden state (B,1,H) = sum of both encoders' final states over layers and directions (models.py:143)."""
         dev = text_emb.device
+        if getattr(self, "precision", None) is not None and not getattr(self, "_in_precision_scope", False):
+            # this model's own arithmetic ('fp32' / 'bf16'): it travels in the descriptors of every library call made below (a
+            # per-call value: another model of the process with a different setting is not affected, nor is the process default)
+            self._in_precision_scope = True
+            try:
+                with MF.precision_scope(self.precision):
+                    return self.hot_path(text_emb, audio_emb, image_emb, text_lengths, audio_lengths, image_lengths, with_decoder_hidden)
+            finally:
+                self._in_precision_scope = False
         if dev.type == "cuda":
             # the whole region as ONE autograd node with a lean host side (mmbidaf_amd/region_fn.py): same library calls, same
             # results; taken for the reference's exact module structure, anything else runs module by module below

@@ -268,7 +268,7 @@ def eligible(R, xs, lens3):
         return False
     if 2 * H > _lib.ATT_MAX_D or H % 4 != 0:
         return False
-    if MF.get_precision() != "fp32":
+    if MF.current_precision() != "fp32":      # (bf16 operand mode: the modular path)
         return False
     for l, n in zip(lens3, (T, x_aud.shape[1], x_img.shape[1])):
         if len(l) != B or min(l) < 1 or max(l) > n:
@@ -439,7 +439,7 @@ def _build_templates(plan):
                     t.dynamic(i, "y", f"y{i}")
                     continue
                 t.ptr(i, fld, base, (ko if base == "keep" else so)[tag + name])
-            t.ints(i, B=B, T=Tn[tag], I=In[tag], H=H)
+            t.ints(i, B=B, T=Tn[tag], I=In[tag], H=H, precision=_lib.PRECISION_F32)
         return t.freeze()
 
     tm["f_enc"] = fwd(("et", "ea", "ei"), [("dyn", "x0"), ("dyn", "x1"), ("dyn", "x2")])
@@ -477,7 +477,7 @@ def _build_templates(plan):
             else:
                 t.ptr(i, "workspace", "scr", so[tag + ".ws"])
                 t.sizes(i, workspace_bytes=256)
-            t.ints(i, T=T, M=M)
+            t.ints(i, T=T, M=M, precision=_lib.PRECISION_F32)
         return t.freeze()
 
     tm["f_att"], tm["b_att"] = att(False), att(True)
@@ -514,7 +514,7 @@ def _build_templates(plan):
             t.ptr(i, "d_a", "bw", bo[tag + ".d_a"])
             t.ptr(i, "d_w_cat", "bw", bo[tag + ".d_w_cat"])
             t.ptr(i, "ws", "bw", bo[tag + ".ws"])
-            t.ints(i, B=B, T=Tn[tag], I=In[tag], H=H)
+            t.ints(i, B=B, T=Tn[tag], I=In[tag], H=H, precision=_lib.PRECISION_F32)
         return t.freeze()
 
     tm["b_l1"] = bwd(("a1", "i1"), [("dyn", "x0"), ("dyn", "x1")], [("dyn", "dy0"), ("dyn", "dy1")], y_dyn=True)

@@ -1731,6 +1731,65 @@ def test_side_stream_head_start_forms_give_identical_results(monkeypatch, mode):
             assert torch.equal(x.grad, b)
 
 
+def test_two_models_at_different_precision_in_one_process():
+    """The arithmetic of a call travels WITH the call (mmb_*_desc.precision, SURVEY 8(b)'s per-call dtype): a model that computes
+    its LSTM products from bf16 operands and one that computes fp32-accurately, stepped alternately in one process, give exactly
+    what each gives alone under the matching process default -- forward and backward (the backward runs on autograd's thread and
+    reads the value its node remembered), whatever the process default says meanwhile."""
+    from mmbidaf_amd import synth, functional as MF
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    shape = (3, 40, 25, 9, 100)
+    batch = synth.make_batch(shape, ragged=True)
+    gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def make():
+        torch.manual_seed(224)
+        return HotRegion(100).to(d).eval()
+
+    def run(region):
+        for p in region.parameters():
+            p.grad = None
+        xs = [gpu[k].detach().clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+        outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+        synth.region_loss(outs, gpu).backward()
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in outs] + [x.grad.clone() for x in xs] + [p.grad.clone() for n, p in region.named_parameters() if "bidaf_att" not in n]
+    assert MF.get_precision() == "fp32"
+    try:
+        ref32 = run(make())
+        MF.set_precision("bf16")
+        ref16 = run(make())
+    finally:
+        MF.set_precision("fp32")
+    assert max(float((a - b).abs().max()) for a, b in zip(ref32, ref16)) > 1e-4, "the two modes must differ for the test to mean anything"
+    m16, m32 = make(), make()
+    m16.precision, m32.precision = "bf16", "fp32"
+    try:
+        for default in ("fp32", "bf16", "fp32"):
+            MF.set_precision(default)                     # the process default must not matter to either model
+            got16, got32 = run(m16), run(m32)
+            for a, b in zip(got16, ref16):
+                assert torch.equal(a, b)
+            for a, b in zip(got32, ref32):
+                assert torch.equal(a, b)
+    finally:
+        MF.set_precision("fp32")
+    # a forward under one scope, its backward after the scope has gone and the default has changed: the node remembered
+    xs = [gpu[k].detach().clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+    for p in m16.parameters():
+        p.grad = None
+    outs = m16(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+    try:
+        MF.set_precision("fp32")
+        synth.region_loss(outs, gpu).backward()
+        torch.cuda.synchronize()
+    finally:
+        MF.set_precision("fp32")
+    for a, b in zip([x.grad for x in xs], ref16[5:8]):
+        assert torch.equal(a, b)
+
+
 def test_cu_masked_stream_runs_kernels():
     """mmb_stream_create_cu_mask / mmb_stream_destroy: a stream restricted to half of the CUs computes the same GEMM
     (the option is measured and not used by default, profiles/r02_side_stream.md; the entry points stay covered)."""
