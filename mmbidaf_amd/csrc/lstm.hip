@@ -637,6 +637,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+__global__ __launch_bounds__(64) void gate_add_kernel(unsigned* gate, unsigned n) {
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(gate, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // d_w_cat (8H, I+2H) -> d_w_ih (2,4H,I), d_w_hh (2,4H,H): rows [dir*4H..), columns [0,I) | [I + dir*H, +H);
 // with db_part, also d_b (2,4H) = sum over the B samples of the recurrence's per-sample partials
 struct UnpackProb { const float* cat; float* d_w_ih; float* d_w_hh; const float* db_part; float* d_b; int I, B; };
@@ -1277,6 +1281,12 @@ extern "C" int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* d, int n, int
     ra.gate = big ? nullptr : d[0].gate;
     ra.gate_wgs = wg < 256 ? wg : 256;
     int rc;
+    if (big && d[0].gate) {
+        // the general-size recurrences do not count themselves in: the call adds the same total up front (a gate that waits on this
+        // word then passes at once), so that the word's book-keeping -- back to zero after every (call, gate) pair -- holds for every H
+        hipLaunchKernelGGL(gate_add_kernel, dim3(1), dim3(64), 0, stream, d[0].gate, (unsigned)ra.gate_wgs);
+        MMB_HIP(hipGetLastError());
+    }
     if (big) {
         char* big_ws[MMB_MAX_GROUP];
         for (int i = 0; i < n; ++i) big_ws[i] = static_cast<char*>(d[i].ws) + ws_bwd_layout((long)d[i].B * d[i].T, d[i].B, d[i].I, H).big;
