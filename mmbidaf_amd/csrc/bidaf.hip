@@ -487,6 +487,11 @@ struct AttG {
     // operand planes + inverse row scales: text, dropped text, mod, dropped mod, q
     char *pT, *pTd, *pM, *pMd, *pQ;
     float *iT, *iTd, *iM, *iMd, *iQ;
+    // S-reuse (round 5; null: off): the raw similarity S_ij = r_i + c_j + <text_d_i w_tm, mod_d_j> as the column pass computed it, stored
+    // j-major -- sT[(b Mp + j) Tp + i] -- which is the accumulator layout of every kernel whose lane side is the modality rows: the dq
+    // sweep reads its 2 x 4 values per lane and panel back (32 B per lane, prefetched a panel ahead) instead of recomputing the
+    // S-type product (42 of its 81 MFMAs per panel, the S-only panel's staging and the lane-side operand with its split)
+    float* sT;
     // backward
     const float* d_out;
     float *d_text, *d_mod, *d_text_d, *d_mod_d, *d_w_t, *d_w_m, *d_w_tm, *d_bias;
@@ -813,7 +818,8 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
     const char* pS_b = A.pTd + (size_t)b * szR;
     const float* iV_b = (KIND == 0 ? A.iT : A.iDb) + (size_t)b * Rp;
     const float* iS_b = A.iTd + (size_t)b * Rp;
-    const bool sep_s = KIND == 1 || A.pTd != A.pT;
+    const bool use_sT = KIND == 1 && A.sT != nullptr;      // dq sweep: similarity tiles from the column pass instead of an S-type product
+    const bool sep_s = KIND == 1 ? !use_sT : A.pTd != A.pT;
     const int npan = sep_s ? 2 : 1;
     const int stage_b = 2 * npan * PANEL_B;               // both groups' panels of one iteration
     const bool db = !sep_s;                               // two stages fit only with one streamed tensor
@@ -861,8 +867,19 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
     // from LDS (round 4; loaded by both, they were 100 of the 158 KB a workgroup requests in its prologue, and the prologue's
     // length is those bytes at the ~11 B/clk a CU gets while every CU asks at once)
     float xrow[KT][8];
-    if (grp == 0) load_row_regs(xrow, A.mod_d + (size_t)b * N * D, n, N, D, g, A.w_tm);
+    if (grp == 0 && !use_sT) load_row_regs(xrow, A.mod_d + (size_t)b * N * D, n, N, D, g, A.w_tm);
     const bool nin = n < N;
+    // similarity tile of (lane row n, streamed rows 64 it + 32 grp + 16 mb + 4 g ..+3): two 16-B loads, one panel ahead
+    const int Tp_ = pad32(R);
+    const float* sT_n = use_sT ? A.sT + ((size_t)b * Np + min(n, Np - 1)) * Tp_ + 32 * grp + 4 * g : nullptr;
+    f4 st_next[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+    auto st_fetch = [&](int it) {
+        if (use_sT && 64 * it + 32 * grp < Rp) {
+            st_next[0] = *reinterpret_cast<const f4*>(sT_n + 64 * it);
+            st_next[1] = *reinterpret_cast<const f4*>(sT_n + 64 * it + 16);
+        }
+    };
+    if (niter > 0) st_fetch(0);
     const float nterm = nin ? A.cterm[(size_t)b * N + n] : 0.f;
     const bool mm = nin ? mask_live(A.mod_mask, A.mod_len, b, N, n) : false;
     const tr_off tr = make_tr_off(lane);
@@ -901,7 +918,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
     // the value-panel slots of the one stage); the inverse scales in the second scalar buffer (first written in iteration 1)
     char* xs = (db ? smem + stage_b : smem) + (w4 >> 1) * (db ? PANEL_B : 2 * PANEL_B) + (w4 & 1) * (2 * KT * 1024) + lane * 16;
     float* xinv = sc + NSC * 64 + w4 * 64 + lane;
-    if (grp == 0) {
+    if (grp == 0 && !use_sT) {
         side_from_regs(xrow, side, inv_n);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
@@ -913,7 +930,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
     // c: power of two mapping the largest inverse scale of the value rows to 2^14
     wg_allmax_w<1, 8>(im, red, tid);     // (its barriers also publish the exchange area)
     const float cV = cmap(im[0]);
-    if (grp == 1) {
+    if (grp == 1 && !use_sT) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             side.h[kt][0] = *reinterpret_cast<const half8*>(xs + (2 * kt) * 1024);
@@ -944,6 +961,8 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
         sc_commit(sb);
         dma_sync();                 // db: this iteration's stage has landed, the other is free; else: the S-only panels have landed
         if (more) sc_fetch(it + 1);
+        const f4 st_cur[2] = {st_next[0], st_next[1]};      // (S-reuse: this panel's similarity tile, requested a panel ago)
+        if (more) st_fetch(it + 1);
         char* const hs_dst = db ? smem + (sb ^ 1) * stage_b : smem;
         const int hs_stride = db ? PANEL_B : 2 * PANEL_B, hs_it = db ? it + 1 : it;
         const bool hs_on = db ? more : true;
@@ -958,7 +977,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
         if (act) {
             const float* s0 = sc + (sb * NSC) * 64 + 32 * grp;     // scalar k of local row ml: s0[k * 64 + ml]
             f4 v[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-            if (!(dbg & 2)) sprod2p(pS, r, g, side, v, hookS);
+            if (!(dbg & 2) && !use_sT) sprod2p(pS, r, g, side, v, hookS);
             ts_cyc<DBG>(tsr, 10, tsi);
             // the per-row scalars of the lane's 2 x 4 rows as whole 16-B reads, all requested before the arithmetic (written with
             // one scalar read per use, hipcc made each row a branch around its own reads: 16 dependent LDS round trips per panel)
@@ -974,16 +993,23 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
             }
             if (KIND == 0) {
                 float bmax = -INFINITY;
+                f4 xraw[2];
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float code = q1[mb][e];
                         const float x = v[mb][e] * (q2[mb][e] * inv_n) + q0[mb][e] + nterm;
+                        xraw[mb][e] = x;
                         const float off = code == 1.f ? NEG : -INFINITY;
                         v[mb][e] = code == 2.f ? x : off;
                         bmax = fmaxf(bmax, v[mb][e]);
                     }
+                if (A.sT && nin) {      // S-reuse: the raw similarity of the tile, j-major (see AttG::sT); 2 x 16 B per lane
+                    float* d = A.sT + ((size_t)b * Np + n) * pad32(R) + 64 * it + 32 * grp + 4 * g;
+                    *reinterpret_cast<f4*>(d) = xraw[0];
+                    *reinterpret_cast<f4*>(d + 16) = xraw[1];
+                }
                 bmax = kg_allmax(bmax);
                 const float m_new = fmaxf(m_run, bmax);
                 const float alpha = __expf(m_run - m_new);
@@ -1007,14 +1033,14 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float xs = v[mb][e] * (q3[mb][e] * inv_n) + q0[mb][e] + nterm;
+                        const float xs = use_sT ? st_cur[mb][e] : v[mb][e] * (q3[mb][e] * inv_n) + q0[mb][e] + nterm;
                         const float x = mm ? xs : NEG;
                         const float p = __expf(x - q1[mb][e]) * q2[mb][e];
                         w[mb][e] = p * (q4[mb][e] * cV);
                     }
             }
         }
-        if (!act || (dbg & 2)) {
+        if (!act || (dbg & 2) || use_sT) {
 #pragma unroll
             for (int k = 0; k < KT; ++k) hookS(k);
         }
@@ -2317,8 +2343,19 @@ static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 // saved-for-backward buffer of the fused path: planes + inverse row scales of text, mod, q and of the dropped copies (training mode)
 struct SavedLayout {
-    size_t pT, pTd, pM, pMd, pQ, iT, iTd, iM, iMd, iQ, total;
+    size_t pT, pTd, pM, pMd, pQ, iT, iTd, iM, iMd, iQ, sT, total;     // sT = (size_t)-1: S-reuse off for these sizes
 };
+// S-reuse is taken while the similarity of the whole batch is small beside the tensors the kernels move anyway (cfg2: 13.6 + 3.4 MB
+// against 250 MB of algorithmic bytes); at cfg4's lengths it would be 210 MB per attention: recomputing is the cheaper side there
+constexpr size_t SREUSE_MAX_BYTES = (size_t)48 << 20;
+static bool sreuse_env() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MMB_ATT_SREUSE");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v == 1;
+}
 static SavedLayout saved_layout(int B, int T, int M, int drop) {
     SavedLayout L{};
     size_t o = 0;
@@ -2335,6 +2372,8 @@ static SavedLayout saved_layout(int B, int T, int M, int drop) {
     L.iM = take(nM);
     L.iMd = drop ? take(nM) : L.iM;
     L.iQ = take(nM);
+    const size_t sT_b = (size_t)B * pad32(M) * pad32(T) * sizeof(float);
+    L.sT = (sreuse_env() && sT_b <= SREUSE_MAX_BYTES) ? take(sT_b) : (size_t)-1;
     L.total = o;
     return L;
 }
@@ -2445,6 +2484,7 @@ static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backwar
         auto fp = [&](size_t off) { return reinterpret_cast<float*>(sv + off); };
         g.pT = sv + L.pT; g.pTd = sv + L.pTd; g.pM = sv + L.pM; g.pMd = sv + L.pMd; g.pQ = sv + L.pQ;
         g.iT = fp(L.iT); g.iTd = fp(L.iTd); g.iM = fp(L.iM); g.iMd = fp(L.iMd); g.iQ = fp(L.iQ);
+        g.sT = L.sT == (size_t)-1 ? nullptr : fp(L.sT);
         // attentions of one call that read the same text tensor share ONE set of text planes (made once by the split pass)
         for (int j = 0; j < k; ++j)
             if (d[j].text == s.text && d[j].T == s.T) {
