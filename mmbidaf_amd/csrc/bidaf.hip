@@ -40,6 +40,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -1527,7 +1528,9 @@ constexpr int SWEEP_XCH_OFF = SWEEP_SC_OFF + 10 * 32 * 4;
 constexpr int SWEEP_RED_OFF = SWEEP_XCH_OFF + 4 * XCH_PAIR;
 constexpr int SWEEP_LOOP_LDS = SWEEP_RED_OFF + 64 * 4;
 
-template <int DBG, bool SAME>
+// SREUSE: the similarity tiles come back from the column pass's store (AttG::sT is set) -- a compile-time form: the kernel sits at
+// its 256-register budget, and as a run-time switch the unused side (a 56-register operand or the tile registers) stayed live
+template <int DBG, bool SAME, bool SREUSE>
 __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, int local, char* smem) {
     const int dbg = DBG == 1 ? a.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1640,8 +1643,24 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     // operands + arithmetic and role 1's operands apart instead of their union.
     if (role == 0) {
         side_t sS, sDq;      // mod_d * w_tm (similarity), dq (dP2)
-        float inS, inDq;
-        load_side_f32(sS, inS, A.mod_d + (size_t)b * M * D, n, M, D, g, A.w_tm);
+        float inS = 0.f, inDq;
+        // S-reuse (AttG::sT): the similarity tile of (row n, panel) comes back from the column pass's store -- 2 x 16 B per lane and
+        // panel, requested a panel ahead -- instead of an S-type product: no lane-side operand for it (51 KB of fp32 rows and their
+        // split less in the prologue), 42 MFMAs per panel less in this role
+        constexpr bool use_sT = SREUSE;
+        const float* sT_n = use_sT ? A.sT + ((size_t)b * Mp + min(n, Mp - 1)) * Tp + 4 * g : nullptr;
+        f4 st_next[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+        auto st_fetch = [&](int pi) {
+            if (use_sT) {
+                st_next[0] = *reinterpret_cast<const f4*>(sT_n + 32 * pi);
+                st_next[1] = *reinterpret_cast<const f4*>(sT_n + 32 * pi + 16);
+            }
+        };
+        if constexpr (use_sT) {
+            if (np > 0) st_fetch(0);
+        } else {
+            load_side_f32(sS, inS, A.mod_d + (size_t)b * M * D, n, M, D, g, A.w_tm);
+        }
         load_side_planes(sDq, inDq, A.pDq + (size_t)b * szM, A.iDq + (size_t)b * Mp, n, M, g);
         const float inM = nin ? A.iM[(size_t)b * Mp + n] : 0.f, inQ = nin ? A.iQ[(size_t)b * Mp + n] : 0.f;
         const float cterm = nin ? A.cterm[(size_t)b * M + n] : 0.f;
@@ -1676,13 +1695,17 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
             }
             dma_sync();               // this panel's DMA has landed (4 tensors: all but the last, see role 1), its scalars are visible
             if (pi + 1 < np && f_on) sc_next = fetch((pi + 1) * PR + scr);
+            const f4 st_cur[2] = {st_next[0], st_next[1]};
+            if (pi + 1 < np) st_fetch(pi + 1);
             ts_cyc<DBG>(tsr, 9, tsi);
             const char* pTd = sweep_slot<SAME, NT, X_DB, X_TD>(smem, pi, X_TD);
             const char* pT = sweep_slot<SAME, NT, X_DB, X_TD>(smem, pi, X_T);
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
-            if (!(dbg & 2)) sprod2p(pTd, r, g, sS, c1);
+            if constexpr (!use_sT) {
+                if (!(dbg & 2)) sprod2p(pTd, r, g, sS, c1);
+            }
             plain_barrier();                // the role-1 waves' rendezvous: their late tensor of THIS panel has landed (see role 1)
             if (!(dbg & 2)) sprod2p(pT, r, g, sDq, c2);
             ts_cyc<DBG>(tsr, 10, tsi);
@@ -1699,7 +1722,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float code = s_code[e];
-                    const float xr = c1[mb][e] * (s_sTd[e] * inS) + s_rt[e] + cterm;
+                    const float xr = use_sT ? st_cur[mb][e] : c1[mb][e] * (s_sTd[e] * inS) + s_rt[e] + cterm;
                     const float P1s = __expf((mm ? xr : NEG) - s_rmax[e]) * s_rinv[e];    // 0 beyond the range (rinv = 0); < 0: one-hot row
                     const float P1 = fabsf(P1s);
                     const float P2 = code != 0.f ? __expf((code == 2.f ? xr : NEG) - cmax) * cinv : 0.f;
@@ -2316,7 +2339,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
 // (a_dq: a second copy of the SAME argument block, read by the dq body alone.  With one copy hipcc merged the loads of the
 //  attention's pointers that both bodies make and kept them in SGPRs across the dq loop: 16-20 spill instructions per iteration
 //  of a loop that has none as a kernel of its own; two kernel arguments cannot be proven equal.)
-template <int DBG, bool SAME>
+template <int DBG, bool SAME, bool SREUSE, bool FUSE>
 __global__ __launch_bounds__(NT8) void att_bwd_sweep_kernel(const GroupArgs a, const SweepMap sm, const GroupArgs a_dq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int local;
@@ -2328,9 +2351,9 @@ __global__ __launch_bounds__(NT8) void att_bwd_sweep_kernel(const GroupArgs a, c
         // text rows streamed -- and the j sweep needs dq only for ITS OWN rows: the workgroup runs the dq body first (dq = P1^T db as
         // planes, delta2), publishes its rows for the i blocks of this launch, and goes on with the j sweep.  One launch and one
         // prologue / epilogue / launch ramp less than the three-launch form, and the i blocks fill the CUs the 160 j blocks leave free.
-        if (a_dq.fuse_dq) att_jsweep_body<1, DBG, true>(a_dq, sm.j);
+        if constexpr (FUSE) att_jsweep_body<1, DBG, true>(a_dq, sm.j);
         const AttG& A = a.g[find_att(sm.j, a.n, blockIdx.x, local)];
-        sweep_j_body<DBG, SAME>(a, A, local, smem);
+        sweep_j_body<DBG, SAME, SREUSE>(a, A, local, smem);
     } else {
         const AttG& A = a.g[find_att(sm.i, a.n, blockIdx.x, local)];
         sweep_i_body<DBG, SAME>(a, A, local, smem);
@@ -2509,6 +2532,11 @@ static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backwar
             g.dq_cnt = reinterpret_cast<unsigned*>(ws + W.dq_cnt);
         }
     }
+    // S-reuse is a property of the LAUNCH (one kernel variant for the whole group): on only when every attention of the call has it
+    bool all_sT = true;
+    for (int k = 0; k < n; ++k) all_sT = all_sT && ga.g[k].sT != nullptr;
+    if (!all_sT)
+        for (int k = 0; k < n; ++k) ga.g[k].sT = nullptr;
     return MMB_OK;
 }
 
@@ -2698,9 +2726,17 @@ extern "C" int mmb_bidaf_group_bwd(const mmb_bidaf_desc* d, int n, int B, int D,
         const size_t epi = ((size_t)2 * 64 * LDP + 64 + 8 * 2 * 256) * sizeof(float);
         const size_t dq_b = (size_t)2 * 2 * PANEL_B + (2 * 5 * 64 + 64) * sizeof(float);      // the dq body in front of the j sweep
         const size_t lds = std::max(std::max(loop_b, epi), ga.fuse_dq ? dq_b : (size_t)0);
-        auto kern = ga.ts    ? (drop ? att_bwd_sweep_kernel<2, false> : att_bwd_sweep_kernel<2, true>)
-                    : ga.dbg ? (drop ? att_bwd_sweep_kernel<1, false> : att_bwd_sweep_kernel<1, true>)
-                             : (drop ? att_bwd_sweep_kernel<0, false> : att_bwd_sweep_kernel<0, true>);
+        // (S-reuse is on for every attention of a call or for none: same B, same rule -- fill_group has checked; the fused-dq form is
+        //  instantiated for the recomputing sweep only: it is a measured, non-default form)
+        const bool sre = ga.g[0].sT != nullptr;
+        auto pick = [&](auto dbg_c) {
+            constexpr int DBGV = decltype(dbg_c)::value;
+            using K = void (*)(const GroupArgs, const SweepMap, const GroupArgs);
+            if (ga.fuse_dq) return drop ? (K)att_bwd_sweep_kernel<DBGV, false, false, true> : (K)att_bwd_sweep_kernel<DBGV, true, false, true>;
+            if (sre) return drop ? (K)att_bwd_sweep_kernel<DBGV, false, true, false> : (K)att_bwd_sweep_kernel<DBGV, true, true, false>;
+            return drop ? (K)att_bwd_sweep_kernel<DBGV, false, false, false> : (K)att_bwd_sweep_kernel<DBGV, true, false, false>;
+        };
+        auto kern = ga.ts ? pick(std::integral_constant<int, 2>{}) : ga.dbg ? pick(std::integral_constant<int, 1>{}) : pick(std::integral_constant<int, 0>{});
         if (int rc = allow_lds(kern, lds)) return rc;
         ProfScope ps_(MMB_K_ATT_BWD_I, stream);
         hipLaunchKernelGGL(kern, dim3(sm.i.begin[n]), dim3(NT8), lds, stream, ga, sm, ga);
