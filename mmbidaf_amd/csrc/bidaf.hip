@@ -493,6 +493,7 @@ struct AttG {
     // sweep reads its 2 x 4 values per lane and panel back (32 B per lane, prefetched a panel ahead) instead of recomputing the
     // S-type product (42 of its 81 MFMAs per panel, the S-only panel's staging and the lane-side operand with its split)
     float* sT;
+    float* sI;      // the same similarity i-major -- sI[(b Tp + i) Mp + j] -- stored by the row pass (lane side = text rows) for the i sweep
     // backward
     const float* d_out;
     float *d_text, *d_mod, *d_text_d, *d_mod_d, *d_w_t, *d_w_m, *d_w_tm, *d_bias;
@@ -1284,15 +1285,20 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
         }
         float bmax = -INFINITY;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < 2; ++mb) {
+            f4 xraw;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float code = q1[mb][e];
                 const float x = v[mb][e] * (q2[mb][e] * inv_n) + q0[mb][e] + nterm;
+                xraw[e] = x;
                 const float off = code == 1.f ? NEG : -INFINITY;
                 v[mb][e] = code == 2.f ? x : off;
                 bmax = fmaxf(bmax, v[mb][e]);
             }
+            // S-reuse: the raw similarity of the tile, i-major, for the i sweep of the backward pass (AttG::sI); 16 B per lane and block
+            if (A.sI && n < N) *reinterpret_cast<f4*>(A.sI + ((size_t)b * pad32(N) + n) * Rp + p0 + 16 * mb + 4 * g) = xraw;
+        }
         bmax = kg_allmax(bmax);
         const float m_new = fmaxf(m_run, bmax);
         const float alpha = __expf(m_run - m_new);
@@ -1924,7 +1930,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
     ts_flush<DBG>(a, 3, tsr);
 }
 
-template <int DBG, bool SAME>
+template <int DBG, bool SAME, bool SREUSE>
 __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, int local, char* smem) {
     const int dbg = DBG == 1 ? a.dbg : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2066,11 +2072,25 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
 
     if (role == 0) {
         side_t sT, sS;       // text (dP2); text_d * w_tm (similarity)
-        float inS, inT_;
+        float inS = 0.f, inT_;
+        // S-reuse (AttG::sI): the similarity tile of (row n, panel) from the row pass's store, as in the j sweep
+        constexpr bool use_sI = SREUSE;
+        const float* sI_n = use_sI ? A.sI + ((size_t)b * Tp + min(n, Tp - 1)) * Mp + 4 * g : nullptr;
+        f4 st_next[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+        auto st_fetch = [&](int pi) {
+            if (use_sI) {
+                st_next[0] = *reinterpret_cast<const f4*>(sI_n + 32 * pi);
+                st_next[1] = *reinterpret_cast<const f4*>(sI_n + 32 * pi + 16);
+            }
+        };
         if (!(dbg & 256)) {
         load_side_planes(sT, inT_, A.pT + (size_t)b * szT, A.iT + (size_t)b * Tp, n, T, g);
-        if (SAME) side_times_w(sT, inT_, A.w_tm, D, g, sS, inS);
-        else load_side_f32(sS, inS, A.text_d + (size_t)b * T * D, n, T, D, g, A.w_tm);
+        if constexpr (use_sI) {
+            if (np > 0) st_fetch(0);
+        } else {
+            if (SAME) side_times_w(sT, inT_, A.w_tm, D, g, sS, inS);
+            else load_side_f32(sS, inS, A.text_d + (size_t)b * T * D, n, T, D, g, A.w_tm);
+        }
         }
         const float rterm = nin ? A.rterm[(size_t)b * T + n] : 0.f;
         const float rmax = nin ? A.row_stat[((size_t)b * T + n) * 2] : 0.f;
@@ -2101,13 +2121,17 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
             }
             dma_sync();               // this panel's DMA has landed (4 tensors: all but the last, see role 1), its scalars are visible
             if (pi + 1 < np && f_on) sc_next = fetch((pi + 1) * PR + scr);
+            const f4 st_cur[2] = {st_next[0], st_next[1]};
+            if (pi + 1 < np) st_fetch(pi + 1);
             ts_cyc<DBG>(tsr, 9, tsi);
             const char* pMd = sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, X_MD);
             const char* pDq = sweep_slot<SAME, NT, X_Q, X_DQ>(smem, pi, X_DQ);
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
-            if (!(dbg & 2)) sprod2p(pMd, r, g, sS, c1);
+            if constexpr (!use_sI) {
+                if (!(dbg & 2)) sprod2p(pMd, r, g, sS, c1);
+            }
             plain_barrier();                // the role-1 waves' rendezvous: their late tensor of THIS panel has landed (see role 1)
             if (!(dbg & 2)) sprod2p(pDq, r, g, sT, c2);
             ts_cyc<DBG>(tsr, 10, tsi);
@@ -2124,7 +2148,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float mf = s_mf[e];
-                    const float x = c1[mb][e] * (s_sSp[e] * inS) + rterm + s_ct[e];
+                    const float x = use_sI ? st_cur[mb][e] : c1[mb][e] * (s_sSp[e] * inS) + rterm + s_ct[e];
                     const float P1 = mf >= 0.f ? __expf((mf > 0.f ? x : NEG) - rmax) * rinv : 0.f;
                     const float P2s = mf >= 0.f ? __expf((tm ? x : NEG) - s_cmax[e]) * s_cinv[e] : 0.f;    // < 0: one-hot column
                     const float P2 = fabsf(P2s);
@@ -2356,7 +2380,7 @@ __global__ __launch_bounds__(NT8) void att_bwd_sweep_kernel(const GroupArgs a, c
         sweep_j_body<DBG, SAME, SREUSE>(a, A, local, smem);
     } else {
         const AttG& A = a.g[find_att(sm.i, a.n, blockIdx.x, local)];
-        sweep_i_body<DBG, SAME>(a, A, local, smem);
+        sweep_i_body<DBG, SAME, SREUSE>(a, A, local, smem);
     }
 }
 
@@ -2366,7 +2390,7 @@ static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 // saved-for-backward buffer of the fused path: planes + inverse row scales of text, mod, q and of the dropped copies (training mode)
 struct SavedLayout {
-    size_t pT, pTd, pM, pMd, pQ, iT, iTd, iM, iMd, iQ, sT, total;     // sT = (size_t)-1: S-reuse off for these sizes
+    size_t pT, pTd, pM, pMd, pQ, iT, iTd, iM, iMd, iQ, sT, sI, total;     // sT = sI = (size_t)-1: S-reuse off for these sizes
 };
 // S-reuse is taken while the similarity of the whole batch is small beside the tensors the kernels move anyway (cfg2: 13.6 + 3.4 MB
 // against 250 MB of algorithmic bytes); at cfg4's lengths it would be 210 MB per attention: recomputing is the cheaper side there
@@ -2397,6 +2421,7 @@ static SavedLayout saved_layout(int B, int T, int M, int drop) {
     L.iQ = take(nM);
     const size_t sT_b = (size_t)B * pad32(M) * pad32(T) * sizeof(float);
     L.sT = (sreuse_env() && sT_b <= SREUSE_MAX_BYTES) ? take(sT_b) : (size_t)-1;
+    L.sI = L.sT != (size_t)-1 ? take(sT_b) : (size_t)-1;
     L.total = o;
     return L;
 }
@@ -2508,6 +2533,7 @@ static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backwar
         g.pT = sv + L.pT; g.pTd = sv + L.pTd; g.pM = sv + L.pM; g.pMd = sv + L.pMd; g.pQ = sv + L.pQ;
         g.iT = fp(L.iT); g.iTd = fp(L.iTd); g.iM = fp(L.iM); g.iMd = fp(L.iMd); g.iQ = fp(L.iQ);
         g.sT = L.sT == (size_t)-1 ? nullptr : fp(L.sT);
+        g.sI = L.sI == (size_t)-1 ? nullptr : fp(L.sI);
         // attentions of one call that read the same text tensor share ONE set of text planes (made once by the split pass)
         for (int j = 0; j < k; ++j)
             if (d[j].text == s.text && d[j].T == s.T) {
@@ -2536,7 +2562,7 @@ static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backwar
     bool all_sT = true;
     for (int k = 0; k < n; ++k) all_sT = all_sT && ga.g[k].sT != nullptr;
     if (!all_sT)
-        for (int k = 0; k < n; ++k) ga.g[k].sT = nullptr;
+        for (int k = 0; k < n; ++k) ga.g[k].sT = ga.g[k].sI = nullptr;
     return MMB_OK;
 }
 
