@@ -272,7 +272,10 @@ def test_attention_backward_fused_form_equals_the_three_launch_form(B, T, M, use
     finally:
         lib.mmb_set_att_debug(0)
     assert torch.equal(out1, out0)
-    assert torch.equal(dt1, dt0) and torch.equal(dm1, dm0)
+    # (the fused form's sweeps recompute the similarity -- in the i sweep from the text planes times w_tm, split again -- where the
+    #  default form reads back the tiles the forward pass stored: the same quantity, rounded along two routes)
+    close(dt1, dt0.cpu(), "fused vs three launches d_text", tol=2e-6)
+    close(dm1, dm0.cpu(), "fused vs three launches d_mod", tol=2e-6)
     for k, a, b in zip(("d_w_t", "d_w_m", "d_w_tm"), dps1, dps0):
         close(a, b.cpu(), "fused vs three launches " + k, tol=2e-6)
 
