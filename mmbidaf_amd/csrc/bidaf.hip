@@ -965,10 +965,18 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
         if (more) sc_fetch(it + 1);
         const f4 st_cur[2] = {st_next[0], st_next[1]};      // (S-reuse: this panel's similarity tile, requested a panel ago)
         if (more) st_fetch(it + 1);
+        // S-reuse: no S-type product to spread the next stage's pieces over -- they go out here, right behind the barrier, and have
+        // the whole iteration to land (issued behind the tile arithmetic they were still in flight at the next top barrier:
+        // 1 700 of an iteration's 4 350 clocks)
+        const bool early_dma = use_sT;
         char* const hs_dst = db ? smem + (sb ^ 1) * stage_b : smem;
         const int hs_stride = db ? PANEL_B : 2 * PANEL_B, hs_it = db ? it + 1 : it;
         const bool hs_on = db ? more : true;
         auto hookS = [&](int k) { if (hs_on) piece2(pV_b, hs_dst, hs_stride, hs_it, k); };
+        if (early_dma) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) hookS(k);
+        }
         auto hookP = [&](int k) { if (!db && more && k < 7) piece2(pS_b, smem + PANEL_B, 2 * PANEL_B, it + 1, k); };
         const int p0 = 64 * it + 32 * grp;
         ts_cyc<DBG>(tsr, 9, tsi);
@@ -1042,7 +1050,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
                     }
             }
         }
-        if (!act || (dbg & 2) || use_sT) {
+        if ((!act || (dbg & 2)) && !early_dma) {
 #pragma unroll
             for (int k = 0; k < KT; ++k) hookS(k);
         }
@@ -2394,7 +2402,14 @@ struct SavedLayout {
 };
 // S-reuse is taken while the similarity of the whole batch is small beside the tensors the kernels move anyway (cfg2: 13.6 + 3.4 MB
 // against 250 MB of algorithmic bytes); at cfg4's lengths it would be 210 MB per attention: recomputing is the cheaper side there
-constexpr size_t SREUSE_MAX_BYTES = (size_t)48 << 20;
+static size_t sreuse_max_bytes() {
+    static long v = -1;
+    if (v < 0) {
+        const char* e = getenv("MMB_ATT_SREUSE_MAX_MB");      // (tuning aid)
+        v = e ? atol(e) : 48;
+    }
+    return (size_t)v << 20;
+}
 static bool sreuse_env() {
     static int v = -1;
     if (v < 0) {
@@ -2420,7 +2435,7 @@ static SavedLayout saved_layout(int B, int T, int M, int drop) {
     L.iMd = drop ? take(nM) : L.iM;
     L.iQ = take(nM);
     const size_t sT_b = (size_t)B * pad32(M) * pad32(T) * sizeof(float);
-    L.sT = (sreuse_env() && sT_b <= SREUSE_MAX_BYTES) ? take(sT_b) : (size_t)-1;
+    L.sT = (sreuse_env() && sT_b <= sreuse_max_bytes()) ? take(sT_b) : (size_t)-1;
     L.sI = L.sT != (size_t)-1 ? take(sT_b) : (size_t)-1;
     L.total = o;
     return L;
