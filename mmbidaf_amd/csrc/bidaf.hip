@@ -2400,13 +2400,14 @@ static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 struct SavedLayout {
     size_t pT, pTd, pM, pMd, pQ, iT, iTd, iM, iMd, iQ, sT, sI, total;     // sT = sI = (size_t)-1: S-reuse off for these sizes
 };
-// S-reuse is taken while the similarity of the whole batch is small beside the tensors the kernels move anyway (cfg2: 13.6 + 3.4 MB
-// against 250 MB of algorithmic bytes); at cfg4's lengths it would be 210 MB per attention: recomputing is the cheaper side there
+// S-reuse is taken while one copy of the batch's similarity stays under 256 MB (cfg2: 13.6 + 3.4 MB per copy beside 250 MB of
+// algorithmic bytes; cfg4: 210 + 52 MB per copy, two copies -- measured there too: attention 2 212 -> 2 057 us, the MFMAs it
+// saves outweigh the gigabyte it moves); beyond that the sweeps recompute it (MMB_ATT_SREUSE_MAX_MB moves the line, =0 .. off)
 static size_t sreuse_max_bytes() {
     static long v = -1;
     if (v < 0) {
         const char* e = getenv("MMB_ATT_SREUSE_MAX_MB");      // (tuning aid)
-        v = e ? atol(e) : 48;
+        v = e ? atol(e) : 256;
     }
     return (size_t)v << 20;
 }
