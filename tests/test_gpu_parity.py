@@ -1139,7 +1139,7 @@ def test_training_trajectory_golden_through_the_train_py_caller_contract():
                 # 800 entries against N(0,1) vectors) holds every entry's trajectory to ~1e-6
                 close(v, g[f"s{k}__param__{n}__{kind}"], f"step {k} {n} ({kind})", tol=2e-5, absolute=True)
                 n_cmp += 1
-        assert n_cmp >= 200
+        assert n_cmp >= 180
     for n, v in ema.shadow.items():
         if "image_keyframes_emb" in n:
             continue
