@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MMB_VERSION 500            /* round 5 ABI: + mmb_bilstm_layer_fwd_phase (streamed input projection), mmb_stream_gate + mmb_lstm_bwd_desc.gate, per-call precision field in the descriptors */
+#define MMB_VERSION 500            /* round 5 ABI: + mmb_bilstm_layer_fwd_phase (streamed input projection), mmb_stream_gate + mmb_lstm_bwd_desc.gate, per-call precision field in the descriptors, mmb_dx_att_epilogue */
 #define MMB_MAX_GROUP 8            /* problems per grouped LSTM launch */
 #define MMB_ATT_MAX_D 208          /* attention feature width D = 2H of the fused (register-resident) kernels */
 #define MMB_ATT_GENERAL_MAX_D 4096 /* wider D (up to this) runs the general path: similarity matrix in a workspace */
@@ -143,6 +143,9 @@ typedef struct {
     /* backward */
     const float* d_out;
     float *d_text, *d_mod, *d_text_d, *d_mod_d, *d_w_t, *d_w_m, *d_w_tm, *d_bias;
+    /* backward with d_out == NULL: the prologue has been formed by the producer of d_out (mmb_dx_att_epilogue): da, db (B,T,D) fp32,
+     * the partial sums of delta1 (B*T, mmb_dx_att_parts(D)), and d_text already holds its direct part */
+    const float *pre_da, *pre_db, *pre_d1_part;
     int32_t T, M;
     int32_t precision;         /* MMB_PRECISION_* of THIS call (all attentions of a grouped call carry the same value) */
     int32_t reserved;
@@ -240,6 +243,24 @@ int mmb_bilstm_layer_fwd(const mmb_lstm_fwd_desc* descs, int n, int device, void
 #define MMB_LSTM_FWD_CHUNKS(K, KH) (((K) << 8) | ((KH) << 16))
 int mmb_bilstm_layer_fwd_phase(const mmb_lstm_fwd_desc* descs, int n, int phase, int device, void* stream);
 
+/* Fused hand-over of an input gradient to the attention's backward pass.  The input of a modelling encoder's first layer IS the
+ * attention's output out = [text, a, text*a, text*b] (reference models.py:134-135, attention.py:52), so its gradient d_x (B,T,4D) =
+ * [g0,g1,g2,g3] is consumed by exactly one thing: the prologue of the attention's backward pass,
+ *     da = g1 + g2*text,  db = g3*text,  d_text(direct part) = g0 + g2*a + g3*b,  delta1 = <da,a> + <db,b>.
+ * With this descriptor in mmb_lstm_bwd_desc.dx_att the d_x GEMM's epilogue forms those where the values are, and d_x itself is
+ * never written (desc.d_x must then be NULL; I == 4 D): 164 MB of writes and re-reads and a 36-us kernel less per step at the
+ * metric configuration.  The attention's backward call takes the results through mmb_bidaf_desc.pre_da / pre_db / pre_d1_part. */
+typedef struct {
+    const float* text;         /* (B,T,D)  the attention's text operand                                                        */
+    const float* out;          /* (B,T,4D) the attention's output: a = out[:, :, D:2D]                                          */
+    const float* bsave;        /* (B,T,D)  b, as saved by the attention's forward call                                          */
+    float *da, *db;            /* (B,T,D)  fp32                                                                                 */
+    float* d_text;             /* (B,T,D)  receives the direct part (the attention's backward call adds the rest)               */
+    float* d1_part;            /* (B*T, mmb_dx_att_parts(D)) partial sums of delta1 (summed in a fixed order by the consumer)    */
+    int32_t D, reserved;
+} mmb_dx_att_epilogue;
+int mmb_dx_att_parts(int D);   /* partial sums per row the epilogue writes (a property of the GEMM's tiling of 4 D columns)   */
+
 typedef struct {
     /* inputs */
     const float* d_y;          /* (B,T,2H) cotangent of y                                        */
@@ -265,6 +286,7 @@ typedef struct {
     const float* x_absmax;     /* as left by the forward call                                     */
     uint32_t* gate;            /* NULL, or (descs[0] only) a device word that is ZERO between steps: the first min(2 B n, 256) workgroups */
                                /* of the BPTT recurrence add 1 to it as they start; mmb_stream_gate on another stream waits for them */
+    const mmb_dx_att_epilogue* dx_att;   /* NULL, or the fused hand-over above (host pointer, read during the call)               */
     int32_t B, T, I, H;
     int32_t precision;         /* MMB_PRECISION_* of THIS call: the value the forward call of the same layer was given */
     int32_t reserved;

@@ -40,7 +40,7 @@ class LstmBwdDesc(ctypes.Structure):
         ("d_y", c_f), ("d_hn", c_f), ("x", c_f), ("y", c_f), ("lengths", c_f),
         ("w_ih", c_f * 2), ("w_hh", c_f * 2), ("gates", c_f), ("cs", c_f),
         ("d_x", c_f), ("d_w_ih", c_f), ("d_w_hh", c_f), ("d_b", c_f), ("d_a", c_f), ("d_w_cat", c_f), ("ws", c_f),
-        ("hn_pos", c_f), ("x_absmax", c_f), ("gate", c_f),
+        ("hn_pos", c_f), ("x_absmax", c_f), ("gate", c_f), ("dx_att", c_f),
         ("B", ctypes.c_int32), ("T", ctypes.c_int32), ("I", ctypes.c_int32), ("H", ctypes.c_int32),
         ("precision", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
@@ -52,10 +52,17 @@ class BidafDesc(ctypes.Structure):
                                    "w_t", "w_m", "w_tm", "bias", "out", "bsave", "rterm", "cterm", "row_stat", "col_stat",
                                    "saved")] + [("saved_bytes", ctypes.c_size_t), ("workspace", c_f),
                                                 ("workspace_bytes", ctypes.c_size_t)] + \
-               [(n, c_f) for n in ("d_out", "d_text", "d_mod", "d_text_d", "d_mod_d", "d_w_t", "d_w_m", "d_w_tm", "d_bias")] + \
+               [(n, c_f) for n in ("d_out", "d_text", "d_mod", "d_text_d", "d_mod_d", "d_w_t", "d_w_m", "d_w_tm", "d_bias",
+                                   "pre_da", "pre_db", "pre_d1_part")] + \
                [("T", ctypes.c_int32), ("M", ctypes.c_int32), ("precision", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 PRECISION_DEFAULT, PRECISION_F32, PRECISION_BF16 = 0, 1, 2      # MMB_PRECISION_* (descriptor field `precision`)
+
+
+class DxAttEpilogue(ctypes.Structure):
+    """mmb_dx_att_epilogue"""
+    _fields_ = [("text", c_f), ("out", c_f), ("bsave", c_f), ("da", c_f), ("db", c_f), ("d_text", c_f), ("d1_part", c_f),
+                ("D", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class MaskedSumDesc(ctypes.Structure):
@@ -105,6 +112,7 @@ SIGNATURES = {
     "mmb_lstm_persist_enable": (c_i, [c_i]),
     "mmb_stream_delay": (c_i, [c_i, c_f, c_i]),
     "mmb_stream_gate": (c_i, [c_i, c_f, c_f, c_i, c_i]),
+    "mmb_dx_att_parts": (c_i, [c_i]),
     "mmb_stream_occupy": (c_i, [c_i, c_f, c_i, c_i, c_i]),
     "mmb_hidden_states_fwd": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i, c_i, ctypes.POINTER(ctypes.c_void_p), c_f, c_i, c_i, c_i, c_f]),
     "mmb_hidden_states_bwd": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_f, ctypes.POINTER(ctypes.c_void_p), c_i, c_i, c_i, c_i, c_i, c_f]),

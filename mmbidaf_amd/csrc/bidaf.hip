@@ -500,6 +500,10 @@ struct AttG {
     char *pDa, *pDb, *pDq;
     float *iDa, *iDb, *iDq, *delta1, *delta2;
     unsigned* dq_cnt;       // (B) fused backward: j tiles of sample b whose dq rows (planes, scales, delta2) are complete; zeroed by the prologue
+    // prologue formed by the producer of d_out (mmb_dx_att_epilogue: the d_x GEMM's epilogue of the modelling layer above): da, db (B,T,D)
+    // fp32, npart partial sums of delta1 per row; d_text already holds its direct part.  Null: d_out is given and the prologue runs here
+    const float *pre_da, *pre_db, *pre_d1;
+    int npart;
     int T, M;
 };
 struct GroupArgs {
@@ -1431,6 +1435,26 @@ __global__ __launch_bounds__(256) void att_bwd_pre_kernel(const GroupArgs a) {
     const int b = rowi / Tp, row = rowi - (long)b * Tp, c = threadIdx.x & 63, d = 4 * c;
     f4 xa = f4{0.f, 0.f, 0.f, 0.f}, xb = xa;
     float acc = 0.f;
+    if (A.pre_da) {
+        // the producer's form: only the re-encoding is left -- da, db as planes with their row scales, delta1 from its partial sums
+        // (summed in index order: the same bits every run)
+        if (row < T && d < D) {
+            const size_t rr = (size_t)b * T + row;
+            xa = *reinterpret_cast<const f4*>(A.pre_da + rr * D + d);
+            xb = *reinterpret_cast<const f4*>(A.pre_db + rr * D + d);
+        }
+        if (c == 0 && row < T) {
+            const float* pp = A.pre_d1 + ((size_t)b * T + row) * A.npart;
+            float s1 = 0.f;
+            for (int k = 0; k < A.npart; ++k) s1 += pp[k];
+            A.delta1[(size_t)b * T + row] = s1;
+        }
+        const float amax_a = wave_allmax(f4amax(xa)), amax_b = wave_allmax(f4amax(xb));
+        const size_t sz = planes_sample_bytes(T);
+        store_split_row(A.pDa + (size_t)b * sz, A.iDa + (size_t)b * Tp + row, row, c, xa, amax_a);
+        store_split_row(A.pDb + (size_t)b * sz, A.iDb + (size_t)b * Tp + row, row, c, xb, amax_b);
+        return;
+    }
     if (row < T && d < D) {
         const size_t rr = (size_t)b * T + row;
         const float* g = A.d_out + rr * 4 * D;
@@ -2558,8 +2582,8 @@ static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backwar
                 break;
             }
         if (backward) {
-            MMB_REQUIRE(s.d_out && s.d_text && s.d_mod && s.d_w_t && s.d_w_m && s.d_w_tm && s.d_bias && s.workspace,
-                        "bidaf group bwd: null pointer in attention %d", k);
+            MMB_REQUIRE((s.d_out || (s.pre_da && s.pre_db && s.pre_d1_part)) && s.d_text && s.d_mod && s.d_w_t && s.d_w_m && s.d_w_tm && s.d_bias && s.workspace,
+                        "bidaf group bwd: null pointer in attention %d (d_out, or pre_da + pre_db + pre_d1_part)", k);
             MMB_REQUIRE(drop ? (s.d_text_d && s.d_mod_d) : (!s.d_text_d && !s.d_mod_d),
                         "bidaf bwd: d_text_d/d_mod_d must be given exactly when text_d/mod_d are");
             MMB_REQUIRE(s.workspace_bytes >= mmb_bidaf_bwd_workspace_bytes(B, s.T, s.M, D), "bidaf bwd: workspace too small (%zu < %zu)",
@@ -2572,6 +2596,7 @@ static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backwar
             g.pDa = ws + W.pDa; g.pDb = ws + W.pDb; g.pDq = ws + W.pDq;
             g.iDa = wf(W.iDa); g.iDb = wf(W.iDb); g.iDq = wf(W.iDq); g.delta1 = wf(W.delta1); g.delta2 = wf(W.delta2);
             g.dq_cnt = reinterpret_cast<unsigned*>(ws + W.dq_cnt);
+            if (!s.d_out) { g.pre_da = s.pre_da; g.pre_db = s.pre_db; g.pre_d1 = s.pre_d1_part; g.npart = mmb_dx_att_parts(D); }
         }
     }
     // S-reuse is a property of the LAUNCH (one kernel variant for the whole group): on only when every attention of the call has it

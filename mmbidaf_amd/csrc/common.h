@@ -145,6 +145,8 @@ struct SplitRowsArgs {
     int rb0, nrb;
 };
 struct SplitTArgs {
+    int perm4_F;     // > 0 (one segment, Ctot == 4 F): plane row 4 f + q is source column q F + f -- the four quarter blocks of a
+                     // (.., 4F) matrix interleaved feature by feature (the d_x GEMM with the attention epilogue, DxAttEpi)
     int nseg;
     const float* seg_ptr[3];
     int seg_ld[3], seg_cols[3], seg_shift[3];
@@ -158,7 +160,23 @@ struct SplitTArgs {
     const float* seg_absmax[3]; int seg_absmax_n[3]; float seg_bound[3];
     float* inv_out;      // np == 2: (Ctot) 1/s of every plane row (= source column)
 };
+// Epilogue of the d_x GEMM of a modelling encoder's first layer, whose input is the attention's output out = [text, a, text*a,
+// text*b] (reference attention.py:52): with the output columns interleaved (SplitTArgs::perm4_F: column 4 f + q = quarter q of
+// feature f) a lane's float4 holds (g0, g1, g2, g3) of ONE (row, feature), and the prologue of the attention's backward pass is formed
+// where the values are -- da = g1 + g2 text, db = g3 text, d_text = g0 + g2 a + g3 b, and per (row, wave) the partial sum of
+// da a + db b (delta1 = their sum over the row's waves, taken in a fixed order by the consumer) -- d_x itself is never written.
+struct DxAttEpi {
+    const float* text;   // (rows, D); null: plain epilogue
+    const float* a;      // (rows, a_ld) the attention's a
+    const float* b;      // (rows, D)
+    float* da;           // (rows, D)
+    float* db;           // (rows, D)
+    float* d_text;       // (rows, D)
+    float* d1_part;      // (rows, npart) partial sums of delta1: one per (column tile, wave column) of the launch
+    int D, a_ld, npart;
+};
 struct PlanesGemmArgs {
+    DxAttEpi epi;
     const bf16_t* A;   // tiled planes of the (M x K) operand
     const bf16_t* B;   // tiled planes of the (N x K) operand
     float* C; int ldc;

@@ -942,10 +942,12 @@ static int grads_planes_group(const mmb_lstm_bwd_desc* d, const int* idx, int m,
         }
         return planes_split_transpose_group(tx, m, stream);
     };
-    // problems that want an input gradient (W_ih^T planes + the d_x GEMM); a PREPARE call names them all
+    // problems that want an input gradient (W_ih^T planes + the d_x GEMM); a PREPARE call names them all.  dx_att: the gradient goes
+    // straight into the attention's backward prologue (mmb_dx_att_epilogue) -- d_x columns interleaved by feature, never stored
+    auto wants_dx = [&](const mmb_lstm_bwd_desc& p) { return p.d_x != nullptr || p.dx_att != nullptr; };
     int dxi[MMB_MAX_GROUP], ndx = 0;
     for (int k = 0; k < m; ++k)
-        if (d[idx[k]].d_x || prepare) dxi[ndx++] = k;
+        if (wants_dx(d[idx[k]]) || prepare) dxi[ndx++] = k;
     auto split_wt = [&]() -> int {
         if (ndx == 0) return MMB_OK;
         SplitTArgs tw[MMB_MAX_GROUP];
@@ -957,6 +959,7 @@ static int grads_planes_group(const mmb_lstm_bwd_desc* d, const int* idx, int m,
             t = SplitTArgs{};
             t.nseg = 1; t.seg_ptr[0] = p.w_ih[0]; t.seg_ld[0] = I; t.seg_cols[0] = I; t.seg_shift[0] = 0;
             t.stack_ptr = p.w_ih[1]; t.stack_R1 = 4 * H;
+            t.perm4_F = p.dx_att ? p.dx_att->D : 0;      // attention epilogue: d_x column 4 f + q = quarter q of feature f
             t.R = 8 * H; t.period = 1; t.Rp = L[k].K8; t.Ctot = I; t.planes = reinterpret_cast<bf16_t*>(ws[k] + L[k].wT);
             t.np = np; t.seg_absmax[0] = p.x_absmax ? p.x_absmax + ((long)p.B * p.T + 15) / 16 : nullptr; t.seg_absmax_n[0] = (8 * H + 15) / 16;
             t.inv_out = reinterpret_cast<float*>(ws[k] + L[k].wTinv);
@@ -976,7 +979,7 @@ static int grads_planes_group(const mmb_lstm_bwd_desc* d, const int* idx, int m,
     bool split_now[MMB_MAX_GROUP];
     for (int k = 0; k < m; ++k) {
         const mmb_lstm_bwd_desc& p = d[idx[k]];
-        split_now[k] = one_split && (phase == 3 || (phase == 1 && p.d_x) || (phase == 2 && !p.d_x));
+        split_now[k] = one_split && (phase == 3 || (phase == 1 && wants_dx(p)) || (phase == 2 && !wants_dx(p)));
         if (np == 2 && !db_partials && ((phase & 2) || split_now[k])) {
             // general-size recurrence: max |d_a| was not tracked by the recurrence, one reduction here
             float* scal = reinterpret_cast<float*>(ws[k] + L[k].scal);
@@ -1050,7 +1053,7 @@ static int grads_planes_group(const mmb_lstm_bwd_desc* d, const int* idx, int m,
         // d_x (BT, I) = d_a (BT x 8H) . [W_ih_f ; W_ih_r] (8H x I): one GEMM over both directions
         int nd = 0;
         for (int k = 0; k < m; ++k)
-            if (d[idx[k]].d_x) dxi[nd++] = k;
+            if (wants_dx(d[idx[k]])) dxi[nd++] = k;
         ndx = nd;
         if (ndx) {
             if (!one_split) {
@@ -1070,6 +1073,14 @@ static int grads_planes_group(const mmb_lstm_bwd_desc* d, const int* idx, int m,
                 g.B = reinterpret_cast<bf16_t*>(ws[k] + L[k].wT);
                 g.C = p.d_x; g.ldc = p.I; g.M = p.B * p.T; g.N = p.I; g.K = L[k].K8;
                 g.np = np; g.a_inv = reinterpret_cast<float*>(ws[k] + L[k].dainv); g.b_inv = reinterpret_cast<float*>(ws[k] + L[k].wTinv);
+                if (p.dx_att) {
+                    const mmb_dx_att_epilogue& e = *p.dx_att;
+                    MMB_REQUIRE(!p.d_x && p.I == 4 * e.D && e.text && e.out && e.bsave && e.da && e.db && e.d_text && e.d1_part,
+                                "mmb_bilstm_layer_bwd: dx_att needs d_x == NULL, I == 4 D and all its pointers");
+                    g.epi.text = e.text; g.epi.a = e.out + e.D; g.epi.a_ld = 4 * e.D; g.epi.b = e.bsave;
+                    g.epi.da = e.da; g.epi.db = e.db; g.epi.d_text = e.d_text; g.epi.d1_part = e.d1_part;
+                    g.epi.D = e.D; g.epi.npart = mmb_dx_att_parts(e.D);
+                }
             }
             if (int rc = planes_gemm_group(gx, ndx, stream)) return rc;
         }
@@ -1080,6 +1091,8 @@ static int grads_planes_group(const mmb_lstm_bwd_desc* d, const int* idx, int m,
 }  // namespace mmb
 
 using namespace mmb;
+
+extern "C" int mmb_dx_att_parts(int D) { return D > 0 ? 2 * ((4 * D + 159) / 160) : 0; }
 
 extern "C" size_t mmb_bilstm_absmax_floats(int B, int T, int H) {
     if (B < 1 || T < 1 || H < 1) return 0;

@@ -285,7 +285,10 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTGroup 
     if (kbase >= a.Rp || c0 >= (a.Ctot + 15) / 16 * 16) return;
     // load ST_KT x (32 source rows x 64 columns) (two float4 per thread and K tile), per-chunk segment lookup, shifted rows,
     // zero outside
-    const int lcol = c0 + (t & 15) * 4;
+    // perm4_F: the 64 plane rows of this workgroup are features c0/4 .. c0/4 + 15 of the four quarters: four runs of 16 source columns
+    const int lloc = (t & 15) * 4;
+    const bool perm = a.perm4_F > 0;
+    const int lcol = perm ? ((c0 >> 2) + (lloc & 15) < a.perm4_F ? (lloc >> 4) * a.perm4_F + (c0 >> 2) + (lloc & 15) : a.Ctot) : c0 + lloc;
     int lc = lcol, lsg = 0;
     while (lsg < a.nseg - 1 && lc >= a.seg_cols[lsg]) lc -= a.seg_cols[lsg++];
     const int lsh = a.seg_shift[lsg];
@@ -345,8 +348,9 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTGroup 
         const int k0 = kbase + 32 * kt;
         if (k0 >= a.Rp) break;
         float x[8];
+        const int tc = perm ? (cl & 3) * 16 + (cl >> 2) : cl;      // (perm4_F: plane row 4 f + q sits in run q of the tile)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = tile[kt][8 * oc + j][cl];
+        for (int j = 0; j < 8; ++j) x[j] = tile[kt][8 * oc + j][tc];
         if (a.np == 2) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] *= sc;
@@ -652,13 +656,39 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGroup G) {
                 const int u = it * 64 + lane, row = u / (W / 4), c4 = u - row * (W / 4);
                 const int m = mw0 + row, n = nw0 + 4 * c4;
                 if (m < g.M && n < g.N) {
-                    float* dst = g.C + (size_t)m * g.ldc + n;
                     f4 v = *reinterpret_cast<const f4*>(stg + row * LDW + 4 * c4);
+                    if (g.epi.text) {
+                        // attention epilogue (DxAttEpi): (g0, g1, g2, g3) of feature f of row m -> da, db, the direct part of d_text; the
+                        // lane's term of delta1 goes back into its staging slot for the fixed-order row sums below
+                        const int f = n >> 2;
+                        const size_t o = (size_t)m * g.epi.D + f;
+                        const float tv = g.epi.text[o], av = g.epi.a[(size_t)m * g.epi.a_ld + f], bv = g.epi.b[o];
+                        const float xa = v.y + v.z * tv, xb = v.w * tv;
+                        g.epi.da[o] = xa;
+                        g.epi.db[o] = xb;
+                        g.epi.d_text[o] = v.x + v.z * av + v.w * bv;
+                        stg[row * LDW + 4 * c4] = xa * av + xb * bv;
+                        continue;
+                    }
+                    float* dst = g.C + (size_t)m * g.ldc + n;
                     if (g.accumulate) v += *reinterpret_cast<const f4*>(dst);
                     // write-through (see PlanesGroup); the s_nop: hipcc does not pad an asm store, and its next instruction may
                     // overwrite the data registers before a 128-bit store has read them (cdna_hip_programming.md 5.7 item 1)
                     if (G.chunked) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
                     else *reinterpret_cast<f4*>(dst) = v;
+                } else if (g.epi.text) {
+                    stg[row * LDW + 4 * c4] = 0.f;      // (beyond the matrix: nothing to add)
+                }
+            }
+            if (g.epi.text) {
+                // this wave's share of delta1 for its 16 rows: the W / 4 lane terms of a row summed in a FIXED order (a lane per row),
+                // stored as partial (column tile, wave column) of the row -- the consumer adds the row's partials in a fixed order
+                // too: no atomics, the same bits every run
+                if (lane < 16 && mw0 + lane < g.M) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int c = 0; c < W / 4; ++c) acc += stg[lane * LDW + 4 * c];
+                    g.epi.d1_part[(size_t)(mw0 + lane) * g.epi.npart + tn * WN + wn] = acc;
                 }
             }
         }
@@ -906,12 +936,23 @@ int planes_gemm_group(const PlanesGemmArgs* gs, int n, hipStream_t stream) {
         MMB_REQUIRE(!g.ta || (g.np == 2 && g.K % 32 == 0), "planes_gemm: a k-major A operand needs the fp16 planes and K %% 32 == 0");
         MMB_REQUIRE(g.np == G.g[0].np && g.ta == G.g[0].ta, "planes_gemm_group: the products of a group share the plane format");
     }
+    // the attention epilogue (DxAttEpi) counts its partial sums per (160-column tile, wave column): tile shapes with BN = 160 only
+    bool need160 = false;
+    for (int p = 0; p < n; ++p) {
+        need160 = need160 || G.g[p].epi.text != nullptr;
+        if (G.g[p].epi.text) {
+            G.g[p].no_splitk = 1;
+            MMB_REQUIRE(G.g[p].N == 4 * G.g[p].epi.D && G.g[p].epi.npart == 2 * ((G.g[p].N + 159) / 160) && !G.g[p].ta && !G.g[p].accumulate,
+                        "planes_gemm: the attention epilogue needs N = 4 D and npart = 2 ceil(N / 160)");
+        }
+    }
     // one tile shape for the launch: the one that minimises the summed cost estimate with each product's best K split
     int best = 0;
     {
         double best_cost = 1e300;
         for (int c = 0; c < N_PLANES_CFGS; ++c) {
-            if (n == 1) { int s_; planes_choose(G.g[0], best, s_); break; }
+            if (n == 1 && !need160) { int s_; planes_choose(G.g[0], best, s_); break; }
+            if (need160 && !(c == 0 || c == 2 || c == 4)) continue;
             if (G.g[0].ta && (PLANES_CFGS[c].wm * PLANES_CFGS[c].mt * 16) % 32) continue;
             double cost = 0;
             for (int p = 0; p < n; ++p) { int b_, s_; cost += planes_choose(G.g[p], b_, s_, c); }
@@ -921,7 +962,7 @@ int planes_gemm_group(const PlanesGemmArgs* gs, int n, hipStream_t stream) {
     for (int p = 0; p < n; ++p) {
         PlanesGemmArgs& g = G.g[p];
         int b_, s_;
-        if (n == 1) planes_choose(g, b_, s_);   // honours MMB_PLANES_TUNE
+        if (n == 1 && !need160) planes_choose(g, b_, s_);   // honours MMB_PLANES_TUNE
         else planes_choose(g, b_, s_, best);
         g.splitk = s_;
         if (verbose)

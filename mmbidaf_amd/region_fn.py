@@ -55,6 +55,9 @@ def _parse_stream_cfg(text):
 # 1.6-1.8x less efficient than the one-launch product, and the recurrence loses 3-10 % beside it).  MMB_FWD_STREAM="0,0;8,3;0,0"
 # (modelling layer 0 only: break-even) or "8,0;8,2;8,0" select it.
 _FWD_STREAM = _parse_stream_cfg(os.environ.get("MMB_FWD_STREAM", "0"))
+# The modelling layer-0 input gradient handed straight to the attentions' backward prologue (mmb_dx_att_epilogue): the d_x GEMM's
+# epilogue forms da, db, the direct part of d_text and the partial sums of delta1; d_x (the attentions' d_out) is never written.
+_DX_ATT = os.environ.get("MMB_DX_ATT", "1") != "0"
 _FWD_STREAM_MIN_ROWS = 4096          # B * T below this: the one-launch projection (a few microseconds) is not worth 2 K launches
 
 
@@ -131,8 +134,12 @@ class _Plan:
             bw.add(tag + ".d_x", B * Tn * I * f)
             bw.add(tag + ".d_y", B * Tn * D * f)             # zero cotangent / masked cotangent staging
         bw.add("d_h", 4 * B * 2 * H * f)
+        self.d1_parts = int(lib.mmb_dx_att_parts(D))
         for tag, M in self.att:
             bw.add(tag + ".ws", self.att_ws_b[tag])
+            bw.add(tag + ".da32", B * T * D * f)               # the backward prologue as the layer-0 d_x GEMM's epilogue leaves it
+            bw.add(tag + ".db32", B * T * D * f)
+            bw.add(tag + ".d1p", B * T * self.d1_parts * f)
             bw.add(tag + ".d_text", B * T * D * f)
             bw.add(tag + ".d_mod", B * M * D * f)
             if drop:
@@ -466,7 +473,9 @@ def _build_templates(plan):
             if backward:
                 t.ptr(i, "workspace", "bw", bo[tag + ".ws"])
                 t.sizes(i, workspace_bytes=plan.att_ws_b[tag])
-                t.ptr(i, "d_out", "bw", bo[("a0" if tag == "aa" else "i0") + ".d_x"])
+                t.dynamic(i, "d_out", f"d_out{i}")
+                for fld in ("pre_da", "pre_db", "pre_d1_part"):
+                    t.dynamic(i, fld, f"{fld}{i}")
                 t.ptr(i, "d_text", "bw", bo[tag + ".d_text"])
                 t.ptr(i, "d_mod", "bw", bo[tag + ".d_mod"])
                 if plan.drop:
@@ -494,6 +503,7 @@ def _build_templates(plan):
             t.dynamic(i, "d_hn", f"d_hn{i}")
             if i == 0:
                 t.dynamic(0, "gate", "gate")
+            t.dynamic(i, "dx_att", f"dx_att{i}")
             t.dynamic(i, "d_x", f"d_x{i}")
             t.dynamic(i, "d_w_ih", f"d_w_ih{i}")
             t.dynamic(i, "d_w_hh", f"d_w_hh{i}")
@@ -769,7 +779,23 @@ class _RegionFn(torch.autograd.Function):
         L1, w1 = tm["b_l1"].build(bases, pp, x0=c.l1_in[0], x1=c.l1_in[1], dy0=pa, dy1=pi, y0=y1[0].data_ptr(), y1=y1[1].data_ptr(),
                                   d_hn0=dh["a1"], d_hn1=dh["i1"], gate=gate[2],
                                   **lstm_dyn(("a1", "i1"), (True, True)))
-        L0, w0 = tm["b_l0"].build(bases, pp, d_hn0=dh["a0"], d_hn1=dh["i0"], gate=gate[2], **lstm_dyn(("a0", "i0"), (True, True)))
+        # fused hand-over of layer 0's input gradient to the attentions' backward (their d_out is never materialised)
+        fuse_dx = _DX_ATT
+        epi = (_lib.DxAttEpilogue * 2)()
+        if fuse_dx:
+            for k, tag in enumerate(("aa", "ai")):
+                e = epi[k]
+                e.text = c.enc_out[0]
+                e.out = kb + plan.keep.off[tag + ".out"]
+                e.bsave = kb + plan.keep.off[tag + ".bsave"]
+                e.da, e.db, e.d1_part = bb + bo[tag + ".da32"], bb + bo[tag + ".db32"], bb + bo[tag + ".d1p"]
+                e.d_text = bb + bo[tag + ".d_text"]
+                e.D = D
+            hold.append(epi)
+        epi_sz = ctypes.sizeof(_lib.DxAttEpilogue)
+        l0_dyn = lstm_dyn(("a0", "i0"), (not fuse_dx, not fuse_dx))
+        L0, w0 = tm["b_l0"].build(bases, pp, d_hn0=dh["a0"], d_hn1=dh["i0"], gate=gate[2],
+                                  dx_att0=ctypes.addressof(epi) if fuse_dx else 0, dx_att1=ctypes.addressof(epi) + epi_sz if fuse_dx else 0, **l0_dyn)
         EN, we = tm["b_en"].build(bases, pp, x0=c.xs[0].data_ptr(), x1=c.xs[1].data_ptr(), x2=c.xs[2].data_ptr(),
                                   d_hn0=0, d_hn1=0, d_hn2=0, gate=gate[3], **lstm_dyn(("et", "ea", "ei"), c.need_dx))
         hold += [w1, w0, we]
@@ -818,6 +844,12 @@ class _RegionFn(torch.autograd.Function):
         for k, tag in enumerate(("aa", "ai")):
             g0 = gaddr(tag)
             adyn.update({f"d_w_t{k}": g0, f"d_w_m{k}": g0 + 4 * D, f"d_w_tm{k}": g0 + 8 * D, f"d_bias{k}": g0 + 12 * D})
+        for k, (tag, lt) in enumerate((("aa", "a0"), ("ai", "i0"))):
+            if fuse_dx:
+                adyn.update({f"d_out{k}": 0, f"pre_da{k}": bb + bo[tag + ".da32"], f"pre_db{k}": bb + bo[tag + ".db32"],
+                             f"pre_d1_part{k}": bb + bo[tag + ".d1p"]})
+            else:
+                adyn.update({f"d_out{k}": bb + bo[lt + ".d_x"], f"pre_da{k}": 0, f"pre_db{k}": 0, f"pre_d1_part{k}": 0})
         AT, wa = tm["b_att"].build(bases, pp, text0=c.enc_out[0], mod0=c.enc_out[1], text1=c.enc_out[0], mod1=c.enc_out[2],
                                    text_d0=c.att_d[0], mod_d0=c.att_d[1], text_d1=c.att_d[2], mod_d1=c.att_d[3], **adyn)
         _lib.check(lib.mmb_bidaf_group_bwd(AT, 2, B, D, di, ms), "mmb_bidaf_group_bwd")

@@ -1793,6 +1793,45 @@ def test_two_models_at_different_precision_in_one_process():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("shape,drop_prob", [((32, 400, 256, 64, 100), 0.0), ((5, 70, 41, 9, 100), 0.0), ((4, 130, 70, 33, 100), 0.2)])
+def test_layer0_input_gradient_handed_to_the_attention_backward_in_the_gemm_epilogue(monkeypatch, shape, drop_prob):
+    """Round 5 (mmb_dx_att_epilogue): the modelling encoders' layer-0 input gradient IS the attentions' d_out, and is consumed by
+    nothing but their backward prologue (da = g1 + g2 text, db = g3 text, d_text = g0 + g2 a + g3 b, delta1) -- the d_x GEMM's
+    epilogue forms those and d_out is never written.  Same products, same element-wise arithmetic; delta1 is summed over its
+    partials in a fixed order: every gradient agrees with the stand-alone prologue's to fp32 round-off (1e-6 of scale), and two
+    runs of the fused form agree BIT FOR BIT (no atomics on the way), in eval mode and in training mode (same masks)."""
+    from mmbidaf_amd import synth, region_fn
+    from mmbidaf_amd.hot_region import HotRegion
+    d = dev()
+    torch.manual_seed(224)
+    region = HotRegion(shape[4], drop_prob=drop_prob).to(d)
+    region.train(drop_prob > 0)
+    batch = synth.make_batch(shape, ragged=True)
+    gpu = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def run(fused):
+        monkeypatch.setattr(region_fn, "_DX_ATT", fused)
+        for p in region.parameters():
+            p.grad = None
+        xs = [gpu[k].detach().clone().requires_grad_(True) for k in ("x_text", "x_aud", "x_img")]
+        torch.manual_seed(4242)
+        outs = region(*xs, batch["text_len"], batch["aud_len"], batch["img_len"])
+        synth.region_loss(outs, gpu).backward()
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in outs], [x.grad.clone() for x in xs], {n: p.grad.clone() for n, p in region.named_parameters()}
+    o1, g1, p1 = run(True)
+    o1b, g1b, _ = run(True)
+    o0, g0, p0 = run(False)
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    for a, b in zip(g1, g1b):
+        assert torch.equal(a, b), "the fused form must repeat bit for bit"
+    for n, a, b in zip(("d_x_text", "d_x_aud", "d_x_img"), g1, g0):
+        close(a, b.cpu(), "fused hand-over " + n, tol=2e-6)
+    for n in p1:
+        close(p1[n], p0[n].cpu(), "fused hand-over grad " + n, tol=2e-6 if "bidaf_att" not in n else 1e-5)
+
+
 def test_cu_masked_stream_runs_kernels():
     """mmb_stream_create_cu_mask / mmb_stream_destroy: a stream restricted to half of the CUs computes the same GEMM
     (the option is measured and not used by default, profiles/r02_side_stream.md; the entry points stay covered)."""
@@ -2241,6 +2280,9 @@ def test_single_node_region_equals_the_modular_path_bit_for_bit(monkeypatch, dro
     calls = []
     orig = region_fn._RegionFn.apply
     monkeypatch.setattr(region_fn._RegionFn, "apply", staticmethod(lambda *a: (calls.append(1), orig(*a))[1]))
+    # (the node's fused hand-over of layer 0's input gradient sums delta1 in another order than the stand-alone prologue: its own
+    #  test below; here the node issues the modular path's calls one for one)
+    monkeypatch.setattr(region_fn, "_DX_ATT", False)
 
     def run(enabled):
         monkeypatch.setattr(region_fn, "_ENABLED", enabled)

@@ -26,7 +26,7 @@ def test_cabi_library_exports_every_declared_symbol():
     assert _lib.load().mmb_version() == _lib.ABI_VERSION == int(re.search(r"#define MMB_VERSION (\d+)", header).group(1))
     # struct layouts mirror the header (pointer/int counts)
     assert ctypes.sizeof(_lib.LstmFwdDesc) == 8 * 19 + 4 * 6      # (+ precision, reserved: round 5)
-    assert ctypes.sizeof(_lib.LstmBwdDesc) == 8 * 21 + 4 * 6      # (+ gate, precision, reserved: round 5)
+    assert ctypes.sizeof(_lib.LstmBwdDesc) == 8 * 22 + 4 * 6      # (+ gate, dx_att, precision, reserved: round 5)
 
 
 def test_stale_library_is_refused(tmp_path, monkeypatch):
