@@ -631,10 +631,28 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGroup G) {
             sb[j][e] = (NP == 2 && g.b_inv) ? g.b_inv[min(n, g.N - 1)] : 1.0f;
         }
     }
+    // attention epilogue (DxAttEpi): the lane's operands (text, a, b of its elements) of a 16-row block are fetched one block AHEAD, so
+    // their latency runs under the previous block's stores instead of once per element group
+    constexpr int EIT = (16 * W / 4) / 64;
+    float e_t[2][EIT], e_a[2][EIT], e_b[2][EIT];
+    auto epi_fetch = [&](int i, int s) {
+        const int mw0 = m0 + (wm * MT + i) * 16;
+#pragma unroll
+        for (int it = 0; it < EIT; ++it) {
+            const int u = it * 64 + lane, row = u / (W / 4), c4 = u - row * (W / 4);
+            const int m = min(mw0 + row, g.M - 1), f = min(nw0 + 4 * c4, g.N - 4) >> 2;
+            const size_t o = (size_t)m * g.epi.D + f;
+            e_t[s][it] = g.epi.text[o];
+            e_a[s][it] = g.epi.a[(size_t)m * g.epi.a_ld + f];
+            e_b[s][it] = g.epi.b[o];
+        }
+    };
+    if (g.epi.text) epi_fetch(0, 0);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int mrow = min(m0 + (wm * MT + i) * 16 + r, g.M - 1);
         const float sa = (NP == 2 && g.a_inv) ? g.a_inv[TA ? 0 : mrow] : 1.0f;
+        if (g.epi.text && i + 1 < MT) epi_fetch(i + 1, (i + 1) & 1);
 #pragma unroll
         for (int j = 0; j < NT; ++j) *reinterpret_cast<f4*>(stg + r * LDW + j * 16 + 4 * kg) = acc[i][j] * (sb[j] * sa) + bv[j];
         const int mw0 = m0 + (wm * MT + i) * 16;
@@ -662,7 +680,7 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGroup G) {
                         // lane's term of delta1 goes back into its staging slot for the fixed-order row sums below
                         const int f = n >> 2;
                         const size_t o = (size_t)m * g.epi.D + f;
-                        const float tv = g.epi.text[o], av = g.epi.a[(size_t)m * g.epi.a_ld + f], bv = g.epi.b[o];
+                        const float tv = e_t[i & 1][it], av = e_a[i & 1][it], bv = e_b[i & 1][it];
                         const float xa = v.y + v.z * tv, xb = v.w * tv;
                         g.epi.da[o] = xa;
                         g.epi.db[o] = xb;
