@@ -552,10 +552,12 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGroup G) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) b[j][s] = *reinterpret_cast<const bf16x8*>(img + s * (RT * 64) + offB[j]);
         }
-        // group 1 must have landed its pieces of tile t+1 (group 0 reads it after this barrier); with 3 stages its newest
-        // batch (tile t+2, issued one iteration ago) may stay in flight
+        // group 1 must have landed its pieces of tile t+1 (group 0 reads it after this barrier); the STAGES - 2 batches it issued
+        // behind that one (tiles t+2 .. t+STAGES-1) may stay in flight (vmcnt retires in order)
         if (grp == 1) {
-            if (STAGES == 3 && t >= 1 && t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER_WAVE) : "memory");
+            const int newer = min(t + STAGES - 1, nk - 1) - (t + 1);      // batches this wave issued behind tile t+1's
+            if (STAGES >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PER_WAVE) : "memory");
+            else if (STAGES >= 3 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER_WAVE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -596,7 +598,9 @@ __global__ __launch_bounds__(512) void gemm_planes_kernel(const PlanesGroup G) {
         }
         // group 0 must have landed its pieces of tile t+1 before it reads them; its newest batch (tile t+2) may stay in flight
         if (grp == 0) {
-            if (STAGES == 3 && t >= 1 && t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+            const int newer = min(t + STAGES - 1, nk - 1) - (t + 1);
+            if (STAGES >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
+            else if (STAGES >= 3 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (!only_mfma) bar();
@@ -786,9 +790,10 @@ int planes_split_transpose(const SplitTArgs& a, hipStream_t stream) { return pla
 template <int WM, int WN, int MT, int NT, int NP, bool TA = false>
 static int launch_planes_np(PlanesGroup& G, hipStream_t stream) {
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
-    // The kernel also runs with 3 stages (counted vmcnt waits, the fp16 tiles leave room for it), but measured it brings
-    // nothing (459 vs 446 us over the hot-path shapes): the limit is L2 -> LDS throughput next to the MFMA stream, not
-    // the latency of a DMA batch.
+    // The kernel also runs with 3 or 4 stages (counted vmcnt waits), but measured it brings nothing: two-plane products 459 vs
+    // 446 us over the hot-path shapes with 3 stages (r03); the single-plane product (bf16 operand mode, 256 x 256 tile) with 4
+    // stages 858 TFLOP/s on 25 600 x 4 096 x 4 096 against 904 with 2 (r05, tools/gemm_bf16_bench.py; boxes differ by more) --
+    // the limit is L2 -> LDS throughput next to the MFMA stream, not the latency of a DMA batch.
     constexpr int STAGES = 2;
     constexpr size_t lds_stages = (size_t)STAGES * NP * (BM + BN) * 64;
     constexpr size_t lds_epilogue = (size_t)8 * 16 * (NT * 16 + 4) * sizeof(float);   // the waves' private C staging rows
