@@ -1741,9 +1741,59 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (!use_sT) {
-                if (!(dbg & 2)) sprod2p(pTd, r, g, sS, c1);
-            }
+            if constexpr (use_sT) {
+                // S-reuse schedule (round 5): with no S-type product of its own to run beside role 1's first, this role takes its
+                // text . dq product THERE, and runs everything of the tile arithmetic that does not depend on dP1 (the exponentials,
+                // P2, g2, role 1's weights) under role 1's second product; behind the dP1 barrier only g1 and its own weights are
+                // left, and its PV product follows at once -- the third phase of the recomputing form (this role's PV product
+                // alone behind the second barrier) is gone.  Same barrier sequence as role 1's loop.
+                if (!(dbg & 2)) sprod2p(pT, r, g, sDq, c2);
+                plain_barrier();                // the role-1 waves' rendezvous: their late tensor of THIS panel has landed (see role 1)
+                f4 p1g[2], g2v[2], wsc[2], wc[2], wd[2];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const f4 s_rmax = *reinterpret_cast<const f4*>(sg + 32 + mb * 16), s_rinv = *reinterpret_cast<const f4*>(sg + 64 + mb * 16);
+                    const f4 s_code = *reinterpret_cast<const f4*>(sg + 128 + mb * 16), s_sTd = *reinterpret_cast<const f4*>(sg + 160 + mb * 16);
+                    const f4 s_sT = *reinterpret_cast<const f4*>(sg + 192 + mb * 16), s_sDa = *reinterpret_cast<const f4*>(sg + 224 + mb * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float code = s_code[e];
+                        const float xr = st_cur[mb][e];
+                        const float P1s = __expf((mm ? xr : NEG) - s_rmax[e]) * s_rinv[e];    // 0 beyond the range (rinv = 0); < 0: one-hot row
+                        const float P1 = fabsf(P1s);
+                        const float P2 = code != 0.f ? __expf((code == 2.f ? xr : NEG) - cmax) * cinv : 0.f;
+                        p1g[mb][e] = fmaxf(P1s, 0.f) * mmf;
+                        g2v[mb][e] = code == 2.f ? P2 * (c2[mb][e] * (s_sT[e] * inDq) - delta2) : 0.f;
+                        wsc[mb][e] = s_sTd[e] * cS;
+                        wc[mb][e] = P1 * (s_sDa[e] * cDa);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                half8 W0, W1;
+                split_w(wc[0], wc[1], W0, W1);
+                xch_put(xch + 2048, W0, W1);      // (role 1 took the previous panel's weights right behind the last barrier)
+                ts_cyc<DBG>(tsr, 10, tsi);
+                lds_barrier();            // role 1's dP1 is in LDS
+                ts_cyc<DBG>(tsr, 11, tsi);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const f4 dp1 = *reinterpret_cast<const f4*>(xch + mb * 1024);
+                    const f4 s_dl1 = *reinterpret_cast<const f4*>(sg + 96 + mb * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float g1 = p1g[mb][e] * (dp1[e] - s_dl1[e]);
+                        dc += g1;          // sum_i g2_ij = 0 identically (a softmax gradient sums to zero along its axis): only round-off to add
+                        wd[mb][e] = (g1 + g2v[mb][e]) * wsc[mb][e];
+                    }
+                }
+                ts_cyc<DBG>(tsr, 12, tsi);
+                split_w(wd[0], wd[1], W0, W1);
+                ts_cyc<DBG>(tsr, 13, tsi);
+                if (!(dbg & 4)) pvprodp(pTd, tr, W0, W1, O);
+                ts_cyc<DBG>(tsr, 14, tsi);
+                lds_barrier();            // role 1 has its weights; this panel's value tensors are dead
+            } else {
+            if (!(dbg & 2)) sprod2p(pTd, r, g, sS, c1);
             plain_barrier();                // the role-1 waves' rendezvous: their late tensor of THIS panel has landed (see role 1)
             if (!(dbg & 2)) sprod2p(pT, r, g, sDq, c2);
             ts_cyc<DBG>(tsr, 10, tsi);
@@ -1760,7 +1810,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float code = s_code[e];
-                    const float xr = use_sT ? st_cur[mb][e] : c1[mb][e] * (s_sTd[e] * inS) + s_rt[e] + cterm;
+                    const float xr = c1[mb][e] * (s_sTd[e] * inS) + s_rt[e] + cterm;
                     const float P1s = __expf((mm ? xr : NEG) - s_rmax[e]) * s_rinv[e];    // 0 beyond the range (rinv = 0); < 0: one-hot row
                     const float P1 = fabsf(P1s);
                     const float P2 = code != 0.f ? __expf((code == 2.f ? xr : NEG) - cmax) * cinv : 0.f;
@@ -1781,6 +1831,7 @@ __device__ __forceinline__ void sweep_j_body(const GroupArgs& a, const AttG& A, 
             ts_cyc<DBG>(tsr, 13, tsi);
             if (!(dbg & 4)) pvprodp(pTd, tr, W0, W1, O);
             ts_cyc<DBG>(tsr, 14, tsi);
+            }
         }
         dc = kg_allsum(dc);
         __syncthreads();
@@ -2161,9 +2212,61 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
             f4 c1[2], c2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) c1[q] = c2[q] = f4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (!use_sI) {
-                if (!(dbg & 2)) sprod2p(pMd, r, g, sS, c1);
-            }
+            if constexpr (use_sI) {
+                // S-reuse schedule (see sweep_j_body): dq . text beside role 1's first product, the dP1-free part of the arithmetic
+                // (both softmaxes, g2, dr, this role's own weights) under its second, g1 + role 1's weights + the PV product behind
+                // the dP1 barrier
+                (void)pMd;
+                // (with dropped copies dq is the panel's just-in-time tensor, landed only at the rendezvous: the product follows it)
+                if constexpr (SAME) {
+                    if (!(dbg & 2)) sprod2p(pDq, r, g, sT, c2);
+                    plain_barrier();            // the role-1 waves' rendezvous: their late tensor of THIS panel has landed (see role 1)
+                } else {
+                    plain_barrier();
+                    if (!(dbg & 2)) sprod2p(pDq, r, g, sT, c2);
+                }
+                f4 p1g[2], g2v[2], wsc[2], wt[2], wx[2];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const f4 s_cmax = *reinterpret_cast<const f4*>(sg + 32 + mb * 16), s_cinv = *reinterpret_cast<const f4*>(sg + 64 + mb * 16);
+                    const f4 s_dl2 = *reinterpret_cast<const f4*>(sg + 96 + mb * 16), s_mf = *reinterpret_cast<const f4*>(sg + 128 + mb * 16);
+                    const f4 s_sDq = *reinterpret_cast<const f4*>(sg + 192 + mb * 16), s_sMd = *reinterpret_cast<const f4*>(sg + 224 + mb * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float mf = s_mf[e];
+                        const float x = st_cur[mb][e];
+                        const float P1 = mf >= 0.f ? __expf((mf > 0.f ? x : NEG) - rmax) * rinv : 0.f;
+                        const float P2s = mf >= 0.f ? __expf((tm ? x : NEG) - s_cmax[e]) * s_cinv[e] : 0.f;    // < 0: one-hot column
+                        const float P2 = fabsf(P2s);
+                        const float g2 = fmaxf(P2s, 0.f) * (c2[mb][e] * (s_sDq[e] * inT) - s_dl2[e]) * tmf;
+                        dr += g2;          // sum_j g1_ij = 0 identically (see the j sweep)
+                        p1g[mb][e] = mf > 0.f ? P1 : 0.f;
+                        g2v[mb][e] = g2;
+                        wsc[mb][e] = s_sMd[e] * cS;
+                        wt[mb][e] = P2 * (s_sDq[e] * cDq);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                half8 W0, W1, V0, V1;
+                split_w(wt[0], wt[1], W0, W1);      // this role's own weights
+                ts_cyc<DBG>(tsr, 10, tsi);
+                lds_barrier();            // role 1's dP1 is in LDS
+                ts_cyc<DBG>(tsr, 11, tsi);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const f4 dp1 = *reinterpret_cast<const f4*>(xch + mb * 1024);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) wx[mb][e] = (p1g[mb][e] * (dp1[e] - dl1) + g2v[mb][e]) * wsc[mb][e];
+                }
+                ts_cyc<DBG>(tsr, 12, tsi);
+                split_w(wx[0], wx[1], V0, V1);
+                xch_put(xch + 2048, V0, V1);      // (role 1 took the previous panel's weights right behind the last barrier)
+                ts_cyc<DBG>(tsr, 13, tsi);
+                if (!(dbg & 4)) pvprodp(pDq, tr, W0, W1, O);
+                ts_cyc<DBG>(tsr, 14, tsi);
+                lds_barrier();            // role 1 has its weights; this panel's value tensors are dead
+            } else {
+            if (!(dbg & 2)) sprod2p(pMd, r, g, sS, c1);
             plain_barrier();                // the role-1 waves' rendezvous: their late tensor of THIS panel has landed (see role 1)
             if (!(dbg & 2)) sprod2p(pDq, r, g, sT, c2);
             ts_cyc<DBG>(tsr, 10, tsi);
@@ -2180,7 +2283,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float mf = s_mf[e];
-                    const float x = use_sI ? st_cur[mb][e] : c1[mb][e] * (s_sSp[e] * inS) + rterm + s_ct[e];
+                    const float x = c1[mb][e] * (s_sSp[e] * inS) + rterm + s_ct[e];
                     const float P1 = mf >= 0.f ? __expf((mf > 0.f ? x : NEG) - rmax) * rinv : 0.f;
                     const float P2s = mf >= 0.f ? __expf((tm ? x : NEG) - s_cmax[e]) * s_cinv[e] : 0.f;    // < 0: one-hot column
                     const float P2 = fabsf(P2s);
@@ -2201,6 +2304,7 @@ __device__ __forceinline__ void sweep_i_body(const GroupArgs& a, const AttG& A, 
             ts_cyc<DBG>(tsr, 13, tsi);
             if (!(dbg & 4)) pvprodp(pDq, tr, W0, W1, O);
             ts_cyc<DBG>(tsr, 14, tsi);
+            }
         }
         dr = kg_allsum(dr);
         __syncthreads();
