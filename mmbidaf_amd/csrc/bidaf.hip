@@ -2833,6 +2833,7 @@ extern "C" int mmb_bidaf_group_bwd(const mmb_bidaf_desc* d, int n, int B, int D,
             const mmb_bidaf_desc& s = d[k];
             if (int rc = check_att_dims(B, s.T, s.M, D)) return rc;
             MMB_REQUIRE(s.text_mask && s.mod_mask, "mmb_bidaf_bwd: the general-width path (D > %d) takes u8 masks", MMB_ATT_MAX_D);
+            MMB_REQUIRE(s.d_out, "mmb_bidaf_bwd: the general-width path (D > %d) takes d_out (no pre_da / pre_db hand-over)", MMB_ATT_MAX_D);
             MMB_REQUIRE(s.d_out && s.out && s.text && s.mod && s.w_t && s.w_m && s.w_tm && s.saved && s.bsave && s.rterm && s.cterm && s.row_stat &&
                             s.col_stat && s.d_text && s.d_mod && s.d_w_t && s.d_w_m && s.d_w_tm && s.d_bias && s.workspace, "mmb_bidaf_bwd: null pointer");
             MMB_REQUIRE((s.text_d != nullptr) == (s.mod_d != nullptr), "mmb_bidaf_bwd: text_d and mod_d must both be given or both be NULL");

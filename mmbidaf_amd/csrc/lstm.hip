@@ -1280,6 +1280,10 @@ extern "C" int mmb_bilstm_layer_bwd_phase(const mmb_lstm_bwd_desc* d, int n, int
                     "H=%d > %d runs the general recurrence, which needs desc.ws and I, H multiples of 4", p.H, MMB_LSTM_MAX_H);
         MMB_REQUIRE(p.d_y && p.x && p.y && p.lengths && p.gates && p.cs && p.d_w_ih && p.d_w_hh && p.d_b && p.d_a,
                     "null pointer in bwd desc %d", i);
+        // (the attention epilogue lives in the plane GEMM: a problem that cannot take the operand-plane path must not ask for it --
+        //  its input gradient would silently go nowhere)
+        MMB_REQUIRE(!p.dx_att || (p.ws && p.d_w_cat && planes_ok(p.I, H)),
+                    "mmb_bilstm_layer_bwd: dx_att needs the operand-plane path (desc.ws, desc.d_w_cat, I and H multiples of 4) in desc %d", i);
         // the operand-plane path reduces per-sample bias-gradient partials in its unpack kernel; otherwise atomics
         const bool part = !big && p.ws && p.d_w_cat && planes_ok(p.I, H);
         if (!part && !big) MMB_HIP(hipMemsetAsync(p.d_b, 0, sizeof(float) * 8 * H, stream));
