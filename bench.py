@@ -444,8 +444,8 @@ def run_leg(a, rank, world, local, dev):
                            "projection, recurrent product, input / weight gradients) on v_mfma_f32_16x16x32_bf16 from bf16-rounded operands "
                            "(descriptor precision = MMB_PRECISION_BF16; tolerance 3e-2 of the tensor scale vs the fp32 oracle, tests/test_gpu_parity.py); the "
                            + ("attention (D <= 208: fused kernels) keeps its fp32-accurate arithmetic" if fused_att else
-                              "general-width attention (D = %d > 208) runs its batched similarity / context products on the two-term bf16 "
-                              "split in this mode (about 2^-16 relative per product, inside the same 3e-2 bound)" % D)),
+                              "general-width attention (D = %d > 208) runs its batched similarity / context products on ONE bf16 term per "
+                              "operand in this mode as well (the same 3e-2 bound, same tests)" % D)),
             "config": {"workload": f"{a.config}: hot-path region (3 BiLSTM enc -> 2 BiDAF att -> 2 two-layer BiLSTM) "
                                    f"B={B}/GPU T_text={T} T_aud={Ma} T_img={Mi} H={H}, "
                                    f"{'NEW ragged lengths U{n/2..n} every step' if a.fresh_lengths else 'ragged U{n/2..n}' if a.ragged else 'full'} lengths, "

@@ -40,7 +40,7 @@ __device__ __forceinline__ void split_store(char* const (&img)[3], int off, cons
         h2[j] = (__bf16)r;
     }
     *reinterpret_cast<bf16x8*>(img[0] + off) = h0;
-    *reinterpret_cast<bf16x8*>(img[1] + off) = h1;
+    if (NS >= 2) *reinterpret_cast<bf16x8*>(img[1] + off) = h1;
     if (NS == 3) *reinterpret_cast<bf16x8*>(img[2] + off) = h2;
 }
 
@@ -220,12 +220,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_bf16_kernel(const GemmArgs g,
             for (int i = 0; i < MT; ++i) {
                 f4 c = acc[i][j];
                 if (NS == 3) {
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[NS == 3 ? 2 : 0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][NS == 3 ? 1 : 0], b[NS == 3 ? 1 : 0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][NS == 3 ? 2 : 0], b[0], c, 0, 0, 0);
                 }
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[0], c, 0, 0, 0);
+                if (NS >= 2) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[NS >= 2 ? 1 : 0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][NS >= 2 ? 1 : 0], b[0], c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[0], c, 0, 0, 0);
                 acc[i][j] = c;
             }
@@ -337,6 +339,14 @@ int gemm_bf16_launch(const GemmArgs& g, int ns, hipStream_t stream) {
             case 1: return launch_bf16<4, 2, 7, 3>(g, splitk, stream);
             case 2: return launch_bf16<4, 1, 13, 3>(g, splitk, stream);
             default: return launch_bf16<4, 1, 7, 3>(g, splitk, stream);
+        }
+    }
+    if (ns == 1) {      // one bf16 term, one product: the bf16 operand mode's batched attention products (tolerance 3e-2 of scale)
+        switch (cfg) {
+            case 0: return launch_bf16<4, 2, 13, 1>(g, splitk, stream);
+            case 1: return launch_bf16<4, 2, 7, 1>(g, splitk, stream);
+            case 2: return launch_bf16<4, 1, 13, 1>(g, splitk, stream);
+            default: return launch_bf16<4, 1, 7, 1>(g, splitk, stream);
         }
     }
     switch (cfg) {
