@@ -57,11 +57,16 @@ __global__ __launch_bounds__(256) void lstm_big_cell_kernel(const BigFwdArgs arg
 }
 
 // rows t >= len[b] of a (B,T,W) tensor := 0   (y: pad_packed_sequence zeros, encoding.py:99;  d_a: dead steps)
-__global__ __launch_bounds__(256) void lstm_big_zero_tail_kernel(float* __restrict__ p, const int* __restrict__ lens, int B, int T, int W) {
-    const int b = blockIdx.y;
-    const int len = min(max(lens[b], 0), T);
+// (one launch for the problems of a layer call, grid.z = problem: a small kernel issued while a long-running GEMM of the side stream
+//  holds every CU waits for a slot -- 350 us per launch in the cfg5 step, profiles/r05_cfg5_timeline_graph.md -- so there is ONE)
+struct ZeroTailArgs { float* p[MMB_MAX_GROUP]; const int* lens[MMB_MAX_GROUP]; int B[MMB_MAX_GROUP], T[MMB_MAX_GROUP]; int W; };
+__global__ __launch_bounds__(256) void lstm_big_zero_tail_kernel(const ZeroTailArgs a) {
+    const int k = blockIdx.z, b = blockIdx.y;
+    if (b >= a.B[k]) return;
+    const int T = a.T[k], W = a.W;
+    const int len = min(max(a.lens[k][b], 0), T);
     const long n = (long)(T - len) * W;
-    float* base = p + ((size_t)b * T + len) * W;
+    float* base = a.p[k] + ((size_t)b * T + len) * W;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) base[i] = 0.f;
 }
 
@@ -335,9 +340,15 @@ static int grouped_step_gemm(const float* const* A, const float* const* Bm, floa
 
 static int big_fwd_post(const mmb_lstm_fwd_desc* d, int n, hipStream_t stream) {
     const int H = d[0].H;
+    {
+        ZeroTailArgs z{};
+        int maxB = 0;
+        for (int i = 0; i < n; ++i) { z.p[i] = d[i].y; z.lens[i] = d[i].lengths; z.B[i] = d[i].B; z.T[i] = d[i].T; maxB = max(maxB, d[i].B); }
+        z.W = 2 * H;
+        hipLaunchKernelGGL(lstm_big_zero_tail_kernel, dim3(64, maxB, n), dim3(256), 0, stream, z);
+    }
     for (int i = 0; i < n; ++i) {
         const mmb_lstm_fwd_desc& p = d[i];
-        hipLaunchKernelGGL(lstm_big_zero_tail_kernel, dim3(64, p.B), dim3(256), 0, stream, p.y, p.lengths, p.B, p.T, 2 * H);
         hipLaunchKernelGGL(lstm_big_empty_state_kernel, dim3((2 * p.B * H + 255) / 256), dim3(256), 0, stream, p.h_n, p.c_n, p.lengths, p.hn_pos, p.B, H);
     }
     MMB_HIP(hipGetLastError());
@@ -346,9 +357,15 @@ static int big_fwd_post(const mmb_lstm_fwd_desc* d, int n, hipStream_t stream) {
 // have_db: the recurrence launch already accumulated d_b (persistent form)
 static int big_bwd_post(const mmb_lstm_bwd_desc* d, int n, hipStream_t stream, bool have_db = false) {
     const int H = d[0].H;
+    {
+        ZeroTailArgs z{};
+        int maxB = 0;
+        for (int i = 0; i < n; ++i) { z.p[i] = d[i].d_a; z.lens[i] = d[i].lengths; z.B[i] = d[i].B; z.T[i] = d[i].T; maxB = max(maxB, d[i].B); }
+        z.W = 8 * H;
+        hipLaunchKernelGGL(lstm_big_zero_tail_kernel, dim3(64, maxB, n), dim3(256), 0, stream, z);
+    }
     for (int i = 0; i < n; ++i) {
         const mmb_lstm_bwd_desc& p = d[i];
-        hipLaunchKernelGGL(lstm_big_zero_tail_kernel, dim3(64, p.B), dim3(256), 0, stream, p.d_a, p.lengths, p.B, p.T, 8 * H);
         if (have_db) continue;
         MMB_HIP(hipMemsetAsync(p.d_b, 0, sizeof(float) * 8 * H, stream));
         hipLaunchKernelGGL(lstm_big_colsum_kernel, dim3((8 * H + 255) / 256, 64), dim3(256), 0, stream, p.d_a, p.d_b, (long)p.B * p.T, 8 * H);
