@@ -25,6 +25,8 @@ import torch.nn as nn
 
 REF = os.environ.get("MMB_REFERENCE", "/root/reference")
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+TESTS_DIR = os.path.dirname(OUT)                      # tests/: golden_recipe.py
+OUT = os.environ.get("MMB_GOLDEN_OUT", OUT)           # (write somewhere else, e.g. to check that the committed fixtures reproduce)
 
 
 class _StubResNet(nn.Module):
@@ -371,7 +373,8 @@ def gen_training_trajectory(ref_models, ref_util):
 
 
 def main():
-    sys.path.insert(0, OUT[:-len("golden")])   # tests/: golden_recipe.py
+    sys.path.insert(0, TESTS_DIR)
+    os.makedirs(OUT, exist_ok=True)
     _install_torchvision_stub()
     import json as _json
     sys.modules.setdefault("ujson", _json)     # util.py:13 imports ujson (absent here; used by nothing G9 touches): the stdlib module stands in
