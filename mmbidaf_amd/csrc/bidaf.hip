@@ -2564,7 +2564,9 @@ static SavedLayout saved_layout(int B, int T, int M, int drop) {
     L.iMd = drop ? take(nM) : L.iM;
     L.iQ = take(nM);
     const size_t sT_b = (size_t)B * pad32(M) * pad32(T) * sizeof(float);
-    L.sT = (sreuse_env() && sT_b <= sreuse_max_bytes()) ? take(sT_b) : (size_t)-1;
+    // (debug mask 32768: the recomputing form -- what sizes beyond the limit run -- at any size, for the tests; the mask bit selects
+    //  nothing else: the product instantiations of the kernels run)
+    L.sT = (sreuse_env() && !(att_dbg() & 32768) && sT_b <= sreuse_max_bytes()) ? take(sT_b) : (size_t)-1;
     L.sI = L.sT != (size_t)-1 ? take(sT_b) : (size_t)-1;
     L.total = o;
     return L;
@@ -2650,7 +2652,7 @@ extern "C" size_t mmb_bidaf_bwd_workspace_bytes(int B, int T, int M, int D) {
 static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backward, GroupArgs& ga) {
     MMB_REQUIRE(d && n >= 1 && n <= MAXG, "bidaf group: 1..%d attentions per call", MAXG);
     memset(&ga, 0, sizeof(ga));
-    ga.n = n; ga.B = B; ga.D = D; ga.dbg = att_dbg(); ga.ts = (ga.dbg & 4096) ? g_att_ts : nullptr;
+    ga.n = n; ga.B = B; ga.D = D; ga.dbg = att_dbg() & ~32768; ga.ts = (ga.dbg & 4096) ? g_att_ts : nullptr;
     ga.scr = (ga.dbg & 8192) ? reinterpret_cast<char*>(g_att_ts) : nullptr;
     ga.dbg &= ~(4096 | 16384);      // (16384: fused backward, decided in mmb_bidaf_group_bwd: the product kernels either way)
     const bool drop = d[0].text_d != nullptr;

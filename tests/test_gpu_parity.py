@@ -280,6 +280,38 @@ def test_attention_backward_fused_form_equals_the_three_launch_form(B, T, M, use
         close(a, b.cpu(), "fused vs three launches " + k, tol=2e-6)
 
 
+@pytest.mark.parametrize("B,T,M,use_drop", [(32, 400, 256, False), (4, 130, 70, True), (3, 33, 65, False)])
+def test_attention_recomputing_form_vs_oracle_and_the_stored_similarity_form(B, T, M, use_drop):
+    """The backward pass WITHOUT the stored similarity tiles (what sizes beyond MMB_ATT_SREUSE_MAX_MB per copy run; the product form of
+    rounds 1-4): forced at ordinary sizes by debug mask 32768 (which selects nothing else -- the product kernels run), against the
+    oracle and against the default form (same quantity rounded along two routes)."""
+    from mmbidaf_amd import _lib
+    lib = _lib.load()
+    D = 200
+    c, drop = _random_att_case(9900 + B + T + M, B, T, M, D, use_drop)
+    t_ = c["text"].clone().requires_grad_(True)
+    m_ = c["mod"].clone().requires_grad_(True)
+    ps = [c[k].clone().requires_grad_(True) for k in ("w_t", "w_m", "w_tm", "bias")]
+    kw = dict(text_d=t_ * drop[0], mod_d=m_ * drop[1]) if use_drop else {}
+    ref = O.bidaf_attention(t_, m_, c["text_mask"], c["mod_mask"], *ps, **kw)
+    (ref * c["cot"]).sum().backward()
+    try:
+        lib.mmb_set_att_debug(32768)
+        out1, dt1, dm1, dps1 = _run_att(c, drop)
+        torch.cuda.synchronize()
+    finally:
+        lib.mmb_set_att_debug(0)
+    out0, dt0, dm0, dps0 = _run_att(c, drop)
+    close(out1, ref, "recomputing form out")
+    close(dt1, t_.grad, "recomputing form d_text")
+    close(dm1, m_.grad, "recomputing form d_mod")
+    for k, g, p in zip(("d_w_t", "d_w_m", "d_w_tm"), dps1, ps):
+        close(g, p.grad, "recomputing form " + k)
+    assert torch.equal(out1, out0)
+    close(dt1, dt0.cpu(), "recomputing vs stored-similarity d_text", tol=2e-6)
+    close(dm1, dm0.cpu(), "recomputing vs stored-similarity d_mod", tol=2e-6)
+
+
 @pytest.mark.parametrize("T,M", [(1, 33), (31, 1), (32, 32), (33, 31), (64, 65), (65, 96), (97, 97), (160, 129), (129, 160)])
 def test_attention_panel_counts_of_the_pipelined_sweeps_vs_oracle(T, M):
     """The 3-tensor gradient sweeps run role 1's PV product one panel behind, with rotating LDS slots and LDS-DMA pieces in flight
