@@ -513,6 +513,7 @@ struct GroupArgs {
     char* scr;             // timing experiment (debug mask 8192): where att_row ALSO writes its output rows as fp16 planes
     unsigned* tmo_host;    // host-visible word a bounded device-side wait that gave up adds to (the LSTM kernels' word, lstm_fs.hip)
     int fuse_dq;           // backward: the dq sweep runs inside the j blocks of the gradient-sweep launch (see att_bwd_sweep_kernel)
+    int row_si;            // forward: the row pass takes the similarity from the column pass's store (AttG::sI) instead of recomputing it
 };
 // DBG template value of the kernels: 0 = product, 1 = timing-only ablations (a.dbg), 2 = time stamps, nothing ablated
 template <int DBG>
@@ -1023,6 +1024,13 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
                     float* d = A.sT + ((size_t)b * Np + n) * pad32(R) + 64 * it + 32 * grp + 4 * g;
                     *reinterpret_cast<f4*>(d) = xraw[0];
                     *reinterpret_cast<f4*>(d + 16) = xraw[1];
+                    // ... and i-major (AttG::sI) for the row pass of this forward call and the i sweep of the backward pass: the
+                    // similarity is computed ONCE per step.  The 16 lanes of a row group write 64 contiguous bytes per element.
+                    float* di = A.sI + ((size_t)b * pad32(R) + p0 + 4 * g) * Np + n;
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) di[(size_t)(16 * mb + e) * Np] = xraw[mb][e];
                 }
                 bmax = kg_allmax(bmax);
                 const float m_new = fmaxf(m_run, bmax);
@@ -1217,7 +1225,10 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
     const float* iV0_b = A.iM + (size_t)b * Rp;
     const float* iV1_b = A.iQ + (size_t)b * Rp;
     const float* iS_b = A.iMd + (size_t)b * Rp;
-    const bool sep_s = A.pMd != A.pM;
+    // S-reuse (AttG::sI, written i-major by the column pass of this call): no S-type product here, no lane-side operand, and with
+    // dropped copies no third panel to stage -- two workgroups per CU in training mode too
+    const bool use_sI = A.sI != nullptr && a.row_si;
+    const bool sep_s = A.pMd != A.pM && !use_sI;
     const int npan = 2 + (sep_s ? 1 : 0);
     constexpr int NSC = 5;
     float* sc = reinterpret_cast<float*>(smem + npan * PANEL_B);    // [NSC][32]
@@ -1260,6 +1271,15 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
     wg_allmax_w<2, NW>(im, red, tid);
     const float c0 = cmap(im[0]), c1 = cmap(im[1]);
     ts_mark<DBG>(a, 1, 1);
+    const float* sI_n = use_sI ? A.sI + ((size_t)b * pad32(N) + min(n, pad32(N) - 1)) * Rp + 4 * g : nullptr;
+    f4 st_next[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+    auto st_fetch = [&](int p0) {
+        if (use_sI) {
+            st_next[0] = *reinterpret_cast<const f4*>(sI_n + p0);
+            st_next[1] = *reinterpret_cast<const f4*>(sI_n + p0 + 16);
+        }
+    };
+    if (row_end > 0) st_fetch(0);
 
     acc_t O0, O1;
     zero_acc(O0);
@@ -1275,6 +1295,8 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
         if (sck < NSC) sc[sck * 32 + scr] = row_scalar_value(rs, sc_next, p0 + scr, R);
         dma_sync();               // the panel staged above (or by the prologue) has landed
         if (p0 + PR < row_end && sck < NSC) sc_next = fetch(p0 + PR + scr);
+        const f4 st_cur[2] = {st_next[0], st_next[1]};      // (S-reuse: this panel's similarity, requested a panel ago)
+        if (p0 + PR < row_end) st_fetch(p0 + PR);
         ts_cyc<DBG>(tsr, 9, tsi);
         if (!wave_on) continue;
         const char* pV0 = smem;
@@ -1282,7 +1304,7 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
         const char* pS = sep_s ? smem + 2 * PANEL_B : pV0;
 
         f4 v[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-        if (!(dbg & 2)) sprod2p(pS, r, g, side, v);
+        if (!(dbg & 2) && !use_sI) sprod2p(pS, r, g, side, v);
         ts_cyc<DBG>(tsr, 10, tsi);
         // per-row scalars of the lane's 2 x 4 rows as whole 16-B reads, requested before the arithmetic (see the column pass)
         const float* sl = sc + 4 * g;
@@ -1302,14 +1324,13 @@ __global__ __launch_bounds__(NTHR, 2) void att_row_kernel(const GroupArgs a, con
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float code = q1[mb][e];
-                const float x = v[mb][e] * (q2[mb][e] * inv_n) + q0[mb][e] + nterm;
+                const float x = use_sI ? st_cur[mb][e] : v[mb][e] * (q2[mb][e] * inv_n) + q0[mb][e] + nterm;
                 xraw[e] = x;
                 const float off = code == 1.f ? NEG : -INFINITY;
                 v[mb][e] = code == 2.f ? x : off;
                 bmax = fmaxf(bmax, v[mb][e]);
             }
-            // S-reuse: the raw similarity of the tile, i-major, for the i sweep of the backward pass (AttG::sI); 16 B per lane and block
-            if (A.sI && n < N) *reinterpret_cast<f4*>(A.sI + ((size_t)b * pad32(N) + n) * Rp + p0 + 16 * mb + 4 * g) = xraw;
+            (void)xraw;
         }
         bmax = kg_allmax(bmax);
         const float m_new = fmaxf(m_run, bmax);
@@ -2653,6 +2674,14 @@ static int fill_group(const mmb_bidaf_desc* d, int n, int B, int D, bool backwar
     MMB_REQUIRE(d && n >= 1 && n <= MAXG, "bidaf group: 1..%d attentions per call", MAXG);
     memset(&ga, 0, sizeof(ga));
     ga.n = n; ga.B = B; ga.D = D; ga.dbg = att_dbg() & ~32768; ga.ts = (ga.dbg & 4096) ? g_att_ts : nullptr;
+    {
+        static int v = -1;      // MMB_ATT_ROW_SI=0 (tuning aid): the row pass recomputes the similarity, as in rounds 1-4
+        if (v < 0) {
+            const char* e = getenv("MMB_ATT_ROW_SI");
+            v = (e && atoi(e) == 0) ? 0 : 1;
+        }
+        ga.row_si = v;
+    }
     ga.scr = (ga.dbg & 8192) ? reinterpret_cast<char*>(g_att_ts) : nullptr;
     ga.dbg &= ~(4096 | 16384);      // (16384: fused backward, decided in mmb_bidaf_group_bwd: the product kernels either way)
     const bool drop = d[0].text_d != nullptr;
@@ -2811,7 +2840,7 @@ extern "C" int mmb_bidaf_group_fwd(const mmb_bidaf_desc* d, int n, int B, int D,
         BlkMap bm{};
         for (int k = 0; k < n; ++k) bm.begin[k + 1] = bm.begin[k] + sweep_blocks(ga.g[k].T, B);
         for (int k = n; k < MAXG; ++k) bm.begin[k + 1] = bm.begin[n];
-        size_t lds = (size_t)(drop ? 3 : 2) * PANEL_B + (5 * 32 + 16) * sizeof(float);
+        size_t lds = (size_t)(drop && !(ga.g[0].sI != nullptr && ga.row_si) ? 3 : 2) * PANEL_B + (5 * 32 + 16) * sizeof(float);
         const size_t epi = (size_t)64 * LDP * sizeof(float);
         if (lds < epi) lds = epi;
         auto kern = ga.ts ? att_row_kernel<2> : ga.dbg ? att_row_kernel<1> : att_row_kernel<0>;

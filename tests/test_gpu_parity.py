@@ -307,7 +307,7 @@ def test_attention_recomputing_form_vs_oracle_and_the_stored_similarity_form(B, 
     close(dm1, m_.grad, "recomputing form d_mod")
     for k, g, p in zip(("d_w_t", "d_w_m", "d_w_tm"), dps1, ps):
         close(g, p.grad, "recomputing form " + k)
-    assert torch.equal(out1, out0)
+    close(out1, out0.detach().cpu(), "recomputing vs stored-similarity out", tol=2e-6)      # (the row pass reads the column pass's tiles or multiplies again)
     close(dt1, dt0.cpu(), "recomputing vs stored-similarity d_text", tol=2e-6)
     close(dm1, dm0.cpu(), "recomputing vs stored-similarity d_mod", tol=2e-6)
 
