@@ -860,7 +860,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
         const int idx = wv + 8 * k;
         const int pn = idx >= 28 ? 1 : 0, pc = idx - 28 * pn;
         const int p0 = 64 * it_ + 32 * pn;
-        if (p0 < Rp)
+        if (p0 < Rp && !(DBG == 2 && (a.dbg & 1) && it_ > 0))      // (stamped build, extra mask 1: timing only, no LDS-DMA inside the loop)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcb + (size_t)(p0 >> 4) * PRB + pc * 1024 + lane * 16),
                                              (__attribute__((address_space(3))) void*)(dst0 + pn * dstride + pc * 1024), 16, 0, 0);
     };
@@ -881,7 +881,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
     const float* sT_n = use_sT ? A.sT + ((size_t)b * Np + min(n, Np - 1)) * Tp_ + 32 * grp + 4 * g : nullptr;
     f4 st_next[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
     auto st_fetch = [&](int it) {
-        if (use_sT && 64 * it + 32 * grp < Rp) {
+        if (use_sT && 64 * it + 32 * grp < Rp && !(DBG == 2 && (a.dbg & 2) && it > 0)) {      // (extra mask 2: no similarity loads in the loop)
             st_next[0] = *reinterpret_cast<const f4*>(sT_n + 64 * it);
             st_next[1] = *reinterpret_cast<const f4*>(sT_n + 64 * it + 16);
         }
@@ -915,7 +915,7 @@ __device__ __forceinline__ void att_jsweep_body(const GroupArgs& a, const BlkMap
     const RowMask rmk = make_row_mask(A.text_mask, A.text_len, b, R);
     unsigned sc_next = 0u;
     int sc_row = 0;
-    auto sc_fetch = [&](int it) { if (sck < NSC) { sc_row = 64 * it + scr; sc_next = row_scalar_fetch(rs, rmk, sc_row, R); } };
+    auto sc_fetch = [&](int it) { if (sck < NSC && !(DBG == 2 && (a.dbg & 8) && it > 0)) { sc_row = 64 * it + scr; sc_next = row_scalar_fetch(rs, rmk, sc_row, R); } };      // (extra mask 8: no scalar fetches in the loop)
     auto sc_commit = [&](int buf) { if (sck < NSC) sc[(buf * NSC + sck) * 64 + scr] = row_scalar_value(rs, sc_next, sc_row, R); };
 
     if (niter > 0) sc_fetch(0);

@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--D", type=int, default=200)
     ap.add_argument("--Ms", default="256,64")
     ap.add_argument("--drop", action="store_true")
-    ap.add_argument("--extra-mask", type=int, default=0, help="1 = no LDS-DMA inside the gradient sweeps' loops (timing only)")
+    ap.add_argument("--extra-mask", type=int, default=0, help="timing only, stamped build: 1 = no LDS-DMA inside the loops (gradient sweeps, column / dq passes), 2 = no similarity loads in the column / dq loop, 8 = no scalar fetches there")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
